@@ -1,0 +1,132 @@
+"""Mirror of the reference C extension `fastqandfurious._fastqandfurious`
+(/root/reference/src/_fastqandfurious.c) on the MI355X.
+
+    entrypos(blob, offset, posbuffer) -> int     (:25-153)
+    arrayadd_b(a, value)                         (:161-185)
+    arrayadd_q(a, value)                         (:193-217)
+    INVALID, POS_HEAD_BEG .. POS_QUAL_END, COMPLETE, MISSING_QUALHEADER_END (:254-262)
+
+Everything computes on the GPU through libffq_hip.so (include/ffq.h).  There is
+no CPU fallback: without the library or a gfx950 device the calls raise.
+
+`entrypos` is a callable object.  Called per record (the reference's plug-in
+protocol) it scans the whole buffer once on the GPU and serves the following
+calls of the same chain from the resulting table; handed to this package's
+readfastq_iter it is used through `scan_buffer`, one GPU call per buffer fill.
+"""
+from array import array
+
+import numpy as np
+
+from . import hip as _hip
+
+INVALID = _hip.INVALID
+POS_HEAD_BEG = _hip.POS_HEAD_BEG
+POS_HEAD_END = _hip.POS_HEAD_END
+POS_SEQ_BEG = _hip.POS_SEQ_BEG
+POS_SEQ_END = _hip.POS_SEQ_END
+POS_QUAL_BEG = _hip.POS_QUAL_BEG
+POS_QUAL_END = _hip.POS_QUAL_END
+COMPLETE = _hip.COMPLETE
+MISSING_QUALHEADER_END = _hip.MISSING_QUALHEADER_END
+
+
+def _writable_view(obj, itemsize, fmt_name):
+    """Writable view of a buffer-protocol object with the itemsize the
+    reference checks (:38-43, :170-174, :202-206)."""
+    try:
+        m = memoryview(obj)
+    except TypeError:
+        raise TypeError("a bytes-like object is required, not '%s'" % type(obj).__name__)
+    if m.itemsize != itemsize:
+        raise ValueError("The buffer must be of format type %s." % fmt_name)
+    if m.readonly:
+        # the reference's "y*" writes through read-only buffers; we refuse
+        raise TypeError("a writable bytes-like object is required")
+    if not m.c_contiguous:
+        raise BufferError("the buffer must be C-contiguous")
+    return m
+
+
+class _GpuEntrypos:
+    """entrypos(blob, offset, posbuffer) -> status, computed on the MI355X."""
+
+    def __init__(self, device=None):
+        self._device = device
+        self._ctx = None
+        self._blob = None
+        self._table = None
+        self._row = 0
+        self._next_offset = None
+        self._term = None
+
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = _hip.default_context(self._device)
+        return self._ctx
+
+    # -- the reference's plug-in protocol ---------------------------------
+    def __call__(self, blob, offset, posbuffer):
+        pos = _writable_view(posbuffer, 8, 'q')
+        if pos.nbytes < 48:
+            raise ValueError("posbuffer must hold 6 positions")
+        out = np.frombuffer(pos, dtype=np.int64)
+        if isinstance(blob, str):
+            blob = blob.encode('utf-8')
+        offset = int(offset)
+        cacheable = isinstance(blob, bytes)
+        if not (cacheable and self._blob is blob and offset == self._next_offset):
+            table, res = self._context().scan_host(blob, sentinel=False, offset=offset, eof=False, add=0)
+            self._blob = blob if cacheable else None
+            self._table = table
+            self._row = 0
+            self._term = (int(res.last_status), [int(x) for x in res.last_pos])
+        if self._row < len(self._table):
+            row = self._table[self._row]
+            out[:6] = row
+            self._row += 1
+            self._next_offset = int(row[5]) - 1
+            return COMPLETE
+        status, last = self._term
+        out[:6] = last
+        self._next_offset = None        # the chain has ended: rescan on the next call
+        return status
+
+    # -- batched protocol used by this package's readfastq_iter ------------
+    def scan_buffer(self, buf, offset, eof):
+        table, res = self._context().scan_host(buf, sentinel=False, offset=offset, eof=eof, add=0)
+        rows = array('q')
+        rows.frombytes(np.ascontiguousarray(table).tobytes())
+        return rows, int(res.end_state), int(res.end_offset)
+
+
+entrypos = _GpuEntrypos()
+
+
+def arrayadd_b(a, value):
+    """Add `value` to every element of the int8 buffer `a`, in place
+    (:161-185).  The reference parses `value` as a C short and keeps its low 8
+    bits; so does this."""
+    if not isinstance(value, int):
+        raise TypeError("an integer is required (got type %s)" % type(value).__name__)
+    if value < -32768:
+        raise OverflowError("signed short integer is less than minimum")
+    if value > 32767:
+        raise OverflowError("signed short integer is greater than maximum")
+    m = _writable_view(a, 1, 'b')
+    if m.nbytes:
+        _hip.default_context().arrayadd_b(np.frombuffer(m, dtype=np.int8), value)
+    return None
+
+
+def arrayadd_q(a, value):
+    """Add `value` to every element of the int64 buffer `a`, in place,
+    wrapping modulo 2**64 (:193-217)."""
+    if not isinstance(value, int):
+        raise TypeError("an integer is required (got type %s)" % type(value).__name__)
+    if not (-2**63 <= value < 2**63):
+        raise OverflowError("Python int too large to convert to C long")
+    m = _writable_view(a, 8, 'q')
+    if m.nbytes:
+        _hip.default_context().arrayadd_q(np.frombuffer(m, dtype=np.int64), value)
+    return None

@@ -1,0 +1,204 @@
+// ffq_dev.h -- device-side data structures and helpers shared by the kernels
+// of libffq_hip.so (gfx950 only; wave64 is hard-coded).
+//
+// Line index.  The scan kernel (k_scan_lines) turns the byte stream into a
+// two-level index of newline positions: the buffer is cut into TILE-byte
+// tiles, tile t owns a SLOT-entry slot of u16 entries, one per '\n' in the
+// tile, in position order:
+//     entry = offset_in_tile (14 bits) | AT << 14 | PLUS << 15
+// AT / PLUS say that the byte AFTER the newline exists and is '@' / '+': they
+// are exactly the matches of the reference's memmem("\n@") / memmem("\n+")
+// (/root/reference/src/_fastqandfurious.c:62,87).  cnt[t] is the number of
+// newlines in the tile; a tile with more than SLOT of them stores its entries
+// in an overflow pool at ovf[t].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ffq {
+
+constexpr int TILE_SHIFT = 14;
+constexpr int TILE = 1 << TILE_SHIFT;          // bytes per line-index tile
+constexpr int SLOT = 1024;                     // u16 entries per tile slot
+constexpr uint32_t OFF_MASK = TILE - 1;
+constexpr int FL_AT = 1, FL_PLUS = 2;
+
+// scanner status codes (_fastqandfurious.c:7-15)
+constexpr int ST_INVALID = -1, ST_HEAD_BEG = 0, ST_HEAD_END = 1, ST_SEQ_BEG = 2,
+              ST_SEQ_END = 3, ST_QUAL_BEG = 4, ST_QUAL_END = 5, ST_COMPLETE = 6,
+              ST_QUALHEAD_END = 7;
+constexpr int ST_FINAL = 21;   // internal: status 5 at eof, accepted by the final-record rule
+
+// control-block error bits
+constexpr uint32_t ERR_POOL = 1u;       // overflow pool exhausted -> host grows it and re-runs
+constexpr uint32_t ERR_INTERNAL = 2u;   // an invariant of the chain kernels failed
+
+struct Ctl {
+    uint32_t err;
+    uint32_t pad;
+    unsigned long long pool_head;
+};
+
+struct LineIndex {
+    const uint8_t *d;          // the bytes (read only for the sentinel's flags)
+    int64_t n;                 // number of bytes
+    int32_t s;                 // 1: a virtual '\n' sits at buffer coordinate 0
+    int32_t ntiles;
+    const uint16_t *ent;       // [ntiles][SLOT]
+    const uint32_t *cnt;       // [ntiles]
+    const unsigned long long *ovf;   // [ntiles] pool offset of dense tiles
+    const uint16_t *pool;
+    __device__ __forceinline__ int64_t len() const { return n + s; }
+};
+
+// Handle of one line-index entry.  tile == -2: before everything,
+// tile == -1: the sentinel.
+struct H {
+    int32_t tile;
+    int32_t i;
+};
+
+// ---- accessor over the global index (slow path, serial walker) -----------
+struct GAcc {
+    typedef H Hd;
+    const LineIndex &L;
+    __device__ GAcc(const LineIndex &l) : L(l) {}
+    __device__ __forceinline__ Hd before() const { return H{-2, 0}; }
+    __device__ bool next(Hd &h) const {
+        if (h.tile == -2 && L.s) { h.tile = -1; h.i = 0; return true; }
+        if (h.tile >= 0 && h.i + 1 < (int32_t)L.cnt[h.tile]) { h.i++; return true; }
+        int32_t t = h.tile < 0 ? 0 : h.tile + 1;
+        while (t < L.ntiles && L.cnt[t] == 0) t++;
+        if (t >= L.ntiles) return false;
+        h.tile = t; h.i = 0;
+        return true;
+    }
+    __device__ void get(const Hd &h, int64_t &P, int &fl) const {
+        if (h.tile < 0) {
+            P = 0;
+            const uint8_t b = L.n > 0 ? L.d[0] : 0;
+            fl = (b == '@') ? FL_AT : (b == '+') ? FL_PLUS : 0;
+            return;
+        }
+        const uint32_t c = L.cnt[h.tile];
+        const uint32_t e = (c <= (uint32_t)SLOT) ? L.ent[(int64_t)h.tile * SLOT + h.i]
+                                                 : L.pool[L.ovf[h.tile] + h.i];
+        P = ((int64_t)h.tile << TILE_SHIFT) + (e & OFF_MASK) + L.s;
+        fl = (int)(e >> 14);
+    }
+};
+
+// One scanner call, restated over the line index.
+//   /root/reference/src/_fastqandfurious.c:25-153  (C extension entrypos)
+// k = handle of the "\n@" newline (P = its buffer coordinate).  The final-
+// record rule of the iterator (fastqandfurious.py:259-266) is applied here
+// when eof is set: status 5 with qualend < len becomes `final`.
+struct Rec {
+    int64_t p0, p1, p3, p4, p5;
+    int32_t status;
+    bool final_;
+};
+
+template <class A>
+__device__ void compute_record(const A &a, typename A::Hd k, int64_t Pk, int64_t len, int eof,
+                               Rec &r, typename A::Hd &hm, typename A::Hd &hm1)
+{
+    r.p0 = Pk + 1; r.p1 = r.p3 = r.p4 = r.p5 = -1; r.final_ = false;
+    hm = k; hm1 = k;
+    int64_t P; int fl;
+    typename A::Hd j = k;
+    // header end: memchr(pos0+1, '\n', len-(pos0+1)-1) -- last byte excluded (:70-71)
+    if (!a.next(j)) { r.status = ST_HEAD_END; return; }
+    a.get(j, P, fl);
+    if (P > len - 2) { r.status = ST_HEAD_END; return; }
+    r.p1 = P;
+    const int64_t p2 = P + 1;
+    // sequence end: memmem(pos2+1, "\n+") (:87-88)
+    for (;;) {
+        if (!a.next(j)) { r.status = ST_SEQ_END; return; }
+        a.get(j, P, fl);
+        if ((fl & FL_PLUS) && P >= p2 + 1) break;
+    }
+    r.p3 = P; hm = j;
+    if (P + 2 >= len) { r.status = ST_QUALHEAD_END; return; }
+    // '+' line end: memchr(se+2, '\n', len-(se+2)-1) (:102-103)
+    if (!a.next(j)) { r.status = ST_QUALHEAD_END; return; }
+    a.get(j, P, fl);
+    if (P > len - 2) { r.status = ST_QUALHEAD_END; return; }
+    hm1 = j;
+    const int64_t qhe = P, se = r.p3, he = r.p1;
+    // '+' line LENGTH rule (:109-117)
+    if ((qhe - se - 1 > 1) && (qhe - se != he - r.p0 + 1)) { r.status = ST_INVALID; return; }
+    r.p4 = qhe + 1;
+    const int64_t qe = r.p4 + se - he - 1;     // (:129)
+    if (qe + 2 >= len) {                       // (:130-133)
+        r.status = ST_QUAL_END;
+        if (eof && qe < len) { r.p5 = qe; r.final_ = true; }   // fastqandfurious.py:259-266
+        return;
+    }
+    r.p5 = qe;
+    r.status = ST_COMPLETE;
+}
+
+// first "\n@" match at buffer coordinate >= X among the entries AFTER `from`
+// (memmem(blob+offset, "\n@"), _fastqandfurious.c:62).
+template <class A>
+__device__ bool find_cand(const A &a, typename A::Hd from, int64_t X, typename A::Hd &out,
+                          int64_t &Pout)
+{
+    typename A::Hd j = from;
+    int64_t P; int fl;
+    while (a.next(j)) {
+        a.get(j, P, fl);
+        if ((fl & FL_AT) && P >= X) { out = j; Pout = P; return true; }
+    }
+    return false;
+}
+
+// ---- wave64 helpers -------------------------------------------------------
+// inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return x;
+}
+
+// 16-bit mask of the bytes of v equal to '\n' (bit p = byte p in memory order)
+__device__ __forceinline__ uint32_t nl_mask16(const uint4 v)
+{
+    const uint32_t K = 0x0A0A0A0Au, L7 = 0x7F7F7F7Fu, H1 = 0x80808080u;
+    uint32_t a = v.x ^ K, b = v.y ^ K, c = v.z ^ K, e = v.w ^ K;
+    // bit 7 of each byte = 1 iff the byte is non-zero (exact, no cross-byte carry)
+    a = (((a & L7) + L7) | a) & H1;
+    b = (((b & L7) + L7) | b) & H1;
+    c = (((c & L7) + L7) | c) & H1;
+    e = (((e & L7) + L7) | e) & H1;
+    // gather the four flag bits of each dword with one v_dot4_u32_u8 each
+    uint32_t lo = __builtin_amdgcn_udot4(a, 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(b, 0x80402010u, lo, false);
+    uint32_t hi = __builtin_amdgcn_udot4(c, 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(e, 0x80402010u, hi, false);
+    return ((((hi << 8) | lo) >> 7) ^ 0xFFFFu) & 0xFFFFu;
+}
+
+// byte q (0..15) of v, memory order
+__device__ __forceinline__ uint32_t get_byte(const uint4 v, uint32_t q)
+{
+    const uint32_t w = (q < 8) ? ((q < 4) ? v.x : v.y) : ((q < 12) ? v.z : v.w);
+    return (w >> ((q & 3) * 8)) & 0xFFu;
+}
+
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace ffq

@@ -1,0 +1,573 @@
+// ffq_hip.hip -- C ABI of libffq_hip.so (see include/ffq.h).
+// Host side of the MI355X FASTQ buffer-scan path: context, scratch sizing,
+// kernel sequencing on one HIP stream, pinned staging for host buffers.
+// No CPU fallback: every compute entry point needs a live gfx950 device.
+#include "../../include/ffq.h"
+#include "ffq_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace ffq;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return fail(FFQ_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+struct ffq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // scratch, grow-only
+    int64_t cap_tiles = 0;
+    uint16_t *ent = nullptr;
+    uint32_t *cnt = nullptr;
+    unsigned long long *ovf = nullptr;
+    uint16_t *pool = nullptr;
+    unsigned long long pool_cap = 0;
+    int64_t cap_groups = 0;
+    GroupSum *sums = nullptr;
+    int64_t *ystart = nullptr, *rbase = nullptr, *qbase = nullptr;
+    Ctl *ctl = nullptr;
+    DevRes *dres = nullptr;
+    // pinned mirrors
+    Ctl *h_ctl = nullptr;
+    DevRes *h_res = nullptr;
+    // staging for the host-buffer entry points
+    uint8_t *stage_d = nullptr;
+    int64_t stage_d_cap = 0;
+    uint8_t *stage_h = nullptr;
+    int64_t stage_h_cap = 0;
+    int64_t *tab_d = nullptr;
+    int64_t tab_d_cap = 0;
+    int8_t *qual_d = nullptr;
+    int64_t qual_d_cap = 0;
+    int64_t *qoff_d = nullptr;
+    int64_t qoff_d_cap = 0;
+    int64_t *tab_h = nullptr;      // pinned bounce for rows
+    int64_t tab_h_cap = 0;
+};
+
+extern "C" int ffq_abi_version(void) { return FFQ_ABI_VERSION; }
+extern "C" const char *ffq_last_error(void) { return g_err.c_str(); }
+
+extern "C" int ffq_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ffq_ctx_create(int device, ffq_ctx **out)
+{
+    if (!out) return fail(FFQ_E_ARG, "ffq_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(FFQ_E_NODEVICE, "no HIP device visible: the FASTQ scan path needs an MI355X (gfx950); there is no CPU fallback");
+    if (device < 0 || device >= n) return fail(FFQ_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FFQ_E_NODEVICE, "device %d is %s; libffq_hip is built for gfx950 only", device, prop.gcnArchName);
+    HIPCHK(hipSetDevice(device));
+    ffq_ctx *c = new (std::nothrow) ffq_ctx();
+    if (!c) return fail(FFQ_E_NOMEM, "out of host memory");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->ctl, sizeof(Ctl));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->dres, sizeof(DevRes));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_res, sizeof(DevRes), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ffq_ctx_destroy(c);
+        return fail(FFQ_E_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return FFQ_OK;
+}
+
+extern "C" void ffq_ctx_destroy(ffq_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
+    (void)hipFree(c->sums); (void)hipFree(c->ystart); (void)hipFree(c->rbase); (void)hipFree(c->qbase);
+    (void)hipFree(c->ctl); (void)hipFree(c->dres);
+    (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->stage_h) (void)hipHostFree(c->stage_h);
+    if (c->tab_h) (void)hipHostFree(c->tab_h);
+    for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void *ffq_ctx_stream(ffq_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+static int64_t tiles_for(int64_t n) { return (n + TILE - 1) >> TILE_SHIFT; }
+static int64_t groups_for(int64_t ntiles) { return (ntiles + OWN - 1) / OWN; }
+
+static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
+{
+    if (ntiles <= c->cap_tiles) return FFQ_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf);
+    (void)hipFree(c->sums); (void)hipFree(c->ystart); (void)hipFree(c->rbase); (void)hipFree(c->qbase);
+    c->ent = nullptr; c->cnt = nullptr; c->ovf = nullptr; c->sums = nullptr;
+    c->ystart = c->rbase = c->qbase = nullptr;
+    c->cap_tiles = 0; c->cap_groups = 0;
+    const int64_t ng = groups_for(ntiles);
+    HIPCHK(hipMalloc((void **)&c->ent, (size_t)ntiles * SLOT * sizeof(uint16_t)));
+    HIPCHK(hipMalloc((void **)&c->cnt, (size_t)ntiles * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&c->ovf, (size_t)ntiles * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&c->sums, (size_t)ng * sizeof(GroupSum)));
+    HIPCHK(hipMalloc((void **)&c->ystart, (size_t)ng * sizeof(int64_t)));
+    HIPCHK(hipMalloc((void **)&c->rbase, (size_t)ng * sizeof(int64_t)));
+    HIPCHK(hipMalloc((void **)&c->qbase, (size_t)ng * sizeof(int64_t)));
+    c->cap_tiles = ntiles;
+    c->cap_groups = ng;
+    return FFQ_OK;
+}
+
+static int reserve_pool(ffq_ctx *c, unsigned long long entries)
+{
+    if (entries <= c->pool_cap) return FFQ_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->pool);
+    c->pool = nullptr; c->pool_cap = 0;
+    HIPCHK(hipMalloc((void **)&c->pool, (size_t)entries * sizeof(uint16_t)));
+    c->pool_cap = entries;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
+{
+    if (!c || max_bytes < 0) return fail(FFQ_E_ARG, "ffq_ctx_reserve: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = reserve_tiles(c, std::max<int64_t>(tiles_for(max_bytes), 1));
+    if (rc) return rc;
+    return reserve_pool(c, 1ull << 20);
+}
+
+// ---- memory plumbing -----------------------------------------------------
+extern "C" int ffq_dev_alloc(ffq_ctx *c, int64_t bytes, void **dptr)
+{
+    if (!c || !dptr || bytes < 0) return fail(FFQ_E_ARG, "ffq_dev_alloc: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    *dptr = nullptr;
+    hipError_t e = hipMalloc(dptr, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e));
+    return FFQ_OK;
+}
+extern "C" int ffq_dev_free(ffq_ctx *c, void *dptr)
+{
+    if (!c) return fail(FFQ_E_ARG, "ffq_dev_free: ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(dptr));
+    return FFQ_OK;
+}
+extern "C" int ffq_pinned_alloc(int64_t bytes, void **hptr)
+{
+    if (!hptr || bytes < 0) return fail(FFQ_E_ARG, "ffq_pinned_alloc: bad argument");
+    *hptr = nullptr;
+    hipError_t e = hipHostMalloc(hptr, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipHostMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e));
+    return FFQ_OK;
+}
+extern "C" int ffq_pinned_free(void *hptr)
+{
+    HIPCHK(hipHostFree(hptr));
+    return FFQ_OK;
+}
+extern "C" int ffq_copy_h2d(ffq_ctx *c, void *dptr, const void *hptr, int64_t bytes, int async)
+{
+    if (!c || bytes < 0) return fail(FFQ_E_ARG, "ffq_copy_h2d: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(dptr, hptr, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    if (!async) HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+extern "C" int ffq_copy_d2h(ffq_ctx *c, void *hptr, const void *dptr, int64_t bytes, int async)
+{
+    if (!c || bytes < 0) return fail(FFQ_E_ARG, "ffq_copy_d2h: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(hptr, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    if (!async) HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+extern "C" int ffq_sync(ffq_ctx *c)
+{
+    if (!c) return fail(FFQ_E_ARG, "ffq_sync: ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+
+// ---- the hot path ----------------------------------------------------------
+static void fill_result(ffq_scan_result *res, const DevRes &r, int path, int retries)
+{
+    res->n_records = r.n_records;
+    res->n_qual_bytes = r.n_qual_bytes;
+    res->end_offset = r.end_offset;
+    for (int i = 0; i < 6; i++) res->last_pos[i] = r.last_pos[i];
+    res->last_status = r.last_status;
+    res->end_state = r.end_state;
+    res->path = path;
+    res->retries = retries;
+    res->n_lines = r.n_lines;
+}
+
+extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int sentinel,
+                               int64_t offset, int eof, int64_t add, uint32_t flags, int qual_add,
+                               int64_t *d_table, int64_t table_cap, int8_t *d_qual,
+                               int64_t qual_cap, int64_t *d_qoff, ffq_scan_result *res)
+{
+    if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_device: ctx/res is NULL");
+    if (n_bytes < 0 || offset < 0 || table_cap < 0) return fail(FFQ_E_ARG, "ffq_scan_device: negative size");
+    if (n_bytes > 0 && !d_buf) return fail(FFQ_E_ARG, "ffq_scan_device: d_buf is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_buf) & 15) != 0) return fail(FFQ_E_ARG, "ffq_scan_device: d_buf must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d_table) & 15) != 0) return fail(FFQ_E_ARG, "ffq_scan_device: d_table must be 16-byte aligned");
+    if (table_cap > 0 && !d_table) return fail(FFQ_E_ARG, "ffq_scan_device: d_table is NULL");
+    const bool decode = (flags & FFQ_F_DECODE_QUAL) != 0;
+    if (decode && (!d_qual || !d_qoff)) return fail(FFQ_E_ARG, "ffq_scan_device: FFQ_F_DECODE_QUAL needs d_qual and d_qoff");
+    memset(res, 0, sizeof *res);
+    HIPCHK(hipSetDevice(c->device));
+    const int s = sentinel ? 1 : 0;
+
+    const int64_t ntiles = tiles_for(n_bytes);
+    if (ntiles == 0) {
+        // empty data: with a sentinel the buffer is "\n", no "\n@" can match
+        res->end_state = eof ? FFQ_END_OK : FFQ_END_REFILL;
+        res->last_status = FFQ_POS_HEAD_BEG;
+        res->end_offset = offset;
+        for (int i = 0; i < 6; i++) res->last_pos[i] = -1;
+        if (decode) {
+            const int64_t z = 0;
+            HIPCHK(hipMemcpyAsync(d_qoff, &z, sizeof z, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        return FFQ_OK;
+    }
+    if (ntiles > 0x7FFFFFF0) return fail(FFQ_E_ARG, "buffer too large");
+    int rc = reserve_tiles(c, ntiles);
+    if (rc) return rc;
+    rc = reserve_pool(c, 1ull << 20);
+    if (rc) return rc;
+    const int ngroups = (int)groups_for(ntiles);
+    int64_t *qoff = decode ? d_qoff : nullptr;
+
+    int retries = 0;
+    for (;;) {
+        LineIndex L;
+        L.d = d_buf; L.n = n_bytes; L.s = s; L.ntiles = (int32_t)ntiles;
+        L.ent = c->ent; L.cnt = c->cnt; L.ovf = c->ovf; L.pool = c->pool;
+
+        HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), c->stream));
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        hipLaunchKernelGGL(k_scan_lines, dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_buf, n_bytes,
+                           c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl);
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        const bool serial = (flags & FFQ_F_FORCE_SERIAL) != 0;
+        if (!serial) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3(ngroups), dim3(256), 0, c->stream, L,
+                               offset, eof, add, c->sums, (const int64_t *)nullptr, (const int64_t *)nullptr,
+                               (const int64_t *)nullptr, (const DevRes *)nullptr, (int64_t *)nullptr,
+                               (int64_t)0, (int64_t *)nullptr, c->ctl);
+            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, c->stream, c->sums, ngroups, eof, offset,
+                               add, c->ystart, c->rbase, c->qbase, c->dres);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true>), dim3(ngroups), dim3(256), 0, c->stream, L,
+                               offset, eof, add, c->sums, c->ystart, c->rbase, c->qbase, c->dres, d_table,
+                               table_cap, qoff, c->ctl);
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->dres, d_table, table_cap, add,
+                               offset, qoff);
+        }
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        if (!serial && decode) {
+            hipLaunchKernelGGL(k_decode_quals, dim3(2048), dim3(256), 0, c->stream, d_buf, s, d_table, qoff,
+                               c->dres, table_cap, add, qual_add, d_qual, qual_cap);
+        }
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+
+        if (c->h_ctl->err & ERR_POOL) {
+            // dense tiles did not fit the overflow pool: size it for what was asked and re-run
+            if (retries >= 2) return fail(FFQ_E_INTERNAL, "line-index pool overflow persists");
+            rc = reserve_pool(c, std::max<unsigned long long>(c->h_ctl->pool_head, 1ull << 20));
+            if (rc) return rc;
+            retries++;
+            continue;
+        }
+        if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); res->ms_chain = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); res->ms_decode = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total = ms;
+
+        int path = 0;
+        if (serial || c->h_res->fallback) {
+            path = 1;
+            HIPCHK(hipEventRecord(c->ev[4], c->stream));
+            hipLaunchKernelGGL(k_chain_serial, dim3(1), dim3(64), 0, c->stream, L, offset, eof, add, d_table,
+                               table_cap, qoff, c->dres);
+            hipLaunchKernelGGL(k_finalize_serial, dim3(1), dim3(64), 0, c->stream, c->dres, table_cap, qoff);
+            if (decode)
+                hipLaunchKernelGGL(k_decode_quals, dim3(2048), dim3(256), 0, c->stream, d_buf, s, d_table,
+                                   qoff, c->dres, table_cap, add, qual_add, d_qual, qual_cap);
+            HIPCHK(hipEventRecord(c->ev[5], c->stream));
+            HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+            res->ms_chain += ms;
+            res->ms_total += ms;
+        }
+        fill_result(res, *c->h_res, path, retries);
+        break;
+    }
+    if (res->n_records > table_cap)
+        return fail(FFQ_E_TABLE_FULL, "table holds %lld rows, the buffer has %lld records", (long long)table_cap,
+                    (long long)res->n_records);
+    if (decode && res->n_qual_bytes > qual_cap)
+        return fail(FFQ_E_TABLE_FULL, "quality buffer holds %lld bytes, %lld needed", (long long)qual_cap,
+                    (long long)res->n_qual_bytes);
+    return FFQ_OK;
+}
+
+template <class T>
+static int grow_dev(ffq_ctx *c, T **p, int64_t *cap, int64_t need)
+{
+    if (need <= *cap) return FFQ_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    const int64_t want = std::max<int64_t>(need, 1 << 16);
+    hipError_t e = hipMalloc((void **)p, (size_t)want * sizeof(T));
+    if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    *cap = want;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_scan_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, int sentinel,
+                             int64_t offset, int eof, int64_t add, uint32_t flags, int qual_add,
+                             int64_t *h_table, int64_t table_cap, int8_t *h_qual, int64_t qual_cap,
+                             int64_t *h_qoff, ffq_scan_result *res)
+{
+    if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_host: ctx/res is NULL");
+    if (n_bytes < 0 || table_cap < 0 || qual_cap < 0) return fail(FFQ_E_ARG, "ffq_scan_host: negative size");
+    if (n_bytes > 0 && !h_buf) return fail(FFQ_E_ARG, "ffq_scan_host: h_buf is NULL");
+    const bool decode = (flags & FFQ_F_DECODE_QUAL) != 0;
+    if (decode && (!h_qual || !h_qoff)) return fail(FFQ_E_ARG, "ffq_scan_host: FFQ_F_DECODE_QUAL needs h_qual and h_qoff");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = grow_dev(c, &c->stage_d, &c->stage_d_cap, n_bytes + 16))) return rc;
+    if ((rc = grow_dev(c, &c->tab_d, &c->tab_d_cap, std::max<int64_t>(table_cap, 1) * 6))) return rc;
+    if (decode) {
+        if ((rc = grow_dev(c, &c->qual_d, &c->qual_d_cap, std::max<int64_t>(qual_cap, 16)))) return rc;
+        if ((rc = grow_dev(c, &c->qoff_d, &c->qoff_d_cap, table_cap + 1))) return rc;
+    }
+    // pinned staging, chunked so the H2D copy of chunk i overlaps the host memcpy of chunk i+1
+    const int64_t CH = 8 << 20;
+    if (c->stage_h_cap < 2 * CH) {
+        if (c->stage_h) (void)hipHostFree(c->stage_h);
+        c->stage_h = nullptr; c->stage_h_cap = 0;
+        hipError_t e = hipHostMalloc((void **)&c->stage_h, (size_t)(2 * CH), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+        c->stage_h_cap = 2 * CH;
+    }
+    hipEvent_t done[2];
+    HIPCHK(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+    bool used[2] = {false, false};
+    for (int64_t at = 0, k = 0; at < n_bytes; at += CH, k++) {
+        const int b = (int)(k & 1);
+        const int64_t m = std::min<int64_t>(CH, n_bytes - at);
+        if (used[b]) HIPCHK(hipEventSynchronize(done[b]));
+        memcpy(c->stage_h + b * CH, h_buf + at, (size_t)m);
+        HIPCHK(hipMemcpyAsync(c->stage_d + at, c->stage_h + b * CH, (size_t)m, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipEventRecord(done[b], c->stream));
+        used[b] = true;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipEventDestroy(done[0]);
+    (void)hipEventDestroy(done[1]);
+
+    rc = ffq_scan_device(c, c->stage_d, n_bytes, sentinel, offset, eof, add, flags, qual_add, c->tab_d,
+                         table_cap, decode ? c->qual_d : nullptr, qual_cap, decode ? c->qoff_d : nullptr, res);
+    if (rc != FFQ_OK && rc != FFQ_E_TABLE_FULL) return rc;
+    const int64_t rows = std::min<int64_t>(res->n_records, table_cap);
+    if (rows > 0) HIPCHK(hipMemcpyAsync(h_table, c->tab_d, (size_t)rows * 48, hipMemcpyDeviceToHost, c->stream));
+    if (decode) {
+        const int64_t qb = std::min<int64_t>(res->n_qual_bytes, qual_cap);
+        if (qb > 0) HIPCHK(hipMemcpyAsync(h_qual, c->qual_d, (size_t)qb, hipMemcpyDeviceToHost, c->stream));
+        if (res->n_records <= table_cap)
+            HIPCHK(hipMemcpyAsync(h_qoff, c->qoff_d, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return rc;
+}
+
+extern "C" int ffq_entrypos(ffq_ctx *c, const uint8_t *h_buf, int64_t len, int64_t offset, int64_t *pos,
+                            int *status)
+{
+    if (!c || !pos || !status) return fail(FFQ_E_ARG, "ffq_entrypos: NULL argument");
+    int64_t row[6];
+    ffq_scan_result r;
+    int rc = ffq_scan_host(c, h_buf, len, 0, offset, 0, 0, 0, 0, row, 1, nullptr, 0, nullptr, &r);
+    if (rc != FFQ_OK && rc != FFQ_E_TABLE_FULL) return rc;
+    if (r.n_records >= 1) {
+        for (int i = 0; i < 6; i++) pos[i] = row[i];
+        *status = FFQ_COMPLETE;
+    } else {
+        for (int i = 0; i < 6; i++) pos[i] = r.last_pos[i];
+        *status = r.last_status;
+    }
+    g_err.clear();
+    return FFQ_OK;
+}
+
+// ---- arrayadd ----------------------------------------------------------------
+extern "C" int ffq_arrayadd_b_device(ffq_ctx *c, int8_t *d_a, int64_t n, int value)
+{
+    if (!c || n < 0 || (n > 0 && !d_a)) return fail(FFQ_E_ARG, "ffq_arrayadd_b_device: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) return FFQ_OK;
+    const int64_t nv = (n + 15) / 16;
+    const unsigned grid = (unsigned)std::min<int64_t>((nv + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(k_arrayadd_b, dim3(std::max(grid, 1u)), dim3(256), 0, c->stream, (uint8_t *)d_a, n,
+                       (uint32_t)(uint8_t)value);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+
+extern "C" int ffq_arrayadd_q_device(ffq_ctx *c, int64_t *d_a, int64_t n, int64_t value)
+{
+    if (!c || n < 0 || (n > 0 && !d_a)) return fail(FFQ_E_ARG, "ffq_arrayadd_q_device: bad argument");
+    if ((reinterpret_cast<uintptr_t>(d_a) & 7) != 0) return fail(FFQ_E_ARG, "ffq_arrayadd_q_device: unaligned");
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) return FFQ_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((n / 2 + 255) / 256 + 1, 256 * 8);
+    hipLaunchKernelGGL(k_arrayadd_q, dim3(grid), dim3(256), 0, c->stream, (unsigned long long *)d_a, n,
+                       (unsigned long long)value);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+
+extern "C" int ffq_arrayadd_b(ffq_ctx *c, int8_t *h_a, int64_t n, int value)
+{
+    if (!c || n < 0 || (n > 0 && !h_a)) return fail(FFQ_E_ARG, "ffq_arrayadd_b: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) return FFQ_OK;
+    int rc = grow_dev(c, &c->stage_d, &c->stage_d_cap, n + 16);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->stage_d, h_a, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    rc = ffq_arrayadd_b_device(c, (int8_t *)c->stage_d, n, value);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_a, c->stage_d, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+
+extern "C" int ffq_arrayadd_q(ffq_ctx *c, int64_t *h_a, int64_t n, int64_t value)
+{
+    if (!c || n < 0 || (n > 0 && !h_a)) return fail(FFQ_E_ARG, "ffq_arrayadd_q: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) return FFQ_OK;
+    int rc = grow_dev(c, &c->stage_d, &c->stage_d_cap, n * 8 + 16);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->stage_d, h_a, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    rc = ffq_arrayadd_q_device(c, (int64_t *)c->stage_d, n, value);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_a, c->stage_d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+
+// ---- synthetic inputs ------------------------------------------------------------
+extern "C" int ffq_synth_single(ffq_ctx *c, uint8_t *d_out, int64_t first, int64_t count, uint64_t seed)
+{
+    if (!c || count < 0 || (count > 0 && !d_out)) return fail(FFQ_E_ARG, "ffq_synth_single: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (count == 0) return FFQ_OK;
+    hipLaunchKernelGGL(k_synth_single, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, d_out,
+                       first, count, seed);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+
+extern "C" int64_t ffq_synth_wrapped_size(int64_t i, uint64_t seed) { return synth_wrapped_size(i, seed); }
+
+extern "C" int ffq_synth_wrapped(ffq_ctx *c, uint8_t *d_out, const int64_t *d_start, int64_t first,
+                                 int64_t count, uint64_t seed)
+{
+    if (!c || count < 0 || (count > 0 && (!d_out || !d_start))) return fail(FFQ_E_ARG, "ffq_synth_wrapped: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (count == 0) return FFQ_OK;
+    hipLaunchKernelGGL(k_synth_wrapped, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, d_out,
+                       d_start, first, count, seed);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+
+// ---- diagnostics ---------------------------------------------------------------------
+extern "C" int ffq_selftest(ffq_ctx *c)
+{
+    if (!c) return fail(FFQ_E_ARG, "ffq_selftest: ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    const int NB = 256 * 16;
+    uint8_t host[NB];
+    uint64_t x = 12345;
+    for (int i = 0; i < NB; i++) {
+        x = splitmix64(x);
+        const unsigned r = (unsigned)(x & 7);
+        host[i] = (r == 0) ? '\n' : (r == 1) ? 0x0B : (r == 2) ? 0x8A : (r == 3) ? 0x00 : (uint8_t)(x >> 8);
+    }
+    uint8_t *d = nullptr;
+    uint32_t *bad = nullptr;
+    HIPCHK(hipMalloc((void **)&d, NB));
+    HIPCHK(hipMalloc((void **)&bad, 4));
+    HIPCHK(hipMemcpyAsync(d, host, NB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(bad, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(256), 0, c->stream, d, bad);
+    uint32_t hb = 0;
+    HIPCHK(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(d);
+    (void)hipFree(bad);
+    if (hb) return fail(FFQ_E_INTERNAL, "device self-test: %u mismatches (wave scan / newline mask)", hb);
+    return FFQ_OK;
+}

@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference module `fastqandfurious.fastqandfurious`
+for the FASTQ hot path (reference: /root/reference/src/fastqandfurious.py).
+
+Same names, argument order, status constants and exception texts as the
+reference, so code written against it runs unchanged:
+
+    from fastqandfurious_amd import fastqandfurious, _fastqandfurious
+    for header, sequence, quality in fastqandfurious.readfastq_iter(
+            fh, fbufsize, fastqandfurious.entryfunc, _fastqandfurious.entrypos):
+        ...
+
+`entrypos` below is the pure-Python plug-in scanner of the reference
+(:39-100) -- the CPU-only configuration of BASELINE.json -- written from its
+documented behaviour.  `_fastqandfurious.entrypos` is the MI355X scanner; when
+readfastq_iter is handed a scanner that exposes `scan_buffer` it parses every
+record of a buffer fill with ONE batched GPU call instead of one call per
+record, and yields exactly the same entries.
+
+Out of scope here: FASTA helpers, automagic_open.
+"""
+from array import array
+from collections import namedtuple
+import typing
+
+CHAR_AT: int = ord(b'@')
+CHAR_PLUS: int = ord(b'+')
+CHAR_NEWLINE: int = ord(b'\n')
+BYTES_NEWLINE_AT: bytes = b'\n@'
+BYTES_NEWLINE_PLUS: bytes = b'\n+'
+ARRAY_INIT = array('q', [-1, ] * 6)
+
+Entry = namedtuple('Entry', 'header sequence quality')
+EntryType = typing.Tuple[bytes, bytes, typing.Optional[bytes]]
+
+# status codes, reference :19-27
+INVALID: int = -1
+MISSING_SEQHEADER_BEGIN: int = 0
+MISSING_SEQHEADER_END: int = 1
+MISSING_SEQ_BEG: int = 2
+MISSING_SEQ_END: int = 3
+MISSING_QUAL_BEGIN: int = 4
+MISSING_QUAL_END: int = 5
+COMPLETE: int = 6
+MISSING_QUALHEADER_END: int = 7
+
+# end states reported by a batched scanner (include/ffq.h FFQ_END_*)
+_END_OK, _END_REFILL, _END_ERR_FINAL_QUAL, _END_ERR_INCOMPLETE, _END_ERR_INVALID = range(5)
+
+
+def read(fh: typing.BinaryIO, fbufsize: int) -> typing.Tuple[bytes, bool]:
+    """One chunk of the stream and whether it was the last one.
+
+    Reference :30-36: end of stream is signalled by a short read."""
+    blob = fh.read(fbufsize)
+    return (blob, len(blob) < fbufsize)
+
+
+def entrypos(buf: bytes, offset: int, posbuffer) -> int:
+    """Pure-Python scanner: positions of the next FASTQ entry in `buf`.
+
+    Behaviour of the reference's Python `entrypos` (:39-100): searches with
+    bytes.find, fills posbuffer[0..5] as far as it gets (earlier content is
+    left in place, there is no reset) and returns a status code.
+    """
+    size = len(buf)
+    nl_at = buf.find(BYTES_NEWLINE_AT, offset)
+    if nl_at < 0:
+        return MISSING_SEQHEADER_BEGIN
+    posbuffer[0] = nl_at + 1
+    head_end = buf.find(b'\n', nl_at + 2)
+    if head_end < 0:
+        return MISSING_SEQHEADER_END
+    posbuffer[1] = head_end
+    seq_beg = head_end + 1
+    if seq_beg >= size:
+        return MISSING_SEQ_BEG
+    posbuffer[2] = seq_beg
+    seq_end = buf.find(BYTES_NEWLINE_PLUS, seq_beg)
+    if seq_end < 0:
+        return MISSING_SEQ_END
+    posbuffer[3] = seq_end
+    plus_end = buf.find(b'\n', seq_end + 2)
+    if plus_end < 0:
+        return MISSING_QUALHEADER_END
+    plus_line = plus_end - seq_end          # '+' line incl. its newline
+    if plus_line - 1 > 1 and plus_line != head_end - nl_at:
+        return INVALID                      # '+' line carries text of another length
+    qual_beg = plus_end + 1
+    if qual_beg >= size:
+        return MISSING_QUAL_BEGIN
+    posbuffer[4] = qual_beg
+    qual_end = qual_beg + (seq_end - seq_beg)
+    if qual_end + 2 >= size:
+        return MISSING_QUAL_END
+    posbuffer[5] = qual_end
+    return COMPLETE
+
+
+def entryfunc_namedtuple(buf: bytes, pos, globaloffset: int) -> Entry:
+    """Entry(header, sequence, quality) namedtuple (reference :146-158)."""
+    return Entry(buf[(pos[0] + 1):pos[1]], buf[pos[2]:pos[3]], buf[pos[4]:pos[5]])
+
+
+def entryfunc(buf: bytes, pos, globaloffset: int) -> EntryType:
+    """(header, sequence, quality) byte slices (reference :161-171)."""
+    return (buf[(pos[0] + 1):pos[1]], buf[pos[2]:pos[3]], buf[pos[4]:pos[5]])
+
+
+def entryfunc_abspos(buf: bytes, pos, globaloffset: int):
+    """Absolute stream positions: pos[i] += globaloffset, in place; returns
+    the same `pos` object (reference :186-195)."""
+    for i in range(6):
+        pos[i] += globaloffset
+    return pos
+
+
+def _raise_for_end(end_state: int, where: int):
+    if end_state == _END_ERR_FINAL_QUAL:
+        raise ValueError('Incomplete final quality string at byte')
+    if end_state == _END_ERR_INCOMPLETE:
+        raise ValueError('Incomplete entry at byte %i' % where)
+    if end_state == _END_ERR_INVALID:
+        raise ValueError('Entry is invalid at byte %i' % where)
+    raise RuntimeError('unknown end state %r' % (end_state,))
+
+
+def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
+    """readfastq_iter with a batched scanner: one scan per buffer fill.
+
+    scan_buffer(buf, offset, eof) -> (rows, end_state, end_offset) where rows
+    is an array('q') of 6*n buffer-relative positions.  The refill, the
+    sentinel, globaloffset and the error texts follow the reference loop
+    (:241-279) step for step.
+    """
+    globaloffset = -1
+    offset = 0
+    buf, eof = read(fh, fbufsize)
+    buf = b'\n' + buf
+    while True:
+        rows, end_state, end_offset = scan_buffer(buf, offset, eof)
+        for i in range(0, len(rows), 6):
+            yield entryfunc(buf, rows[i:i + 6], globaloffset)
+        offset = end_offset
+        if end_state == _END_OK:
+            return
+        if end_state != _END_REFILL:
+            _raise_for_end(end_state, globaloffset + offset)
+        globaloffset += offset
+        tmp_buf, eof = read(fh, fbufsize)
+        buf = buf[offset:] + tmp_buf
+        del tmp_buf
+        offset = 0
+
+
+def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
+                   entryfunc: typing.Callable = entryfunc,
+                   entrypos: typing.Callable = entrypos,
+                   globaloffset: int = 0) -> typing.Iterator[EntryType]:
+    """Iterate through entries in a FASTQ stream (reference :198-279).
+
+    :param fh: anything with a `read(n)` method returning bytes
+    :param fbufsize: chunk size of the reads from `fh`
+    :param entryfunc: builds the yielded object from (buf, pos, globaloffset)
+    :param entrypos: scanner (buf, offset, posbuffer) -> status
+    :param globaloffset: accepted and ignored, as in the reference (:242)
+
+    Differences from the reference, both on malformed input only: an INVALID
+    entry met after the end of the stream raises 'Entry is invalid at byte'
+    (the reference never leaves its loop, :256-270).
+    """
+    scan_buffer = getattr(entrypos, 'scan_buffer', None)
+    if scan_buffer is not None:
+        yield from _iter_batched(fh, fbufsize, entryfunc, scan_buffer)
+        return
+
+    posbuffer = array('q', [-1, ] * 6)
+    globaloffset = -1
+    offset = 0
+    buf, eof = read(fh, fbufsize)
+    buf = b'\n' + buf               # sentinel: the first '@' is then a "\n@" match
+    while True:
+        status = entrypos(buf, offset, posbuffer)
+        if status == COMPLETE:
+            offset = posbuffer[5] - 1
+            yield entryfunc(buf, posbuffer, globaloffset)
+            continue
+        if eof:
+            if status == MISSING_SEQHEADER_BEGIN:
+                return
+            if status == MISSING_QUAL_END:
+                # last record of a stream: its quality may run to the last byte
+                qualend = posbuffer[4] + (posbuffer[3] - posbuffer[2])
+                if qualend >= len(buf):
+                    raise ValueError('Incomplete final quality string at byte')
+                posbuffer[5] = qualend
+                yield entryfunc(buf, posbuffer, globaloffset)
+                return
+            if status == INVALID:
+                raise ValueError('Entry is invalid at byte %i' % (globaloffset + offset))
+            raise ValueError('Incomplete entry at byte %i' % (globaloffset + offset))
+        if status == INVALID:
+            raise ValueError('Entry is invalid at byte %i' % (globaloffset + offset))
+        globaloffset += offset
+        tmp_buf, eof = read(fh, fbufsize)
+        buf = buf[offset:] + tmp_buf
+        del tmp_buf
+        offset = 0

@@ -1,0 +1,269 @@
+"""ctypes binding of libffq_hip.so -- the C ABI declared in include/ffq.h.
+
+This module is plumbing only: it loads the in-tree shared library, declares the
+argument types and turns error codes into exceptions.  There is no CPU
+fallback: if the library is missing or no gfx950 device is usable, everything
+here raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libffq_hip.so")
+
+# status codes (include/ffq.h; reference: _fastqandfurious.c:7-15)
+INVALID = -1
+POS_HEAD_BEG = 0
+POS_HEAD_END = 1
+POS_SEQ_BEG = 2
+POS_SEQ_END = 3
+POS_QUAL_BEG = 4
+POS_QUAL_END = 5
+COMPLETE = 6
+MISSING_QUALHEADER_END = 7
+
+END_OK, END_REFILL, END_ERR_FINAL_QUAL, END_ERR_INCOMPLETE, END_ERR_INVALID = range(5)
+
+OK = 0
+E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_TABLE_FULL, E_INTERNAL = -1, -2, -3, -4, -5, -6
+
+F_DECODE_QUAL = 1
+F_FORCE_SERIAL = 2
+
+# every symbol include/ffq.h declares (tests check the library exports them all)
+SYMBOLS = (
+    "ffq_abi_version", "ffq_last_error", "ffq_device_count", "ffq_ctx_create",
+    "ffq_ctx_destroy", "ffq_ctx_reserve", "ffq_ctx_stream", "ffq_dev_alloc", "ffq_dev_free",
+    "ffq_pinned_alloc", "ffq_pinned_free", "ffq_copy_h2d", "ffq_copy_d2h", "ffq_sync",
+    "ffq_scan_device", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
+    "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_synth_single",
+    "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
+)
+
+
+class ScanResult(ctypes.Structure):
+    _fields_ = [
+        ("n_records", ctypes.c_int64),
+        ("n_qual_bytes", ctypes.c_int64),
+        ("end_offset", ctypes.c_int64),
+        ("last_pos", ctypes.c_int64 * 6),
+        ("last_status", ctypes.c_int32),
+        ("end_state", ctypes.c_int32),
+        ("path", ctypes.c_int32),
+        ("retries", ctypes.c_int32),
+        ("n_lines", ctypes.c_int64),
+        ("ms_index", ctypes.c_float),
+        ("ms_chain", ctypes.c_float),
+        ("ms_decode", ctypes.c_float),
+        ("ms_total", ctypes.c_float),
+    ]
+
+
+class FFQError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libffq_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FFQError(E_NODEVICE,
+                           "%s is missing: build it with `python fastq-and-furious_amd/build.py` "
+                           "(there is no CPU fallback for the scan path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i64, i32, u32, u64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32,
+                                  ctypes.c_uint64)
+        P = ctypes.POINTER
+        L.ffq_abi_version.restype = i32
+        L.ffq_last_error.restype = ctypes.c_char_p
+        L.ffq_device_count.restype = i32
+        L.ffq_ctx_create.argtypes = [i32, P(vp)]
+        L.ffq_ctx_destroy.argtypes = [vp]
+        L.ffq_ctx_destroy.restype = None
+        L.ffq_ctx_reserve.argtypes = [vp, i64]
+        L.ffq_ctx_stream.argtypes = [vp]
+        L.ffq_ctx_stream.restype = vp
+        L.ffq_dev_alloc.argtypes = [vp, i64, P(vp)]
+        L.ffq_dev_free.argtypes = [vp, vp]
+        L.ffq_pinned_alloc.argtypes = [i64, P(vp)]
+        L.ffq_pinned_free.argtypes = [vp]
+        L.ffq_copy_h2d.argtypes = [vp, vp, vp, i64, i32]
+        L.ffq_copy_d2h.argtypes = [vp, vp, vp, i64, i32]
+        L.ffq_sync.argtypes = [vp]
+        L.ffq_scan_device.argtypes = [vp, vp, i64, i32, i64, i32, i64, u32, i32, vp, i64, vp, i64, vp,
+                                      P(ScanResult)]
+        L.ffq_scan_host.argtypes = [vp, vp, i64, i32, i64, i32, i64, u32, i32, vp, i64, vp, i64, vp,
+                                    P(ScanResult)]
+        L.ffq_entrypos.argtypes = [vp, vp, i64, i64, vp, P(i32)]
+        L.ffq_arrayadd_b_device.argtypes = [vp, vp, i64, i32]
+        L.ffq_arrayadd_b.argtypes = [vp, vp, i64, i32]
+        L.ffq_arrayadd_q_device.argtypes = [vp, vp, i64, i64]
+        L.ffq_arrayadd_q.argtypes = [vp, vp, i64, i64]
+        L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
+        L.ffq_synth_wrapped_size.argtypes = [i64, u64]
+        L.ffq_synth_wrapped_size.restype = i64
+        L.ffq_synth_wrapped.argtypes = [vp, vp, vp, i64, i64, u64]
+        L.ffq_selftest.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def check(rc, allow=()):
+    if rc != OK and rc not in allow:
+        raise FFQError(rc, lib().ffq_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+class Context:
+    """One GPU context (stream + scratch).  Not thread-safe; one per thread."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        self.device = device
+        check(lib().ffq_ctx_create(int(device), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().ffq_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise FFQError(E_ARG, "context is closed")
+        return self._h
+
+    def reserve(self, max_bytes):
+        check(lib().ffq_ctx_reserve(self.handle, int(max_bytes)))
+
+    def selftest(self):
+        check(lib().ffq_selftest(self.handle))
+
+    # ---- raw device memory (for hosts without torch) -------------------
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        check(lib().ffq_dev_alloc(self.handle, int(nbytes), ctypes.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        check(lib().ffq_dev_free(self.handle, ctypes.c_void_p(ptr)))
+
+    def h2d(self, dptr, arr):
+        a = np.ascontiguousarray(arr)
+        check(lib().ffq_copy_h2d(self.handle, ctypes.c_void_p(dptr), a.ctypes.data, a.nbytes, 0))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags.c_contiguous
+        check(lib().ffq_copy_d2h(self.handle, arr.ctypes.data, ctypes.c_void_p(dptr), arr.nbytes, 0))
+
+    def sync(self):
+        check(lib().ffq_sync(self.handle))
+
+    # ---- hot path --------------------------------------------------------
+    def scan_device(self, d_buf, n_bytes, d_table, table_cap, sentinel=True, offset=0, eof=True,
+                    add=None, flags=0, qual_add=-33, d_qual=None, qual_cap=0, d_qoff=None):
+        """Record chain over a device-resident buffer (raw device pointers).
+
+        Returns (rc, ScanResult); rc is OK or E_TABLE_FULL."""
+        if add is None:
+            add = -1 if sentinel else 0
+        res = ScanResult()
+        rc = lib().ffq_scan_device(self.handle, ctypes.c_void_p(d_buf), int(n_bytes), int(bool(sentinel)),
+                                   int(offset), int(bool(eof)), int(add), int(flags), int(qual_add),
+                                   ctypes.c_void_p(d_table), int(table_cap),
+                                   ctypes.c_void_p(d_qual) if d_qual else None, int(qual_cap),
+                                   ctypes.c_void_p(d_qoff) if d_qoff else None, ctypes.byref(res))
+        check(rc, allow=(E_TABLE_FULL,))
+        return rc, res
+
+    def scan_host(self, buf, sentinel=True, offset=0, eof=True, add=None, flags=0, qual_add=-33,
+                  table_cap=None):
+        """Record chain over a host bytes-like object.
+
+        Returns (table int64[n,6], ScanResult[, qual int8[], qoff int64[n+1]])."""
+        a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+        if add is None:
+            add = -1 if sentinel else 0
+        decode = bool(flags & F_DECODE_QUAL)
+        cap = int(table_cap) if table_cap is not None else max(a.size // 64 + 16, 16)
+        while True:
+            table = np.empty((cap, 6), dtype=np.int64)
+            qual = np.empty(a.size if decode else 0, dtype=np.int8)
+            qoff = np.empty(cap + 1 if decode else 0, dtype=np.int64)
+            res = ScanResult()
+            rc = lib().ffq_scan_host(self.handle, a.ctypes.data if a.size else None, a.size,
+                                     int(bool(sentinel)), int(offset), int(bool(eof)), int(add),
+                                     int(flags), int(qual_add), table.ctypes.data, cap,
+                                     qual.ctypes.data if decode else None, qual.size,
+                                     qoff.ctypes.data if decode else None, ctypes.byref(res))
+            check(rc, allow=(E_TABLE_FULL,))
+            if rc == E_TABLE_FULL and table_cap is None:
+                cap = int(res.n_records) + 1
+                continue
+            break
+        n = min(int(res.n_records), cap)
+        if decode:
+            return table[:n], res, qual[:int(res.n_qual_bytes)], qoff[:n + 1]
+        return table[:n], res
+
+    def entrypos(self, buf, offset, pos):
+        """One scanner call on the GPU: fills pos (6 x int64), returns status."""
+        a = np.frombuffer(buf, dtype=np.uint8)
+        st = ctypes.c_int(0)
+        p = np.empty(6, dtype=np.int64)
+        check(lib().ffq_entrypos(self.handle, a.ctypes.data if a.size else None, a.size, int(offset),
+                                 p.ctypes.data, ctypes.byref(st)))
+        for i in range(6):
+            pos[i] = int(p[i])
+        return st.value
+
+    def arrayadd_b(self, arr, value):
+        a = np.frombuffer(arr, dtype=np.int8) if not isinstance(arr, np.ndarray) else arr
+        check(lib().ffq_arrayadd_b(self.handle, a.ctypes.data, a.size, int(value)))
+
+    def arrayadd_q(self, arr, value):
+        a = np.frombuffer(arr, dtype=np.int64) if not isinstance(arr, np.ndarray) else arr
+        v = (int(value) + 2**63) % 2**64 - 2**63
+        check(lib().ffq_arrayadd_q(self.handle, a.ctypes.data, a.size, v))
+
+    def arrayadd_b_device(self, dptr, n, value):
+        check(lib().ffq_arrayadd_b_device(self.handle, ctypes.c_void_p(dptr), int(n), int(value)))
+
+    def arrayadd_q_device(self, dptr, n, value):
+        v = (int(value) + 2**63) % 2**64 - 2**63
+        check(lib().ffq_arrayadd_q_device(self.handle, ctypes.c_void_p(dptr), int(n), v))
+
+    def synth_single(self, dptr, first, count, seed=42):
+        check(lib().ffq_synth_single(self.handle, ctypes.c_void_p(dptr), int(first), int(count), int(seed)))
+
+    def synth_wrapped(self, dptr, d_start, first, count, seed=43):
+        check(lib().ffq_synth_wrapped(self.handle, ctypes.c_void_p(dptr), ctypes.c_void_p(d_start),
+                                      int(first), int(count), int(seed)))
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context for `device` (default: LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,179 @@
+/*
+ * ffq.h -- C ABI of libffq_hip.so: the MI355X (gfx950) FASTQ buffer-scan path.
+ *
+ * This is the drop-in boundary for the hot path of lgautier/fastq-and-furious
+ * (reference checkout: /root/reference).  Every entry point names the
+ * reference interface it replaces (file:line).  Plain pointers and sizes only;
+ * no torch / Python types.  The reference-side binding a maintainer would add
+ * is shown in INTEGRATION.md.
+ *
+ * Coordinates.  The reference scanners work on one `bytes` buffer; the
+ * iterator prepends a b'\n' sentinel to the stream (fastqandfurious.py:245)
+ * and compensates with globaloffset = -1 (:242).  All scan entry points take
+ *   sentinel = 0  the n_bytes ARE the buffer the scanner sees, or
+ *   sentinel = 1  the buffer is b'\n' + bytes, without the copy,
+ * and work in BUFFER coordinates (index into that buffer).  `add` is added to
+ * every emitted position (entryfunc_abspos' globaloffset, :186-195), so
+ * sentinel = 1, add = -1 yields absolute file offsets.
+ *
+ * Errors.  Functions return FFQ_OK (0) or a negative FFQ_E_* code;
+ * ffq_last_error() gives the text for the calling thread.  There is no CPU
+ * fallback anywhere in this library: without a usable gfx950 device the
+ * context cannot be created and every compute call fails.
+ */
+#ifndef FFQ_H
+#define FFQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFQ_ABI_VERSION 1
+
+/* scanner status codes -- identical to the reference's module constants
+ * (_fastqandfurious.c:7-15,254-262; fastqandfurious.py:19-27)             */
+#define FFQ_INVALID                 (-1)
+#define FFQ_POS_HEAD_BEG            0   /* MISSING_SEQHEADER_BEGIN */
+#define FFQ_POS_HEAD_END            1   /* MISSING_SEQHEADER_END   */
+#define FFQ_POS_SEQ_BEG             2   /* MISSING_SEQ_BEG         */
+#define FFQ_POS_SEQ_END             3   /* MISSING_SEQ_END         */
+#define FFQ_POS_QUAL_BEG            4   /* MISSING_QUAL_BEGIN      */
+#define FFQ_POS_QUAL_END            5   /* MISSING_QUAL_END        */
+#define FFQ_COMPLETE                6
+#define FFQ_MISSING_QUALHEADER_END  7
+
+/* end states of a record chain = the exits of readfastq_iter's loop
+ * (fastqandfurious.py:256-279)                                            */
+#define FFQ_END_OK              0   /* eof, stream ended cleanly (:257-258, :264-266) */
+#define FFQ_END_REFILL          1   /* !eof, entry incomplete: caller refills (:274-279) */
+#define FFQ_END_ERR_FINAL_QUAL  2   /* 'Incomplete final quality string at byte' (:262) */
+#define FFQ_END_ERR_INCOMPLETE  3   /* 'Incomplete entry at byte %i' (:269)            */
+#define FFQ_END_ERR_INVALID     4   /* 'Entry is invalid at byte %i' (:272; at eof the
+                                       reference loops forever, we report this instead) */
+
+/* return codes */
+#define FFQ_OK               0
+#define FFQ_E_NODEVICE      (-1)
+#define FFQ_E_HIP           (-2)
+#define FFQ_E_ARG           (-3)
+#define FFQ_E_NOMEM         (-4)
+#define FFQ_E_TABLE_FULL    (-5)   /* more records than table_cap: n_records holds the need */
+#define FFQ_E_INTERNAL      (-6)
+
+/* flags for the scan calls */
+#define FFQ_F_DECODE_QUAL   1u     /* also emit Phred-decoded qualities (value added = qual_add) */
+#define FFQ_F_FORCE_SERIAL  2u     /* debugging/tests: use the single-wave chain walker */
+
+typedef struct ffq_ctx ffq_ctx;
+
+typedef struct ffq_scan_result {
+    int64_t n_records;      /* rows of the chain (all of them, even if > table_cap)      */
+    int64_t n_qual_bytes;   /* total decoded quality bytes (FFQ_F_DECODE_QUAL)           */
+    int64_t end_offset;     /* buffer coordinate where the last, unsuccessful search
+                               started: the iterator's `offset` at exit (:254, :275-277) */
+    int64_t last_pos[6];    /* posbuffer as the last scanner call left it (+add applied
+                               to entries != -1); for FFQ_END_OK after the final-record
+                               rule, the final record's row                              */
+    int32_t last_status;    /* status of that last call                                   */
+    int32_t end_state;      /* FFQ_END_*                                                  */
+    int32_t path;           /* 0 = parallel chain kernels, 1 = serial walker              */
+    int32_t retries;        /* internal re-runs (line-index pool growth)                  */
+    int64_t n_lines;        /* newline count seen by the line-index kernel                */
+    float   ms_index;       /* device time of the line-index kernel (hipEvent)            */
+    float   ms_chain;       /* device time of chain summary + resolve + emit kernels      */
+    float   ms_decode;      /* device time of the quality decode kernel                   */
+    float   ms_total;       /* device time of the whole call                              */
+} ffq_scan_result;
+
+/* ---- library / context ------------------------------------------------ */
+int         ffq_abi_version(void);
+const char *ffq_last_error(void);
+int         ffq_device_count(void);
+/* device = HIP ordinal.  Fails (FFQ_E_NODEVICE) if it is not a gfx950 part. */
+int         ffq_ctx_create(int device, ffq_ctx **out);
+void        ffq_ctx_destroy(ffq_ctx *ctx);
+/* Pre-size the per-context scratch (line index, group summaries) for buffers
+ * of up to max_bytes so that no allocation happens inside a timed scan.     */
+int         ffq_ctx_reserve(ffq_ctx *ctx, int64_t max_bytes);
+/* The HIP stream all of this context's work is enqueued on (hipStream_t).   */
+void       *ffq_ctx_stream(ffq_ctx *ctx);
+
+/* ---- memory plumbing (so a ctypes host needs nothing else) ------------ */
+int ffq_dev_alloc(ffq_ctx *ctx, int64_t bytes, void **dptr);
+int ffq_dev_free(ffq_ctx *ctx, void *dptr);
+int ffq_pinned_alloc(int64_t bytes, void **hptr);
+int ffq_pinned_free(void *hptr);
+int ffq_copy_h2d(ffq_ctx *ctx, void *dptr, const void *hptr, int64_t bytes, int async);
+int ffq_copy_d2h(ffq_ctx *ctx, void *hptr, const void *dptr, int64_t bytes, int async);
+int ffq_sync(ffq_ctx *ctx);
+
+/* ---- the hot path ------------------------------------------------------
+ * Record chain over one device-resident buffer.  Replaces the per-record
+ * loop `status = entrypos(buf, offset, posbuffer); yield entryfunc(...)` of
+ * readfastq_iter (fastqandfurious.py:251-279) with the C extension's scanner
+ * semantics (_fastqandfurious.c:25-153) for every record of the buffer at
+ * once.  d_buf must be 16-byte aligned.
+ *
+ *   offset      buffer coordinate where the first "\n@" search starts
+ *   eof         nonzero: apply the iterator's end-of-stream rules (:256-270)
+ *   d_table     device int64[table_cap][6]: pos0..pos5 per record, + add
+ *   d_qual      device int8[qual_cap] or NULL: with FFQ_F_DECODE_QUAL the
+ *               bytes buf[pos4:pos5] + qual_add of every record, packed
+ *               (arrayadd_b, _fastqandfurious.c:161-185; usage
+ *               doc/user-guide.rst:130-141)
+ *   d_qoff      device int64[table_cap+1] or NULL: start of record i in d_qual
+ * Blocks until the result is known.                                        */
+int ffq_scan_device(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes,
+                    int sentinel, int64_t offset, int eof, int64_t add,
+                    uint32_t flags, int qual_add,
+                    int64_t *d_table, int64_t table_cap,
+                    int8_t *d_qual, int64_t qual_cap, int64_t *d_qoff,
+                    ffq_scan_result *res);
+
+/* Same over a host buffer: pinned staging + hipMemcpyAsync in, kernels, rows
+ * (and qualities) copied back.  h_table: int64[table_cap][6].              */
+int ffq_scan_host(ffq_ctx *ctx, const uint8_t *h_buf, int64_t n_bytes,
+                  int sentinel, int64_t offset, int eof, int64_t add,
+                  uint32_t flags, int qual_add,
+                  int64_t *h_table, int64_t table_cap,
+                  int8_t *h_qual, int64_t qual_cap, int64_t *h_qoff,
+                  ffq_scan_result *res);
+
+/* One scanner call: entrypos(blob, offset, posbuffer) -> status
+ * (_fastqandfurious.c:25-153).  Host buffers; pos receives 6 x int64.       */
+int ffq_entrypos(ffq_ctx *ctx, const uint8_t *h_buf, int64_t len, int64_t offset,
+                 int64_t *pos, int *status);
+
+/* arrayadd_b(a, value): int8[i] += value in place, wrapping
+ * (_fastqandfurious.c:161-185).  _device: a is device memory.               */
+int ffq_arrayadd_b_device(ffq_ctx *ctx, int8_t *d_a, int64_t n, int value);
+int ffq_arrayadd_b(ffq_ctx *ctx, int8_t *h_a, int64_t n, int value);
+/* arrayadd_q(a, value): int64[i] += value in place, wrapping
+ * (_fastqandfurious.c:193-217).                                             */
+int ffq_arrayadd_q_device(ffq_ctx *ctx, int64_t *d_a, int64_t n, int64_t value);
+int ffq_arrayadd_q(ffq_ctx *ctx, int64_t *h_a, int64_t n, int64_t value);
+
+/* ---- synthetic FASTQ generators (bench / test inputs) -----
+ * Counter-based (splitmix64), so the numpy generator in
+ * fastq-and-furious_amd/synth.py produces the same bytes.
+ * S-single: record i = "@SYN.%010d/1\n" + 150 bases + "\n+\n" + 150 quals +
+ * "\n" = 322 bytes.  Writes records [first, first+count) at d_out.          */
+int ffq_synth_single(ffq_ctx *ctx, uint8_t *d_out, int64_t first, int64_t count,
+                     uint64_t seed);
+/* S-wrapped: lengths 50..300, 80-column wrap, '+' line repeats the header
+ * for one record in four.  d_start[i] (int64, count+1 entries, relative to
+ * d_out) must hold the exclusive prefix sum of ffq_synth_wrapped_size().     */
+int64_t ffq_synth_wrapped_size(int64_t i, uint64_t seed);
+int ffq_synth_wrapped(ffq_ctx *ctx, uint8_t *d_out, const int64_t *d_start,
+                      int64_t first, int64_t count, uint64_t seed);
+
+/* ---- diagnostics ---------------------------------------------------------
+ * Runs the device self-checks (wave scan, newline mask) and returns FFQ_OK.  */
+int ffq_selftest(ffq_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFQ_H */

@@ -1,0 +1,264 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+golden vectors.  Bit-exact: integer offsets and bytes."""
+import io
+import os
+from array import array
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, end_matches, golden_file, rows_of
+
+pytestmark = pytest.mark.gpu
+
+FILES = ("test.fq", "test_longqualityheader.fq", "test_multiline.fq")
+
+
+@pytest.fixture(scope="module")
+def hipmod(pkg):
+    from fastqandfurious_amd import hip
+    return hip
+
+
+def check_same(ctx, oracle, data, flags=0, **kw):
+    """GPU scan == oracle scan on `data` (rows, end state, last status/pos)."""
+    want, end, status, off = oracle.scan(data, **kw)
+    table, res = ctx.scan_host(data, flags=flags, **kw)
+    assert rows_of(table) == rows_of(want)
+    assert int(res.n_records) == len(want)
+    assert int(res.end_state) == end
+    assert int(res.last_status) == status
+    assert int(res.end_offset) == off
+    return table, res
+
+
+def test_selftest(gpu_ctx):
+    gpu_ctx.selftest()
+
+
+@pytest.mark.parametrize("fn", FILES)
+@pytest.mark.parametrize("serial", (False, True))
+def test_golden_files(gpu_ctx, hipmod, golden, oracle, fn, serial):
+    data = golden_file(fn)
+    flags = hipmod.F_FORCE_SERIAL if serial else 0
+    table, res = check_same(gpu_ctx, oracle, data, flags=flags)
+    assert rows_of(table) == golden["files"][fn]["bufsizes"]["65536"]["c"]["rows"]
+    assert res.path == (1 if serial else 0)
+
+
+def test_template_prefix_curves_entrypos(gpu_ctx, golden):
+    """ffq_entrypos == the C extension's entrypos at every prefix length."""
+    n = 0
+    for tpl in golden["templates"]:
+        buf = bytes.fromhex(tpl["buf"])
+        for rec in tpl["curve"]:
+            if "c" not in rec:
+                continue
+            pos = array("q", [0] * 6)
+            st = gpu_ctx.entrypos(buf[:rec["cut"]], 0, pos)
+            assert [st, list(pos)] == rec["c"], (tpl["name"], rec["cut"])
+            n += 1
+    assert n > 300
+
+
+@pytest.mark.parametrize("serial", (False, True))
+def test_edge_corpus(gpu_ctx, hipmod, golden, oracle, serial):
+    flags = hipmod.F_FORCE_SERIAL if serial else 0
+    for name, ent in golden["edge"].items():
+        data = bytes.fromhex(ent["data"])
+        table, res = check_same(gpu_ctx, oracle, data, flags=flags)
+        run = ent["runs"]["65536"]["c"]
+        assert rows_of(table) == run["rows"], name
+        assert end_matches(run, int(res.end_state), int(res.end_offset)), name
+
+
+@pytest.mark.parametrize("serial", (False, True))
+def test_fuzz_corpus(gpu_ctx, hipmod, golden, oracle, serial):
+    flags = hipmod.F_FORCE_SERIAL if serial else 0
+    for i, ent in enumerate(golden["fuzz"]):
+        data = bytes.fromhex(ent["data"])
+        table, res = check_same(gpu_ctx, oracle, data, flags=flags)
+        if "c" in ent:
+            assert rows_of(table) == ent["c"]["rows"], i
+            assert end_matches(ent["c"], int(res.end_state), int(res.end_offset)), i
+
+
+def test_not_eof_and_offsets(gpu_ctx, oracle):
+    buf = b"\n" + golden_file("test_multiline.fq")
+    for eof in (False, True):
+        for off in (0, 1, 2, 137, 200, len(buf) - 3, len(buf)):
+            check_same(gpu_ctx, oracle, buf, sentinel=False, offset=off, eof=eof, add=0)
+    check_same(gpu_ctx, oracle, golden_file("test.fq"), sentinel=True, eof=False)
+    check_same(gpu_ctx, oracle, b"", sentinel=True)
+    check_same(gpu_ctx, oracle, b"@", sentinel=True)
+    check_same(gpu_ctx, oracle, b"\n@", sentinel=False, add=0)
+
+
+@pytest.mark.parametrize("nrec,first", ((1, 0), (50, 7), (51, 0), (2000, 0), (12345, 1000), (60000, 5)))
+def test_synth_single(gpu_ctx, oracle, pkg, nrec, first):
+    from fastqandfurious_amd import synth
+    data = synth.single(first, nrec, seed=42)
+    table, res = check_same(gpu_ctx, oracle, data)
+    assert res.path == 0
+    if nrec == 2000 and first == 0:
+        assert (table == np.load(os.path.join(GOLDEN_DIR, "synth_single_table.npy"))).all()
+
+
+@pytest.mark.parametrize("nrec,first", ((3, 0), (2000, 0), (30000, 17)))
+def test_synth_wrapped(gpu_ctx, oracle, pkg, nrec, first):
+    from fastqandfurious_amd import synth
+    data, _ = synth.wrapped(first, nrec, seed=43)
+    table, res = check_same(gpu_ctx, oracle, data)
+    assert res.path == 0
+    if nrec == 2000 and first == 0:
+        assert (table == np.load(os.path.join(GOLDEN_DIR, "synth_wrapped_table.npy"))).all()
+
+
+def test_truncations_of_synthetic(gpu_ctx, oracle, pkg):
+    """Every way a stream can stop inside the last record."""
+    from fastqandfurious_amd import synth
+    data = synth.single(0, 120, seed=42).tobytes()       # > 2 tiles
+    for cut in list(range(len(data) - 330, len(data) + 1, 7)) + [len(data) - 1]:
+        for eof in (True, False):
+            check_same(gpu_ctx, oracle, data[:cut], eof=eof)
+
+
+def test_short_records_dense_tiles(gpu_ctx, oracle):
+    """Lines shorter than 16 bytes on average: tiles overflow their slot and go
+    through the pool; the chain falls back to the serial walker."""
+    rec = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(6000))
+    table, res = check_same(gpu_ctx, oracle, rec)
+    assert len(table) == 6000
+    rec2 = b"\n" * 40000 + rec
+    check_same(gpu_ctx, oracle, rec2)
+
+
+def test_long_records(gpu_ctx, oracle):
+    """Records longer than the chain kernel's window (long reads)."""
+    rng = np.random.default_rng(5)
+    parts = []
+    for i in range(12):
+        L = int(rng.integers(20000, 200000))
+        seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L).tobytes()
+        qual = rng.choice(np.frombuffer(bytes(range(33, 74)), dtype=np.uint8), size=L).tobytes()
+        parts.append(b"@long%d\n" % i + seq + b"\n+\n" + qual + b"\n")
+    check_same(gpu_ctx, oracle, b"".join(parts))
+
+
+def test_decode_quals(gpu_ctx, hipmod, oracle, pkg):
+    from fastqandfurious_amd import synth
+    for data in (synth.single(0, 3000, seed=42), synth.wrapped(0, 3000, seed=43)[0]):
+        want, *_ = oracle.scan(data)
+        wq, wqoff = oracle.decode_quals(data, want)
+        table, res, qual, qoff = gpu_ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL)
+        assert (table == want).all()
+        assert (qoff == wqoff).all()
+        assert (qual == wq).all()
+        assert int(res.n_qual_bytes) == wq.size
+
+
+def test_arrayadd(gpu_ctx, golden, oracle, pkg):
+    from fastqandfurious_amd import _fastqandfurious as C
+    for k in golden["arrayadd"]["b"]:
+        a = array("b")
+        a.frombytes(bytes.fromhex(k["in"]))
+        C.arrayadd_b(a, k["value"])
+        assert a.tobytes().hex() == k["out"]
+    for k in golden["arrayadd"]["q"]:
+        a = array("q", k["in"])
+        C.arrayadd_q(a, k["value"])
+        assert [int(x) for x in a] == k["out"]
+    rng = np.random.default_rng(11)
+    for n in (1, 15, 16, 17, 1000, 100003):
+        for shift in (0, 1, 3):
+            src = rng.integers(-128, 128, size=n + shift, dtype=np.int8)
+            a = src.copy()
+            gpu_ctx.arrayadd_b(a[shift:], -33)
+            b = src.copy()
+            oracle.arrayadd_b(b[shift:], -33)
+            assert (a == b).all()
+        src = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+        a = src.copy()
+        gpu_ctx.arrayadd_q(a, -12345678901)
+        b = src.copy()
+        oracle.arrayadd_q(b, -12345678901)
+        assert (a == b).all()
+
+
+def test_device_generators_match_numpy(gpu_ctx, pkg):
+    from fastqandfurious_amd import synth
+    n = 5000
+    d = gpu_ctx.dev_alloc(n * 322)
+    gpu_ctx.synth_single(d, 123, n, seed=42)
+    out = np.empty(n * 322, dtype=np.uint8)
+    gpu_ctx.d2h(out, d)
+    gpu_ctx.dev_free(d)
+    assert (out == synth.single(123, n, seed=42)).all()
+    want, start = synth.wrapped(77, n, seed=43)
+    d = gpu_ctx.dev_alloc(want.size)
+    ds = gpu_ctx.dev_alloc(start.nbytes)
+    gpu_ctx.h2d(ds, start)
+    gpu_ctx.synth_wrapped(d, ds, 77, n, seed=43)
+    out = np.empty(want.size, dtype=np.uint8)
+    gpu_ctx.d2h(out, d)
+    gpu_ctx.dev_free(d)
+    gpu_ctx.dev_free(ds)
+    assert (out == want).all()
+
+
+# ---- the reference-shaped API on the GPU ------------------------------------------
+def run_iter(F, data, bufsize, entrypos):
+    rows, err = [], None
+    try:
+        for p in F.readfastq_iter(io.BytesIO(data), bufsize, entryfunc=F.entryfunc_abspos, entrypos=entrypos):
+            rows.append([int(x) for x in p])
+    except ValueError as e:
+        err = str(e)
+    return rows, err
+
+
+@pytest.mark.parametrize("fn", FILES)
+@pytest.mark.parametrize("bufsize", (100, 600, 65536))
+def test_readfastq_iter_with_gpu_entrypos(gpu_ctx, golden, pkg, fn, bufsize):
+    """readfastq_iter(..., entrypos=_fastqandfurious.entrypos): batched protocol."""
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C
+    data = golden_file(fn)
+    rows, err = run_iter(F, data, bufsize, C.entrypos)
+    assert err is None and rows == golden["files"][fn]["bufsizes"][str(bufsize)]["c"]["rows"]
+    got = [[h.hex(), s.hex(), q.hex()] for h, s, q in F.readfastq_iter(io.BytesIO(data), bufsize, entrypos=C.entrypos)]
+    assert got == golden["files"][fn]["tuples"]
+
+
+@pytest.mark.parametrize("fn", FILES)
+def test_per_record_protocol(gpu_ctx, golden, pkg, fn):
+    """The per-record plug-in protocol: a loop that calls entrypos(buf, offset,
+    posbuffer) once per record, as the reference's iterator does."""
+    from fastqandfurious_amd import _fastqandfurious as C
+    buf = b"\n" + golden_file(fn)
+    pos = array("q", [-1] * 6)
+    rows, offset = [], 0
+    while True:
+        st = C.entrypos(buf, offset, pos)
+        if st != C.COMPLETE:
+            break
+        rows.append([x - 1 for x in pos])
+        offset = pos[5] - 1
+    assert st == C.POS_QUAL_END
+    assert rows == golden["files"][fn]["bufsizes"]["65536"]["c"]["rows"][:-1]
+    # an arbitrary offset (not on the cached chain) rescans
+    st = C.entrypos(buf, 5, pos)
+    assert st == C.COMPLETE and pos[0] - 1 == rows[1][0]
+
+
+def test_iterator_errors_on_gpu(gpu_ctx, golden, pkg):
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C
+    for name, ent in golden["edge"].items():
+        data = bytes.fromhex(ent["data"])
+        for bs in ("16", "65536"):
+            run = ent["runs"][bs]["c"]
+            rows, err = run_iter(F, data, int(bs), C.entrypos)
+            assert rows == run["rows"], (name, bs)
+            if run["hang"]:
+                assert err is not None and err.startswith("Entry is invalid at byte")
+            else:
+                assert err == run["error"], (name, bs)
