@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- FASTQ buffer-scan hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" = one pass of the hot path (line index -> record chain -> int64[n][6]
+offset table, optionally Phred decode) over one batch of synthetic FASTQ that is
+already resident in HBM.  Prints ONE JSON line (rank 0).
+
+Workloads (BASELINE.json configs):
+    single-1g    1 GiB S-single, 150 bp, Phred+33            (configs[1], default)
+    decode-10g   10 GiB S-single + quality -> int8 decode     (configs[2])
+    wrapped-10g  10 GiB S-wrapped, 50-300 bp, 80-col wrap     (configs[3])
+For N > 1 the same per-GPU workload is one byte range of a single logical
+stream N times as long (weak scaling); ranks exchange only the bytes around
+their range edges (RCCL send/recv) and verify the hand-off.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GIB = 1 << 30
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+WORKLOADS = {
+    "single-1g": dict(kind="single", bytes=1 * GIB, decode=False),
+    "decode-10g": dict(kind="single", bytes=10 * GIB, decode=True),
+    "wrapped-10g": dict(kind="wrapped", bytes=10 * GIB, decode=False),
+    # small variants for quick checks
+    "single-64m": dict(kind="single", bytes=64 << 20, decode=False),
+    "wrapped-64m": dict(kind="wrapped", bytes=64 << 20, decode=False),
+    "decode-64m": dict(kind="single", bytes=64 << 20, decode=True),
+    "single-10g": dict(kind="single", bytes=10 * GIB, decode=False),
+}
+
+
+def cpu_baseline(sample_u8, budget_s=10.0):
+    """The oracle's whole-buffer chain (C restatement of the reference scanner),
+    one host core, timed on a bounded sample of the same bytes."""
+    from oracle import ffq_oracle
+    ffq_oracle.lib()
+    n = int(sample_u8.size)
+    cap = n // 64 + 16
+    table = np.empty((cap, 6), dtype=np.int64)
+    out = np.zeros(4, dtype=np.int64)
+    L = ffq_oracle.lib()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        L.ffq_oracle_scan(sample_u8.ctypes.data, n, 1, 0, 1, 0, -1, table.ctypes.data, cap, out.ctypes.data)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 200:
+            break
+    recs = int(out[0])
+    return {
+        "value": round(n * reps / el / 1e9, 4),
+        "unit": "GB/s",
+        "m_reads_per_s": round(recs * reps / el / 1e6, 4),
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d passes of oracle/ffq_oracle_scan (C restatement of _fastqandfurious.c entrypos + "
+                  "the readfastq_iter chain) over the first %d bytes (%d records) of the workload, %.1f s"
+                  % (reps, n, recs, el),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="single-1g", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    import torch
+    import fastqandfurious_amd  # noqa: F401
+    from fastqandfurious_amd import hip, sharded, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    ctx = hip.Context(local_rank)
+    decode = wl["decode"]
+    flags = hip.F_DECODE_QUAL if decode else 0
+
+    # ---- this rank's byte range of the logical stream, generated in HBM ----------
+    shard = sharded.SyntheticShard(ctx, wl["kind"], wl["bytes"], rank, world, dev)
+    n_own = shard.n_own_bytes
+    ctx.reserve(shard.ext.numel())
+    table = torch.empty((shard.max_records + 64, 6), dtype=torch.int64, device=dev)
+    qual = qoff = None
+    if decode:
+        qual = torch.empty(shard.ext.numel(), dtype=torch.int8, device=dev)
+        qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        return shard.scan(table, flags=flags, qual=qual, qoff=qoff)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    ms_index, ms_chain, ms_decode, ms_total = [], [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        ms_index.append(out.res.ms_index)
+        ms_chain.append(out.res.ms_chain)
+        ms_decode.append(out.res.ms_decode)
+        ms_total.append(out.res.ms_total)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([out.n_own_records, n_own], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        total_records, total_bytes = int(tot[0].item()), int(tot[1].item())
+    else:
+        total_records, total_bytes = out.n_own_records, n_own
+    assert out.res.path == 0, "the parallel chain path must be the one measured (got the serial walker)"
+
+    # ---- parity spot check on the measured output (size-independent properties) -----
+    shard.verify(table, out)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = total_bytes / (elapsed / args.steps) / 1e9
+        # dominant kernel: k_scan_lines.  Algorithmic bytes per launch = every byte of the
+        # scanned buffer read once + 2 bytes of line index written per newline.
+        t_idx = float(np.mean(ms_index)) * 1e-3
+        algo = shard.ext_scanned_bytes + 2 * int(out.res.n_lines)
+        achieved = algo / t_idx / 1e9
+        # whole path priced with SURVEY.md 8(d): record bytes + 48 B row (+ decode bytes)
+        t_dev = float(np.mean(ms_total)) * 1e-3
+        algo_path = n_own + 48 * out.n_own_records
+        if decode:
+            algo_path += int(out.res.n_qual_bytes) + 8 * out.n_own_records
+        line = {
+            "metric": "GB/s FASTQ parsed",
+            "value": round(value, 3),
+            "unit": "GB/s",
+            "m_reads_per_s": round(total_records / (elapsed / args.steps) / 1e6, 3),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload,
+                "description": "%s synthetic FASTQ, %d bytes/GPU, %d records/GPU%s"
+                               % ("S-single 150 bp" if wl["kind"] == "single" else "S-wrapped 50-300 bp",
+                                  n_own, out.n_own_records, ", quality->int8 decode" if decode else ""),
+                "bytes_per_gpu": n_own,
+                "records_per_gpu": out.n_own_records,
+                "sharding": "byte ranges, RCCL edge hand-off" if world > 1 else "single range",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_scan_lines",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": algo,
+                "avg_launch_ms": round(t_idx * 1e3, 4),
+            },
+            "path_roofline": {
+                "what": "all kernels of one step, SURVEY.md 8(d) bytes (record bytes + 48 B row%s)"
+                        % (" + decoded bytes + 8 B CSR offset" if decode else ""),
+                "achieved": round(algo_path / t_dev / 1e9, 2),
+                "frac": round(algo_path / t_dev / 1e9 / HBM_PEAK_GBS, 4),
+                "device_ms": round(t_dev * 1e3, 4),
+                "ms_index": round(float(np.mean(ms_index)), 4),
+                "ms_chain": round(float(np.mean(ms_chain)), 4),
+                "ms_decode": round(float(np.mean(ms_decode)), 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = shard.host_sample(256 << 20)
+            line["cpu_baseline"] = cpu_baseline(sample, args.cpu_seconds)
+            line["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

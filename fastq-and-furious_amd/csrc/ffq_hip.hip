@@ -456,6 +456,22 @@ extern "C" int ffq_entrypos(ffq_ctx *c, const uint8_t *h_buf, int64_t len, int64
     return FFQ_OK;
 }
 
+extern "C" int ffq_table_lower_bound(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int col,
+                                     int64_t value, int64_t *idx)
+{
+    if (!c || !idx || n_rows < 0 || col < 0 || col > 5 || (n_rows > 0 && !d_table))
+        return fail(FFQ_E_ARG, "ffq_table_lower_bound: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    int64_t *slot = reinterpret_cast<int64_t *>(&c->h_ctl->pool_head);   // pinned scratch word
+    int64_t *dslot = reinterpret_cast<int64_t *>(&c->ctl->pool_head);
+    hipLaunchKernelGGL(k_table_lower_bound, dim3(1), dim3(64), 0, c->stream, d_table, n_rows, col, value, dslot);
+    HIPCHK(hipMemcpyAsync(slot, dslot, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *idx = *slot;
+    return FFQ_OK;
+}
+
 // ---- arrayadd ----------------------------------------------------------------
 extern "C" int ffq_arrayadd_b_device(ffq_ctx *c, int8_t *d_a, int64_t n, int value)
 {

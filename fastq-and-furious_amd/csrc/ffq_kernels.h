@@ -815,6 +815,19 @@ __global__ __launch_bounds__(256) void k_decode_quals(const uint8_t *__restrict_
     }
 }
 
+// lower bound over one column of the (record-ordered) offset table
+__global__ void k_table_lower_bound(const int64_t *__restrict__ table, int64_t n, int col,
+                                    int64_t value, int64_t *__restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (table[mid * 6 + col] < value) lo = mid + 1; else hi = mid;
+    }
+    *out = lo;
+}
+
 // =========================================================================
 // arrayadd_b / arrayadd_q (_fastqandfurious.c:161-217), in place, wrapping
 // =========================================================================

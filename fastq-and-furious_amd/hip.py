@@ -38,7 +38,8 @@ SYMBOLS = (
     "ffq_ctx_destroy", "ffq_ctx_reserve", "ffq_ctx_stream", "ffq_dev_alloc", "ffq_dev_free",
     "ffq_pinned_alloc", "ffq_pinned_free", "ffq_copy_h2d", "ffq_copy_d2h", "ffq_sync",
     "ffq_scan_device", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
-    "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_synth_single",
+    "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
+    "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
 )
 
@@ -107,6 +108,7 @@ def lib():
         L.ffq_arrayadd_b.argtypes = [vp, vp, i64, i32]
         L.ffq_arrayadd_q_device.argtypes = [vp, vp, i64, i64]
         L.ffq_arrayadd_q.argtypes = [vp, vp, i64, i64]
+        L.ffq_table_lower_bound.argtypes = [vp, vp, i64, i32, i64, P(i64)]
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
         L.ffq_synth_wrapped_size.argtypes = [i64, u64]
         L.ffq_synth_wrapped_size.restype = i64
@@ -246,6 +248,12 @@ class Context:
     def arrayadd_q_device(self, dptr, n, value):
         v = (int(value) + 2**63) % 2**64 - 2**63
         check(lib().ffq_arrayadd_q_device(self.handle, ctypes.c_void_p(dptr), int(n), v))
+
+    def table_lower_bound(self, d_table, n_rows, col, value):
+        idx = ctypes.c_int64(0)
+        check(lib().ffq_table_lower_bound(self.handle, ctypes.c_void_p(d_table), int(n_rows), int(col),
+                                          int(value), ctypes.byref(idx)))
+        return idx.value
 
     def synth_single(self, dptr, first, count, seed=42):
         check(lib().ffq_synth_single(self.handle, ctypes.c_void_p(dptr), int(first), int(count), int(seed)))

@@ -1,0 +1,293 @@
+"""Byte-range sharding of one FASTQ stream over the GPUs of a node.
+
+The reference has nothing like this (it is a single-threaded generator); the
+unit that shards is the record chain of readfastq_iter
+(/root/reference/src/fastqandfurious.py:251-279): once a record start is known,
+records are independent.
+
+Rank r owns the bytes [S_r, S_{r+1}) of the stream and every record whose '@'
+lies in that range.  One process per GPU; per step:
+
+  1. edge hand-off (torch.distributed P2P = RCCL send/recv over xGMI): each
+     rank sends the first HEAD bytes of its range to its left neighbour (so the
+     neighbour can finish the record that straddles the edge) and the last TAIL
+     bytes to its right neighbour (run-in: a chain started anywhere in it has
+     re-synchronised with the true record chain before the range starts);
+  2. one ordinary scan of [tail | own | head] on the local GPU;
+  3. the rows with S_r <= pos0 < S_{r+1} are the shard's records;
+  4. verification, 8 bytes per edge: the first record start at/after S_{r+1}
+     as rank r sees it must equal the first row rank r+1 claims.  Together with
+     rank 0's exact start this proves every shard's rows by induction;
+  5. all_gather of the per-rank record counts -> global record ordinals.
+
+No collective touches the data path; traffic is KiB per edge.
+
+The scan engine is injected (`backend`): the product backend is HipBackend
+(libffq_hip.so); tests drive the same host logic on CPU tensors over gloo with
+a checker backend.
+"""
+import ctypes
+
+import numpy as np
+
+from . import hip as _hip
+
+TAIL_BYTES = 1 << 20      # run-in taken from the left neighbour
+HEAD_BYTES = 1 << 20      # look-ahead taken from the right neighbour
+
+
+def shard_bounds(total_bytes, world):
+    """S_0..S_world: 16-byte aligned cut points of the stream."""
+    b = [(r * total_bytes // world) // 16 * 16 for r in range(world)]
+    b.append(total_bytes)
+    return b
+
+
+class ScanOutput:
+    def __init__(self, res, n_rows, row_lo, row_hi, exit_pos, first_pos):
+        self.res = res
+        self.n_rows = n_rows
+        self.row_lo = row_lo
+        self.row_hi = row_hi
+        self.exit_pos = exit_pos
+        self.first_pos = first_pos
+        self.n_own_records = row_hi - row_lo
+        self.record_base = 0          # global ordinal of this shard's first record
+
+
+class HipBackend:
+    """Scan engine on the local MI355X through the C ABI."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def scan(self, ext, n_bytes, sentinel, offset, eof, add, table, flags=0, qual=None, qoff=None,
+             table_cap=None):
+        cap = table.shape[0] if table_cap is None else table_cap
+        rc, res = self.ctx.scan_device(
+            ext.data_ptr(), n_bytes, table.data_ptr(), cap, sentinel=sentinel, offset=offset,
+            eof=eof, add=add, flags=flags,
+            d_qual=qual.data_ptr() if qual is not None else None,
+            qual_cap=qual.numel() if qual is not None else 0,
+            d_qoff=qoff.data_ptr() if qoff is not None else None)
+        return rc, res
+
+    def lower_bound(self, table, n_rows, value):
+        return self.ctx.table_lower_bound(table.data_ptr(), n_rows, 0, value)
+
+    def row(self, table, idx):
+        out = np.empty(6, dtype=np.int64)
+        self.ctx.d2h(out, table.data_ptr() + idx * 48)
+        return [int(x) for x in out]
+
+    def sync_inputs(self):
+        import torch
+        torch.cuda.synchronize()
+
+
+def exchange_edges(dist, ext, tail, n_own, head, rank, world, group=None):
+    """Fill ext[:tail] from the left neighbour's last bytes and
+    ext[tail+n_own : tail+n_own+head] from the right neighbour's first bytes."""
+    if world == 1:
+        return
+    ops = []
+    own = ext[tail:tail + n_own]
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, own[:min(HEAD_BYTES, n_own)], rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, ext[:tail], rank - 1, group))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.isend, own[n_own - min(TAIL_BYTES, n_own):], rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, ext[tail + n_own:tail + n_own + head], rank + 1, group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
+class ShardScanner:
+    """Steps 2-5 above for one rank."""
+
+    def __init__(self, backend, rank, world, dist=None, group=None, device=None):
+        self.backend = backend
+        self.rank = rank
+        self.world = world
+        self.dist = dist
+        self.group = group
+        self.device = device
+
+    def _start_offset(self, ext, tail, add, table):
+        """A search offset inside the run-in whose chain survives into the own
+        range.  A chain that starts at a false '@' candidate can stop at an
+        INVALID entry right away; step past that candidate and try again."""
+        if self.rank == 0 or tail == 0:
+            return 0
+        probe = min(ext.numel(), tail + (64 << 10))
+        offset = 0
+        for _ in range(32):
+            rc, res = self.backend.scan(ext, probe, False, offset, False, add, table)
+            if res.end_state == _hip.END_REFILL or res.end_offset >= tail:
+                return offset
+            if res.last_pos[0] < 0:
+                break
+            offset = int(res.last_pos[0]) - add      # the '@' of the failing entry: search after it
+        raise RuntimeError("rank %d: no record chain survives the %d-byte run-in" % (self.rank, tail))
+
+    def scan(self, ext, tail, n_own, head, own_lo_file, own_hi_file, table, flags=0, qual=None, qoff=None):
+        """ext = [tail | own | head] bytes (1-D uint8 tensor); the file offset of
+        ext[tail] is own_lo_file.  Returns ScanOutput; table rows are absolute
+        file offsets."""
+        rank, world = self.rank, self.world
+        sentinel = rank == 0
+        eof = rank == world - 1
+        ext_start = own_lo_file - tail
+        add = ext_start - (1 if sentinel else 0)
+        n_bytes = tail + n_own + head
+        offset = self._start_offset(ext, tail, add, table)
+        rc, res = self.backend.scan(ext, n_bytes, sentinel, offset, eof, add, table, flags, qual, qoff)
+        if rc != _hip.OK:
+            raise RuntimeError("rank %d: offset table too small (%d records)" % (rank, res.n_records))
+        n = int(res.n_records)
+        if eof:
+            if res.end_state != _hip.END_OK:
+                raise ValueError("stream does not end cleanly (end state %d at byte %d)"
+                                 % (res.end_state, add + res.end_offset))
+        elif res.end_state != _hip.END_REFILL:
+            raise ValueError("rank %d: invalid entry at byte %d" % (rank, add + res.end_offset))
+        i0 = 0 if rank == 0 else self.backend.lower_bound(table, n, own_lo_file)
+        i1 = n if eof else self.backend.lower_bound(table, n, own_hi_file)
+        first_pos = self.backend.row(table, i0)[0] if i0 < n else -1
+        exit_pos = self.backend.row(table, i1)[0] if i1 < n else -1
+        if not eof and exit_pos < 0:
+            raise RuntimeError("rank %d: no complete record starts after byte %d within the %d-byte "
+                               "look-ahead (record longer than the halo)" % (rank, own_hi_file, head))
+        out = ScanOutput(res, n, i0, i1, exit_pos, first_pos)
+        if world > 1:
+            self._verify_and_count(out)
+        return out
+
+    def _verify_and_count(self, out):
+        import torch
+        dist, rank, world = self.dist, self.rank, self.world
+        dev = self.device
+        mine = torch.tensor([out.exit_pos, out.n_own_records], dtype=torch.int64, device=dev)
+        allv = [torch.empty(2, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(allv, mine, group=self.group)
+        allv = [[int(x) for x in t.tolist()] for t in allv]
+        if rank > 0 and allv[rank - 1][0] != out.first_pos:
+            raise RuntimeError("rank %d: edge hand-off mismatch: left neighbour's chain enters this range "
+                               "at byte %d, this rank started at %d" % (rank, allv[rank - 1][0], out.first_pos))
+        out.record_base = sum(v[1] for v in allv[:rank])
+        out.total_records = sum(v[1] for v in allv)
+
+
+class SyntheticShard:
+    """bench.py's input: this rank's byte range of a synthetic stream, built in
+    HBM.  The logical stream is world * n_per records of S-single / S-wrapped
+    (SURVEY.md 8d); cut points are moved off the record boundaries so that a
+    record straddles every edge."""
+
+    def __init__(self, ctx, kind, bytes_per_gpu, rank, world, dev, edge_shift=144):
+        import torch
+        from . import synth
+        self.ctx, self.kind, self.rank, self.world, self.dev = ctx, kind, rank, world, dev
+        self.dist = None
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+        if kind == "single":
+            n_per = bytes_per_gpu // synth.RECORD_BYTES
+            blk_bytes = [n_per * synth.RECORD_BYTES] * world
+            starts = None
+        else:
+            n_per = int(bytes_per_gpu // 379.3)
+            sizes = synth.wrapped_sizes(rank * n_per, n_per + 1, seed=43)
+            starts = np.zeros(n_per + 2, dtype=np.int64)
+            np.cumsum(sizes, out=starts[1:])
+            mine = int(starts[n_per])
+            if world > 1:
+                t = torch.tensor([mine], dtype=torch.int64, device=dev)
+                allt = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
+                self.dist.all_gather(allt, t)
+                blk_bytes = [int(x.item()) for x in allt]
+            else:
+                blk_bytes = [mine]
+        self.n_per = n_per
+        B = [0]
+        for b in blk_bytes:
+            B.append(B[-1] + b)
+        total = B[-1]
+        S = [0] + [(B[r] + edge_shift) // 16 * 16 for r in range(1, world)] + [total]
+        self.own_lo, self.own_hi = S[rank], S[rank + 1]
+        self.n_own_bytes = self.own_hi - self.own_lo
+        self.tail = TAIL_BYTES if rank > 0 else 0
+        self.head = HEAD_BYTES if rank < world - 1 else 0
+        self.block_start = B[rank]
+
+        # records [rank*n_per, (rank+1)*n_per (+1)) generated record-aligned, then the range is cut out
+        n_gen = n_per + (1 if rank < world - 1 else 0)
+        if kind == "single":
+            gen_bytes = n_gen * synth.RECORD_BYTES
+            tmp = torch.empty(gen_bytes + 64, dtype=torch.uint8, device=dev)
+            ctx.synth_single(tmp.data_ptr(), rank * n_per, n_gen, seed=42)
+        else:
+            gen_bytes = int(starts[n_gen])
+            tmp = torch.empty(gen_bytes + 64, dtype=torch.uint8, device=dev)
+            dstart = torch.from_numpy(starts[:n_gen + 1].copy()).to(dev)
+            torch.cuda.synchronize()
+            ctx.synth_wrapped(tmp.data_ptr(), dstart.data_ptr(), rank * n_per, n_gen, seed=43)
+            self.starts = starts
+        self.ext = torch.zeros(self.tail + self.n_own_bytes + self.head + 64, dtype=torch.uint8, device=dev)
+        a = self.own_lo - self.block_start
+        self.ext[self.tail:self.tail + self.n_own_bytes] = tmp[a:a + self.n_own_bytes]
+        del tmp
+        torch.cuda.synchronize()
+        self.ext_scanned_bytes = self.tail + self.n_own_bytes + self.head
+        min_rec = 322 if kind == "single" else 120
+        self.max_records = n_per + (self.tail + self.head) // min_rec + 64
+        self.scanner = ShardScanner(HipBackend(ctx), rank, world, self.dist, None, dev)
+
+    def scan(self, table, flags=0, qual=None, qoff=None):
+        if self.world > 1:
+            exchange_edges(self.dist, self.ext, self.tail, self.n_own_bytes, self.head, self.rank, self.world)
+            import torch
+            torch.cuda.synchronize()
+        return self.scanner.scan(self.ext, self.tail, self.n_own_bytes, self.head, self.own_lo, self.own_hi,
+                                 table, flags, qual, qoff)
+
+    def host_sample(self, nbytes):
+        """First whole records of this rank's range, on the host."""
+        import torch
+        skip = 0
+        if self.rank > 0:
+            skip = 322 - (self.own_lo - self.block_start)   # only used on rank 0 in practice
+        n = min(nbytes, self.n_own_bytes - skip)
+        if self.kind == "single":
+            n = n // 322 * 322
+        else:
+            k = int(np.searchsorted(self.starts, n, side="right")) - 1
+            n = int(self.starts[k])
+        return self.ext[self.tail + skip:self.tail + skip + n].cpu().numpy()
+
+    def verify(self, table, out):
+        """Size-independent parity properties on the full-size output: the rows
+        must equal the closed form of the generator (which the parity tests
+        prove equal to the oracle / reference on the same bytes)."""
+        import torch
+        rows = table[out.row_lo:out.row_hi]
+        n = rows.shape[0]
+        # ownership is by '@' position: the first owned record is the first whose start >= own_lo
+        if self.kind == "single":
+            k0 = -(-self.own_lo // 322)
+            k = torch.arange(k0, k0 + n, dtype=torch.int64, device=rows.device) * 322
+            want = torch.stack([k, k + 17, k + 18, k + 168, k + 171, k + 321], dim=1)
+            assert n == -(-self.own_hi // 322) - k0, "record count differs from the closed form"
+            assert bool((rows == want).all()), "offset table differs from the closed form"
+        else:
+            st = torch.from_numpy(self.starts).to(rows.device) + self.block_start
+            k0 = int(np.searchsorted(self.starts + self.block_start, self.own_lo, side="left"))
+            k1 = int(np.searchsorted(self.starts + self.block_start, self.own_hi, side="left"))
+            if self.rank == self.world - 1:
+                k1 = self.n_per
+            assert n == k1 - k0, "record count differs from the generator's"
+            assert bool((rows[:, 0] == st[k0:k1]).all()), "record starts differ from the generator's"
+            assert bool((rows[:, 1] == st[k0:k1] + 17).all())
+            assert bool((rows[:, 5] == st[k0 + 1:k1 + 1] - 1).all()), "record ends differ"
+            assert bool((rows[:, 5] - rows[:, 4] == rows[:, 3] - rows[:, 2]).all())

@@ -155,6 +155,12 @@ int ffq_arrayadd_b(ffq_ctx *ctx, int8_t *h_a, int64_t n, int value);
 int ffq_arrayadd_q_device(ffq_ctx *ctx, int64_t *d_a, int64_t n, int64_t value);
 int ffq_arrayadd_q(ffq_ctx *ctx, int64_t *h_a, int64_t n, int64_t value);
 
+/* First row i of a device offset table (rows sorted by record) with
+ * d_table[i][col] >= value; n_rows if none.  Used to cut a shard's rows out of
+ * a table that also covers its halo (multi-GPU byte-range sharding).        */
+int ffq_table_lower_bound(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int col,
+                          int64_t value, int64_t *idx);
+
 /* ---- synthetic FASTQ generators (bench / test inputs) -----
  * Counter-based (splitmix64), so the numpy generator in
  * fastq-and-furious_amd/synth.py produces the same bytes.
