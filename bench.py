@@ -55,7 +55,7 @@ def cpu_baseline(sample_u8, budget_s=10.0):
         L.ffq_oracle_scan(sample_u8.ctypes.data, n, 1, 0, 1, 0, -1, table.ctypes.data, cap, out.ctypes.data)
         reps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 200:
+        if el >= budget_s or reps >= 100000:
             break
     recs = int(out[0])
     return {
