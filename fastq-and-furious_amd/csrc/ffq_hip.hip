@@ -48,8 +48,8 @@ struct ffq_ctx {
     uint16_t *pool = nullptr;
     unsigned long long pool_cap = 0;
     int64_t cap_groups = 0;
-    GroupSum *sums = nullptr;
-    int64_t *ystart = nullptr, *rbase = nullptr, *qbase = nullptr;
+    ChainBufs cb = {};
+    int64_t stage_cap = 0;        // StageRec entries allocated
     Ctl *ctl = nullptr;
     DevRes *dres = nullptr;
     // pinned mirrors
@@ -110,13 +110,23 @@ extern "C" int ffq_ctx_create(int device, ffq_ctx **out)
     return FFQ_OK;
 }
 
+static void free_chain(ffq_ctx *c)
+{
+    (void)hipFree(c->cb.y); (void)hipFree(c->cb.exit); (void)hipFree(c->cb.cnt); (void)hipFree(c->cb.flags);
+    (void)hipFree(c->cb.lines); (void)hipFree(c->cb.qb); (void)hipFree(c->cb.term); (void)hipFree(c->cb.stage);
+    (void)hipFree(c->cb.rloc); (void)hipFree(c->cb.qloc); (void)hipFree(c->cb.part); (void)hipFree(c->cb.mins);
+    c->cb = ChainBufs{};
+    c->stage_cap = 0;
+    c->cap_groups = 0;
+}
+
 extern "C" void ffq_ctx_destroy(ffq_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
-    (void)hipFree(c->sums); (void)hipFree(c->ystart); (void)hipFree(c->rbase); (void)hipFree(c->qbase);
+    free_chain(c);
     (void)hipFree(c->ctl); (void)hipFree(c->dres);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -131,27 +141,49 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
 extern "C" void *ffq_ctx_stream(ffq_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 static int64_t tiles_for(int64_t n) { return (n + TILE - 1) >> TILE_SHIFT; }
-static int64_t groups_for(int64_t ntiles) { return (ntiles + OWN - 1) / OWN; }
+static int64_t groups_for(int64_t ntiles) { return (ntiles + OWN_T - 1) / OWN_T; }
+constexpr int NMAX_FAST = 256, EMAX_FAST = 2048;      // k_chain_wave, usual line/record density
+constexpr int NMAX_DENSE = 1024, EMAX_DENSE = NTW * SLOT + 8;   // short records / short lines
 
 static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
 {
     if (ntiles <= c->cap_tiles) return FFQ_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf);
-    (void)hipFree(c->sums); (void)hipFree(c->ystart); (void)hipFree(c->rbase); (void)hipFree(c->qbase);
-    c->ent = nullptr; c->cnt = nullptr; c->ovf = nullptr; c->sums = nullptr;
-    c->ystart = c->rbase = c->qbase = nullptr;
-    c->cap_tiles = 0; c->cap_groups = 0;
+    c->ent = nullptr; c->cnt = nullptr; c->ovf = nullptr;
+    free_chain(c);
+    c->cap_tiles = 0;
     const int64_t ng = groups_for(ntiles);
+    const int64_t nblk = (ng + RES_BLOCK - 1) / RES_BLOCK;
     HIPCHK(hipMalloc((void **)&c->ent, (size_t)ntiles * SLOT * sizeof(uint16_t)));
     HIPCHK(hipMalloc((void **)&c->cnt, (size_t)ntiles * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&c->ovf, (size_t)ntiles * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void **)&c->sums, (size_t)ng * sizeof(GroupSum)));
-    HIPCHK(hipMalloc((void **)&c->ystart, (size_t)ng * sizeof(int64_t)));
-    HIPCHK(hipMalloc((void **)&c->rbase, (size_t)ng * sizeof(int64_t)));
-    HIPCHK(hipMalloc((void **)&c->qbase, (size_t)ng * sizeof(int64_t)));
+    HIPCHK(hipMalloc((void **)&c->cb.y, (size_t)ng * 8));
+    HIPCHK(hipMalloc((void **)&c->cb.exit, (size_t)ng * 8));
+    HIPCHK(hipMalloc((void **)&c->cb.cnt, (size_t)ng * 4));
+    HIPCHK(hipMalloc((void **)&c->cb.flags, (size_t)ng * 4));
+    HIPCHK(hipMalloc((void **)&c->cb.lines, (size_t)ng * 4));
+    HIPCHK(hipMalloc((void **)&c->cb.qb, (size_t)ng * 8));
+    HIPCHK(hipMalloc((void **)&c->cb.term, (size_t)ng * sizeof(GroupTerm)));
+    HIPCHK(hipMalloc((void **)&c->cb.rloc, (size_t)ng * 8));
+    HIPCHK(hipMalloc((void **)&c->cb.qloc, (size_t)ng * 8));
+    HIPCHK(hipMalloc((void **)&c->cb.part, (size_t)nblk * 4 * 8));
+    HIPCHK(hipMalloc((void **)&c->cb.mins, 16));
     c->cap_tiles = ntiles;
     c->cap_groups = ng;
+    return FFQ_OK;
+}
+
+static int reserve_stage(ffq_ctx *c, int64_t ng, int nmax)
+{
+    const int64_t need = ng * nmax;
+    if (need <= c->stage_cap) return FFQ_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->cb.stage);
+    c->cb.stage = nullptr; c->stage_cap = 0;
+    hipError_t e = hipMalloc((void **)&c->cb.stage, (size_t)need * sizeof(StageRec));
+    if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(stage) failed: %s", hipGetErrorString(e));
+    c->stage_cap = need;
     return FFQ_OK;
 }
 
@@ -170,7 +202,10 @@ extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
 {
     if (!c || max_bytes < 0) return fail(FFQ_E_ARG, "ffq_ctx_reserve: bad argument");
     HIPCHK(hipSetDevice(c->device));
-    int rc = reserve_tiles(c, std::max<int64_t>(tiles_for(max_bytes), 1));
+    const int64_t nt = std::max<int64_t>(tiles_for(max_bytes), 1);
+    int rc = reserve_tiles(c, nt);
+    if (rc) return rc;
+    rc = reserve_stage(c, groups_for(nt), NMAX_FAST);
     if (rc) return rc;
     return reserve_pool(c, 1ull << 20);
 }
@@ -284,6 +319,7 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
     int64_t *qoff = decode ? d_qoff : nullptr;
 
     int retries = 0;
+    bool dense_cfg = false;
     for (;;) {
         LineIndex L;
         L.d = d_buf; L.n = n_bytes; L.s = s; L.ntiles = (int32_t)ntiles;
@@ -296,15 +332,23 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
         HIPCHK(hipEventRecord(c->ev[1], c->stream));
         const bool serial = (flags & FFQ_F_FORCE_SERIAL) != 0;
         if (!serial) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3(ngroups), dim3(256), 0, c->stream, L,
-                               offset, eof, add, c->sums, (const int64_t *)nullptr, (const int64_t *)nullptr,
-                               (const int64_t *)nullptr, (const DevRes *)nullptr, (int64_t *)nullptr,
-                               (int64_t)0, (int64_t *)nullptr, c->ctl);
-            hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, c->stream, c->sums, ngroups, eof, offset,
-                               add, c->ystart, c->rbase, c->qbase, c->dres);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true>), dim3(ngroups), dim3(256), 0, c->stream, L,
-                               offset, eof, add, c->sums, c->ystart, c->rbase, c->qbase, c->dres, d_table,
-                               table_cap, qoff, c->ctl);
+            const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
+            rc = reserve_stage(c, ngroups, dense_cfg ? NMAX_DENSE : NMAX_FAST);
+            if (rc) return rc;
+            ChainBufs cb = c->cb;
+            cb.ng = ngroups;
+            cb.nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
+            HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, c->stream));
+            if (!dense_cfg)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<NMAX_FAST, EMAX_FAST>), dim3(ngroups), dim3(64), 0,
+                                   c->stream, L, offset, eof, cb);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<NMAX_DENSE, EMAX_DENSE>), dim3(ngroups), dim3(64),
+                                   0, c->stream, L, offset, eof, cb);
+            hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, c->stream, cb);
+            hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, c->stream, cb, nblk, eof, offset, add, c->dres);
+            hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, c->stream, cb, (const DevRes *)c->dres, add,
+                               d_table, table_cap, qoff);
             hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->dres, d_table, table_cap, add,
                                offset, qoff);
         }
@@ -335,6 +379,12 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total = ms;
 
         int path = 0;
+        if (!serial && c->h_res->fallback && !dense_cfg) {
+            // second tier: the same kernels with the LDS budget for short lines / short records
+            dense_cfg = true;
+            continue;
+        }
+        if (dense_cfg) path = 2;
         if (serial || c->h_res->fallback) {
             path = 1;
             HIPCHK(hipEventRecord(c->ev[4], c->stream));

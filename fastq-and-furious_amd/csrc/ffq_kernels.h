@@ -141,581 +141,11 @@ __global__ __launch_bounds__(256) void k_scan_lines(const uint8_t *__restrict__ 
     }
 }
 
-// =========================================================================
-// Chain kernels.
-// A "group" is OWN consecutive tiles.  The workgroup of group g loads the
-// line index of a window = RUNIN tiles before + OWN tiles + AHEAD tiles after
-// into LDS, computes one scanner call per "\n@" candidate of the run-in and
-// own regions (thread per candidate), and follows the successor links
-// (offset = pos5-1 -> next "\n@", fastqandfurious.py:254) by pointer doubling.
-//
-// Speculation: the chain's entry into the own region (Y) is guessed as the
-// exit of the chain that starts at the earliest run-in candidate (a chain
-// started at a false '@' candidate, e.g. a quality line beginning with '@',
-// re-synchronises with the true chain within a few records).
-// k_resolve checks yguess[g+1] == exit[g] for every group up to the chain's
-// end, which proves all guesses by induction from group 0 (whose Y is exact).
-// Any mismatch -> the serial walker redoes the buffer (still on the GPU).
-// =========================================================================
-constexpr int RUNIN = 1, OWN = 4, AHEAD = 1;
-constexpr int NT = RUNIN + OWN + AHEAD;
-constexpr int E_MAX = NT * SLOT + 16;      // window entries (+ sentinel)
-constexpr int C_MAX = 1024;                // candidates in run-in + own
-constexpr uint32_t W_POS = 0x3FFFFu;       // 18 bits: window-relative position
-constexpr int W_NODE_SHIFT = 18;           // 10 bits: node id of a candidate entry
-constexpr uint32_t W_NODE_MASK = 0x3FFu;
-constexpr uint32_t NO_NODE = 0x3FFu;       // candidate without a node id
-constexpr uint16_t NX_OUT = 0xFFFF, NX_NOCAND = 0xFFFE, NX_STOP = 0xFFFD;
-constexpr uint16_t NM_EXT = 0xFFFF;
-constexpr uint16_t UNMARKED = 0xFFFF;
+}  // namespace ffq
 
-constexpr int64_t Y_NOCAND = -1, X_END_TERM = -2, Y_UNRES = -3, X_END_FINAL = -4;
+#include "ffq_chain.h"
 
-struct GroupSum {
-    int64_t yguess;       // >=0: buffer coordinate of the '\n' of the entry candidate
-    int64_t exit;         // >=0: first chain candidate past the own region; X_*/Y_NOCAND
-    int64_t qbytes;
-    uint32_t count;
-    uint32_t lines;
-    int32_t flags;        // bit0: irregular (window does not fit the LDS budget)
-    int32_t term_status;
-    int64_t term_pos[6];
-};
-
-struct DevRes {
-    int64_t n_records, n_qual_bytes, n_lines, end_offset;
-    int64_t last_pos[6];
-    int32_t last_status, end_state, fallback, term_group;
-    int32_t has_final, pad;
-};
-
-// window accessor: flat LDS index while inside the window, global beyond
-struct WH {
-    int32_t idx;     // >= 0: window entry; -1: use g; -2: before the window's first entry
-    H g;
-};
-struct WAcc {
-    typedef WH Hd;
-    const LineIndex &L;
-    const uint32_t *went;
-    int32_t nwin;
-    int32_t wt1;          // first tile after the window
-    int64_t wpos0;        // buffer coordinate of window-relative position 0
-    __device__ WAcc(const LineIndex &l, const uint32_t *we, int32_t nw, int32_t t1, int64_t p0)
-        : L(l), went(we), nwin(nw), wt1(t1), wpos0(p0) {}
-    __device__ bool next(Hd &h) const {
-        if (h.idx != -1) {
-            const int32_t j = (h.idx == -2) ? 0 : h.idx + 1;
-            if (j < nwin) { h.idx = j; return true; }
-            h.idx = -1;
-            h.g = H{wt1 - 1, 0x7FFFFFF0};     // "after the last entry of tile wt1-1"
-            if (wt1 <= 0) h.g = H{-1, 0x7FFFFFF0};
-        }
-        // global continuation: entries of tiles >= h.g.tile+1, or further in h.g.tile
-        if (h.g.tile >= 0 && h.g.i != 0x7FFFFFF0 && h.g.i + 1 < (int32_t)L.cnt[h.g.tile]) {
-            h.g.i++;
-            return true;
-        }
-        int32_t t = h.g.tile + 1;
-        if (t < 0) t = 0;
-        while (t < L.ntiles && L.cnt[t] == 0) t++;
-        if (t >= L.ntiles) return false;
-        h.g.tile = t; h.g.i = 0;
-        return true;
-    }
-    __device__ void get(const Hd &h, int64_t &P, int &fl) const {
-        if (h.idx >= 0) {
-            const uint32_t e = went[h.idx];
-            P = wpos0 + (int64_t)(e & W_POS);
-            fl = (int)(e >> 30);
-            return;
-        }
-        GAcc(L).get(h.g, P, fl);
-    }
-};
-
-template <bool EMIT>
-__global__ __launch_bounds__(256) void k_chain(LineIndex L, int64_t offset, int eof, int64_t add,
-                                               GroupSum *__restrict__ sums,
-                                               const int64_t *__restrict__ ystart,
-                                               const int64_t *__restrict__ rbase,
-                                               const int64_t *__restrict__ qbase,
-                                               const DevRes *__restrict__ dres,
-                                               int64_t *__restrict__ table, int64_t table_cap,
-                                               int64_t *__restrict__ qoff, Ctl *ctl)
-{
-    __shared__ uint32_t went[E_MAX];
-    __shared__ uint16_t cidx[C_MAX];     // node -> window entry index
-    __shared__ uint16_t nm[C_MAX];       // node -> window index of its "\n+" entry (NM_EXT: recompute)
-    __shared__ uint16_t nxtE[C_MAX];     // node -> window entry index of the successor candidate
-    __shared__ uint16_t S[C_MAX];        // pointer doubling: node reached
-    __shared__ uint16_t cn[C_MAX];       //                   steps taken
-    __shared__ uint32_t Q[C_MAX];        //                   quality bytes of the nodes stepped over
-    __shared__ uint32_t qlen[C_MAX];
-    __shared__ int8_t nstat[C_MAX];
-    __shared__ uint16_t dist[EMIT ? C_MAX : 1];   // EMIT: rank of a chain member (UNMARKED otherwise)
-    __shared__ uint32_t qpre[EMIT ? C_MAX : 1];   // EMIT: quality bytes before the member
-    __shared__ int32_t s_tcnt[NT + 1];
-    __shared__ int32_t s_tbase[NT + 2];
-    __shared__ int32_t s_wc[4];
-    __shared__ int32_t s_misc[8];
-    __shared__ long long s_y;
-
-    const int g = blockIdx.x;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-
-    if (EMIT) {
-        if (dres->fallback) return;
-        if (ystart[g] < 0) return;        // chain does not reach this group
-    }
-
-    const int own0 = g * OWN;
-    const int own1 = min(own0 + OWN, L.ntiles);
-    const int wt0 = max(own0 - RUNIN, 0);
-    const int wt1 = min(own1 + AHEAD, L.ntiles);
-    const int nwt = wt1 - wt0;
-    const int sent = (wt0 == 0 && L.s) ? 1 : 0;
-    const int64_t wpos0 = (int64_t)wt0 << TILE_SHIFT;     // buffer coord of rel 0 (rel includes +s)
-    const int64_t len = L.len();
-
-    // ---- window directory ------------------------------------------------
-    if (tid < nwt) s_tcnt[tid] = (int32_t)L.cnt[wt0 + tid];
-    __syncthreads();
-    if (tid == 0) {
-        int32_t b = sent, irregular = 0, lines = 0;
-        for (int t = 0; t < nwt; t++) {
-            s_tbase[t] = b;
-            if (s_tcnt[t] > SLOT) irregular = 1;
-            b += s_tcnt[t];
-            if (wt0 + t >= own0 && wt0 + t < own1) lines += s_tcnt[t];
-        }
-        s_tbase[nwt] = b;
-        if (b > E_MAX) irregular = 1;
-        s_misc[0] = irregular;
-        s_misc[1] = lines;
-    }
-    __syncthreads();
-    const int nwin = s_tbase[nwt];
-    if (s_misc[0]) {
-        if (!EMIT) {
-            if (tid == 0) {
-                GroupSum &o = sums[g];
-                o.yguess = Y_UNRES; o.exit = Y_UNRES; o.qbytes = 0; o.count = 0;
-                o.lines = (uint32_t)s_misc[1]; o.flags = 1; o.term_status = 0;
-            }
-        } else if (tid == 0) atomicOr(&ctl->err, ERR_INTERNAL);
-        return;
-    }
-    // entry index boundaries of the own region
-    const int own_lo = (g == 0) ? 0 : s_tbase[own0 - wt0];
-    const int own_hi = s_tbase[own1 - wt0];
-    const int64_t own_hi_pos = ((int64_t)own1 << TILE_SHIFT) + L.s;   // buffer coord of first byte after own
-
-    // ---- load the window's entries ---------------------------------------
-    if (sent && tid == 0) {
-        const uint8_t b0 = L.n > 0 ? L.d[0] : 0;
-        const uint32_t fl = (b0 == '@') ? FL_AT : (b0 == '+') ? FL_PLUS : 0;
-        went[0] = 0u | (NO_NODE << W_NODE_SHIFT) | (fl << 30);
-    }
-    for (int t = 0; t < nwt; t++) {
-        const int c = s_tcnt[t];
-        const uint16_t *src = L.ent + (int64_t)(wt0 + t) * SLOT;
-        const uint32_t relb = (uint32_t)(t << TILE_SHIFT) + (uint32_t)L.s;
-        for (int i = tid; i < c; i += 256) {
-            const uint32_t e = src[i];
-            went[s_tbase[t] + i] = (relb + (e & OFF_MASK)) | (NO_NODE << W_NODE_SHIFT) | ((e >> 14) << 30);
-        }
-    }
-    __syncthreads();
-
-    // ---- compact the candidates of run-in + own into node ids -------------
-    // each wave takes a contiguous quarter of [0, own_hi), two passes
-    const int per = (own_hi + 3) >> 2;
-    const int q0 = min(w * per, own_hi), q1 = min(q0 + per, own_hi);
-    int wc = 0;
-    for (int j = q0 + l; j - l < q1; j += 64) {
-        bool isc = false;
-        if (j < q1) {
-            const uint32_t e = went[j];
-            isc = ((e >> 30) & FL_AT) && (wpos0 + (int64_t)(e & W_POS) >= offset);
-        }
-        wc += __popcll(__ballot(isc));
-    }
-    if (l == 0) s_wc[w] = wc;
-    __syncthreads();
-    int nbase = 0, ncomp = 0;
-    for (int q = 0; q < 4; q++) { if (q < w) nbase += s_wc[q]; ncomp += s_wc[q]; }
-    if (ncomp >= C_MAX) {      // node id C_MAX-1 == NO_NODE is reserved
-        if (!EMIT) {
-            if (tid == 0) {
-                GroupSum &o = sums[g];
-                o.yguess = Y_UNRES; o.exit = Y_UNRES; o.qbytes = 0; o.count = 0;
-                o.lines = (uint32_t)s_misc[1]; o.flags = 1; o.term_status = 0;
-            }
-        } else if (tid == 0) atomicOr(&ctl->err, ERR_INTERNAL);
-        return;
-    }
-    for (int j = q0 + l; j - l < q1; j += 64) {
-        bool isc = false;
-        uint32_t e = 0;
-        if (j < q1) {
-            e = went[j];
-            isc = ((e >> 30) & FL_AT) && (wpos0 + (int64_t)(e & W_POS) >= offset);
-        }
-        const unsigned long long bal = __ballot(isc);
-        if (isc) {
-            const int r = nbase + __popcll(bal & ((1ull << l) - 1ull));
-            cidx[r] = (uint16_t)j;
-            went[j] = (e & ~(W_NODE_MASK << W_NODE_SHIFT)) | ((uint32_t)r << W_NODE_SHIFT);
-        }
-        nbase += __popcll(bal);
-    }
-    __syncthreads();
-
-    // ---- one scanner call per node ----------------------------------------
-    const WAcc acc(L, went, nwin, wt1, wpos0);
-    for (int c = tid; c < ncomp; c += 256) {
-        const int k = cidx[c];
-        WH hk; hk.idx = k; hk.g = H{0, 0};
-        WH hm, hm1;
-        Rec r;
-        const int64_t Pk = wpos0 + (int64_t)(went[k] & W_POS);
-        compute_record(acc, hk, Pk, len, eof, r, hm, hm1);
-        nstat[c] = (int8_t)(r.final_ ? ST_FINAL : r.status);
-        const bool emits = (r.status == ST_COMPLETE) || r.final_;
-        qlen[c] = emits ? (uint32_t)(r.p5 - r.p4) : 0u;
-        nm[c] = (emits && hm.idx >= 0 && hm1.idx >= 0) ? (uint16_t)hm.idx : NM_EXT;
-        uint16_t nx = NX_STOP;
-        if (r.status == ST_COMPLETE) {
-            WH hs; int64_t Ps;
-            if (find_cand(acc, hm1, r.p5 - 1, hs, Ps)) nx = (hs.idx >= 0) ? (uint16_t)hs.idx : NX_OUT;
-            else nx = NX_NOCAND;
-        }
-        nxtE[c] = nx;
-    }
-    __syncthreads();
-
-    // ---- pointer doubling inside each region --------------------------------
-    for (int c = tid; c < ncomp; c += 256) {
-        const int reg = (cidx[c] < own_lo) ? 0 : 1;
-        const uint16_t nx = nxtE[c];
-        uint16_t s = (uint16_t)c;
-        if (nx < NX_STOP && nx < own_hi) {
-            const int nreg = ((int)nx < own_lo) ? 0 : 1;
-            const uint32_t nid = (went[nx] >> W_NODE_SHIFT) & W_NODE_MASK;
-            if (nreg == reg && nid != NO_NODE) s = (uint16_t)nid;
-        }
-        S[c] = s;
-        cn[c] = (s != c) ? 1 : 0;
-        Q[c] = (s != c) ? qlen[c] : 0u;
-        if (EMIT) { dist[c] = UNMARKED; qpre[c] = 0; }
-    }
-    __syncthreads();
-
-    // ---- pointer doubling (summary pass): S = last node of the chain inside its region
-    int rounds = 1;
-    while ((1 << rounds) < ncomp) rounds++;
-    if (!EMIT) {
-        for (int k = 0; k < rounds; k++) {
-            uint16_t s1[C_MAX / 256], s2[C_MAX / 256], c1[C_MAX / 256], c2[C_MAX / 256];
-            uint32_t g1[C_MAX / 256], g2[C_MAX / 256];
-#pragma unroll
-            for (int u = 0; u < C_MAX / 256; u++) {
-                const int c = tid + u * 256;
-                if (c < ncomp) {
-                    s1[u] = S[c]; c1[u] = cn[c]; g1[u] = Q[c];
-                    s2[u] = S[s1[u]]; c2[u] = cn[s1[u]]; g2[u] = Q[s1[u]];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < C_MAX / 256; u++) {
-                const int c = tid + u * 256;
-                if (c < ncomp) {
-                    S[c] = s2[u];
-                    cn[c] = (uint16_t)(c1[u] + c2[u]);
-                    Q[c] = g1[u] + g2[u];
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- the chain's entry candidate Y --------------------------------------
-    // EMIT: given (verified by k_resolve).  Group 0: exact, the first "\n@" at >= offset.
-    // Otherwise guessed: the exit of the chain that starts at the EARLIEST run-in
-    // candidate -- it had the whole run-in region to re-synchronise with the true
-    // chain.  With no usable run-in chain: the first candidate at/after the own region.
-    if (tid == 0) {
-        long long y = Y_UNRES;
-        if (EMIT) y = ystart[g];
-        else if (g == 0) {
-            WH hb; hb.idx = -2; hb.g = H{0, 0};
-            WH hs; int64_t Ps;
-            y = find_cand(acc, hb, offset, hs, Ps) ? Ps : Y_NOCAND;
-        } else {
-            bool got = false;
-            for (int c = 0; c < ncomp && c < 8 && cidx[c] < own_lo && !got; c++) {
-                const int last = S[c];
-                if (nstat[last] != ST_COMPLETE) continue;      // this chain dies inside the run-in
-                const uint16_t nx = nxtE[last];
-                if (nx == NX_NOCAND) y = Y_NOCAND;
-                else if (nx != NX_OUT) y = wpos0 + (long long)(went[nx] & W_POS);
-                else {   // successor beyond the window: recompute through the global index
-                    const int k = cidx[last];
-                    WH hk; hk.idx = k; hk.g = H{0, 0};
-                    WH hm, hm1, hs; Rec r; int64_t Ps;
-                    compute_record(acc, hk, wpos0 + (int64_t)(went[k] & W_POS), len, eof, r, hm, hm1);
-                    y = find_cand(acc, hm1, r.p5 - 1, hs, Ps) ? Ps : Y_NOCAND;
-                }
-                got = true;
-            }
-            if (!got) {
-                WH hb; hb.g = H{0, 0};
-                hb.idx = (own_lo > 0) ? own_lo - 1 : -2;
-                WH hs; int64_t Ps;
-                const int64_t own_lo_pos = ((int64_t)own0 << TILE_SHIFT) + L.s;
-                y = find_cand(acc, hb, max(offset, own_lo_pos), hs, Ps) ? Ps : Y_NOCAND;
-            }
-        }
-        s_y = y;
-    }
-    __syncthreads();
-    const int64_t Y = s_y;
-
-    // locate Y's node (thread 0), decide what this group does
-    if (tid == 0) {
-        int32_t ynode = -1, kind;      // kind: 0 walk from ynode, 1 skip, 2 chain over, 3 unresolved
-        if (Y == Y_UNRES) kind = 3;
-        else if (Y < 0) kind = 2;
-        else if (Y >= own_hi_pos) kind = 1;
-        else {
-            const int64_t rel = Y - wpos0;
-            int lo = 0, hi = ncomp;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((int64_t)(went[cidx[mid]] & W_POS) < rel) lo = mid + 1; else hi = mid;
-            }
-            if (lo < ncomp && (int64_t)(went[cidx[lo]] & W_POS) == rel && cidx[lo] >= own_lo) {
-                ynode = lo; kind = 0;
-            } else kind = 3;
-        }
-        s_misc[2] = ynode;
-        s_misc[3] = kind;
-        if (EMIT && kind == 0) { dist[ynode] = 0; qpre[ynode] = 0; }
-    }
-    __syncthreads();
-    const int ynode = s_misc[2], kind = s_misc[3];
-    if (EMIT && kind != 0) {
-        if (kind == 3 && tid == 0) atomicOr(&ctl->err, ERR_INTERNAL);
-        return;
-    }
-
-    // ---- emit pass: doubling rounds with bottom-up marking from Y ------------
-    // before round k the marked set is every chain node at distance < 2^k from Y;
-    // a marked node whose 2^k-step jump is exact marks its target (distance + 2^k).
-    if (EMIT) {
-        for (int k = 0; k < rounds; k++) {
-            uint16_t s1[C_MAX / 256], s2[C_MAX / 256], c1[C_MAX / 256], c2[C_MAX / 256];
-            uint32_t g1[C_MAX / 256], g2[C_MAX / 256];
-            bool mk[C_MAX / 256];
-            uint16_t dd[C_MAX / 256];
-            uint32_t qq[C_MAX / 256];
-#pragma unroll
-            for (int u = 0; u < C_MAX / 256; u++) {
-                const int c = tid + u * 256;
-                mk[u] = false;
-                if (c < ncomp) {
-                    s1[u] = S[c]; c1[u] = cn[c]; g1[u] = Q[c];
-                    s2[u] = S[s1[u]]; c2[u] = cn[s1[u]]; g2[u] = Q[s1[u]];
-                    dd[u] = dist[c]; qq[u] = qpre[c];
-                    mk[u] = (dd[u] != UNMARKED) && (c1[u] == (uint16_t)(1u << k));
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < C_MAX / 256; u++) {
-                const int c = tid + u * 256;
-                if (c < ncomp) {
-                    if (mk[u]) {
-                        dist[s1[u]] = (uint16_t)(dd[u] + (1u << k));
-                        qpre[s1[u]] = qq[u] + g1[u];
-                    }
-                    S[c] = s2[u];
-                    cn[c] = (uint16_t)(c1[u] + c2[u]);
-                    Q[c] = g1[u] + g2[u];
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    if (!EMIT) {
-        // ---- summary -------------------------------------------------------
-        if (tid == 0) {
-            GroupSum &o = sums[g];
-            o.yguess = Y; o.flags = 0; o.lines = (uint32_t)s_misc[1];
-            o.count = 0; o.qbytes = 0; o.term_status = 0;
-            for (int i = 0; i < 6; i++) o.term_pos[i] = -1;
-            if (kind == 3) { o.yguess = Y_UNRES; o.exit = Y_UNRES; }
-            else if (kind == 2) { o.exit = Y_NOCAND; o.term_status = ST_HEAD_BEG; }
-            else if (kind == 1) { o.exit = Y; }
-            else {
-                const int last = S[ynode];
-                const int st = nstat[last];
-                const bool emits = (st == ST_COMPLETE) || (st == ST_FINAL);
-                o.count = (uint32_t)cn[ynode] + (emits ? 1u : 0u);
-                o.qbytes = (int64_t)Q[ynode] + (emits ? (int64_t)qlen[last] : 0);
-                if (st == ST_COMPLETE) {
-                    const uint16_t nx = nxtE[last];
-                    if (nx == NX_NOCAND) { o.exit = Y_NOCAND; o.term_status = ST_HEAD_BEG; }
-                    else if (nx != NX_OUT) o.exit = wpos0 + (int64_t)(went[nx] & W_POS);
-                    else {
-                        const int k = cidx[last];
-                        WH hk; hk.idx = k; hk.g = H{0, 0};
-                        WH hm, hm1, hs; Rec r; int64_t Ps;
-                        compute_record(acc, hk, wpos0 + (int64_t)(went[k] & W_POS), len, eof, r, hm, hm1);
-                        if (find_cand(acc, hm1, r.p5 - 1, hs, Ps)) o.exit = Ps;
-                        else { o.exit = Y_NOCAND; o.term_status = ST_HEAD_BEG; }
-                    }
-                } else {
-                    // the chain stops at `last`: report the scanner's posbuffer for that call
-                    const int k = cidx[last];
-                    WH hk; hk.idx = k; hk.g = H{0, 0};
-                    WH hm, hm1; Rec r;
-                    compute_record(acc, hk, wpos0 + (int64_t)(went[k] & W_POS), len, eof, r, hm, hm1);
-                    o.exit = (st == ST_FINAL) ? X_END_FINAL : X_END_TERM;
-                    o.term_status = r.status;
-                    o.term_pos[0] = r.p0; o.term_pos[1] = r.p1;
-                    o.term_pos[2] = (r.p1 >= 0) ? r.p1 + 1 : -1;
-                    o.term_pos[3] = r.p3; o.term_pos[4] = r.p4; o.term_pos[5] = r.p5;
-                }
-            }
-        }
-        return;
-    } else {
-        // ---- emission: every marked node is a record of the chain ------------
-        const int64_t r0 = rbase[g], qb0 = qbase[g];
-        for (int c = tid; c < ncomp; c += 256) {
-            const uint16_t dc = dist[c];
-            if (dc == UNMARKED) continue;
-            const int st = nstat[c];
-            if (st != ST_COMPLETE && st != ST_FINAL) continue;
-            const int64_t row = r0 + dc;
-            if (qoff) {
-                if (row < table_cap) qoff[row] = qb0 + qpre[c];
-            }
-            if (row >= table_cap) continue;
-            int64_t p0, p1, p3, p4, p5;
-            const uint16_t mi = nm[c];
-            const int k = cidx[c];
-            if (mi != NM_EXT) {
-                p0 = wpos0 + (int64_t)(went[k] & W_POS) + 1;
-                p1 = wpos0 + (int64_t)(went[k + 1] & W_POS);
-                p3 = wpos0 + (int64_t)(went[mi] & W_POS);
-                p4 = wpos0 + (int64_t)(went[mi + 1] & W_POS) + 1;
-                p5 = p4 + p3 - p1 - 1;
-            } else {
-                WH hk; hk.idx = k; hk.g = H{0, 0};
-                WH hm, hm1; Rec r;
-                compute_record(acc, hk, wpos0 + (int64_t)(went[k] & W_POS), len, eof, r, hm, hm1);
-                p0 = r.p0; p1 = r.p1; p3 = r.p3; p4 = r.p4; p5 = r.p5;
-            }
-            int64_t *o = table + row * 6;
-            // rows are 48 bytes and 16-byte aligned: three 16-byte stores
-            longlong2 *o2 = reinterpret_cast<longlong2 *>(o);
-            o2[0] = make_longlong2(p0 + add, p1 + add);
-            o2[1] = make_longlong2(p1 + 1 + add, p3 + add);
-            o2[2] = make_longlong2(p4 + add, p5 + add);
-        }
-    }
-}
-
-// =========================================================================
-// k_resolve: one workgroup.  Verifies the per-group guesses, finds the group
-// the chain ends in, exclusive-scans record counts / quality bytes, and fills
-// the result block (end state per fastqandfurious.py:256-279).
-// =========================================================================
-__global__ __launch_bounds__(1024) void k_resolve(const GroupSum *__restrict__ sums, int ngroups,
-                                                  int eof, int64_t offset, int64_t add,
-                                                  int64_t *__restrict__ ystart,
-                                                  int64_t *__restrict__ rbase,
-                                                  int64_t *__restrict__ qbase, DevRes *res)
-{
-    __shared__ int s_term, s_bad;
-    __shared__ long long s_part[1024], s_partq[1024];
-    __shared__ unsigned long long s_lines;
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_term = 0x7FFFFFFF; s_bad = 0x7FFFFFFF; s_lines = 0; }
-    __syncthreads();
-    int lt = 0x7FFFFFFF, lb = 0x7FFFFFFF;
-    unsigned long long ll = 0;
-    for (int t = tid; t < ngroups; t += 1024) {
-        const GroupSum &sg = sums[t];
-        ll += sg.lines;
-        const int64_t ex = sg.exit;
-        if (ex == Y_NOCAND || ex == X_END_TERM || ex == X_END_FINAL) lt = min(lt, t);
-        bool bad = (sg.flags & 1) || (sg.yguess == Y_UNRES);
-        if (t > 0) {
-            const int64_t pe = sums[t - 1].exit;
-            if (pe >= 0 && sg.yguess != pe) bad = true;
-        }
-        if (bad) lb = min(lb, t);
-    }
-    atomicMin(&s_term, lt);
-    atomicMin(&s_bad, lb);
-    atomicAdd(&s_lines, ll);
-    __syncthreads();
-    const int tterm = s_term, tbad = s_bad;
-    const bool fallback = (tterm == 0x7FFFFFFF) || (tbad <= tterm);
-
-    // exclusive scan of counts over groups 0..tterm
-    const int per = (ngroups + 1023) / 1024;
-    const int a0 = min(tid * per, ngroups), a1 = min(a0 + per, ngroups);
-    long long ps = 0, pq = 0;
-    for (int t = a0; t < a1; t++)
-        if (!fallback && t <= tterm) { ps += sums[t].count; pq += sums[t].qbytes; }
-    s_part[tid] = ps; s_partq[tid] = pq;
-    __syncthreads();
-    // Hillis-Steele over 1024 partials
-    for (int d = 1; d < 1024; d <<= 1) {
-        long long v = 0, vq = 0;
-        if (tid >= d) { v = s_part[tid - d]; vq = s_partq[tid - d]; }
-        __syncthreads();
-        s_part[tid] += v; s_partq[tid] += vq;
-        __syncthreads();
-    }
-    long long run = s_part[tid] - ps, runq = s_partq[tid] - pq;
-    for (int t = a0; t < a1; t++) {
-        const bool on = !fallback && t <= tterm;
-        ystart[t] = on ? sums[t].yguess : (int64_t)-1;
-        rbase[t] = run; qbase[t] = runq;
-        if (on) { run += sums[t].count; runq += sums[t].qbytes; }
-    }
-    if (tid == 1023) {
-        res->n_records = s_part[1023];
-        res->n_qual_bytes = s_partq[1023];
-    }
-    if (tid == 0) {
-        res->n_lines = (int64_t)s_lines;
-        res->fallback = fallback ? 1 : 0;
-        res->term_group = fallback ? -1 : tterm;
-        res->end_offset = offset;
-        res->has_final = 0;
-        if (!fallback) {
-            const GroupSum &tg = sums[tterm];
-            const int st = tg.term_status;
-            res->last_status = st;
-            for (int i = 0; i < 6; i++) res->last_pos[i] = (tg.term_pos[i] >= 0) ? tg.term_pos[i] + add : -1;
-            int end;
-            if (tg.exit == X_END_FINAL) { end = 0; res->has_final = 1; }
-            else if (tg.exit == Y_NOCAND) end = eof ? 0 : 1;
-            else if (eof) end = (st == ST_QUAL_END) ? 2 : (st == ST_INVALID) ? 4 : 3;
-            else end = (st == ST_INVALID) ? 4 : 1;
-            res->end_state = end;
-        }
-    }
-}
+namespace ffq {
 
 // =========================================================================
 // k_chain_serial: the whole chain by one lane over the global index.  Exact on

@@ -269,7 +269,7 @@ class SyntheticShard:
     def verify(self, table, out):
         """Size-independent parity properties on the full-size output: the rows
         must equal the closed form of the generator (which the parity tests
-        prove equal to the oracle / reference on the same bytes)."""
+        prove equal to the reference on the same bytes)."""
         import torch
         rows = table[out.row_lo:out.row_hi]
         n = rows.shape[0]
