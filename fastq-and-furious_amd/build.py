@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libffq_hip.so")
 SOURCES = ["ffq_hip.hip"]
-HEADERS = ["ffq_dev.h", "ffq_kernels.h", os.path.join("..", "..", "include", "ffq.h")]
+HEADERS = ["ffq_dev.h", "ffq_kernels.h", "ffq_chain.h", os.path.join("..", "..", "include", "ffq.h")]
 
 
 def _hipcc():
@@ -29,6 +29,7 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

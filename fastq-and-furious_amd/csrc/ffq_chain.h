@@ -34,13 +34,14 @@
 
 namespace ffq {
 
-constexpr int OWN_T = 2;                   // own tiles per group
+constexpr int OWN_T = 4;                   // own tiles per group
 constexpr int NTW = OWN_T + 2;             // + run-in tile + look-ahead tile
 constexpr int RUNIN_BYTES = 8192;          // tail of the previous tile used as run-in
-// LDS entry word: window-relative position (17 bits) | flags << 17 | node id << 19
-constexpr uint32_t WP_MASK = 0x1FFFFu;
-constexpr int WF_SHIFT = 17;
-constexpr int WN_SHIFT = 19;
+// LDS entry word: window-relative position (18 bits) | flags << 18 | node id << 20
+constexpr uint32_t WP_MASK = 0x3FFFFu;
+constexpr int WF_SHIFT = 18;
+constexpr int WN_SHIFT = 20;
+static_assert(NTW * TILE + 1 <= (int)WP_MASK, "window positions must fit WP_MASK");
 constexpr uint32_t WN_MASK = 0x3FFu;
 constexpr uint32_t NO_NODE = 0x3FFu;
 constexpr uint16_t NX_OUT = 0xFFFF, NX_NOCAND = 0xFFFE, NX_STOP = 0xFFFD;
@@ -72,6 +73,7 @@ struct ChainBufs {
     int64_t *qloc;       // [ng] same for qb
     int64_t *part;       // [nblk][4] block totals (cnt, qb, lines, -) -> exclusive prefixes
     int32_t *mins;       // [2] first terminating group, first bad group
+    unsigned long long *prof;   // optional: per-phase cycle sums of k_chain_wave (diagnostics)
     int32_t nmax;
     int32_t ng;
 };
@@ -95,8 +97,10 @@ struct WAcc {
     int32_t nwin;
     int32_t wt1;          // first tile after the window
     int64_t wpos0;        // buffer coordinate of window-relative position 0
-    __device__ WAcc(const LineIndex &l, const uint32_t *we, int32_t nw, int32_t t1, int64_t p0)
-        : L(l), went(we), nwin(nw), wt1(t1), wpos0(p0) {}
+    uint32_t *defer;      // group flag word: bit 2 is set when a lookup needs index tiles that
+                          // are not computed yet (the scan kernel runs chunk by chunk ahead of us)
+    __device__ WAcc(const LineIndex &l, const uint32_t *we, int32_t nw, int32_t t1, int64_t p0, uint32_t *df)
+        : L(l), went(we), nwin(nw), wt1(t1), wpos0(p0), defer(df) {}
     __device__ bool next(Hd &h) const {
         if (h.idx != -1) {
             const int32_t j = (h.idx == -2) ? 0 : h.idx + 1;
@@ -110,8 +114,11 @@ struct WAcc {
         }
         int32_t t = h.g.tile + 1;
         if (t < 0) t = 0;
-        while (t < L.ntiles && L.cnt[t] == 0) t++;
-        if (t >= L.ntiles) return false;
+        while (t < L.ready && L.cnt[t] == 0) t++;
+        if (t >= L.ready) {
+            if (L.ready < L.ntiles && defer) atomicOr(defer, 4u);
+            return false;
+        }
         h.g.tile = t; h.g.i = 0;
         return true;
     }
@@ -143,21 +150,156 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return (uint32_t)__shfl((int)wave_incl_scan(v), 63);
 }
 
-template <int NMAX, int EMAX>
-__global__ __launch_bounds__(64) void k_chain_wave(LineIndex L, int64_t offset, int eof, ChainBufs B)
+// wave-local ordering of LDS traffic (several independent waves share a workgroup)
+__device__ __forceinline__ void wave_sync()
 {
-    __shared__ uint32_t went[EMAX];
-    __shared__ uint32_t qlen[NMAX];
-    __shared__ uint16_t nidx[NMAX];      // node -> window entry index of its "\n@"
-    __shared__ uint16_t nm[NMAX];        // node -> window entry index of its "\n+" (NM_EXT: recompute)
-    __shared__ uint16_t nxtE[NMAX];      // node -> window entry index of the successor candidate / NX_*
-    __shared__ uint16_t S[NMAX];         // pointer doubling: node reached
-    __shared__ uint16_t cn[NMAX];        //                   steps taken
-    __shared__ uint16_t dist[NMAX];      // rank along the chain (UNMARKED: not on it)
-    __shared__ int8_t nstat[NMAX];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-    const int g = blockIdx.x;
-    const int lane = threadIdx.x;
+// successor codes of a node (values below are node ids)
+constexpr uint32_t SN_OUT = 0xFFFFu;      // successor candidate lies beyond the window
+constexpr uint32_t SN_NOCAND = 0xFFFEu;   // no further "\n@" in the buffer
+constexpr uint32_t SN_STOP = 0xFFFDu;     // the node's scanner call is not COMPLETE
+constexpr uint32_t SN_AHEAD = 0xFFFCu;    // in the window, past the own tiles (position in sx)
+constexpr int SEG_LIMIT = 128;
+
+// value a[node >> 6] held by lane (node & 63), for a wave-uniform node id:
+// v_readlane with scalar operands (a select over the slots would be turned into an
+// indexed load from scratch by the compiler)
+template <int PER>
+__device__ __forceinline__ uint32_t read_node(const uint32_t (&a)[PER], int node)
+{
+    const int u = __builtin_amdgcn_readfirstlane(node >> 6);
+    const int l = __builtin_amdgcn_readfirstlane(node & 63);
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (u == i) v = (uint32_t)__builtin_amdgcn_readlane((int)a[i], l);
+    return v;
+}
+
+// first set bit at or after node id c over the per-slot masks; PER*64 if none
+template <int PER>
+__device__ __forceinline__ int first_set_from(const unsigned long long (&m)[PER], int c)
+{
+    int r = PER * 64;
+#pragma unroll
+    for (int u = PER - 1; u >= 0; u--) {
+        unsigned long long x = m[u];
+        if (c > u * 64) x = (c >= u * 64 + 64) ? 0ull : (x >> (c - u * 64)) << (c - u * 64);
+        if (x) r = u * 64 + (__ffsll((long long)x) - 1);
+    }
+    return r;
+}
+
+// number of set bits strictly below node id c
+template <int PER>
+__device__ __forceinline__ int count_below(const unsigned long long (&m)[PER], int c)
+{
+    int n = 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        unsigned long long x = m[u];
+        if (c < u * 64 + 64) x = (c <= u * 64) ? 0ull : (x & ((1ull << (c - u * 64)) - 1ull));
+        n += __popcll(x);
+    }
+    return n;
+}
+
+// ---- the generic (entry by entry) scanner call of a window node, out of line --------------
+// The fast path of k_chain_wave covers records whose lines all lie within the next 12
+// index entries; everything else (long wrapped records, window / buffer edges, records
+// that continue beyond the window) goes through these two functions.  They are kept
+// out of line on purpose: inlined at every use they made the kernel ~100 KB of code.
+struct WinCtx {
+    const LineIndex *L;
+    const uint32_t *went;
+    uint32_t *defer;
+    int32_t nwin, wt1, own_hi, eof;
+    int64_t wpos0, len;
+};
+struct NodeOut {
+    uint32_t st, nxn, sx, f0, f1, f3, f4, ext;
+};
+
+__device__ __noinline__ void node_generic(const WinCtx *w, int k, NodeOut *o)
+{
+    const WAcc acc(*w->L, w->went, w->nwin, w->wt1, w->wpos0, w->defer);
+    WH hk; hk.idx = k; hk.g = H{0, 0};
+    WH hm, hm1;
+    Rec r;
+    compute_record(acc, hk, w->wpos0 + (int64_t)(w->went[k] & WP_MASK), w->len, w->eof, r, hm, hm1);
+    o->st = (uint32_t)(r.final_ ? ST_FINAL : r.status);
+    o->nxn = 0xFFFDu; o->sx = 0; o->f0 = o->f1 = o->f3 = o->f4 = 0; o->ext = 0;
+    if ((r.status == ST_COMPLETE) || r.final_) {
+        const int64_t q0 = r.p0 - w->wpos0, q1 = r.p1 - w->wpos0, q3 = r.p3 - w->wpos0, q4 = r.p4 - w->wpos0;
+        if (q4 > 0xFFFFFFF0ll) o->ext = 1;
+        o->f0 = (uint32_t)q0; o->f1 = (uint32_t)q1; o->f3 = (uint32_t)q3; o->f4 = (uint32_t)q4;
+    }
+    if (r.status == ST_COMPLETE) {
+        WH hs; int64_t Ps;
+        if (find_cand(acc, hm1, r.p5 - 1, hs, Ps)) {
+            if (hs.idx >= 0) {
+                const uint32_t wj = w->went[hs.idx];
+                const uint32_t nid = (wj >> WN_SHIFT) & WN_MASK;
+                if (hs.idx < w->own_hi && nid != NO_NODE) o->nxn = nid;
+                else { o->nxn = 0xFFFCu; o->sx = wj & WP_MASK; }
+            } else o->nxn = 0xFFFFu;
+        } else o->nxn = 0xFFFEu;
+    }
+}
+
+// the scanner call of node k again (all of it: posbuffer, status) and the candidate the
+// chain continues with after it (Y_NOCAND if none) -- used once per group at most
+__device__ __noinline__ void node_followup(const WinCtx *w, int k, Rec *r, int64_t *after)
+{
+    const WAcc acc(*w->L, w->went, w->nwin, w->wt1, w->wpos0, w->defer);
+    WH hk; hk.idx = k; hk.g = H{0, 0};
+    WH hm, hm1, hs;
+    int64_t Ps;
+    compute_record(acc, hk, w->wpos0 + (int64_t)(w->went[k] & WP_MASK), w->len, w->eof, *r, hm, hm1);
+    *after = Y_NOCAND;
+    if (r->status == ST_COMPLETE && find_cand(acc, hm1, r->p5 - 1, hs, Ps)) *after = Ps;
+}
+
+// first "\n@" match at >= X among the window/global entries after window index `from`
+__device__ __noinline__ int64_t cand_after(const WinCtx *w, int from, int64_t X)
+{
+    const WAcc acc(*w->L, w->went, w->nwin, w->wt1, w->wpos0, w->defer);
+    WH hb; hb.g = H{0, 0};
+    hb.idx = from;
+    WH hs; int64_t Ps;
+    return find_cand(acc, hb, X, hs, Ps) ? Ps : Y_NOCAND;
+}
+
+// PER: node slots per lane (NMAX = 64*PER nodes per group); EMAX: window entries;
+// WPB: waves (= groups) per workgroup; DOUBLING: keep the pointer-doubling fallback for
+// chains with more than SEG_LIMIT jumps (otherwise such a group is reported irregular
+// and the host re-runs the stage with the DOUBLING configuration).
+template <int PER, int EMAX, int WPB, bool DOUBLING>
+__global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, int64_t offset, int eof, ChainBufs B,
+                                                         int g0, int g1, int only_deferred, int ablate)
+{
+    constexpr int NMAX = PER * 64;
+    constexpr int ND = DOUBLING ? NMAX : 1;
+    __shared__ uint32_t went_all[WPB][EMAX];
+    __shared__ uint16_t nidx_all[WPB][NMAX];   // node -> window entry index of its "\n@"
+    __shared__ uint16_t nx16_all[WPB][NMAX];   // node -> successor node / SN_*
+    __shared__ uint32_t pk_all[WPB][NMAX];     // node -> run end | successor of the run end << 16
+    __shared__ uint32_t bits_all[WPB][2 * (NMAX / 32)];   // run start bits, run end bits
+    __shared__ uint16_t dS_all[WPB][ND];       // doubling fallback: node reached
+    __shared__ uint16_t dC_all[WPB][ND];       //                    steps taken
+    __shared__ uint16_t dD_all[WPB][ND];       //                    rank (UNMARKED: not on the chain)
+
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = g0 + blockIdx.x * WPB + wid;
+    if (g >= g1) return;                 // no workgroup barrier is used below
+    if (only_deferred && !(B.flags[g] & 4u)) return;   // second pass: only what the first one deferred
+    uint32_t *went = went_all[wid];
+    uint16_t *nidx = nidx_all[wid];
+
     const int own0 = g * OWN_T;
     const int own1 = min(own0 + OWN_T, L.ntiles);
     const bool has_runin = own0 > 0;
@@ -168,6 +310,9 @@ __global__ __launch_bounds__(64) void k_chain_wave(LineIndex L, int64_t offset, 
     const int64_t wpos0 = (int64_t)wt0 << TILE_SHIFT;
     const int64_t len = L.len();
 
+    const bool prof = B.prof != nullptr;
+    long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if (prof) ts[0] = clock64();
     // ---- window directory + first 256 entries of every tile, one memory round trip ----
     int tc[NTW];
     uint2 ev[NTW];
@@ -192,244 +337,431 @@ __global__ __launch_bounds__(64) void k_chain_wave(LineIndex L, int64_t offset, 
     if (irregular) {
         if (lane == 0) {
             B.y[g] = Y_UNRES; B.exit[g] = Y_UNRES; B.cnt[g] = 0; B.qb[g] = 0;
-            B.flags[g] = 1; B.lines[g] = lines;
+            B.flags[g] = 1; B.lines[g] = lines;      // (bit 2 cannot be pending: nothing was looked up)
         }
         return;
     }
-    if (sent && lane == 0) {
+    if (prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[1] = clock64(); }
+    // own tiles are window tiles [kown0, kown1); tile 0 is the run-in tile when has_runin
+    const int kown0 = has_runin ? 1 : 0, kown1 = own1 - wt0;
+    // a candidate must lie at buffer coordinate >= offset: as a window-relative bound
+    const int64_t offrel64 = offset - wpos0;
+    const uint32_t offrel = offrel64 <= 0 ? 0u : (offrel64 > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)offrel64);
+    int ncomp = 0, n_runin = 0;
+    if (sent) {
+        // the iterator's sentinel (fastqandfurious.py:245) is entry 0 of group 0
         const uint8_t b0 = L.n > 0 ? L.d[0] : 0;
         const uint32_t fl = (b0 == '@') ? FL_AT : (b0 == '+') ? FL_PLUS : 0;
-        went[0] = 0u | (fl << WF_SHIFT) | (NO_NODE << WN_SHIFT);
+        const bool isn = (fl & FL_AT) && offrel == 0;
+        if (lane == 0) {
+            went[0] = 0u | (fl << WF_SHIFT) | ((isn ? 0u : NO_NODE) << WN_SHIFT);
+            if (isn) nidx[0] = 0;
+        }
+        ncomp = isn ? 1 : 0;
     }
-    int below = 0;      // entries of the run-in tile in front of its last RUNIN_BYTES
+    // ---- window entries -> LDS; the "\n@" matches of the run-in tail and the own tiles
+    //      become nodes, numbered in entry order (wave prefix sum per tile) ---------------
+    int maxc = 0;
 #pragma unroll
     for (int k = 0; k < NTW; k++) {
-        const int c = tc[k];
+        // first 256 entries of tile k (already in registers), 4 per lane
+        const int c = min(tc[k], 256);
+        maxc = max(maxc, tc[k]);
         const uint32_t relb = (uint32_t)(k << TILE_SHIFT) + (uint32_t)L.s;
-        for (int j0 = 0; j0 < c; j0 += 256) {
-            uint2 v = ev[k];
-            if (j0 > 0) v = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)(wt0 + k) * SLOT + j0 + 4 * lane);
-            const uint32_t x[4] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
+        const uint32_t x[4] = {ev[k].x & 0xFFFFu, ev[k].x >> 16, ev[k].y & 0xFFFFu, ev[k].y >> 16};
+        const bool runin_tile = has_runin && k == 0;
+        const bool node_tile = runin_tile || (k >= kown0 && k < kown1);
+        uint32_t isn = 0;      // bit i: entry i of this lane becomes a node
+        if (node_tile) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int j = j0 + 4 * lane + i;
-                const bool ok = j < c;
-                if (ok) went[tb[k] + j] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | (NO_NODE << WN_SHIFT);
-                if (k == 0 && has_runin)
-                    below += __popcll(__ballot(ok && (x[i] & OFF_MASK) < (uint32_t)(TILE - RUNIN_BYTES)));
+                const uint32_t off = x[i] & OFF_MASK;
+                if (4 * lane + i < c && ((x[i] >> 14) & FL_AT) && relb + off >= offrel &&
+                    (!runin_tile || off >= (uint32_t)(TILE - RUNIN_BYTES)))
+                    isn |= 1u << i;
             }
         }
+        uint32_t id = 0;
+        if (node_tile) {
+            const uint32_t nc = __popc(isn);
+            const uint32_t incl = wave_incl_scan(nc);
+            id = (uint32_t)ncomp + incl - nc;
+            ncomp += (int)__shfl((int)incl, 63);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = 4 * lane + i;
+            if (j < c) {
+                uint32_t nid = NO_NODE;
+                if ((isn >> i) & 1u) {
+                    if (id < (uint32_t)(NMAX - 1)) { nid = id; nidx[id] = (uint16_t)(tb[k] + j); }
+                    id++;
+                }
+                went[tb[k] + j] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | (nid << WN_SHIFT);
+            }
+        }
+        if (runin_tile && tc[k] <= 256) n_runin = ncomp;
     }
-    const int lo_idx = has_runin ? tb[0] + below : 0;     // first entry that may become a node
-    const int own_lo = has_runin ? tb[1] : 0;             // entry index boundaries of the own tiles
-    int own_hi = 0;
+    if (maxc > 256) {
+        // tiles with more than 256 lines (average line under 64 bytes).  Node ids must
+        // follow entry order, so redo the numbering from the first such tile on.
+        ncomp = 0; n_runin = 0;
+        if (sent) ncomp = (((went[0] >> WN_SHIFT) & WN_MASK) != NO_NODE) ? 1 : 0;
+        for (int k = 0; k < nwt; k++) {
+            const int c = (int)L.cnt[wt0 + k];
+            int base = sent;
+            for (int q = 0; q < k; q++) base += (int)L.cnt[wt0 + q];
+            const uint32_t relb = (uint32_t)(k << TILE_SHIFT) + (uint32_t)L.s;
+            const bool runin_tile = has_runin && k == 0;
+            const bool node_tile = runin_tile || (k >= kown0 && k < kown1);
+            for (int j0 = 0; j0 < c; j0 += 256) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)(wt0 + k) * SLOT + j0 + 4 * lane);
+                const uint32_t x[4] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
+                uint32_t isn = 0;
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t off = x[i] & OFF_MASK;
+                    if (node_tile && j0 + 4 * lane + i < c && ((x[i] >> 14) & FL_AT) && relb + off >= offrel &&
+                        (!runin_tile || off >= (uint32_t)(TILE - RUNIN_BYTES)))
+                        isn |= 1u << i;
+                }
+                const uint32_t nc = __popc(isn);
+                const uint32_t incl = wave_incl_scan(nc);
+                uint32_t id = (uint32_t)ncomp + incl - nc;
+                ncomp += (int)__shfl((int)incl, 63);
+                for (int i = 0; i < 4; i++) {
+                    const int j = j0 + 4 * lane + i;
+                    if (j < c) {
+                        uint32_t nid = NO_NODE;
+                        if ((isn >> i) & 1u) {
+                            if (id < (uint32_t)(NMAX - 1)) { nid = id; nidx[id] = (uint16_t)(base + j); }
+                            id++;
+                        }
+                        went[base + j] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | (nid << WN_SHIFT);
+                    }
+                }
+            }
+            if (runin_tile) n_runin = ncomp;
+        }
+    }
+    if (ablate == 1) { if (lane == 0) B.lines[g] = lines + ncomp; return; }
+    int own_hi = 0;                                    // entry index just past the own tiles
 #pragma unroll
     for (int k = 0; k <= NTW; k++)
-        if (k == own1 - wt0) own_hi = tb[k];
-    __syncthreads();
-
-    // ---- nodes: the "\n@" matches of [lo_idx, own_hi) at >= offset ---------------------
-    int ncomp = 0;
-    for (int j0 = lo_idx; j0 < own_hi; j0 += 64) {
-        const int j = j0 + lane;
-        bool isc = false;
-        uint32_t e = 0;
-        if (j < own_hi) {
-            e = went[j];
-            isc = ((e >> WF_SHIFT) & FL_AT) && (wpos0 + (int64_t)(e & WP_MASK) >= offset);
-        }
-        const unsigned long long bal = __ballot(isc);
-        const int r = ncomp + __popcll(bal & ((1ull << lane) - 1ull));
-        if (isc && r < NMAX - 1) {
-            nidx[r] = (uint16_t)j;
-            went[j] = (e & ~(WN_MASK << WN_SHIFT)) | ((uint32_t)r << WN_SHIFT);
-        }
-        ncomp += __popcll(bal);
-    }
+        if (k == kown1) own_hi = tb[k];
+    if (prof) ts[2] = clock64();
     if (ncomp >= NMAX) {         // node id NMAX-1 == NO_NODE is reserved
         if (lane == 0) {
             B.y[g] = Y_UNRES; B.exit[g] = Y_UNRES; B.cnt[g] = 0; B.qb[g] = 0;
-            B.flags[g] = 1; B.lines[g] = lines;
+            B.flags[g] = 1; B.lines[g] = lines;      // (bit 2 cannot be pending: nothing was looked up)
         }
         return;
     }
-    __syncthreads();
+    wave_sync();
+    if (ablate == 2) { if (lane == 0) B.lines[g] = lines + ncomp; return; }
 
-    // ---- one scanner call + successor search per node ------------------------------------
-    const WAcc acc(L, went, nwin, wt1, wpos0);
-    for (int c = lane; c < ncomp; c += 64) {
+    if (prof) ts[3] = clock64();
+    // ---- one scanner call + successor search per node (node c = u*64 + lane) -------------
+    WinCtx wc;
+    wc.L = &L; wc.went = went; wc.defer = B.flags + g; wc.nwin = nwin; wc.wt1 = wt1; wc.own_hi = own_hi; wc.eof = eof;
+    wc.wpos0 = wpos0; wc.len = len;
+    // per node ONE register: successor (16 bits) | status (5 bits, biased by 1) << 16 |
+    // mi << 21 (batch index of the "\n+" entry) | sj << 25 (batch index of the successor) |
+    // fast << 29 (set: fields are re-read from the window when the record is staged)
+    uint32_t info[PER];
+    uint32_t pend = 0;          // slots of this lane that need the generic path
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int c = u * 64 + lane;
+        info[u] = SN_STOP | ((uint32_t)(ST_HEAD_BEG + 1) << 16);
+        if (c >= ncomp) continue;
         const int k = nidx[c];
-        WH hk; hk.idx = k; hk.g = H{0, 0};
-        WH hm, hm1;
-        Rec r;
-        compute_record(acc, hk, wpos0 + (int64_t)(went[k] & WP_MASK), len, eof, r, hm, hm1);
-        nstat[c] = (int8_t)(r.final_ ? ST_FINAL : r.status);
-        const bool emits = (r.status == ST_COMPLETE) || r.final_;
-        qlen[c] = emits ? (uint32_t)(r.p5 - r.p4) : 0u;
-        nm[c] = (emits && hm.idx >= 0 && hm1.idx >= 0) ? (uint16_t)hm.idx : NM_EXT;
-        uint16_t nx = NX_STOP;
-        if (r.status == ST_COMPLETE) {
-            WH hs; int64_t Ps;
-            if (find_cand(acc, hm1, r.p5 - 1, hs, Ps)) nx = (hs.idx >= 0) ? (uint16_t)hs.idx : NX_OUT;
-            else nx = NX_NOCAND;
+        bool done = false;
+        if (k + 12 < nwin) {
+            // fast path: the 12 entries after the candidate, read independently
+            uint32_t w[13];
+#pragma unroll
+            for (int i = 0; i < 13; i++) w[i] = went[k + i];
+            const uint32_t r0 = w[0] & WP_MASK, r1 = w[1] & WP_MASK;
+            if (wpos0 + (int64_t)(w[12] & WP_MASK) + 4 < len) {
+                uint32_t plusmask = 0;
+#pragma unroll
+                for (int i = 2; i <= 9; i++)
+                    if (((w[i] >> WF_SHIFT) & FL_PLUS) && (w[i] & WP_MASK) >= r1 + 2) plusmask |= 1u << i;
+                if (plusmask) {
+                    const int mi = __ffs((int)plusmask) - 1;
+                    uint32_t r3 = 0, rm1 = 0;
+#pragma unroll
+                    for (int i = 2; i <= 10; i++) {
+                        if (i == mi) r3 = w[i] & WP_MASK;
+                        if (i == mi + 1) rm1 = w[i] & WP_MASK;
+                    }
+                    const bool invalid = (rm1 - r3 - 1 > 1) && (rm1 - r3 != r1 - r0);
+                    const uint32_t qe = rm1 + 1 + r3 - r1 - 1;
+                    if (invalid) {
+                        info[u] = SN_STOP | ((uint32_t)(ST_INVALID + 1) << 16);
+                        done = true;
+                    } else {
+                        uint32_t atmask = 0;
+#pragma unroll
+                        for (int j = 4; j <= 12; j++)
+                            if (((w[j] >> WF_SHIFT) & FL_AT) && (w[j] & WP_MASK) + 1 >= qe && j >= mi + 2)
+                                atmask |= 1u << j;
+                        if (atmask) {
+                            const int j = __ffs((int)atmask) - 1;
+                            uint32_t wj = 0;
+#pragma unroll
+                            for (int i = 4; i <= 12; i++) if (i == j) wj = w[i];
+                            const uint32_t nid = (wj >> WN_SHIFT) & WN_MASK;
+                            const uint32_t nx = (k + j < own_hi && nid != NO_NODE) ? nid : SN_AHEAD;
+                            info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
+                                      ((uint32_t)j << 25) | (1u << 29);
+                            done = true;
+                        }
+                    }
+                }
+            }
         }
-        nxtE[c] = nx;
+        if (!done) pend |= 1u << u;
     }
-    __syncthreads();
-
-    // ---- the chain from the earliest node: pointer doubling with bottom-up marking -------
-    // before round k the marked set is every chain node at distance < 2^k from the start;
-    // a marked node whose 2^k-step jump is exact marks its target at distance + 2^k.
-    int rounds = 1;
-    while ((1 << rounds) < ncomp) rounds++;
-    constexpr int PER = (NMAX + 63) / 64;
-    int e0 = 0;                       // start node of the speculative chain
-    int lastn = -1, ynode = -1;
-    bool unresolved = false;
+    // nodes the fast path could not finish (long wrapped records, window / buffer edges)
+    while (__ballot(pend != 0u)) {
+        if (pend) {
+            const int u = __ffs((int)pend) - 1;
+            pend &= pend - 1u;
+            NodeOut o;
+            node_generic(&wc, nidx[u * 64 + lane], &o);
+            const uint32_t v = o.nxn | ((o.st + 1u) << 16) | (o.ext ? (1u << 30) : 0u);
+#pragma unroll
+            for (int q = 0; q < PER; q++) if (q == u) info[q] = v;
+        }
+    }
+    if (ablate == 3) { if (lane == 0) B.lines[g] = lines + info[0]; return; }
+    if (prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[4] = clock64(); }
+    // ---- chain membership ---------------------------------------------------------------------
+    // Node ids are in position order and a successor always lies further on, so a
+    // chain is a union of runs c, c+1, ..., r of "simple" nodes (successor == c+1)
+    // joined by jumps.  Walk run by run (wave-uniform); MB = member bit per node.
+    unsigned long long NS[PER], MB[PER];
+    uint16_t *nx16 = nx16_all[wid];
+    uint32_t *pk = pk_all[wid];
+    uint32_t *sbits = bits_all[wid], *ebits = bits_all[wid] + NMAX / 32;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int c = u * 64 + lane;
+        NS[u] = __ballot(!(c < ncomp && (info[u] & 0xFFFFu) == (uint32_t)(c + 1)));
+        if (c < ncomp) nx16[c] = (uint16_t)(info[u] & 0xFFFFu);
+    }
+    wave_sync();
+    // pk[c] = end of the run that contains c | (successor of that run end) << 16
+    {
+        int later = NMAX;                 // first non-simple node in the slots behind u (uniform)
+#pragma unroll
+        for (int u = PER - 1; u >= 0; u--) {
+            const int c = u * 64 + lane;
+            const unsigned long long m = NS[u] >> lane;
+            const int r = m ? c + (__ffsll((long long)m) - 1) : later;
+            if (c < ncomp) pk[c] = (uint32_t)r | ((uint32_t)nx16[min(r, NMAX - 1)] << 16);
+            if (NS[u]) later = u * 64 + (__ffsll((long long)NS[u]) - 1);
+        }
+    }
+    int e0 = 0, lastn = -1;
+    bool unresolved = false, too_many_jumps = false;
     for (int attempt = 0; attempt < 4 && ncomp > 0; attempt++) {
-        for (int c = lane; c < ncomp; c += 64) {
-            const uint16_t nx = nxtE[c];
-            uint16_t s = (uint16_t)c;
-            if (nx < NX_STOP && (int)nx < own_hi) {
-                const uint32_t nid = (went[nx] >> WN_SHIFT) & WN_MASK;
-                if (nid != NO_NODE) s = (uint16_t)nid;
+        if (lane < 2 * (NMAX / 32)) bits_all[wid][lane] = 0u;
+        wave_sync();
+        // serial part: one LDS read per run; run [cur, r] recorded as a start bit and an end bit
+        int cur = e0, seg = 0;
+        bool walked = false;
+        for (; seg < SEG_LIMIT; seg++) {
+            const uint32_t p = pk[cur];
+            const int r = (int)(p & 0xFFFFu);
+            const uint32_t nx = p >> 16;
+            if (lane == 0) {
+                atomicOr(&sbits[cur >> 5], 1u << (cur & 31));
+                atomicOr(&ebits[r >> 5], 1u << (r & 31));
             }
-            S[c] = s;
-            cn[c] = (s != c) ? 1 : 0;
-            dist[c] = (c == e0) ? 0 : UNMARKED;
+            lastn = r;
+            if (nx >= SN_AHEAD) { walked = true; break; }
+            cur = (int)nx;
         }
-        __syncthreads();
-        for (int k = 0; k < rounds; k++) {
-            uint16_t s1[PER], s2[PER], c1[PER], c2[PER], dd[PER];
-            bool mk[PER];
+        wave_sync();
+        if (walked) {
+            // member(c) = runs started at or before c outnumber runs ended before c
+            int sb = 0, eb = 0;
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const int c = lane + u * 64;
-                mk[u] = false;
-                if (c < ncomp) {
-                    s1[u] = S[c]; c1[u] = cn[c];
-                    s2[u] = S[s1[u]]; c2[u] = cn[s1[u]];
-                    dd[u] = dist[c];
-                    mk[u] = (dd[u] != UNMARKED) && (c1[u] == (uint16_t)(1u << k));
-                }
+                const unsigned long long sw = (unsigned long long)sbits[2 * u] | ((unsigned long long)sbits[2 * u + 1] << 32);
+                const unsigned long long ew = (unsigned long long)ebits[2 * u] | ((unsigned long long)ebits[2 * u + 1] << 32);
+                const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                const int s_le = sb + __popcll(sw & le);
+                const int e_lt = eb + __popcll(ew & ((1ull << lane) - 1ull));
+                MB[u] = __ballot(s_le > e_lt);
+                sb += __popcll(sw); eb += __popcll(ew);
             }
-            __syncthreads();
+        }
+        if (!walked && !DOUBLING) { unresolved = true; too_many_jumps = true; break; }
+        if (!walked) {
+            // too many jumps for the run walk: pointer doubling with bottom-up marking
+            uint16_t *dS = dS_all[wid], *dC = dC_all[wid], *dD = dD_all[wid];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const int c = lane + u * 64;
+                const int c = u * 64 + lane;
                 if (c < ncomp) {
-                    if (mk[u]) dist[s1[u]] = (uint16_t)(dd[u] + (1u << k));
-                    S[c] = s2[u];
-                    cn[c] = (uint16_t)(c1[u] + c2[u]);
+                    const uint16_t s = ((info[u] & 0xFFFFu) < SN_AHEAD) ? (uint16_t)(info[u] & 0xFFFFu) : (uint16_t)c;
+                    dS[c] = s; dC[c] = (s != c) ? 1 : 0; dD[c] = (c == e0) ? 0 : UNMARKED;
                 }
             }
-            __syncthreads();
+            wave_sync();
+            int rounds = 1;
+            while ((1 << rounds) < ncomp) rounds++;
+            for (int k = 0; k < rounds; k++) {
+                uint16_t s1[PER], s2[PER], c1[PER], c2[PER], dd[PER];
+                bool mk[PER];
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int c = u * 64 + lane;
+                    mk[u] = false;
+                    if (c < ncomp) {
+                        s1[u] = dS[c]; c1[u] = dC[c];
+                        s2[u] = dS[s1[u]]; c2[u] = dC[s1[u]];
+                        dd[u] = dD[c];
+                        mk[u] = (dd[u] != UNMARKED) && (c1[u] == (uint16_t)(1u << k));
+                    }
+                }
+                wave_sync();
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const int c = u * 64 + lane;
+                    if (c < ncomp) {
+                        if (mk[u]) dD[s1[u]] = (uint16_t)(dd[u] + (1u << k));
+                        dS[c] = s2[u];
+                        dC[c] = (uint16_t)(c1[u] + c2[u]);
+                    }
+                }
+                wave_sync();
+            }
+            uint32_t lastkey = 0;
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int c = u * 64 + lane;
+                const bool m = (c < ncomp) && dD[c] != UNMARKED;
+                MB[u] = __ballot(m);
+                if (m) lastkey = max(lastkey, (uint32_t)c);
+            }
+            lastn = (int)wave_max_u32(lastkey);
         }
-        // last marked node and first marked node of the own tiles
-        uint32_t lastkey = 0, ykey = 0xFFFFFFFFu;
-        for (int c = lane; c < ncomp; c += 64) {
-            const uint16_t dc = dist[c];
-            if (dc == UNMARKED) continue;
-            const uint32_t key = ((uint32_t)dc << 16) | (uint32_t)c;
-            lastkey = max(lastkey, key);
-            if ((int)nidx[c] >= own_lo) ykey = min(ykey, key);
-        }
-        lastkey = wave_max_u32(lastkey);
-        ykey = wave_min_u32(ykey);
-        lastn = (int)(lastkey & 0xFFFFu);
-        ynode = (ykey == 0xFFFFFFFFu) ? -1 : (int)(ykey & 0xFFFFu);
-        const bool died_in_runin = ((int)nidx[lastn] < own_lo) && (nstat[lastn] != ST_COMPLETE);
+        const int lst = (int)((read_node<PER>(info, lastn) >> 16) & 31u) - 1;
+        const bool died_in_runin = (lastn < n_runin) && (lst != ST_COMPLETE);
         if (!died_in_runin) break;
-        // this chain stops inside the run-in (it started at a false candidate):
+        // the chain stopped inside the run-in (it started at a false candidate):
         // restart from the next run-in node it did not visit
-        uint32_t nxt = 0xFFFFFFFFu;
-        for (int c = lane; c < ncomp; c += 64)
-            if (c > e0 && dist[c] == UNMARKED && (int)nidx[c] < own_lo) nxt = min(nxt, (uint32_t)c);
-        nxt = wave_min_u32(nxt);
-        __syncthreads();
-        if (nxt == 0xFFFFFFFFu || attempt == 3) { unresolved = true; break; }
-        e0 = (int)nxt;
+        unsigned long long free_[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) free_[u] = ~MB[u];
+        const int nxt = first_set_from<PER>(free_, e0 + 1);
+        if (nxt >= n_runin || attempt == 3) { unresolved = true; break; }
+        e0 = nxt;
     }
+    if (ablate == 4) { if (lane == 0) B.lines[g] = lines + lastn; return; }
 
-    // ---- summary (lane 0) + staging of the own tiles' records -------------------------------
+    if (prof) ts[5] = clock64();
+    // ---- summary + staging of the own tiles' records ---------------------------------------------
+    const int ynode = (ncomp > 0 && !unresolved) ? first_set_from<PER>(MB, n_runin) : NMAX;
+    const bool have_y = ynode < ncomp;
     int64_t Y = Y_UNRES, EX = Y_UNRES;
     int32_t tstatus = 0;
     bool have_term = false;
     Rec tr;
     tr.p0 = tr.p1 = tr.p3 = tr.p4 = tr.p5 = -1; tr.status = 0; tr.final_ = false;
-    if (lane == 0 && !unresolved) {
+    if (!unresolved) {
         if (ncomp == 0) {
-            // no candidate in the run-in tail / own tiles: the chain passes over this group
-            WH hb; hb.g = H{0, 0};
-            hb.idx = (own_hi > 0) ? own_hi - 1 : -2;
-            WH hs; int64_t Ps;
-            Y = find_cand(acc, hb, offset, hs, Ps) ? Ps : Y_NOCAND;
-            EX = Y;
-            if (Y == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
-        } else {
-            const int st = nstat[lastn];
-            int64_t after = Y_NOCAND;      // the candidate the chain continues with after lastn
-            if (st == ST_COMPLETE) {
-                const uint16_t nx = nxtE[lastn];
-                if (nx == NX_NOCAND) after = Y_NOCAND;
-                else if (nx != NX_OUT) after = wpos0 + (int64_t)(went[nx] & WP_MASK);
-                else {
-                    const int k = nidx[lastn];
-                    WH hk; hk.idx = k; hk.g = H{0, 0};
-                    WH hm, hm1, hs; Rec r; int64_t Ps;
-                    compute_record(acc, hk, wpos0 + (int64_t)(went[k] & WP_MASK), len, eof, r, hm, hm1);
-                    after = find_cand(acc, hm1, r.p5 - 1, hs, Ps) ? Ps : Y_NOCAND;
-                }
-                EX = after;
-                if (after == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
-            } else {
-                // the chain stops at lastn: keep the scanner's posbuffer of that call
-                const int k = nidx[lastn];
-                WH hk; hk.idx = k; hk.g = H{0, 0};
-                WH hm, hm1;
-                compute_record(acc, hk, wpos0 + (int64_t)(went[k] & WP_MASK), len, eof, tr, hm, hm1);
-                EX = (st == ST_FINAL) ? X_END_FINAL : X_END_TERM;
-                have_term = true; tstatus = tr.status;
+            if (lane == 0) {
+                // no candidate in the run-in tail / own tiles: the chain passes over this group
+                Y = cand_after(&wc, (own_hi > 0) ? own_hi - 1 : -2, offset);
+                EX = Y;
+                if (Y == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
             }
-            Y = (ynode >= 0) ? wpos0 + (int64_t)(went[nidx[ynode]] & WP_MASK) : EX;
-            if (ynode < 0 && EX < 0 && EX != Y_NOCAND) Y = Y_UNRES;   // cannot happen: died in run-in
+        } else {
+            const uint32_t li = read_node<PER>(info, lastn);
+            const int st = (int)((li >> 16) & 31u) - 1;
+            const uint32_t nx = li & 0xFFFFu;
+            if (lane == 0) {
+                if (st == ST_COMPLETE) {
+                    int64_t after;
+                    if (nx == SN_NOCAND) after = Y_NOCAND;
+                    else if (nx == SN_AHEAD && (li >> 29 & 1u))
+                        after = wpos0 + (int64_t)(went[nidx[lastn] + ((li >> 25) & 15u)] & WP_MASK);
+                    else {   // beyond the window (or a generic node): through the global index
+                        Rec r;
+                        node_followup(&wc, nidx[lastn], &r, &after);
+                    }
+                    EX = after;
+                    if (after == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
+                } else {
+                    // the chain stops at lastn: keep the scanner's posbuffer of that call
+                    int64_t dummy;
+                    node_followup(&wc, nidx[lastn], &tr, &dummy);
+                    EX = (st == ST_FINAL) ? X_END_FINAL : X_END_TERM;
+                    have_term = true; tstatus = tr.status;
+                }
+                Y = have_y ? wpos0 + (int64_t)(went[nidx[ynode]] & WP_MASK) : EX;
+            }
         }
     }
-    // records of the own tiles, in chain order
+    // records of the own tiles, in chain order: rank = members in front (position order)
     uint32_t cnt = 0;
     unsigned long long qsum = 0;
     bool bad_range = false;
-    if (!unresolved && ynode >= 0) {
-        const uint32_t d0 = dist[ynode];
-        StageRec *st = B.stage + (int64_t)g * B.nmax;
-        for (int c = lane; c < ncomp; c += 64) {
-            const uint16_t dc = dist[c];
-            if (dc == UNMARKED || (int)nidx[c] < own_lo) continue;
-            const int s = nstat[c];
-            if (s != ST_COMPLETE && s != ST_FINAL) continue;
-            const int k = nidx[c];
-            int64_t p0, p1, p3, p4;
-            const uint16_t mi = nm[c];
-            if (mi != NM_EXT) {
-                p0 = (int64_t)(went[k] & WP_MASK) + 1;
-                p1 = (int64_t)(went[k + 1] & WP_MASK);
-                p3 = (int64_t)(went[mi] & WP_MASK);
-                p4 = (int64_t)(went[mi + 1] & WP_MASK) + 1;
-            } else {
-                WH hk; hk.idx = k; hk.g = H{0, 0};
-                WH hm, hm1; Rec r;
-                compute_record(acc, hk, wpos0 + (int64_t)(went[k] & WP_MASK), len, eof, r, hm, hm1);
-                p0 = r.p0 - wpos0; p1 = r.p1 - wpos0; p3 = r.p3 - wpos0; p4 = r.p4 - wpos0;
-                if (p4 > 0xFFFFFFF0ll) bad_range = true;
-            }
+    unsigned long long RM[PER];              // own-tile members that are records (emit a row)
+    const int d0 = (!unresolved && have_y) ? count_below<PER>(MB, ynode) : 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int c = u * 64 + lane;
+        const int st = (int)((info[u] >> 16) & 31u) - 1;
+        const bool rec = !unresolved && have_y && c < ncomp && c >= n_runin && ((MB[u] >> lane) & 1ull) &&
+                         (st == ST_COMPLETE || st == ST_FINAL);
+        if (rec && ((info[u] >> 30) & 1u)) bad_range = true;
+        RM[u] = __ballot(rec && !((info[u] >> 30) & 1u));
+        cnt += (uint32_t)__popcll(RM[u]);            // wave-uniform
+    }
+    {
+        StageRec *stg = B.stage + (int64_t)g * B.nmax;
+        int mbase = 0;                       // members in the slots in front (wave-uniform)
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int c = u * 64 + lane;
+            const int rank = mbase + __popcll(MB[u] & ((1ull << lane) - 1ull)) - d0;
+            mbase += __popcll(MB[u]);
+            if (!((RM[u] >> lane) & 1ull)) continue;
             StageRec o;
-            o.p0 = (uint32_t)p0; o.p1 = (uint32_t)p1; o.p3 = (uint32_t)p3; o.p4 = (uint32_t)p4;
-            st[dc - d0] = o;
-            cnt++;
-            qsum += qlen[c];
+            if ((info[u] >> 29) & 1u) {
+                const int k = nidx[c];
+                const int mi = (int)((info[u] >> 21) & 15u);
+                o.p0 = (went[k] & WP_MASK) + 1;
+                o.p1 = went[k + 1] & WP_MASK;
+                o.p3 = went[k + mi] & WP_MASK;
+                o.p4 = (went[k + mi + 1] & WP_MASK) + 1;
+            } else {
+                pend |= 1u << u;       // fields through the generic path, below
+                continue;
+            }
+            stg[rank] = o;
+            qsum += (unsigned long long)(o.p3 - o.p1 - 1);
+        }
+        while (__ballot(pend != 0u)) {
+            if (pend) {
+                const int u = __ffs((int)pend) - 1;
+                pend &= pend - 1u;
+                const int c = u * 64 + lane;
+                NodeOut no;
+                node_generic(&wc, nidx[c], &no);
+                StageRec o;
+                o.p0 = no.f0; o.p1 = no.f1; o.p3 = no.f3; o.p4 = no.f4;
+                stg[count_below<PER>(MB, c) - d0] = o;
+                qsum += (unsigned long long)(o.p3 - o.p1 - 1);
+            }
         }
     }
-    cnt = wave_sum_u32(cnt);
     const uint32_t qlo = wave_sum_u32((uint32_t)(qsum & 0xFFFFFu)), qhi = wave_sum_u32((uint32_t)(qsum >> 20));
     const bool anybad = __ballot(bad_range) != 0ull;
     if (lane == 0) {
@@ -438,13 +770,26 @@ __global__ __launch_bounds__(64) void k_chain_wave(LineIndex L, int64_t offset, 
         B.exit[g] = bad ? Y_UNRES : EX;
         B.cnt[g] = cnt;
         B.qb[g] = ((int64_t)qhi << 20) + (int64_t)qlo;
-        B.flags[g] = anybad ? 1u : 0u;
+        // bit 2 (deferred) may have been set by a lookup of this pass: keep it
+        if (only_deferred) B.flags[g] = (anybad || too_many_jumps) ? 1u : 0u;
+        else if (anybad || too_many_jumps) atomicOr(&B.flags[g], 1u);
         B.lines[g] = lines;
         if (have_term) {
             GroupTerm &t = B.term[g];
             t.status = tstatus;
             t.pos[0] = tr.p0; t.pos[1] = tr.p1; t.pos[2] = (tr.p1 >= 0) ? tr.p1 + 1 : -1;
             t.pos[3] = tr.p3; t.pos[4] = tr.p4; t.pos[5] = tr.p5;
+        }
+        if (prof) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const long long te = clock64();
+            atomicAdd(&B.prof[0], (unsigned long long)(ts[1] - ts[0]));   // loads landed
+            atomicAdd(&B.prof[1], (unsigned long long)(ts[2] - ts[1]));   // window written to LDS
+            atomicAdd(&B.prof[2], (unsigned long long)(ts[3] - ts[2]));   // nodes numbered
+            atomicAdd(&B.prof[3], (unsigned long long)(ts[4] - ts[3]));   // scanner calls
+            atomicAdd(&B.prof[4], (unsigned long long)(ts[5] - ts[4]));   // membership
+            atomicAdd(&B.prof[5], (unsigned long long)(te - ts[5]));      // summary + staging
+            atomicAdd(&B.prof[6], 1ull);
         }
     }
 }
@@ -470,7 +815,7 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve_a(ChainBufs B)
         const int64_t y = B.y[g], ex = B.exit[g];
         c = B.cnt[g]; q = B.qb[g];
         if (ex == Y_NOCAND || ex == X_END_TERM || ex == X_END_FINAL) atomicMin(&s_term, g);
-        bool bad = (B.flags[g] & 1u) || (y == Y_UNRES);
+        bool bad = (B.flags[g] & 5u) || (y == Y_UNRES);
         if (g > 0) {
             const int64_t pe = B.exit[g - 1];
             if (pe >= 0 && y != pe) bad = true;

@@ -44,6 +44,8 @@ struct LineIndex {
     int64_t n;                 // number of bytes
     int32_t s;                 // 1: a virtual '\n' sits at buffer coordinate 0
     int32_t ntiles;
+    int32_t ready;             // tiles [0, ready) of the index are valid (chunked pipelining)
+    int32_t pad_;
     const uint16_t *ent;       // [ntiles][SLOT]
     const uint32_t *cnt;       // [ntiles]
     const unsigned long long *ovf;   // [ntiles] pool offset of dense tiles
@@ -68,8 +70,8 @@ struct GAcc {
         if (h.tile == -2 && L.s) { h.tile = -1; h.i = 0; return true; }
         if (h.tile >= 0 && h.i + 1 < (int32_t)L.cnt[h.tile]) { h.i++; return true; }
         int32_t t = h.tile < 0 ? 0 : h.tile + 1;
-        while (t < L.ntiles && L.cnt[t] == 0) t++;
-        if (t >= L.ntiles) return false;
+        while (t < L.ready && L.cnt[t] == 0) t++;
+        if (t >= L.ready) return false;
         h.tile = t; h.i = 0;
         return true;
     }

@@ -10,8 +10,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace ffq;
 
@@ -39,6 +41,8 @@ static int fail(int code, const char *fmt, ...)
 struct ffq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;       // chain kernels, overlapped with the scan kernel chunk by chunk
+    std::vector<hipEvent_t> chunk_ev;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // scratch, grow-only
     int64_t cap_tiles = 0;
@@ -50,6 +54,7 @@ struct ffq_ctx {
     int64_t cap_groups = 0;
     ChainBufs cb = {};
     int64_t stage_cap = 0;        // StageRec entries allocated
+    unsigned long long *prof_d = nullptr;
     Ctl *ctl = nullptr;
     DevRes *dres = nullptr;
     // pinned mirrors
@@ -97,6 +102,7 @@ extern "C" int ffq_ctx_create(int device, ffq_ctx **out)
     if (!c) return fail(FFQ_E_NOMEM, "out of host memory");
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&c->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipMalloc((void **)&c->dres, sizeof(DevRes));
@@ -125,6 +131,9 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (hipEvent_t ev : c->chunk_ev) (void)hipEventDestroy(ev);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
     free_chain(c);
     (void)hipFree(c->ctl); (void)hipFree(c->dres);
@@ -142,8 +151,9 @@ extern "C" void *ffq_ctx_stream(ffq_ctx *c) { return c ? (void *)c->stream : nul
 
 static int64_t tiles_for(int64_t n) { return (n + TILE - 1) >> TILE_SHIFT; }
 static int64_t groups_for(int64_t ntiles) { return (ntiles + OWN_T - 1) / OWN_T; }
-constexpr int NMAX_FAST = 256, EMAX_FAST = 2048;      // k_chain_wave, usual line/record density
-constexpr int NMAX_DENSE = 1024, EMAX_DENSE = NTW * SLOT + 8;   // short records / short lines
+constexpr int PER_FAST = 6, EMAX_FAST = 2048, WPB_FAST = 2;   // k_chain_wave, usual line/record density
+constexpr int PER_DENSE = 15, EMAX_DENSE = NTW * SLOT + 8, WPB_DENSE = 1;   // short records / short lines
+constexpr int NMAX_FAST = PER_FAST * 64, NMAX_DENSE = PER_DENSE * 64;
 
 static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
 {
@@ -322,46 +332,110 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
     bool dense_cfg = false;
     for (;;) {
         LineIndex L;
-        L.d = d_buf; L.n = n_bytes; L.s = s; L.ntiles = (int32_t)ntiles;
+        L.d = d_buf; L.n = n_bytes; L.s = s; L.ntiles = (int32_t)ntiles; L.ready = (int32_t)ntiles; L.pad_ = 0;
         L.ent = c->ent; L.cnt = c->cnt; L.ovf = c->ovf; L.pool = c->pool;
-
-        HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), c->stream));
-        HIPCHK(hipEventRecord(c->ev[0], c->stream));
-        hipLaunchKernelGGL(k_scan_lines, dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_buf, n_bytes,
-                           c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl);
-        HIPCHK(hipEventRecord(c->ev[1], c->stream));
         const bool serial = (flags & FFQ_F_FORCE_SERIAL) != 0;
+        const char *abl = getenv("FFQ_ABLATE");
+        const int ablate = abl ? atoi(abl) : 0;
+        hipStream_t sA = c->stream, sB = c->stream2;
+        const int k1abl = getenv("FFQ_K1_ABLATE") ? atoi(getenv("FFQ_K1_ABLATE")) : 0;
+
+        // The scan kernel runs chunk by chunk on stream A; the chain kernel of the groups
+        // whose window lies inside the finished chunks runs behind it on stream B (it is
+        // latency-bound and hides under the HBM-bound scan).
+        // (measured on MI355X: co-running the two kernels slows the scan kernel by more than
+        //  the chain kernel gains, so by default everything is one chunk; FFQ_CHUNK_TILES
+        //  re-enables the chunked overlap for experiments)
+        int64_t CH_TILES = 1ll << 40;
+        if (const char *e = getenv("FFQ_CHUNK_TILES")) CH_TILES = std::max<int64_t>(atoll(e), 64);
+        const int nch = (int)((ntiles + CH_TILES - 1) / CH_TILES);
+        while ((int)c->chunk_ev.size() < nch) {
+            hipEvent_t ev;
+            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->chunk_ev.push_back(ev);
+        }
+        ChainBufs cb = c->cb;
+        const int nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
+        if (!serial) {
+            rc = reserve_stage(c, ngroups, nmax);
+            if (rc) return rc;
+            cb = c->cb;
+            cb.ng = ngroups;
+            cb.nmax = nmax;
+            cb.prof = nullptr;
+            if (getenv("FFQ_PROF")) {
+                if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 64));
+                HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sA));
+                cb.prof = c->prof_d;
+            }
+        }
+        auto launch_chain = [&](int g0, int g1, int ready, int only_deferred) {
+            LineIndex Lr = L;
+            Lr.ready = ready;
+            if (!dense_cfg)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
+                                   dim3((g1 - g0 + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sB, Lr, offset,
+                                   eof, cb, g0, g1, only_deferred, ablate);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
+                                   dim3((g1 - g0 + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sB, Lr,
+                                   offset, eof, cb, g0, g1, only_deferred, ablate);
+        };
+
+        HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
+        HIPCHK(hipEventRecord(c->ev[0], sA));
+        HIPCHK(hipStreamWaitEvent(sB, c->ev[0], 0));        // stream B starts behind the control-block reset
+        int gdone = 0;
+        for (int ch = 0; ch < nch; ch++) {
+            const int64_t t0 = (int64_t)ch * CH_TILES, t1 = std::min<int64_t>(ntiles, t0 + CH_TILES);
+            {
+                // full tiles in one launch, the ragged last tile of the buffer alone
+                const int64_t nfull = std::max<int64_t>(std::min<int64_t>(t1, n_bytes >> TILE_SHIFT), t0);
+                // the ragged last tile (byte-wise loads, one workgroup) goes first on stream B so
+                // that it runs beside the main launch instead of after it
+                if (t1 > nfull)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 4>), dim3((unsigned)(t1 - nfull)), dim3(256), 0,
+                                       sB, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
+                                       (int)nfull, 0);
+                if (nfull > t0)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 6>), dim3((unsigned)(nfull - t0)), dim3(256), 0,
+                                       sA, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
+                                       (int)t0, k1abl);
+            }
+            HIPCHK(hipEventRecord(c->chunk_ev[ch], sA));
+            if (serial) continue;
+            HIPCHK(hipStreamWaitEvent(sB, c->chunk_ev[ch], 0));
+            const int gend = (ch == nch - 1) ? ngroups : (int)std::max<int64_t>((t1 - 1) / OWN_T, 0);
+            if (gend > gdone) {
+                HIPCHK(hipMemsetAsync(cb.flags + gdone, 0, (size_t)(gend - gdone) * 4, sB));
+                launch_chain(gdone, gend, (int)t1, 0);
+                gdone = gend;
+            }
+        }
+        HIPCHK(hipEventRecord(c->ev[1], sA));
         if (!serial) {
             const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
-            rc = reserve_stage(c, ngroups, dense_cfg ? NMAX_DENSE : NMAX_FAST);
-            if (rc) return rc;
-            ChainBufs cb = c->cb;
-            cb.ng = ngroups;
-            cb.nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
-            HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, c->stream));
-            if (!dense_cfg)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<NMAX_FAST, EMAX_FAST>), dim3(ngroups), dim3(64), 0,
-                                   c->stream, L, offset, eof, cb);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<NMAX_DENSE, EMAX_DENSE>), dim3(ngroups), dim3(64),
-                                   0, c->stream, L, offset, eof, cb);
-            hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, c->stream, cb);
-            hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, c->stream, cb, nblk, eof, offset, add, c->dres);
-            hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, c->stream, cb, (const DevRes *)c->dres, add,
-                               d_table, table_cap, qoff);
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->dres, d_table, table_cap, add,
-                               offset, qoff);
+            if (nch > 1) launch_chain(0, ngroups, (int)ntiles, 1);      // groups that had to wait for later chunks
+            HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sB));
+            hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sB, cb);
+            hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sB, cb, nblk, eof, offset, add, c->dres);
+            hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sB, cb, (const DevRes *)c->dres, add, d_table,
+                               table_cap, qoff);
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sB, c->dres, d_table, table_cap, add, offset, qoff);
+        } else {
+            HIPCHK(hipStreamWaitEvent(sB, c->chunk_ev[nch - 1], 0));
         }
-        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        HIPCHK(hipEventRecord(c->ev[2], sB));
         if (!serial && decode) {
-            hipLaunchKernelGGL(k_decode_quals, dim3(2048), dim3(256), 0, c->stream, d_buf, s, d_table, qoff,
-                               c->dres, table_cap, add, qual_add, d_qual, qual_cap);
+            hipLaunchKernelGGL(k_decode_quals, dim3(2048), dim3(256), 0, sB, d_buf, s, d_table, qoff, c->dres,
+                               table_cap, add, qual_add, d_qual, qual_cap);
         }
-        HIPCHK(hipEventRecord(c->ev[3], c->stream));
-        HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->ev[3], sB));
+        HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
+        HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(sB));
+        HIPCHK(hipStreamSynchronize(sA));
 
         if (c->h_ctl->err & ERR_POOL) {
             // dense tiles did not fit the overflow pool: size it for what was asked and re-run
@@ -372,13 +446,42 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
             continue;
         }
         if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
+        if (!serial && getenv("FFQ_PROF") && c->prof_d) {
+            unsigned long long hp[8];
+            HIPCHK(hipMemcpy(hp, c->prof_d, 64, hipMemcpyDeviceToHost));
+            if (hp[6])
+                fprintf(stderr, "[ffq prof] k_chain_wave per-wave cycles: load %.0f lds %.0f nodes %.0f scan %.0f member %.0f summary %.0f (waves %llu)\n",
+                        (double)hp[0] / hp[6], (double)hp[1] / hp[6], (double)hp[2] / hp[6], (double)hp[3] / hp[6],
+                        (double)hp[4] / hp[6], (double)hp[5] / hp[6], hp[6]);
+        }
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); res->ms_chain = ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); res->ms_decode = ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total = ms;
 
+        if (!serial && getenv("FFQ_DEBUG")) {
+            const int ng = std::min(ngroups, 24);
+            std::vector<int64_t> y(ng), ex(ng);
+            std::vector<uint32_t> cn(ng), fl(ng);
+            int32_t mins[2];
+            HIPCHK(hipMemcpy(y.data(), c->cb.y, ng * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(ex.data(), c->cb.exit, ng * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(cn.data(), c->cb.cnt, ng * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(fl.data(), c->cb.flags, ng * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(mins, c->cb.mins, 8, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[ffq debug] dense=%d fallback=%d ngroups=%d term=%d bad=%d\n", (int)dense_cfg,
+                    c->h_res->fallback, ngroups, mins[0], mins[1]);
+            for (int g = 0; g < ng; g++)
+                fprintf(stderr, "[ffq debug]  g=%d y=%lld exit=%lld cnt=%u flags=%u\n", g, (long long)y[g],
+                        (long long)ex[g], cn[g], fl[g]);
+        }
         int path = 0;
+        if (!serial && getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) {
+            // diagnostics build of the pipeline: results are meaningless, only timings count
+            fill_result(res, *c->h_res, 0, retries);
+            return FFQ_OK;
+        }
         if (!serial && c->h_res->fallback && !dense_cfg) {
             // second tier: the same kernels with the LDS budget for short lines / short records
             dense_cfg = true;
@@ -606,6 +709,27 @@ extern "C" int ffq_synth_wrapped(ffq_ctx *c, uint8_t *d_out, const int64_t *d_st
                        d_start, first, count, seed);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    return FFQ_OK;
+}
+
+extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int mode, int reps, float *ms_avg)
+{
+    if (!c || !d_buf || !ms_avg || n_bytes < TILE || reps < 1) return fail(FFQ_E_ARG, "ffq_read_probe: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t ntiles = n_bytes >> TILE_SHIFT;
+    uint32_t *sink = reinterpret_cast<uint32_t *>(c->ctl);
+    for (int r = 0; r < reps + 2; r++) {
+        if (r == 2) HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        if (mode == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_read_probe<0>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_buf, ntiles, sink);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_read_probe<1>), dim3(256 * 8), dim3(256), 0, c->stream, d_buf, ntiles, sink);
+    }
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    *ms_avg = ms / reps;
     return FFQ_OK;
 }
 

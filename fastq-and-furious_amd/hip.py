@@ -40,7 +40,7 @@ SYMBOLS = (
     "ffq_scan_device", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
     "ffq_synth_single",
-    "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
+    "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
 )
 
 
@@ -113,6 +113,7 @@ def lib():
         L.ffq_synth_wrapped_size.argtypes = [i64, u64]
         L.ffq_synth_wrapped_size.restype = i64
         L.ffq_synth_wrapped.argtypes = [vp, vp, vp, i64, i64, u64]
+        L.ffq_read_probe.argtypes = [vp, vp, i64, i32, i32, P(ctypes.c_float)]
         L.ffq_selftest.argtypes = [vp]
         _lib = L
     return _lib
@@ -254,6 +255,12 @@ class Context:
         check(lib().ffq_table_lower_bound(self.handle, ctypes.c_void_p(d_table), int(n_rows), int(col),
                                           int(value), ctypes.byref(idx)))
         return idx.value
+
+    def read_probe(self, dptr, n_bytes, mode=0, reps=10):
+        ms = ctypes.c_float(0)
+        check(lib().ffq_read_probe(self.handle, ctypes.c_void_p(dptr), int(n_bytes), int(mode), int(reps),
+                                   ctypes.byref(ms)))
+        return ms.value
 
     def synth_single(self, dptr, first, count, seed=42):
         check(lib().ffq_synth_single(self.handle, ctypes.c_void_p(dptr), int(first), int(count), int(seed)))

@@ -175,6 +175,12 @@ int64_t ffq_synth_wrapped_size(int64_t i, uint64_t seed);
 int ffq_synth_wrapped(ffq_ctx *ctx, uint8_t *d_out, const int64_t *d_start,
                       int64_t first, int64_t count, uint64_t seed);
 
+/* Measured streaming-read ceiling of the device in the scan kernel's launch geometry
+ * (mode 0) or as a grid-stride loop (mode 1): average ms over `reps` launches of a
+ * kernel that only reads n_bytes (rounded down to 16 KiB).  Diagnostics.            */
+int ffq_read_probe(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes, int mode, int reps,
+                   float *ms_avg);
+
 /* ---- diagnostics ---------------------------------------------------------
  * Runs the device self-checks (wave scan, newline mask) and returns FFQ_OK.  */
 int ffq_selftest(ffq_ctx *ctx);
