@@ -420,16 +420,12 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
             hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sB, cb);
             hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sB, cb, nblk, eof, offset, add, c->dres);
             hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sB, cb, (const DevRes *)c->dres, add, d_table,
-                               table_cap, qoff);
+                               table_cap, qoff, d_buf, s, qual_add, decode ? d_qual : (int8_t *)nullptr, qual_cap);
             hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sB, c->dres, d_table, table_cap, add, offset, qoff);
         } else {
             HIPCHK(hipStreamWaitEvent(sB, c->chunk_ev[nch - 1], 0));
         }
         HIPCHK(hipEventRecord(c->ev[2], sB));
-        if (!serial && decode) {
-            hipLaunchKernelGGL(k_decode_quals, dim3(2048), dim3(256), 0, sB, d_buf, s, d_table, qoff, c->dres,
-                               table_cap, add, qual_add, d_qual, qual_cap);
-        }
         HIPCHK(hipEventRecord(c->ev[3], sB));
         HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
         HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));

@@ -229,8 +229,8 @@ __global__ void k_finalize_serial(DevRes *res, int64_t table_cap, int64_t *__res
 }
 
 // =========================================================================
-// k_decode_quals: out[qoff[i] + b] = buf[pos4_i + b] + qadd, one wave per record
-// (arrayadd_b over each record's quality slice, _fastqandfurious.c:161-185).
+// k_decode_quals: stand-alone Phred decode over a finished table (used behind the serial
+// walker; the parallel path decodes inside k_expand, where the rows are in registers).
 // =========================================================================
 __global__ __launch_bounds__(256) void k_decode_quals(const uint8_t *__restrict__ d, int s,
                                                       const int64_t *__restrict__ table,
@@ -240,17 +240,15 @@ __global__ __launch_bounds__(256) void k_decode_quals(const uint8_t *__restrict_
                                                       int8_t *__restrict__ out, int64_t out_cap)
 {
     const int64_t n = min(res->n_records, table_cap);
-    const int l = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const uint8_t v = (uint8_t)qadd;
-    for (int64_t i = wave; i < n; i += nwaves) {
-        const int64_t p4 = table[i * 6 + 4] - add, p5 = table[i * 6 + 5] - add;
-        const int64_t qo = qoff[i];
-        const uint8_t *src = d + (p4 - s);
-        const int64_t m = p5 - p4;
-        for (int64_t b = l; b < m; b += 64)
-            if (qo + b < out_cap) out[qo + b] = (int8_t)(uint8_t)(src[b] + v);
+    for (int64_t r0 = wave * 64; r0 < n; r0 += nwaves * 64) {
+        const int64_t i = r0 + lane;
+        const bool ok = i < n;
+        const longlong2 pq = ok ? *reinterpret_cast<const longlong2 *>(table + i * 6 + 4) : make_longlong2(0, 0);
+        decode_batch(d, pq.x - add - s, ok ? (uint32_t)(pq.y - pq.x) : 0u, ok ? qoff[i] : 0,
+                     (int)min((int64_t)64, n - r0), qadd, out, out_cap, lane);
     }
 }
 
