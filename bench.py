@@ -70,6 +70,27 @@ def cpu_baseline(sample_u8, budget_s=10.0):
     }
 
 
+def pmc_traffic(workload):
+    """HBM bytes per k_scan_lines launch from the committed rocprofv3 PMC passes of this
+    workload (profiles/*/pmc_fetch_write.json): FETCH_SIZE and WRITE_SIZE are KiB; on gfx950
+    FETCH_SIZE counts 64 B per 128 B request of a wide streaming read, so it is doubled
+    (MI355X_MICROARCH.md, HBM section).  None if no profile of this workload is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_fetch_write.json"))):
+        if workload.replace("-", "") not in os.path.basename(os.path.dirname(f)).replace("_", "").replace("-", ""):
+            continue
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if "k_scan_lines<true" in k and "FETCH_SIZE_KiB_avg_per_launch" in v:
+                best = (int(2 * v["FETCH_SIZE_KiB_avg_per_launch"] * 1024 +
+                            v.get("WRITE_SIZE_KiB_avg_per_launch", 0) * 1024), os.path.relpath(f, ROOT))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +183,7 @@ def main():
         algo_path = n_own + 48 * out.n_own_records
         if decode:
             algo_path += int(out.res.n_qual_bytes) + 8 * out.n_own_records
+        traffic = pmc_traffic(args.workload)
         line = {
             "metric": "GB/s FASTQ parsed",
             "value": round(value, 3),
@@ -192,7 +214,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic[0] if traffic else None,
+                "traffic_source": traffic[1] if traffic else None,
                 "algorithmic_bytes_per_launch": algo,
                 "avg_launch_ms": round(t_idx * 1e3, 4),
             },

@@ -99,8 +99,10 @@ struct WAcc {
     int64_t wpos0;        // buffer coordinate of window-relative position 0
     uint32_t *defer;      // group flag word: bit 2 is set when a lookup needs index tiles that
                           // are not computed yet (the scan kernel runs chunk by chunk ahead of us)
-    __device__ WAcc(const LineIndex &l, const uint32_t *we, int32_t nw, int32_t t1, int64_t p0, uint32_t *df)
-        : L(l), went(we), nwin(nw), wt1(t1), wpos0(p0), defer(df) {}
+    int32_t ready;        // index tiles [0, ready) are valid
+    __device__ WAcc(const LineIndex &l, const uint32_t *we, int32_t nw, int32_t t1, int64_t p0, uint32_t *df,
+                    int32_t rdy)
+        : L(l), went(we), nwin(nw), wt1(t1), wpos0(p0), defer(df), ready(rdy) {}
     __device__ bool next(Hd &h) const {
         if (h.idx != -1) {
             const int32_t j = (h.idx == -2) ? 0 : h.idx + 1;
@@ -114,9 +116,9 @@ struct WAcc {
         }
         int32_t t = h.g.tile + 1;
         if (t < 0) t = 0;
-        while (t < L.ready && L.cnt[t] == 0) t++;
-        if (t >= L.ready) {
-            if (L.ready < L.ntiles && defer) atomicOr(defer, 4u);
+        while (t < ready && L.cnt[t] == 0) t++;
+        if (t >= ready) {
+            if (ready < L.ntiles && defer) atomicOr(defer, 4u);
             return false;
         }
         h.g.tile = t; h.g.i = 0;
@@ -213,61 +215,70 @@ __device__ __forceinline__ int count_below(const unsigned long long (&m)[PER], i
 // index entries; everything else (long wrapped records, window / buffer edges, records
 // that continue beyond the window) goes through these two functions.  They are kept
 // out of line on purpose: inlined at every use they made the kernel ~100 KB of code.
-struct WinCtx {
-    const LineIndex *L;
-    const uint32_t *went;
-    uint32_t *defer;
-    int32_t nwin, wt1, own_hi, eof;
-    int64_t wpos0, len;
-};
+// Everything is passed and returned BY VALUE (registers): a struct whose address is taken
+// in the kernel lives in per-lane scratch memory, which cost ~160 B of HBM writes per lane.
+// Lg points to a copy of the LineIndex in global memory for the same reason.
 struct NodeOut {
     uint32_t st, nxn, sx, f0, f1, f3, f4, ext;
 };
+struct FollowOut {
+    Rec r;
+    int64_t after;
+};
 
-__device__ __noinline__ void node_generic(const WinCtx *w, int k, NodeOut *o)
+__device__ __noinline__ NodeOut node_generic(const LineIndex *Lg, const uint32_t *went, int nwin, int wt1,
+                                             int own_hi, int eof, int ready, int64_t wpos0, int64_t len,
+                                             uint32_t *defer, int k)
 {
-    const WAcc acc(*w->L, w->went, w->nwin, w->wt1, w->wpos0, w->defer);
+    const WAcc acc(*Lg, went, nwin, wt1, wpos0, defer, ready);
     WH hk; hk.idx = k; hk.g = H{0, 0};
     WH hm, hm1;
     Rec r;
-    compute_record(acc, hk, w->wpos0 + (int64_t)(w->went[k] & WP_MASK), w->len, w->eof, r, hm, hm1);
-    o->st = (uint32_t)(r.final_ ? ST_FINAL : r.status);
-    o->nxn = 0xFFFDu; o->sx = 0; o->f0 = o->f1 = o->f3 = o->f4 = 0; o->ext = 0;
+    compute_record(acc, hk, wpos0 + (int64_t)(went[k] & WP_MASK), len, eof, r, hm, hm1);
+    NodeOut o;
+    o.st = (uint32_t)(r.final_ ? ST_FINAL : r.status);
+    o.nxn = 0xFFFDu; o.sx = 0; o.f0 = o.f1 = o.f3 = o.f4 = 0; o.ext = 0;
     if ((r.status == ST_COMPLETE) || r.final_) {
-        const int64_t q0 = r.p0 - w->wpos0, q1 = r.p1 - w->wpos0, q3 = r.p3 - w->wpos0, q4 = r.p4 - w->wpos0;
-        if (q4 > 0xFFFFFFF0ll) o->ext = 1;
-        o->f0 = (uint32_t)q0; o->f1 = (uint32_t)q1; o->f3 = (uint32_t)q3; o->f4 = (uint32_t)q4;
+        const int64_t q0 = r.p0 - wpos0, q1 = r.p1 - wpos0, q3 = r.p3 - wpos0, q4 = r.p4 - wpos0;
+        if (q4 > 0xFFFFFFF0ll) o.ext = 1;
+        o.f0 = (uint32_t)q0; o.f1 = (uint32_t)q1; o.f3 = (uint32_t)q3; o.f4 = (uint32_t)q4;
     }
     if (r.status == ST_COMPLETE) {
         WH hs; int64_t Ps;
         if (find_cand(acc, hm1, r.p5 - 1, hs, Ps)) {
             if (hs.idx >= 0) {
-                const uint32_t wj = w->went[hs.idx];
+                const uint32_t wj = went[hs.idx];
                 const uint32_t nid = (wj >> WN_SHIFT) & WN_MASK;
-                if (hs.idx < w->own_hi && nid != NO_NODE) o->nxn = nid;
-                else { o->nxn = 0xFFFCu; o->sx = wj & WP_MASK; }
-            } else o->nxn = 0xFFFFu;
-        } else o->nxn = 0xFFFEu;
+                if (hs.idx < own_hi && nid != NO_NODE) o.nxn = nid;
+                else { o.nxn = 0xFFFCu; o.sx = wj & WP_MASK; }
+            } else o.nxn = 0xFFFFu;
+        } else o.nxn = 0xFFFEu;
     }
+    return o;
 }
 
 // the scanner call of node k again (all of it: posbuffer, status) and the candidate the
 // chain continues with after it (Y_NOCAND if none) -- used once per group at most
-__device__ __noinline__ void node_followup(const WinCtx *w, int k, Rec *r, int64_t *after)
+__device__ __noinline__ FollowOut node_followup(const LineIndex *Lg, const uint32_t *went, int nwin, int wt1,
+                                                int eof, int ready, int64_t wpos0, int64_t len,
+                                                uint32_t *defer, int k)
 {
-    const WAcc acc(*w->L, w->went, w->nwin, w->wt1, w->wpos0, w->defer);
+    const WAcc acc(*Lg, went, nwin, wt1, wpos0, defer, ready);
     WH hk; hk.idx = k; hk.g = H{0, 0};
     WH hm, hm1, hs;
     int64_t Ps;
-    compute_record(acc, hk, w->wpos0 + (int64_t)(w->went[k] & WP_MASK), w->len, w->eof, *r, hm, hm1);
-    *after = Y_NOCAND;
-    if (r->status == ST_COMPLETE && find_cand(acc, hm1, r->p5 - 1, hs, Ps)) *after = Ps;
+    FollowOut f;
+    compute_record(acc, hk, wpos0 + (int64_t)(went[k] & WP_MASK), len, eof, f.r, hm, hm1);
+    f.after = Y_NOCAND;
+    if (f.r.status == ST_COMPLETE && find_cand(acc, hm1, f.r.p5 - 1, hs, Ps)) f.after = Ps;
+    return f;
 }
 
 // first "\n@" match at >= X among the window/global entries after window index `from`
-__device__ __noinline__ int64_t cand_after(const WinCtx *w, int from, int64_t X)
+__device__ __noinline__ int64_t cand_after(const LineIndex *Lg, const uint32_t *went, int nwin, int wt1,
+                                           int ready, int64_t wpos0, uint32_t *defer, int from, int64_t X)
 {
-    const WAcc acc(*w->L, w->went, w->nwin, w->wt1, w->wpos0, w->defer);
+    const WAcc acc(*Lg, went, nwin, wt1, wpos0, defer, ready);
     WH hb; hb.g = H{0, 0};
     hb.idx = from;
     WH hs; int64_t Ps;
@@ -279,8 +290,9 @@ __device__ __noinline__ int64_t cand_after(const WinCtx *w, int from, int64_t X)
 // chains with more than SEG_LIMIT jumps (otherwise such a group is reported irregular
 // and the host re-runs the stage with the DOUBLING configuration).
 template <int PER, int EMAX, int WPB, bool DOUBLING>
-__global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, int64_t offset, int eof, ChainBufs B,
-                                                         int g0, int g1, int only_deferred, int ablate)
+__global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const LineIndex *__restrict__ Lg,
+                                                         int64_t offset, int eof, ChainBufs B, int g0, int g1,
+                                                         int only_deferred, int ablate)
 {
     constexpr int NMAX = PER * 64;
     constexpr int ND = DOUBLING ? NMAX : 1;
@@ -461,9 +473,8 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, int64_t of
 
     if (prof) ts[3] = clock64();
     // ---- one scanner call + successor search per node (node c = u*64 + lane) -------------
-    WinCtx wc;
-    wc.L = &L; wc.went = went; wc.defer = B.flags + g; wc.nwin = nwin; wc.wt1 = wt1; wc.own_hi = own_hi; wc.eof = eof;
-    wc.wpos0 = wpos0; wc.len = len;
+    uint32_t *const defer = B.flags + g;
+    const int ready = L.ready;
     // per node ONE register: successor (16 bits) | status (5 bits, biased by 1) << 16 |
     // mi << 21 (batch index of the "\n+" entry) | sj << 25 (batch index of the successor) |
     // fast << 29 (set: fields are re-read from the window when the record is staged)
@@ -528,8 +539,8 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, int64_t of
         if (pend) {
             const int u = __ffs((int)pend) - 1;
             pend &= pend - 1u;
-            NodeOut o;
-            node_generic(&wc, nidx[u * 64 + lane], &o);
+            const NodeOut o = node_generic(Lg, went, nwin, wt1, own_hi, eof, ready, wpos0, len, defer,
+                                           nidx[u * 64 + lane]);
             const uint32_t v = o.nxn | ((o.st + 1u) << 16) | (o.ext ? (1u << 30) : 0u);
 #pragma unroll
             for (int q = 0; q < PER; q++) if (q == u) info[q] = v;
@@ -677,7 +688,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, int64_t of
         if (ncomp == 0) {
             if (lane == 0) {
                 // no candidate in the run-in tail / own tiles: the chain passes over this group
-                Y = cand_after(&wc, (own_hi > 0) ? own_hi - 1 : -2, offset);
+                Y = cand_after(Lg, went, nwin, wt1, ready, wpos0, defer, (own_hi > 0) ? own_hi - 1 : -2, offset);
                 EX = Y;
                 if (Y == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
             }
@@ -692,15 +703,13 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, int64_t of
                     else if (nx == SN_AHEAD && (li >> 29 & 1u))
                         after = wpos0 + (int64_t)(went[nidx[lastn] + ((li >> 25) & 15u)] & WP_MASK);
                     else {   // beyond the window (or a generic node): through the global index
-                        Rec r;
-                        node_followup(&wc, nidx[lastn], &r, &after);
+                        after = node_followup(Lg, went, nwin, wt1, eof, ready, wpos0, len, defer, nidx[lastn]).after;
                     }
                     EX = after;
                     if (after == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
                 } else {
                     // the chain stops at lastn: keep the scanner's posbuffer of that call
-                    int64_t dummy;
-                    node_followup(&wc, nidx[lastn], &tr, &dummy);
+                    tr = node_followup(Lg, went, nwin, wt1, eof, ready, wpos0, len, defer, nidx[lastn]).r;
                     EX = (st == ST_FINAL) ? X_END_FINAL : X_END_TERM;
                     have_term = true; tstatus = tr.status;
                 }
@@ -753,8 +762,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, int64_t of
                 const int u = __ffs((int)pend) - 1;
                 pend &= pend - 1u;
                 const int c = u * 64 + lane;
-                NodeOut no;
-                node_generic(&wc, nidx[c], &no);
+                const NodeOut no = node_generic(Lg, went, nwin, wt1, own_hi, eof, ready, wpos0, len, defer, nidx[c]);
                 StageRec o;
                 o.p0 = no.f0; o.p1 = no.f1; o.p3 = no.f3; o.p4 = no.f4;
                 stg[count_below<PER>(MB, c) - d0] = o;

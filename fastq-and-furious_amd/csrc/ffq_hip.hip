@@ -56,6 +56,8 @@ struct ffq_ctx {
     int64_t stage_cap = 0;        // StageRec entries allocated
     unsigned long long *prof_d = nullptr;
     Ctl *ctl = nullptr;
+    LineIndex *d_L = nullptr;          // device copy of the LineIndex (out-of-line device functions)
+    LineIndex *h_L = nullptr;          // pinned source of that copy
     DevRes *dres = nullptr;
     // pinned mirrors
     Ctl *h_ctl = nullptr;
@@ -106,6 +108,8 @@ extern "C" int ffq_ctx_create(int device, ffq_ctx **out)
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&c->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipMalloc((void **)&c->dres, sizeof(DevRes));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_L, sizeof(LineIndex));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_L, sizeof(LineIndex), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_res, sizeof(DevRes), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -136,7 +140,8 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
     free_chain(c);
-    (void)hipFree(c->ctl); (void)hipFree(c->dres);
+    (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L);
+    if (c->h_L) (void)hipHostFree(c->h_L);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -334,6 +339,8 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
         LineIndex L;
         L.d = d_buf; L.n = n_bytes; L.s = s; L.ntiles = (int32_t)ntiles; L.ready = (int32_t)ntiles; L.pad_ = 0;
         L.ent = c->ent; L.cnt = c->cnt; L.ovf = c->ovf; L.pool = c->pool;
+        *c->h_L = L;
+        HIPCHK(hipMemcpyAsync(c->d_L, c->h_L, sizeof(LineIndex), hipMemcpyHostToDevice, c->stream));
         const bool serial = (flags & FFQ_F_FORCE_SERIAL) != 0;
         const char *abl = getenv("FFQ_ABLATE");
         const int ablate = abl ? atoi(abl) : 0;
@@ -374,12 +381,12 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
             Lr.ready = ready;
             if (!dense_cfg)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
-                                   dim3((g1 - g0 + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sB, Lr, offset,
-                                   eof, cb, g0, g1, only_deferred, ablate);
+                                   dim3((g1 - g0 + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sB, Lr,
+                                   (const LineIndex *)c->d_L, offset, eof, cb, g0, g1, only_deferred, ablate);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
                                    dim3((g1 - g0 + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sB, Lr,
-                                   offset, eof, cb, g0, g1, only_deferred, ablate);
+                                   (const LineIndex *)c->d_L, offset, eof, cb, g0, g1, only_deferred, ablate);
         };
 
         HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
