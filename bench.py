@@ -165,7 +165,7 @@ def main():
         total_records, total_bytes = int(tot[0].item()), int(tot[1].item())
     else:
         total_records, total_bytes = out.n_own_records, n_own
-    assert out.res.path == 0, "the parallel chain path must be the one measured (got the serial walker)"
+    assert out.res.path in (0, 3), "a parallel chain path must be the one measured (got path %d)" % out.res.path
 
     # ---- parity spot check on the measured output (size-independent properties) -----
     shard.verify(table, out)

@@ -55,6 +55,10 @@ struct ffq_ctx {
     ChainBufs cb = {};
     int64_t stage_cap = 0;        // StageRec entries allocated
     unsigned long long *prof_d = nullptr;
+    unsigned int *sbsum = nullptr;       // newlines per 64 tiles (k_scan_lines) -> ordinal bases
+    long long *sbbase = nullptr;
+    Fast4Hdr *hdr4 = nullptr;
+    TermInfo4 *tinfo4 = nullptr;
     Ctl *ctl = nullptr;
     LineIndex *d_L = nullptr;          // device copy of the LineIndex (out-of-line device functions)
     LineIndex *h_L = nullptr;          // pinned source of that copy
@@ -125,6 +129,8 @@ static void free_chain(ffq_ctx *c)
     (void)hipFree(c->cb.y); (void)hipFree(c->cb.exit); (void)hipFree(c->cb.cnt); (void)hipFree(c->cb.flags);
     (void)hipFree(c->cb.lines); (void)hipFree(c->cb.qb); (void)hipFree(c->cb.term); (void)hipFree(c->cb.stage);
     (void)hipFree(c->cb.rloc); (void)hipFree(c->cb.qloc); (void)hipFree(c->cb.part); (void)hipFree(c->cb.mins);
+    (void)hipFree(c->sbsum); (void)hipFree(c->sbbase); (void)hipFree(c->tinfo4);
+    c->sbsum = nullptr; c->sbbase = nullptr; c->tinfo4 = nullptr;
     c->cb = ChainBufs{};
     c->stage_cap = 0;
     c->cap_groups = 0;
@@ -140,7 +146,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
     free_chain(c);
-    (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L);
+    (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -184,6 +190,13 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
     HIPCHK(hipMalloc((void **)&c->cb.qloc, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.part, (size_t)nblk * 4 * 8));
     HIPCHK(hipMalloc((void **)&c->cb.mins, 16));
+    {
+        const int64_t nsb = (ntiles + SB_TILES - 1) / SB_TILES;
+        HIPCHK(hipMalloc((void **)&c->sbsum, (size_t)nsb * sizeof(unsigned int)));
+        HIPCHK(hipMalloc((void **)&c->sbbase, (size_t)nsb * sizeof(long long)));
+        HIPCHK(hipMalloc((void **)&c->tinfo4, (size_t)ntiles * sizeof(TermInfo4)));
+        if (!c->hdr4) HIPCHK(hipMalloc((void **)&c->hdr4, sizeof(Fast4Hdr)));
+    }
     c->cap_tiles = ntiles;
     c->cap_groups = ng;
     return FFQ_OK;
@@ -334,7 +347,7 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
     int64_t *qoff = decode ? d_qoff : nullptr;
 
     int retries = 0;
-    bool dense_cfg = false;
+    bool dense_cfg = false, fast4_failed = false;
     for (;;) {
         LineIndex L;
         L.d = d_buf; L.n = n_bytes; L.s = s; L.ntiles = (int32_t)ntiles; L.ready = (int32_t)ntiles; L.pad_ = 0;
@@ -344,23 +357,14 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
         const bool serial = (flags & FFQ_F_FORCE_SERIAL) != 0;
         const char *abl = getenv("FFQ_ABLATE");
         const int ablate = abl ? atoi(abl) : 0;
-        hipStream_t sA = c->stream, sB = c->stream2;
         const int k1abl = getenv("FFQ_K1_ABLATE") ? atoi(getenv("FFQ_K1_ABLATE")) : 0;
+        hipStream_t sA = c->stream, sB = c->stream2;
+        // the four-line fast path (ffq_rows4.h) is tried first unless qualities are decoded
+        // (their CSR offsets need the general path's per-group sums) or it already failed
+        const bool try_fast4 = !serial && !decode && !dense_cfg && !fast4_failed && ablate == 0 &&
+                               getenv("FFQ_NO_FAST4") == nullptr;
+        const int nsb = (int)((ntiles + SB_TILES - 1) / SB_TILES);
 
-        // The scan kernel runs chunk by chunk on stream A; the chain kernel of the groups
-        // whose window lies inside the finished chunks runs behind it on stream B (it is
-        // latency-bound and hides under the HBM-bound scan).
-        // (measured on MI355X: co-running the two kernels slows the scan kernel by more than
-        //  the chain kernel gains, so by default everything is one chunk; FFQ_CHUNK_TILES
-        //  re-enables the chunked overlap for experiments)
-        int64_t CH_TILES = 1ll << 40;
-        if (const char *e = getenv("FFQ_CHUNK_TILES")) CH_TILES = std::max<int64_t>(atoll(e), 64);
-        const int nch = (int)((ntiles + CH_TILES - 1) / CH_TILES);
-        while ((int)c->chunk_ev.size() < nch) {
-            hipEvent_t ev;
-            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            c->chunk_ev.push_back(ev);
-        }
         ChainBufs cb = c->cb;
         const int nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
         if (!serial) {
@@ -389,56 +393,75 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
                                    (const LineIndex *)c->d_L, offset, eof, cb, g0, g1, only_deferred, ablate);
         };
 
+        // ---- line index: one launch over the full tiles on stream A; the ragged last tile
+        //      (byte-wise loads, one workgroup) beside it on stream B ---------------------------
         HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
+        HIPCHK(hipMemsetAsync(c->sbsum, 0, (size_t)nsb * sizeof(unsigned int), sA));
         HIPCHK(hipEventRecord(c->ev[0], sA));
-        HIPCHK(hipStreamWaitEvent(sB, c->ev[0], 0));        // stream B starts behind the control-block reset
-        int gdone = 0;
-        for (int ch = 0; ch < nch; ch++) {
-            const int64_t t0 = (int64_t)ch * CH_TILES, t1 = std::min<int64_t>(ntiles, t0 + CH_TILES);
-            {
-                // full tiles in one launch, the ragged last tile of the buffer alone
-                const int64_t nfull = std::max<int64_t>(std::min<int64_t>(t1, n_bytes >> TILE_SHIFT), t0);
-                // the ragged last tile (byte-wise loads, one workgroup) goes first on stream B so
-                // that it runs beside the main launch instead of after it
-                if (t1 > nfull)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 4>), dim3((unsigned)(t1 - nfull)), dim3(256), 0,
-                                       sB, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
-                                       (int)nfull, 0);
-                if (nfull > t0)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 6>), dim3((unsigned)(nfull - t0)), dim3(256), 0,
-                                       sA, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
-                                       (int)t0, k1abl);
-            }
-            HIPCHK(hipEventRecord(c->chunk_ev[ch], sA));
-            if (serial) continue;
-            HIPCHK(hipStreamWaitEvent(sB, c->chunk_ev[ch], 0));
-            const int gend = (ch == nch - 1) ? ngroups : (int)std::max<int64_t>((t1 - 1) / OWN_T, 0);
-            if (gend > gdone) {
-                HIPCHK(hipMemsetAsync(cb.flags + gdone, 0, (size_t)(gend - gdone) * 4, sB));
-                launch_chain(gdone, gend, (int)t1, 0);
-                gdone = gend;
-            }
+        HIPCHK(hipStreamWaitEvent(sB, c->ev[0], 0));        // stream B starts behind the resets
+        {
+            const int64_t nfull = n_bytes >> TILE_SHIFT;
+            if (ntiles > nfull)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 4>), dim3((unsigned)(ntiles - nfull)), dim3(256), 0,
+                                   sB, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
+                                   (int)nfull, 0, c->sbsum);
+            if (nfull > 0)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 6>), dim3((unsigned)nfull), dim3(256), 0, sA,
+                                   d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
+                                   c->sbsum);
         }
         HIPCHK(hipEventRecord(c->ev[1], sA));
-        if (!serial) {
-            const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
-            if (nch > 1) launch_chain(0, ngroups, (int)ntiles, 1);      // groups that had to wait for later chunks
-            HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sB));
-            hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sB, cb);
-            hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sB, cb, nblk, eof, offset, add, c->dres);
-            hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sB, cb, (const DevRes *)c->dres, add, d_table,
-                               table_cap, qoff, d_buf, s, qual_add, decode ? d_qual : (int8_t *)nullptr, qual_cap);
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sB, c->dres, d_table, table_cap, add, offset, qoff);
-        } else {
-            HIPCHK(hipStreamWaitEvent(sB, c->chunk_ev[nch - 1], 0));
+        HIPCHK(hipStreamWaitEvent(sB, c->ev[1], 0));
+
+        bool fast4_ok = false;
+        if (try_fast4) {
+            // ---- plain four-line records: rows straight from newline ordinals, then validated -----
+            hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sB, L, (const unsigned int *)c->sbsum, nsb, c->sbbase,
+                               offset, c->hdr4);
+            hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sB, L,
+                               (const long long *)c->sbbase, eof, add, c->hdr4, c->tinfo4, d_table, table_cap);
+            hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sB, L, c->hdr4, (const TermInfo4 *)c->tinfo4, eof,
+                               offset, add, (const int64_t *)d_table, table_cap, c->dres);
+            HIPCHK(hipEventRecord(c->ev[4], sB));
+            HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
+            HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(sB));
+            HIPCHK(hipStreamSynchronize(sA));
+            if (!(c->h_ctl->err & ERR_POOL) && !c->h_res->fallback) fast4_ok = true;
+            else if (!(c->h_ctl->err & ERR_POOL)) fast4_failed = true;
         }
-        HIPCHK(hipEventRecord(c->ev[2], sB));
-        HIPCHK(hipEventRecord(c->ev[3], sB));
-        HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
-        HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(sB));
-        HIPCHK(hipStreamSynchronize(sA));
+        if (fast4_ok) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[4])); res->ms_chain = ms;
+            res->ms_decode = 0;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[4])); res->ms_total = ms;
+            fill_result(res, *c->h_res, 3, retries);
+            break;
+        }
+        if (!(try_fast4 && (c->h_ctl->err & ERR_POOL))) {
+            // ---- general path: chain summaries -> resolve -> expand (or the serial walker below) ----
+            if (!serial) {
+                const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
+                HIPCHK(hipMemsetAsync(cb.flags, 0, (size_t)ngroups * 4, sB));
+                launch_chain(0, ngroups, (int)ntiles, 0);
+                HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sB));
+                hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sB, cb);
+                hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sB, cb, nblk, eof, offset, add, c->dres);
+                hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sB, cb, (const DevRes *)c->dres, add, d_table,
+                                   table_cap, qoff, d_buf, s, qual_add, decode ? d_qual : (int8_t *)nullptr, qual_cap);
+                hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sB, c->dres, d_table, table_cap, add, offset,
+                                   qoff);
+            }
+            HIPCHK(hipEventRecord(c->ev[2], sB));
+            HIPCHK(hipEventRecord(c->ev[3], sB));
+            HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
+            HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(sB));
+            HIPCHK(hipStreamSynchronize(sA));
+        }
 
         if (c->h_ctl->err & ERR_POOL) {
             // dense tiles did not fit the overflow pool: size it for what was asked and re-run

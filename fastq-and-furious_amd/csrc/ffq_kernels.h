@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
                                                     unsigned long long *__restrict__ ovf,
                                                     uint16_t *__restrict__ pool,
                                                     unsigned long long pool_cap, Ctl *ctl, int tile0,
-                                                    int ablate)
+                                                    int ablate, unsigned int *__restrict__ sbsum)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_list[SLOT];
     __shared__ uint32_t s_wtot[4];
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
     if (tid == 0 && ablate != 7) {
         cnt[tile] = total;
         ovf[tile] = pbase;
+        if (sbsum) atomicAdd(&sbsum[tile >> 6], total);     // newlines per 64 tiles (fast four-line path)
     }
     if (ablate == 6 || ablate == 7) return;
     if (!dense) {
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
 
 }  // namespace ffq
 
-#include "ffq_chain.h"
+#include "ffq_rows4.h"
 
 namespace ffq {
 

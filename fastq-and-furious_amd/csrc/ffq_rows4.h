@@ -1,0 +1,350 @@
+// ffq_rows4.h -- fast path of the record chain for plain four-line FASTQ.
+//
+// On input where every record is exactly four lines (header, sequence, '+' line,
+// quality) the chain of readfastq_iter (/root/reference/src/fastqandfurious.py:251-279)
+// has a closed form over NEWLINE ORDINALS: if the chain's first "\n@" match is newline
+// number j0, record k is made of newlines j0+4k .. j0+4k+4.  The
+// scanner call of /root/reference/src/_fastqandfurious.c:25-153 on record k then reads
+//   e0 = nl[j0+4k]    the "\n@" match            pos0 = P(e0)+1
+//   e1 = nl[j0+4k+1]  header end  (:70-71)        pos1 = P(e1), pos2 = pos1+1
+//   e2 = nl[j0+4k+2]  "\n+" match (:87-88)        pos3 = P(e2)
+//   e3 = nl[j0+4k+3]  '+' line end (:102-103)     pos4 = P(e3)+1
+//   e4 = nl[j0+4k+4]  next "\n@" match (:62 of the next call), must lie at >= pos5-1
+// with pos5 = pos4 + pos3 - pos2 (:129).  k_rows4 evaluates every record in parallel
+// under that assumption AND checks, per record, exactly the conditions under which
+// the reference would have made the same choices (flags of e2 / e4, non-empty
+// sequence, '+' line length rule, buffer-end rules).  A record that does not satisfy
+// them is "irregular".  k_finalize4 accepts the result only if no irregular record
+// lies in front of the record the chain ends at; otherwise the general kernels
+// (ffq_chain.h) redo the work from the same line index.  So the output is either the
+// reference's chain, bit for bit, or discarded.
+//
+//   k_sbscan      exclusive scan of the per-superblock newline counts (filled by
+//                 k_scan_lines with one atomic per tile), first candidate j0
+//   k_rows4       one wave per tile: rows of the records whose "\n@" lies in the tile,
+//                 written as whole lines through an LDS transpose (48 B / record)
+//   k_finalize4   validity, record count, end state
+#pragma once
+#include "ffq_chain.h"
+
+namespace ffq {
+
+constexpr int SB_TILES = 64;                  // tiles per superblock (one ordinal base each)
+constexpr int R4_LIST = SLOT + 8;             // tile entries + look-ahead entries in LDS
+
+struct Fast4Hdr {
+    long long j0;                  // ordinal of the chain's first "\n@" match; -1: there is none
+    int32_t attempt;               // 0: fast path not applicable (decided before k_rows4)
+    int32_t pad;
+    unsigned long long irr_min;    // smallest irregular record index (~0: none)
+    unsigned long long term_min;   // smallest (k << 24 | tile & 0xFFFFFF) where the chain ends (~0: none)
+    long long n_lines;
+};
+
+struct TermInfo4 {
+    int64_t pos[6];
+    int32_t status;
+    int32_t final_;
+};
+
+// global ordinal of the first entry of tile t (the sentinel, if any, is ordinal 0)
+__device__ __forceinline__ long long tile_ordinal_base(const LineIndex &L, const long long *sbbase, int t, int lane)
+{
+    const int sb = t / SB_TILES, t0 = sb * SB_TILES;
+    const uint32_t c = (t0 + lane < t) ? L.cnt[t0 + lane] : 0u;       // SB_TILES == 64 lanes
+    return sbbase[sb] + (long long)wave_sum_u32(c) + L.s;
+}
+
+__global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, const unsigned int *__restrict__ sbsum, int nsb,
+                                                 long long *__restrict__ sbbase, int64_t offset,
+                                                 Fast4Hdr *hdr)
+{
+    __shared__ long long s_v[1024];
+    const int tid = threadIdx.x;
+    long long carry = 0;
+    for (int b0 = 0; b0 < nsb; b0 += 1024) {
+        const int b = b0 + tid;
+        const long long v = (b < nsb) ? (long long)sbsum[b] : 0;
+        s_v[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            long long x = 0;
+            if (tid >= d) x = s_v[tid - d];
+            __syncthreads();
+            s_v[tid] += x;
+            __syncthreads();
+        }
+        if (b < nsb) sbbase[b] = carry + s_v[tid] - v;
+        const long long tot = s_v[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        hdr->n_lines = carry;
+        hdr->irr_min = ~0ull;
+        hdr->term_min = ~0ull;
+        hdr->attempt = 1;
+        hdr->j0 = -1;
+        // the chain's first "\n@" match at buffer coordinate >= offset, as an ordinal
+        const GAcc a(L);
+        H h = a.before();
+        long long ord = -1;           // ordinal of h
+        long long found = -1;
+        int64_t P; int fl;
+        // entries in front of the tile that holds `offset` cannot match: skip whole tiles
+        int tskip = (int)min((int64_t)L.ntiles, max((int64_t)0, (offset - L.s) >> TILE_SHIFT));
+        if (tskip > 0) {
+            long long o = sbbase[tskip / SB_TILES] + L.s;
+            for (int t = (tskip / SB_TILES) * SB_TILES; t < tskip; t++) o += L.cnt[t];
+            // continue right before the first entry of tile tskip
+            h = H{tskip - 1, 0x7FFFFFF0};
+            ord = o - 1;
+        }
+        bool gave_up = false;
+        for (int steps = 0;; steps++) {
+            if (steps > 4096) { gave_up = true; break; }
+            bool ok;
+            if (h.tile >= 0 && h.i == 0x7FFFFFF0) {       // "after tile h.tile"
+                int t = h.tile + 1;
+                while (t < L.ntiles && L.cnt[t] == 0) t++;
+                ok = t < L.ntiles;
+                if (ok) { h.tile = t; h.i = 0; }
+            } else ok = a.next(h);
+            if (!ok) break;
+            ord++;
+            a.get(h, P, fl);
+            if ((fl & FL_AT) && P >= offset) { found = ord; break; }
+        }
+        if (gave_up) hdr->attempt = 0;
+        else {
+            hdr->j0 = found;
+            if (found >= 0) {
+                // a wrapped / non-four-line first record: do not even try
+                H h2 = h;
+                if (a.next(h2) && a.next(h2)) {
+                    a.get(h2, P, fl);
+                    if (!(fl & FL_PLUS)) hdr->attempt = 0;
+                }
+            }
+        }
+    }
+}
+
+// One wave per tile, four tiles per workgroup (no workgroup barrier).
+__global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
+                                               int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
+                                               int64_t *__restrict__ table, int64_t table_cap)
+{
+    __shared__ uint32_t s_pos_all[4][R4_LIST];      // buffer coordinate - tile base, flags in bits 30..31
+    __shared__ __attribute__((aligned(16))) int64_t s_rows_all[4][64 * 6];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wid;
+    if (t >= L.ntiles) return;
+    if (!hdr->attempt) return;
+    const long long j0 = hdr->j0;
+    uint32_t *s_pos = s_pos_all[wid];
+    int64_t *s_rows = s_rows_all[wid];
+    const int64_t len = L.len();
+
+    const int c = (int)L.cnt[t];
+    if (c > SLOT) {                    // dense tile: leave it to the general path
+        if (lane == 0) atomicMin(&hdr->irr_min, 0ull);
+        return;
+    }
+    const long long ob = tile_ordinal_base(L, sbbase, t, lane);     // ordinal of entry 0 of this tile
+    // the sentinel is entry -1 of tile 0 (ordinal 0): give tile 0 a list that starts with it
+    const int pre = (t == 0 && L.s) ? 1 : 0;
+    const long long obl = ob - pre;                                    // ordinal of list element 0
+    const int64_t tbase = ((int64_t)t << TILE_SHIFT) + L.s;            // buffer coordinate of tile offset 0
+    if (j0 < 0) {
+        // no "\n@" at all: the chain ends at once with MISSING_SEQHEADER_BEGIN
+        if (t == 0 && lane == 0) {
+            TermInfo4 &ti = tinfo[0];
+            for (int i = 0; i < 6; i++) ti.pos[i] = -1;
+            ti.status = ST_HEAD_BEG; ti.final_ = 0;
+            atomicMin(&hdr->term_min, 0ull);
+        }
+        return;
+    }
+    if (pre && lane == 0) {
+        const uint8_t b0 = L.n > 0 ? L.d[0] : 0;
+        const uint32_t fl = (b0 == '@') ? FL_AT : (b0 == '+') ? FL_PLUS : 0;
+        s_pos[0] = 0x0FFFFFFFu | (fl << 30);         // position -1 relative to tbase: special-cased below
+    }
+    const uint16_t *src = L.ent + (int64_t)t * SLOT;
+    for (int i = lane; i < c; i += 64) {
+        const uint32_t e = src[i];
+        s_pos[pre + i] = (e & OFF_MASK) | ((e >> 14) << 30);
+    }
+    // look-ahead: the first entries of the following tiles (a record needs 4 more newlines)
+    int nl = pre + c;
+    bool idx_end = false;           // the look-ahead ran into the end of the index
+    {
+        int tt = t + 1, got = 0;
+        while (got < 5) {
+            if (tt >= L.ntiles) { idx_end = true; break; }
+            const int cc = (int)L.cnt[tt];
+            if (cc > SLOT) break;
+            const int take = min(cc, 5 - got);
+            if (lane < take) {
+                const uint32_t e = L.ent[(int64_t)tt * SLOT + lane];
+                s_pos[nl + got + lane] = ((uint32_t)(tt - t) << TILE_SHIFT) + (e & OFF_MASK) | ((e >> 14) << 30);
+            }
+            got += take;
+            tt++;
+            if (tt - t > 60000) break;              // positions must stay below 2^30
+        }
+        nl += got;
+    }
+    wave_sync();
+    const int nown = pre + c;                        // list elements this tile owns
+
+    // records whose "\n@" is list element i: ordinal obl + i = j0 + 4k
+    long long kfirst = -1;
+    int nrec_tile = 0;
+    bool tile_term_done = false;
+    {
+        // first owned element with ordinal >= j0 and (ordinal - j0) % 4 == 0
+        long long i0 = (obl >= j0) ? ((4 - ((obl - j0) & 3)) & 3) : (j0 - obl);
+        if (i0 < nown) {
+            kfirst = (obl + i0 - j0) >> 2;
+            nrec_tile = (int)((nown - i0 + 3) >> 2);
+        }
+        // positions of list elements: (s_pos & 0x0FFFFFFF) + tbase, the sentinel is coordinate 0
+        for (int r0 = 0; r0 < nrec_tile; r0 += 64) {
+            const int r = r0 + lane;
+            const bool act = r < nrec_tile;
+            const int i = (int)i0 + 4 * r;
+            int64_t p0 = 0, p1 = 0, p3 = 0, p4 = 0, p5 = 0;
+            int cls = 0;          // 0 regular COMPLETE, 1 irregular, 2 chain ends here (status below), 3 complete and last
+            int status = ST_COMPLETE;
+            bool fin = false;
+            if (act) {
+                const long long k = kfirst + r;
+                const int have = nl - i;           // list elements from e0 on (e0 included)
+                auto POS = [&](int q) -> int64_t {
+                    const uint32_t w = s_pos[i + q];
+                    return ((w & 0x0FFFFFFFu) == 0x0FFFFFFFu) ? (int64_t)0 : tbase + (int64_t)(w & 0x0FFFFFFFu);
+                };
+                auto FLG = [&](int q) -> uint32_t { return s_pos[i + q] >> 30; };
+                const int64_t P0 = POS(0);
+                p0 = P0 + 1; p1 = p3 = p4 = p5 = -1;
+                // fewer elements than needed: a real end only if the index itself ends there
+                if (have < 2) { cls = idx_end ? 2 : 1; status = ST_HEAD_END; }
+                else {
+                    const int64_t P1 = POS(1);
+                    if (P1 > len - 2) { cls = 2; status = ST_HEAD_END; }
+                    else {
+                        p1 = P1;
+                        if (have < 3) { cls = idx_end ? 2 : 1; status = ST_SEQ_END; }
+                        else {
+                            const int64_t P2 = POS(2);
+                            if (!(FLG(2) & FL_PLUS) || P2 < P1 + 2) cls = 1;      // wrapped / empty read: not this path
+                            else {
+                                p3 = P2;
+                                if (P2 + 2 >= len) { cls = 2; status = ST_QUALHEAD_END; }
+                                else if (have < 4) { cls = idx_end ? 2 : 1; status = ST_QUALHEAD_END; }
+                                else {
+                                    const int64_t P3 = POS(3);
+                                    if (P3 > len - 2) { cls = 2; status = ST_QUALHEAD_END; }
+                                    else if ((P3 - P2 - 1 > 1) && (P3 - P2 != P1 - P0)) { cls = 2; status = ST_INVALID; }
+                                    else {
+                                        p4 = P3 + 1;
+                                        const int64_t qe = p4 + P2 - P1 - 1;
+                                        if (qe + 2 >= len) {
+                                            cls = 2; status = ST_QUAL_END;
+                                            if (eof && qe < len) { p5 = qe; fin = true; }
+                                        } else {
+                                            p5 = qe;
+                                            // the next call must find e4: "\n@" at >= qe - 1
+                                            if (have < 5) cls = idx_end ? 3 : 1;
+                                            else if (!(FLG(4) & FL_AT) || POS(4) < qe - 1) cls = 1;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (cls == 1) atomicMin(&hdr->irr_min, (unsigned long long)k);
+                else if (cls == 2 || cls == 3) {
+                    // where the chain ends: cls 2 -> at record k (status of its call); cls 3 -> after
+                    // record k: the next call finds no "\n@" at all
+                    const unsigned long long kk = (unsigned long long)(cls == 3 ? k + 1 : k);
+                    atomicMin(&hdr->term_min, (kk << 24) | (unsigned long long)(t & 0xFFFFFF));
+                }
+            }
+            // per tile: the terminal information of the smallest k (lanes are in k order)
+            const unsigned long long tm = __ballot(act && (cls == 2 || cls == 3));
+            if (tm != 0ull && !tile_term_done) {
+                tile_term_done = true;
+                if (lane == __ffsll((long long)tm) - 1) {
+                    TermInfo4 ti;
+                    if (cls == 3) {
+                        for (int q = 0; q < 6; q++) ti.pos[q] = -1;
+                        ti.status = ST_HEAD_BEG; ti.final_ = 0;
+                    } else {
+                        ti.pos[0] = p0; ti.pos[1] = p1; ti.pos[2] = (p1 >= 0) ? p1 + 1 : -1;
+                        ti.pos[3] = p3; ti.pos[4] = p4; ti.pos[5] = p5;
+                        ti.status = status; ti.final_ = fin ? 1 : 0;
+                    }
+                    tinfo[t] = ti;
+                }
+            }
+            // rows: COMPLETE records (cls 0, 3) and the final record
+            const bool emit = act && (cls == 0 || cls == 3 || (cls == 2 && fin));
+            int64_t *mine = s_rows + lane * 6;
+            mine[0] = p0 + add; mine[1] = p1 + add; mine[2] = p1 + 1 + add;
+            mine[3] = p3 + add; mine[4] = p4 + add; mine[5] = p5 + add;
+            wave_sync();
+            // rows of one chunk are consecutive in the table: 16-byte pieces, consecutive lanes ->
+            // consecutive pieces; a row is written iff its record emits
+            const unsigned long long em = __ballot(emit);
+            const int64_t rowbase = kfirst + r0;
+            const longlong2 *srcr = reinterpret_cast<const longlong2 *>(s_rows);
+            longlong2 *dst = reinterpret_cast<longlong2 *>(table + rowbase * 6);
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int q = lane + u * 64;
+                const int row = q / 3;
+                if (((em >> row) & 1ull) && rowbase + row < table_cap) dst[q] = srcr[q];
+            }
+            wave_sync();
+        }
+    }
+}
+
+// validity + result block (end state per fastqandfurious.py:256-279)
+__global__ void k_finalize4(LineIndex L, Fast4Hdr *hdr, const TermInfo4 *__restrict__ tinfo, int eof,
+                            int64_t offset, int64_t add, const int64_t *__restrict__ table, int64_t table_cap,
+                            DevRes *res)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    res->n_lines = hdr->n_lines;
+    res->n_qual_bytes = 0;
+    res->term_group = -1;
+    res->has_final = 0;
+    const unsigned long long tm = hdr->term_min, im = hdr->irr_min;
+    const unsigned long long tk = tm >> 24;
+    if (!hdr->attempt || tm == ~0ull || (im != ~0ull && im <= tk)) { res->fallback = 1; return; }
+    res->fallback = 0;
+    const int tt = (int)(tm & 0xFFFFFF);
+    const TermInfo4 ti = tinfo[tt];
+    const int status = ti.status;
+    res->last_status = status;
+    for (int i = 0; i < 6; i++) res->last_pos[i] = (ti.pos[i] >= 0) ? ti.pos[i] + add : -1;
+    const long long ncomplete = (long long)tk;
+    res->n_records = ncomplete + (ti.final_ ? 1 : 0);
+    res->has_final = ti.final_ ? 1 : 0;
+    int end;
+    if (ti.final_) end = 0;
+    else if (status == ST_HEAD_BEG) end = eof ? 0 : 1;
+    else if (eof) end = (status == ST_QUAL_END) ? 2 : (status == ST_INVALID) ? 4 : 3;
+    else end = (status == ST_INVALID) ? 4 : 1;
+    res->end_state = end;
+    if (ncomplete > 0 && ncomplete <= table_cap) res->end_offset = table[(ncomplete - 1) * 6 + 5] - add - 1;
+    else res->end_offset = offset;
+}
+
+}  // namespace ffq

@@ -78,7 +78,8 @@ typedef struct ffq_scan_result {
                                rule, the final record's row                              */
     int32_t last_status;    /* status of that last call                                   */
     int32_t end_state;      /* FFQ_END_*                                                  */
-    int32_t path;           /* 0 = parallel chain kernels, 1 = serial walker              */
+    int32_t path;           /* 3 = four-line fast path, 0 = general chain kernels, 2 = the
+                               same with the dense LDS budget, 1 = serial walker          */
     int32_t retries;        /* internal re-runs (line-index pool growth)                  */
     int64_t n_lines;        /* newline count seen by the line-index kernel                */
     float   ms_index;       /* device time of the line-index kernel (hipEvent)            */

@@ -43,7 +43,8 @@ def test_golden_files(gpu_ctx, hipmod, golden, oracle, fn, serial):
     flags = hipmod.F_FORCE_SERIAL if serial else 0
     table, res = check_same(gpu_ctx, oracle, data, flags=flags)
     assert rows_of(table) == golden["files"][fn]["bufsizes"]["65536"]["c"]["rows"]
-    assert res.path == (1 if serial else 0)
+    # four-line files take the fast path, the wrapped one the general kernels
+    assert res.path == (1 if serial else (0 if fn == "test_multiline.fq" else 3))
 
 
 def test_template_prefix_curves_entrypos(gpu_ctx, golden):
@@ -62,7 +63,7 @@ def test_template_prefix_curves_entrypos(gpu_ctx, golden):
 
 
 @pytest.mark.parametrize("serial", (False, True))
-def test_edge_corpus(gpu_ctx, hipmod, golden, oracle, serial):
+def test_edge_corpus(gpu_ctx, hipmod, golden, oracle, serial, chain_path):
     flags = hipmod.F_FORCE_SERIAL if serial else 0
     for name, ent in golden["edge"].items():
         data = bytes.fromhex(ent["data"])
@@ -73,7 +74,7 @@ def test_edge_corpus(gpu_ctx, hipmod, golden, oracle, serial):
 
 
 @pytest.mark.parametrize("serial", (False, True))
-def test_fuzz_corpus(gpu_ctx, hipmod, golden, oracle, serial):
+def test_fuzz_corpus(gpu_ctx, hipmod, golden, oracle, serial, chain_path):
     flags = hipmod.F_FORCE_SERIAL if serial else 0
     for i, ent in enumerate(golden["fuzz"]):
         data = bytes.fromhex(ent["data"])
@@ -83,7 +84,7 @@ def test_fuzz_corpus(gpu_ctx, hipmod, golden, oracle, serial):
             assert end_matches(ent["c"], int(res.end_state), int(res.end_offset)), i
 
 
-def test_not_eof_and_offsets(gpu_ctx, oracle):
+def test_not_eof_and_offsets(gpu_ctx, oracle, chain_path):
     buf = b"\n" + golden_file("test_multiline.fq")
     for eof in (False, True):
         for off in (0, 1, 2, 137, 200, len(buf) - 3, len(buf)):
@@ -94,12 +95,20 @@ def test_not_eof_and_offsets(gpu_ctx, oracle):
     check_same(gpu_ctx, oracle, b"\n@", sentinel=False, add=0)
 
 
+@pytest.fixture(params=("fast4", "general"))
+def chain_path(request, monkeypatch):
+    """Run with the four-line fast path (default) and with the general chain kernels."""
+    if request.param == "general":
+        monkeypatch.setenv("FFQ_NO_FAST4", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("nrec,first", ((1, 0), (50, 7), (51, 0), (2000, 0), (12345, 1000), (60000, 5)))
-def test_synth_single(gpu_ctx, oracle, pkg, nrec, first):
+def test_synth_single(gpu_ctx, oracle, pkg, chain_path, nrec, first):
     from fastqandfurious_amd import synth
     data = synth.single(first, nrec, seed=42)
     table, res = check_same(gpu_ctx, oracle, data)
-    assert res.path == 0
+    assert res.path == (3 if chain_path == "fast4" else 0)
     if nrec == 2000 and first == 0:
         assert (table == np.load(os.path.join(GOLDEN_DIR, "synth_single_table.npy"))).all()
 
@@ -114,7 +123,7 @@ def test_synth_wrapped(gpu_ctx, oracle, pkg, nrec, first):
         assert (table == np.load(os.path.join(GOLDEN_DIR, "synth_wrapped_table.npy"))).all()
 
 
-def test_truncations_of_synthetic(gpu_ctx, oracle, pkg):
+def test_truncations_of_synthetic(gpu_ctx, oracle, pkg, chain_path):
     """Every way a stream can stop inside the last record."""
     from fastqandfurious_amd import synth
     data = synth.single(0, 120, seed=42).tobytes()       # > 2 tiles
