@@ -136,23 +136,34 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap)
 {
-    __shared__ uint32_t s_pos_all[4][R4_LIST];      // buffer coordinate - tile base, flags in bits 30..31
+    __shared__ uint16_t s_ent_all[4][R4_LIST];      // the tile's own entries as stored (offset | flags << 14)
+    __shared__ uint32_t s_la_all[4][8];             // look-ahead entries: position - tile base, flags << 30
     __shared__ __attribute__((aligned(16))) int64_t s_rows_all[4][64 * 6];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= L.ntiles) return;
     if (!hdr->attempt) return;
     const long long j0 = hdr->j0;
-    uint32_t *s_pos = s_pos_all[wid];
+    uint16_t *s_ent = s_ent_all[wid];
+    uint32_t *s_la = s_la_all[wid];
     int64_t *s_rows = s_rows_all[wid];
     const int64_t len = L.len();
 
+    // everything this tile usually needs in ONE memory round trip: its count, its first 256
+    // entries (4 per lane), the counts for its ordinal base, and -- speculatively -- the
+    // first 8 entries of the next tile as look-ahead
     const int c = (int)L.cnt[t];
+    const uint16_t *src = L.ent + (int64_t)t * SLOT;
+    const uint2 v0 = *reinterpret_cast<const uint2 *>(src + 4 * lane);
+    const bool have_next = t + 1 < L.ntiles;
+    const int c1 = have_next ? (int)L.cnt[t + 1] : 0;
+    uint2 vla = make_uint2(0, 0);
+    if (have_next && lane < 2) vla = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)(t + 1) * SLOT + 4 * lane);
+    const long long ob = tile_ordinal_base(L, sbbase, t, lane);     // ordinal of entry 0 of this tile
     if (c > SLOT) {                    // dense tile: leave it to the general path
         if (lane == 0) atomicMin(&hdr->irr_min, 0ull);
         return;
     }
-    const long long ob = tile_ordinal_base(L, sbbase, t, lane);     // ordinal of entry 0 of this tile
     // the sentinel is entry -1 of tile 0 (ordinal 0): give tile 0 a list that starts with it
     const int pre = (t == 0 && L.s) ? 1 : 0;
     const long long obl = ob - pre;                                    // ordinal of list element 0
@@ -170,17 +181,30 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
     if (pre && lane == 0) {
         const uint8_t b0 = L.n > 0 ? L.d[0] : 0;
         const uint32_t fl = (b0 == '@') ? FL_AT : (b0 == '+') ? FL_PLUS : 0;
-        s_pos[0] = 0x0FFFFFFFu | (fl << 30);         // position -1 relative to tbase: special-cased below
+        s_ent[0] = (uint16_t)(fl << 14);             // the sentinel: coordinate 0, special-cased below
     }
-    const uint16_t *src = L.ent + (int64_t)t * SLOT;
-    for (int i = lane; i < c; i += 64) {
-        const uint32_t e = src[i];
-        s_pos[pre + i] = (e & OFF_MASK) | ((e >> 14) << 30);
+    {
+        const uint32_t x[4] = {v0.x & 0xFFFFu, v0.x >> 16, v0.y & 0xFFFFu, v0.y >> 16};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (4 * lane + i < c) s_ent[pre + 4 * lane + i] = (uint16_t)x[i];
+        for (int i = 256 + lane; i < c; i += 64) {          // more than 256 lines in the tile
+            s_ent[pre + i] = src[i];
+        }
     }
     // look-ahead: the first entries of the following tiles (a record needs 4 more newlines)
     int nl = pre + c;
     bool idx_end = false;           // the look-ahead ran into the end of the index
-    {
+    if (have_next && c1 >= 5 && c1 <= SLOT) {
+        if (lane < 2) {
+            const uint32_t x[4] = {vla.x & 0xFFFFu, vla.x >> 16, vla.y & 0xFFFFu, vla.y >> 16};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (4 * lane + i < 5)
+                    s_la[4 * lane + i] = ((1u << TILE_SHIFT) + (x[i] & OFF_MASK)) | ((x[i] >> 14) << 30);
+        }
+        nl += 5;
+    } else {
         int tt = t + 1, got = 0;
         while (got < 5) {
             if (tt >= L.ntiles) { idx_end = true; break; }
@@ -189,7 +213,7 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
             const int take = min(cc, 5 - got);
             if (lane < take) {
                 const uint32_t e = L.ent[(int64_t)tt * SLOT + lane];
-                s_pos[nl + got + lane] = ((uint32_t)(tt - t) << TILE_SHIFT) + (e & OFF_MASK) | ((e >> 14) << 30);
+                s_la[got + lane] = (((uint32_t)(tt - t) << TILE_SHIFT) + (e & OFF_MASK)) | ((e >> 14) << 30);
             }
             got += take;
             tt++;
@@ -223,11 +247,17 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
             if (act) {
                 const long long k = kfirst + r;
                 const int have = nl - i;           // list elements from e0 on (e0 included)
+                // list element i+q: an own entry (the sentinel is element 0 of tile 0) or look-ahead
                 auto POS = [&](int q) -> int64_t {
-                    const uint32_t w = s_pos[i + q];
-                    return ((w & 0x0FFFFFFFu) == 0x0FFFFFFFu) ? (int64_t)0 : tbase + (int64_t)(w & 0x0FFFFFFFu);
+                    const int e = i + q;
+                    if (e >= nown) return tbase + (int64_t)(s_la[e - nown] & 0x3FFFFFFFu);
+                    if (pre && e == 0) return (int64_t)0;
+                    return tbase + (int64_t)(s_ent[e] & OFF_MASK);
                 };
-                auto FLG = [&](int q) -> uint32_t { return s_pos[i + q] >> 30; };
+                auto FLG = [&](int q) -> uint32_t {
+                    const int e = i + q;
+                    return (e >= nown) ? (s_la[e - nown] >> 30) : ((uint32_t)s_ent[e] >> 14);
+                };
                 const int64_t P0 = POS(0);
                 p0 = P0 + 1; p1 = p3 = p4 = p5 = -1;
                 // fewer elements than needed: a real end only if the index itself ends there
