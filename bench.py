@@ -134,28 +134,80 @@ def main():
         qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
-    def step():
-        return shard.scan(table, flags=flags, qual=qual, qoff=qoff)
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
     ms_index, ms_chain, ms_decode, ms_total = [], [], [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+
+    def note(out):
         ms_index.append(out.res.ms_index)
         ms_chain.append(out.res.ms_chain)
         ms_decode.append(out.res.ms_decode)
         ms_total.append(out.res.ms_total)
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    if world == 1:
+        # Single range: steps are submitted through two contexts that share their HIP streams,
+        # one step ahead (ffq_scan_submit / ffq_scan_wait): while the host waits for step i the
+        # kernels of step i+1 are already queued behind it.  Every step is a full scan of the
+        # resident buffer into its own output table.
+        ctx2 = hip.Context(share=ctx)
+        ctx2.reserve(shard.ext.numel())
+        ctxs = (ctx, ctx2)
+        tables = (table, torch.empty_like(table))
+        quals = (qual, torch.empty_like(qual) if decode else None)
+        qoffs = (qoff, torch.empty_like(qoff) if decode else None)
+        torch.cuda.synchronize()
+
+        def submit(i):
+            k = i & 1
+            ctxs[k].scan_submit(shard.ext.data_ptr(), shard.n_own_bytes, tables[k].data_ptr(), tables[k].shape[0],
+                                sentinel=True, eof=True, flags=flags,
+                                d_qual=quals[k].data_ptr() if decode else None,
+                                qual_cap=quals[k].numel() if decode else 0,
+                                d_qoff=qoffs[k].data_ptr() if decode else None)
+
+        def wait(i):
+            rc, res = ctxs[i & 1].scan_wait()
+            assert rc == hip.OK
+            return sharded.ScanOutput(res, int(res.n_records), 0, int(res.n_records), -1, 0)
+
+        def run(nsteps, record):
+            out = None
+            submit(0)
+            for i in range(1, nsteps):
+                submit(i)
+                out = wait(i - 1)
+                if record:
+                    note(out)
+            out = wait(nsteps - 1)
+            if record:
+                note(out)
+            return out
+
+        if args.warmup:
+            out = run(args.warmup, False)
+        barrier()
+        t0 = time.perf_counter()
+        out = run(args.steps, True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        table = tables[(args.steps - 1) & 1]
+    else:
+        def step():
+            return shard.scan(table, flags=flags, qual=qual, qoff=qoff)
+
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+            note(out)
+        barrier()
+        elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -38,7 +38,24 @@ static int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                             \
     } while (0)
 
+struct ScanArgs {
+    const uint8_t *d_buf; int64_t n_bytes; int s; int64_t offset; int eof; int64_t add; uint32_t flags;
+    int qual_add; int64_t *d_table; int64_t table_cap; int8_t *d_qual; int64_t qual_cap; int64_t *d_qoff;
+};
+
+struct ScanState {
+    bool active = false;
+    ScanArgs a{};
+    int retries = 0;
+    bool dense_cfg = false, fast4_failed = false;
+    int stage = 0;            // what the pending front consisted of: 1 fast four-line path, 2 general path
+    int64_t ntiles = 0;
+    int ngroups = 0;
+};
+
 struct ffq_ctx {
+    ScanState pend;                      // the scan enqueued by ffq_scan_submit, if any
+    bool owns_streams = true;            // false: streams borrowed from another context
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;       // chain kernels, overlapped with the scan kernel chunk by chunk
@@ -91,7 +108,12 @@ extern "C" int ffq_device_count(void)
     return n;
 }
 
-extern "C" int ffq_ctx_create(int device, ffq_ctx **out)
+static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out);
+extern "C" void ffq_ctx_destroy(ffq_ctx *c);
+
+extern "C" int ffq_ctx_create(int device, ffq_ctx **out) { return ctx_create_impl(device, nullptr, out); }
+
+static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
 {
     if (!out) return fail(FFQ_E_ARG, "ffq_ctx_create: out is NULL");
     *out = nullptr;
@@ -107,8 +129,14 @@ extern "C" int ffq_ctx_create(int device, ffq_ctx **out)
     ffq_ctx *c = new (std::nothrow) ffq_ctx();
     if (!c) return fail(FFQ_E_NOMEM, "out of host memory");
     c->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
+    if (share) {
+        // same streams as `share`: scans of the two contexts execute in submission order
+        c->stream = share->stream; c->stream2 = share->stream2; c->owns_streams = false;
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    }
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&c->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipMalloc((void **)&c->dres, sizeof(DevRes));
@@ -136,6 +164,12 @@ static void free_chain(ffq_ctx *c)
     c->cap_groups = 0;
 }
 
+extern "C" int ffq_ctx_create_shared(ffq_ctx *parent, ffq_ctx **out)
+{
+    if (!parent || !out) return fail(FFQ_E_ARG, "ffq_ctx_create_shared: NULL argument");
+    return ctx_create_impl(parent->device, parent, out);
+}
+
 extern "C" void ffq_ctx_destroy(ffq_ctx *c)
 {
     if (!c) return;
@@ -143,7 +177,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (hipEvent_t ev : c->chunk_ev) (void)hipEventDestroy(ev);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream2 && c->owns_streams) (void)hipStreamDestroy(c->stream2);
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
     free_chain(c);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
@@ -154,7 +188,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     if (c->stage_h) (void)hipHostFree(c->stage_h);
     if (c->tab_h) (void)hipHostFree(c->tab_h);
     for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->owns_streams) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -307,171 +341,183 @@ static void fill_result(ffq_scan_result *res, const DevRes &r, int path, int ret
     res->n_lines = r.n_lines;
 }
 
-extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int sentinel,
-                               int64_t offset, int eof, int64_t add, uint32_t flags, int qual_add,
-                               int64_t *d_table, int64_t table_cap, int8_t *d_qual,
-                               int64_t qual_cap, int64_t *d_qoff, ffq_scan_result *res)
+// ---- one scan = front (enqueue) + finish (sync, fallbacks) ---------------------------------
+// ffq_scan_submit enqueues the front and returns; ffq_scan_wait finishes.  ffq_scan_device is
+// submit + wait.  Two contexts that share their streams (ffq_ctx_create_shared) let a host
+// keep the next batch's kernels queued behind the current one's: no idle GPU between steps.
+static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
 {
-    if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_device: ctx/res is NULL");
-    if (n_bytes < 0 || offset < 0 || table_cap < 0) return fail(FFQ_E_ARG, "ffq_scan_device: negative size");
-    if (n_bytes > 0 && !d_buf) return fail(FFQ_E_ARG, "ffq_scan_device: d_buf is NULL");
-    if ((reinterpret_cast<uintptr_t>(d_buf) & 15) != 0) return fail(FFQ_E_ARG, "ffq_scan_device: d_buf must be 16-byte aligned");
-    if ((reinterpret_cast<uintptr_t>(d_table) & 15) != 0) return fail(FFQ_E_ARG, "ffq_scan_device: d_table must be 16-byte aligned");
-    if (table_cap > 0 && !d_table) return fail(FFQ_E_ARG, "ffq_scan_device: d_table is NULL");
-    const bool decode = (flags & FFQ_F_DECODE_QUAL) != 0;
-    if (decode && (!d_qual || !d_qoff)) return fail(FFQ_E_ARG, "ffq_scan_device: FFQ_F_DECODE_QUAL needs d_qual and d_qoff");
-    memset(res, 0, sizeof *res);
-    HIPCHK(hipSetDevice(c->device));
-    const int s = sentinel ? 1 : 0;
+    LineIndex L;
+    L.d = a.d_buf; L.n = a.n_bytes; L.s = a.s; L.ntiles = (int32_t)ntiles; L.ready = (int32_t)ntiles; L.pad_ = 0;
+    L.ent = c->ent; L.cnt = c->cnt; L.ovf = c->ovf; L.pool = c->pool;
+    return L;
+}
 
-    const int64_t ntiles = tiles_for(n_bytes);
-    if (ntiles == 0) {
-        // empty data: with a sentinel the buffer is "\n", no "\n@" can match
-        res->end_state = eof ? FFQ_END_OK : FFQ_END_REFILL;
-        res->last_status = FFQ_POS_HEAD_BEG;
-        res->end_offset = offset;
-        for (int i = 0; i < 6; i++) res->last_pos[i] = -1;
-        if (decode) {
-            const int64_t z = 0;
-            HIPCHK(hipMemcpyAsync(d_qoff, &z, sizeof z, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-        }
-        return FFQ_OK;
+// general path: chain summaries -> resolve -> expand (+ fused decode) -> finalize, on stream B
+static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups)
+{
+    const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
+    int64_t *qoff = decode ? a.d_qoff : nullptr;
+    const int nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
+    int rc = reserve_stage(c, ngroups, nmax);
+    if (rc) return rc;
+    ChainBufs cb = c->cb;
+    cb.ng = ngroups;
+    cb.nmax = nmax;
+    cb.prof = nullptr;
+    hipStream_t sB = c->stream2;
+    const char *abl = getenv("FFQ_ABLATE");
+    const int ablate = abl ? atoi(abl) : 0;
+    if (getenv("FFQ_PROF")) {
+        if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 64));
+        HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sB));
+        cb.prof = c->prof_d;
     }
-    if (ntiles > 0x7FFFFFF0) return fail(FFQ_E_ARG, "buffer too large");
-    int rc = reserve_tiles(c, ntiles);
-    if (rc) return rc;
-    rc = reserve_pool(c, 1ull << 20);
-    if (rc) return rc;
-    const int ngroups = (int)groups_for(ntiles);
-    int64_t *qoff = decode ? d_qoff : nullptr;
+    const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
+    HIPCHK(hipMemsetAsync(cb.flags, 0, (size_t)ngroups * 4, sB));
+    if (!dense_cfg)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
+                           dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sB, L,
+                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
+                           dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sB, L,
+                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
+    HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sB));
+    hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sB, cb);
+    hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sB, cb, nblk, a.eof, a.offset, a.add, c->dres);
+    hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sB, cb, (const DevRes *)c->dres, a.add, a.d_table,
+                       a.table_cap, qoff, a.d_buf, a.s, a.qual_add, decode ? a.d_qual : (int8_t *)nullptr, a.qual_cap);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sB, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff);
+    return FFQ_OK;
+}
 
-    int retries = 0;
-    bool dense_cfg = false, fast4_failed = false;
-    for (;;) {
-        LineIndex L;
-        L.d = d_buf; L.n = n_bytes; L.s = s; L.ntiles = (int32_t)ntiles; L.ready = (int32_t)ntiles; L.pad_ = 0;
-        L.ent = c->ent; L.cnt = c->cnt; L.ovf = c->ovf; L.pool = c->pool;
-        *c->h_L = L;
-        HIPCHK(hipMemcpyAsync(c->d_L, c->h_L, sizeof(LineIndex), hipMemcpyHostToDevice, c->stream));
-        const bool serial = (flags & FFQ_F_FORCE_SERIAL) != 0;
-        const char *abl = getenv("FFQ_ABLATE");
-        const int ablate = abl ? atoi(abl) : 0;
-        const int k1abl = getenv("FFQ_K1_ABLATE") ? atoi(getenv("FFQ_K1_ABLATE")) : 0;
-        hipStream_t sA = c->stream, sB = c->stream2;
-        // the four-line fast path (ffq_rows4.h) is tried first unless qualities are decoded
-        // (their CSR offsets need the general path's per-group sums) or it already failed
-        const bool try_fast4 = !serial && !decode && !dense_cfg && !fast4_failed && ablate == 0 &&
-                               getenv("FFQ_NO_FAST4") == nullptr;
-        const int nsb = (int)((ntiles + SB_TILES - 1) / SB_TILES);
+// front: line index on stream A, then either the four-line fast path or the general path on
+// stream B, then the result block on its way to pinned memory.  No host synchronisation.
+static int enqueue_front(ffq_ctx *c, ScanState &st)
+{
+    const ScanArgs &a = st.a;
+    const bool serial = (a.flags & FFQ_F_FORCE_SERIAL) != 0;
+    const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
+    const char *abl = getenv("FFQ_ABLATE");
+    const int ablate = abl ? atoi(abl) : 0;
+    const int k1abl = getenv("FFQ_K1_ABLATE") ? atoi(getenv("FFQ_K1_ABLATE")) : 0;
+    hipStream_t sA = c->stream, sB = c->stream2;
+    const int64_t ntiles = st.ntiles;
+    const int nsb = (int)((ntiles + SB_TILES - 1) / SB_TILES);
+    // the four-line fast path (ffq_rows4.h) is tried first unless qualities are decoded (their
+    // CSR offsets need the general path's per-group sums) or it already failed on this buffer
+    const bool try_fast4 = !serial && !decode && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
+                           getenv("FFQ_NO_FAST4") == nullptr;
+    const LineIndex L = make_index(c, a, ntiles);
+    *c->h_L = L;
+    HIPCHK(hipMemcpyAsync(c->d_L, c->h_L, sizeof(LineIndex), hipMemcpyHostToDevice, sA));
 
-        ChainBufs cb = c->cb;
-        const int nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
+    // ---- line index: one launch over the full tiles on stream A; the ragged last tile
+    //      (byte-wise loads, one workgroup) beside it on stream B ---------------------------
+    HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
+    HIPCHK(hipMemsetAsync(c->sbsum, 0, (size_t)nsb * sizeof(unsigned int), sA));
+    HIPCHK(hipEventRecord(c->ev[0], sA));
+    HIPCHK(hipStreamWaitEvent(sB, c->ev[0], 0));        // stream B starts behind the resets
+    {
+        const int64_t nfull = a.n_bytes >> TILE_SHIFT;
+        if (ntiles > nfull)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 4>), dim3((unsigned)(ntiles - nfull)), dim3(256), 0,
+                               sB, a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
+                               (int)nfull, 0, c->sbsum);
+        if (nfull > 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 6>), dim3((unsigned)nfull), dim3(256), 0, sA,
+                               a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
+                               c->sbsum);
+    }
+    HIPCHK(hipEventRecord(c->ev[1], sA));
+    HIPCHK(hipStreamWaitEvent(sB, c->ev[1], 0));
+    if (try_fast4) {
+        // ---- plain four-line records: rows straight from newline ordinals, then validated -----
+        hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sB, L, (const unsigned int *)c->sbsum, nsb, c->sbbase,
+                           a.offset, c->hdr4);
+        hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sB, L,
+                           (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap);
+        // the next scan's index kernel (stream A, possibly another context) may start once the
+        // bandwidth-heavy kernels of this one are through: only the one-thread epilogue and
+        // the result copy overlap with it, so per-kernel timings stay clean
+        HIPCHK(hipEventRecord(c->ev[5], sB));
+        HIPCHK(hipStreamWaitEvent(sA, c->ev[5], 0));
+        hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sB, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
+                           a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres);
+        st.stage = 1;
+    } else {
         if (!serial) {
-            rc = reserve_stage(c, ngroups, nmax);
+            int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups);
             if (rc) return rc;
-            cb = c->cb;
-            cb.ng = ngroups;
-            cb.nmax = nmax;
-            cb.prof = nullptr;
-            if (getenv("FFQ_PROF")) {
-                if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 64));
-                HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sA));
-                cb.prof = c->prof_d;
+        }
+        HIPCHK(hipEventRecord(c->ev[5], sB));
+        HIPCHK(hipStreamWaitEvent(sA, c->ev[5], 0));
+        st.stage = 2;
+    }
+    HIPCHK(hipEventRecord(c->ev[2], sB));
+    HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
+    HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));
+    // ev[3]: this scan's result block has landed in pinned memory.  Stream A is NOT made to
+    // wait for it: the next scan on these streams belongs to another context (own scratch), or
+    // comes after the host has waited for this one.
+    HIPCHK(hipEventRecord(c->ev[3], sB));
+    HIPCHK(hipGetLastError());
+    return FFQ_OK;
+}
+
+static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
+{
+    const ScanArgs &a = st.a;
+    const bool serial = (a.flags & FFQ_F_FORCE_SERIAL) != 0;
+    const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
+    int64_t *qoff = decode ? a.d_qoff : nullptr;
+    hipStream_t sA = c->stream, sB = c->stream2;
+    bool front_done = true;           // the first front was enqueued by the caller (submit)
+    for (;;) {
+        if (!front_done) {
+            int rc = enqueue_front(c, st);
+            if (rc) return rc;
+        }
+        front_done = false;
+        // wait for THIS scan's result block only (ev[3] follows its copy on stream B): the
+        // streams may already hold the next scan of a context that shares them
+        HIPCHK(hipEventSynchronize(c->ev[3]));
+        const LineIndex L = make_index(c, a, st.ntiles);
+
+        if (c->h_ctl->err & ERR_POOL) {
+            // dense tiles did not fit the overflow pool: size it for what was asked and re-run
+            if (st.retries >= 2) return fail(FFQ_E_INTERNAL, "line-index pool overflow persists");
+            int rc = reserve_pool(c, std::max<unsigned long long>(c->h_ctl->pool_head, 1ull << 20));
+            if (rc) return rc;
+            st.retries++;
+            continue;
+        }
+        if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); res->ms_chain += ms;
+        res->ms_decode = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[2])); res->ms_total += ms;
+
+        if (st.stage == 1) {
+            if (!c->h_res->fallback) {
+                fill_result(res, *c->h_res, 3, st.retries);
+                break;
             }
-        }
-        auto launch_chain = [&](int g0, int g1, int ready, int only_deferred) {
-            LineIndex Lr = L;
-            Lr.ready = ready;
-            if (!dense_cfg)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
-                                   dim3((g1 - g0 + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sB, Lr,
-                                   (const LineIndex *)c->d_L, offset, eof, cb, g0, g1, only_deferred, ablate);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
-                                   dim3((g1 - g0 + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sB, Lr,
-                                   (const LineIndex *)c->d_L, offset, eof, cb, g0, g1, only_deferred, ablate);
-        };
-
-        // ---- line index: one launch over the full tiles on stream A; the ragged last tile
-        //      (byte-wise loads, one workgroup) beside it on stream B ---------------------------
-        HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
-        HIPCHK(hipMemsetAsync(c->sbsum, 0, (size_t)nsb * sizeof(unsigned int), sA));
-        HIPCHK(hipEventRecord(c->ev[0], sA));
-        HIPCHK(hipStreamWaitEvent(sB, c->ev[0], 0));        // stream B starts behind the resets
-        {
-            const int64_t nfull = n_bytes >> TILE_SHIFT;
-            if (ntiles > nfull)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 4>), dim3((unsigned)(ntiles - nfull)), dim3(256), 0,
-                                   sB, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
-                                   (int)nfull, 0, c->sbsum);
-            if (nfull > 0)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 6>), dim3((unsigned)nfull), dim3(256), 0, sA,
-                                   d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
-                                   c->sbsum);
-        }
-        HIPCHK(hipEventRecord(c->ev[1], sA));
-        HIPCHK(hipStreamWaitEvent(sB, c->ev[1], 0));
-
-        bool fast4_ok = false;
-        if (try_fast4) {
-            // ---- plain four-line records: rows straight from newline ordinals, then validated -----
-            hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sB, L, (const unsigned int *)c->sbsum, nsb, c->sbbase,
-                               offset, c->hdr4);
-            hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sB, L,
-                               (const long long *)c->sbbase, eof, add, c->hdr4, c->tinfo4, d_table, table_cap);
-            hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sB, L, c->hdr4, (const TermInfo4 *)c->tinfo4, eof,
-                               offset, add, (const int64_t *)d_table, table_cap, c->dres);
+            // not plain four-line input: the general kernels, from the same line index
+            st.fast4_failed = true;
+            int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups);
+            if (rc) return rc;
             HIPCHK(hipEventRecord(c->ev[4], sB));
             HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
             HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(sB));
-            HIPCHK(hipStreamSynchronize(sA));
-            if (!(c->h_ctl->err & ERR_POOL) && !c->h_res->fallback) fast4_ok = true;
-            else if (!(c->h_ctl->err & ERR_POOL)) fast4_failed = true;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[4]));
+            res->ms_chain += ms; res->ms_total += ms;
+            if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
         }
-        if (fast4_ok) {
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[4])); res->ms_chain = ms;
-            res->ms_decode = 0;
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[4])); res->ms_total = ms;
-            fill_result(res, *c->h_res, 3, retries);
-            break;
-        }
-        if (!(try_fast4 && (c->h_ctl->err & ERR_POOL))) {
-            // ---- general path: chain summaries -> resolve -> expand (or the serial walker below) ----
-            if (!serial) {
-                const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
-                HIPCHK(hipMemsetAsync(cb.flags, 0, (size_t)ngroups * 4, sB));
-                launch_chain(0, ngroups, (int)ntiles, 0);
-                HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sB));
-                hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sB, cb);
-                hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sB, cb, nblk, eof, offset, add, c->dres);
-                hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sB, cb, (const DevRes *)c->dres, add, d_table,
-                                   table_cap, qoff, d_buf, s, qual_add, decode ? d_qual : (int8_t *)nullptr, qual_cap);
-                hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sB, c->dres, d_table, table_cap, add, offset,
-                                   qoff);
-            }
-            HIPCHK(hipEventRecord(c->ev[2], sB));
-            HIPCHK(hipEventRecord(c->ev[3], sB));
-            HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
-            HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(sB));
-            HIPCHK(hipStreamSynchronize(sA));
-        }
-
-        if (c->h_ctl->err & ERR_POOL) {
-            // dense tiles did not fit the overflow pool: size it for what was asked and re-run
-            if (retries >= 2) return fail(FFQ_E_INTERNAL, "line-index pool overflow persists");
-            rc = reserve_pool(c, std::max<unsigned long long>(c->h_ctl->pool_head, 1ull << 20));
-            if (rc) return rc;
-            retries++;
-            continue;
-        }
-        if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
         if (!serial && getenv("FFQ_PROF") && c->prof_d) {
             unsigned long long hp[8];
             HIPCHK(hipMemcpy(hp, c->prof_d, 64, hipMemcpyDeviceToHost));
@@ -480,14 +526,8 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
                         (double)hp[0] / hp[6], (double)hp[1] / hp[6], (double)hp[2] / hp[6], (double)hp[3] / hp[6],
                         (double)hp[4] / hp[6], (double)hp[5] / hp[6], hp[6]);
         }
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); res->ms_chain = ms;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); res->ms_decode = ms;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total = ms;
-
         if (!serial && getenv("FFQ_DEBUG")) {
-            const int ng = std::min(ngroups, 24);
+            const int ng = std::min(st.ngroups, 24);
             std::vector<int64_t> y(ng), ex(ng);
             std::vector<uint32_t> cn(ng), fl(ng);
             int32_t mins[2];
@@ -496,8 +536,8 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
             HIPCHK(hipMemcpy(cn.data(), c->cb.cnt, ng * 4, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(fl.data(), c->cb.flags, ng * 4, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(mins, c->cb.mins, 8, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[ffq debug] dense=%d fallback=%d ngroups=%d term=%d bad=%d\n", (int)dense_cfg,
-                    c->h_res->fallback, ngroups, mins[0], mins[1]);
+            fprintf(stderr, "[ffq debug] dense=%d fallback=%d ngroups=%d term=%d bad=%d\n", (int)st.dense_cfg,
+                    c->h_res->fallback, st.ngroups, mins[0], mins[1]);
             for (int g = 0; g < ng; g++)
                 fprintf(stderr, "[ffq debug]  g=%d y=%lld exit=%lld cnt=%u flags=%u\n", g, (long long)y[g],
                         (long long)ex[g], cn[g], fl[g]);
@@ -505,42 +545,110 @@ extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
         int path = 0;
         if (!serial && getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) {
             // diagnostics build of the pipeline: results are meaningless, only timings count
-            fill_result(res, *c->h_res, 0, retries);
+            fill_result(res, *c->h_res, 0, st.retries);
             return FFQ_OK;
         }
-        if (!serial && c->h_res->fallback && !dense_cfg) {
+        if (!serial && c->h_res->fallback && !st.dense_cfg) {
             // second tier: the same kernels with the LDS budget for short lines / short records
-            dense_cfg = true;
+            st.dense_cfg = true;
             continue;
         }
-        if (dense_cfg) path = 2;
+        if (st.dense_cfg) path = 2;
         if (serial || c->h_res->fallback) {
             path = 1;
-            HIPCHK(hipEventRecord(c->ev[4], c->stream));
-            hipLaunchKernelGGL(k_chain_serial, dim3(1), dim3(64), 0, c->stream, L, offset, eof, add, d_table,
-                               table_cap, qoff, c->dres);
-            hipLaunchKernelGGL(k_finalize_serial, dim3(1), dim3(64), 0, c->stream, c->dres, table_cap, qoff);
+            HIPCHK(hipEventRecord(c->ev[4], sA));
+            hipLaunchKernelGGL(k_chain_serial, dim3(1), dim3(64), 0, sA, L, a.offset, a.eof, a.add, a.d_table,
+                               a.table_cap, qoff, c->dres);
+            hipLaunchKernelGGL(k_finalize_serial, dim3(1), dim3(64), 0, sA, c->dres, a.table_cap, qoff);
             if (decode)
-                hipLaunchKernelGGL(k_decode_quals, dim3(2048), dim3(256), 0, c->stream, d_buf, s, d_table,
-                                   qoff, c->dres, table_cap, add, qual_add, d_qual, qual_cap);
-            HIPCHK(hipEventRecord(c->ev[5], c->stream));
-            HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, c->stream));
+                hipLaunchKernelGGL(k_decode_quals, dim3(2048), dim3(256), 0, sA, a.d_buf, a.s, a.d_table, qoff, c->dres,
+                                   a.table_cap, a.add, a.qual_add, a.d_qual, a.qual_cap);
+            HIPCHK(hipEventRecord(c->ev[5], sA));
+            HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sA));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipStreamSynchronize(sA));
             HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
             res->ms_chain += ms;
             res->ms_total += ms;
         }
-        fill_result(res, *c->h_res, path, retries);
+        fill_result(res, *c->h_res, path, st.retries);
         break;
     }
-    if (res->n_records > table_cap)
-        return fail(FFQ_E_TABLE_FULL, "table holds %lld rows, the buffer has %lld records", (long long)table_cap,
+    if (res->n_records > a.table_cap)
+        return fail(FFQ_E_TABLE_FULL, "table holds %lld rows, the buffer has %lld records", (long long)a.table_cap,
                     (long long)res->n_records);
-    if (decode && res->n_qual_bytes > qual_cap)
-        return fail(FFQ_E_TABLE_FULL, "quality buffer holds %lld bytes, %lld needed", (long long)qual_cap,
+    if (decode && res->n_qual_bytes > a.qual_cap)
+        return fail(FFQ_E_TABLE_FULL, "quality buffer holds %lld bytes, %lld needed", (long long)a.qual_cap,
                     (long long)res->n_qual_bytes);
     return FFQ_OK;
+}
+
+extern "C" int ffq_scan_submit(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int sentinel, int64_t offset,
+                               int eof, int64_t add, uint32_t flags, int qual_add, int64_t *d_table,
+                               int64_t table_cap, int8_t *d_qual, int64_t qual_cap, int64_t *d_qoff)
+{
+    if (!c) return fail(FFQ_E_ARG, "ffq_scan_submit: ctx is NULL");
+    if (c->pend.active) return fail(FFQ_E_ARG, "ffq_scan_submit: a scan is already pending on this context");
+    if (n_bytes < 0 || offset < 0 || table_cap < 0) return fail(FFQ_E_ARG, "ffq_scan: negative size");
+    if (n_bytes > 0 && !d_buf) return fail(FFQ_E_ARG, "ffq_scan: d_buf is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_buf) & 15) != 0) return fail(FFQ_E_ARG, "ffq_scan: d_buf must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d_table) & 15) != 0) return fail(FFQ_E_ARG, "ffq_scan: d_table must be 16-byte aligned");
+    if (table_cap > 0 && !d_table) return fail(FFQ_E_ARG, "ffq_scan: d_table is NULL");
+    const bool decode = (flags & FFQ_F_DECODE_QUAL) != 0;
+    if (decode && (!d_qual || !d_qoff)) return fail(FFQ_E_ARG, "ffq_scan: FFQ_F_DECODE_QUAL needs d_qual and d_qoff");
+    HIPCHK(hipSetDevice(c->device));
+    ScanState &st = c->pend;
+    st = ScanState{};
+    st.a = ScanArgs{d_buf, n_bytes, sentinel ? 1 : 0, offset, eof, add, flags, qual_add, d_table, table_cap,
+                    d_qual, qual_cap, d_qoff};
+    st.ntiles = tiles_for(n_bytes);
+    st.active = true;
+    if (st.ntiles == 0) return FFQ_OK;                   // nothing to enqueue: ffq_scan_wait fills the result
+    if (st.ntiles > 0x7FFFFFF0) { st.active = false; return fail(FFQ_E_ARG, "buffer too large"); }
+    int rc = reserve_tiles(c, st.ntiles);
+    if (!rc) rc = reserve_pool(c, 1ull << 20);
+    if (!rc) {
+        st.ngroups = (int)groups_for(st.ntiles);
+        rc = enqueue_front(c, st);
+    }
+    if (rc) st.active = false;
+    return rc;
+}
+
+extern "C" int ffq_scan_wait(ffq_ctx *c, ffq_scan_result *res)
+{
+    if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_wait: ctx/res is NULL");
+    if (!c->pend.active) return fail(FFQ_E_ARG, "ffq_scan_wait: no scan is pending on this context");
+    memset(res, 0, sizeof *res);
+    HIPCHK(hipSetDevice(c->device));
+    ScanState &st = c->pend;
+    st.active = false;
+    if (st.ntiles == 0) {
+        // empty data: with a sentinel the buffer is "\n", no "\n@" can match
+        res->end_state = st.a.eof ? FFQ_END_OK : FFQ_END_REFILL;
+        res->last_status = FFQ_POS_HEAD_BEG;
+        res->end_offset = st.a.offset;
+        for (int i = 0; i < 6; i++) res->last_pos[i] = -1;
+        if ((st.a.flags & FFQ_F_DECODE_QUAL) != 0) {
+            const int64_t z = 0;
+            HIPCHK(hipMemcpyAsync(st.a.d_qoff, &z, sizeof z, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        return FFQ_OK;
+    }
+    return scan_finish(c, st, res);
+}
+
+extern "C" int ffq_scan_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int sentinel,
+                               int64_t offset, int eof, int64_t add, uint32_t flags, int qual_add,
+                               int64_t *d_table, int64_t table_cap, int8_t *d_qual,
+                               int64_t qual_cap, int64_t *d_qoff, ffq_scan_result *res)
+{
+    if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_device: ctx/res is NULL");
+    int rc = ffq_scan_submit(c, d_buf, n_bytes, sentinel, offset, eof, add, flags, qual_add, d_table, table_cap,
+                             d_qual, qual_cap, d_qoff);
+    if (rc) return rc;
+    return ffq_scan_wait(c, res);
 }
 
 template <class T>

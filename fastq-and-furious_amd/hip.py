@@ -34,10 +34,10 @@ F_FORCE_SERIAL = 2
 
 # every symbol include/ffq.h declares (tests check the library exports them all)
 SYMBOLS = (
-    "ffq_abi_version", "ffq_last_error", "ffq_device_count", "ffq_ctx_create",
+    "ffq_abi_version", "ffq_last_error", "ffq_device_count", "ffq_ctx_create", "ffq_ctx_create_shared",
     "ffq_ctx_destroy", "ffq_ctx_reserve", "ffq_ctx_stream", "ffq_dev_alloc", "ffq_dev_free",
     "ffq_pinned_alloc", "ffq_pinned_free", "ffq_copy_h2d", "ffq_copy_d2h", "ffq_sync",
-    "ffq_scan_device", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
+    "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
@@ -87,6 +87,7 @@ def lib():
         L.ffq_last_error.restype = ctypes.c_char_p
         L.ffq_device_count.restype = i32
         L.ffq_ctx_create.argtypes = [i32, P(vp)]
+        L.ffq_ctx_create_shared.argtypes = [vp, P(vp)]
         L.ffq_ctx_destroy.argtypes = [vp]
         L.ffq_ctx_destroy.restype = None
         L.ffq_ctx_reserve.argtypes = [vp, i64]
@@ -101,6 +102,8 @@ def lib():
         L.ffq_sync.argtypes = [vp]
         L.ffq_scan_device.argtypes = [vp, vp, i64, i32, i64, i32, i64, u32, i32, vp, i64, vp, i64, vp,
                                       P(ScanResult)]
+        L.ffq_scan_submit.argtypes = [vp, vp, i64, i32, i64, i32, i64, u32, i32, vp, i64, vp, i64, vp]
+        L.ffq_scan_wait.argtypes = [vp, P(ScanResult)]
         L.ffq_scan_host.argtypes = [vp, vp, i64, i32, i64, i32, i64, u32, i32, vp, i64, vp, i64, vp,
                                     P(ScanResult)]
         L.ffq_entrypos.argtypes = [vp, vp, i64, i64, vp, P(i32)]
@@ -128,10 +131,17 @@ def check(rc, allow=()):
 class Context:
     """One GPU context (stream + scratch).  Not thread-safe; one per thread."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, share=None):
+        """share: another Context whose HIP streams this one uses (own scratch); scans of
+        the two then execute in submission order (see scan_submit / scan_wait)."""
         self._h = ctypes.c_void_p()
-        self.device = device
-        check(lib().ffq_ctx_create(int(device), ctypes.byref(self._h)))
+        self._parent = share
+        if share is not None:
+            self.device = share.device
+            check(lib().ffq_ctx_create_shared(share.handle, ctypes.byref(self._h)))
+        else:
+            self.device = device
+            check(lib().ffq_ctx_create(int(device), ctypes.byref(self._h)))
 
     def close(self):
         if self._h:
@@ -190,6 +200,23 @@ class Context:
                                    ctypes.c_void_p(d_table), int(table_cap),
                                    ctypes.c_void_p(d_qual) if d_qual else None, int(qual_cap),
                                    ctypes.c_void_p(d_qoff) if d_qoff else None, ctypes.byref(res))
+        check(rc, allow=(E_TABLE_FULL,))
+        return rc, res
+
+    def scan_submit(self, d_buf, n_bytes, d_table, table_cap, sentinel=True, offset=0, eof=True,
+                    add=None, flags=0, qual_add=-33, d_qual=None, qual_cap=0, d_qoff=None):
+        """Enqueue a scan and return at once; scan_wait() completes it."""
+        if add is None:
+            add = -1 if sentinel else 0
+        check(lib().ffq_scan_submit(self.handle, ctypes.c_void_p(d_buf), int(n_bytes), int(bool(sentinel)),
+                                    int(offset), int(bool(eof)), int(add), int(flags), int(qual_add),
+                                    ctypes.c_void_p(d_table), int(table_cap),
+                                    ctypes.c_void_p(d_qual) if d_qual else None, int(qual_cap),
+                                    ctypes.c_void_p(d_qoff) if d_qoff else None))
+
+    def scan_wait(self):
+        res = ScanResult()
+        rc = lib().ffq_scan_wait(self.handle, ctypes.byref(res))
         check(rc, allow=(E_TABLE_FULL,))
         return rc, res
 

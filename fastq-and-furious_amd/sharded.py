@@ -140,10 +140,19 @@ class ShardScanner:
         ext_start = own_lo_file - tail
         add = ext_start - (1 if sentinel else 0)
         n_bytes = tail + n_own + head
-        offset = self._start_offset(ext, tail, add, table)
-        rc, res = self.backend.scan(ext, n_bytes, sentinel, offset, eof, add, table, flags, qual, qoff)
-        if rc != _hip.OK:
-            raise RuntimeError("rank %d: offset table too small (%d records)" % (rank, res.n_records))
+        # Start the chain at the first "\n@" of the run-in.  If that is a false candidate the
+        # chain re-synchronises long before the own range starts (the hand-off check below
+        # proves it); only if such a chain stops at an invalid entry inside the run-in is a
+        # start that survives searched for (a scan of the run-in alone) and the scan redone.
+        offset = 0
+        for attempt in range(2):
+            rc, res = self.backend.scan(ext, n_bytes, sentinel, offset, eof, add, table, flags, qual, qoff)
+            if rc != _hip.OK:
+                raise RuntimeError("rank %d: offset table too small (%d records)" % (rank, res.n_records))
+            good = res.end_state == (_hip.END_OK if eof else _hip.END_REFILL)
+            if good or rank == 0 or attempt == 1 or res.end_offset >= tail:
+                break
+            offset = self._start_offset(ext, tail, add, table)
         n = int(res.n_records)
         if eof:
             if res.end_state != _hip.END_OK:

@@ -94,6 +94,11 @@ const char *ffq_last_error(void);
 int         ffq_device_count(void);
 /* device = HIP ordinal.  Fails (FFQ_E_NODEVICE) if it is not a gfx950 part. */
 int         ffq_ctx_create(int device, ffq_ctx **out);
+/* A second context on the same HIP streams as `parent` (own scratch): work submitted
+ * through either context executes in submission order.  With ffq_scan_submit/_wait this
+ * lets a host queue the next batch behind the current one (no idle GPU between batches).
+ * Destroy it before the parent.                                                        */
+int         ffq_ctx_create_shared(ffq_ctx *parent, ffq_ctx **out);
 void        ffq_ctx_destroy(ffq_ctx *ctx);
 /* Pre-size the per-context scratch (line index, group summaries) for buffers
  * of up to max_bytes so that no allocation happens inside a timed scan.     */
@@ -132,6 +137,16 @@ int ffq_scan_device(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes,
                     int64_t *d_table, int64_t table_cap,
                     int8_t *d_qual, int64_t qual_cap, int64_t *d_qoff,
                     ffq_scan_result *res);
+
+/* The same in two halves: ffq_scan_submit enqueues the kernels and returns at once;
+ * ffq_scan_wait blocks, applies the fallbacks if the input needs them, and fills `res`.
+ * One scan may be pending per context.                                                 */
+int ffq_scan_submit(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes,
+                    int sentinel, int64_t offset, int eof, int64_t add,
+                    uint32_t flags, int qual_add,
+                    int64_t *d_table, int64_t table_cap,
+                    int8_t *d_qual, int64_t qual_cap, int64_t *d_qoff);
+int ffq_scan_wait(ffq_ctx *ctx, ffq_scan_result *res);
 
 /* Same over a host buffer: pinned staging + hipMemcpyAsync in, kernels, rows
  * (and qualities) copied back.  h_table: int64[table_cap][6].              */

@@ -271,3 +271,47 @@ def test_iterator_errors_on_gpu(gpu_ctx, golden, pkg):
                 assert err is not None and err.startswith("Entry is invalid at byte")
             else:
                 assert err == run["error"], (name, bs)
+
+
+def test_submit_wait_two_contexts(gpu_ctx, hipmod, oracle, pkg):
+    """ffq_scan_submit / ffq_scan_wait with two contexts that share their streams: scans are
+    queued one ahead and complete in order, each with its own scratch and output."""
+    import torch
+    from fastqandfurious_amd import synth
+    ctx2 = hipmod.Context(share=gpu_ctx)
+    datas = [synth.single(0, 30000, seed=42), synth.wrapped(0, 20000, seed=43)[0],
+             synth.single(500, 12345, seed=42), np.frombuffer(golden_file("test_multiline.fq"), dtype=np.uint8)]
+    wants = [oracle.scan(d)[0] for d in datas]
+    bufs = [torch.from_numpy(np.ascontiguousarray(d)).cuda() for d in datas]
+    tabs = [torch.empty((len(w) + 8, 6), dtype=torch.int64, device="cuda") for w in wants]
+    torch.cuda.synchronize()
+    ctxs = (gpu_ctx, ctx2)
+    def submit(i):
+        ctxs[i & 1].scan_submit(bufs[i].data_ptr(), bufs[i].numel(), tabs[i].data_ptr(), tabs[i].shape[0])
+    submit(0)
+    for i in range(1, len(datas)):
+        submit(i)
+        rc, res = ctxs[(i - 1) & 1].scan_wait()
+        assert rc == hipmod.OK and int(res.n_records) == len(wants[i - 1])
+    rc, res = ctxs[(len(datas) - 1) & 1].scan_wait()
+    assert rc == hipmod.OK and int(res.n_records) == len(wants[-1])
+    for t, w in zip(tabs, wants):
+        assert (t[:len(w)].cpu().numpy() == w).all()
+    with pytest.raises(hipmod.FFQError):
+        gpu_ctx.scan_wait()              # nothing pending
+    ctx2.close()
+
+
+def test_quarter_gib_closed_form(gpu_ctx, pkg):
+    """A size-independent property at a bench-like size: on S-single the table equals the
+    generator's closed form (which the small tests prove equal to the reference)."""
+    import torch
+    n = (256 << 20) // 322
+    buf = torch.empty(n * 322 + 64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.synth_single(buf.data_ptr(), 0, n, seed=42)
+    table = torch.empty((n + 8, 6), dtype=torch.int64, device="cuda")
+    rc, res = gpu_ctx.scan_device(buf.data_ptr(), n * 322, table.data_ptr(), n + 8)
+    assert rc == 0 and int(res.n_records) == n and int(res.end_state) == 0 and res.path == 3
+    k = torch.arange(n, dtype=torch.int64, device="cuda") * 322
+    want = torch.stack([k, k + 17, k + 18, k + 168, k + 171, k + 321], dim=1)
+    assert bool((table[:n] == want).all())
