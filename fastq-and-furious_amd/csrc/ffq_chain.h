@@ -325,14 +325,19 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     const bool prof = B.prof != nullptr;
     long long ts[6] = {0, 0, 0, 0, 0, 0};
     if (prof) ts[0] = clock64();
-    // ---- window directory + first 256 entries of every tile, one memory round trip ----
+    // ---- window directory + first FPE entries of every tile, one memory round trip ----
+    constexpr int FP = 2, FPE = FP * 256;        // 512 entries: lines of 32 bytes or more on average
     int tc[NTW];
-    uint2 ev[NTW];
+    uint2 ev[NTW][FP];
 #pragma unroll
     for (int k = 0; k < NTW; k++) {
         tc[k] = (k < nwt) ? (int)L.cnt[wt0 + k] : 0;
-        ev[k] = make_uint2(0, 0);
-        if (k < nwt) ev[k] = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)(wt0 + k) * SLOT + 4 * lane);
+#pragma unroll
+        for (int p = 0; p < FP; p++) {
+            ev[k][p] = make_uint2(0, 0);
+            if (k < nwt)
+                ev[k][p] = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)(wt0 + k) * SLOT + p * 256 + 4 * lane);
+        }
     }
     int tb[NTW + 1];
     tb[0] = sent;
@@ -376,46 +381,50 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     int maxc = 0;
 #pragma unroll
     for (int k = 0; k < NTW; k++) {
-        // first 256 entries of tile k (already in registers), 4 per lane
-        const int c = min(tc[k], 256);
+        // first FPE entries of tile k (already in registers), 4 per lane and pass
+        const int c = min(tc[k], FPE);
         maxc = max(maxc, tc[k]);
         const uint32_t relb = (uint32_t)(k << TILE_SHIFT) + (uint32_t)L.s;
-        const uint32_t x[4] = {ev[k].x & 0xFFFFu, ev[k].x >> 16, ev[k].y & 0xFFFFu, ev[k].y >> 16};
         const bool runin_tile = has_runin && k == 0;
         const bool node_tile = runin_tile || (k >= kown0 && k < kown1);
-        uint32_t isn = 0;      // bit i: entry i of this lane becomes a node
-        if (node_tile) {
+#pragma unroll
+        for (int p = 0; p < FP; p++) {
+            if (p * 256 >= c) continue;          // wave-uniform
+            const uint32_t x[4] = {ev[k][p].x & 0xFFFFu, ev[k][p].x >> 16, ev[k][p].y & 0xFFFFu, ev[k][p].y >> 16};
+            uint32_t isn = 0;      // bit i: entry i of this lane becomes a node
+            if (node_tile) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t off = x[i] & OFF_MASK;
+                    if (p * 256 + 4 * lane + i < c && ((x[i] >> 14) & FL_AT) && relb + off >= offrel &&
+                        (!runin_tile || off >= (uint32_t)(TILE - RUNIN_BYTES)))
+                        isn |= 1u << i;
+                }
+            }
+            uint32_t id = 0;
+            if (node_tile) {
+                const uint32_t nc = __popc(isn);
+                const uint32_t incl = wave_incl_scan(nc);
+                id = (uint32_t)ncomp + incl - nc;
+                ncomp += (int)__shfl((int)incl, 63);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t off = x[i] & OFF_MASK;
-                if (4 * lane + i < c && ((x[i] >> 14) & FL_AT) && relb + off >= offrel &&
-                    (!runin_tile || off >= (uint32_t)(TILE - RUNIN_BYTES)))
-                    isn |= 1u << i;
-            }
-        }
-        uint32_t id = 0;
-        if (node_tile) {
-            const uint32_t nc = __popc(isn);
-            const uint32_t incl = wave_incl_scan(nc);
-            id = (uint32_t)ncomp + incl - nc;
-            ncomp += (int)__shfl((int)incl, 63);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int j = 4 * lane + i;
-            if (j < c) {
-                uint32_t nid = NO_NODE;
-                if ((isn >> i) & 1u) {
-                    if (id < (uint32_t)(NMAX - 1)) { nid = id; nidx[id] = (uint16_t)(tb[k] + j); }
-                    id++;
+                const int j = p * 256 + 4 * lane + i;
+                if (j < c) {
+                    uint32_t nid = NO_NODE;
+                    if ((isn >> i) & 1u) {
+                        if (id < (uint32_t)(NMAX - 1)) { nid = id; nidx[id] = (uint16_t)(tb[k] + j); }
+                        id++;
+                    }
+                    went[tb[k] + j] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | (nid << WN_SHIFT);
                 }
-                went[tb[k] + j] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | (nid << WN_SHIFT);
             }
         }
-        if (runin_tile && tc[k] <= 256) n_runin = ncomp;
+        if (runin_tile && tc[k] <= FPE) n_runin = ncomp;
     }
-    if (maxc > 256) {
-        // tiles with more than 256 lines (average line under 64 bytes).  Node ids must
+    if (maxc > FPE) {
+        // tiles with more than FPE lines (average line under 32 bytes).  Node ids must
         // follow entry order, so redo the numbering from the first such tile on.
         ncomp = 0; n_runin = 0;
         if (sent) ncomp = (((went[0] >> WN_SHIFT) & WN_MASK) != NO_NODE) ? 1 : 0;
