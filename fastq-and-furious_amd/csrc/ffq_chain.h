@@ -919,72 +919,6 @@ __global__ __launch_bounds__(1024) void k_resolve_b(ChainBufs B, int nblk, int e
 // (/root/reference/src/_fastqandfurious.c:161-185; doc/user-guide.rst:130-141).
 // Eight records at a time, one per 8-lane group, 2 x 16 bytes per lane and step; unaligned
 // 16-byte loads/stores, SWAR byte add.
-__device__ __forceinline__ uint32_t addb4(uint32_t y, uint32_t vv)
-{
-    return ((y & 0x7F7F7F7Fu) + (vv & 0x7F7F7F7Fu)) ^ ((y ^ vv) & 0x80808080u);
-}
-
-__device__ __forceinline__ void decode_batch(const uint8_t *__restrict__ d, int64_t src, uint32_t len, int64_t qo,
-                                             int nrec, int qadd, int8_t *__restrict__ out, int64_t out_cap,
-                                             int lane)
-{
-    const uint32_t vv = (uint32_t)(uint8_t)qadd * 0x01010101u;
-    const int grp = lane >> 3, sub = lane & 7;
-    // batch-relative 32-bit offsets (a batch of 64 records spans far less than 4 GiB)
-    const int64_t src0 = ((int64_t)__shfl((int)(src >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)src, 0);
-    const int64_t qo0 = ((int64_t)__shfl((int)(qo >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)qo, 0);
-    const uint32_t srel = (uint32_t)(src - src0), qrel = (uint32_t)(qo - qo0);
-    const uint32_t lmax = wave_max_u32(len);
-    const uint8_t *sbase = d + src0;
-    int8_t *obase = out + qo0;
-    for (int j0 = 0; j0 < nrec; j0 += 8) {
-        const int j = j0 + grp;                           // < 64
-        const uint32_t lj = (uint32_t)__shfl((int)len, j);
-        const uint32_t sj = (uint32_t)__shfl((int)srel, j), oj = (uint32_t)__shfl((int)qrel, j);
-        for (uint32_t b0 = 0; b0 < lmax; b0 += 256) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t b = b0 + (uint32_t)sub * 32u + (uint32_t)h * 16u;
-                if (b >= lj) continue;
-                const uint32_t rem = lj - b;
-                const uint8_t *sp = sbase + sj + b;
-                int8_t *dp = obase + oj + b;
-                if (qo0 + oj + b + min(rem, 16u) > out_cap) continue;
-                if (rem >= 16u) {
-                    uint4 x;
-                    __builtin_memcpy(&x, sp, 16);
-                    x.x = addb4(x.x, vv); x.y = addb4(x.y, vv); x.z = addb4(x.z, vv); x.w = addb4(x.w, vv);
-                    __builtin_memcpy(dp, &x, 16);
-                } else {
-                    uint32_t o = 0;
-                    if (rem & 8u) {
-                        uint2 x;
-                        __builtin_memcpy(&x, sp, 8);
-                        x.x = addb4(x.x, vv); x.y = addb4(x.y, vv);
-                        __builtin_memcpy(dp, &x, 8);
-                        o = 8;
-                    }
-                    if (rem & 4u) {
-                        uint32_t x;
-                        __builtin_memcpy(&x, sp + o, 4);
-                        x = addb4(x, vv);
-                        __builtin_memcpy(dp + o, &x, 4);
-                        o += 4;
-                    }
-                    if (rem & 2u) {
-                        uint16_t x;
-                        __builtin_memcpy(&x, sp + o, 2);
-                        x = (uint16_t)addb4(x, vv);
-                        __builtin_memcpy(dp + o, &x, 2);
-                        o += 2;
-                    }
-                    if (rem & 1u) dp[o] = (int8_t)(uint8_t)(sp[o] + (uint8_t)qadd);
-                }
-            }
-        }
-    }
-}
-
 // =========================================================================
 // k_expand: one wave per group.  Turns the staged group-relative tuples into the
 // int64[n][6] rows (pos0..pos5 + add), rows written as whole 1 KiB lines through
@@ -993,8 +927,8 @@ __device__ __forceinline__ void decode_batch(const uint8_t *__restrict__ d, int6
 // =========================================================================
 __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__restrict__ res, int64_t add,
                                                int64_t *__restrict__ table, int64_t table_cap,
-                                               int64_t *__restrict__ qoff, const uint8_t *__restrict__ d, int s,
-                                               int qadd, int8_t *__restrict__ qual, int64_t qual_cap)
+                                               int64_t *__restrict__ qoff, int64_t *__restrict__ qdir,
+                                               int64_t qdir_cap)
 {
     __shared__ __attribute__((aligned(16))) int64_t s_rows[64 * 6];
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -1019,9 +953,7 @@ __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__rest
             const uint32_t lo = wave_incl_scan(ql & 0xFFFFu), hi = wave_incl_scan(ql >> 16);
             const int64_t incl = ((int64_t)hi << 16) + (int64_t)lo;
             const int64_t myq = q0 + incl - ql;
-            if (ok && r0 + dd < table_cap) qoff[r0 + dd] = myq;
-            // Phred decode of these records right here: pos4/pos5 and the offsets are in registers
-            if (qual) decode_batch(d, p4 - add - s, ql, myq, (int)min(64u, cnt - d0), qadd, qual, qual_cap, lane);
+            if (ok && r0 + dd < table_cap) { qoff[r0 + dd] = myq; qdir_mark(qdir, qdir_cap, myq, ql, r0 + dd); }
             q0 += ((int64_t)__shfl((int)hi, 63) << 16) + (int64_t)(uint32_t)__shfl((int)lo, 63);
         }
         int64_t *mine = s_rows + lane * 6;

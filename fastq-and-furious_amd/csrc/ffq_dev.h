@@ -195,6 +195,23 @@ __device__ __forceinline__ uint32_t get_byte(const uint4 v, uint32_t q)
     return (w >> ((q & 3) * 8)) & 0xFFu;
 }
 
+// per-byte wrap-around add of two packed u8x4 (arrayadd_b, _fastqandfurious.c:161-185)
+__device__ __forceinline__ uint32_t addb4(uint32_t y, uint32_t vv)
+{
+    return ((y & 0x7F7F7F7Fu) + (vv & 0x7F7F7F7Fu)) ^ ((y ^ vv) & 0x80808080u);
+}
+
+// Directory of the decoded-quality stream: qdir[b] = the record whose decoded bytes cover
+// stream offset b << DQ_SHIFT.  Record r with bytes [q, q + len) owns every such boundary
+// inside its range, so each entry below the stream's end has exactly one writer.
+constexpr int DQ_SHIFT = 16;
+__device__ __forceinline__ void qdir_mark(int64_t *__restrict__ qdir, int64_t qdir_cap, int64_t q, int64_t len,
+                                          int64_t r)
+{
+    for (int64_t b = (q + (1 << DQ_SHIFT) - 1) >> DQ_SHIFT; (b << DQ_SHIFT) < q + len && b < qdir_cap; b++)
+        qdir[b] = r;
+}
+
 __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
     uint64_t z = x + 0x9E3779B97F4A7C15ull;

@@ -80,6 +80,8 @@ struct ffq_ctx {
     LineIndex *d_L = nullptr;          // device copy of the LineIndex (out-of-line device functions)
     LineIndex *h_L = nullptr;          // pinned source of that copy
     DevRes *dres = nullptr;
+    int64_t *qdir = nullptr;           // directory of the decoded-quality stream (qdir_mark)
+    int64_t qdir_cap = 0;
     // pinned mirrors
     Ctl *h_ctl = nullptr;
     DevRes *h_res = nullptr;
@@ -182,6 +184,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     free_chain(c);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
+    (void)hipFree(c->qdir);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -246,6 +249,26 @@ static int reserve_stage(ffq_ctx *c, int64_t ng, int nmax)
     hipError_t e = hipMalloc((void **)&c->cb.stage, (size_t)need * sizeof(StageRec));
     if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(stage) failed: %s", hipGetErrorString(e));
     c->stage_cap = need;
+    return FFQ_OK;
+}
+
+// blocks of the decoded-quality stream for this scan (upper bound: half of the bytes are
+// qualities at most, and no more than the caller's buffer holds)
+static int64_t qdir_blocks(int64_t n_bytes, int64_t qual_cap)
+{
+    return (std::min<int64_t>(qual_cap, n_bytes / 2 + 16) + DQ_BLK - 1) / DQ_BLK + 1;
+}
+
+static int reserve_qdir(ffq_ctx *c, int64_t blocks)
+{
+    if (blocks <= c->qdir_cap) return FFQ_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    (void)hipFree(c->qdir);
+    c->qdir = nullptr; c->qdir_cap = 0;
+    hipError_t e = hipMalloc((void **)&c->qdir, (size_t)blocks * sizeof(int64_t));
+    if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(qdir) failed: %s", hipGetErrorString(e));
+    c->qdir_cap = blocks;
     return FFQ_OK;
 }
 
@@ -353,6 +376,17 @@ static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
     return L;
 }
 
+// Phred decode of the finished table: the grid covers the largest possible quality stream;
+// workgroups past the real end return at once
+static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st)
+{
+    const int64_t nblk = qdir_blocks(a.n_bytes, a.qual_cap);
+    static const int ablate = getenv("FFQ_DQ_ABLATE") ? atoi(getenv("FFQ_DQ_ABLATE")) : 0;
+    hipLaunchKernelGGL(k_decode_stream, dim3((unsigned)nblk), dim3(256), 0, st, a.d_buf, a.n_bytes, a.s,
+                       (const int64_t *)a.d_table, (const int64_t *)a.d_qoff, (const int64_t *)c->qdir,
+                       (const DevRes *)c->dres, a.table_cap, a.add, a.qual_add, a.d_qual, a.qual_cap, ablate);
+}
+
 // general path: chain summaries -> resolve -> expand (+ fused decode) -> finalize, on stream B
 static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups)
 {
@@ -387,8 +421,9 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sB, cb);
     hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sB, cb, nblk, a.eof, a.offset, a.add, c->dres);
     hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sB, cb, (const DevRes *)c->dres, a.add, a.d_table,
-                       a.table_cap, qoff, a.d_buf, a.s, a.qual_add, decode ? a.d_qual : (int8_t *)nullptr, a.qual_cap);
+                       a.table_cap, qoff, c->qdir, c->qdir_cap);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sB, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff);
+    if (decode) enqueue_decode(c, a, sB);
     return FFQ_OK;
 }
 
@@ -558,11 +593,9 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             path = 1;
             HIPCHK(hipEventRecord(c->ev[4], sA));
             hipLaunchKernelGGL(k_chain_serial, dim3(1), dim3(64), 0, sA, L, a.offset, a.eof, a.add, a.d_table,
-                               a.table_cap, qoff, c->dres);
+                               a.table_cap, qoff, c->qdir, c->qdir_cap, c->dres);
             hipLaunchKernelGGL(k_finalize_serial, dim3(1), dim3(64), 0, sA, c->dres, a.table_cap, qoff);
-            if (decode)
-                hipLaunchKernelGGL(k_decode_quals, dim3(2048), dim3(256), 0, sA, a.d_buf, a.s, a.d_table, qoff, c->dres,
-                                   a.table_cap, a.add, a.qual_add, a.d_qual, a.qual_cap);
+            if (decode) enqueue_decode(c, a, sA);
             HIPCHK(hipEventRecord(c->ev[5], sA));
             HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sA));
             HIPCHK(hipGetLastError());
@@ -607,6 +640,7 @@ extern "C" int ffq_scan_submit(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
     if (st.ntiles > 0x7FFFFFF0) { st.active = false; return fail(FFQ_E_ARG, "buffer too large"); }
     int rc = reserve_tiles(c, st.ntiles);
     if (!rc) rc = reserve_pool(c, 1ull << 20);
+    if (!rc && (flags & FFQ_F_DECODE_QUAL)) rc = reserve_qdir(c, qdir_blocks(n_bytes, qual_cap));
     if (!rc) {
         st.ngroups = (int)groups_for(st.ntiles);
         rc = enqueue_front(c, st);

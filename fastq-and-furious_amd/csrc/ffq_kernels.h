@@ -164,7 +164,8 @@ namespace ffq {
 // =========================================================================
 __global__ void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add,
                                int64_t *__restrict__ table, int64_t table_cap,
-                               int64_t *__restrict__ qoff, DevRes *res)
+                               int64_t *__restrict__ qoff, int64_t *__restrict__ qdir, int64_t qdir_cap,
+                               DevRes *res)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const GAcc a(L);
@@ -185,7 +186,7 @@ __global__ void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add
             int64_t *o = table + n * 6;
             o[0] = r.p0 + add; o[1] = r.p1 + add; o[2] = r.p1 + 1 + add;
             o[3] = r.p3 + add; o[4] = r.p4 + add; o[5] = r.p5 + add;
-            if (qoff) qoff[n] = qb;
+            if (qoff) { qoff[n] = qb; qdir_mark(qdir, qdir_cap, qb, r.p5 - r.p4, n); }
         }
         n++;
         qb += r.p5 - r.p4;
@@ -230,26 +231,207 @@ __global__ void k_finalize_serial(DevRes *res, int64_t table_cap, int64_t *__res
 }
 
 // =========================================================================
-// k_decode_quals: stand-alone Phred decode over a finished table (used behind the serial
-// walker; the parallel path decodes inside k_expand, where the rows are in registers).
+// k_decode_stream: Phred decode over a finished table + CSR offsets (all paths).
+//   array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, -33)
+//   (/root/reference/doc/user-guide.rst:130-141, src/demo/benchmark.py:159-168)
+// The OUTPUT stream is cut into blocks of DQ_BLK bytes, one per workgroup, and those into
+// 16-byte chunks aligned on the destination address.  qdir[b] (written by whoever produced
+// qoff, see qdir_mark) names the record under the block's first byte; the workgroup keeps
+// (offset, source) of the records under its block in LDS and gathers every chunk from its
+// record(s) with unaligned 16-byte loads, DQ_PER chunks per thread in flight.  Stores are
+// whole aligned 16-byte pieces, 1 KiB per wave instruction.
+// Algorithmic traffic per record: quality bytes read + written, 16 B of (qoff, pos4) read.
 // =========================================================================
-__global__ __launch_bounds__(256) void k_decode_quals(const uint8_t *__restrict__ d, int s,
-                                                      const int64_t *__restrict__ table,
-                                                      const int64_t *__restrict__ qoff,
-                                                      const DevRes *__restrict__ res,
-                                                      int64_t table_cap, int64_t add, int qadd,
-                                                      int8_t *__restrict__ out, int64_t out_cap)
+constexpr int DQ_PER = 4;                         // chunks per thread and batch
+constexpr int DQ_BLK = 1 << DQ_SHIFT;             // output bytes per workgroup
+constexpr int DQ_REC = 1024;                      // records cached in LDS per window
+
+// dword w of the 16-byte mask with bytes [0, nb) set
+__device__ __forceinline__ uint32_t lt_mask(int nb, int w)
 {
-    const int64_t n = min(res->n_records, table_cap);
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t r0 = wave * 64; r0 < n; r0 += nwaves * 64) {
-        const int64_t i = r0 + lane;
-        const bool ok = i < n;
-        const longlong2 pq = ok ? *reinterpret_cast<const longlong2 *>(table + i * 6 + 4) : make_longlong2(0, 0);
-        decode_batch(d, pq.x - add - s, ok ? (uint32_t)(pq.y - pq.x) : 0u, ok ? qoff[i] : 0,
-                     (int)min((int64_t)64, n - r0), qadd, out, out_cap, lane);
+    const int t = nb - 4 * w;
+    return t <= 0 ? 0u : (t >= 4 ? 0xFFFFFFFFu : ((1u << (8 * t)) - 1u));
+}
+
+// 16 bytes at buffer offset a; bytes outside [0, nbytes) read as zero
+__device__ __noinline__ uint4 load16_edge(const uint8_t *__restrict__ d, int64_t nbytes, int64_t a)
+{
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (a + k >= 0 && a + k < nbytes) w[k >> 2] |= (uint32_t)d[a + k] << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint4 load16_any(const uint8_t *__restrict__ d, int64_t nbytes, int64_t a)
+{
+    if (a >= 0 && a + 16 <= nbytes) {
+        uint4 x;
+        __builtin_memcpy(&x, d + a, 16);
+        return x;
+    }
+    return load16_edge(d, nbytes, a);
+}
+
+// bytes [kb, ke) of a chunk whose first byte goes to o[0]
+__device__ __noinline__ void store16_part(int8_t *__restrict__ o, uint4 v, int kb, int ke)
+{
+    const uint32_t y[4] = {v.x, v.y, v.z, v.w};
+    for (; kb < ke; kb++) {
+        uint32_t wv = y[0];
+#pragma unroll
+        for (int w = 1; w < 4; w++)
+            if ((kb >> 2) == w) wv = y[w];
+        o[kb] = (int8_t)(uint8_t)(wv >> (8 * (kb & 3)));
+    }
+}
+
+// records shorter than 16 bytes: chunk bytes [kb, kend) gathered byte by byte from the
+// cached records m, m+1, ...
+__device__ __noinline__ uint4 gather_tail(const uint8_t *__restrict__ d, const int32_t *s_q, const int64_t *s_adj,
+                                          uint4 v, int m, int kb, int kend, int clo, int vhi)
+{
+    uint32_t y[4] = {v.x, v.y, v.z, v.w};
+    while (kb < kend) {
+        const int he = min(s_q[m + 1], vhi) - clo;
+        const int64_t sa = s_adj[m] + clo;
+        for (; kb < he; kb++) {
+            const uint32_t sh = 8u * (kb & 3), val = (uint32_t)d[sa + kb] << sh, msk = ~(0xFFu << sh);
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if ((kb >> 2) == w) y[w] = (y[w] & msk) | val;
+        }
+        m++;
+    }
+    return make_uint4(y[0], y[1], y[2], y[3]);
+}
+
+__global__ __launch_bounds__(256) void k_decode_stream(const uint8_t *__restrict__ d, int64_t nbytes, int s,
+                                                       const int64_t *__restrict__ table,
+                                                       const int64_t *__restrict__ qoff,
+                                                       const int64_t *__restrict__ qdir,
+                                                       const DevRes *__restrict__ res,
+                                                       int64_t table_cap, int64_t add, int qadd,
+                                                       int8_t *__restrict__ out, int64_t out_cap, int ablate)
+{
+    __shared__ int32_t s_q[DQ_REC];               // stream offset of cached record i, relative to ob
+    __shared__ int64_t s_adj[DQ_REC];             // buffer offset of the byte decoded to stream offset ob
+    const int tid = threadIdx.x;
+    const int64_t ob = (int64_t)blockIdx.x << DQ_SHIFT;
+    int64_t rbase = qdir[blockIdx.x];             // garbage past the end of the stream: not used then
+    const int64_t n = res->n_records;
+    const int64_t qtotal = res->n_qual_bytes;     // == qoff[n]
+    if (res->fallback || n > table_cap || n <= 0) return;        // a table that overflowed decodes nothing
+    const int64_t total = min(qtotal, out_cap);
+    if (ob >= total) return;
+    const int oe = (int)min((int64_t)DQ_BLK, total - ob);        // block-relative from here on
+    const int shiftA = (int)(reinterpret_cast<uintptr_t>(out + ob) & 15);
+    int8_t *__restrict__ outb = out + ob;
+    const int mean = (int)min(max(qtotal / n, (int64_t)1), (int64_t)1 << 20);
+    const uint32_t vv = (uint32_t)(uint8_t)qadd * 0x01010101u;
+
+    // chunk k covers [16 k - shiftA, +16) cut to [0, oe); a destination that is not 16-byte
+    // aligned has one more (partial) chunk at the end
+    const int nchunk = (oe + shiftA + 15) >> 4;
+    int done = 0;                                  // chunks [0, done) are written
+    int want = 0;
+    for (;;) {
+        // ---- window: (offset, source) of records rbase .. rbase + nrec in LDS.  Sized from the
+        //      mean quality length; a window that covers no whole chunk is redone at full size
+        const int rem = oe - max(16 * done - shiftA, 0);
+        want = (want < 0) ? DQ_REC - 1 : min(DQ_REC - 1, rem / mean + rem / (8 * mean) + 8);
+        const int nrec = (int)min((int64_t)want, n - rbase);     // >= 1
+        for (int i = tid; i <= nrec; i += 256) {
+            const int64_t q = qoff[rbase + i] - ob;
+            s_q[i] = (int32_t)min(max(q, (int64_t)-0x7FFFFFFF), (int64_t)0x7FFFFFFF);
+            if (i < nrec) s_adj[i] = table[(rbase + i) * 6 + 4] - add - s - q;
+        }
+        __syncthreads();
+        const int cend = s_q[nrec];                // every byte below cend has its record cached
+        const int klim = (rbase + nrec == n || cend >= oe) ? nchunk : min(nchunk, (cend + shiftA) >> 4);
+        const float inv_mean = (float)nrec / (float)(cend - s_q[0]);
+
+        for (int k0 = done; k0 < klim; k0 += 256 * DQ_PER) {
+            // phase 1: the record under the first byte of each chunk; phase 2: 16 bytes from that
+            // record and 16 from the next, positioned chunk-relative, all loads in flight
+            // together; phase 3: byte-select, rare tails (records under 16 bytes), store
+            int ci[DQ_PER], h0[DQ_PER], h1[DQ_PER];
+            uint4 xa[DQ_PER], xb[DQ_PER];
+#pragma unroll
+            for (int j = 0; j < DQ_PER; j++) {
+                const int k = k0 + j * 256 + tid;
+                const int clo = 16 * k - shiftA;
+                const int vlo = max(clo, 0), vhi = min(clo + 16, oe);
+                ci[j] = -1;
+                if (k >= klim || vlo >= vhi) continue;
+                // largest cached index a with s_q[a] <= vlo (it is below nrec); equal-length
+                // records make the interpolated guess exact
+                int a = 0, b = nrec - 1;
+                const int g = min(max((int)((float)(vlo - s_q[0]) * inv_mean), 0), nrec - 1);
+                if (s_q[g] <= vlo) { a = g; if (s_q[g + 1] > vlo) b = g; } else b = g - 1;
+                while (b > a) {
+                    const int m = (a + b + 1) >> 1;
+                    if (s_q[m] <= vlo) a = m; else b = m - 1;
+                }
+                ci[j] = a;
+                h0[j] = min(s_q[a + 1], vhi) - clo;                 // chunk bytes [.., h0) come from record a
+                h1[j] = (h0[j] < vhi - clo) ? min(s_q[a + 2], vhi) - clo : h0[j];
+            }
+#pragma unroll
+            for (int j = 0; j < DQ_PER; j++) {
+                xa[j] = xb[j] = make_uint4(0, 0, 0, 0);
+                if (ci[j] < 0 || (ablate & 4)) continue;
+                const int clo = 16 * (k0 + j * 256 + tid) - shiftA;
+                xa[j] = load16_any(d, nbytes, s_adj[ci[j]] + clo);
+                if (h1[j] > h0[j]) xb[j] = load16_any(d, nbytes, s_adj[ci[j] + 1] + clo);
+            }
+#pragma unroll
+            for (int j = 0; j < DQ_PER; j++) {
+                if (ci[j] < 0) continue;
+                const int clo = 16 * (k0 + j * 256 + tid) - shiftA;
+                const int vlo = max(clo, 0), vhi = min(clo + 16, oe);
+                uint32_t y[4];
+                {
+                    const uint32_t A[4] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w};
+                    const uint32_t B[4] = {xb[j].x, xb[j].y, xb[j].z, xb[j].w};
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const uint32_t m = lt_mask(h0[j], w);
+                        y[w] = (A[w] & m) | (B[w] & ~m);
+                    }
+                }
+                if (h1[j] < vhi - clo) {
+                    const uint4 t = gather_tail(d, s_q, s_adj, make_uint4(y[0], y[1], y[2], y[3]), ci[j] + 2, h1[j],
+                                                vhi - clo, clo, vhi);
+                    y[0] = t.x; y[1] = t.y; y[2] = t.z; y[3] = t.w;
+                }
+#pragma unroll
+                for (int w = 0; w < 4; w++) y[w] = addb4(y[w], vv);
+                if (ablate & 2) { if (y[0] == 0x12345678u && y[1] == 77u) outb[0] = 1; }
+                else if (vhi - vlo == 16) {
+                    *reinterpret_cast<uint4 *>(outb + clo) = make_uint4(y[0], y[1], y[2], y[3]);
+                } else {
+                    store16_part(outb + clo, make_uint4(y[0], y[1], y[2], y[3]), vlo - clo, vhi - clo);
+                }
+            }
+        }
+        if (klim >= nchunk) break;
+        // ---- next window starts at the record under the first byte of chunk klim
+        int nb = -1;
+        if (klim > done) {
+            const int vlo = 16 * klim - shiftA;    // > 0 and < cend
+            int a = 0, b = nrec - 1;
+            while (b > a) {
+                const int m = (a + b + 1) >> 1;
+                if (s_q[m] <= vlo) a = m; else b = m - 1;
+            }
+            nb = a;
+        }
+        __syncthreads();                           // the cache is rewritten next
+        if (nb < 0) { want = -1; continue; }       // no whole chunk covered: full-size window, same base
+        rbase += nb;
+        done = klim;
+        want = 0;
     }
 }
 

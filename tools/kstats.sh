@@ -2,7 +2,7 @@
 # per-kernel average times of tools/run_scan.py under the current environment
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/kst; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o p -- python $R/tools/run_scan.py ${1:-1073741824} 6 > /dev/null 2>&1
+rm -rf /tmp/kst; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o p -- python $R/tools/run_scan.py ${1:-1073741824} 6 ${2:-single} ${3:-} > /dev/null 2>&1
 python - <<PY
 import csv
 tot = 0
