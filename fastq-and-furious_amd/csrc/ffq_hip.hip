@@ -74,6 +74,9 @@ struct ffq_ctx {
     unsigned long long *prof_d = nullptr;
     unsigned int *sbsum = nullptr;       // newlines per 64 tiles (k_scan_lines) -> ordinal bases
     long long *sbbase = nullptr;
+    TileQ *tileq = nullptr;              // fast path + decode: records / quality bytes per tile
+    unsigned int *sbq = nullptr;         //   quality bytes per 64 tiles
+    long long *sbqbase = nullptr;        //   their exclusive scan
     Fast4Hdr *hdr4 = nullptr;
     TermInfo4 *tinfo4 = nullptr;
     Ctl *ctl = nullptr;
@@ -160,7 +163,9 @@ static void free_chain(ffq_ctx *c)
     (void)hipFree(c->cb.lines); (void)hipFree(c->cb.qb); (void)hipFree(c->cb.term); (void)hipFree(c->cb.stage);
     (void)hipFree(c->cb.rloc); (void)hipFree(c->cb.qloc); (void)hipFree(c->cb.part); (void)hipFree(c->cb.mins);
     (void)hipFree(c->sbsum); (void)hipFree(c->sbbase); (void)hipFree(c->tinfo4);
+    (void)hipFree(c->tileq); (void)hipFree(c->sbq); (void)hipFree(c->sbqbase);
     c->sbsum = nullptr; c->sbbase = nullptr; c->tinfo4 = nullptr;
+    c->tileq = nullptr; c->sbq = nullptr; c->sbqbase = nullptr;
     c->cb = ChainBufs{};
     c->stage_cap = 0;
     c->cap_groups = 0;
@@ -232,6 +237,9 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
         HIPCHK(hipMalloc((void **)&c->sbsum, (size_t)nsb * sizeof(unsigned int)));
         HIPCHK(hipMalloc((void **)&c->sbbase, (size_t)nsb * sizeof(long long)));
         HIPCHK(hipMalloc((void **)&c->tinfo4, (size_t)ntiles * sizeof(TermInfo4)));
+        HIPCHK(hipMalloc((void **)&c->tileq, (size_t)ntiles * sizeof(TileQ)));
+        HIPCHK(hipMalloc((void **)&c->sbq, (size_t)nsb * sizeof(unsigned int)));
+        HIPCHK(hipMalloc((void **)&c->sbqbase, (size_t)nsb * sizeof(long long)));
         if (!c->hdr4) HIPCHK(hipMalloc((void **)&c->hdr4, sizeof(Fast4Hdr)));
     }
     c->cap_tiles = ntiles;
@@ -440,9 +448,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     hipStream_t sA = c->stream, sB = c->stream2;
     const int64_t ntiles = st.ntiles;
     const int nsb = (int)((ntiles + SB_TILES - 1) / SB_TILES);
-    // the four-line fast path (ffq_rows4.h) is tried first unless qualities are decoded (their
-    // CSR offsets need the general path's per-group sums) or it already failed on this buffer
-    const bool try_fast4 = !serial && !decode && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
+    // the four-line fast path (ffq_rows4.h) is tried first unless it already failed on this buffer
+    const bool try_fast4 = !serial && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
                            getenv("FFQ_NO_FAST4") == nullptr;
     const LineIndex L = make_index(c, a, ntiles);
     *c->h_L = L;
@@ -471,8 +478,13 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         // ---- plain four-line records: rows straight from newline ordinals, then validated -----
         hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sB, L, (const unsigned int *)c->sbsum, nsb, c->sbbase,
                            a.offset, c->hdr4);
+        if (decode) {
+            HIPCHK(hipMemsetAsync(c->tileq, 0, (size_t)ntiles * sizeof(TileQ), sB));
+            HIPCHK(hipMemsetAsync(c->sbq, 0, (size_t)nsb * sizeof(unsigned int), sB));
+        }
         hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sB, L,
-                           (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap);
+                           (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
+                           decode ? a.d_qoff : (int64_t *)nullptr, c->tileq, c->sbq);
         // the next scan's index kernel (stream A, possibly another context) may start once the
         // bandwidth-heavy kernels of this one are through: only the one-thread epilogue and
         // the result copy overlap with it, so per-kernel timings stay clean
@@ -480,6 +492,17 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         HIPCHK(hipStreamWaitEvent(sA, c->ev[5], 0));
         hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sB, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                            a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres);
+        if (decode) {
+            // quality offsets: superblock scan, per-tile fix-up (+ stream directory), total; then
+            // the decode itself.  All of it is skipped on the device if the fast path is rejected.
+            hipLaunchKernelGGL(k_qscan4, dim3(1), dim3(1024), 0, sB, (const unsigned int *)c->sbq, nsb, c->sbqbase);
+            hipLaunchKernelGGL(k_qfix4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sB, (int)ntiles,
+                               (const Fast4Hdr *)c->hdr4, (const TileQ *)c->tileq, (const long long *)c->sbqbase,
+                               a.d_qoff, a.table_cap, c->qdir, c->qdir_cap);
+            hipLaunchKernelGGL(k_qtotal4, dim3(1), dim3(1), 0, sB, c->dres, (const int64_t *)a.d_table, a.table_cap,
+                               a.d_qoff);
+            enqueue_decode(c, a, sB);
+        }
         st.stage = 1;
     } else {
         if (!serial) {

@@ -198,6 +198,7 @@ __global__ void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add
     else if (status == ST_HEAD_BEG) end = eof ? 0 : 1;
     else if (eof) end = (status == ST_QUAL_END) ? 2 : (status == ST_INVALID) ? 4 : 3;
     else end = (status == ST_INVALID) ? 4 : 1;
+    res->fallback = 0;               // the walker is exact: whatever a parallel attempt left here is void
     res->n_records = n;
     res->n_qual_bytes = qb;
     res->end_offset = off;

@@ -47,6 +47,13 @@ struct TermInfo4 {
     int32_t final_;
 };
 
+// per tile, for the decoded-quality offsets: its records and their quality bytes
+struct TileQ {
+    long long kfirst;              // record index of the tile's first record
+    int32_t nrec;                  // records whose "\n@" lies in the tile (0: none)
+    uint32_t qsum;                 // their quality bytes
+};
+
 // global ordinal of the first entry of tile t (the sentinel, if any, is ordinal 0)
 __device__ __forceinline__ long long tile_ordinal_base(const LineIndex &L, const long long *sbbase, int t, int lane)
 {
@@ -134,7 +141,9 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, const unsigned int
 // One wave per tile, four tiles per workgroup (no workgroup barrier).
 __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
-                                               int64_t *__restrict__ table, int64_t table_cap)
+                                               int64_t *__restrict__ table, int64_t table_cap,
+                                               int64_t *__restrict__ qoff, TileQ *__restrict__ tileq,
+                                               unsigned int *__restrict__ sbq)
 {
     __shared__ uint16_t s_ent_all[4][R4_LIST];      // the tile's own entries as stored (offset | flags << 14)
     __shared__ uint32_t s_la_all[4][8];             // look-ahead entries: position - tile base, flags << 30
@@ -228,6 +237,7 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
     long long kfirst = -1;
     int nrec_tile = 0;
     bool tile_term_done = false;
+    uint32_t qrun = 0;
     {
         // first owned element with ordinal >= j0 and (ordinal - j0) % 4 == 0
         long long i0 = (obl >= j0) ? ((4 - ((obl - j0) & 3)) & 3) : (j0 - obl);
@@ -324,6 +334,13 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
             }
             // rows: COMPLETE records (cls 0, 3) and the final record
             const bool emit = act && (cls == 0 || cls == 3 || (cls == 2 && fin));
+            if (qoff) {
+                // tile-relative offsets of the decoded qualities; k_qfix4 adds the tile's base
+                const uint32_t ql = emit ? (uint32_t)(p5 - p4) : 0u;
+                const uint32_t incl = wave_incl_scan(ql);
+                if (act && kfirst + r < table_cap) qoff[kfirst + r] = (int64_t)(qrun + incl - ql);
+                qrun += (uint32_t)__shfl((int)incl, 63);
+            }
             int64_t *mine = s_rows + lane * 6;
             mine[0] = p0 + add; mine[1] = p1 + add; mine[2] = p1 + 1 + add;
             mine[3] = p3 + add; mine[4] = p4 + add; mine[5] = p5 + add;
@@ -343,6 +360,80 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
             wave_sync();
         }
     }
+    if (qoff && lane == 0 && nrec_tile > 0) {
+        tileq[t] = TileQ{kfirst, nrec_tile, qrun};
+        atomicAdd(&sbq[t / SB_TILES], qrun);
+    }
+}
+
+// exclusive scan of the per-superblock quality bytes (one workgroup)
+__global__ __launch_bounds__(1024) void k_qscan4(const unsigned int *__restrict__ sbq, int nsb,
+                                                 long long *__restrict__ sbqbase)
+{
+    __shared__ long long s_v[1024];
+    const int tid = threadIdx.x;
+    long long carry = 0;
+    for (int b0 = 0; b0 < nsb; b0 += 1024) {
+        const int b = b0 + tid;
+        const long long v = (b < nsb) ? (long long)sbq[b] : 0;
+        s_v[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            long long x = 0;
+            if (tid >= d) x = s_v[tid - d];
+            __syncthreads();
+            s_v[tid] += x;
+            __syncthreads();
+        }
+        if (b < nsb) sbqbase[b] = carry + s_v[tid] - v;
+        const long long tot = s_v[1023];
+        __syncthreads();
+        carry += tot;
+    }
+}
+
+// One wave per tile: tile-relative quality offsets -> stream offsets, directory of the stream.
+__global__ __launch_bounds__(256) void k_qfix4(int ntiles, const Fast4Hdr *__restrict__ hdr,
+                                               const TileQ *__restrict__ tileq,
+                                               const long long *__restrict__ sbqbase,
+                                               int64_t *__restrict__ qoff, int64_t table_cap,
+                                               int64_t *__restrict__ qdir, int64_t qdir_cap)
+{
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wid;
+    if (t >= ntiles || !hdr->attempt) return;
+    const TileQ me = tileq[t];
+    if (me.nrec <= 0) return;
+    const int t0 = (t / SB_TILES) * SB_TILES;
+    const uint32_t before = (t0 + lane < t) ? tileq[t0 + lane].qsum : 0u;       // SB_TILES == 64 lanes
+    const int64_t base = sbqbase[t / SB_TILES] + (int64_t)wave_sum_u32(before);
+    for (int r0 = 0; r0 < me.nrec; r0 += 64) {
+        const int r = r0 + lane;
+        const int64_t idx = me.kfirst + r;
+        const bool act = r < me.nrec && idx < table_cap;
+        const int64_t loc = act ? qoff[idx] : 0;
+        // the record's bytes end where the next record's begin
+        int64_t nxt = ((int64_t)__shfl((int)(loc >> 32), lane + 1) << 32) | (uint32_t)__shfl((int)(uint32_t)loc, lane + 1);
+        if (r + 1 >= me.nrec) nxt = me.qsum;
+        else if (lane == 63) nxt = (idx + 1 < table_cap) ? qoff[idx + 1] : (int64_t)me.qsum;
+        if (act) {
+            qoff[idx] = base + loc;
+            qdir_mark(qdir, qdir_cap, base + loc, nxt - loc, idx);
+        }
+    }
+}
+
+// total of the decoded stream and its closing offset (after k_finalize4 and k_qfix4)
+__global__ void k_qtotal4(DevRes *res, const int64_t *__restrict__ table, int64_t table_cap,
+                          int64_t *__restrict__ qoff)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (res->fallback) return;
+    const int64_t n = res->n_records;
+    int64_t tot = 0;
+    if (n > 0 && n <= table_cap) tot = qoff[n - 1] + (table[(n - 1) * 6 + 5] - table[(n - 1) * 6 + 4]);
+    res->n_qual_bytes = tot;
+    if (n <= table_cap) qoff[n] = tot;
 }
 
 // validity + result block (end state per fastqandfurious.py:256-279)

@@ -154,16 +154,104 @@ def test_long_records(gpu_ctx, oracle):
     check_same(gpu_ctx, oracle, b"".join(parts))
 
 
-def test_decode_quals(gpu_ctx, hipmod, oracle, pkg):
+def decode_same(ctx, hipmod, oracle, data, flags=0, **kw):
+    want, *_ = oracle.scan(data, **kw)
+    wq, wqoff = oracle.decode_quals(data, want)
+    table, res, qual, qoff = ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL | flags, **kw)
+    assert (table == want).all()
+    assert (qoff == wqoff).all()
+    assert int(res.n_qual_bytes) == wq.size
+    assert (qual == wq).all()
+    return res
+
+
+def random_records(rng, n, seq_lo, seq_hi, wrap=0, hdr_hi=40, repeat_hdr=False):
+    """n records with sequence lengths in [seq_lo, seq_hi]; wrap > 0 folds sequence and
+    quality lines at `wrap` columns."""
+    parts = []
+    for i in range(n):
+        L = int(rng.integers(seq_lo, seq_hi + 1))
+        h = b"r%d" % i + b"x" * int(rng.integers(0, hdr_hi))
+        seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=L).tobytes()
+        qual = rng.choice(np.frombuffer(bytes(range(35, 74)), dtype=np.uint8), size=L).tobytes()   # no '@', no '+'
+        if wrap:
+            seq = b"\n".join(seq[k:k + wrap] for k in range(0, L, wrap))
+            qual = b"\n".join(qual[k:k + wrap] for k in range(0, L, wrap))
+        parts.append(b"@" + h + b"\n" + seq + b"\n+" + (h if repeat_hdr else b"") + b"\n" + qual + b"\n")
+    return b"".join(parts)
+
+
+def test_decode_quals(gpu_ctx, hipmod, oracle, pkg, chain_path):
     from fastqandfurious_amd import synth
     for data in (synth.single(0, 3000, seed=42), synth.wrapped(0, 3000, seed=43)[0]):
-        want, *_ = oracle.scan(data)
-        wq, wqoff = oracle.decode_quals(data, want)
-        table, res, qual, qoff = gpu_ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL)
-        assert (table == want).all()
-        assert (qoff == wqoff).all()
-        assert (qual == wq).all()
-        assert int(res.n_qual_bytes) == wq.size
+        decode_same(gpu_ctx, hipmod, oracle, data)
+
+
+@pytest.mark.parametrize("fn", FILES)
+@pytest.mark.parametrize("serial", (False, True))
+def test_decode_golden_files(gpu_ctx, hipmod, oracle, fn, serial):
+    decode_same(gpu_ctx, hipmod, oracle, golden_file(fn), flags=hipmod.F_FORCE_SERIAL if serial else 0)
+
+
+@pytest.mark.parametrize("shape", ("tiny", "short", "illumina", "mixed", "long", "wrapped", "huge"))
+def test_decode_record_shapes(gpu_ctx, hipmod, oracle, chain_path, shape):
+    """Quality streams of every granularity against the output blocks of k_decode_stream:
+    thousands of records per 64 KiB block (several LDS windows, byte-wise tails), records
+    that straddle chunks, records that span several blocks."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(shape.encode()))
+    data = {
+        "tiny": lambda: random_records(rng, 60000, 1, 3, hdr_hi=3),
+        "short": lambda: random_records(rng, 40000, 1, 40, hdr_hi=8),
+        "illumina": lambda: random_records(rng, 20000, 151, 151, repeat_hdr=True),
+        "mixed": lambda: random_records(rng, 20000, 1, 400),
+        "long": lambda: random_records(rng, 60, 30000, 300000),
+        "wrapped": lambda: random_records(rng, 8000, 1, 700, wrap=61),
+        "huge": lambda: random_records(rng, 3, 1 << 20, 3 << 20),
+    }[shape]()
+    res = decode_same(gpu_ctx, hipmod, oracle, data)
+    if chain_path == "fast4" and shape in ("illumina", "mixed", "long", "huge"):
+        assert res.path == 3
+    # a stream that ends without the last newline: the final record is decoded too
+    decode_same(gpu_ctx, hipmod, oracle, data[:-1])
+    # not at eof: the cut record is not part of the stream
+    decode_same(gpu_ctx, hipmod, oracle, data[:len(data) * 2 // 3], eof=False)
+
+
+def test_decode_unaligned_destination_and_small_buffer(gpu_ctx, hipmod, oracle, pkg):
+    """Device entry point with a destination at every alignment; a quality buffer that is
+    too small reports the size needed and keeps what fits."""
+    import torch
+    from fastqandfurious_amd import synth
+    data = synth.single(0, 2500, seed=7)
+    want, *_ = oracle.scan(data)
+    wq, wqoff = oracle.decode_quals(data, want)
+    dbuf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    cap = len(want) + 8
+    table = torch.empty((cap, 6), dtype=torch.int64, device="cuda")
+    qoff = torch.empty(cap + 1, dtype=torch.int64, device="cuda")
+    qbuf = torch.zeros(wq.size + 64, dtype=torch.int8, device="cuda")
+    for shift in (0, 1, 7, 15):
+        qbuf.fill_(99)
+        rc, res = gpu_ctx.scan_device(dbuf.data_ptr(), len(data), table.data_ptr(), cap, flags=hipmod.F_DECODE_QUAL,
+                                      d_qual=qbuf.data_ptr() + shift, qual_cap=wq.size, d_qoff=qoff.data_ptr())
+        assert rc == 0 and int(res.n_qual_bytes) == wq.size
+        got = qbuf.cpu().numpy()
+        assert (got[shift:shift + wq.size] == wq).all()
+        assert (got[:shift] == 99).all() and (got[shift + wq.size:] == 99).all()      # nothing outside
+        assert (qoff[:len(want) + 1].cpu().numpy() == wqoff).all()
+    small = wq.size // 2 + 5
+    qbuf.fill_(99)
+    rc, res = gpu_ctx.scan_device(dbuf.data_ptr(), len(data), table.data_ptr(), cap, flags=hipmod.F_DECODE_QUAL,
+                                  d_qual=qbuf.data_ptr(), qual_cap=small, d_qoff=qoff.data_ptr())
+    assert rc == hipmod.E_TABLE_FULL and int(res.n_qual_bytes) == wq.size
+    got = qbuf.cpu().numpy()
+    assert (got[:small] == wq[:small]).all() and (got[small:] == 99).all()
+
+
+def test_decode_64mib(gpu_ctx, hipmod, oracle, pkg, chain_path):
+    from fastqandfurious_amd import synth
+    decode_same(gpu_ctx, hipmod, oracle, synth.single(5, (64 << 20) // synth.RECORD_BYTES, seed=11))
 
 
 def test_arrayadd(gpu_ctx, golden, oracle, pkg):
