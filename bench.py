@@ -70,6 +70,66 @@ def cpu_baseline(sample_u8, budget_s=10.0):
     }
 
 
+def cpu_baseline_all_cores(sample_u8, budget_s=5.0):
+    """Same oracle scan, one independent pass loop per host core (threads; ctypes drops the GIL)."""
+    import threading
+    from oracle import ffq_oracle
+    L = ffq_oracle.lib()
+    n = int(sample_u8.size)
+    cores = os.cpu_count() or 1
+    cap = n // 64 + 16
+    counts = [0] * cores
+    t_end = time.perf_counter() + budget_s
+
+    def work(i):
+        table = np.empty((cap, 6), dtype=np.int64)
+        out = np.zeros(4, dtype=np.int64)
+        while time.perf_counter() < t_end:
+            L.ffq_oracle_scan(sample_u8.ctypes.data, n, 1, 0, 1, 0, -1, table.ctypes.data, cap, out.ctypes.data)
+            counts[i] += 1
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el = time.perf_counter() - t0
+    return {"value": round(n * sum(counts) / el / 1e9, 4), "unit": "GB/s", "cores": cores,
+            "sample": "%d passes over %d bytes on %d threads, %.1f s" % (sum(counts), n, cores, el)}
+
+
+def cpu_iterator_rate(sample_bytes, budget_s=3.0):
+    """The reference-shaped number: the package's readfastq_iter with its pure-Python entrypos
+    (mirror of src/fastqandfurious.py:39-100, 198-279), one record per Python call, one core."""
+    import io
+    from fastqandfurious_amd import fastqandfurious as F
+    n = 0
+    t0 = time.perf_counter()
+    last = 0
+    for e in F.readfastq_iter(io.BytesIO(sample_bytes), 1 << 20, F.entryfunc_abspos, F.entrypos):
+        n += 1
+        last = e[5]
+        if (n & 1023) == 0 and time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"value": round(last / el / 1e9, 5), "unit": "GB/s", "m_reads_per_s": round(n / el / 1e6, 4), "cores": 1,
+            "sample": "%d records through readfastq_iter(entryfunc_abspos, Python entrypos), %.1f s" % (n, el)}
+
+
+def host_inclusive(ctx, sample_u8, flags):
+    """Host buffer in, host table out (ffq_scan_host): pinned staging + H2D + kernels + D2H.
+    PCIe-bound; reported beside `value`, never as `value`."""
+    ctx.scan_host(sample_u8, flags=flags)
+    reps, t0 = 3, time.perf_counter()
+    for _ in range(reps):
+        out = ctx.scan_host(sample_u8, flags=flags)
+    el = (time.perf_counter() - t0) / reps
+    return {"value": round(sample_u8.size / el / 1e9, 3), "unit": "GB/s",
+            "m_reads_per_s": round(int(out[1].n_records) / el / 1e6, 3),
+            "sample": "ffq_scan_host over the first %d bytes, pageable host memory in and out" % sample_u8.size}
+
+
 def pmc_traffic(workload):
     """HBM bytes per k_scan_lines launch from the committed rocprofv3 PMC passes of this
     workload (profiles/*/pmc_fetch_write.json): FETCH_SIZE and WRITE_SIZE are KiB; on gfx950
@@ -286,6 +346,9 @@ def main():
             sample = shard.host_sample(256 << 20)
             line["cpu_baseline"] = cpu_baseline(sample, args.cpu_seconds)
             line["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(sample[:64 << 20], args.cpu_seconds / 2)
+            line["cpu_baseline"]["python_iterator"] = cpu_iterator_rate(sample.tobytes(), 3.0)
+            line["host_inclusive"] = host_inclusive(ctx, sample, flags)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

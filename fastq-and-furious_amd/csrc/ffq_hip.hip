@@ -60,7 +60,8 @@ struct ffq_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;       // chain kernels, overlapped with the scan kernel chunk by chunk
     std::vector<hipEvent_t> chunk_ev;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool decode_timed = false;           // ev[6] marks the start of the decode kernel of the pending front
     // scratch, grow-only
     int64_t cap_tiles = 0;
     uint16_t *ent = nullptr;
@@ -142,7 +143,7 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
         e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     }
-    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 7 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&c->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipMalloc((void **)&c->dres, sizeof(DevRes));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_L, sizeof(LineIndex));
@@ -195,7 +196,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->stage_h) (void)hipHostFree(c->stage_h);
     if (c->tab_h) (void)hipHostFree(c->tab_h);
-    for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 7; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream && c->owns_streams) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -386,8 +387,9 @@ static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
 
 // Phred decode of the finished table: the grid covers the largest possible quality stream;
 // workgroups past the real end return at once
-static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st)
+static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st, bool timed = false)
 {
+    if (timed) { (void)hipEventRecord(c->ev[6], st); c->decode_timed = true; }
     const int64_t nblk = qdir_blocks(a.n_bytes, a.qual_cap);
     static const int ablate = getenv("FFQ_DQ_ABLATE") ? atoi(getenv("FFQ_DQ_ABLATE")) : 0;
     hipLaunchKernelGGL(k_decode_stream, dim3((unsigned)nblk), dim3(256), 0, st, a.d_buf, a.n_bytes, a.s,
@@ -396,7 +398,8 @@ static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st)
 }
 
 // general path: chain summaries -> resolve -> expand (+ fused decode) -> finalize, on stream B
-static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups)
+static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups,
+                           bool timed = false)
 {
     const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
     int64_t *qoff = decode ? a.d_qoff : nullptr;
@@ -431,7 +434,7 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sB, cb, (const DevRes *)c->dres, a.add, a.d_table,
                        a.table_cap, qoff, c->qdir, c->qdir_cap);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sB, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff);
-    if (decode) enqueue_decode(c, a, sB);
+    if (decode) enqueue_decode(c, a, sB, timed);
     return FFQ_OK;
 }
 
@@ -452,6 +455,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     const bool try_fast4 = !serial && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
                            getenv("FFQ_NO_FAST4") == nullptr;
     const LineIndex L = make_index(c, a, ntiles);
+    c->decode_timed = false;
     *c->h_L = L;
     HIPCHK(hipMemcpyAsync(c->d_L, c->h_L, sizeof(LineIndex), hipMemcpyHostToDevice, sA));
 
@@ -486,10 +490,12 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            decode ? a.d_qoff : (int64_t *)nullptr, c->tileq, c->sbq);
         // the next scan's index kernel (stream A, possibly another context) may start once the
-        // bandwidth-heavy kernels of this one are through: only the one-thread epilogue and
+        // bandwidth-heavy kernels of this one are through: only the one-thread epilogues and
         // the result copy overlap with it, so per-kernel timings stay clean
-        HIPCHK(hipEventRecord(c->ev[5], sB));
-        HIPCHK(hipStreamWaitEvent(sA, c->ev[5], 0));
+        if (!decode) {
+            HIPCHK(hipEventRecord(c->ev[5], sB));
+            HIPCHK(hipStreamWaitEvent(sA, c->ev[5], 0));
+        }
         hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sB, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                            a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres);
         if (decode) {
@@ -501,12 +507,14 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
                                a.d_qoff, a.table_cap, c->qdir, c->qdir_cap);
             hipLaunchKernelGGL(k_qtotal4, dim3(1), dim3(1), 0, sB, c->dres, (const int64_t *)a.d_table, a.table_cap,
                                a.d_qoff);
-            enqueue_decode(c, a, sB);
+            enqueue_decode(c, a, sB, true);
+            HIPCHK(hipEventRecord(c->ev[5], sB));
+            HIPCHK(hipStreamWaitEvent(sA, c->ev[5], 0));
         }
         st.stage = 1;
     } else {
         if (!serial) {
-            int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups);
+            int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups, true);
             if (rc) return rc;
         }
         HIPCHK(hipEventRecord(c->ev[5], sB));
@@ -556,6 +564,11 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); res->ms_chain += ms;
         res->ms_decode = 0;
+        if (c->decode_timed) {
+            // the decode kernel is the tail of the front: split it off the chain time
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[2]));
+            res->ms_decode = ms; res->ms_chain -= ms;
+        }
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[2])); res->ms_total += ms;
 
         if (st.stage == 1) {
