@@ -61,6 +61,7 @@ struct ffq_ctx {
     hipStream_t stream2 = nullptr;       // chain kernels, overlapped with the scan kernel chunk by chunk
     std::vector<hipEvent_t> chunk_ev;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int fast4_skip = 0;                  // scans left that go straight to the general kernels (see scan_finish)
     bool decode_timed = false;           // ev[6] marks the start of the decode kernel of the pending front
     // scratch, grow-only
     int64_t cap_tiles = 0;
@@ -292,6 +293,11 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
     return FFQ_OK;
 }
 
+extern "C" void ffq_ctx_forget(ffq_ctx *c)
+{
+    if (c) c->fast4_skip = 0;
+}
+
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
 {
     if (!c || max_bytes < 0) return fail(FFQ_E_ARG, "ffq_ctx_reserve: bad argument");
@@ -452,6 +458,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     const int64_t ntiles = st.ntiles;
     const int nsb = (int)((ntiles + SB_TILES - 1) / SB_TILES);
     // the four-line fast path (ffq_rows4.h) is tried first unless it already failed on this buffer
+    // (nor while the context remembers that its recent input was not four-line)
+    if (c->fast4_skip > 0 && !st.fast4_failed) { c->fast4_skip--; st.fast4_failed = true; }
     const bool try_fast4 = !serial && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
                            getenv("FFQ_NO_FAST4") == nullptr;
     const LineIndex L = make_index(c, a, ntiles);
@@ -576,8 +584,10 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 fill_result(res, *c->h_res, 3, st.retries);
                 break;
             }
-            // not plain four-line input: the general kernels, from the same line index
+            // not plain four-line input: the general kernels, from the same line index.  The next
+            // scans of this context skip the attempt (and the host round trip it costs here).
             st.fast4_failed = true;
+            c->fast4_skip = 15;
             int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups);
             if (rc) return rc;
             HIPCHK(hipEventRecord(c->ev[4], sB));

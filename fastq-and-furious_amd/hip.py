@@ -35,7 +35,7 @@ F_FORCE_SERIAL = 2
 # every symbol include/ffq.h declares (tests check the library exports them all)
 SYMBOLS = (
     "ffq_abi_version", "ffq_last_error", "ffq_device_count", "ffq_ctx_create", "ffq_ctx_create_shared",
-    "ffq_ctx_destroy", "ffq_ctx_reserve", "ffq_ctx_stream", "ffq_dev_alloc", "ffq_dev_free",
+    "ffq_ctx_destroy", "ffq_ctx_reserve", "ffq_ctx_forget", "ffq_ctx_stream", "ffq_dev_alloc", "ffq_dev_free",
     "ffq_pinned_alloc", "ffq_pinned_free", "ffq_copy_h2d", "ffq_copy_d2h", "ffq_sync",
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
@@ -91,6 +91,8 @@ def lib():
         L.ffq_ctx_destroy.argtypes = [vp]
         L.ffq_ctx_destroy.restype = None
         L.ffq_ctx_reserve.argtypes = [vp, i64]
+        L.ffq_ctx_forget.argtypes = [vp]
+        L.ffq_ctx_forget.restype = None
         L.ffq_ctx_stream.argtypes = [vp]
         L.ffq_ctx_stream.restype = vp
         L.ffq_dev_alloc.argtypes = [vp, i64, P(vp)]
@@ -162,6 +164,10 @@ class Context:
 
     def reserve(self, max_bytes):
         check(lib().ffq_ctx_reserve(self.handle, int(max_bytes)))
+
+    def forget(self):
+        """Drop the context's memory of what its recent input looked like."""
+        lib().ffq_ctx_forget(self.handle)
 
     def selftest(self):
         check(lib().ffq_selftest(self.handle))

@@ -103,6 +103,10 @@ void        ffq_ctx_destroy(ffq_ctx *ctx);
 /* Pre-size the per-context scratch (line index, group summaries) for buffers
  * of up to max_bytes so that no allocation happens inside a timed scan.     */
 int         ffq_ctx_reserve(ffq_ctx *ctx, int64_t max_bytes);
+/* A context remembers whether its recent input was plain four-line FASTQ and
+ * then starts the following scans with the kernels that fit (results are the
+ * same either way).  This forgets that history.                             */
+void        ffq_ctx_forget(ffq_ctx *ctx);
 /* The HIP stream all of this context's work is enqueued on (hipStream_t).   */
 void       *ffq_ctx_stream(ffq_ctx *ctx);
 

@@ -43,6 +43,15 @@ def gpu_ctx(pkg):
     return ctx
 
 
+@pytest.fixture(autouse=True)
+def _forget_input_history(request):
+    """GPU tests assert which kernels ran (res.path): start each from a context without
+    memory of the previous test's input."""
+    if request.node.get_closest_marker("gpu") is not None:
+        request.getfixturevalue("gpu_ctx").forget()
+    yield
+
+
 def golden_file(name):
     with open(os.path.join(GOLDEN_DIR, "data", name), "rb") as fh:
         return fh.read()
