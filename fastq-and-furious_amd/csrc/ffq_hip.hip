@@ -470,7 +470,6 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     // ---- line index: one launch over the full tiles on stream A; the ragged last tile
     //      (byte-wise loads, one workgroup) beside it on stream B ---------------------------
     HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
-    HIPCHK(hipMemsetAsync(c->sbsum, 0, (size_t)nsb * sizeof(unsigned int), sA));
     HIPCHK(hipEventRecord(c->ev[0], sA));
     HIPCHK(hipStreamWaitEvent(sB, c->ev[0], 0));        // stream B starts behind the resets
     {
@@ -478,25 +477,25 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         if (ntiles > nfull)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 4>), dim3((unsigned)(ntiles - nfull)), dim3(256), 0,
                                sB, a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
-                               (int)nfull, 0, c->sbsum);
+                               (int)nfull, 0);
         if (nfull > 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 6>), dim3((unsigned)nfull), dim3(256), 0, sA,
-                               a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
-                               c->sbsum);
+                               a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl);
     }
     HIPCHK(hipEventRecord(c->ev[1], sA));
     HIPCHK(hipStreamWaitEvent(sB, c->ev[1], 0));
     if (try_fast4) {
         // ---- plain four-line records: rows straight from newline ordinals, then validated -----
+        hipLaunchKernelGGL(k_sum64, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, sB, (const uint32_t *)c->cnt, 1,
+                           (int64_t)ntiles, c->sbsum, nsb);
         hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sB, L, (const unsigned int *)c->sbsum, nsb, c->sbbase,
                            a.offset, c->hdr4);
         if (decode) {
             HIPCHK(hipMemsetAsync(c->tileq, 0, (size_t)ntiles * sizeof(TileQ), sB));
-            HIPCHK(hipMemsetAsync(c->sbq, 0, (size_t)nsb * sizeof(unsigned int), sB));
         }
         hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sB, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
-                           decode ? a.d_qoff : (int64_t *)nullptr, c->tileq, c->sbq);
+                           decode ? a.d_qoff : (int64_t *)nullptr, c->tileq);
         // the next scan's index kernel (stream A, possibly another context) may start once the
         // bandwidth-heavy kernels of this one are through: only the one-thread epilogues and
         // the result copy overlap with it, so per-kernel timings stay clean
@@ -509,6 +508,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         if (decode) {
             // quality offsets: superblock scan, per-tile fix-up (+ stream directory), total; then
             // the decode itself.  All of it is skipped on the device if the fast path is rejected.
+            hipLaunchKernelGGL(k_sum64, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, sB,
+                               reinterpret_cast<const uint32_t *>(c->tileq) + 3, 4, (int64_t)ntiles, c->sbq, nsb);
             hipLaunchKernelGGL(k_qscan4, dim3(1), dim3(1024), 0, sB, (const unsigned int *)c->sbq, nsb, c->sbqbase);
             hipLaunchKernelGGL(k_qfix4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sB, (int)ntiles,
                                (const Fast4Hdr *)c->hdr4, (const TileQ *)c->tileq, (const long long *)c->sbqbase,

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
                                                     unsigned long long *__restrict__ ovf,
                                                     uint16_t *__restrict__ pool,
                                                     unsigned long long pool_cap, Ctl *ctl, int tile0,
-                                                    int ablate, unsigned int *__restrict__ sbsum)
+                                                    int ablate)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_list[SLOT];
     __shared__ uint32_t s_wtot[4];
@@ -137,9 +137,10 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
         rb += rowtot[i];
     }
     if (tid == 0 && ablate != 7) {
+        // no atomics here: an agent-scope atomic of 64 tiles on one address costs more than the
+        // whole scan (measured: +45 us per GiB); the per-superblock sums are a kernel of their own
         cnt[tile] = total;
-        ovf[tile] = pbase;
-        if (sbsum) atomicAdd(&sbsum[tile >> 6], total);     // newlines per 64 tiles (fast four-line path)
+        if (dense) ovf[tile] = pbase;                       // read only for tiles with cnt > SLOT
     }
     if (ablate == 6 || ablate == 7) return;
     if (!dense) {

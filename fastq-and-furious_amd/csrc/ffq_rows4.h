@@ -19,8 +19,8 @@
 // (ffq_chain.h) redo the work from the same line index.  So the output is either the
 // reference's chain, bit for bit, or discarded.
 //
-//   k_sbscan      exclusive scan of the per-superblock newline counts (filled by
-//                 k_scan_lines with one atomic per tile), first candidate j0
+//   k_sum64       newlines per superblock of 64 tiles (from the tile counts)
+//   k_sbscan      exclusive scan of those, first candidate j0
 //   k_rows4       one wave per tile: rows of the records whose "\n@" lies in the tile,
 //                 written as whole lines through an LDS transpose (48 B / record)
 //   k_finalize4   validity, record count, end state
@@ -60,6 +60,19 @@ __device__ __forceinline__ long long tile_ordinal_base(const LineIndex &L, const
     const int sb = t / SB_TILES, t0 = sb * SB_TILES;
     const uint32_t c = (t0 + lane < t) ? L.cnt[t0 + lane] : 0u;       // SB_TILES == 64 lanes
     return sbbase[sb] + (long long)wave_sum_u32(c) + L.s;
+}
+
+// sums of 64 consecutive u32 values at a stride of `stride` words: one wave per sum
+// (newlines per superblock from cnt[]; quality bytes per superblock from tileq[].qsum)
+__global__ __launch_bounds__(256) void k_sum64(const uint32_t *__restrict__ src, int stride, int64_t nsrc,
+                                               unsigned int *__restrict__ dst, int ndst)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= ndst) return;
+    const int64_t i = (int64_t)b * 64 + lane;
+    const uint32_t v = (i < nsrc) ? src[i * stride] : 0u;
+    const uint32_t t = wave_sum_u32(v);
+    if (lane == 0) dst[b] = t;
 }
 
 __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, const unsigned int *__restrict__ sbsum, int nsb,
@@ -142,8 +155,7 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, const unsigned int
 __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap,
-                                               int64_t *__restrict__ qoff, TileQ *__restrict__ tileq,
-                                               unsigned int *__restrict__ sbq)
+                                               int64_t *__restrict__ qoff, TileQ *__restrict__ tileq)
 {
     __shared__ uint16_t s_ent_all[4][R4_LIST];      // the tile's own entries as stored (offset | flags << 14)
     __shared__ uint32_t s_la_all[4][8];             // look-ahead entries: position - tile base, flags << 30
@@ -360,10 +372,7 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
             wave_sync();
         }
     }
-    if (qoff && lane == 0 && nrec_tile > 0) {
-        tileq[t] = TileQ{kfirst, nrec_tile, qrun};
-        atomicAdd(&sbq[t / SB_TILES], qrun);
-    }
+    if (qoff && lane == 0 && nrec_tile > 0) tileq[t] = TileQ{kfirst, nrec_tile, qrun};
 }
 
 // exclusive scan of the per-superblock quality bytes (one workgroup)

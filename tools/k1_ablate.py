@@ -6,7 +6,7 @@ import torch
 import fastqandfurious_amd
 from fastqandfurious_amd import hip
 levels = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7".split(","))]
-nbytes = 1 << 30
+nbytes = int(float(sys.argv[2])) if len(sys.argv) > 2 else (1 << 30)
 ctx = hip.Context(0)
 n = nbytes // 322
 buf = torch.empty(n * 322 + 64, dtype=torch.uint8, device='cuda')
