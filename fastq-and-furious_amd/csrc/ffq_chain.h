@@ -85,6 +85,24 @@ struct DevRes {
     int32_t has_final, pad;
 };
 
+// Result hand-over.  The last result-writing kernel of a scan copies the result block and the
+// control block into host-mapped pinned memory and leaves the control block zeroed for the
+// context's next scan: no copy engine and no memset on the path between two scans.
+struct Pub {
+    Ctl *ctl;
+    Ctl *h_ctl;        // nullptr: this kernel is not the publisher
+    DevRes *h_res;
+};
+__device__ __forceinline__ void publish(const Pub &pb, const DevRes *res)
+{
+    if (!pb.h_res) return;
+    *pb.h_res = *res;
+    pb.h_ctl->err = pb.ctl->err;
+    pb.h_ctl->pool_head = pb.ctl->pool_head;
+    pb.ctl->err = 0;
+    pb.ctl->pool_head = 0;
+}
+
 // window accessor: flat LDS index while inside the window, global index beyond
 struct WH {
     int32_t idx;     // >= 0: window entry; -1: use g; -2: before the window's first entry

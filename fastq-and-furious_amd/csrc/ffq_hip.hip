@@ -74,7 +74,6 @@ struct ffq_ctx {
     ChainBufs cb = {};
     int64_t stage_cap = 0;        // StageRec entries allocated
     unsigned long long *prof_d = nullptr;
-    unsigned int *sbsum = nullptr;       // newlines per 64 tiles (k_scan_lines) -> ordinal bases
     long long *sbbase = nullptr;
     TileQ *tileq = nullptr;              // fast path + decode: records / quality bytes per tile
     unsigned int *sbq = nullptr;         //   quality bytes per 64 tiles
@@ -88,8 +87,11 @@ struct ffq_ctx {
     int64_t *qdir = nullptr;           // directory of the decoded-quality stream (qdir_mark)
     int64_t qdir_cap = 0;
     // pinned mirrors
-    Ctl *h_ctl = nullptr;
+    Ctl *h_ctl = nullptr;               // host-mapped pinned: written by the publishing kernel (Pub)
     DevRes *h_res = nullptr;
+    Ctl *hm_ctl = nullptr;              // device addresses of the two
+    DevRes *hm_res = nullptr;
+    bool ctl_clean = false;             // the control block is zero (creation, or a publisher ran last)
     // staging for the host-buffer entry points
     uint8_t *stage_d = nullptr;
     int64_t stage_d_cap = 0;
@@ -149,8 +151,10 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&c->dres, sizeof(DevRes));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_L, sizeof(LineIndex));
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_L, sizeof(LineIndex), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_res, sizeof(DevRes), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_res, sizeof(DevRes), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->hm_ctl, c->h_ctl, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->hm_res, c->h_res, 0);
     if (e != hipSuccess) {
         ffq_ctx_destroy(c);
         return fail(FFQ_E_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -164,9 +168,9 @@ static void free_chain(ffq_ctx *c)
     (void)hipFree(c->cb.y); (void)hipFree(c->cb.exit); (void)hipFree(c->cb.cnt); (void)hipFree(c->cb.flags);
     (void)hipFree(c->cb.lines); (void)hipFree(c->cb.qb); (void)hipFree(c->cb.term); (void)hipFree(c->cb.stage);
     (void)hipFree(c->cb.rloc); (void)hipFree(c->cb.qloc); (void)hipFree(c->cb.part); (void)hipFree(c->cb.mins);
-    (void)hipFree(c->sbsum); (void)hipFree(c->sbbase); (void)hipFree(c->tinfo4);
+    (void)hipFree(c->sbbase); (void)hipFree(c->tinfo4);
     (void)hipFree(c->tileq); (void)hipFree(c->sbq); (void)hipFree(c->sbqbase);
-    c->sbsum = nullptr; c->sbbase = nullptr; c->tinfo4 = nullptr;
+    c->sbbase = nullptr; c->tinfo4 = nullptr;
     c->tileq = nullptr; c->sbq = nullptr; c->sbqbase = nullptr;
     c->cb = ChainBufs{};
     c->stage_cap = 0;
@@ -236,7 +240,6 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
     HIPCHK(hipMalloc((void **)&c->cb.mins, 16));
     {
         const int64_t nsb = (ntiles + SB_TILES - 1) / SB_TILES;
-        HIPCHK(hipMalloc((void **)&c->sbsum, (size_t)nsb * sizeof(unsigned int)));
         HIPCHK(hipMalloc((void **)&c->sbbase, (size_t)nsb * sizeof(long long)));
         HIPCHK(hipMalloc((void **)&c->tinfo4, (size_t)ntiles * sizeof(TermInfo4)));
         HIPCHK(hipMalloc((void **)&c->tileq, (size_t)ntiles * sizeof(TileQ)));
@@ -403,7 +406,10 @@ static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st, bool t
                        (const DevRes *)c->dres, a.table_cap, a.add, a.qual_add, a.d_qual, a.qual_cap, ablate);
 }
 
-// general path: chain summaries -> resolve -> expand (+ fused decode) -> finalize, on stream B
+static Pub make_pub(ffq_ctx *c) { return Pub{c->ctl, c->hm_ctl, c->hm_res}; }
+static Pub no_pub(ffq_ctx *c) { return Pub{c->ctl, nullptr, nullptr}; }
+
+// general path: chain summaries -> resolve -> expand -> finalize (publishes) [-> decode]
 static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups,
                            bool timed = false)
 {
@@ -416,36 +422,43 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     cb.ng = ngroups;
     cb.nmax = nmax;
     cb.prof = nullptr;
-    hipStream_t sB = c->stream2;
+    hipStream_t sA = c->stream;
     const char *abl = getenv("FFQ_ABLATE");
     const int ablate = abl ? atoi(abl) : 0;
     if (getenv("FFQ_PROF")) {
         if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 64));
-        HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sB));
+        HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sA));
         cb.prof = c->prof_d;
     }
     const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
-    HIPCHK(hipMemsetAsync(cb.flags, 0, (size_t)ngroups * 4, sB));
+    HIPCHK(hipMemsetAsync(cb.flags, 0, (size_t)ngroups * 4, sA));
     if (!dense_cfg)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
-                           dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sB, L,
+                           dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
-                           dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sB, L,
+                           dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
-    HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sB));
-    hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sB, cb);
-    hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sB, cb, nblk, a.eof, a.offset, a.add, c->dres);
-    hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sB, cb, (const DevRes *)c->dres, a.add, a.d_table,
+    HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sA));
+    hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sA, cb);
+    hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sA, cb, nblk, a.eof, a.offset, a.add, c->dres);
+    hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sA, cb, (const DevRes *)c->dres, a.add, a.d_table,
                        a.table_cap, qoff, c->qdir, c->qdir_cap);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sB, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff);
-    if (decode) enqueue_decode(c, a, sB, timed);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sA, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff,
+                       make_pub(c));
+    c->ctl_clean = true;
+    if (decode) enqueue_decode(c, a, sA, timed);
     return FFQ_OK;
 }
 
-// front: line index on stream A, then either the four-line fast path or the general path on
-// stream B, then the result block on its way to pinned memory.  No host synchronisation.
+// front of a scan: everything on ONE in-order stream (the context's), no host synchronisation
+// and no copy or fill between the kernels:
+//     k_scan_lines -> (k_sbscan -> k_rows4 -> k_finalize4)  or  (general kernels) [-> decode]
+// The ragged last tile of the buffer is a one-workgroup launch on the side stream, beside the
+// main index kernel.  The last result-writing kernel publishes the result block into host-mapped
+// memory and zeroes the control block for the next scan; ev[3] follows the last kernel.  A
+// second context on the same stream queues its front right behind: the GPU never idles.
 static int enqueue_front(ffq_ctx *c, ScanState &st)
 {
     const ScanArgs &a = st.a;
@@ -454,7 +467,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     const char *abl = getenv("FFQ_ABLATE");
     const int ablate = abl ? atoi(abl) : 0;
     const int k1abl = getenv("FFQ_K1_ABLATE") ? atoi(getenv("FFQ_K1_ABLATE")) : 0;
-    hipStream_t sA = c->stream, sB = c->stream2;
+    hipStream_t sA = c->stream;
     const int64_t ntiles = st.ntiles;
     const int nsb = (int)((ntiles + SB_TILES - 1) / SB_TILES);
     // the four-line fast path (ffq_rows4.h) is tried first unless it already failed on this buffer
@@ -464,79 +477,62 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
                            getenv("FFQ_NO_FAST4") == nullptr;
     const LineIndex L = make_index(c, a, ntiles);
     c->decode_timed = false;
-    *c->h_L = L;
-    HIPCHK(hipMemcpyAsync(c->d_L, c->h_L, sizeof(LineIndex), hipMemcpyHostToDevice, sA));
+    if (!c->ctl_clean) HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));    // first scan, or an abandoned front
+    c->ctl_clean = false;
 
-    // ---- line index: one launch over the full tiles on stream A; the ragged last tile
-    //      (byte-wise loads, one workgroup) beside it on stream B ---------------------------
-    HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
+    // ---- line index --------------------------------------------------------------------
     HIPCHK(hipEventRecord(c->ev[0], sA));
-    HIPCHK(hipStreamWaitEvent(sB, c->ev[0], 0));        // stream B starts behind the resets
-    {
-        const int64_t nfull = a.n_bytes >> TILE_SHIFT;
-        if (ntiles > nfull)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 4>), dim3((unsigned)(ntiles - nfull)), dim3(256), 0,
-                               sB, a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
-                               (int)nfull, 0);
-        if (nfull > 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 6>), dim3((unsigned)nfull), dim3(256), 0, sA,
-                               a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl);
-    }
+    // one launch over all tiles; a buffer that ends inside a tile takes the variant whose loads
+    // are bounds-checked (same occupancy, the checks hide behind the memory traffic)
+    const int64_t nfull = a.n_bytes >> TILE_SHIFT;
+    if (ntiles > nfull)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 6>), dim3((unsigned)ntiles), dim3(256), 0, sA,
+                           a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
+                           L, c->d_L);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 6>), dim3((unsigned)nfull), dim3(256), 0, sA,
+                           a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
+                           L, c->d_L);
     HIPCHK(hipEventRecord(c->ev[1], sA));
-    HIPCHK(hipStreamWaitEvent(sB, c->ev[1], 0));
+
     if (try_fast4) {
         // ---- plain four-line records: rows straight from newline ordinals, then validated -----
-        hipLaunchKernelGGL(k_sum64, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, sB, (const uint32_t *)c->cnt, 1,
-                           (int64_t)ntiles, c->sbsum, nsb);
-        hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sB, L, (const unsigned int *)c->sbsum, nsb, c->sbbase,
-                           a.offset, c->hdr4);
-        if (decode) {
-            HIPCHK(hipMemsetAsync(c->tileq, 0, (size_t)ntiles * sizeof(TileQ), sB));
-        }
-        hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sB, L,
+        hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4);
+        if (decode) HIPCHK(hipMemsetAsync(c->tileq, 0, (size_t)ntiles * sizeof(TileQ), sA));
+        hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            decode ? a.d_qoff : (int64_t *)nullptr, c->tileq);
-        // the next scan's index kernel (stream A, possibly another context) may start once the
-        // bandwidth-heavy kernels of this one are through: only the one-thread epilogues and
-        // the result copy overlap with it, so per-kernel timings stay clean
-        if (!decode) {
-            HIPCHK(hipEventRecord(c->ev[5], sB));
-            HIPCHK(hipStreamWaitEvent(sA, c->ev[5], 0));
-        }
-        hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sB, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
-                           a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres);
+        hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
+                           a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres,
+                           decode ? no_pub(c) : make_pub(c));
         if (decode) {
-            // quality offsets: superblock scan, per-tile fix-up (+ stream directory), total; then
-            // the decode itself.  All of it is skipped on the device if the fast path is rejected.
-            hipLaunchKernelGGL(k_sum64, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, sB,
+            // quality offsets: superblock sums + scan, per-tile fix-up (+ stream directory), total
+            // (publishes); then the decode itself.  All of it is skipped on the device if the
+            // fast path is rejected.
+            hipLaunchKernelGGL(k_sum64, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, sA,
                                reinterpret_cast<const uint32_t *>(c->tileq) + 3, 4, (int64_t)ntiles, c->sbq, nsb);
-            hipLaunchKernelGGL(k_qscan4, dim3(1), dim3(1024), 0, sB, (const unsigned int *)c->sbq, nsb, c->sbqbase);
-            hipLaunchKernelGGL(k_qfix4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sB, (int)ntiles,
+            hipLaunchKernelGGL(k_qscan4, dim3(1), dim3(1024), 0, sA, (const unsigned int *)c->sbq, nsb, c->sbqbase);
+            hipLaunchKernelGGL(k_qfix4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, (int)ntiles,
                                (const Fast4Hdr *)c->hdr4, (const TileQ *)c->tileq, (const long long *)c->sbqbase,
                                a.d_qoff, a.table_cap, c->qdir, c->qdir_cap);
-            hipLaunchKernelGGL(k_qtotal4, dim3(1), dim3(1), 0, sB, c->dres, (const int64_t *)a.d_table, a.table_cap,
-                               a.d_qoff);
-            enqueue_decode(c, a, sB, true);
-            HIPCHK(hipEventRecord(c->ev[5], sB));
-            HIPCHK(hipStreamWaitEvent(sA, c->ev[5], 0));
+            hipLaunchKernelGGL(k_qtotal4, dim3(1), dim3(1), 0, sA, c->dres, (const int64_t *)a.d_table, a.table_cap,
+                               a.d_qoff, make_pub(c));
+            enqueue_decode(c, a, sA, true);
         }
+        c->ctl_clean = true;
         st.stage = 1;
     } else {
         if (!serial) {
             int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups, true);
             if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, sA, c->dres, make_pub(c));
+            c->ctl_clean = true;
         }
-        HIPCHK(hipEventRecord(c->ev[5], sB));
-        HIPCHK(hipStreamWaitEvent(sA, c->ev[5], 0));
         st.stage = 2;
     }
-    HIPCHK(hipEventRecord(c->ev[2], sB));
-    HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
-    HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));
-    // ev[3]: this scan's result block has landed in pinned memory.  Stream A is NOT made to
-    // wait for it: the next scan on these streams belongs to another context (own scratch), or
-    // comes after the host has waited for this one.
-    HIPCHK(hipEventRecord(c->ev[3], sB));
+    // ev[3]: the last kernel of this front is through (its result block is in host memory)
+    HIPCHK(hipEventRecord(c->ev[3], sA));
     HIPCHK(hipGetLastError());
     return FFQ_OK;
 }
@@ -547,7 +543,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
     const bool serial = (a.flags & FFQ_F_FORCE_SERIAL) != 0;
     const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
     int64_t *qoff = decode ? a.d_qoff : nullptr;
-    hipStream_t sA = c->stream, sB = c->stream2;
+    hipStream_t sA = c->stream;
     bool front_done = true;           // the first front was enqueued by the caller (submit)
     for (;;) {
         if (!front_done) {
@@ -555,8 +551,8 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             if (rc) return rc;
         }
         front_done = false;
-        // wait for THIS scan's result block only (ev[3] follows its copy on stream B): the
-        // streams may already hold the next scan of a context that shares them
+        // wait for THIS scan's front only: the stream may already hold the next scan of a
+        // context that shares it
         HIPCHK(hipEventSynchronize(c->ev[3]));
         const LineIndex L = make_index(c, a, st.ntiles);
 
@@ -571,14 +567,14 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); res->ms_chain += ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[3])); res->ms_chain += ms;
         res->ms_decode = 0;
         if (c->decode_timed) {
             // the decode kernel is the tail of the front: split it off the chain time
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[2]));
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[3]));
             res->ms_decode = ms; res->ms_chain -= ms;
         }
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[2])); res->ms_total += ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total += ms;
 
         if (st.stage == 1) {
             if (!c->h_res->fallback) {
@@ -589,14 +585,13 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             // scans of this context skip the attempt (and the host round trip it costs here).
             st.fast4_failed = true;
             c->fast4_skip = 15;
+            HIPCHK(hipEventRecord(c->ev[4], sA));
             int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups);
             if (rc) return rc;
-            HIPCHK(hipEventRecord(c->ev[4], sB));
-            HIPCHK(hipMemcpyAsync(c->h_ctl, c->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, sB));
-            HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sB));
+            HIPCHK(hipEventRecord(c->ev[2], sA));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(sB));
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[4]));
+            HIPCHK(hipEventSynchronize(c->ev[2]));
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[2]));
             res->ms_chain += ms; res->ms_total += ms;
             if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
         }
@@ -641,13 +636,13 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             HIPCHK(hipEventRecord(c->ev[4], sA));
             hipLaunchKernelGGL(k_chain_serial, dim3(1), dim3(64), 0, sA, L, a.offset, a.eof, a.add, a.d_table,
                                a.table_cap, qoff, c->qdir, c->qdir_cap, c->dres);
-            hipLaunchKernelGGL(k_finalize_serial, dim3(1), dim3(64), 0, sA, c->dres, a.table_cap, qoff);
+            hipLaunchKernelGGL(k_finalize_serial, dim3(1), dim3(64), 0, sA, c->dres, a.table_cap, qoff, make_pub(c));
+            c->ctl_clean = true;
             if (decode) enqueue_decode(c, a, sA);
-            HIPCHK(hipEventRecord(c->ev[5], sA));
-            HIPCHK(hipMemcpyAsync(c->h_res, c->dres, sizeof(DevRes), hipMemcpyDeviceToHost, sA));
+            HIPCHK(hipEventRecord(c->ev[2], sA));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(sA));
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+            HIPCHK(hipEventSynchronize(c->ev[2]));
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[2]));
             res->ms_chain += ms;
             res->ms_total += ms;
         }

@@ -27,7 +27,7 @@ namespace ffq {
 // copies to the tile's slot with 16-byte stores.
 // Algorithmic HBM traffic: TILE bytes read + 2 bytes per newline written.
 // =========================================================================
-__device__ __forceinline__ uint4 load_tail16(const uint8_t *d, int64_t n, int64_t at)
+__device__ __noinline__ uint4 load_tail16(const uint8_t *d, int64_t n, int64_t at)
 {
     uint32_t w[4] = {0, 0, 0, 0};
     for (int b = 0; b < 16; b++) {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
                                                     unsigned long long *__restrict__ ovf,
                                                     uint16_t *__restrict__ pool,
                                                     unsigned long long pool_cap, Ctl *ctl, int tile0,
-                                                    int ablate)
+                                                    int ablate, LineIndex Lval, LineIndex *__restrict__ d_L)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_list[SLOT];
     __shared__ uint32_t s_wtot[4];
@@ -58,7 +58,6 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
     const int tile = tile0 + blockIdx.x;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int64_t base = (int64_t)tile << TILE_SHIFT;
-
     uint4 v[4];
     uint32_t o[4];
 #pragma unroll
@@ -150,6 +149,9 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
         const uint4 *src = reinterpret_cast<const uint4 *>(s_list);
         for (uint32_t q = tid; q < nvec; q += 256) dst[q] = src[q];
     }
+    // the device copy of the index descriptor (out-of-line device functions take it by pointer);
+    // here, where nothing else is live
+    if (tile == 0 && tid == 0 && d_L) *d_L = Lval;
 }
 
 }  // namespace ffq
@@ -216,20 +218,29 @@ __global__ void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add
 // k_finalize: the iterator's `offset` at exit = pos5 - 1 of the last COMPLETE
 // record (fastqandfurious.py:254), read back from the table; qoff[n].
 __global__ void k_finalize(DevRes *res, const int64_t *__restrict__ table, int64_t table_cap,
-                           int64_t add, int64_t offset, int64_t *__restrict__ qoff)
+                           int64_t add, int64_t offset, int64_t *__restrict__ qoff, Pub pb)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (res->fallback) return;
+    if (res->fallback) { publish(pb, res); return; }
     const int64_t ncomplete = res->n_records - (res->has_final ? 1 : 0);
     if (ncomplete > 0 && ncomplete <= table_cap) res->end_offset = table[(ncomplete - 1) * 6 + 5] - add - 1;
     else res->end_offset = offset;
     if (qoff && res->n_records <= table_cap) qoff[res->n_records] = res->n_qual_bytes;
+    publish(pb, res);
 }
 
-__global__ void k_finalize_serial(DevRes *res, int64_t table_cap, int64_t *__restrict__ qoff)
+__global__ void k_finalize_serial(DevRes *res, int64_t table_cap, int64_t *__restrict__ qoff, Pub pb)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (qoff && res->n_records <= table_cap) qoff[res->n_records] = res->n_qual_bytes;
+    publish(pb, res);
+}
+
+// publisher of a front that ends without a result kernel (forced serial walker)
+__global__ void k_publish(DevRes *res, Pub pb)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    publish(pb, res);
 }
 
 // =========================================================================

@@ -75,27 +75,64 @@ __global__ __launch_bounds__(256) void k_sum64(const uint32_t *__restrict__ src,
     if (lane == 0) dst[b] = t;
 }
 
-__global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, const unsigned int *__restrict__ sbsum, int nsb,
-                                                 long long *__restrict__ sbbase, int64_t offset,
+__global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long *__restrict__ sbbase, int64_t offset,
                                                  Fast4Hdr *hdr)
 {
-    __shared__ long long s_v[1024];
-    const int tid = threadIdx.x;
+    __shared__ long long s_w[16];
+    __shared__ uint32_t s_sum[16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // warm this CU's cache with what the serial candidate search below will read one dependent
+    // load at a time: the first bytes, and the first entries of the tile that holds `offset`
+    if (wid == 15) {
+        const int tq = (int)min((int64_t)max(L.ntiles - 1, 0), max((int64_t)0, (offset - L.s) >> TILE_SHIFT));
+        uint32_t sink = (L.n > 0) ? (uint32_t)L.d[0] : 0u;
+        if (L.ntiles > 0) sink += L.cnt[tq] + L.ent[(int64_t)tq * SLOT + lane * 4];
+        if (tq + 1 < L.ntiles) sink += L.cnt[tq + 1] + L.ent[(int64_t)(tq + 1) * SLOT + (lane & 15) * 4];
+        asm volatile("" ::"v"(sink));
+    }
     long long carry = 0;
     for (int b0 = 0; b0 < nsb; b0 += 1024) {
         const int b = b0 + tid;
-        const long long v = (b < nsb) ? (long long)sbsum[b] : 0;
-        s_v[tid] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            long long x = 0;
-            if (tid >= d) x = s_v[tid - d];
-            __syncthreads();
-            s_v[tid] += x;
-            __syncthreads();
+        // newlines per superblock.  A wave owns 64 superblocks = 16 KiB of tile counts and reads
+        // them as 16 fully coalesced 1 KiB loads (4 superblocks each, 16 lanes per superblock);
+        // a thread-per-superblock read of the same bytes is bound by one CU's cache-line rate.
+        uint32_t part[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int64_t t = ((int64_t)(b0 + wid * 64 + 4 * j) << 6) + lane * 4;     // first tile of this lane's piece
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (t + 4 <= L.ntiles) x = *reinterpret_cast<const uint4 *>(L.cnt + t);
+            else {
+                if (t < L.ntiles) x.x = L.cnt[t];
+                if (t + 1 < L.ntiles) x.y = L.cnt[t + 1];
+                if (t + 2 < L.ntiles) x.z = L.cnt[t + 2];
+            }
+            part[j] = x.x + x.y + x.z + x.w;
         }
-        if (b < nsb) sbbase[b] = carry + s_v[tid] - v;
-        const long long tot = s_v[1023];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            // sum over each row of 16 lanes: the row's last lane ends up with the superblock's sum
+            uint32_t r = part[j];
+            r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x111, 0xf, 0xf, false);  // row_shr:1
+            r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x112, 0xf, 0xf, false);  // row_shr:2
+            r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xf, false);  // row_shr:4
+            r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xf, false);  // row_shr:8
+            if ((lane & 15) == 15) s_sum[wid][4 * j + (lane >> 4)] = r;
+        }
+        __syncthreads();
+        const uint32_t v = (b < nsb) ? s_sum[wid][lane] : 0u;      // <= 64 tiles * 16384 newlines
+        // wave scan (sums of 64 superblocks fit 32 bits), then the 16 wave totals through LDS
+        const uint32_t incl = wave_incl_scan(v);
+        if (lane == 63) s_w[wid] = (long long)incl;
+        __syncthreads();
+        long long wpre = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const long long t = s_w[q];
+            if (q < wid) wpre += t;
+            tot += t;
+        }
+        if (b < nsb) sbbase[b] = carry + wpre + (long long)(incl - v);
         __syncthreads();
         carry += tot;
     }
@@ -434,21 +471,22 @@ __global__ __launch_bounds__(256) void k_qfix4(int ntiles, const Fast4Hdr *__res
 
 // total of the decoded stream and its closing offset (after k_finalize4 and k_qfix4)
 __global__ void k_qtotal4(DevRes *res, const int64_t *__restrict__ table, int64_t table_cap,
-                          int64_t *__restrict__ qoff)
+                          int64_t *__restrict__ qoff, Pub pb)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (res->fallback) return;
+    if (res->fallback) { publish(pb, res); return; }
     const int64_t n = res->n_records;
     int64_t tot = 0;
     if (n > 0 && n <= table_cap) tot = qoff[n - 1] + (table[(n - 1) * 6 + 5] - table[(n - 1) * 6 + 4]);
     res->n_qual_bytes = tot;
     if (n <= table_cap) qoff[n] = tot;
+    publish(pb, res);
 }
 
 // validity + result block (end state per fastqandfurious.py:256-279)
 __global__ void k_finalize4(LineIndex L, Fast4Hdr *hdr, const TermInfo4 *__restrict__ tinfo, int eof,
                             int64_t offset, int64_t add, const int64_t *__restrict__ table, int64_t table_cap,
-                            DevRes *res)
+                            DevRes *res, Pub pb)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     res->n_lines = hdr->n_lines;
@@ -457,7 +495,7 @@ __global__ void k_finalize4(LineIndex L, Fast4Hdr *hdr, const TermInfo4 *__restr
     res->has_final = 0;
     const unsigned long long tm = hdr->term_min, im = hdr->irr_min;
     const unsigned long long tk = tm >> 24;
-    if (!hdr->attempt || tm == ~0ull || (im != ~0ull && im <= tk)) { res->fallback = 1; return; }
+    if (!hdr->attempt || tm == ~0ull || (im != ~0ull && im <= tk)) { res->fallback = 1; publish(pb, res); return; }
     res->fallback = 0;
     const int tt = (int)(tm & 0xFFFFFF);
     const TermInfo4 ti = tinfo[tt];
@@ -475,6 +513,7 @@ __global__ void k_finalize4(LineIndex L, Fast4Hdr *hdr, const TermInfo4 *__restr
     res->end_state = end;
     if (ncomplete > 0 && ncomplete <= table_cap) res->end_offset = table[(ncomplete - 1) * 6 + 5] - add - 1;
     else res->end_offset = offset;
+    publish(pb, res);
 }
 
 }  // namespace ffq
