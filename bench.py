@@ -145,7 +145,7 @@ def pmc_traffic(workload):
         except Exception:
             continue
         for k, v in d.items():
-            if "k_scan_lines<true" in k and "FETCH_SIZE_KiB_avg_per_launch" in v:
+            if "k_scan_lines<" in k and v.get("FETCH_SIZE_KiB_avg_per_launch", 0) > 1024 and "FETCH_SIZE_KiB_avg_per_launch" in v:
                 best = (int(2 * v["FETCH_SIZE_KiB_avg_per_launch"] * 1024 +
                             v.get("WRITE_SIZE_KiB_avg_per_launch", 0) * 1024), os.path.relpath(f, ROOT))
     return best
