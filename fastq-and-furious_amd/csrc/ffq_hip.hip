@@ -58,8 +58,6 @@ struct ffq_ctx {
     bool owns_streams = true;            // false: streams borrowed from another context
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;       // chain kernels, overlapped with the scan kernel chunk by chunk
-    std::vector<hipEvent_t> chunk_ev;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int fast4_skip = 0;                  // scans left that go straight to the general kernels (see scan_finish)
     bool decode_timed = false;           // ev[6] marks the start of the decode kernel of the pending front
@@ -141,10 +139,9 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
     hipError_t e = hipSuccess;
     if (share) {
         // same streams as `share`: scans of the two contexts execute in submission order
-        c->stream = share->stream; c->stream2 = share->stream2; c->owns_streams = false;
+        c->stream = share->stream; c->owns_streams = false;
     } else {
         e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     }
     for (int i = 0; i < 7 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&c->ctl, sizeof(Ctl));
@@ -188,9 +185,6 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-    for (hipEvent_t ev : c->chunk_ev) (void)hipEventDestroy(ev);
-    if (c->stream2 && c->owns_streams) (void)hipStreamDestroy(c->stream2);
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
     free_chain(c);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
@@ -276,7 +270,6 @@ static int reserve_qdir(ffq_ctx *c, int64_t blocks)
 {
     if (blocks <= c->qdir_cap) return FFQ_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream2));
     (void)hipFree(c->qdir);
     c->qdir = nullptr; c->qdir_cap = 0;
     hipError_t e = hipMalloc((void **)&c->qdir, (size_t)blocks * sizeof(int64_t));
