@@ -554,6 +554,36 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                             info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
                                       ((uint32_t)j << 25) | (1u << 29);
                             done = true;
+                        } else if (wpos0 + (int64_t)qe + 2 < len) {
+                            // the record is COMPLETE but its successor lies beyond the batch (a
+                            // candidate inside a wrapped quality block "reads" several records as
+                            // one): binary search of the window for the first entry at >= qe - 1,
+                            // then the first "\n@" among the next 8.  sj = 15: not encoded.
+                            int lo = k + 13, hi = nwin;
+                            while (lo < hi) {
+                                const int md = (lo + hi) >> 1;
+                                if ((went[md] & WP_MASK) + 1 >= qe) hi = md; else lo = md + 1;
+                            }
+                            if (lo + 8 <= nwin) {
+                                uint32_t x[8];
+#pragma unroll
+                                for (int i = 0; i < 8; i++) x[i] = went[lo + i];
+                                uint32_t am = 0;
+#pragma unroll
+                                for (int i = 0; i < 8; i++)
+                                    if ((x[i] >> WF_SHIFT) & FL_AT) am |= 1u << i;
+                                if (am) {
+                                    const int i0 = __ffs((int)am) - 1;
+                                    uint32_t wj = 0;
+#pragma unroll
+                                    for (int i = 0; i < 8; i++) if (i == i0) wj = x[i];
+                                    const uint32_t nid = (wj >> WN_SHIFT) & WN_MASK;
+                                    const uint32_t nx = (lo + i0 < own_hi && nid != NO_NODE) ? nid : SN_AHEAD;
+                                    info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
+                                              (15u << 25) | (1u << 29);
+                                    done = true;
+                                }
+                            }
                         }
                     }
                 }
@@ -562,6 +592,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         if (!done) pend |= 1u << u;
     }
     // nodes the fast path could not finish (long wrapped records, window / buffer edges)
+    if (prof) { const uint32_t np = wave_sum_u32((uint32_t)__popc(pend)); if (lane == 0) atomicAdd(&B.prof[7], (unsigned long long)np | ((unsigned long long)wave_max_u32((uint32_t)__popc(pend)) << 32)); }
     while (__ballot(pend != 0u)) {
         if (pend) {
             const int u = __ffs((int)pend) - 1;
@@ -727,7 +758,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                 if (st == ST_COMPLETE) {
                     int64_t after;
                     if (nx == SN_NOCAND) after = Y_NOCAND;
-                    else if (nx == SN_AHEAD && (li >> 29 & 1u))
+                    else if (nx == SN_AHEAD && (li >> 29 & 1u) && ((li >> 25) & 15u) != 15u)
                         after = wpos0 + (int64_t)(went[nidx[lastn] + ((li >> 25) & 15u)] & WP_MASK);
                     else {   // beyond the window (or a generic node): through the global index
                         after = node_followup(Lg, went, nwin, wt1, eof, ready, wpos0, len, defer, nidx[lastn]).after;

@@ -143,7 +143,11 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
     } else {
         e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     }
-    for (int i = 0; i < 7 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    // timing marks need no system-scope release (an L2 write-back per record); only ev[3] / ev[2],
+    // which the host waits on before it reads the published result block, keep the default
+    for (int i = 0; i < 7 && e == hipSuccess; i++)
+        e = (i == 2 || i == 3) ? hipEventCreate(&c->ev[i])
+                               : hipEventCreateWithFlags(&c->ev[i], hipEventDisableSystemFence);
     if (e == hipSuccess) e = hipMalloc((void **)&c->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipMalloc((void **)&c->dres, sizeof(DevRes));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_L, sizeof(LineIndex));
@@ -595,6 +599,9 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 fprintf(stderr, "[ffq prof] k_chain_wave per-wave cycles: load %.0f lds %.0f nodes %.0f scan %.0f member %.0f summary %.0f (waves %llu)\n",
                         (double)hp[0] / hp[6], (double)hp[1] / hp[6], (double)hp[2] / hp[6], (double)hp[3] / hp[6],
                         (double)hp[4] / hp[6], (double)hp[5] / hp[6], hp[6]);
+            if (hp[6])
+                fprintf(stderr, "[ffq prof] generic-path nodes per wave %.2f, serial generic rounds per wave %.2f\n",
+                        (double)(hp[7] & 0xFFFFFFFFull) / hp[6], (double)(hp[7] >> 32) / hp[6]);
         }
         if (!serial && getenv("FFQ_DEBUG")) {
             const int ng = std::min(st.ngroups, 24);
