@@ -483,11 +483,11 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     // are bounds-checked (same occupancy, the checks hide behind the memory traffic)
     const int64_t nfull = a.n_bytes >> TILE_SHIFT;
     if (ntiles > nfull)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 6>), dim3((unsigned)ntiles), dim3(256), 0, sA,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 8>), dim3((unsigned)ntiles), dim3(256), 0, sA,
                            a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
                            L, c->d_L);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 6>), dim3((unsigned)nfull), dim3(256), 0, sA,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)nfull), dim3(256), 0, sA,
                            a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
                            L, c->d_L);
     HIPCHK(hipEventRecord(c->ev[1], sA));

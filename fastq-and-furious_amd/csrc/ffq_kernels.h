@@ -22,9 +22,13 @@ namespace ffq {
 // k_scan_lines: one 256-thread workgroup per 16 KiB tile.  Wave w owns the
 // contiguous 4 KiB [w*4096, (w+1)*4096) of the tile and reads it as four
 // coalesced 1 KiB rows (16 B per lane).  Per row: SWAR newline mask,
-// wave-prefix-sum (DPP) of the per-lane counts, entries (offset | flags)
-// written in position order into an LDS list, which the workgroup then
-// copies to the tile's slot with 16-byte stores.
+// wave-prefix-sum (fused DPP adds) of the per-lane counts, newline OFFSETS
+// written in position order into an LDS list.  The bytes themselves are
+// parked in LDS too, so that the AT / PLUS flags ("the byte after the
+// newline is '@' / '+'") are looked up once per entry by the threads that
+// copy the list to the tile's slot (16-byte stores), instead of inside the
+// per-lane compaction loop: 279 instead of 462 VALU instructions per wave and
+// half the registers (8 resident workgroups per CU).
 // Algorithmic HBM traffic: TILE bytes read + 2 bytes per newline written.
 // =========================================================================
 __device__ __noinline__ uint4 load_tail16(const uint8_t *d, int64_t n, int64_t at)
@@ -37,11 +41,18 @@ __device__ __noinline__ uint4 load_tail16(const uint8_t *d, int64_t n, int64_t a
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// flags of one entry: the byte after the newline at tile offset `off` (s_data holds the tile,
+// nxt the first byte of the next tile, 0 past the end of the buffer)
+__device__ __forceinline__ uint32_t entry_flags(const uint8_t *s_data, uint32_t off, uint32_t nxt)
+{
+    const uint32_t nb = (off + 1u < (uint32_t)TILE) ? (uint32_t)s_data[off + 1u] : nxt;
+    return (nb == '@') ? (uint32_t)FL_AT : (nb == '+') ? (uint32_t)FL_PLUS : 0u;
+}
+
 // FULL: every tile of the launch lies completely inside the buffer (no bounds checks in
-// the loads; the ragged last tile of a buffer is a separate one-workgroup launch).
-// One tile per workgroup and as many resident waves as the registers allow: measured on
-// MI355X, register double-buffering / several tiles per workgroup lower the occupancy
-// and lose 15-25 % of the bandwidth.
+// the loads).  One tile per workgroup and as many resident waves as possible: measured on
+// MI355X (twice, before and after the register diet), several tiles per workgroup with the
+// next tile's loads issued ahead lose 15-25 % of the bandwidth.
 template <bool FULL, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restrict__ d, int64_t n,
                                                     uint16_t *__restrict__ ent,
@@ -51,6 +62,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
                                                     unsigned long long pool_cap, Ctl *ctl, int tile0,
                                                     int ablate, LineIndex Lval, LineIndex *__restrict__ d_L)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[TILE];
     __shared__ __attribute__((aligned(16))) uint16_t s_list[SLOT];
     __shared__ uint32_t s_wtot[4];
     __shared__ unsigned long long s_ovf;
@@ -58,6 +70,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
     const int tile = tile0 + blockIdx.x;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int64_t base = (int64_t)tile << TILE_SHIFT;
+
     uint4 v[4];
     uint32_t o[4];
 #pragma unroll
@@ -66,25 +79,17 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
         if (FULL || base + o[i] + 16 <= n) v[i] = *reinterpret_cast<const uint4 *>(d + base + o[i]);
         else v[i] = load_tail16(d, n, base + o[i]);
     }
-    // the byte that follows this wave's 4 KiB span (wave-uniform address)
-    const int64_t nxa = base + (int64_t)(w + 1) * 4096;
-    const uint32_t nxw = (nxa < n) ? (uint32_t)d[nxa] : 0u;
+    // first byte of the next tile (workgroup-uniform): the flags of a newline at offset TILE-1
+    const uint32_t nxt = (base + TILE < n) ? (uint32_t)d[base + TILE] : 0u;
 
-    uint32_t m[4], c[4], nf[4];
+    uint32_t m[4], c[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        m[i] = (ablate == 2) ? (v[i].x & 1u) : nl_mask16(v[i]);
+        *reinterpret_cast<uint4 *>(s_data + o[i]) = v[i];
+        m[i] = nl_mask16(v[i]);
         c[i] = __popc(m[i]);
     }
     if (ablate == 3) { if ((c[0] + c[1] + c[2] + c[3]) == 77u) cnt[tile] = 1; return; }
-    // first byte of the NEXT 16-byte piece in position order
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t fb = v[i].x & 0xFFu;
-        const uint32_t dn = (uint32_t)__shfl_down((int)fb, 1);
-        const uint32_t wrap = (i < 3) ? (uint32_t)__shfl((int)(v[(i + 1) & 3].x & 0xFFu), 0) : nxw;
-        nf[i] = (l == 63) ? wrap : dn;
-    }
     // wave prefix sums of the four row counts, two 16-bit fields per register
     const uint32_t s01 = wave_incl_scan(c[0] | (c[1] << 16));
     const uint32_t s23 = wave_incl_scan(c[2] | (c[3] << 16));
@@ -95,7 +100,6 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
     ex[2] = (s23 & 0xFFFFu) - c[2];  rowtot[2] = t23 & 0xFFFFu;
     ex[3] = (s23 >> 16) - c[3];      rowtot[3] = t23 >> 16;
     const uint32_t wtot = rowtot[0] + rowtot[1] + rowtot[2] + rowtot[3];
-    if (ablate == 4) { if (wtot + nf[0] + nf[1] + nf[2] + nf[3] + ex[1] + ex[2] + ex[3] == 0x7777u) cnt[tile] = 1; return; }
     if (l == 0) s_wtot[w] = wtot;
     __syncthreads();
     uint32_t wbase = 0, total = 0;
@@ -118,19 +122,18 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
     const unsigned long long pbase = dense ? s_ovf : 0ull;
     const bool pool_ok = dense && (pbase + total <= pool_cap);
 
+    // newline offsets in position order (no flags yet); this wave's entries are ranks
+    // [wbase, wbase + wtot) of the tile
     uint32_t rb = wbase;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        uint32_t mm = (ablate == 1) ? 0u : m[i];
+        uint32_t mm = m[i];
         uint32_t idx = rb + ex[i];
         while (mm) {
             const uint32_t p = (uint32_t)__ffs((int)mm) - 1u;
             mm &= mm - 1u;
-            const uint32_t nb = (p < 15u) ? get_byte(v[i], p + 1u) : nf[i];
-            const uint32_t fl = (nb == '@') ? (uint32_t)FL_AT : (nb == '+') ? (uint32_t)FL_PLUS : 0u;
-            const uint16_t e = (uint16_t)((o[i] + p) | (fl << 14));
-            if (!dense) s_list[idx] = e;
-            else if (pool_ok) pool[pbase + idx] = e;
+            if (!dense) s_list[idx] = (uint16_t)(o[i] + p);
+            else if (pool_ok) pool[pbase + idx] = (uint16_t)(o[i] + p);
             idx++;
         }
         rb += rowtot[i];
@@ -142,12 +145,15 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
         if (dense) ovf[tile] = pbase;                       // read only for tiles with cnt > SLOT
     }
     if (ablate == 6 || ablate == 7) return;
-    if (!dense) {
-        __syncthreads();
-        const uint32_t nvec = (total * 2u + 15u) >> 4;      // 16-byte pieces
-        uint4 *dst = reinterpret_cast<uint4 *>(ent + (int64_t)tile * SLOT);
-        const uint4 *src = reinterpret_cast<const uint4 *>(s_list);
-        for (uint32_t q = tid; q < nvec; q += 256) dst[q] = src[q];
+    // Each wave stores its own entries, flags looked up on the way, and is done: no second
+    // workgroup barrier, no wave waits for another one's store (a workgroup-wide copy of the
+    // finished list cost 20 us per GiB in barrier + tail latency).
+    uint16_t *gdst = dense ? pool + pbase : ent + (int64_t)tile * SLOT;
+    if (!dense || pool_ok) {
+        for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
+            const uint32_t off = dense ? (uint32_t)gdst[wbase + j] : (uint32_t)s_list[wbase + j];
+            gdst[wbase + j] = (uint16_t)(off | (entry_flags(s_data, off & OFF_MASK, nxt) << 14));
+        }
     }
     // the device copy of the index descriptor (out-of-line device functions take it by pointer);
     // here, where nothing else is live
