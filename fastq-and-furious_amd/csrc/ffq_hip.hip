@@ -90,6 +90,8 @@ struct ffq_ctx {
     Ctl *hm_ctl = nullptr;              // device addresses of the two
     DevRes *hm_res = nullptr;
     bool ctl_clean = false;             // the control block is zero (creation, or a publisher ran last)
+    int64_t *d_word = nullptr;          // 2 scratch words for the small table queries
+    int64_t *h_word = nullptr;          //   and their pinned mirror
     // staging for the host-buffer entry points
     uint8_t *stage_d = nullptr;
     int64_t stage_d_cap = 0;
@@ -101,6 +103,10 @@ struct ffq_ctx {
     int64_t qual_d_cap = 0;
     int64_t *qoff_d = nullptr;
     int64_t qoff_d_cap = 0;
+    unsigned int *sel_cnt = nullptr;   // row selection: kept rows per workgroup, their scan
+    int64_t sel_cnt_cap = 0;
+    long long *sel_base = nullptr;
+    int64_t sel_base_cap = 0;
     int64_t *tab_h = nullptr;      // pinned bounce for rows
     int64_t tab_h_cap = 0;
 };
@@ -151,6 +157,8 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&c->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipMalloc((void **)&c->dres, sizeof(DevRes));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_L, sizeof(LineIndex));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_word, 16);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_word, 16, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_L, sizeof(LineIndex), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_res, sizeof(DevRes), hipHostMallocMapped);
@@ -194,7 +202,10 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
     (void)hipFree(c->qdir);
+    (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
+    if (c->h_word) (void)hipHostFree(c->h_word);
+    (void)hipFree(c->d_word);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->stage_h) (void)hipHostFree(c->stage_h);
@@ -275,6 +286,7 @@ static int reserve_qdir(ffq_ctx *c, int64_t blocks)
     if (blocks <= c->qdir_cap) return FFQ_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(c->qdir);
+    (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base);
     c->qdir = nullptr; c->qdir_cap = 0;
     hipError_t e = hipMalloc((void **)&c->qdir, (size_t)blocks * sizeof(int64_t));
     if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(qdir) failed: %s", hipGetErrorString(e));
@@ -825,13 +837,41 @@ extern "C" int ffq_table_lower_bound(ffq_ctx *c, const int64_t *d_table, int64_t
     if (!c || !idx || n_rows < 0 || col < 0 || col > 5 || (n_rows > 0 && !d_table))
         return fail(FFQ_E_ARG, "ffq_table_lower_bound: bad argument");
     HIPCHK(hipSetDevice(c->device));
-    int64_t *slot = reinterpret_cast<int64_t *>(&c->h_ctl->pool_head);   // pinned scratch word
-    int64_t *dslot = reinterpret_cast<int64_t *>(&c->ctl->pool_head);
+    int64_t *slot = c->h_word, *dslot = c->d_word;
     hipLaunchKernelGGL(k_table_lower_bound, dim3(1), dim3(64), 0, c->stream, d_table, n_rows, col, value, dslot);
     HIPCHK(hipMemcpyAsync(slot, dslot, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     *idx = *slot;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_table_select_seqlen(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t min_len,
+                                       int64_t max_len, int64_t *d_out, int64_t *n_out)
+{
+    if (!c || !n_out || n_rows < 0 || (n_rows > 0 && (!d_table || !d_out)))
+        return fail(FFQ_E_ARG, "ffq_table_select_seqlen: bad argument");
+    if (d_table == d_out && n_rows > 0) return fail(FFQ_E_ARG, "ffq_table_select_seqlen: d_out must not be d_table");
+    if (((reinterpret_cast<uintptr_t>(d_table) | reinterpret_cast<uintptr_t>(d_out)) & 15) != 0)
+        return fail(FFQ_E_ARG, "ffq_table_select_seqlen: tables must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->device));
+    *n_out = 0;
+    if (n_rows == 0) return FFQ_OK;
+    const int64_t nblk = (n_rows + 255) / 256;
+    int rc = grow_dev(c, &c->sel_cnt, &c->sel_cnt_cap, nblk);
+    if (!rc) rc = grow_dev(c, &c->sel_base, &c->sel_base_cap, nblk);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nblk), dim3(256), 0, st, d_table, n_rows, min_len, max_len,
+                       c->sel_cnt);
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, st, (const unsigned int *)c->sel_cnt, nblk, c->sel_base,
+                       (long long *)c->d_word);
+    hipLaunchKernelGGL(k_sel_scatter, dim3((unsigned)nblk), dim3(256), 0, st, d_table, n_rows, min_len, max_len,
+                       (const long long *)c->sel_base, d_out);
+    HIPCHK(hipMemcpyAsync(c->h_word, c->d_word, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    *n_out = c->h_word[0];
     return FFQ_OK;
 }
 

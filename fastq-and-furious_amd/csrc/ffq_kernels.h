@@ -454,6 +454,80 @@ __global__ __launch_bounds__(256) void k_decode_stream(const uint8_t *__restrict
     }
 }
 
+// =========================================================================
+// Row selection by sequence length (push-down of the length filter of
+// /root/reference/doc/user-guide.rst:153-180, evaluated on the offset table):
+// stable compaction of the rows with min_len <= pos3 - pos2 <= max_len.
+//   k_sel_count    one row per thread: kept rows per workgroup
+//   k_scan_i64     exclusive scan of those counts (one workgroup)
+//   k_sel_scatter  rank inside the workgroup by ballots, 48-byte row copy
+// =========================================================================
+__device__ __forceinline__ bool sel_keep(const int64_t *__restrict__ table, int64_t i, int64_t n, int64_t lo,
+                                         int64_t hi)
+{
+    if (i >= n) return false;
+    const longlong2 p = *reinterpret_cast<const longlong2 *>(table + i * 6 + 2);      // pos2, pos3
+    const int64_t ln = p.y - p.x;
+    return ln >= lo && ln <= hi;
+}
+
+__global__ __launch_bounds__(256) void k_sel_count(const int64_t *__restrict__ table, int64_t n, int64_t lo,
+                                                   int64_t hi, unsigned int *__restrict__ bcnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = __syncthreads_count(sel_keep(table, i, n, lo, hi) ? 1 : 0);
+    if (threadIdx.x == 0) bcnt[blockIdx.x] = (unsigned int)c;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_i64(const unsigned int *__restrict__ v, int64_t nv,
+                                                   long long *__restrict__ base, long long *__restrict__ total)
+{
+    __shared__ long long s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    long long carry = 0;
+    for (int64_t b0 = 0; b0 < nv; b0 += 1024) {
+        const int64_t b = b0 + tid;
+        const uint32_t x = (b < nv) ? v[b] : 0u;                 // <= 256 each: wave sums fit 32 bits
+        const uint32_t incl = wave_incl_scan(x);
+        if (lane == 63) s_w[wid] = (long long)incl;
+        __syncthreads();
+        long long wpre = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const long long t = s_w[q];
+            if (q < wid) wpre += t;
+            tot += t;
+        }
+        if (b < nv) base[b] = carry + wpre + (long long)(incl - x);
+        __syncthreads();
+        carry += tot;
+    }
+    if (tid == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_sel_scatter(const int64_t *__restrict__ table, int64_t n, int64_t lo,
+                                                     int64_t hi, const long long *__restrict__ bbase,
+                                                     int64_t *__restrict__ out)
+{
+    __shared__ uint32_t s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const bool keep = sel_keep(table, i, n, lo, hi);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_w[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t wpre = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q < wid) wpre += s_w[q];
+    if (!keep) return;
+    const int64_t r = bbase[blockIdx.x] + wpre + __popcll(m & ((1ull << lane) - 1ull));
+    const longlong2 *src = reinterpret_cast<const longlong2 *>(table + i * 6);
+    longlong2 *dst = reinterpret_cast<longlong2 *>(out + r * 6);
+    const longlong2 a = src[0], b = src[1], c = src[2];
+    dst[0] = a; dst[1] = b; dst[2] = c;
+}
+
 // lower bound over one column of the (record-ordered) offset table
 __global__ void k_table_lower_bound(const int64_t *__restrict__ table, int64_t n, int col,
                                     int64_t value, int64_t *__restrict__ out)

@@ -39,6 +39,7 @@ SYMBOLS = (
     "ffq_pinned_alloc", "ffq_pinned_free", "ffq_copy_h2d", "ffq_copy_d2h", "ffq_sync",
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
+    "ffq_table_select_seqlen",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
 )
@@ -114,6 +115,7 @@ def lib():
         L.ffq_arrayadd_q_device.argtypes = [vp, vp, i64, i64]
         L.ffq_arrayadd_q.argtypes = [vp, vp, i64, i64]
         L.ffq_table_lower_bound.argtypes = [vp, vp, i64, i32, i64, P(i64)]
+        L.ffq_table_select_seqlen.argtypes = [vp, vp, i64, i64, i64, vp, P(i64)]
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
         L.ffq_synth_wrapped_size.argtypes = [i64, u64]
         L.ffq_synth_wrapped_size.restype = i64
@@ -294,6 +296,14 @@ class Context:
         check(lib().ffq_read_probe(self.handle, ctypes.c_void_p(dptr), int(n_bytes), int(mode), int(reps),
                                    ctypes.byref(ms)))
         return ms.value
+
+    def table_select_seqlen(self, d_table, n_rows, min_len, max_len, d_out):
+        """Rows with min_len <= pos3 - pos2 <= max_len of a device table, in order, into
+        d_out (raw device pointers); returns the number kept."""
+        k = ctypes.c_int64(0)
+        check(lib().ffq_table_select_seqlen(self.handle, ctypes.c_void_p(d_table), int(n_rows), int(min_len),
+                                            int(max_len), ctypes.c_void_p(d_out), ctypes.byref(k)))
+        return k.value
 
     def synth_single(self, dptr, first, count, seed=42):
         check(lib().ffq_synth_single(self.handle, ctypes.c_void_p(dptr), int(first), int(count), int(seed)))

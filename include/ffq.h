@@ -181,6 +181,14 @@ int ffq_arrayadd_q(ffq_ctx *ctx, int64_t *h_a, int64_t n, int64_t value);
 int ffq_table_lower_bound(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int col,
                           int64_t value, int64_t *idx);
 
+/* Rows of a device offset table whose sequence length pos3 - pos2 lies in
+ * [min_len, max_len], in order, written to d_out (n_rows rows of room; not
+ * d_table itself); *n_out = rows kept.  The length filter of the reference's
+ * user guide (doc/user-guide.rst:153-180) evaluated on the table, before any
+ * per-record object exists: filtering reads is deleting rows (:199-204).    */
+int ffq_table_select_seqlen(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t min_len,
+                            int64_t max_len, int64_t *d_out, int64_t *n_out);
+
 /* ---- synthetic FASTQ generators (bench / test inputs) -----
  * Counter-based (splitmix64), so the numpy generator in
  * fastq-and-furious_amd/synth.py produces the same bytes.
