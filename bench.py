@@ -171,12 +171,20 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
                          % (args.gpus, args.gpus, world))
+    # FFQ_BENCH_DRY_MULTI=1: every rank on GPU 0 over gloo -- a functional dry run of the N > 1
+    # code path on a one-GPU box (its number means nothing; RCCL refuses two ranks per device)
+    dry = os.environ.get("FFQ_BENCH_DRY_MULTI") == "1"
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     wl = WORKLOADS[args.workload]
     ctx = hip.Context(local_rank)

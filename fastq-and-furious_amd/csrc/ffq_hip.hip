@@ -92,6 +92,7 @@ struct ffq_ctx {
     bool ctl_clean = false;             // the control block is zero (creation, or a publisher ran last)
     int64_t *d_word = nullptr;          // 2 scratch words for the small table queries
     int64_t *h_word = nullptr;          //   and their pinned mirror
+    int64_t *d_cut = nullptr, *h_cut = nullptr;    // ffq_table_cut: 4 words
     // staging for the host-buffer entry points
     uint8_t *stage_d = nullptr;
     int64_t stage_d_cap = 0;
@@ -159,6 +160,8 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_L, sizeof(LineIndex));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_word, 16);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_word, 16, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_cut, 32);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_cut, 32, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_L, sizeof(LineIndex), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_res, sizeof(DevRes), hipHostMallocMapped);
@@ -205,7 +208,8 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_word) (void)hipHostFree(c->h_word);
-    (void)hipFree(c->d_word);
+    if (c->h_cut) (void)hipHostFree(c->h_cut);
+    (void)hipFree(c->d_word); (void)hipFree(c->d_cut);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->stage_h) (void)hipHostFree(c->stage_h);
@@ -843,6 +847,19 @@ extern "C" int ffq_table_lower_bound(ffq_ctx *c, const int64_t *d_table, int64_t
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     *idx = *slot;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_table_cut(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t lo, int64_t hi,
+                             int64_t out[4])
+{
+    if (!c || !out || n_rows < 0 || (n_rows > 0 && !d_table)) return fail(FFQ_E_ARG, "ffq_table_cut: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_table_cut, dim3(1), dim3(64), 0, c->stream, d_table, n_rows, lo, hi, c->d_cut);
+    HIPCHK(hipMemcpyAsync(c->h_cut, c->d_cut, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 4; i++) out[i] = c->h_cut[i];
     return FFQ_OK;
 }
 

@@ -528,6 +528,38 @@ __global__ __launch_bounds__(256) void k_sel_scatter(const int64_t *__restrict__
     dst[0] = a; dst[1] = b; dst[2] = c;
 }
 
+// The rows of a shard inside the table of its [tail | own | head] scan, one wave, one launch:
+// i0 = first row with pos0 >= lo, i1 = first row with pos0 >= hi (64-ary searches), and pos0
+// of both rows (-1 past the end).  out = {i0, i1, pos0[i0], pos0[i1]}.
+__global__ __launch_bounds__(64) void k_table_cut(const int64_t *__restrict__ table, int64_t n, int64_t lo,
+                                                  int64_t hi, int64_t *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    int64_t res[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int64_t value = q ? hi : lo;
+        int64_t a = 0, b = n;                   // answer in [a, b]
+        while (b - a > 0) {
+            const int64_t stride = (b - a + 63) / 64;
+            const int64_t i = a + (int64_t)lane * stride;
+            const bool below = (i < b) && (table[i * 6] < value);       // monotone in i
+            const int k = __popcll(__ballot(below));                    // rows probed that are below
+            if (k == 0) { b = a; break; }
+            const int64_t last = a + (int64_t)(k - 1) * stride;         // largest probed row below value
+            a = last + 1;
+            b = min(b, last + stride);
+        }
+        res[q] = a;
+    }
+    if (lane == 0) {
+        out[0] = res[0];
+        out[1] = res[1];
+        out[2] = (res[0] < n) ? table[res[0] * 6] : -1;
+        out[3] = (res[1] < n) ? table[res[1] * 6] : -1;
+    }
+}
+
 // lower bound over one column of the (record-ordered) offset table
 __global__ void k_table_lower_bound(const int64_t *__restrict__ table, int64_t n, int col,
                                     int64_t value, int64_t *__restrict__ out)

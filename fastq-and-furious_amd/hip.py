@@ -39,7 +39,7 @@ SYMBOLS = (
     "ffq_pinned_alloc", "ffq_pinned_free", "ffq_copy_h2d", "ffq_copy_d2h", "ffq_sync",
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
-    "ffq_table_select_seqlen",
+    "ffq_table_select_seqlen", "ffq_table_cut",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
 )
@@ -116,6 +116,7 @@ def lib():
         L.ffq_arrayadd_q.argtypes = [vp, vp, i64, i64]
         L.ffq_table_lower_bound.argtypes = [vp, vp, i64, i32, i64, P(i64)]
         L.ffq_table_select_seqlen.argtypes = [vp, vp, i64, i64, i64, vp, P(i64)]
+        L.ffq_table_cut.argtypes = [vp, vp, i64, i64, i64, P(i64)]
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
         L.ffq_synth_wrapped_size.argtypes = [i64, u64]
         L.ffq_synth_wrapped_size.restype = i64
@@ -166,6 +167,10 @@ class Context:
 
     def reserve(self, max_bytes):
         check(lib().ffq_ctx_reserve(self.handle, int(max_bytes)))
+
+    def stream(self):
+        """The HIP stream (hipStream_t as an integer) every scan of this context runs on."""
+        return int(lib().ffq_ctx_stream(self.handle) or 0)
 
     def forget(self):
         """Drop the context's memory of what its recent input looked like."""
@@ -296,6 +301,12 @@ class Context:
         check(lib().ffq_read_probe(self.handle, ctypes.c_void_p(dptr), int(n_bytes), int(mode), int(reps),
                                    ctypes.byref(ms)))
         return ms.value
+
+    def table_cut(self, d_table, n_rows, lo, hi):
+        """(i0, i1, pos0[i0], pos0[i1]): first rows with pos0 >= lo / >= hi and their pos0."""
+        out = (ctypes.c_int64 * 4)()
+        check(lib().ffq_table_cut(self.handle, ctypes.c_void_p(d_table), int(n_rows), int(lo), int(hi), out))
+        return [int(x) for x in out]
 
     def table_select_seqlen(self, d_table, n_rows, min_len, max_len, d_out):
         """Rows with min_len <= pos3 - pos2 <= max_len of a device table, in order, into

@@ -75,6 +75,10 @@ class HipBackend:
     def lower_bound(self, table, n_rows, value):
         return self.ctx.table_lower_bound(table.data_ptr(), n_rows, 0, value)
 
+    def cut(self, table, n_rows, lo, hi):
+        """(i0, i1, pos0[i0], pos0[i1]) in one launch and one host wait."""
+        return self.ctx.table_cut(table.data_ptr(), n_rows, lo, hi)
+
     def row(self, table, idx):
         out = np.empty(6, dtype=np.int64)
         self.ctx.d2h(out, table.data_ptr() + idx * 48)
@@ -92,14 +96,31 @@ def exchange_edges(dist, ext, tail, n_own, head, rank, world, group=None):
         return
     ops = []
     own = ext[tail:tail + n_own]
+    # a transport that cannot move device memory (gloo: the CPU tests, and the one-GPU dry run
+    # of bench.py) gets the edges through host copies; RCCL moves them GPU to GPU
+    staged = ext.is_cuda and dist.get_backend(group) == "gloo"
+    recv = []
+
+    def _send(t, peer):
+        ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, group))
+
+    def _recv(t, peer):
+        if staged:
+            h = t.cpu()
+            recv.append((t, h))
+            t = h
+        ops.append(dist.P2POp(dist.irecv, t, peer, group))
+
     if rank > 0:
-        ops.append(dist.P2POp(dist.isend, own[:min(HEAD_BYTES, n_own)], rank - 1, group))
-        ops.append(dist.P2POp(dist.irecv, ext[:tail], rank - 1, group))
+        _send(own[:min(HEAD_BYTES, n_own)], rank - 1)
+        _recv(ext[:tail], rank - 1)
     if rank < world - 1:
-        ops.append(dist.P2POp(dist.isend, own[n_own - min(TAIL_BYTES, n_own):], rank + 1, group))
-        ops.append(dist.P2POp(dist.irecv, ext[tail + n_own:tail + n_own + head], rank + 1, group))
+        _send(own[n_own - min(TAIL_BYTES, n_own):], rank + 1)
+        _recv(ext[tail + n_own:tail + n_own + head], rank + 1)
     for w in dist.batch_isend_irecv(ops):
         w.wait()
+    for t, h in recv:
+        t.copy_(h)
 
 
 class ShardScanner:
@@ -160,10 +181,15 @@ class ShardScanner:
                                  % (res.end_state, add + res.end_offset))
         elif res.end_state != _hip.END_REFILL:
             raise ValueError("rank %d: invalid entry at byte %d" % (rank, add + res.end_offset))
-        i0 = 0 if rank == 0 else self.backend.lower_bound(table, n, own_lo_file)
-        i1 = n if eof else self.backend.lower_bound(table, n, own_hi_file)
-        first_pos = self.backend.row(table, i0)[0] if i0 < n else -1
-        exit_pos = self.backend.row(table, i1)[0] if i1 < n else -1
+        cut = getattr(self.backend, "cut", None)
+        if cut is not None:
+            i0, i1, first_pos, exit_pos = cut(table, n, -(1 << 62) if rank == 0 else own_lo_file,
+                                              (1 << 62) if eof else own_hi_file)
+        else:
+            i0 = 0 if rank == 0 else self.backend.lower_bound(table, n, own_lo_file)
+            i1 = n if eof else self.backend.lower_bound(table, n, own_hi_file)
+            first_pos = self.backend.row(table, i0)[0] if i0 < n else -1
+            exit_pos = self.backend.row(table, i1)[0] if i1 < n else -1
         if not eof and exit_pos < 0:
             raise RuntimeError("rank %d: no complete record starts after byte %d within the %d-byte "
                                "look-ahead (record longer than the halo)" % (rank, own_hi_file, head))
@@ -176,10 +202,19 @@ class ShardScanner:
         import torch
         dist, rank, world = self.dist, self.rank, self.world
         dev = self.device
+        if dist.get_backend(self.group) == "gloo":
+            dev = torch.device("cpu")
         mine = torch.tensor([out.exit_pos, out.n_own_records], dtype=torch.int64, device=dev)
-        allv = [torch.empty(2, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(allv, mine, group=self.group)
-        allv = [[int(x) for x in t.tolist()] for t in allv]
+        if dev.type == "cuda":
+            # one collective into one tensor, one copy back
+            flat = torch.empty(2 * world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(flat, mine, group=self.group)
+            v = flat.tolist()
+            allv = [v[2 * r:2 * r + 2] for r in range(world)]
+        else:
+            allv = [torch.empty(2, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(allv, mine, group=self.group)
+            allv = [[int(x) for x in t.tolist()] for t in allv]
         if rank > 0 and allv[rank - 1][0] != out.first_pos:
             raise RuntimeError("rank %d: edge hand-off mismatch: left neighbour's chain enters this range "
                                "at byte %d, this rank started at %d" % (rank, allv[rank - 1][0], out.first_pos))
@@ -252,12 +287,17 @@ class SyntheticShard:
         min_rec = 322 if kind == "single" else 120
         self.max_records = n_per + (self.tail + self.head) // min_rec + 64
         self.scanner = ShardScanner(HipBackend(ctx), rank, world, self.dist, None, dev)
+        self._xstream = None
 
     def scan(self, table, flags=0, qual=None, qoff=None):
         if self.world > 1:
-            exchange_edges(self.dist, self.ext, self.tail, self.n_own_bytes, self.head, self.rank, self.world)
+            # the hand-off runs on the scan's own stream (RCCL orders itself against the current
+            # stream): the scan that follows needs no host synchronisation in between
             import torch
-            torch.cuda.synchronize()
+            if self._xstream is None:
+                self._xstream = torch.cuda.ExternalStream(self.ctx.stream(), device=self.dev)
+            with torch.cuda.stream(self._xstream):
+                exchange_edges(self.dist, self.ext, self.tail, self.n_own_bytes, self.head, self.rank, self.world)
         return self.scanner.scan(self.ext, self.tail, self.n_own_bytes, self.head, self.own_lo, self.own_hi,
                                  table, flags, qual, qoff)
 

@@ -181,6 +181,12 @@ int ffq_arrayadd_q(ffq_ctx *ctx, int64_t *h_a, int64_t n, int64_t value);
 int ffq_table_lower_bound(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int col,
                           int64_t value, int64_t *idx);
 
+/* The rows of a byte-range shard inside the table of its scan: out = {i0, i1, pos0[i0],
+ * pos0[i1]} with i0 / i1 the first rows whose pos0 (column 0) is >= lo / >= hi
+ * (n_rows if none; the positions are -1 then).  One launch, one host wait.   */
+int ffq_table_cut(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t lo, int64_t hi,
+                  int64_t out[4]);
+
 /* Rows of a device offset table whose sequence length pos3 - pos2 lies in
  * [min_len, max_len], in order, written to d_out (n_rows rows of room; not
  * d_table itself); *n_out = rows kept.  The length filter of the reference's

@@ -403,3 +403,22 @@ def test_quarter_gib_closed_form(gpu_ctx, pkg):
     k = torch.arange(n, dtype=torch.int64, device="cuda") * 322
     want = torch.stack([k, k + 17, k + 18, k + 168, k + 171, k + 321], dim=1)
     assert bool((table[:n] == want).all())
+
+
+def test_table_cut(gpu_ctx):
+    """ffq_table_cut == searchsorted on column 0, for every kind of bound."""
+    import torch
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 63, 64, 65, 4096, 100003):
+        p0 = np.sort(rng.choice(10 * n + 10, size=n, replace=False)).astype(np.int64) if n else np.zeros(0, np.int64)
+        t = np.zeros((max(n, 1), 6), dtype=np.int64)
+        t[:n, 0] = p0
+        d = torch.from_numpy(t).cuda()
+        qs = [-(1 << 62), 0, 1 << 62] + ([int(p0[0]), int(p0[-1]), int(p0[-1]) + 1, int(p0[n // 2]), int(p0[n // 2]) + 1]
+                                       if n else [])
+        for lo in qs:
+            for hi in qs:
+                i0, i1, f0, f1 = gpu_ctx.table_cut(d.data_ptr(), n, lo, hi)
+                e0, e1 = int(np.searchsorted(p0, lo, side="left")), int(np.searchsorted(p0, hi, side="left"))
+                assert (i0, i1) == (e0, e1), (n, lo, hi)
+                assert f0 == (int(p0[e0]) if e0 < n else -1) and f1 == (int(p0[e1]) if e1 < n else -1)
