@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--workload", default="single-1g", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--sharded-step", action="store_true",
+                    help="N=1 through the synchronous step the N>1 ranks run (diagnostics)")
     args = ap.parse_args()
 
     import torch
@@ -216,7 +218,7 @@ def main():
         ms_decode.append(out.res.ms_decode)
         ms_total.append(out.res.ms_total)
 
-    if world == 1:
+    if world == 1 and not args.sharded_step:
         # Single range: steps are submitted through two contexts that share their HIP streams,
         # one step ahead (ffq_scan_submit / ffq_scan_wait): while the host waits for step i the
         # kernels of step i+1 are already queued behind it.  Every step is a full scan of the
