@@ -265,7 +265,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         table = tables[(args.steps - 1) & 1]
-    else:
+    elif world == 1:
         def step():
             return shard.scan(table, flags=flags, qual=qual, qoff=qoff)
 
@@ -278,6 +278,39 @@ def main():
             note(out)
         barrier()
         elapsed = time.perf_counter() - t0
+    else:
+        # Byte-range shards: the same one-step-ahead queue per rank.  A step = edge hand-off
+        # (RCCL send/recv, ordered on the scan stream) + scan of [tail | own | head] + cut of the
+        # own rows + hand-off verification (all_gather of 16 bytes per rank).  submit(i + 1) is
+        # queued before finish(i); finish's small kernel runs on a stream of its own.
+        shard.make_lanes(2)
+        tables = (table, torch.empty_like(table))
+        quals = (qual, torch.empty_like(qual) if decode else None)
+        qoffs = (qoff, torch.empty_like(qoff) if decode else None)
+        torch.cuda.synchronize()
+
+        def run(nsteps, record):
+            out = None
+            shard.submit(0, tables[0], flags, quals[0], qoffs[0])
+            for i in range(1, nsteps):
+                k = i & 1
+                shard.submit(k, tables[k], flags, quals[k], qoffs[k])
+                out = shard.finish(k ^ 1)
+                if record:
+                    note(out)
+            out = shard.finish((nsteps - 1) & 1)
+            if record:
+                note(out)
+            return out
+
+        if args.warmup:
+            out = run(args.warmup, False)
+        barrier()
+        t0 = time.perf_counter()
+        out = run(args.steps, True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        table = tables[(args.steps - 1) & 1]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

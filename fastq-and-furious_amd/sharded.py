@@ -58,8 +58,9 @@ class ScanOutput:
 class HipBackend:
     """Scan engine on the local MI355X through the C ABI."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, post_ctx=None):
         self.ctx = ctx
+        self.post = post_ctx or ctx     # context (stream) the small table queries run on
 
     def scan(self, ext, n_bytes, sentinel, offset, eof, add, table, flags=0, qual=None, qoff=None,
              table_cap=None):
@@ -72,12 +73,23 @@ class HipBackend:
             d_qoff=qoff.data_ptr() if qoff is not None else None)
         return rc, res
 
+    def scan_submit(self, ext, n_bytes, sentinel, offset, eof, add, table, flags=0, qual=None, qoff=None):
+        self.ctx.scan_submit(
+            ext.data_ptr(), n_bytes, table.data_ptr(), table.shape[0], sentinel=sentinel, offset=offset,
+            eof=eof, add=add, flags=flags,
+            d_qual=qual.data_ptr() if qual is not None else None,
+            qual_cap=qual.numel() if qual is not None else 0,
+            d_qoff=qoff.data_ptr() if qoff is not None else None)
+
+    def scan_wait(self):
+        return self.ctx.scan_wait()
+
     def lower_bound(self, table, n_rows, value):
         return self.ctx.table_lower_bound(table.data_ptr(), n_rows, 0, value)
 
     def cut(self, table, n_rows, lo, hi):
         """(i0, i1, pos0[i0], pos0[i1]) in one launch and one host wait."""
-        return self.ctx.table_cut(table.data_ptr(), n_rows, lo, hi)
+        return self.post.table_cut(table.data_ptr(), n_rows, lo, hi)
 
     def row(self, table, idx):
         out = np.empty(6, dtype=np.int64)
@@ -151,7 +163,24 @@ class ShardScanner:
             offset = int(res.last_pos[0]) - add      # the '@' of the failing entry: search after it
         raise RuntimeError("rank %d: no record chain survives the %d-byte run-in" % (self.rank, tail))
 
-    def scan(self, ext, tail, n_own, head, own_lo_file, own_hi_file, table, flags=0, qual=None, qoff=None):
+    def submit(self, ext, tail, n_own, head, own_lo_file, own_hi_file, table, flags=0, qual=None, qoff=None):
+        """Enqueue the (offset 0) scan of a step and return; finish() completes the step.  With a
+        second ShardScanner on a context that shares the stream, the next step is queued while
+        this one is finished: the GPU does not idle during the host's part of a step."""
+        rank, world = self.rank, self.world
+        sentinel = rank == 0
+        eof = rank == world - 1
+        add = (own_lo_file - tail) - (1 if sentinel else 0)
+        self.backend.scan_submit(ext, tail + n_own + head, sentinel, 0, eof, add, table, flags, qual, qoff)
+        self._pending = (ext, tail, n_own, head, own_lo_file, own_hi_file, table, flags, qual, qoff)
+
+    def finish(self):
+        args = self._pending
+        self._pending = None
+        return self.scan(*args, first=self.backend.scan_wait())
+
+    def scan(self, ext, tail, n_own, head, own_lo_file, own_hi_file, table, flags=0, qual=None, qoff=None,
+             first=None):
         """ext = [tail | own | head] bytes (1-D uint8 tensor); the file offset of
         ext[tail] is own_lo_file.  Returns ScanOutput; table rows are absolute
         file offsets."""
@@ -167,7 +196,11 @@ class ShardScanner:
         # start that survives searched for (a scan of the run-in alone) and the scan redone.
         offset = 0
         for attempt in range(2):
-            rc, res = self.backend.scan(ext, n_bytes, sentinel, offset, eof, add, table, flags, qual, qoff)
+            if first is not None:
+                rc, res = first          # the offset-0 scan was submitted ahead (submit / finish)
+                first = None
+            else:
+                rc, res = self.backend.scan(ext, n_bytes, sentinel, offset, eof, add, table, flags, qual, qoff)
             if rc != _hip.OK:
                 raise RuntimeError("rank %d: offset table too small (%d records)" % (rank, res.n_records))
             good = res.end_state == (_hip.END_OK if eof else _hip.END_REFILL)
@@ -288,6 +321,7 @@ class SyntheticShard:
         self.max_records = n_per + (self.tail + self.head) // min_rec + 64
         self.scanner = ShardScanner(HipBackend(ctx), rank, world, self.dist, None, dev)
         self._xstream = None
+        self._lanes = None
 
     def scan(self, table, flags=0, qual=None, qoff=None):
         if self.world > 1:
@@ -300,6 +334,35 @@ class SyntheticShard:
                 exchange_edges(self.dist, self.ext, self.tail, self.n_own_bytes, self.head, self.rank, self.world)
         return self.scanner.scan(self.ext, self.tail, self.n_own_bytes, self.head, self.own_lo, self.own_hi,
                                  table, flags, qual, qoff)
+
+    # ---- pipelined steps: submit(i + 1) before finish(i) -------------------------------------
+    def make_lanes(self, n=2):
+        """n scanners on contexts that share the scan stream (own scratch each) + one context
+        with its own stream for the small queries of finish(), so that they do not queue
+        behind the next step's kernels."""
+        from . import hip
+        post = hip.Context(self.ctx.device)
+        lanes = [ShardScanner(HipBackend(self.ctx, post), self.rank, self.world, self.dist, None, self.dev)]
+        for _ in range(n - 1):
+            c = hip.Context(share=self.ctx)
+            c.reserve(self.ext.numel())
+            lanes.append(ShardScanner(HipBackend(c, post), self.rank, self.world, self.dist, None, self.dev))
+        self._lanes = lanes
+        self._post = post
+        return lanes
+
+    def submit(self, lane, table, flags=0, qual=None, qoff=None):
+        import torch
+        if self.world > 1:
+            if self._xstream is None:
+                self._xstream = torch.cuda.ExternalStream(self.ctx.stream(), device=self.dev)
+            with torch.cuda.stream(self._xstream):
+                exchange_edges(self.dist, self.ext, self.tail, self.n_own_bytes, self.head, self.rank, self.world)
+        self._lanes[lane].submit(self.ext, self.tail, self.n_own_bytes, self.head, self.own_lo, self.own_hi,
+                                 table, flags, qual, qoff)
+
+    def finish(self, lane):
+        return self._lanes[lane].finish()
 
     def host_sample(self, nbytes):
         """First whole records of this rank's range, on the host."""
