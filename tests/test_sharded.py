@@ -35,6 +35,14 @@ class OracleBackend:
             res.last_pos = [int(p) + add if p >= 0 else -1 for p in pos]
         return 0, res
 
+    # submit / wait: the engine runs at wait time (what matters is the protocol above it)
+    def scan_submit(self, *a, **kw):
+        self._queued = (a, kw)
+
+    def scan_wait(self):
+        a, kw = self._queued
+        return self.scan(*a, **kw)
+
     def lower_bound(self, table, n_rows, value):
         return int(np.searchsorted(table[:n_rows, 0].numpy(), value, side="left"))
 
@@ -73,6 +81,17 @@ def _worker(rank, world, port, kind, tmpdir):
         table = torch.empty((20000, 6), dtype=torch.int64)
         sc = sharded.ShardScanner(OracleBackend(), rank, world, dist, None, torch.device("cpu"))
         out = sc.scan(ext, tail, hi - lo, head, lo, hi, table)
+        # the same step through submit / finish, two lanes, two rounds (the queue bench.py keeps)
+        lanes = [sc, sharded.ShardScanner(OracleBackend(), rank, world, dist, None, torch.device("cpu"))]
+        tabs = [table, torch.empty_like(table)]
+        lanes[0].submit(ext, tail, hi - lo, head, lo, hi, tabs[0])
+        for i in range(1, 4):
+            lanes[i & 1].submit(ext, tail, hi - lo, head, lo, hi, tabs[i & 1])
+            o2 = lanes[(i - 1) & 1].finish()
+            assert (o2.row_lo, o2.row_hi, o2.exit_pos, o2.first_pos, o2.record_base) == \
+                   (out.row_lo, out.row_hi, out.exit_pos, out.first_pos, out.record_base)
+            assert (tabs[(i - 1) & 1][:o2.n_rows] == table[:out.n_rows]).all()
+        lanes[3 & 1].finish()
         want, end, st, off = ffq_oracle.scan(stream)
         mine = want[(want[:, 0] >= lo) & (want[:, 0] < hi)]
         got = table[out.row_lo:out.row_hi].numpy()
