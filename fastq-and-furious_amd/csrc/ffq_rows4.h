@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= L.ntiles) return;
-    if (!hdr->attempt) return;
+    // the header words are only TESTED after the tile's own loads have been issued: a branch on
+    // them up here would put a second memory round trip in front of every wave
+    const int attempt = hdr->attempt;
     const long long j0 = hdr->j0;
     uint16_t *s_ent = s_ent_all[wid];
     uint32_t *s_la = s_la_all[wid];
@@ -210,14 +212,29 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
     // everything this tile usually needs in ONE memory round trip: its count, its first 256
     // entries (4 per lane), the counts for its ordinal base, and -- speculatively -- the
     // first 8 entries of the next tile as look-ahead
-    const int c = (int)L.cnt[t];
+    // All of these loads are unconditional (clamped addresses, values masked afterwards): any
+    // branch between them makes the compiler wait for the earlier ones first, and the prologue
+    // was four dependent memory round trips instead of one.
+    const int tn = min(t + 1, L.ntiles - 1);                        // next tile, clamped
+    const int sb = t / SB_TILES, t0 = sb * SB_TILES;
     const uint16_t *src = L.ent + (int64_t)t * SLOT;
+    const uint32_t c_raw = L.cnt[t];
     const uint2 v0 = *reinterpret_cast<const uint2 *>(src + 4 * lane);
+    const uint32_t c1_raw = L.cnt[tn];
+    const uint2 vla_raw = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)tn * SLOT + 4 * (lane & 1));
+    const uint32_t cb_raw = L.cnt[min(t0 + lane, L.ntiles - 1)];     // SB_TILES == 64 lanes
+    const long long sbb = sbbase[sb];
+    // pin the loads here: without a use in front of the early exits below the compiler sinks
+    // each load behind the branch that precedes its first use
+    asm volatile("" ::"v"(c_raw), "v"(v0.x), "v"(v0.y), "v"(c1_raw), "v"(vla_raw.x), "v"(vla_raw.y), "v"(cb_raw),
+                 "v"(sbb), "s"(attempt), "s"(j0));
+    const int c = (int)c_raw;
     const bool have_next = t + 1 < L.ntiles;
-    const int c1 = have_next ? (int)L.cnt[t + 1] : 0;
-    uint2 vla = make_uint2(0, 0);
-    if (have_next && lane < 2) vla = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)(t + 1) * SLOT + 4 * lane);
-    const long long ob = tile_ordinal_base(L, sbbase, t, lane);     // ordinal of entry 0 of this tile
+    const int c1 = have_next ? (int)c1_raw : 0;
+    const uint2 vla = vla_raw;                                       // used by lanes 0, 1 when have_next
+    // global ordinal of entry 0 of this tile (the sentinel, if any, is ordinal 0)
+    const long long ob = sbb + (long long)wave_sum_u32((t0 + lane < t) ? cb_raw : 0u) + L.s;
+    if (!attempt) return;
     if (c > SLOT) {                    // dense tile: leave it to the general path
         if (lane == 0) atomicMin(&hdr->irr_min, 0ull);
         return;
