@@ -362,9 +362,14 @@ __global__ __launch_bounds__(256) void k_decode_stream(const uint8_t *__restrict
         want = (want < 0) ? DQ_REC - 1 : min(DQ_REC - 1, rem / mean + rem / (8 * mean) + 8);
         const int nrec = (int)min((int64_t)want, n - rbase);     // >= 1
         for (int i = tid; i <= nrec; i += 256) {
-            const int64_t q = qoff[rbase + i] - ob;
+            // both loads before either is used (the source position of index nrec is not needed:
+            // a clamped address keeps the load unconditional)
+            const int64_t qraw = qoff[rbase + i];
+            const int64_t p4 = table[(rbase + min(i, nrec - 1)) * 6 + 4];
+            asm volatile("" ::"v"(qraw), "v"(p4));
+            const int64_t q = qraw - ob;
             s_q[i] = (int32_t)min(max(q, (int64_t)-0x7FFFFFFF), (int64_t)0x7FFFFFFF);
-            if (i < nrec) s_adj[i] = table[(rbase + i) * 6 + 4] - add - s - q;
+            if (i < nrec) s_adj[i] = p4 - add - s - q;
         }
         __syncthreads();
         const int cend = s_q[nrec];                // every byte below cend has its record cached

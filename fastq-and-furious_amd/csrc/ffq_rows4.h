@@ -97,17 +97,24 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
         // them as 16 fully coalesced 1 KiB loads (4 superblocks each, 16 lanes per superblock);
         // a thread-per-superblock read of the same bytes is bound by one CU's cache-line rate.
         uint32_t part[16];
+        const int64_t tw0 = ((int64_t)(b0 + wid * 64) << 6) + lane * 4;    // this lane's first tile, piece 0
+        if (tw0 + (15 << 8) + 4 <= L.ntiles - (63 - lane) * 4) {
+            // the whole 16 KiB of counts of this wave lies inside the index (wave-uniform test:
+            // the last lane's last piece): 16 loads, no branch between them, one wait
+            uint4 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int64_t t = ((int64_t)(b0 + wid * 64 + 4 * j) << 6) + lane * 4;     // first tile of this lane's piece
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (t + 4 <= L.ntiles) x = *reinterpret_cast<const uint4 *>(L.cnt + t);
-            else {
-                if (t < L.ntiles) x.x = L.cnt[t];
-                if (t + 1 < L.ntiles) x.y = L.cnt[t + 1];
-                if (t + 2 < L.ntiles) x.z = L.cnt[t + 2];
+            for (int j = 0; j < 16; j++) x[j] = *reinterpret_cast<const uint4 *>(L.cnt + tw0 + ((int64_t)j << 8));
+#pragma unroll
+            for (int j = 0; j < 16; j++) part[j] = x[j].x + x[j].y + x[j].z + x[j].w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int64_t t = tw0 + ((int64_t)j << 8);
+                uint32_t a = 0;
+                for (int q = 0; q < 4; q++)
+                    if (t + q < L.ntiles) a += L.cnt[t + q];
+                part[j] = a;
             }
-            part[j] = x.x + x.y + x.z + x.w;
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -465,11 +472,15 @@ __global__ __launch_bounds__(256) void k_qfix4(int ntiles, const Fast4Hdr *__res
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= ntiles || !hdr->attempt) return;
-    const TileQ me = tileq[t];
-    if (me.nrec <= 0) return;
+    // the three loads go out together (clamped addresses, masked values): a branch between them
+    // is a memory round trip each
     const int t0 = (t / SB_TILES) * SB_TILES;
-    const uint32_t before = (t0 + lane < t) ? tileq[t0 + lane].qsum : 0u;       // SB_TILES == 64 lanes
-    const int64_t base = sbqbase[t / SB_TILES] + (int64_t)wave_sum_u32(before);
+    const TileQ me = tileq[t];
+    const uint32_t bq = tileq[min(t0 + lane, ntiles - 1)].qsum;                  // SB_TILES == 64 lanes
+    const long long sbb = sbqbase[t / SB_TILES];
+    asm volatile("" ::"v"(me.kfirst), "v"(me.nrec), "v"(me.qsum), "v"(bq), "v"(sbb));
+    if (me.nrec <= 0) return;
+    const int64_t base = sbb + (int64_t)wave_sum_u32((t0 + lane < t) ? bq : 0u);
     for (int r0 = 0; r0 < me.nrec; r0 += 64) {
         const int r = r0 + lane;
         const int64_t idx = me.kfirst + r;
