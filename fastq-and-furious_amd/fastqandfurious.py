@@ -16,10 +16,15 @@ readfastq_iter is handed a scanner that exposes `scan_buffer` it parses every
 record of a buffer fill with ONE batched GPU call instead of one call per
 record, and yields exactly the same entries.
 
-Out of scope here: FASTA helpers, automagic_open.
+Beyond the hot path: the FASTA plug-in scanner of the reference
+(`entrypos_fasta`, `entryfunc_fasta`, :103-143, :174-183) and a working `automagic_open`
+(:282-334; the reference's own cannot run: it calls `importlib.importmodule` and ignores its
+`openers` argument).
 """
 from array import array
 from collections import namedtuple
+import importlib
+import os
 import typing
 
 CHAR_AT: int = ord(b'@')
@@ -27,6 +32,8 @@ CHAR_PLUS: int = ord(b'+')
 CHAR_NEWLINE: int = ord(b'\n')
 BYTES_NEWLINE_AT: bytes = b'\n@'
 BYTES_NEWLINE_PLUS: bytes = b'\n+'
+CHAR_GT: int = ord(b'>')
+BYTES_NEWLINE_GT: bytes = b'\n>'
 ARRAY_INIT = array('q', [-1, ] * 6)
 
 Entry = namedtuple('Entry', 'header sequence quality')
@@ -94,6 +101,36 @@ def entrypos(buf: bytes, offset: int, posbuffer) -> int:
         return MISSING_QUAL_END
     posbuffer[5] = qual_end
     return COMPLETE
+
+
+def entrypos_fasta(buf: bytes, offset: int, posbuffer) -> int:
+    """Plug-in scanner for FASTA (reference :103-143): next "\\n>" from `offset`, end of the
+    header line, then the sequence up to the next "\\n>".  Fills posbuffer[0..3] as far as
+    it gets and returns MISSING_SEQHEADER_BEGIN / _END, MISSING_SEQ_BEG, MISSING_SEQ_END (the
+    buffer ended first: posbuffer[3] is then the end of the buffer, without a trailing
+    newline) or COMPLETE."""
+    i = buf.find(BYTES_NEWLINE_GT, offset)
+    if i < 0:
+        return MISSING_SEQHEADER_BEGIN
+    posbuffer[0] = i + 1
+    j = buf.find(b'\n', i + 2)
+    if j < 0:
+        return MISSING_SEQHEADER_END
+    posbuffer[1] = j
+    if j + 1 >= len(buf):
+        return MISSING_SEQ_BEG
+    posbuffer[2] = j + 1
+    k = buf.find(BYTES_NEWLINE_GT, j + 1)
+    if k < 0:
+        posbuffer[3] = len(buf) - 1 if buf[-1] == CHAR_NEWLINE else len(buf)
+        return MISSING_SEQ_END
+    posbuffer[3] = k
+    return COMPLETE
+
+
+def entryfunc_fasta(buf: bytes, pos, globaloffset: int):
+    """(header, sequence) byte slices of a FASTA entry (reference :174-183)."""
+    return (buf[(pos[0] + 1):pos[1]], buf[pos[2]:pos[3]])
 
 
 def entryfunc_namedtuple(buf: bytes, pos, globaloffset: int) -> Entry:
@@ -205,3 +242,31 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
         buf = buf[offset:] + tmp_buf
         del tmp_buf
         offset = 0
+
+
+# extension -> (module name or namespace, opener name, positional arguments after the file name)
+FORMAT_OPENERS: typing.Dict[str, typing.Tuple[typing.Union[str, object], str, list]] = {
+    'gz': ('gzip', 'open', list()),
+    'gzip': ('gzip', 'open', list()),
+    'bz2': ('bz2', 'open', list()),
+    'lzma': ('lzma', 'open', list()),
+    'xz': ('lzma', 'open', list()),
+}
+
+
+def automagic_open(filename, openers=None) -> typing.BinaryIO:
+    """Open a (presumably FASTQ) file, compressed or not, by its extension (reference
+    :290-334): `foo/bar.fq.gz` through gzip, `foo/bar.fq` as a plain binary file.  `openers`
+    maps extensions to (module name or namespace, function name, extra positional arguments);
+    None means FORMAT_OPENERS.  The stream it returns feeds readfastq_iter: decompression
+    runs on the host, the scan of every buffer fill on the GPU."""
+    if openers is None:
+        openers = FORMAT_OPENERS
+    parts = str(filename).rsplit(os.path.extsep, maxsplit=1)
+    ext = parts[-1] if len(parts) > 1 else None
+    try:
+        modulename, funcname, args = openers[ext]
+    except KeyError:
+        modulename, funcname, args = ('io', 'open', ('rb', ))
+    module = importlib.import_module(modulename) if isinstance(modulename, str) else modulename
+    return getattr(module, funcname)(filename, *args)

@@ -270,6 +270,37 @@ for name, blob in (("synth_single_2000", synth.single(0, 2000, seed=42).tobytes(
     index[name] = {"sha256": hashlib.sha256(fi.getvalue()).hexdigest(), "bytes": len(fi.getvalue())}
 golden["index"] = index
 
+# ---- (e3) FASTA scanner (reference :103-143; templates of tests.py:36-53): status and posbuffer
+#      at every prefix length, Python scanner (the reference has no C one for FASTA)
+FA_TPL = {
+    "NOTFINAL": "\n>{h}\n{s}\n>{h}_2\n{s}\n",
+    "FINAL": "\n>{h}\n{s}\n",
+    "NOSEQ": "\n>{h}\n",
+    "GT_IN_SEQ": "\n>{h}\n{s}>x\n{s}\n>{h}_2\n{s}",
+}
+fasta = []
+for name, tpl in FA_TPL.items():
+    for sq in (SEQ, MSEQ, ""):
+        full = tpl.format(h=HEADER, s=sq).encode("ascii")
+        curve = []
+        for cut in range(len(full) + 1):
+            for off in (0, 3):
+                b = full[:cut]
+                pp = array("q", [-1] * 6)
+                if cut == 0:
+                    # buf[-1] of an empty buffer raises in the reference only when "\n>" and a
+                    # header end were found first: never for the empty prefix
+                    pass
+                st = py.entrypos_fasta(b, off, pp)
+                curve.append({"cut": cut, "offset": off, "r": [int(st), [int(x) for x in pp]]})
+        ent = None
+        pp = array("q", [-1] * 6)
+        if py.entrypos_fasta(full, 0, pp) in (py.COMPLETE, py.MISSING_SEQ_END):
+            h, q = py.entryfunc_fasta(full, pp, 0)
+            ent = [h.hex(), q.hex()]
+        fasta.append({"name": name, "seq": sq, "buf": full.hex(), "curve": curve, "entry": ent})
+golden["fasta"] = fasta
+
 with open(os.path.join(HERE, "golden.json"), "w") as fh:
     json.dump(golden, fh, indent=0, sort_keys=True)
 
