@@ -422,3 +422,55 @@ def test_table_cut(gpu_ctx):
                 e0, e1 = int(np.searchsorted(p0, lo, side="left")), int(np.searchsorted(p0, hi, side="left"))
                 assert (i0, i1) == (e0, e1), (n, lo, hi)
                 assert f0 == (int(p0[e0]) if e0 < n else -1) and f1 == (int(p0[e1]) if e1 < n else -1)
+
+
+def _mess(rng, n, fatal=True):
+    """FASTQ-like text with everything that makes the chain hard: '@' and '+' heavy quality,
+    wrapped and unwrapped records mixed, '+' lines that repeat (or garble) the header, empty
+    lines, CRLF, stray text between records, records cut short."""
+    qchars = np.frombuffer(b"@+@+IIII#5?@+", dtype=np.uint8)
+    parts = []
+    for i in range(n):
+        L = int(rng.integers(1, 180))
+        h = b"r%d" % i + (b" desc" if rng.random() < 0.3 else b"")
+        seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=L).tobytes()
+        qual = rng.choice(qchars, size=L).tobytes()
+        u = rng.random()
+        if u < 0.35:
+            w = int(rng.integers(7, 70))
+            seq = b"\n".join(seq[k:k + w] for k in range(0, L, w))
+            qual = b"\n".join(qual[k:k + w] for k in range(0, L, w))
+        plus = b"+" + (h if rng.random() < 0.25 else b"")
+        if fatal and rng.random() < 0.01:
+            plus += b"xy"                                   # '+' line length rule -> INVALID
+        # CRLF after the header makes a repeated '+' header one byte short of it -> INVALID
+        nl = b"\r\n" if rng.random() < 0.02 and (fatal or len(plus) == 1) else b"\n"
+        rec = b"@" + h + nl + seq + b"\n" + plus + b"\n" + qual + b"\n"
+        v = rng.random()
+        if fatal and v < 0.01:
+            rec = rec[:int(rng.integers(1, len(rec)))] + b"\n"        # cut short
+        elif v < 0.02:
+            rec = b"\n" + rec                                          # empty line in front
+        elif v < 0.03:
+            rec = b"junk line\n" + rec
+        parts.append(rec)
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_differential_mess(gpu_ctx, hipmod, oracle, chain_path, seed):
+    """Seeded differential test against the oracle on hostile input, every path, with the
+    decode; then the same stream from a later offset, not at eof, and without the sentinel."""
+    rng = np.random.default_rng(1000 + seed)
+    data = _mess(rng, 20000, fatal=seed >= 4)      # seeds 0-3: the chain runs through all of it
+    want, end, status, off = oracle.scan(data)
+    if seed < 4:
+        assert len(want) > 15000
+    table, res, qual, qoff = gpu_ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL)
+    assert int(res.end_state) == end and int(res.last_status) == status and int(res.end_offset) == off
+    assert (table == want).all()
+    wq, wqoff = oracle.decode_quals(data, want)
+    assert (qoff == wqoff).all() and (qual == wq).all()
+    cut = len(data) // 3
+    for kw in (dict(offset=cut), dict(eof=False), dict(sentinel=False, offset=7, eof=False)):
+        check_same(gpu_ctx, oracle, data[:len(data) - 11], **kw)
