@@ -329,6 +329,8 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     if (only_deferred && !(B.flags[g] & 4u)) return;   // second pass: only what the first one deferred
     uint32_t *went = went_all[wid];
     uint16_t *nidx = nidx_all[wid];
+    uint32_t *npos = pk_all[wid];              // node -> window position of its "\n@"; the scanner phase
+                                                // is through before the membership phase reuses the array
 
     const int own0 = g * OWN_T;
     const int own1 = min(own0 + OWN_T, L.ntiles);
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         const bool isn = (fl & FL_AT) && offrel == 0;
         if (lane == 0) {
             went[0] = 0u | (fl << WF_SHIFT) | ((isn ? 0u : NO_NODE) << WN_SHIFT);
-            if (isn) nidx[0] = 0;
+            if (isn) { nidx[0] = 0; npos[0] = 0u; }
         }
         ncomp = isn ? 1 : 0;
     }
@@ -432,7 +434,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                 if (j < c) {
                     uint32_t nid = NO_NODE;
                     if ((isn >> i) & 1u) {
-                        if (id < (uint32_t)(NMAX - 1)) { nid = id; nidx[id] = (uint16_t)(tb[k] + j); }
+                        if (id < (uint32_t)(NMAX - 1)) {
+                            nid = id; nidx[id] = (uint16_t)(tb[k] + j); npos[id] = relb + (x[i] & OFF_MASK);
+                        }
                         id++;
                     }
                     went[tb[k] + j] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | (nid << WN_SHIFT);
@@ -472,7 +476,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                     if (j < c) {
                         uint32_t nid = NO_NODE;
                         if ((isn >> i) & 1u) {
-                            if (id < (uint32_t)(NMAX - 1)) { nid = id; nidx[id] = (uint16_t)(base + j); }
+                            if (id < (uint32_t)(NMAX - 1)) {
+                                nid = id; nidx[id] = (uint16_t)(base + j); npos[id] = relb + (x[i] & OFF_MASK);
+                            }
                             id++;
                         }
                         went[base + j] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | (nid << WN_SHIFT);
@@ -515,40 +521,57 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         const int k = nidx[c];
         bool done = false;
         if (k + 12 < nwin) {
-            // fast path: the 12 entries after the candidate, read independently
-            uint32_t w[13];
+            // fast path: the entries after the candidate, read independently, and the positions
+            // of the next three nodes (every "\n@" of the own range is a node, so the successor
+            // -- the first "\n@" at >= qe - 1 -- is almost always one of them: three reads from
+            // consecutive addresses instead of a search through nine entries)
+            uint32_t w[10];
 #pragma unroll
-            for (int i = 0; i < 13; i++) w[i] = went[k + i];
+            for (int i = 0; i < 10; i++) w[i] = went[k + i];
+            const uint32_t w12 = went[k + 12];
+            uint32_t np[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) np[q] = npos[min(c + 1 + q, NMAX - 1)];
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                if (c + 1 + q >= ncomp) np[q] = 0xFFFFFFFEu;          // no such node: never >= qe - 1
             const uint32_t r0 = w[0] & WP_MASK, r1 = w[1] & WP_MASK;
-            if (wpos0 + (int64_t)(w[12] & WP_MASK) + 4 < len) {
+            if (wpos0 + (int64_t)(w12 & WP_MASK) + 4 < len) {
                 uint32_t plusmask = 0;
 #pragma unroll
                 for (int i = 2; i <= 9; i++)
                     if (((w[i] >> WF_SHIFT) & FL_PLUS) && (w[i] & WP_MASK) >= r1 + 2) plusmask |= 1u << i;
                 if (plusmask) {
                     const int mi = __ffs((int)plusmask) - 1;
-                    uint32_t r3 = 0, rm1 = 0;
-#pragma unroll
-                    for (int i = 2; i <= 10; i++) {
-                        if (i == mi) r3 = w[i] & WP_MASK;
-                        if (i == mi + 1) rm1 = w[i] & WP_MASK;
-                    }
+                    const uint32_t r3 = went[k + mi] & WP_MASK, rm1 = went[k + mi + 1] & WP_MASK;
                     const bool invalid = (rm1 - r3 - 1 > 1) && (rm1 - r3 != r1 - r0);
                     const uint32_t qe = rm1 + 1 + r3 - r1 - 1;
+                    int dn = 0;                       // successor = node c + dn (0: not among the next three)
+                    if (np[2] != 0xFFFFFFFEu && np[2] + 1 >= qe) dn = 3;
+                    if (np[1] != 0xFFFFFFFEu && np[1] + 1 >= qe) dn = 2;
+                    if (np[0] != 0xFFFFFFFEu && np[0] + 1 >= qe) dn = 1;
                     if (invalid) {
                         info[u] = SN_STOP | ((uint32_t)(ST_INVALID + 1) << 16);
                         done = true;
+                    } else if (dn) {
+                        info[u] = (uint32_t)(c + dn) | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
+                                  (15u << 25) | (1u << 29);
+                        done = true;
                     } else {
+                        // the successor is not an own node (it lies in the look-ahead tile: the last
+                        // records of the group) or more than three candidates away
                         uint32_t atmask = 0;
+                        uint32_t wj = 0;
 #pragma unroll
-                        for (int j = 4; j <= 12; j++)
-                            if (((w[j] >> WF_SHIFT) & FL_AT) && (w[j] & WP_MASK) + 1 >= qe && j >= mi + 2)
+                        for (int j = 12; j >= 4; j--) {
+                            const uint32_t x = went[k + j];
+                            if (((x >> WF_SHIFT) & FL_AT) && (x & WP_MASK) + 1 >= qe && j >= mi + 2) {
                                 atmask |= 1u << j;
+                                wj = x;                       // ends up as the lowest qualifying j
+                            }
+                        }
                         if (atmask) {
                             const int j = __ffs((int)atmask) - 1;
-                            uint32_t wj = 0;
-#pragma unroll
-                            for (int i = 4; i <= 12; i++) if (i == j) wj = w[i];
                             const uint32_t nid = (wj >> WN_SHIFT) & WN_MASK;
                             const uint32_t nx = (k + j < own_hi && nid != NO_NODE) ? nid : SN_AHEAD;
                             info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
