@@ -130,6 +130,34 @@ def host_inclusive(ctx, sample_u8, flags):
             "sample": "ffq_scan_host over the first %d bytes, pageable host memory in and out" % sample_u8.size}
 
 
+def stream_inclusive(ctx, sample_u8):
+    """File in, offset table out through the native stream front end (ffq_stream_*): chunked
+    reads into pinned memory overlapped with H2D + scan + D2H.  The file sits in /dev/shm (page
+    cache speed, no disk); like `host_inclusive` this is never `value`."""
+    import tempfile
+    from fastqandfurious_amd import hip
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(d, "ffq_bench_%d.fq" % os.getpid())
+    with open(path, "wb") as fh:
+        fh.write(sample_u8.tobytes())
+    try:
+        best, recs = None, 0
+        for _ in range(3):
+            fd = os.open(path, os.O_RDONLY)
+            t0 = time.perf_counter()
+            st = hip.FileStream(ctx, fd, 1 << 24)
+            recs = sum(rows.shape[0] for rows, _f, _o, _e, _x in st)
+            st.close()
+            os.close(fd)
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+    finally:
+        os.unlink(path)
+    return {"value": round(sample_u8.size / best / 1e9, 3), "unit": "GB/s",
+            "m_reads_per_s": round(recs / best / 1e6, 3),
+            "sample": "ffq_stream over a %d-byte file in %s, 16 MiB chunks, best of 3" % (sample_u8.size, d)}
+
+
 def pmc_traffic(workload):
     """HBM bytes per k_scan_lines launch from the committed rocprofv3 PMC passes of this
     workload (profiles/*/pmc_fetch_write.json): FETCH_SIZE and WRITE_SIZE are KiB; on gfx950
@@ -392,6 +420,7 @@ def main():
             line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(sample[:64 << 20], args.cpu_seconds / 2)
             line["cpu_baseline"]["python_iterator"] = cpu_iterator_rate(sample.tobytes(), 3.0)
             line["host_inclusive"] = host_inclusive(ctx, sample, flags)
+            line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, sample)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

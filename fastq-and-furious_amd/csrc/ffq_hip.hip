@@ -1028,3 +1028,5 @@ extern "C" int ffq_selftest(ffq_ctx *c)
     if (hb) return fail(FFQ_E_INTERNAL, "device self-test: %u mismatches (wave scan / newline mask)", hb);
     return FFQ_OK;
 }
+
+#include "ffq_stream.h"

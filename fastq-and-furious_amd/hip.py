@@ -39,7 +39,7 @@ SYMBOLS = (
     "ffq_pinned_alloc", "ffq_pinned_free", "ffq_copy_h2d", "ffq_copy_d2h", "ffq_sync",
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
-    "ffq_table_select_seqlen", "ffq_table_cut",
+    "ffq_table_select_seqlen", "ffq_table_cut", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
 )
@@ -117,6 +117,10 @@ def lib():
         L.ffq_table_lower_bound.argtypes = [vp, vp, i64, i32, i64, P(i64)]
         L.ffq_table_select_seqlen.argtypes = [vp, vp, i64, i64, i64, vp, P(i64)]
         L.ffq_table_cut.argtypes = [vp, vp, i64, i64, i64, P(i64)]
+        L.ffq_stream_open.argtypes = [vp, i32, i64, P(vp)]
+        L.ffq_stream_next.argtypes = [vp, P(vp), P(i64), P(i32), P(i64), P(vp), P(i64), P(i64)]
+        L.ffq_stream_close.argtypes = [vp]
+        L.ffq_stream_close.restype = None
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
         L.ffq_synth_wrapped_size.argtypes = [i64, u64]
         L.ffq_synth_wrapped_size.restype = i64
@@ -322,6 +326,45 @@ class Context:
     def synth_wrapped(self, dptr, d_start, first, count, seed=43):
         check(lib().ffq_synth_wrapped(self.handle, ctypes.c_void_p(dptr), ctypes.c_void_p(d_start),
                                       int(first), int(count), int(seed)))
+
+
+class FileStream:
+    """The native stream front end (ffq_stream_*): buffer fills of a file descriptor, read ahead
+    into pinned memory while the previous fill is scanned.  Iterating yields
+    (rows, fill, fill_offset, end_state, err_offset): `rows` int64[n][6] absolute offsets and
+    `fill` (uint8 array, fill[i] = stream byte fill_offset + i) are views of memory the stream
+    owns -- valid until the next iteration step."""
+
+    def __init__(self, ctx, fd, fbufsize=1 << 24):
+        self._ctx = ctx
+        self._h = ctypes.c_void_p()
+        check(lib().ffq_stream_open(ctx.handle, int(fd), int(fbufsize), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().ffq_stream_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __iter__(self):
+        rows_p, fill_p = ctypes.c_void_p(), ctypes.c_void_p()
+        n, nb, off, err = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        end = ctypes.c_int32()
+        while True:
+            check(lib().ffq_stream_next(self._h, ctypes.byref(rows_p), ctypes.byref(n), ctypes.byref(end),
+                                        ctypes.byref(err), ctypes.byref(fill_p), ctypes.byref(nb), ctypes.byref(off)))
+            rows = (np.ctypeslib.as_array((ctypes.c_int64 * (n.value * 6)).from_address(rows_p.value)).reshape(-1, 6)
+                    if n.value else np.zeros((0, 6), dtype=np.int64))
+            fill = (np.ctypeslib.as_array((ctypes.c_uint8 * nb.value).from_address(fill_p.value))
+                    if nb.value else np.zeros(0, dtype=np.uint8))
+            yield rows, fill, off.value, end.value, err.value
+            if end.value != END_REFILL:
+                return
 
 
 _default_ctx = {}

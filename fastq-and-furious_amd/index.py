@@ -20,6 +20,20 @@ from . import fastqandfurious as _F
 ROW_BYTES = 48          # 6 x int64 per record
 
 
+def _fileno(fh):
+    """File descriptor of a real, unbuffered-position-safe binary file object, else None."""
+    try:
+        fd = fh.fileno()
+    except (AttributeError, OSError, ValueError):
+        return None
+    try:
+        import os
+        os.lseek(fd, fh.tell(), os.SEEK_SET)         # the descriptor follows the object's position
+    except (OSError, ValueError, AttributeError):
+        return None
+    return fd
+
+
 def iter_tables(fh, fbufsize, scan_buffer):
     """One (buf, rows, globaloffset) per buffer fill: `rows` is an array('q') of 6*n
     buffer-relative positions, `rows[i] + globaloffset` the absolute ones.  Same refill,
@@ -54,6 +68,23 @@ def build_index(fh, fh_index, fbufsize=1 << 24, entrypos=None):
     if entrypos is None:
         from . import _fastqandfurious
         entrypos = _fastqandfurious.entrypos
+        fd = _fileno(fh)
+        if fd is not None:
+            # a real file and the GPU scanner: the native stream front end (ffq_stream_*) reads
+            # ahead into pinned memory and hands back whole tables; no per-fill Python copies
+            from . import hip
+            n = 0
+            st = hip.FileStream(hip.default_context(), fd, fbufsize)
+            try:
+                for rows, _fill, _off, end_state, err in st:
+                    if rows.shape[0]:
+                        fh_index.write(memoryview(rows).cast("B"))
+                        n += rows.shape[0]
+                    if end_state not in (_F._END_OK, _F._END_REFILL):
+                        _F._raise_for_end(end_state, err)
+            finally:
+                st.close()
+            return n
     scan_buffer = getattr(entrypos, 'scan_buffer', None)
     n = 0
     if scan_buffer is None:

@@ -195,6 +195,23 @@ int ffq_table_cut(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t 
 int ffq_table_select_seqlen(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t min_len,
                             int64_t max_len, int64_t *d_out, int64_t *n_out);
 
+/* ---- stream front end (reference: read(), fastqandfurious.py:30-36, and the refill loop of
+ * readfastq_iter, :241-279, natively over a file descriptor) ---------------------------------
+ * Chunks of fbufsize bytes are read into pinned memory; the read of the next chunk overlaps the
+ * copy and the scan of the current buffer fill.  ffq_stream_next returns the rows of ONE fill:
+ * absolute stream offsets (what entryfunc_abspos yields, :186-195), in pinned memory owned by
+ * the stream and valid until the next call, together with the fill's bytes
+ * (h_bytes[i] is stream offset bytes_offset + i).  end_state: FFQ_END_REFILL while more
+ * follows, FFQ_END_OK with the last fill, FFQ_END_ERR_* (+ err_offset, the byte the reference's
+ * ValueError names) when the stream is malformed.  The descriptor is read from its current
+ * position (pread when it can seek) and is not closed.                                          */
+typedef struct ffq_stream ffq_stream;
+int  ffq_stream_open(ffq_ctx *ctx, int fd, int64_t fbufsize, ffq_stream **out);
+int  ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n_rows, int *end_state,
+                     int64_t *err_offset, const uint8_t **h_bytes, int64_t *n_bytes,
+                     int64_t *bytes_offset);
+void ffq_stream_close(ffq_stream *s);
+
 /* ---- synthetic FASTQ generators (bench / test inputs) -----
  * Counter-based (splitmix64), so the numpy generator in
  * fastq-and-furious_amd/synth.py produces the same bytes.

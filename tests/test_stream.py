@@ -1,0 +1,138 @@
+"""The native stream front end (ffq_stream_*: reference read() + the refill loop of
+readfastq_iter, src/fastqandfurious.py:30-36, :241-279) against the golden runs of the
+reference iterator: same rows, same slices, same error texts, at every buffer size."""
+import hashlib
+import io
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import golden_file
+
+pytestmark = pytest.mark.gpu
+FILES = ("test.fq", "test_longqualityheader.fq", "test_multiline.fq")
+
+
+@pytest.fixture(scope="module")
+def mods(pkg, gpu_ctx):
+    from fastqandfurious_amd import fastqandfurious as F, hip, index
+    return F, hip, index
+
+
+def run_stream(mods, gpu_ctx, fd, bufsize):
+    """(rows, tuples, error text) of a whole stream"""
+    F, hip, _ = mods
+    rows, tuples, err = [], [], None
+    st = hip.FileStream(gpu_ctx, fd, bufsize)
+    try:
+        for t, fill, off, end_state, err_off in st:
+            for r in t.tolist():
+                rows.append(r)
+                p = [x - off for x in r]
+                b = fill.tobytes()
+                tuples.append([b[p[0] + 1:p[1]].hex(), b[p[2]:p[3]].hex(), b[p[4]:p[5]].hex()])
+            if end_state not in (hip.END_OK, hip.END_REFILL):
+                try:
+                    F._raise_for_end(end_state, err_off)
+                except ValueError as e:
+                    err = str(e)
+    finally:
+        st.close()
+    return rows, tuples, err
+
+
+def with_file(tmp_path, data, fn):
+    path = str(tmp_path / "in.fq")
+    with open(path, "wb") as fh:
+        fh.write(data)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        return fn(fd)
+    finally:
+        os.close(fd)
+
+
+@pytest.mark.parametrize("fn", FILES)
+@pytest.mark.parametrize("bufsize", (100, 200, 600, 700, 65536))
+def test_stream_golden_files(mods, gpu_ctx, golden, tmp_path, fn, bufsize):
+    rows, tuples, err = with_file(tmp_path, golden_file(fn), lambda fd: run_stream(mods, gpu_ctx, fd, bufsize))
+    assert err is None
+    assert rows == golden["files"][fn]["bufsizes"]["65536"]["c"]["rows"]
+    assert tuples == golden["files"][fn]["tuples"]
+
+
+def test_stream_edge_corpus(mods, gpu_ctx, golden, tmp_path):
+    """rows and ValueError texts of the reference iterator (C scanner) on the edge corpus"""
+    n = 0
+    for name, ent in golden["edge"].items():
+        data = bytes.fromhex(ent["data"])
+        for bs, run in ent["runs"].items():
+            want = run["c"]
+            if want.get("hang") or want.get("skipped"):
+                continue
+            rows, _, err = with_file(tmp_path, data, lambda fd: run_stream(mods, gpu_ctx, fd, int(bs)))
+            assert rows == want["rows"], (name, bs)
+            assert err == want["error"], (name, bs)
+            n += 1
+    assert n > 40
+
+
+def test_stream_synthetic_chunks_and_index(mods, gpu_ctx, oracle, golden, tmp_path, pkg):
+    F, hip, index = mods
+    from fastqandfurious_amd import synth
+    blob = synth.single(0, 60000, seed=42).tobytes()          # 19 MB
+    want, *_ = oracle.scan(blob)
+    for bs in (1 << 20, (1 << 22) + 37, 1 << 25):
+        rows, _, err = with_file(tmp_path, blob, lambda fd: run_stream(mods, gpu_ctx, fd, bs))
+        assert err is None and np.array_equal(np.array(rows, dtype=np.int64), want)
+    # build_index over a real file takes the native stream: same bytes as the reference's index
+    small = synth.single(0, 2000, seed=42).tobytes()
+    path = str(tmp_path / "s.fq")
+    open(path, "wb").write(small)
+    fi = io.BytesIO()
+    with open(path, "rb") as fh:
+        assert index.build_index(fh, fi, 1 << 16) == 2000
+    assert hashlib.sha256(fi.getvalue()).hexdigest() == golden["index"]["synth_single_2000"]["sha256"]
+    for fn in FILES:
+        p2 = str(tmp_path / fn)
+        open(p2, "wb").write(golden_file(fn))
+        fi = io.BytesIO()
+        with open(p2, "rb") as fh:
+            index.build_index(fh, fi, 600)
+        assert fi.getvalue().hex() == golden["index"][fn]["index_hex"]
+
+
+def test_stream_long_record_grows_the_carry(mods, gpu_ctx, oracle, tmp_path):
+    """a record longer than the chunk and than the initial 1 MiB carry space"""
+    rng = np.random.default_rng(3)
+    L = 3 << 20
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L).tobytes()
+    qual = rng.choice(np.frombuffer(bytes(range(35, 74)), dtype=np.uint8), size=L).tobytes()
+    data = b"@a\nACGT\n+\nIIII\n@long\n" + seq + b"\n+\n" + qual + b"\n@b\nAC\n+\nII\n"
+    want, *_ = oracle.scan(data)
+    rows, _, err = with_file(tmp_path, data, lambda fd: run_stream(mods, gpu_ctx, fd, 1 << 18))
+    assert err is None and np.array_equal(np.array(rows, dtype=np.int64), want)
+
+
+def test_stream_pipe_and_empty(mods, gpu_ctx, golden, tmp_path):
+    """a descriptor that cannot seek (read() instead of pread()); an empty file"""
+    data = golden_file("test.fq") * 50
+    r, w = os.pipe()
+
+    def feed():
+        with os.fdopen(w, "wb") as fh:
+            for i in range(0, len(data), 777):
+                fh.write(data[i:i + 777])
+    t = threading.Thread(target=feed)
+    t.start()
+    try:
+        rows, tuples, err = run_stream(mods, gpu_ctx, r, 4096)
+    finally:
+        os.close(r)
+        t.join()
+    assert err is None and len(rows) == 200
+    assert tuples[:4] == golden["files"]["test.fq"]["tuples"]
+    rows, _, err = with_file(tmp_path, b"", lambda fd: run_stream(mods, gpu_ctx, fd, 4096))
+    assert rows == [] and err is None
