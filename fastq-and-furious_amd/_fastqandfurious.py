@@ -92,6 +92,14 @@ class _GpuEntrypos:
         self._next_offset = None        # the chain has ended: rescan on the next call
         return status
 
+    # -- stream protocol: a real file is read, carried and scanned by the library itself -------
+    def open_stream(self, fh, fbufsize):
+        from .index import _fileno
+        fd = _fileno(fh)
+        if fd is None:
+            return None
+        return _hip.FileStream(self._context(), fd, fbufsize)
+
     # -- batched protocol used by this package's readfastq_iter ------------
     def scan_buffer(self, buf, offset, eof):
         table, res = self._context().scan_host(buf, sentinel=False, offset=offset, eof=eof, add=0)

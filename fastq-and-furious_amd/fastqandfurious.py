@@ -189,6 +189,25 @@ def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
         offset = 0
 
 
+def _iter_stream(st, entryfunc):
+    """readfastq_iter over the native stream front end (ffq_stream_*): the library reads the
+    file (ahead, into pinned memory), scans every buffer fill and hands back the rows; this loop
+    only builds the entries.  `buf` is the fill as bytes and `pos` its buffer-relative positions,
+    exactly what the reference's loop passes to entryfunc (:252-255), globaloffset included."""
+    try:
+        for rows, fill, fill_offset, end_state, err_offset in st:
+            if rows.shape[0]:
+                buf = fill.tobytes()
+                rel = array('q')
+                rel.frombytes((rows - fill_offset).tobytes())
+                for i in range(0, len(rel), 6):
+                    yield entryfunc(buf, rel[i:i + 6], fill_offset)
+            if end_state != _END_OK and end_state != _END_REFILL:
+                _raise_for_end(end_state, err_offset)
+    finally:
+        st.close()
+
+
 def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
                    entryfunc: typing.Callable = entryfunc,
                    entrypos: typing.Callable = entrypos,
@@ -205,6 +224,12 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
     entry met after the end of the stream raises 'Entry is invalid at byte'
     (the reference never leaves its loop, :256-270).
     """
+    open_stream = getattr(entrypos, 'open_stream', None)
+    if open_stream is not None:
+        st = open_stream(fh, fbufsize)           # None unless fh is a real file
+        if st is not None:
+            yield from _iter_stream(st, entryfunc)
+            return
     scan_buffer = getattr(entrypos, 'scan_buffer', None)
     if scan_buffer is not None:
         yield from _iter_batched(fh, fbufsize, entryfunc, scan_buffer)

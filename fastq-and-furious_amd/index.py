@@ -22,6 +22,11 @@ ROW_BYTES = 48          # 6 x int64 per record
 
 def _fileno(fh):
     """File descriptor of a real, unbuffered-position-safe binary file object, else None."""
+    import io
+    # only plain files: a GzipFile also has a fileno() -- that of the COMPRESSED file
+    raw = fh.raw if isinstance(fh, io.BufferedReader) else fh
+    if not isinstance(raw, io.FileIO):
+        return None
     try:
         fd = fh.fileno()
     except (AttributeError, OSError, ValueError):

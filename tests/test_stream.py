@@ -136,3 +136,48 @@ def test_stream_pipe_and_empty(mods, gpu_ctx, golden, tmp_path):
     assert tuples[:4] == golden["files"]["test.fq"]["tuples"]
     rows, _, err = with_file(tmp_path, b"", lambda fd: run_stream(mods, gpu_ctx, fd, 4096))
     assert rows == [] and err is None
+
+
+@pytest.mark.parametrize("fn", FILES)
+@pytest.mark.parametrize("bufsize", (100, 600, 65536))
+def test_iterator_over_real_files_takes_the_stream(mods, gpu_ctx, golden, tmp_path, fn, bufsize, monkeypatch):
+    """readfastq_iter(open(path, 'rb'), ..., GPU scanner): same entries, and it IS the native
+    stream that produced them (the per-fill Python path is made to fail)"""
+    F, hip, _ = mods
+    from fastqandfurious_amd import _fastqandfurious as C
+    path = str(tmp_path / fn)
+    open(path, "wb").write(golden_file(fn))
+
+    def boom(*a, **k):
+        raise AssertionError("the Python buffer loop must not run for a real file")
+    monkeypatch.setattr(F, "_iter_batched", boom)
+    with open(path, "rb") as fh:
+        got = [[h.hex(), s.hex(), q.hex()] for h, s, q in F.readfastq_iter(fh, bufsize, F.entryfunc, C.entrypos)]
+    assert got == golden["files"][fn]["tuples"]
+    with open(path, "rb") as fh:
+        rows = [list(p) for p in F.readfastq_iter(fh, bufsize, F.entryfunc_abspos, C.entrypos)]
+    assert rows == golden["files"][fn]["bufsizes"]["65536"]["c"]["rows"]
+    with open(path, "rb") as fh:
+        fh.seek(0)
+        ents = list(F.readfastq_iter(fh, bufsize, F.entryfunc_namedtuple, C.entrypos))
+    assert [e.sequence.hex() for e in ents] == [t[1] for t in golden["files"][fn]["tuples"]]
+
+
+def test_iterator_errors_over_real_files(mods, gpu_ctx, golden, tmp_path):
+    F, hip, _ = mods
+    from fastqandfurious_amd import _fastqandfurious as C
+    n = 0
+    for name, ent in golden["edge"].items():
+        want = ent["runs"]["100"]["c"]
+        if want.get("hang") or want.get("skipped") or want["error"] is None:
+            continue
+        path = str(tmp_path / "e.fq")
+        open(path, "wb").write(bytes.fromhex(ent["data"]))
+        rows = []
+        with open(path, "rb") as fh:
+            with pytest.raises(ValueError) as ei:
+                for p in F.readfastq_iter(fh, 100, F.entryfunc_abspos, C.entrypos):
+                    rows.append(list(p))
+        assert str(ei.value) == want["error"] and rows == want["rows"], name
+        n += 1
+    assert n >= 5
