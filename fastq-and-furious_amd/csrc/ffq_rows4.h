@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
     }
     // the sentinel is entry -1 of tile 0 (ordinal 0): give tile 0 a list that starts with it
     const int pre = (t == 0 && L.s) ? 1 : 0;
+    if (c + pre == 0 && t != 0) return;   // no newline in the tile (long reads): no record starts here
     const long long obl = ob - pre;                                    // ordinal of list element 0
     const int64_t tbase = ((int64_t)t << TILE_SHIFT) + L.s;            // buffer coordinate of tile offset 0
     if (j0 < 0) {
