@@ -49,6 +49,7 @@ constexpr uint16_t NM_EXT = 0xFFFF;
 constexpr uint16_t UNMARKED = 0xFFFF;
 
 constexpr int64_t Y_NOCAND = -1, X_END_TERM = -2, Y_UNRES = -3, X_END_FINAL = -4;
+constexpr int64_t FORCE_NONE = -1;
 
 constexpr int RES_BLOCK = 1024;            // groups per k_resolve_a workgroup
 
@@ -73,6 +74,7 @@ struct ChainBufs {
     int64_t *qloc;       // [ng] same for qb
     int64_t *part;       // [nblk][4] block totals (cnt, qb, lines, -) -> exclusive prefixes
     int32_t *mins;       // [2] first terminating group, first bad group
+    int64_t *force;      // [ng] repair pass: the "\n@" the chain enters the group with (FORCE_NONE: leave alone)
     unsigned long long *prof;   // optional: per-phase cycle sums of k_chain_wave (diagnostics)
     int32_t nmax;
     int32_t ng;
@@ -82,7 +84,8 @@ struct DevRes {
     int64_t n_records, n_qual_bytes, n_lines, end_offset;
     int64_t last_pos[6];
     int32_t last_status, end_state, fallback, term_group;
-    int32_t has_final, pad;
+    int32_t has_final;
+    int32_t bad_group;   // first group whose guess was not confirmed (fallback only; 0x7F7F7F7F: none)
 };
 
 // Result hand-over.  The last result-writing kernel of a scan copies the result block and the
@@ -326,7 +329,11 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = g0 + blockIdx.x * WPB + wid;
     if (g >= g1) return;                 // no workgroup barrier is used below
-    if (only_deferred && !(B.flags[g] & 4u)) return;   // second pass: only what the first one deferred
+    if (only_deferred == 1 && !(B.flags[g] & 4u)) return;   // second pass: only what the first one deferred
+    // repair pass (only_deferred == 2): only the groups whose guess the verification rejected,
+    // entered where the predecessor's chain says (no run-in speculation)
+    const int64_t fpos = (only_deferred == 2) ? B.force[g] : FORCE_NONE;
+    if (only_deferred == 2 && fpos == FORCE_NONE) return;
     uint32_t *went = went_all[wid];
     uint16_t *nidx = nidx_all[wid];
     uint32_t *npos = pk_all[wid];              // node -> window position of its "\n@"; the scanner phase
@@ -628,6 +635,24 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         }
     }
     if (ablate == 3) { if (lane == 0) B.lines[g] = lines + info[0]; return; }
+    int e_forced = -1;
+    if (fpos != FORCE_NONE) {
+        if (fpos >= ((int64_t)own1 << TILE_SHIFT) + L.s) {
+            // the chain passes over this group (one record spans it): no members, same exit
+            if (lane == 0) {
+                B.y[g] = fpos; B.exit[g] = fpos; B.cnt[g] = 0; B.qb[g] = 0; B.flags[g] = 0; B.lines[g] = lines;
+            }
+            return;
+        }
+        const uint32_t frel = (uint32_t)(fpos - wpos0);
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int c = u * 64 + lane;
+            const unsigned long long hit = __ballot(c < ncomp && npos[c] == frel);
+            if (hit) e_forced = u * 64 + (__ffsll((long long)hit) - 1);
+        }
+        if (e_forced >= 0) n_runin = e_forced;       // nothing in front of it belongs to the chain
+    }
     if (prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[4] = clock64(); }
     // ---- chain membership ---------------------------------------------------------------------
     // Node ids are in position order and a successor always lies further on, so a
@@ -656,9 +681,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             if (NS[u]) later = u * 64 + (__ffsll((long long)NS[u]) - 1);
         }
     }
-    int e0 = 0, lastn = -1;
-    bool unresolved = false, too_many_jumps = false;
-    for (int attempt = 0; attempt < 4 && ncomp > 0; attempt++) {
+    int e0 = (e_forced >= 0) ? e_forced : 0, lastn = -1;
+    bool unresolved = (fpos != FORCE_NONE && e_forced < 0), too_many_jumps = false;
+    for (int attempt = 0; attempt < 4 && ncomp > 0 && !unresolved; attempt++) {
         if (lane < 2 * (NMAX / 32)) bits_all[wid][lane] = 0u;
         wave_sync();
         // serial part: one LDS read per run; run [cur, r] recorded as a start bit and an end bit
@@ -933,6 +958,22 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve_a(ChainBufs B)
     }
 }
 
+// k_repair_mark: which groups a repair pass re-runs and where they are entered.  A group whose
+// entry guess differs from its predecessor's exit (or that could not settle on one) is re-run
+// from that exit.  The first such group is then exact (everything in front of it is verified);
+// the later ones are exact if their predecessors were -- the next verification decides.
+__global__ void k_repair_mark(ChainBufs B)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B.ng) return;
+    int64_t f = FORCE_NONE;
+    if (g > 0 && !(B.flags[g] & 5u)) {
+        const int64_t pe = B.exit[g - 1], y = B.y[g];
+        if (pe >= 0 && y != pe) f = pe;
+    }
+    B.force[g] = f;
+}
+
 __global__ __launch_bounds__(1024) void k_resolve_b(ChainBufs B, int nblk, int eof, int64_t offset,
                                                     int64_t add, DevRes *res)
 {
@@ -963,6 +1004,7 @@ __global__ __launch_bounds__(1024) void k_resolve_b(ChainBufs B, int nblk, int e
         const bool fallback = (tterm >= B.ng) || (tbad <= tterm);     // mins start at 0x7F7F7F7F
         res->n_lines = carry_l;
         res->fallback = fallback ? 1 : 0;
+        res->bad_group = tbad;
         res->term_group = fallback ? -1 : tterm;
         res->end_offset = offset;
         res->has_final = 0;

@@ -47,6 +47,7 @@ struct ScanState {
     bool active = false;
     ScanArgs a{};
     int retries = 0;
+    int repairs = 0;          // repair passes of the general kernels (reported with retries)
     bool dense_cfg = false, fast4_failed = false;
     int stage = 0;            // what the pending front consisted of: 1 fast four-line path, 2 general path
     int64_t ntiles = 0;
@@ -180,6 +181,7 @@ static void free_chain(ffq_ctx *c)
     (void)hipFree(c->cb.y); (void)hipFree(c->cb.exit); (void)hipFree(c->cb.cnt); (void)hipFree(c->cb.flags);
     (void)hipFree(c->cb.lines); (void)hipFree(c->cb.qb); (void)hipFree(c->cb.term); (void)hipFree(c->cb.stage);
     (void)hipFree(c->cb.rloc); (void)hipFree(c->cb.qloc); (void)hipFree(c->cb.part); (void)hipFree(c->cb.mins);
+    (void)hipFree(c->cb.force);
     (void)hipFree(c->sbbase); (void)hipFree(c->tinfo4);
     (void)hipFree(c->tileq); (void)hipFree(c->sbq); (void)hipFree(c->sbqbase);
     c->sbbase = nullptr; c->tinfo4 = nullptr;
@@ -251,6 +253,7 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
     HIPCHK(hipMalloc((void **)&c->cb.qloc, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.part, (size_t)nblk * 4 * 8));
     HIPCHK(hipMalloc((void **)&c->cb.mins, 16));
+    HIPCHK(hipMalloc((void **)&c->cb.force, (size_t)ng * 8));
     {
         const int64_t nsb = (ntiles + SB_TILES - 1) / SB_TILES;
         HIPCHK(hipMalloc((void **)&c->sbbase, (size_t)nsb * sizeof(long long)));
@@ -422,12 +425,51 @@ static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st, bool t
 static Pub make_pub(ffq_ctx *c) { return Pub{c->ctl, c->hm_ctl, c->hm_res}; }
 static Pub no_pub(ffq_ctx *c) { return Pub{c->ctl, nullptr, nullptr}; }
 
+// verification + scan of the group counts, rows, result block (publishes) [-> decode]
+static int enqueue_resolve(ffq_ctx *c, const ScanArgs &a, const ChainBufs &cb, bool timed)
+{
+    const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
+    int64_t *qoff = decode ? a.d_qoff : nullptr;
+    hipStream_t sA = c->stream;
+    const int ngroups = cb.ng;
+    const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
+    HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sA));
+    hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sA, cb);
+    hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sA, cb, nblk, a.eof, a.offset, a.add, c->dres);
+    hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sA, cb, (const DevRes *)c->dres, a.add, a.d_table,
+                       a.table_cap, qoff, c->qdir, c->qdir_cap);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sA, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff,
+                       make_pub(c));
+    c->ctl_clean = true;
+    if (decode) enqueue_decode(c, a, sA, timed);
+    return FFQ_OK;
+}
+
+// repair pass: the groups whose entry guess the verification rejected are re-run from their
+// predecessor's exit (k_repair_mark), then everything is verified again
+static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups)
+{
+    ChainBufs cb = c->cb;
+    cb.ng = ngroups;
+    cb.nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
+    cb.prof = nullptr;
+    hipStream_t sA = c->stream;
+    hipLaunchKernelGGL(k_repair_mark, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, sA, cb);
+    if (!dense_cfg)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
+                           dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
+                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 2, 0);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
+                           dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
+                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 2, 0);
+    return enqueue_resolve(c, a, cb, false);
+}
+
 // general path: chain summaries -> resolve -> expand -> finalize (publishes) [-> decode]
 static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups,
                            bool timed = false)
 {
-    const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
-    int64_t *qoff = decode ? a.d_qoff : nullptr;
     const int nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
     int rc = reserve_stage(c, ngroups, nmax);
     if (rc) return rc;
@@ -443,7 +485,6 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
         HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sA));
         cb.prof = c->prof_d;
     }
-    const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
     HIPCHK(hipMemsetAsync(cb.flags, 0, (size_t)ngroups * 4, sA));
     if (!dense_cfg)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
@@ -453,16 +494,7 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
                            dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
-    HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sA));
-    hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sA, cb);
-    hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sA, cb, nblk, a.eof, a.offset, a.add, c->dres);
-    hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sA, cb, (const DevRes *)c->dres, a.add, a.d_table,
-                       a.table_cap, qoff, c->qdir, c->qdir_cap);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sA, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff,
-                       make_pub(c));
-    c->ctl_clean = true;
-    if (decode) enqueue_decode(c, a, sA, timed);
-    return FFQ_OK;
+    return enqueue_resolve(c, a, cb, timed);
 }
 
 // front of a scan: everything on ONE in-order stream (the context's), no host synchronisation
@@ -641,6 +673,27 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             fill_result(res, *c->h_res, 0, st.retries);
             return FFQ_OK;
         }
+        // a guess the verification rejected is repaired, not escalated: the rejected groups are
+        // re-run from their predecessor's exit and everything is verified again.  Every round
+        // makes the first rejected group exact, so the first bad group moves forward; a round
+        // that does not move it (a group that does not fit the kernel at all) ends the repairs.
+        if (!serial && !(getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) && !getenv("FFQ_NO_REPAIR")) {
+            int prev_bad = -1;
+            for (int round = 0; round < 16 && c->h_res->fallback && c->h_res->bad_group > prev_bad &&
+                                c->h_res->bad_group < st.ngroups; round++) {
+                prev_bad = c->h_res->bad_group;
+                HIPCHK(hipEventRecord(c->ev[4], sA));
+                int rc = enqueue_repair(c, a, L, st.dense_cfg, st.ngroups);
+                if (rc) return rc;
+                HIPCHK(hipEventRecord(c->ev[2], sA));
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventSynchronize(c->ev[2]));
+                HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[2]));
+                res->ms_chain += ms; res->ms_total += ms;
+                st.repairs++;
+                if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
+            }
+        }
         if (!serial && c->h_res->fallback && !st.dense_cfg) {
             // second tier: the same kernels with the LDS budget for short lines / short records
             st.dense_cfg = true;
@@ -662,7 +715,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             res->ms_chain += ms;
             res->ms_total += ms;
         }
-        fill_result(res, *c->h_res, path, st.retries);
+        fill_result(res, *c->h_res, path, st.retries + st.repairs);
         break;
     }
     if (res->n_records > a.table_cap)

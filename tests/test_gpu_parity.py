@@ -474,3 +474,17 @@ def test_differential_mess(gpu_ctx, hipmod, oracle, chain_path, seed):
     cut = len(data) // 3
     for kw in (dict(offset=cut), dict(eof=False), dict(sentinel=False, offset=7, eof=False)):
         check_same(gpu_ctx, oracle, data[:len(data) - 11], **kw)
+
+
+@pytest.mark.parametrize("L", (1000, 3000))
+def test_wrapped_kilobase_records_are_repaired_not_serialised(gpu_ctx, oracle, L):
+    """Records of a few KB wrapped at 80 columns: a group's 8 KiB run-in holds only a few of
+    them, so some entry guesses are wrong.  The verification must send those groups through a
+    repair pass (entered at the predecessor's exit) instead of giving the buffer to the serial
+    walker -- same rows either way."""
+    rng = np.random.default_rng(L)
+    data = random_records(rng, (6 << 20) // (2 * L), L, L, wrap=80, hdr_hi=10)
+    table, res = check_same(gpu_ctx, oracle, data)
+    assert res.path == 0
+    check_same(gpu_ctx, oracle, data[:-1])
+    check_same(gpu_ctx, oracle, data, offset=len(data) // 2)

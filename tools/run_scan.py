@@ -25,4 +25,4 @@ for i in range(reps):
                               flags=hip.F_DECODE_QUAL if decode else 0,
                               d_qual=qual.data_ptr() if decode else None, qual_cap=qual.numel() if decode else 0,
                               d_qoff=qoff.data_ptr() if decode else None)
-    print("index %.1f us chain %.1f us decode %.1f us total %.1f us path %d n %d" % (res.ms_index * 1e3, res.ms_chain * 1e3, res.ms_decode * 1e3, res.ms_total * 1e3, res.path, res.n_records), flush=True)
+    print("index %.1f us chain %.1f us decode %.1f us total %.1f us path %d retries %d n %d" % (res.ms_index * 1e3, res.ms_chain * 1e3, res.ms_decode * 1e3, res.ms_total * 1e3, res.path, res.retries, res.n_records), flush=True)
