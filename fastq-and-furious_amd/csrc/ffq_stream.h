@@ -25,6 +25,12 @@ struct ffq_stream {
     int64_t *dtab = nullptr;            // rows on the device / in pinned memory
     int64_t *htab = nullptr;
     int64_t tab_cap = 0;
+    uint32_t flags = 0;                 // FFQ_F_DECODE_QUAL: qualities decoded per fill
+    int qual_add = -33;
+    int8_t *dqual = nullptr, *hqual = nullptr;  // decoded stream of the fill (device / pinned)
+    int64_t qual_cap = 0;
+    int64_t *dqoff = nullptr, *hqoff = nullptr; // CSR offsets, tab_cap + 1 entries
+    int64_t last_nq = 0;
     std::future<int64_t> rd;            // read-ahead into hbuf[cur ^ 1] + carry_room
     bool rd_pending = false;
     int cur = 0;
@@ -86,8 +92,12 @@ static void stream_free(ffq_stream *s)
     for (int b = 0; b < 2; b++)
         if (s->hbuf[b]) (void)hipHostFree(s->hbuf[b]);
     if (s->htab) (void)hipHostFree(s->htab);
+    if (s->hqual) (void)hipHostFree(s->hqual);
+    if (s->hqoff) (void)hipHostFree(s->hqoff);
     (void)hipFree(s->dbuf);
     (void)hipFree(s->dtab);
+    (void)hipFree(s->dqual);
+    (void)hipFree(s->dqoff);
     delete s;
 }
 
@@ -101,6 +111,27 @@ static int stream_alloc_tab(ffq_stream *s, int64_t rows)
         hipHostMalloc((void **)&s->htab, (size_t)rows * 48, hipHostMallocDefault) != hipSuccess)
         return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld rows", (long long)rows);
     s->tab_cap = rows;
+    if (s->flags & FFQ_F_DECODE_QUAL) {
+        if (s->hqoff) (void)hipHostFree(s->hqoff);
+        (void)hipFree(s->dqoff);
+        s->hqoff = nullptr; s->dqoff = nullptr;
+        if (hipMalloc((void **)&s->dqoff, (size_t)(rows + 1) * 8) != hipSuccess ||
+            hipHostMalloc((void **)&s->hqoff, (size_t)(rows + 1) * 8, hipHostMallocDefault) != hipSuccess)
+            return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld quality offsets", (long long)rows);
+    }
+    return FFQ_OK;
+}
+
+static int stream_alloc_qual(ffq_stream *s, int64_t bytes)
+{
+    if (bytes <= s->qual_cap) return FFQ_OK;
+    if (s->hqual) (void)hipHostFree(s->hqual);
+    (void)hipFree(s->dqual);
+    s->hqual = nullptr; s->dqual = nullptr; s->qual_cap = 0;
+    if (hipMalloc((void **)&s->dqual, (size_t)bytes) != hipSuccess ||
+        hipHostMalloc((void **)&s->hqual, (size_t)bytes, hipHostMallocDefault) != hipSuccess)
+        return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld decoded bytes", (long long)bytes);
+    s->qual_cap = bytes;
     return FFQ_OK;
 }
 
@@ -123,7 +154,8 @@ static int stream_grow_room(ffq_stream *s, int64_t room, int64_t ahead)
     return FFQ_OK;
 }
 
-extern "C" int ffq_stream_open(ffq_ctx *c, int fd, int64_t fbufsize, ffq_stream **out)
+extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t flags, int qual_add,
+                                ffq_stream **out)
 {
     if (!c || !out || fd < 0 || fbufsize <= 0) return fail(FFQ_E_ARG, "ffq_stream_open: bad argument");
     *out = nullptr;
@@ -131,6 +163,7 @@ extern "C" int ffq_stream_open(ffq_ctx *c, int fd, int64_t fbufsize, ffq_stream 
     ffq_stream *s = new (std::nothrow) ffq_stream();
     if (!s) return fail(FFQ_E_NOMEM, "out of host memory");
     s->c = c; s->fd = fd; s->fbufsize = fbufsize;
+    s->flags = flags & FFQ_F_DECODE_QUAL; s->qual_add = qual_add;
     const off_t at = lseek(fd, 0, SEEK_CUR);
     s->seekable = at != (off_t)-1;
     s->file_pos = s->seekable ? (int64_t)at : 0;
@@ -146,7 +179,22 @@ extern "C" int ffq_stream_open(ffq_ctx *c, int fd, int64_t fbufsize, ffq_stream 
     return FFQ_OK;
 }
 
+extern "C" int ffq_stream_open(ffq_ctx *c, int fd, int64_t fbufsize, ffq_stream **out)
+{
+    return ffq_stream_open2(c, fd, fbufsize, 0, 0, out);
+}
+
 extern "C" void ffq_stream_close(ffq_stream *s) { stream_free(s); }
+
+// decoded qualities of the fill ffq_stream_next has just returned (streams opened with
+// FFQ_F_DECODE_QUAL): int8 stream + CSR offsets (n_rows + 1), pinned, valid until the next call
+extern "C" int ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int64_t **h_qoff, int64_t *n_qual_bytes)
+{
+    if (!s || !h_qual || !h_qoff || !n_qual_bytes) return fail(FFQ_E_ARG, "ffq_stream_quals: NULL argument");
+    if (!(s->flags & FFQ_F_DECODE_QUAL)) return fail(FFQ_E_ARG, "ffq_stream_quals: the stream was opened without FFQ_F_DECODE_QUAL");
+    *h_qual = s->hqual; *h_qoff = s->hqoff; *n_qual_bytes = s->last_nq;
+    return FFQ_OK;
+}
 
 extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n_rows, int *end_state,
                                int64_t *err_offset, const uint8_t **h_bytes, int64_t *n_bytes,
@@ -192,9 +240,15 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
             s->dcap = want;
         }
         HIPCHK(hipMemcpyAsync(s->dbuf, s->hbuf[s->cur] + s->start, (size_t)s->len, hipMemcpyHostToDevice, c->stream));
+        const bool decode = (s->flags & FFQ_F_DECODE_QUAL) != 0;
+        if (decode) {
+            int rc2 = stream_alloc_qual(s, s->len / 2 + 64);      // qualities are at most half of the bytes
+            if (rc2) return rc2;
+        }
         for (int attempt = 0; attempt < 2; attempt++) {
-            rc = ffq_scan_device(c, s->dbuf, s->len, 0, 0, s->fill_eof ? 1 : 0, s->globaloffset, 0, 0, s->dtab,
-                                 s->tab_cap, nullptr, 0, nullptr, &res);
+            rc = ffq_scan_device(c, s->dbuf, s->len, 0, 0, s->fill_eof ? 1 : 0, s->globaloffset, s->flags, s->qual_add,
+                                 s->dtab, s->tab_cap, decode ? s->dqual : nullptr, decode ? s->qual_cap : 0,
+                                 decode ? s->dqoff : nullptr, &res);
             if (rc != FFQ_E_TABLE_FULL) break;
             int rc2 = stream_alloc_tab(s, res.n_records + 1024);
             if (rc2) return rc2;
@@ -202,6 +256,13 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
         if (rc != FFQ_OK) return rc;
         if (res.n_records > 0)
             HIPCHK(hipMemcpyAsync(s->htab, s->dtab, (size_t)res.n_records * 48, hipMemcpyDeviceToHost, c->stream));
+        s->last_nq = 0;
+        if (decode) {
+            s->last_nq = res.n_qual_bytes;
+            if (res.n_qual_bytes > 0)
+                HIPCHK(hipMemcpyAsync(s->hqual, s->dqual, (size_t)res.n_qual_bytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(s->hqoff, s->dqoff, (size_t)(res.n_records + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     *h_rows = s->htab;

@@ -40,6 +40,7 @@ SYMBOLS = (
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
     "ffq_table_select_seqlen", "ffq_table_cut", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
+    "ffq_stream_open2", "ffq_stream_quals",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
 )
@@ -120,6 +121,8 @@ def lib():
         L.ffq_stream_open.argtypes = [vp, i32, i64, P(vp)]
         L.ffq_stream_next.argtypes = [vp, P(vp), P(i64), P(i32), P(i64), P(vp), P(i64), P(i64)]
         L.ffq_stream_close.argtypes = [vp]
+        L.ffq_stream_open2.argtypes = [vp, i32, i64, u32, i32, P(vp)]
+        L.ffq_stream_quals.argtypes = [vp, P(vp), P(vp), P(i64)]
         L.ffq_stream_close.restype = None
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
         L.ffq_synth_wrapped_size.argtypes = [i64, u64]
@@ -335,10 +338,23 @@ class FileStream:
     `fill` (uint8 array, fill[i] = stream byte fill_offset + i) are views of memory the stream
     owns -- valid until the next iteration step."""
 
-    def __init__(self, ctx, fd, fbufsize=1 << 24):
+    def __init__(self, ctx, fd, fbufsize=1 << 24, decode=False, qual_add=-33):
         self._ctx = ctx
         self._h = ctypes.c_void_p()
-        check(lib().ffq_stream_open(ctx.handle, int(fd), int(fbufsize), ctypes.byref(self._h)))
+        self.decode = bool(decode)
+        check(lib().ffq_stream_open2(ctx.handle, int(fd), int(fbufsize), F_DECODE_QUAL if decode else 0,
+                                     int(qual_add), ctypes.byref(self._h)))
+
+    def quals(self):
+        """(qual int8[], qoff int64[n + 1]) of the fill the iteration has just yielded (streams
+        opened with decode=True); views, valid until the next iteration step."""
+        qp, op, nq = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+        check(lib().ffq_stream_quals(self._h, ctypes.byref(qp), ctypes.byref(op), ctypes.byref(nq)))
+        n = self._last_rows
+        qual = (np.ctypeslib.as_array((ctypes.c_int8 * nq.value).from_address(qp.value)) if nq.value
+                else np.zeros(0, dtype=np.int8))
+        qoff = np.ctypeslib.as_array((ctypes.c_int64 * (n + 1)).from_address(op.value))
+        return qual, qoff
 
     def close(self):
         if self._h:
@@ -358,6 +374,7 @@ class FileStream:
         while True:
             check(lib().ffq_stream_next(self._h, ctypes.byref(rows_p), ctypes.byref(n), ctypes.byref(end),
                                         ctypes.byref(err), ctypes.byref(fill_p), ctypes.byref(nb), ctypes.byref(off)))
+            self._last_rows = n.value
             rows = (np.ctypeslib.as_array((ctypes.c_int64 * (n.value * 6)).from_address(rows_p.value)).reshape(-1, 6)
                     if n.value else np.zeros((0, 6), dtype=np.int64))
             fill = (np.ctypeslib.as_array((ctypes.c_uint8 * nb.value).from_address(fill_p.value))

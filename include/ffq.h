@@ -211,6 +211,12 @@ int  ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n_rows, int
                      int64_t *err_offset, const uint8_t **h_bytes, int64_t *n_bytes,
                      int64_t *bytes_offset);
 void ffq_stream_close(ffq_stream *s);
+/* The same with FFQ_F_DECODE_QUAL: every fill's qualities are decoded on the device
+ * (array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, qual_add), doc/user-guide.rst:130-141)
+ * and ffq_stream_quals hands back the int8 stream and its CSR offsets (n_rows + 1 entries) of
+ * the fill ffq_stream_next has just returned; pinned memory, valid until the next call.       */
+int  ffq_stream_open2(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags, int qual_add, ffq_stream **out);
+int  ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int64_t **h_qoff, int64_t *n_qual_bytes);
 
 /* ---- synthetic FASTQ generators (bench / test inputs) -----
  * Counter-based (splitmix64), so the numpy generator in

@@ -181,3 +181,34 @@ def test_iterator_errors_over_real_files(mods, gpu_ctx, golden, tmp_path):
         assert str(ei.value) == want["error"] and rows == want["rows"], name
         n += 1
     assert n >= 5
+
+
+@pytest.mark.parametrize("bufsize", (4096, 1 << 20))
+def test_stream_with_decode(mods, gpu_ctx, oracle, tmp_path, pkg, bufsize):
+    """fills with FFQ_F_DECODE_QUAL: the concatenated int8 streams and the per-fill CSR offsets
+    against arrayadd_b(-33) over every record's quality slice"""
+    F, hip, _ = mods
+    from fastqandfurious_amd import synth
+    for blob in (synth.single(0, 3000, seed=42).tobytes(), synth.wrapped(0, 3000, seed=43)[0].tobytes(),
+                 golden_file("test_multiline.fq")):
+        want, *_ = oracle.scan(blob)
+        wq, wqoff = oracle.decode_quals(blob, want)
+        path = str(tmp_path / "d.fq")
+        open(path, "wb").write(blob)
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            st = hip.FileStream(gpu_ctx, fd, bufsize, decode=True)
+            quals, lens, nrows = [], [], 0
+            for rows, fill, off, end_state, err in st:
+                q, qo = st.quals()
+                assert qo.shape[0] == rows.shape[0] + 1 and qo[0] == 0 and qo[-1] == q.shape[0]
+                quals.append(q.copy())
+                lens.append(np.diff(qo))
+                nrows += rows.shape[0]
+                assert end_state in (hip.END_OK, hip.END_REFILL)
+            st.close()
+        finally:
+            os.close(fd)
+        assert nrows == len(want)
+        assert np.array_equal(np.concatenate(quals), wq)
+        assert np.array_equal(np.concatenate(lens), np.diff(wqoff))
