@@ -1,0 +1,194 @@
+// ffq_fasta.h -- FASTA records on the device (widening row).
+//
+// The reference's scanner (/root/reference/src/fastqandfurious.py:103-143, entrypos_fasta) finds
+// "\n>" from `offset`, the end of that header line, and the next "\n>" searched from the byte
+// AFTER the header's newline.  Repeated with offset := pos[3] it yields every entry of a buffer.
+// Over the line index (built with '>' in place of '@' as the AT character) that chain is local:
+// a "\n>" entry starts a record unless the entry right before it is itself a record start (the
+// search for the end of a sequence skips the header's own newline, :133) -- so inside a run of
+// consecutive "\n>" entries every other one is a start, counted from the run's first entry at
+// or after `offset`.  No speculation, no chain walk:
+//   k_fa_count   one wave per tile: record starts per tile
+//   k_scan_i64   exclusive scan of those counts (ffq_kernels.h)
+//   k_fa_rows    one wave per tile: pos0, pos1, pos2 of every start at its rank
+//   k_fa_fix     pos3 of record r = pos0 of record r + 1, minus one; status and posbuffer of
+//                the last start, which the buffer's end cuts short (it is never COMPLETE)
+#pragma once
+#include "ffq_chain.h"
+
+namespace ffq {
+
+struct FaHdr {
+    long long n_starts;
+    long long last_p0, last_p1;      // buffer coordinates of the last start's '>' and header end (-1: none)
+    int32_t last_has_next;           // the entry after the last start's "\n>" exists
+    int32_t pad;
+};
+
+// flags + position of entry j of tile t (c = its count); tile -1 is the sentinel
+__device__ __forceinline__ uint32_t fa_entry(const LineIndex &L, int t, int j, uint32_t c)
+{
+    return (c <= (uint32_t)SLOT) ? L.ent[(int64_t)t * SLOT + j] : L.pool[L.ovf[t] + j];
+}
+
+// is the entry before (t, j) a "\n>" at buffer coordinate >= offset?  (tb, jb) = that entry
+__device__ bool fa_prev_is_at(const LineIndex &L, int64_t offset, int t, int j, int &tb, int &jb)
+{
+    tb = t; jb = j - 1;
+    if (jb < 0) {
+        tb = t - 1;
+        while (tb >= 0 && L.cnt[tb] == 0) tb--;
+        if (tb < 0) {
+            // before tile 0 there is only the sentinel (coordinate 0)
+            if (!L.s) return false;
+            tb = -1; jb = 0;
+            return L.n > 0 && L.d[0] == '>' && 0 >= offset;
+        }
+        jb = (int)L.cnt[tb] - 1;
+    }
+    const uint32_t e = fa_entry(L, tb, jb, L.cnt[tb]);
+    const int64_t P = ((int64_t)tb << TILE_SHIFT) + (e & OFF_MASK) + L.s;
+    return ((e >> 14) & FL_AT) && P >= offset;
+}
+
+// is entry (t, j) with flags/pos already known to be an eligible "\n>" a record START?
+__device__ bool fa_is_start(const LineIndex &L, int64_t offset, int t, int j)
+{
+    int r = 0, tb, jb;
+    int tt = t, jj = j;
+    while (tt >= 0 && fa_prev_is_at(L, offset, tt, jj, tb, jb)) {
+        r++;
+        tt = tb; jj = jb;
+    }
+    return (r & 1) == 0;
+}
+
+__global__ __launch_bounds__(256) void k_fa_count(LineIndex L, int64_t offset, unsigned int *__restrict__ cnt_start)
+{
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wid;
+    if (t >= L.ntiles) return;
+    const uint32_t c = L.cnt[t];
+    uint32_t n = 0;
+    for (uint32_t j0 = 0; j0 < c; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        bool st = false;
+        if (j < c) {
+            const uint32_t e = fa_entry(L, t, (int)j, c);
+            const int64_t P = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
+            if (((e >> 14) & FL_AT) && P >= offset) st = fa_is_start(L, offset, t, (int)j);
+        }
+        n += (uint32_t)__popcll(__ballot(st));
+    }
+    // the sentinel (a virtual "\n" at coordinate 0) belongs to tile 0's count
+    if (t == 0 && L.s && L.n > 0 && L.d[0] == '>' && offset <= 0) n += 1;
+    if (lane == 0) cnt_start[t] = n;
+}
+
+__global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, int64_t add,
+                                                 const long long *__restrict__ base,
+                                                 const long long *__restrict__ total, int64_t *__restrict__ table,
+                                                 int64_t table_cap, FaHdr *hdr)
+{
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wid;
+    if (t >= L.ntiles) return;
+    const uint32_t c = L.cnt[t];
+    const long long ntot = *total;
+    long long rank = base[t];
+    const int64_t len = L.len();
+    if (t == 0 && lane == 0) hdr->n_starts = ntot;
+    // the sentinel start (rank 0 of tile 0)
+    const bool sent_start = (t == 0 && L.s && L.n > 0 && L.d[0] == '>' && offset <= 0);
+    if (sent_start) {
+        if (lane == 0) {
+            // header end = the first newline of the data = entry 0 of the first non-empty tile
+            int tn = 0;
+            while (tn < L.ntiles && L.cnt[tn] == 0) tn++;
+            const bool has = tn < L.ntiles;
+            const int64_t p1 = has ? ((int64_t)tn << TILE_SHIFT) + (fa_entry(L, tn, 0, L.cnt[tn]) & OFF_MASK) + L.s : -1;
+            if (rank < table_cap) {
+                int64_t *o = table + rank * 6;
+                o[0] = 1 + add; o[1] = p1 + add; o[2] = p1 + 1 + add; o[3] = -1; o[4] = -1; o[5] = -1;
+            }
+            if (rank == ntot - 1) { hdr->last_p0 = 1; hdr->last_p1 = p1; hdr->last_has_next = has ? 1 : 0; }
+        }
+        rank += 1;
+    }
+    for (uint32_t j0 = 0; j0 < c; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        bool st = false;
+        int64_t P = 0;
+        if (j < c) {
+            const uint32_t e = fa_entry(L, t, (int)j, c);
+            P = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
+            if (((e >> 14) & FL_AT) && P >= offset) st = fa_is_start(L, offset, t, (int)j);
+        }
+        const unsigned long long m = __ballot(st);
+        if (st) {
+            const long long r = rank + __popcll(m & ((1ull << lane) - 1ull));
+            // header end: the next entry (the following tiles when this is the tile's last)
+            int tn = t, jn = (int)j + 1;
+            bool has = true;
+            if (jn >= (int)c) {
+                tn = t + 1; jn = 0;
+                while (tn < L.ntiles && L.cnt[tn] == 0) tn++;
+                has = tn < L.ntiles;
+            }
+            const int64_t p1 = has ? ((int64_t)tn << TILE_SHIFT) + (fa_entry(L, tn, jn, L.cnt[tn]) & OFF_MASK) + L.s : -1;
+            if (r < table_cap) {
+                int64_t *o = table + r * 6;
+                o[0] = P + 1 + add; o[1] = p1 + add; o[2] = p1 + 1 + add; o[3] = -1; o[4] = -1; o[5] = -1;
+            }
+            if (r == ntot - 1) { hdr->last_p0 = P + 1; hdr->last_p1 = p1; hdr->last_has_next = has ? 1 : 0; }
+        }
+        rank += __popcll(m);
+    }
+    (void)len;
+}
+
+// pos3 of every COMPLETE entry, and the result block
+__global__ __launch_bounds__(256) void k_fa_fix(LineIndex L, int64_t offset, int64_t add, const FaHdr *__restrict__ hdr,
+                                                int64_t *__restrict__ table, int64_t table_cap, DevRes *res, Pub pb)
+{
+    const long long ntot = hdr->n_starts;
+    const long long ncomplete = ntot > 0 ? ntot - 1 : 0;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ncomplete && i + 1 < table_cap) table[i * 6 + 3] = table[(i + 1) * 6 + 0] - 1;
+    if (i != 0) return;
+    // block 0 thread 0: the last call of the chain (never COMPLETE: no "\n>" follows it)
+    const int64_t len = L.len();
+    res->fallback = 0;
+    res->n_records = ncomplete;
+    res->n_qual_bytes = 0;
+    res->has_final = 0;
+    res->term_group = -1;
+    res->end_state = 0;
+    for (int q = 0; q < 6; q++) res->last_pos[q] = -1;
+    if (ntot == 0) {
+        res->last_status = ST_HEAD_BEG;
+        res->end_offset = offset;
+    } else {
+        const int64_t p0 = hdr->last_p0, p1 = hdr->last_p1;
+        res->end_offset = p0 - 1;                       // the "\n>" the last call matched
+        res->last_pos[0] = p0 + add;
+        if (!hdr->last_has_next) res->last_status = ST_HEAD_END;
+        else {
+            res->last_pos[1] = p1 + add;
+            if (p1 + 1 >= len) res->last_status = ST_SEQ_BEG;
+            else {
+                res->last_pos[2] = p1 + 1 + add;
+                // buf[-1] == '\n' ? len - 1 : len  (:137-140); coordinate len-1 is data byte len-1-s
+                const uint8_t lastb = L.d[L.n - 1];
+                res->last_pos[3] = ((lastb == '\n') ? len - 1 : len) + add;
+                res->last_status = ST_SEQ_END;
+            }
+        }
+    }
+    // the last COMPLETE row's pos3 when the table could not hold the row after it
+    if (ncomplete > 0 && ncomplete - 1 < table_cap && ncomplete >= table_cap)
+        table[(ncomplete - 1) * 6 + 3] = hdr->last_p0 - 1 + add;
+    publish(pb, res);
+}
+
+}  // namespace ffq

@@ -4,6 +4,7 @@
 // No CPU fallback: every compute entry point needs a live gfx950 device.
 #include "../../include/ffq.h"
 #include "ffq_kernels.h"
+#include "ffq_fasta.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -94,6 +95,7 @@ struct ffq_ctx {
     int64_t *d_word = nullptr;          // 2 scratch words for the small table queries
     int64_t *h_word = nullptr;          //   and their pinned mirror
     int64_t *d_cut = nullptr, *h_cut = nullptr;    // ffq_table_cut: 4 words
+    FaHdr *fa_hdr = nullptr;            // FASTA scan: starts, the last start
     // staging for the host-buffer entry points
     uint8_t *stage_d = nullptr;
     int64_t stage_d_cap = 0;
@@ -162,6 +164,7 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_word, 16);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_word, 16, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_cut, 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->fa_hdr, sizeof(FaHdr));
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_cut, 32, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_L, sizeof(LineIndex), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl), hipHostMallocMapped);
@@ -211,7 +214,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_word) (void)hipHostFree(c->h_word);
     if (c->h_cut) (void)hipHostFree(c->h_cut);
-    (void)hipFree(c->d_word); (void)hipFree(c->d_cut);
+    (void)hipFree(c->d_word); (void)hipFree(c->d_cut); (void)hipFree(c->fa_hdr);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->stage_h) (void)hipHostFree(c->stage_h);
@@ -533,11 +536,11 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     if (ntiles > nfull)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 8>), dim3((unsigned)ntiles), dim3(256), 0, sA,
                            a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
-                           L, c->d_L);
+                           L, c->d_L, (uint32_t)'@');
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)nfull), dim3(256), 0, sA,
                            a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
-                           L, c->d_L);
+                           L, c->d_L, (uint32_t)'@');
     HIPCHK(hipEventRecord(c->ev[1], sA));
 
     if (try_fast4) {
@@ -901,6 +904,101 @@ extern "C" int ffq_table_lower_bound(ffq_ctx *c, const int64_t *d_table, int64_t
     HIPCHK(hipStreamSynchronize(c->stream));
     *idx = *slot;
     return FFQ_OK;
+}
+
+// ---- FASTA (ffq_fasta.h) --------------------------------------------------------------------
+extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int sentinel,
+                                     int64_t offset, int64_t add, int64_t *d_table, int64_t table_cap,
+                                     ffq_scan_result *res)
+{
+    if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_fasta: ctx/res is NULL");
+    if (n_bytes < 0 || offset < 0 || table_cap < 0) return fail(FFQ_E_ARG, "ffq_scan_fasta: negative size");
+    if (n_bytes > 0 && !d_buf) return fail(FFQ_E_ARG, "ffq_scan_fasta: d_buf is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_buf) & 15) != 0) return fail(FFQ_E_ARG, "ffq_scan_fasta: d_buf must be 16-byte aligned");
+    if (table_cap > 0 && !d_table) return fail(FFQ_E_ARG, "ffq_scan_fasta: d_table is NULL");
+    if (c->pend.active) return fail(FFQ_E_ARG, "ffq_scan_fasta: a scan is pending on this context");
+    memset(res, 0, sizeof *res);
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t ntiles = tiles_for(n_bytes);
+    if (ntiles == 0) {
+        // nothing but (at most) the sentinel: no "\n>" can match
+        res->last_status = FFQ_POS_HEAD_BEG;
+        res->end_offset = offset;
+        for (int i = 0; i < 6; i++) res->last_pos[i] = -1;
+        res->path = 4;
+        return FFQ_OK;
+    }
+    if (ntiles > 0x7FFFFFF0) return fail(FFQ_E_ARG, "buffer too large");
+    int rc = reserve_tiles(c, ntiles);
+    if (!rc) rc = reserve_pool(c, 1ull << 20);
+    if (!rc) rc = grow_dev(c, &c->sel_cnt, &c->sel_cnt_cap, ntiles);
+    if (!rc) rc = grow_dev(c, &c->sel_base, &c->sel_base_cap, ntiles);
+    if (rc) return rc;
+    hipStream_t sA = c->stream;
+    ScanArgs a{};
+    a.d_buf = d_buf; a.n_bytes = n_bytes; a.s = sentinel ? 1 : 0;
+    for (int attempt = 0;; attempt++) {
+        const LineIndex L = make_index(c, a, ntiles);
+        if (!c->ctl_clean) HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
+        c->ctl_clean = false;
+        HIPCHK(hipEventRecord(c->ev[0], sA));
+        if ((n_bytes >> TILE_SHIFT) < ntiles)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 8>), dim3((unsigned)ntiles), dim3(256), 0, sA, d_buf,
+                               n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, 0, L, c->d_L,
+                               (uint32_t)'>');
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)ntiles), dim3(256), 0, sA, d_buf,
+                               n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, 0, L, c->d_L,
+                               (uint32_t)'>');
+        HIPCHK(hipEventRecord(c->ev[1], sA));
+        const unsigned tb = (unsigned)((ntiles + 3) / 4);
+        hipLaunchKernelGGL(k_fa_count, dim3(tb), dim3(256), 0, sA, L, offset, c->sel_cnt);
+        hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, sA, (const unsigned int *)c->sel_cnt, ntiles, c->sel_base,
+                           (long long *)c->d_word);
+        hipLaunchKernelGGL(k_fa_rows, dim3(tb), dim3(256), 0, sA, L, offset, add, (const long long *)c->sel_base,
+                           (const long long *)c->d_word, d_table, table_cap, c->fa_hdr);
+        const int64_t fix_rows = std::max<int64_t>(std::min<int64_t>(table_cap, n_bytes / 2 + 2), 1);
+        hipLaunchKernelGGL(k_fa_fix, dim3((unsigned)((fix_rows + 255) / 256)), dim3(256), 0, sA, L, offset, add,
+                           (const FaHdr *)c->fa_hdr, d_table, table_cap, c->dres, make_pub(c));
+        c->ctl_clean = true;
+        HIPCHK(hipEventRecord(c->ev[3], sA));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventSynchronize(c->ev[3]));
+        if (c->h_ctl->err & ERR_POOL) {
+            if (attempt >= 2) return fail(FFQ_E_INTERNAL, "line-index pool overflow persists");
+            rc = reserve_pool(c, std::max<unsigned long long>(c->h_ctl->pool_head, 1ull << 20));
+            if (rc) return rc;
+            continue;
+        }
+        break;
+    }
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[3])); res->ms_chain = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total = ms;
+    fill_result(res, *c->h_res, 4, 0);
+    if (res->n_records > table_cap)
+        return fail(FFQ_E_TABLE_FULL, "table holds %lld rows, the buffer has %lld FASTA entries", (long long)table_cap,
+                    (long long)res->n_records);
+    return FFQ_OK;
+}
+
+extern "C" int ffq_scan_fasta_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, int sentinel, int64_t offset,
+                                   int64_t add, int64_t *h_table, int64_t table_cap, ffq_scan_result *res)
+{
+    if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_fasta_host: ctx/res is NULL");
+    if (n_bytes < 0 || table_cap < 0) return fail(FFQ_E_ARG, "ffq_scan_fasta_host: negative size");
+    if (n_bytes > 0 && !h_buf) return fail(FFQ_E_ARG, "ffq_scan_fasta_host: h_buf is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = grow_dev(c, &c->stage_d, &c->stage_d_cap, n_bytes + 16))) return rc;
+    if ((rc = grow_dev(c, &c->tab_d, &c->tab_d_cap, std::max<int64_t>(table_cap, 1) * 6))) return rc;
+    if (n_bytes > 0) HIPCHK(hipMemcpyAsync(c->stage_d, h_buf, (size_t)n_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = ffq_scan_fasta_device(c, c->stage_d, n_bytes, sentinel, offset, add, c->tab_d, table_cap, res);
+    if (rc != FFQ_OK && rc != FFQ_E_TABLE_FULL) return rc;
+    const int64_t rows = std::min<int64_t>(res->n_records, table_cap);
+    if (rows > 0) HIPCHK(hipMemcpy(h_table, c->tab_d, (size_t)rows * 48, hipMemcpyDeviceToHost));
+    return rc;
 }
 
 extern "C" int ffq_table_cut(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t lo, int64_t hi,

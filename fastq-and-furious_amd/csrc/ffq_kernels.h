@@ -43,10 +43,10 @@ __device__ __noinline__ uint4 load_tail16(const uint8_t *d, int64_t n, int64_t a
 
 // flags of one entry: the byte after the newline at tile offset `off` (s_data holds the tile,
 // nxt the first byte of the next tile, 0 past the end of the buffer)
-__device__ __forceinline__ uint32_t entry_flags(const uint8_t *s_data, uint32_t off, uint32_t nxt)
+__device__ __forceinline__ uint32_t entry_flags(const uint8_t *s_data, uint32_t off, uint32_t nxt, uint32_t at_char)
 {
     const uint32_t nb = (off + 1u < (uint32_t)TILE) ? (uint32_t)s_data[off + 1u] : nxt;
-    return (nb == '@') ? (uint32_t)FL_AT : (nb == '+') ? (uint32_t)FL_PLUS : 0u;
+    return (nb == at_char) ? (uint32_t)FL_AT : (nb == '+') ? (uint32_t)FL_PLUS : 0u;
 }
 
 // FULL: every tile of the launch lies completely inside the buffer (no bounds checks in
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
                                                     unsigned long long *__restrict__ ovf,
                                                     uint16_t *__restrict__ pool,
                                                     unsigned long long pool_cap, Ctl *ctl, int tile0,
-                                                    int ablate, LineIndex Lval, LineIndex *__restrict__ d_L)
+                                                    int ablate, LineIndex Lval, LineIndex *__restrict__ d_L,
+                                                    uint32_t at_char)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[TILE];
     __shared__ __attribute__((aligned(16))) uint16_t s_list[SLOT];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
     if (!dense || pool_ok) {
         for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
             const uint32_t off = dense ? (uint32_t)gdst[wbase + j] : (uint32_t)s_list[wbase + j];
-            gdst[wbase + j] = (uint16_t)(off | (entry_flags(s_data, off & OFF_MASK, nxt) << 14));
+            gdst[wbase + j] = (uint16_t)(off | (entry_flags(s_data, off & OFF_MASK, nxt, at_char) << 14));
         }
     }
     // the device copy of the index descriptor (out-of-line device functions take it by pointer);

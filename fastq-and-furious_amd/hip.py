@@ -40,7 +40,7 @@ SYMBOLS = (
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
     "ffq_table_select_seqlen", "ffq_table_cut", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
-    "ffq_stream_open2", "ffq_stream_quals",
+    "ffq_stream_open2", "ffq_stream_quals", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
 )
@@ -121,6 +121,8 @@ def lib():
         L.ffq_stream_open.argtypes = [vp, i32, i64, P(vp)]
         L.ffq_stream_next.argtypes = [vp, P(vp), P(i64), P(i32), P(i64), P(vp), P(i64), P(i64)]
         L.ffq_stream_close.argtypes = [vp]
+        L.ffq_scan_fasta_device.argtypes = [vp, vp, i64, i32, i64, i64, vp, i64, P(ScanResult)]
+        L.ffq_scan_fasta_host.argtypes = [vp, vp, i64, i32, i64, i64, vp, i64, P(ScanResult)]
         L.ffq_stream_open2.argtypes = [vp, i32, i64, u32, i32, P(vp)]
         L.ffq_stream_quals.argtypes = [vp, P(vp), P(vp), P(i64)]
         L.ffq_stream_close.restype = None
@@ -269,6 +271,32 @@ class Context:
         if decode:
             return table[:n], res, qual[:int(res.n_qual_bytes)], qoff[:n + 1]
         return table[:n], res
+
+    def scan_fasta_host(self, buf, sentinel=False, offset=0, add=0, table_cap=None):
+        """Every COMPLETE FASTA entry of a host buffer (the repeated entrypos_fasta call,
+        reference fastqandfurious.py:103-143): (table int64[n,6] with pos4 = pos5 = -1,
+        ScanResult with the last call's status / posbuffer / offset)."""
+        a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+        cap = int(table_cap) if table_cap is not None else max(a.size // 64 + 16, 16)
+        while True:
+            table = np.empty((cap, 6), dtype=np.int64)
+            res = ScanResult()
+            rc = lib().ffq_scan_fasta_host(self.handle, a.ctypes.data if a.size else None, a.size, int(bool(sentinel)),
+                                           int(offset), int(add), table.ctypes.data, cap, ctypes.byref(res))
+            check(rc, allow=(E_TABLE_FULL,))
+            if rc == E_TABLE_FULL and table_cap is None:
+                cap = int(res.n_records) + 1
+                continue
+            break
+        return table[:min(int(res.n_records), cap)], res
+
+    def scan_fasta_device(self, d_buf, n_bytes, d_table, table_cap, sentinel=False, offset=0, add=0):
+        res = ScanResult()
+        rc = lib().ffq_scan_fasta_device(self.handle, ctypes.c_void_p(d_buf), int(n_bytes), int(bool(sentinel)),
+                                         int(offset), int(add), ctypes.c_void_p(d_table), int(table_cap),
+                                         ctypes.byref(res))
+        check(rc, allow=(E_TABLE_FULL,))
+        return rc, res
 
     def entrypos(self, buf, offset, pos):
         """One scanner call on the GPU: fills pos (6 x int64), returns status."""

@@ -195,6 +195,20 @@ int ffq_table_cut(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t 
 int ffq_table_select_seqlen(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t min_len,
                             int64_t max_len, int64_t *d_out, int64_t *n_out);
 
+/* ---- FASTA (reference: the plug-in scanner entrypos_fasta, fastqandfurious.py:103-143) -------
+ * Every COMPLETE entry of a buffer, i.e. the repeated scanner call with offset := pos[3]:
+ * rows = pos0 ('>'), pos1 (header end), pos2, pos3 (the "\n" of the next "\n>") + add, -1, -1.
+ * res->n_records = COMPLETE entries; res->last_status / last_pos = the last call (the entry
+ * the end of the buffer cuts short: MISSING_SEQ_END with pos3 = end of the buffer, or an
+ * earlier MISSING_* code; MISSING_SEQHEADER_BEGIN if there was no entry at all);
+ * res->end_offset = the offset of that last call.  sentinel: a virtual "\n" in front.        */
+int ffq_scan_fasta_device(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes, int sentinel,
+                          int64_t offset, int64_t add, int64_t *d_table, int64_t table_cap,
+                          ffq_scan_result *res);
+int ffq_scan_fasta_host(ffq_ctx *ctx, const uint8_t *h_buf, int64_t n_bytes, int sentinel,
+                        int64_t offset, int64_t add, int64_t *h_table, int64_t table_cap,
+                        ffq_scan_result *res);
+
 /* ---- stream front end (reference: read(), fastqandfurious.py:30-36, and the refill loop of
  * readfastq_iter, :241-279, natively over a file descriptor) ---------------------------------
  * Chunks of fbufsize bytes are read into pinned memory; the read of the next chunk overlaps the

@@ -285,3 +285,51 @@ void ffq_oracle_decode_quals(const uint8_t *base, const int64_t *table, int64_t 
     }
     qoff[n] = w;
 }
+
+/* ---- FASTA (widening row) ---------------------------------------------
+ * One scanner call: /root/reference/src/fastqandfurious.py:103-143 (entrypos_fasta, Python; the
+ * reference has no C scanner for FASTA).  No sentinel arithmetic here: d IS the buffer.        */
+int ffq_oracle_entrypos_fasta(const uint8_t *d, int64_t len, int64_t offset, int64_t *pos)
+{
+    const int64_t i = find2(d, len, offset, '\n', '>');                 /* :118 */
+    if (i < 0) return FFQ_MISSING_SEQHEADER_BEGIN;
+    pos[0] = i + 1;
+    const int64_t j = find1(d, i + 2, len, '\n');                       /* :123 */
+    if (j < 0) return FFQ_MISSING_SEQHEADER_END;
+    pos[1] = j;
+    if (j + 1 >= len) return FFQ_MISSING_SEQ_BEG;                       /* :130 */
+    pos[2] = j + 1;
+    const int64_t k = find2(d, len, j + 1, '\n', '>');                  /* :133 */
+    if (k < 0) {
+        pos[3] = (d[len - 1] == '\n') ? len - 1 : len;                  /* :137-140 */
+        return FFQ_MISSING_SEQ_END;
+    }
+    pos[3] = k;
+    return FFQ_COMPLETE;
+}
+
+/* Every COMPLETE entry of a buffer: repeated calls, each from the "\n>" the previous one ended
+ * at (offset := pos[3]).  table rows = pos0..pos3 + add, -1, -1.  out = {n_complete, last
+ * status, position of the "\n>" the last call matched (its offset argument if it matched none),
+ * 0}; last_pos receives the posbuffer of that last call
+ * (+ add where set).                                                                          */
+void ffq_oracle_scan_fasta(const uint8_t *d, int64_t len, int64_t offset, int64_t add,
+                           int64_t *table, int64_t cap, int64_t *last_pos, int64_t *out)
+{
+    int64_t n = 0;
+    int status;
+    int64_t pos[6];
+    for (;;) {
+        for (int i = 0; i < 6; i++) pos[i] = -1;
+        status = ffq_oracle_entrypos_fasta(d, len, offset, pos);
+        if (status != FFQ_COMPLETE || n >= cap) break;
+        for (int i = 0; i < 4; i++) table[6 * n + i] = pos[i] + add;
+        table[6 * n + 4] = -1; table[6 * n + 5] = -1;
+        n++;
+        offset = pos[3];
+    }
+    for (int i = 0; i < 6; i++) last_pos[i] = pos[i] >= 0 ? pos[i] + add : -1;
+    /* where a caller that refills should carry on from: the "\n>" the last call matched */
+    out[0] = n; out[1] = status; out[2] = (pos[0] >= 0) ? pos[0] - 1 : offset; out[3] = 0;
+}
+

@@ -48,6 +48,10 @@ def lib():
                                       ctypes.c_int, i64, ctypes.c_void_p, i64,
                                       ctypes.c_void_p]
         L.ffq_oracle_scan.restype = None
+        L.ffq_oracle_entrypos_fasta.argtypes = [u8p, i64, i64, ctypes.c_void_p]
+        L.ffq_oracle_entrypos_fasta.restype = ctypes.c_int
+        L.ffq_oracle_scan_fasta.argtypes = [u8p, i64, i64, i64, ctypes.c_void_p, i64, ctypes.c_void_p, ctypes.c_void_p]
+        L.ffq_oracle_scan_fasta.restype = None
         L.ffq_oracle_arrayadd_b.argtypes = [ctypes.c_void_p, i64, ctypes.c_int]
         L.ffq_oracle_arrayadd_b.restype = None
         L.ffq_oracle_arrayadd_q.argtypes = [ctypes.c_void_p, i64, i64]
@@ -124,3 +128,23 @@ def decode_quals(base, table, value=-33):
     lib().ffq_oracle_decode_quals(b.ctypes.data, t.ctypes.data, n, int(value),
                                   out.ctypes.data, qoff.ctypes.data)
     return out, qoff
+
+
+def entrypos_fasta(buf, offset):
+    """(status, [6 positions]) of one FASTA scanner call (reference fastqandfurious.py:103-143)."""
+    b = _as_u8(buf)
+    pos = np.full(6, -1, dtype=np.int64)
+    st = lib().ffq_oracle_entrypos_fasta(b.ctypes.data if b.size else None, b.size, int(offset), pos.ctypes.data)
+    return int(st), [int(x) for x in pos]
+
+
+def scan_fasta(data, offset=0, add=0, cap=None):
+    """(table int64[n,6] of the COMPLETE entries, last status, last posbuffer, offset of the last call)."""
+    b = _as_u8(data)
+    cap = int(cap) if cap is not None else b.size // 4 + 8
+    table = np.empty((cap, 6), dtype=np.int64)
+    last = np.full(6, -1, dtype=np.int64)
+    out = np.zeros(4, dtype=np.int64)
+    lib().ffq_oracle_scan_fasta(b.ctypes.data if b.size else None, b.size, int(offset), int(add),
+                                table.ctypes.data, cap, last.ctypes.data, out.ctypes.data)
+    return table[:int(out[0])], int(out[1]), [int(x) for x in last], int(out[2])

@@ -105,3 +105,73 @@ def test_compressed_input_gpu_scanner(F, golden, gpu_ctx, tmp_path, ext, writer,
     with F.automagic_open(path) as fh:
         n = sum(1 for _ in F.readfastq_iter(fh, 1 << 18, F.entryfunc, C.entrypos))
     assert n == 5000
+
+
+def test_fasta_oracle_matches_golden_curves(oracle, golden):
+    """the C restatement of entrypos_fasta (oracle/) against the reference's own outputs"""
+    n = 0
+    for tpl in golden["fasta"]:
+        full = bytes.fromhex(tpl["buf"])
+        for rec in tpl["curve"]:
+            if rec["cut"] == 0:
+                continue
+            st, pos = oracle.entrypos_fasta(full[:rec["cut"]], rec["offset"])
+            assert [st, pos] == rec["r"], (tpl["name"], rec["cut"], rec["offset"])
+            n += 1
+    assert n > 600
+
+
+def _fasta_blob(rng, n, gt_runs=True):
+    import numpy as np
+    parts = []
+    for i in range(n):
+        L = int(rng.integers(0, 400))
+        seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=L).tobytes()
+        w = int(rng.integers(20, 90))
+        body = b"\n".join(seq[k:k + w] for k in range(0, L, w))
+        rec = b">s%d some description\n" % i + body + b"\n"
+        u = rng.random()
+        if gt_runs and u < 0.08:
+            rec = b">empty%d\n" % i + rec                 # a header right after a header
+        elif gt_runs and u < 0.12:
+            rec = b">a\n>b\n>c\n" + rec                   # a run of three "\n>" lines
+        elif u < 0.16:
+            rec = b"\n" + rec                             # blank line
+        parts.append(rec)
+    return b"\n" + b"".join(parts)
+
+
+@pytest.mark.gpu
+def test_fasta_device_scan(gpu_ctx, oracle, golden, pkg):
+    """ffq_scan_fasta_* == the repeated scanner call of the oracle: rows, last status, last
+    posbuffer, offset of the last call; at prefixes, offsets and with the virtual sentinel"""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    blobs = [_fasta_blob(rng, 3000), _fasta_blob(rng, 200, gt_runs=False), b"", b"\n", b"\n>", b"\n>x", b"\n>x\n",
+             b"\n>x\nAC", b"no entry here\n", b">first\nAC\n>second\nGT\n"]
+    for tpl in golden["fasta"]:
+        blobs.append(bytes.fromhex(tpl["buf"]))
+    n = 0
+    for blob in blobs:
+        cuts = [len(blob)] if len(blob) > 4096 else range(len(blob) + 1)
+        for cut in cuts:
+            b = blob[:cut]
+            for off in (0, 3, max(0, cut // 2)):
+                want, st, last, loff = oracle.scan_fasta(b, offset=off, add=5) if len(b) else (np.zeros((0, 6), np.int64), 0, [-1] * 6, off)
+                table, res = gpu_ctx.scan_fasta_host(b, offset=off, add=5)
+                assert np.array_equal(table, want), (len(blob), cut, off)
+                assert int(res.last_status) == st and list(res.last_pos) == last, (len(blob), cut, off)
+                if st != 0:
+                    assert int(res.end_offset) == loff
+                n += 1
+    assert n > 1000
+    # the virtual sentinel: a file that starts with '>' scanned as b'\n' + file
+    blob = _fasta_blob(rng, 500)[1:]
+    want, st, last, loff = oracle.scan_fasta(b"\n" + blob, add=-1)
+    table, res = gpu_ctx.scan_fasta_host(blob, sentinel=True, add=-1)
+    assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
+    # many entries, several tiles, long single-line sequences
+    big = b"\n" + b"".join(b">chr%d\n" % i + b"ACGT" * int(rng.integers(1, 30000)) + b"\n" for i in range(300))
+    want, st, last, loff = oracle.scan_fasta(big)
+    table, res = gpu_ctx.scan_fasta_host(big)
+    assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
