@@ -296,7 +296,6 @@ static int reserve_qdir(ffq_ctx *c, int64_t blocks)
     if (blocks <= c->qdir_cap) return FFQ_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(c->qdir);
-    (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base);
     c->qdir = nullptr; c->qdir_cap = 0;
     hipError_t e = hipMalloc((void **)&c->qdir, (size_t)blocks * sizeof(int64_t));
     if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(qdir) failed: %s", hipGetErrorString(e));
