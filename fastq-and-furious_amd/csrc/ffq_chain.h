@@ -419,7 +419,13 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             if (p * 256 >= c) continue;          // wave-uniform
             const uint32_t x[4] = {ev[k][p].x & 0xFFFFu, ev[k][p].x >> 16, ev[k][p].y & 0xFFFFu, ev[k][p].y >> 16};
             uint32_t isn = 0;      // bit i: entry i of this lane becomes a node
-            if (node_tile) {
+            if (node_tile && !runin_tile && relb >= offrel) {
+                // an own tile that lies entirely at or behind `offset`: every "\n@" of it is a node
+                const int nv = min(max(c - p * 256 - 4 * lane, 0), 4);
+                const uint32_t at = ((ev[k][p].x >> 14) & 1u) | ((ev[k][p].x >> 29) & 2u) |
+                                    ((ev[k][p].y >> 12) & 4u) | ((ev[k][p].y >> 27) & 8u);
+                isn = at & ((1u << nv) - 1u);
+            } else if (node_tile) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const uint32_t off = x[i] & OFF_MASK;

@@ -73,10 +73,28 @@ class FFQError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One process, one HIP runtime.  PyTorch-ROCm bundles its own libamdhip64; if this
+    library's (the system ROCm one) initialises first, torch later finds "No HIP GPUs".  When
+    torch is installed, load ITS runtime before libffq_hip.so so that both resolve to it --
+    the order that `import torch` first gives anyway.  Without torch nothing happens."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """The loaded library.  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        _share_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise FFQError(E_NODEVICE,
                            "%s is missing: build it with `python fastq-and-furious_amd/build.py` "
