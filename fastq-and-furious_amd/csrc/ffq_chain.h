@@ -526,6 +526,30 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     // fast << 29 (set: fields are re-read from the window when the record is staged)
     uint32_t info[PER];
     uint32_t pend = 0;          // slots of this lane that need the generic path
+    // successor beyond the entries read so far: binary search of the window for the first entry at
+    // >= qe - 1 (from index `from` on), then the first "\n@" among the next 8.  ~0u: not found.
+    auto far_successor = [&](int from, uint32_t qe) -> uint32_t {
+        int lo = from, hi = nwin;
+        while (lo < hi) {
+            const int md = (lo + hi) >> 1;
+            if ((went[md] & WP_MASK) + 1 >= qe) hi = md; else lo = md + 1;
+        }
+        if (lo + 8 > nwin) return 0xFFFFFFFFu;
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = went[lo + i];
+        uint32_t am = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if ((x[i] >> WF_SHIFT) & FL_AT) am |= 1u << i;
+        if (!am) return 0xFFFFFFFFu;
+        const int i0 = __ffs((int)am) - 1;
+        uint32_t wj = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i == i0) wj = x[i];
+        const uint32_t nid = (wj >> WN_SHIFT) & WN_MASK;
+        return (lo + i0 < own_hi && nid != NO_NODE) ? nid : SN_AHEAD;
+    };
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int c = u * 64 + lane;
@@ -593,30 +617,47 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                         } else if (wpos0 + (int64_t)qe + 2 < len) {
                             // the record is COMPLETE but its successor lies beyond the batch (a
                             // candidate inside a wrapped quality block "reads" several records as
-                            // one): binary search of the window for the first entry at >= qe - 1,
-                            // then the first "\n@" among the next 8.  sj = 15: not encoded.
-                            int lo = k + 13, hi = nwin;
-                            while (lo < hi) {
-                                const int md = (lo + hi) >> 1;
-                                if ((went[md] & WP_MASK) + 1 >= qe) hi = md; else lo = md + 1;
+                            // one).  sj = 15: not encoded.
+                            const uint32_t nx = far_successor(k + 13, qe);
+                            if (nx != 0xFFFFFFFFu) {
+                                info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
+                                          (15u << 25) | (1u << 29);
+                                done = true;
                             }
-                            if (lo + 8 <= nwin) {
-                                uint32_t x[8];
+                        }
+                    }
+                } else {
+                    // no "\n+" among the next nine entries: a record wrapped over many lines.  Look
+                    // further, eight entries at a time (up to 250 entries, ~10 KB at 80 columns);
+                    // bit 31 of the node word says that mi is the wide field (8 bits, no sj).
+                    int mi = 0;
+                    const int lim = min(nwin - k - 2, 250);
+                    for (int bb = 10; bb + 8 <= lim && !mi; bb += 8) {
+                        uint32_t pm = 0;
 #pragma unroll
-                                for (int i = 0; i < 8; i++) x[i] = went[lo + i];
-                                uint32_t am = 0;
-#pragma unroll
-                                for (int i = 0; i < 8; i++)
-                                    if ((x[i] >> WF_SHIFT) & FL_AT) am |= 1u << i;
-                                if (am) {
-                                    const int i0 = __ffs((int)am) - 1;
-                                    uint32_t wj = 0;
-#pragma unroll
-                                    for (int i = 0; i < 8; i++) if (i == i0) wj = x[i];
-                                    const uint32_t nid = (wj >> WN_SHIFT) & WN_MASK;
-                                    const uint32_t nx = (lo + i0 < own_hi && nid != NO_NODE) ? nid : SN_AHEAD;
+                        for (int i = 0; i < 8; i++) {
+                            const uint32_t x = went[k + bb + i];
+                            if (((x >> WF_SHIFT) & FL_PLUS) && (x & WP_MASK) >= r1 + 2) pm |= 1u << i;
+                        }
+                        if (pm) mi = bb + (__ffs((int)pm) - 1);
+                    }
+                    if (mi) {
+                        const uint32_t r3 = went[k + mi] & WP_MASK, rm1 = went[k + mi + 1] & WP_MASK;
+                        if (wpos0 + (int64_t)rm1 + 2 <= len) {      // the '+' line end lies inside the scanner's memchr range
+                            const bool invalid = (rm1 - r3 - 1 > 1) && (rm1 - r3 != r1 - r0);
+                            const uint32_t qe = rm1 + 1 + r3 - r1 - 1;
+                            if (invalid) {
+                                info[u] = SN_STOP | ((uint32_t)(ST_INVALID + 1) << 16);
+                                done = true;
+                            } else if (wpos0 + (int64_t)qe + 2 < len) {
+                                uint32_t nx = 0xFFFFFFFFu;
+                                if (np[0] != 0xFFFFFFFEu && np[0] + 1 >= qe) nx = (uint32_t)(c + 1);
+                                else if (np[1] != 0xFFFFFFFEu && np[1] + 1 >= qe) nx = (uint32_t)(c + 2);
+                                else if (np[2] != 0xFFFFFFFEu && np[2] + 1 >= qe) nx = (uint32_t)(c + 3);
+                                else nx = far_successor(k + mi + 2, qe);
+                                if (nx != 0xFFFFFFFFu) {
                                     info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
-                                              (15u << 25) | (1u << 29);
+                                              (1u << 29) | (1u << 31);
                                     done = true;
                                 }
                             }
@@ -812,7 +853,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                 if (st == ST_COMPLETE) {
                     int64_t after;
                     if (nx == SN_NOCAND) after = Y_NOCAND;
-                    else if (nx == SN_AHEAD && (li >> 29 & 1u) && ((li >> 25) & 15u) != 15u)
+                    else if (nx == SN_AHEAD && (li >> 29 & 1u) && !(li >> 31) && ((li >> 25) & 15u) != 15u)
                         after = wpos0 + (int64_t)(went[nidx[lastn] + ((li >> 25) & 15u)] & WP_MASK);
                     else {   // beyond the window (or a generic node): through the global index
                         after = node_followup(Lg, went, nwin, wt1, eof, ready, wpos0, len, defer, nidx[lastn]).after;
@@ -857,7 +898,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             StageRec o;
             if ((info[u] >> 29) & 1u) {
                 const int k = nidx[c];
-                const int mi = (int)((info[u] >> 21) & 15u);
+                const int mi = (info[u] >> 31) ? (int)((info[u] >> 21) & 255u) : (int)((info[u] >> 21) & 15u);
                 o.p0 = (went[k] & WP_MASK) + 1;
                 o.p1 = went[k + 1] & WP_MASK;
                 o.p3 = went[k + mi] & WP_MASK;
