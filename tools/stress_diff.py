@@ -1,0 +1,40 @@
+"""One-off stress: seeded hostile inputs, GPU scan (+decode) vs oracle.  tools/stress_diff.py [seeds]"""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+import fastqandfurious_amd
+from fastqandfurious_amd import hip
+from oracle import ffq_oracle as oracle
+import test_gpu_parity as T
+ctx = hip.default_context(0)
+nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+bad = 0
+paths = {}
+for seed in range(nseeds):
+    rng = np.random.default_rng(5000 + seed)
+    kind = seed % 5
+    if kind == 0:
+        data = T._mess(rng, 4000, fatal=False)
+    elif kind == 1:
+        data = T._mess(rng, 4000, fatal=True)
+    elif kind == 2:
+        data = T.random_records(rng, 600, 200, 4000, wrap=int(rng.integers(30, 100)))
+    elif kind == 3:
+        data = T.random_records(rng, 3000, 1, 300, wrap=0, repeat_hdr=bool(seed & 1))
+    else:
+        data = T.random_records(rng, 2000, 50, 300, wrap=80)
+    cut = int(rng.integers(0, 50))
+    if cut:
+        data = data[:-cut]
+    for kw in (dict(), dict(eof=False), dict(offset=len(data) // 3)):
+        want, end, status, off = oracle.scan(data, **kw)
+        table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL, **kw)
+        wq, wqoff = oracle.decode_quals(data, want)
+        ok = (table.shape == want.shape and (table == want).all() and int(res.end_state) == end and
+              int(res.last_status) == status and int(res.end_offset) == off and (qoff == wqoff).all() and (qual == wq).all())
+        paths[(kind, int(res.path))] = paths.get((kind, int(res.path)), 0) + 1
+        if not ok:
+            bad += 1
+            print("MISMATCH seed", seed, "kind", kind, kw, "path", res.path, "n", len(want), int(res.n_records), flush=True)
+print("seeds", nseeds, "mismatches", bad, "paths (kind, path) -> count", dict(sorted(paths.items())))
