@@ -50,6 +50,7 @@ struct ScanState {
     int retries = 0;
     int repairs = 0;          // repair passes of the general kernels (reported with retries)
     bool dense_cfg = false, fast4_failed = false;
+    bool index_done = false;  // the line index of this buffer is built (a later tier re-uses it)
     int stage = 0;            // what the pending front consisted of: 1 fast four-line path, 2 general path
     int64_t ntiles = 0;
     int ngroups = 0;
@@ -62,6 +63,7 @@ struct ffq_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int fast4_skip = 0;                  // scans left that go straight to the general kernels (see scan_finish)
+    int dense_skip = 0;                  // scans left that start with the dense configuration of them
     bool decode_timed = false;           // ev[6] marks the start of the decode kernel of the pending front
     // scratch, grow-only
     int64_t cap_tiles = 0;
@@ -316,7 +318,7 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 
 extern "C" void ffq_ctx_forget(ffq_ctx *c)
 {
-    if (c) c->fast4_skip = 0;
+    if (c) { c->fast4_skip = 0; c->dense_skip = 0; }
 }
 
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
@@ -520,6 +522,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     // the four-line fast path (ffq_rows4.h) is tried first unless it already failed on this buffer
     // (nor while the context remembers that its recent input was not four-line)
     if (c->fast4_skip > 0 && !st.fast4_failed) { c->fast4_skip--; st.fast4_failed = true; }
+    if (c->dense_skip > 0 && !st.dense_cfg && !st.index_done) { c->dense_skip--; st.dense_cfg = true; }
     const bool try_fast4 = !serial && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
                            getenv("FFQ_NO_FAST4") == nullptr;
     const LineIndex L = make_index(c, a, ntiles);
@@ -532,7 +535,9 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     // one launch over all tiles; a buffer that ends inside a tile takes the variant whose loads
     // are bounds-checked (same occupancy, the checks hide behind the memory traffic)
     const int64_t nfull = a.n_bytes >> TILE_SHIFT;
-    if (ntiles > nfull)
+    if (st.index_done) {
+        // a later tier of the same scan: the index is there already
+    } else if (ntiles > nfull)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 8>), dim3((unsigned)ntiles), dim3(256), 0, sA,
                            a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
                            L, c->d_L, (uint32_t)'@');
@@ -609,11 +614,14 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             int rc = reserve_pool(c, std::max<unsigned long long>(c->h_ctl->pool_head, 1ull << 20));
             if (rc) return rc;
             st.retries++;
+            st.index_done = false;
             continue;
         }
         if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
         float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        if (!st.index_done) res->ms_index = ms;
+        st.index_done = true;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[3])); res->ms_chain += ms;
         res->ms_decode = 0;
         if (c->decode_timed) {
@@ -699,6 +707,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         if (!serial && c->h_res->fallback && !st.dense_cfg) {
             // second tier: the same kernels with the LDS budget for short lines / short records
             st.dense_cfg = true;
+            c->dense_skip = 15;          // and the next scans of this context start there
             continue;
         }
         if (st.dense_cfg) path = 2;
