@@ -99,6 +99,34 @@ def cpu_baseline_all_cores(sample_u8, budget_s=5.0):
             "sample": "%d passes over %d bytes on %d threads, %.1f s" % (sum(counts), n, cores, el)}
 
 
+def cpu_reference_c(sample_bytes, budget_s=3.0):
+    """The reference's own C scanner (oracle/_ref/_fastqandfurious.so, compiled from the reference's
+    source by oracle/Makefile; the binary travels with the repo), called once per record from a
+    Python loop as the reference's iterator does (fastqandfurious.py:252-254), one core.  None if
+    the binary is not there."""
+    from array import array
+    from oracle import refload
+    if not refload.have_reference_ext():
+        return None
+    ext = refload.load_ext()
+    buf = b"\n" + sample_bytes
+    pos = array("q", [-1] * 6)
+    n, offset = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        if ext.entrypos(buf, offset, pos) != 6:
+            break
+        offset = pos[5] - 1
+        n += 1
+        if (n & 4095) == 0 and time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"value": round(offset / el / 1e9, 5), "unit": "GB/s", "m_reads_per_s": round(n / el / 1e6, 4), "cores": 1,
+            "kind": "reference",
+            "sample": "%d entrypos() calls of the reference C extension (bare scanner calls in a Python loop), "
+                      "%.1f s" % (n, el)}
+
+
 def cpu_iterator_rate(sample_bytes, budget_s=3.0):
     """The reference-shaped number: the package's readfastq_iter with its pure-Python entrypos
     (mirror of src/fastqandfurious.py:39-100, 198-279), one record per Python call, one core."""
@@ -433,6 +461,7 @@ def main():
             line["cpu_baseline"]["host_cores_available"] = os.cpu_count()
             line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(sample[:64 << 20], args.cpu_seconds / 2)
             line["cpu_baseline"]["python_iterator"] = cpu_iterator_rate(sample.tobytes(), 3.0)
+            line["cpu_baseline"]["reference_c_extension"] = cpu_reference_c(sample.tobytes(), 3.0)
             line["host_inclusive"] = host_inclusive(ctx, sample, flags)
             line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, sample)
         else:

@@ -1,6 +1,7 @@
 """Load the REAL reference (Python module + C extension) for validating the
-oracle and for generating golden vectors.  Works only where /root/reference is
-mounted (this container); nothing that runs on the GPU box imports this.
+oracle and for generating golden vectors.  load_py works only where
+/root/reference is mounted (the build container); load_ext only needs oracle/_ref/, which
+travels to the GPU box (bench.py's cpu_baseline leg times it there).
 
 The Python module is imported from where it lies (never copied); the C
 extension is the one oracle/Makefile builds into oracle/_ref/.
