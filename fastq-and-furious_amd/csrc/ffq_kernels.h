@@ -78,7 +78,14 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         o[i] = (uint32_t)(w * 4096 + i * 1024 + l * 16);
-        if (FULL || base + o[i] + 16 <= n) v[i] = *reinterpret_cast<const uint4 *>(d + base + o[i]);
+        if (FULL || base + o[i] + 16 <= n) {
+            // non-temporal: the input streams through once; keeping it out of the L2's way lets the
+            // index lines this kernel writes leave for HBM in bulk instead of trickling out between
+            // the reads (-7 us per GiB)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(d + base + o[i]));
+            v[i] = make_uint4(t.x, t.y, t.z, t.w);
+        }
         else v[i] = load_tail16(d, n, base + o[i]);
     }
     // first byte of the next tile (workgroup-uniform): the flags of a newline at offset TILE-1
@@ -435,7 +442,9 @@ __global__ __launch_bounds__(256) void k_decode_stream(const uint8_t *__restrict
                 for (int w = 0; w < 4; w++) y[w] = addb4(y[w], vv);
                 if (ablate & 2) { if (y[0] == 0x12345678u && y[1] == 77u) outb[0] = 1; }
                 else if (vhi - vlo == 16) {
-                    *reinterpret_cast<uint4 *>(outb + clo) = make_uint4(y[0], y[1], y[2], y[3]);
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 t; t.x = y[0]; t.y = y[1]; t.z = y[2]; t.w = y[3];
+                    __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(outb + clo));      // write-once stream
                 } else {
                     store16_part(outb + clo, make_uint4(y[0], y[1], y[2], y[3]), vlo - clo, vhi - clo);
                 }

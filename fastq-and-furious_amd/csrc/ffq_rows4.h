@@ -429,7 +429,13 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
             for (int u = 0; u < 3; u++) {
                 const int q = lane + u * 64;
                 const int row = q / 3;
-                if (((em >> row) & 1ull) && rowbase + row < table_cap) dst[q] = srcr[q];
+                if (((em >> row) & 1ull) && rowbase + row < table_cap) {
+                    // written once, read by someone else later: non-temporal
+                    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+                    const longlong2 vv = srcr[q];
+                    i64x2 t; t.x = vv.x; t.y = vv.y;
+                    __builtin_nontemporal_store(t, reinterpret_cast<i64x2 *>(dst + q));
+                }
             }
             wave_sync();
         }
