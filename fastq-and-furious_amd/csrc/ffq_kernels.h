@@ -294,9 +294,10 @@ __device__ __noinline__ uint4 load16_edge(const uint8_t *__restrict__ d, int64_t
 __device__ __forceinline__ uint4 load16_any(const uint8_t *__restrict__ d, int64_t nbytes, int64_t a)
 {
     if (a >= 0 && a + 16 <= nbytes) {
-        uint4 x;
-        __builtin_memcpy(&x, d + a, 16);
-        return x;
+        // unaligned, non-temporal: the input passes through once more and is not needed again
+        typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+        const auto t = __builtin_nontemporal_load(reinterpret_cast<const u32x4u *>(d + a));
+        return make_uint4(t.x, t.y, t.z, t.w);
     }
     return load16_edge(d, nbytes, a);
 }
