@@ -10,9 +10,12 @@
 //   1. loads the line index of a window [run-in tile | OWN_T own tiles |
 //      look-ahead tile] into LDS (a few hundred entries);
 //   2. makes every "\n@" match of the run-in tail and the own tiles a NODE and
-//      computes that node's scanner call and successor (thread per node);
-//   3. follows the successor links from the window's earliest node by pointer
-//      doubling with bottom-up marking: marked nodes = the chain, with ranks;
+//      computes that node's scanner call and successor (thread per node: the entries
+//      after the candidate read independently, the successor from the positions of
+//      the next three nodes; an entry-by-entry walk only for what does not fit);
+//   3. follows the successor links from the window's earliest node: a chain is a
+//      union of runs of consecutive nodes joined by jumps, walked run by run with
+//      one LDS read per run (pointer doubling in the dense configuration);
 //   4. stages the chain's records of the own tiles as 16-byte group-relative
 //      tuples and writes a per-group summary (entry candidate, exit candidate,
 //      record count, quality bytes).
@@ -22,11 +25,16 @@
 // previous tile): a chain started at a false '@' candidate (a quality line that
 // begins with '@') re-synchronises with the true chain within a few records.
 // k_resolve_* then checks y[g+1] == exit[g] for every group up to the one the
-// chain ends in; with group 0 exact this proves every guess by induction.  On
-// any mismatch the serial walker redoes the buffer (still on the GPU).
+// chain ends in; with group 0 exact this proves every guess by induction.  A
+// rejected guess is repaired: k_repair_mark gives the group its predecessor's exit
+// as a forced entry, k_chain_wave re-runs just those groups, and everything is
+// verified again (the first rejected group is exact after each round).  What does
+// not fit the LDS budget goes to the dense configuration of the same kernels, then
+// to the serial walker (still on the GPU).
 //
-//   k_chain_wave   steps 1-4                                  (latency-bound)
+//   k_chain_wave   steps 1-4                                  (VALU-bound)
 //   k_resolve_a/b  verification + exclusive scan of counts    (tiny)
+//   k_repair_mark  forced entries for the rejected groups
 //   k_expand       staged tuples -> int64[n][6] rows (+ quality CSR offsets)
 //                  48 B written per record, coalesced through LDS
 #pragma once

@@ -1,13 +1,14 @@
 // ffq_kernels.h -- the gfx950 kernels of the FASTQ buffer-scan path.
 //
-//   k_scan_lines     bytes -> line index            (HBM-bound, the dominant kernel)
-//   k_chain<false>   line index -> per-group chain summaries (speculative)
-//   k_resolve        verifies the speculation, prefix-sums record counts
-//   k_chain<true>    emits the int64[n][6] offset table (+ quality CSR offsets)
-//   k_chain_serial   single-lane walker: exact on any input, used when the
-//                    speculation cannot be verified
-//   k_decode_quals   Phred decode of every record's quality span
-//   k_finalize       end offset / result block
+//   k_scan_lines      bytes -> line index            (HBM-bound, the dominant kernel)
+//   k_chain_serial    single-lane walker: exact on any input, the last tier
+//   k_finalize*       end offset / result block, published to host-mapped memory
+//   k_decode_stream   Phred decode of every record's quality span (output-aligned stream)
+//   k_sel_*, k_scan_i64, k_table_cut, k_table_lower_bound   table utilities
+//   k_arrayadd_b/q    the reference's array utilities
+//   k_synth_*, k_read_probe, k_selftest                     generators, diagnostics
+// The record chain itself: ffq_rows4.h (four-line fast path), ffq_chain.h (general path),
+// ffq_fasta.h (FASTA entries).
 //
 // What is computed is the record chain of
 //   /root/reference/src/fastqandfurious.py:251-279 (readfastq_iter)
