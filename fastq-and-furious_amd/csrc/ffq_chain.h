@@ -94,6 +94,8 @@ struct DevRes {
     int32_t last_status, end_state, fallback, term_group;
     int32_t has_final;
     int32_t bad_group;   // first group whose guess was not confirmed (fallback only; 0x7F7F7F7F: none)
+    int32_t bad_irregular;   // that group does not fit this configuration's LDS budget (vs a wrong guess)
+    int32_t pad2;
 };
 
 // Result hand-over.  The last result-writing kernel of a scan copies the result block and the
@@ -1060,6 +1062,7 @@ __global__ __launch_bounds__(1024) void k_resolve_b(ChainBufs B, int nblk, int e
         res->n_lines = carry_l;
         res->fallback = fallback ? 1 : 0;
         res->bad_group = tbad;
+        res->bad_irregular = (tbad >= 0 && tbad < B.ng && (B.flags[tbad] & 5u)) ? 1 : 0;
         res->term_group = fallback ? -1 : tterm;
         res->end_offset = offset;
         res->has_final = 0;

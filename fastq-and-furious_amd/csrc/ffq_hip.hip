@@ -689,8 +689,12 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         // that does not move it (a group that does not fit the kernel at all) ends the repairs.
         if (!serial && !(getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) && !getenv("FFQ_NO_REPAIR")) {
             int prev_bad = -1;
+            const int first_bad = c->h_res->bad_group;
             for (int round = 0; round < 16 && c->h_res->fallback && c->h_res->bad_group > prev_bad &&
-                                c->h_res->bad_group < st.ngroups; round++) {
+                                c->h_res->bad_group < st.ngroups && !c->h_res->bad_irregular; round++) {
+                // records that span whole groups correct one another only a few groups per round:
+                // the wave walker is the better tool then
+                if (round >= 4 && c->h_res->bad_group - first_bad < round * std::max(st.ngroups / 64, 1)) break;
                 prev_bad = c->h_res->bad_group;
                 HIPCHK(hipEventRecord(c->ev[4], sA));
                 int rc = enqueue_repair(c, a, L, st.dense_cfg, st.ngroups);
@@ -704,8 +708,9 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
             }
         }
-        if (!serial && c->h_res->fallback && !st.dense_cfg) {
+        if (!serial && c->h_res->fallback && !st.dense_cfg && c->h_res->bad_irregular) {
             // second tier: the same kernels with the LDS budget for short lines / short records
+            // (only a group that does not FIT is helped by it; a guess that stays wrong is not)
             st.dense_cfg = true;
             c->dense_skip = 15;          // and the next scans of this context start there
             continue;

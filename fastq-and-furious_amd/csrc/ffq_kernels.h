@@ -177,31 +177,117 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
 namespace ffq {
 
 // =========================================================================
-// k_chain_serial: the whole chain by one lane over the global index.  Exact on
-// any input (dense tiles, records longer than the window, chains that do not
-// re-synchronise); ~microseconds per record.
+// k_chain_serial: the whole chain by ONE WAVE over the global index, record after record.
+// Exact on any input (dense tiles, records longer than a window, chains that do not
+// re-synchronise).  The chain is sequential, but each of its searches is not: the wave looks
+// at 64 index entries (or 64 tile counts) per step and jumps straight to the tile a position
+// bound falls into, so a record costs a handful of memory round trips whatever its length
+// (a single lane walking entry by entry paid one per line: 0.3 GB/s on long wrapped records).
 // =========================================================================
-__global__ void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add,
-                               int64_t *__restrict__ table, int64_t table_cap,
-                               int64_t *__restrict__ qoff, int64_t *__restrict__ qdir, int64_t qdir_cap,
-                               DevRes *res)
+// first entry after `from` whose flags meet `mask` (0: any entry) at buffer coordinate >= minP;
+// wave-uniform arguments and result
+__device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &out, int64_t &Pout, int &flout)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const GAcc a(L);
+    const int lane = threadIdx.x & 63;
+    int t, i;
+    if (from.tile == -2) {
+        if (L.s) {
+            const uint8_t b = L.n > 0 ? L.d[0] : 0;
+            const int fl = (b == '@') ? FL_AT : (b == '+') ? FL_PLUS : 0;
+            if ((mask == 0 || (fl & mask)) && 0 >= minP) { out = H{-1, 0}; Pout = 0; flout = fl; return true; }
+        }
+        t = 0; i = 0;
+    } else if (from.tile == -1) { t = 0; i = 0; }
+    else { t = from.tile; i = from.i + 1; }
+    // entries of the tiles in front of the one minP falls into lie in front of minP
+    const int64_t tmin = (minP - L.s) >> TILE_SHIFT;
+    if (tmin > (int64_t)t) { t = (int)min(tmin, (int64_t)L.ready); i = 0; }
+    while (t < L.ready) {
+        const uint32_t c = L.cnt[t];
+        for (uint32_t j0 = (uint32_t)i; j0 < c; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            bool ok = false;
+            int64_t P = 0;
+            uint32_t e = 0;
+            if (j < c) {
+                e = (c <= (uint32_t)SLOT) ? L.ent[(int64_t)t * SLOT + j] : L.pool[L.ovf[t] + j];
+                P = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
+                ok = (mask == 0 || ((int)(e >> 14) & mask)) && P >= minP;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (m) {
+                const int w = __ffsll((long long)m) - 1;
+                out = H{t, (int32_t)(j0 + w)};
+                Pout = ((int64_t)__shfl((int)(P >> 32), w) << 32) | (uint32_t)__shfl((int)(uint32_t)P, w);
+                flout = __shfl((int)(e >> 14), w);
+                return true;
+            }
+        }
+        // next non-empty tile, 64 counts at a time
+        t++; i = 0;
+        while (t < L.ready) {
+            const uint32_t cl = (t + lane < L.ready) ? L.cnt[t + lane] : 1u;
+            const unsigned long long m = __ballot(cl != 0u);
+            if (m) { t += __ffsll((long long)m) - 1; break; }
+            t += 64;
+        }
+    }
+    return false;
+}
+
+// compute_record (ffq_dev.h) with the wave's searches: same rules, same order
+__device__ void wv_record(const LineIndex &L, H k, int64_t Pk, int64_t len, int eof, Rec &r, H &hm1)
+{
+    const int64_t NONE = -(1ll << 62);
+    r.p0 = Pk + 1; r.p1 = r.p3 = r.p4 = r.p5 = -1; r.final_ = false;
+    hm1 = k;
+    int64_t P; int fl;
+    H j = k;
+    if (!wv_find(L, j, 0, NONE, j, P, fl)) { r.status = ST_HEAD_END; return; }          // :70-71
+    if (P > len - 2) { r.status = ST_HEAD_END; return; }
+    r.p1 = P;
+    const int64_t p2 = P + 1;
+    if (!wv_find(L, j, FL_PLUS, p2 + 1, j, P, fl)) { r.status = ST_SEQ_END; return; }   // :87-88
+    r.p3 = P;
+    if (P + 2 >= len) { r.status = ST_QUALHEAD_END; return; }
+    if (!wv_find(L, j, 0, NONE, j, P, fl)) { r.status = ST_QUALHEAD_END; return; }      // :102-103
+    if (P > len - 2) { r.status = ST_QUALHEAD_END; return; }
+    hm1 = j;
+    const int64_t qhe = P, se = r.p3, he = r.p1;
+    if ((qhe - se - 1 > 1) && (qhe - se != he - r.p0 + 1)) { r.status = ST_INVALID; return; }   // :109-117
+    r.p4 = qhe + 1;
+    const int64_t qe = r.p4 + se - he - 1;                                               // :129
+    if (qe + 2 >= len) {                                                                 // :130-133
+        r.status = ST_QUAL_END;
+        if (eof && qe < len) { r.p5 = qe; r.final_ = true; }                             // fastqandfurious.py:259-266
+        return;
+    }
+    r.p5 = qe;
+    r.status = ST_COMPLETE;
+}
+
+__global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add,
+                                                     int64_t *__restrict__ table, int64_t table_cap,
+                                                     int64_t *__restrict__ qoff, int64_t *__restrict__ qdir,
+                                                     int64_t qdir_cap, DevRes *res)
+{
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x & 63;
     const int64_t len = L.len();
     int64_t n = 0, qb = 0, off = offset;
-    H k, hm, hm1;
+    H k, hm1;
     int64_t Pk;
+    int flk;
     Rec r;
     int status = ST_HEAD_BEG, end;
     r.p0 = r.p1 = r.p3 = r.p4 = r.p5 = -1; r.final_ = false;
-    bool have = find_cand(a, a.before(), offset, k, Pk);
+    bool have = wv_find(L, H{-2, 0}, FL_AT, offset, k, Pk, flk);
     for (;;) {
         if (!have) { status = ST_HEAD_BEG; r.p0 = r.p1 = r.p3 = r.p4 = r.p5 = -1; r.final_ = false; break; }
-        compute_record(a, k, Pk, len, eof, r, hm, hm1);
+        wv_record(L, k, Pk, len, eof, r, hm1);
         status = r.status;
         if (status != ST_COMPLETE && !r.final_) break;
-        if (n < table_cap) {
+        if (n < table_cap && lane == 0) {
             int64_t *o = table + n * 6;
             o[0] = r.p0 + add; o[1] = r.p1 + add; o[2] = r.p1 + 1 + add;
             o[3] = r.p3 + add; o[4] = r.p4 + add; o[5] = r.p5 + add;
@@ -211,8 +297,13 @@ __global__ void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add
         qb += r.p5 - r.p4;
         if (r.final_) break;
         off = r.p5 - 1;
-        have = find_cand(a, hm1, r.p5 - 1, k, Pk);
+        have = wv_find(L, hm1, FL_AT, r.p5 - 1, k, Pk, flk);
     }
+    // newlines of the buffer (all lanes)
+    unsigned long long nlp = 0;
+    for (int t = lane; t < L.ntiles; t += 64) nlp += L.cnt[t];
+    const int64_t nl = (int64_t)wave_sum_u32((uint32_t)(nlp & 0xFFFFFu)) + ((int64_t)wave_sum_u32((uint32_t)(nlp >> 20)) << 20);
+    if (lane != 0) return;
     if (r.final_) end = 0;
     else if (status == ST_HEAD_BEG) end = eof ? 0 : 1;
     else if (eof) end = (status == ST_QUAL_END) ? 2 : (status == ST_INVALID) ? 4 : 3;
@@ -226,8 +317,6 @@ __global__ void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add
     res->has_final = r.final_ ? 1 : 0;
     const int64_t p[6] = {r.p0, r.p1, r.p1 >= 0 ? r.p1 + 1 : -1, r.p3, r.p4, r.p5};
     for (int i = 0; i < 6; i++) res->last_pos[i] = p[i] >= 0 ? p[i] + add : -1;
-    int64_t nl = 0;
-    for (int t = 0; t < L.ntiles; t++) nl += L.cnt[t];
     res->n_lines = nl;
 }
 
