@@ -111,6 +111,51 @@ class _GpuEntrypos:
 entrypos = _GpuEntrypos()
 
 
+class _GpuEntryposFasta:
+    """entrypos_fasta(buf, offset, posbuffer) -> status on the MI355X: the FASTA plug-in scanner
+    of the reference (fastqandfurious.py:103-143) with the per-call protocol kept; the first call
+    on a buffer scans all of it (ffq_scan_fasta_host), the following calls (offset = the previous
+    pos[3]) are served from that table.  Like the reference's, it only fills the positions it
+    gets to."""
+
+    def __init__(self, device=None):
+        self._device = device
+        self._blob = None
+        self._table = None
+        self._row = 0
+        self._next_offset = None
+        self._term = None
+
+    def __call__(self, buf, offset, posbuffer):
+        pos = _writable_view(posbuffer, 8, 'q')
+        if pos.nbytes < 32:
+            raise ValueError("posbuffer must hold at least 4 positions")
+        out = np.frombuffer(pos, dtype=np.int64)
+        offset = int(offset)
+        cacheable = isinstance(buf, bytes)
+        if not (cacheable and self._blob is buf and offset == self._next_offset):
+            table, res = _hip.default_context(self._device).scan_fasta_host(buf, offset=offset)
+            self._blob = buf if cacheable else None
+            self._table = table
+            self._row = 0
+            self._term = (int(res.last_status), [int(x) for x in res.last_pos])
+        if self._row < len(self._table):
+            row = self._table[self._row]
+            out[:4] = row[:4]
+            self._row += 1
+            self._next_offset = int(row[3])
+            return COMPLETE
+        status, last = self._term
+        for i in range(4):
+            if last[i] >= 0:
+                out[i] = last[i]
+        self._next_offset = None
+        return status
+
+
+entrypos_fasta = _GpuEntryposFasta()
+
+
 def arrayadd_b(a, value):
     """Add `value` to every element of the int8 buffer `a`, in place
     (:161-185).  The reference parses `value` as a C short and keeps its low 8

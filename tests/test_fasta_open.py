@@ -175,3 +175,29 @@ def test_fasta_device_scan(gpu_ctx, oracle, golden, pkg):
     want, st, last, loff = oracle.scan_fasta(big)
     table, res = gpu_ctx.scan_fasta_host(big)
     assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
+
+
+@pytest.mark.gpu
+def test_fasta_gpu_plugin_scanner(F, golden, gpu_ctx, pkg):
+    """_fastqandfurious.entrypos_fasta keeps the reference's per-call protocol: the golden curves,
+    the reference's own test cases (tests.py:83-107), and a chain of calls over a buffer"""
+    from fastqandfurious_amd import _fastqandfurious as C
+    n = 0
+    for tpl in golden["fasta"]:
+        full = bytes.fromhex(tpl["buf"])
+        for rec in tpl["curve"]:
+            pos = array("q", [-1] * 6)
+            st = C.entrypos_fasta(full[:rec["cut"]], rec["offset"], pos)
+            assert [st, list(pos)] == rec["r"], (tpl["name"], tpl["seq"], rec["cut"], rec["offset"])
+            n += 1
+    assert n > 600
+    buf = b"\n>a desc\nACGT\nAC\n>b\n>c\nGG\n>d\nT"
+    pos_g, pos_p = array("q", [-1] * 6), array("q", [-1] * 6)
+    off_g = off_p = 0
+    for _ in range(6):
+        sg, sp = C.entrypos_fasta(buf, off_g, pos_g), F.entrypos_fasta(buf, off_p, pos_p)
+        assert (sg, list(pos_g)) == (sp, list(pos_p))
+        if sg != F.COMPLETE:
+            break
+        assert F.entryfunc_fasta(buf, pos_g, 0) == F.entryfunc_fasta(buf, pos_p, 0)
+        off_g, off_p = pos_g[3], pos_p[3]

@@ -27,9 +27,10 @@ for seed in range(nseeds):
     cut = int(rng.integers(0, 50))
     if cut:
         data = data[:-cut]
-    for kw in (dict(), dict(eof=False), dict(offset=len(data) // 3)):
+    for kw, extra in ((dict(), 0), (dict(eof=False), 0), (dict(offset=len(data) // 3), 0), (dict(), hip.F_FORCE_SERIAL),
+                      (dict(eof=False, offset=7), hip.F_FORCE_SERIAL)):
         want, end, status, off = oracle.scan(data, **kw)
-        table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL, **kw)
+        table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL | extra, **kw)
         wq, wqoff = oracle.decode_quals(data, want)
         ok = (table.shape == want.shape and (table == want).all() and int(res.end_state) == end and
               int(res.last_status) == status and int(res.end_offset) == off and (qoff == wqoff).all() and (qual == wq).all())
