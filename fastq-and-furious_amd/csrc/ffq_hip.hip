@@ -549,7 +549,14 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
 
     if (try_fast4) {
         // ---- plain four-line records: rows straight from newline ordinals, then validated -----
-        hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4);
+        const unsigned int *presum = nullptr;
+        if (nsb > 2048) {
+            // a large buffer: the per-superblock sums by many workgroups, the scan kernel only scans
+            hipLaunchKernelGGL(k_sum64, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, sA, (const uint32_t *)c->cnt, 1,
+                               (int64_t)ntiles, c->sbq, nsb);
+            presum = c->sbq;
+        }
+        hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
         if (decode) HIPCHK(hipMemsetAsync(c->tileq, 0, (size_t)ntiles * sizeof(TileQ), sA));
         hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,

@@ -75,8 +75,10 @@ __global__ __launch_bounds__(256) void k_sum64(const uint32_t *__restrict__ src,
     if (lane == 0) dst[b] = t;
 }
 
+// presum: per-superblock newline counts computed by k_sum64 (large buffers: many workgroups sum,
+// this one only scans), or nullptr: this workgroup sums the tile counts itself (one launch less)
 __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long *__restrict__ sbbase, int64_t offset,
-                                                 Fast4Hdr *hdr)
+                                                 Fast4Hdr *hdr, const unsigned int *__restrict__ presum)
 {
     __shared__ long long s_w[16];
     __shared__ uint32_t s_sum[16][64];
@@ -91,6 +93,36 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
         asm volatile("" ::"v"(sink));
     }
     long long carry = 0;
+    if (presum) {
+        // all of this thread's values first (one round trip), then scans that only touch LDS
+        for (int c0 = 0; c0 < nsb; c0 += 16 * 1024) {
+            uint32_t pv[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int b = c0 + k * 1024 + tid;
+                pv[k] = (b < nsb) ? presum[b] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int b = c0 + k * 1024 + tid;
+                if (c0 + k * 1024 >= nsb) continue;          // workgroup-uniform
+                const uint32_t v = pv[k];
+                const uint32_t incl = wave_incl_scan(v);
+                if (lane == 63) s_w[wid] = (long long)incl;
+                __syncthreads();
+                long long wpre = 0, tot = 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const long long t = s_w[q];
+                    if (q < wid) wpre += t;
+                    tot += t;
+                }
+                if (b < nsb) sbbase[b] = carry + wpre + (long long)(incl - v);
+                __syncthreads();
+                carry += tot;
+            }
+        }
+    } else
     for (int b0 = 0; b0 < nsb; b0 += 1024) {
         const int b = b0 + tid;
         // newlines per superblock.  A wave owns 64 superblocks = 16 KiB of tile counts and reads
