@@ -390,11 +390,13 @@ def test_submit_wait_two_contexts(gpu_ctx, hipmod, oracle, pkg):
     ctx2.close()
 
 
-def test_quarter_gib_closed_form(gpu_ctx, pkg):
-    """A size-independent property at a bench-like size: on S-single the table equals the
-    generator's closed form (which the small tests prove equal to the reference)."""
+@pytest.mark.parametrize("mib", (256, 2304))
+def test_closed_form_at_size(gpu_ctx, pkg, mib):
+    """A size-independent property at bench-like sizes: on S-single the table equals the
+    generator's closed form (which the small tests prove equal to the reference).  2.25 GiB is
+    past the point where the superblock sums become a kernel of their own."""
     import torch
-    n = (256 << 20) // 322
+    n = (mib << 20) // 322
     buf = torch.empty(n * 322 + 64, dtype=torch.uint8, device="cuda")
     gpu_ctx.synth_single(buf.data_ptr(), 0, n, seed=42)
     table = torch.empty((n + 8, 6), dtype=torch.int64, device="cuda")
@@ -403,6 +405,8 @@ def test_quarter_gib_closed_form(gpu_ctx, pkg):
     k = torch.arange(n, dtype=torch.int64, device="cuda") * 322
     want = torch.stack([k, k + 17, k + 18, k + 168, k + 171, k + 321], dim=1)
     assert bool((table[:n] == want).all())
+    del buf, table, want, k
+    torch.cuda.empty_cache()
 
 
 def test_table_cut(gpu_ctx):
