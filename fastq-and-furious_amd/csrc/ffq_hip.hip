@@ -414,6 +414,23 @@ static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
     return L;
 }
 
+// The line-index launch: one workgroup per whole tile; the ragged last tile (if any) rides along
+// as workgroup 0's second tile.  A buffer shorter than a tile is one workgroup.
+static void launch_scan_lines(ffq_ctx *c, hipStream_t st, const uint8_t *d_buf, int64_t n_bytes, int64_t ntiles,
+                              const LineIndex &L, uint32_t at_char, int ablate = 0)
+{
+    const int64_t nfull = n_bytes >> TILE_SHIFT;
+    const int ragged = ntiles > nfull ? (int)nfull : -1;
+    if (nfull > 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)nfull), dim3(256), 0, st, d_buf,
+                           n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, ablate, L, c->d_L,
+                           at_char, ragged);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 8>), dim3(1), dim3(256), 0, st, d_buf,
+                           n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, ablate, L, c->d_L,
+                           at_char, 0);
+}
+
 // Phred decode of the finished table: the grid covers the largest possible quality stream;
 // workgroups past the real end return at once
 static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st, bool timed = false)
@@ -504,8 +521,8 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
 // front of a scan: everything on ONE in-order stream (the context's), no host synchronisation
 // and no copy or fill between the kernels:
 //     k_scan_lines -> (k_sbscan -> k_rows4 -> k_finalize4)  or  (general kernels) [-> decode]
-// The ragged last tile of the buffer is a one-workgroup launch on the side stream, beside the
-// main index kernel.  The last result-writing kernel publishes the result block into host-mapped
+// The ragged last tile of the buffer rides along in the index kernel's launch (workgroup 0's
+// second tile).  The last result-writing kernel publishes the result block into host-mapped
 // memory and zeroes the control block for the next scan; ev[3] follows the last kernel.  A
 // second context on the same stream queues its front right behind: the GPU never idles.
 static int enqueue_front(ffq_ctx *c, ScanState &st)
@@ -532,19 +549,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
 
     // ---- line index --------------------------------------------------------------------
     HIPCHK(hipEventRecord(c->ev[0], sA));
-    // one launch over all tiles; a buffer that ends inside a tile takes the variant whose loads
-    // are bounds-checked (same occupancy, the checks hide behind the memory traffic)
-    const int64_t nfull = a.n_bytes >> TILE_SHIFT;
-    if (st.index_done) {
-        // a later tier of the same scan: the index is there already
-    } else if (ntiles > nfull)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 8>), dim3((unsigned)ntiles), dim3(256), 0, sA,
-                           a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
-                           L, c->d_L, (uint32_t)'@');
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)nfull), dim3(256), 0, sA,
-                           a.d_buf, a.n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, k1abl,
-                           L, c->d_L, (uint32_t)'@');
+    if (!st.index_done)          // (a later tier of the same scan: the index is there already)
+        launch_scan_lines(c, sA, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', k1abl);
     HIPCHK(hipEventRecord(c->ev[1], sA));
 
     if (try_fast4) {
@@ -962,14 +968,7 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
         if (!c->ctl_clean) HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
         c->ctl_clean = false;
         HIPCHK(hipEventRecord(c->ev[0], sA));
-        if ((n_bytes >> TILE_SHIFT) < ntiles)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 8>), dim3((unsigned)ntiles), dim3(256), 0, sA, d_buf,
-                               n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, 0, L, c->d_L,
-                               (uint32_t)'>');
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)ntiles), dim3(256), 0, sA, d_buf,
-                               n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, 0, L, c->d_L,
-                               (uint32_t)'>');
+        launch_scan_lines(c, sA, d_buf, n_bytes, ntiles, L, (uint32_t)'>');
         HIPCHK(hipEventRecord(c->ev[1], sA));
         const unsigned tb = (unsigned)((ntiles + 3) / 4);
         hipLaunchKernelGGL(k_fa_count, dim3(tb), dim3(256), 0, sA, L, offset, c->sel_cnt);
@@ -1156,9 +1155,44 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
     HIPCHK(hipSetDevice(c->device));
     const int64_t ntiles = n_bytes >> TILE_SHIFT;
     uint32_t *sink = reinterpret_cast<uint32_t *>(c->ctl);
+    ScanArgs a{};
+    a.d_buf = d_buf; a.n_bytes = ntiles << TILE_SHIFT; a.s = 1;
+    if (mode == 2) {
+        // the index kernel alone, back to back: its steady-state time without the rest of a step
+        int rc = reserve_tiles(c, ntiles);
+        if (rc) return rc;
+        rc = reserve_pool(c, 1ull << 20);
+        if (rc) return rc;
+    }
+    const LineIndex L = make_index(c, a, ntiles);
+    if (mode == 3 || mode == 4) {
+        // (mode 4: the variant for a buffer whose last tile is ragged)
+        if (mode == 4) a.n_bytes -= 5;
+        // mode 2's kernel, every launch between its own pair of events (as a scan times it)
+        int rc = reserve_tiles(c, ntiles);
+        if (rc) return rc;
+        rc = reserve_pool(c, 1ull << 20);
+        if (rc) return rc;
+        float sum = 0;
+        for (int r = 0; r < reps + 2; r++) {
+            HIPCHK(hipEventRecord(c->ev[0], c->stream));
+            launch_scan_lines(c, c->stream, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@');
+            HIPCHK(hipEventRecord(c->ev[1], c->stream));
+            HIPCHK(hipEventSynchronize(c->ev[1]));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+            if (r >= 2) sum += ms;
+        }
+        *ms_avg = sum / reps;
+        HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return FFQ_OK;
+    }
     for (int r = 0; r < reps + 2; r++) {
         if (r == 2) HIPCHK(hipEventRecord(c->ev[0], c->stream));
-        if (mode == 0)
+        if (mode == 2)
+            launch_scan_lines(c, c->stream, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@');
+        else if (mode == 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_read_probe<0>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_buf, ntiles, sink);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_read_probe<1>), dim3(256 * 8), dim3(256), 0, c->stream, d_buf, ntiles, sink);
@@ -1168,6 +1202,7 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     *ms_avg = ms / reps;
+    if (mode == 2) { HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
     return FFQ_OK;
 }
 

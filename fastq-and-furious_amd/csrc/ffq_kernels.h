@@ -32,9 +32,11 @@ namespace ffq {
 // half the registers (8 resident workgroups per CU).
 // Algorithmic HBM traffic: TILE bytes read + 2 bytes per newline written.
 // =========================================================================
-__device__ __noinline__ uint4 load_tail16(const uint8_t *d, int64_t n, int64_t at)
+__device__ __forceinline__ uint4 load_tail16(const uint8_t *d, int64_t n, int64_t at)
 {
+    if (at + 16 <= n) return *reinterpret_cast<const uint4 *>(d + at);
     uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
     for (int b = 0; b < 16; b++) {
         const int64_t p = at + b;
         if (p < n) w[b >> 2] |= (uint32_t)d[p] << ((b & 3) * 8);
@@ -50,36 +52,38 @@ __device__ __forceinline__ uint32_t entry_flags(const uint8_t *s_data, uint32_t 
     return (nb == at_char) ? (uint32_t)FL_AT : (nb == '+') ? (uint32_t)FL_PLUS : 0u;
 }
 
-// FULL: every tile of the launch lies completely inside the buffer (no bounds checks in
+// The body for one tile.  FULL: the tile lies completely inside the buffer (no bounds checks in
 // the loads).  One tile per workgroup and as many resident waves as possible.  Measured on
 // MI355X: 2 / 4 / 8 consecutive tiles per workgroup with the next tile's loads issued ahead of
 // the scans, the barrier and the store tail run at 190 / 213 / 224 us per GiB against 190 us
 // (fewer, longer workgroups fill the last round of the grid worse than the prefetch gains).
-template <bool FULL, int MINW>
-__global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restrict__ d, int64_t n,
-                                                    uint16_t *__restrict__ ent,
-                                                    uint32_t *__restrict__ cnt,
-                                                    unsigned long long *__restrict__ ovf,
-                                                    uint16_t *__restrict__ pool,
-                                                    unsigned long long pool_cap, Ctl *ctl, int tile0,
-                                                    int ablate, LineIndex Lval, LineIndex *__restrict__ d_L,
-                                                    uint32_t at_char)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_data[TILE];
-    __shared__ __attribute__((aligned(16))) uint16_t s_list[SLOT];
-    __shared__ uint32_t s_wtot[4];
-    __shared__ unsigned long long s_ovf;
+struct ScanLds {
+    __attribute__((aligned(16))) uint8_t data[TILE];
+    __attribute__((aligned(16))) uint16_t list[SLOT];
+    uint32_t wtot[4];
+    unsigned long long ovf;
+};
 
-    const int tile = tile0 + blockIdx.x;
+template <bool FULL>
+__device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uint8_t *__restrict__ d, int64_t n,
+                                          uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
+                                          unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
+                                          unsigned long long pool_cap, Ctl *ctl, int ablate, uint32_t at_char)
+{
+    uint8_t *const s_data = sm.data;
+    uint16_t *const s_list = sm.list;
+    uint32_t *const s_wtot = sm.wtot;
+    unsigned long long &s_ovf = sm.ovf;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int64_t base = (int64_t)tile << TILE_SHIFT;
 
     uint4 v[4];
     uint32_t o[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        o[i] = (uint32_t)(w * 4096 + i * 1024 + l * 16);
-        if (FULL || base + o[i] + 16 <= n) {
+    for (int i = 0; i < 4; i++) o[i] = (uint32_t)(w * 4096 + i * 1024 + l * 16);
+    if (FULL) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
             // non-temporal: the input streams through once; keeping it out of the L2's way lets the
             // index lines this kernel writes leave for HBM in bulk instead of trickling out between
             // the reads (-7 us per GiB)
@@ -87,7 +91,9 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
             const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(d + base + o[i]));
             v[i] = make_uint4(t.x, t.y, t.z, t.w);
         }
-        else v[i] = load_tail16(d, n, base + o[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = load_tail16(d, n, base + o[i]);
     }
     // first byte of the next tile (workgroup-uniform): the flags of a newline at offset TILE-1
     const uint32_t nxt = (base + TILE < n) ? (uint32_t)d[base + TILE] : 0u;
@@ -165,9 +171,33 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
             gdst[wbase + j] = (uint16_t)(off | (entry_flags(s_data, off & OFF_MASK, nxt, at_char) << 14));
         }
     }
-    // the device copy of the index descriptor (out-of-line device functions take it by pointer);
-    // here, where nothing else is live
-    if (tile == 0 && tid == 0 && d_L) *d_L = Lval;
+}
+
+// The launch: workgroup b takes whole tile tile0 + b.  Only the last tile of a buffer can be
+// ragged; it is workgroup 0's second tile (ragged_tile >= 0), with bounds-checked loads: a
+// variant of the whole kernel with a ragged test in front of the loads ran 3-8 us per GiB slower
+// on every tile, and workgroup 0 is long done when the last round of the grid starts.
+// WHOLE = false: no whole tile at all (a buffer shorter than a tile), one workgroup.
+template <bool WHOLE, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restrict__ d, int64_t n,
+                                                    uint16_t *__restrict__ ent,
+                                                    uint32_t *__restrict__ cnt,
+                                                    unsigned long long *__restrict__ ovf,
+                                                    uint16_t *__restrict__ pool,
+                                                    unsigned long long pool_cap, Ctl *ctl, int tile0,
+                                                    int ablate, LineIndex Lval, LineIndex *__restrict__ d_L,
+                                                    uint32_t at_char, int ragged_tile)
+{
+    __shared__ ScanLds sm;
+    if (WHOLE) scan_tile<true>(sm, tile0 + (int)blockIdx.x, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
+    if (blockIdx.x == 0) {
+        if (ragged_tile >= 0) {
+            if (WHOLE) __syncthreads();
+            scan_tile<false>(sm, ragged_tile, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
+        }
+        // the device copy of the index descriptor (out-of-line device functions take it by pointer)
+        if (threadIdx.x == 0 && d_L) *d_L = Lval;
+    }
 }
 
 }  // namespace ffq

@@ -248,7 +248,8 @@ int ffq_synth_wrapped(ffq_ctx *ctx, uint8_t *d_out, const int64_t *d_start,
 
 /* Measured streaming-read ceiling of the device in the scan kernel's launch geometry
  * (mode 0) or as a grid-stride loop (mode 1): average ms over `reps` launches of a
- * kernel that only reads n_bytes (rounded down to 16 KiB).  Diagnostics.            */
+ * kernel that only reads n_bytes (rounded down to 16 KiB).  Mode 2: the line-index kernel
+ * itself, launched back to back without the rest of a scan.  Diagnostics.               */
 int ffq_read_probe(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes, int mode, int reps,
                    float *ms_avg);
 
