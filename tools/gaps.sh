@@ -2,12 +2,12 @@
 # kernel timeline of the last steps of a bench run: durations and gaps between kernels
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/gp; rocprofv3 --kernel-trace --output-format csv -d /tmp/gp -o p -- python $R/bench.py --workload ${1:-single-1g} --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rm -rf /tmp/gp; rocprofv3 --kernel-trace --output-format csv -d /tmp/gp -o p -- python $R/bench.py --workload ${1:-single-1g} --steps 12 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 python - <<'PY'
 import csv
 rows = [r for r in csv.DictReader(open("/tmp/gp/p_kernel_trace.csv")) if "ffq::k_" in r["Kernel_Name"] and "synth" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-rows = rows[-14:]
+rows = rows[-32:]
 t0 = int(rows[0]["Start_Timestamp"])
 prev_end = None
 for r in rows:
