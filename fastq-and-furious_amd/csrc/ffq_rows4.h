@@ -228,12 +228,13 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
 }
 
 // One wave per tile, four tiles per workgroup (no workgroup barrier).
-__global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
+__global__ __launch_bounds__(256, 7) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap,
                                                int64_t *__restrict__ qoff, TileQ *__restrict__ tileq)
 {
-    __shared__ uint16_t s_ent_all[4][R4_LIST];      // the tile's own entries as stored (offset | flags << 14)
+    __shared__ __attribute__((aligned(16))) uint16_t s_ent_all[4][R4_LIST];   // the tile's own entries as stored (offset | flags << 14),
+                                                                              // then (usually) the first five of the next tile
     __shared__ uint32_t s_la_all[4][8];             // look-ahead entries: position - tile base, flags << 30
     __shared__ __attribute__((aligned(16))) int64_t s_rows_all[4][64 * 6];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -283,6 +284,8 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
     if (c + pre == 0 && t != 0) return;   // no newline in the tile (long reads): no record starts here
     const long long obl = ob - pre;                                    // ordinal of list element 0
     const int64_t tbase = ((int64_t)t << TILE_SHIFT) + L.s;            // buffer coordinate of tile offset 0
+    const int64_t tb_add = tbase + add;                                // (wave-uniform: scalar registers)
+    const int32_t lim = (int32_t)min(len - tbase, (int64_t)0x7FFFFFF0);   // len relative to the tile
     if (j0 < 0) {
         // no "\n@" at all: the chain ends at once with MISSING_SEQHEADER_BEGIN
         if (t == 0 && lane == 0) {
@@ -293,30 +296,40 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
         }
         return;
     }
-    if (pre && lane == 0) {
-        const uint8_t b0 = L.n > 0 ? L.d[0] : 0;
-        const uint32_t fl = (b0 == '@') ? FL_AT : (b0 == '+') ? FL_PLUS : 0;
-        s_ent[0] = (uint16_t)(fl << 14);             // the sentinel: coordinate 0, special-cased below
-    }
-    {
+    if (pre) {
+        if (lane == 0) {
+            const uint8_t b0 = L.n > 0 ? L.d[0] : 0;
+            const uint32_t fl = (b0 == '@') ? FL_AT : (b0 == '+') ? FL_PLUS : 0;
+            s_ent[0] = (uint16_t)(fl << 14);             // the sentinel: coordinate 0, special-cased below
+        }
         const uint32_t x[4] = {v0.x & 0xFFFFu, v0.x >> 16, v0.y & 0xFFFFu, v0.y >> 16};
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            if (4 * lane + i < c) s_ent[pre + 4 * lane + i] = (uint16_t)x[i];
-        for (int i = 256 + lane; i < c; i += 64) {          // more than 256 lines in the tile
-            s_ent[pre + i] = src[i];
-        }
+            if (4 * lane + i < c) s_ent[1 + 4 * lane + i] = (uint16_t)x[i];
+    } else {
+        // four entries per lane as loaded, one 8-byte LDS store; what lies past the tile's count is
+        // never read as an entry of the tile
+        *reinterpret_cast<uint2 *>(s_ent + 4 * lane) = v0;
+    }
+    for (int i = 256 + lane; i < c; i += 64) {              // more than 256 lines in the tile
+        s_ent[pre + i] = src[i];
     }
     // look-ahead: the first entries of the following tiles (a record needs 4 more newlines)
     int nl = pre + c;
     bool idx_end = false;           // the look-ahead ran into the end of the index
-    if (have_next && c1 >= 5 && c1 <= SLOT) {
+    // la_next: the look-ahead is the first five entries of tile t + 1; they are then ALSO list
+    // elements nown .. nown + 4 of s_ent as stored (position = TILE + offset), which is what the
+    // usual-record test below reads
+    const bool la_next = have_next && c1 >= 5 && c1 <= SLOT;
+    if (la_next) {
         if (lane < 2) {
             const uint32_t x[4] = {vla.x & 0xFFFFu, vla.x >> 16, vla.y & 0xFFFFu, vla.y >> 16};
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (4 * lane + i < 5)
+                if (4 * lane + i < 5) {
                     s_la[4 * lane + i] = ((1u << TILE_SHIFT) + (x[i] & OFF_MASK)) | ((x[i] >> 14) << 30);
+                    s_ent[nl + 4 * lane + i] = (uint16_t)x[i];
+                }
         }
         nl += 5;
     } else {
@@ -356,11 +369,36 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
             const int r = r0 + lane;
             const bool act = r < nrec_tile;
             const int i = (int)i0 + 4 * r;
-            int64_t p0 = 0, p1 = 0, p3 = 0, p4 = 0, p5 = 0;
             int cls = 0;          // 0 regular COMPLETE, 1 irregular, 2 chain ends here (status below), 3 complete and last
-            int status = ST_COMPLETE;
             bool fin = false;
-            if (act) {
+            // ---- the usual record: all five list elements at hand and every rule of the scanner
+            //      met, tested branch-free on tile-relative 32-bit positions.  Whatever fails the
+            //      test (the ends of the buffer, irregular text, a look-ahead that is not simply
+            //      the next tile's) takes the rule-by-rule path below, in 64 bits.
+            int32_t f0 = 0, f1 = 0, f3 = 0, f4 = 0, f5 = 0;      // row fields, relative to tbase
+            bool usual = false;
+            {
+                const int ic = min(i, R4_LIST - 5);
+                const uint32_t e0 = s_ent[ic], e1 = s_ent[ic + 1], e2 = s_ent[ic + 2], e3 = s_ent[ic + 3],
+                               e4 = s_ent[ic + 4];
+                const int32_t x0 = (pre && ic == 0) ? -1 : (int32_t)(e0 & OFF_MASK) + ((ic >= nown) ? TILE : 0);
+                const int32_t x1 = (int32_t)(e1 & OFF_MASK) + ((ic + 1 >= nown) ? TILE : 0);
+                const int32_t x2 = (int32_t)(e2 & OFF_MASK) + ((ic + 2 >= nown) ? TILE : 0);
+                const int32_t x3 = (int32_t)(e3 & OFF_MASK) + ((ic + 3 >= nown) ? TILE : 0);
+                const int32_t x4 = (int32_t)(e4 & OFF_MASK) + ((ic + 4 >= nown) ? TILE : 0);
+                const int32_t qe = x3 + x2 - x1;                 // pos4 + (pos3 - pos2) = x3 + 1 + x2 - x1 - 1
+                usual = act & (i + 4 < nl) & (la_next | (i + 4 < nown))
+                      & (x1 <= lim - 2)                                              // header line ends inside
+                      & (((e2 >> 14) & FL_PLUS) != 0) & (x2 >= x1 + 2)               // '+' line right after ONE sequence line
+                      & (x2 + 2 < lim) & (x3 <= lim - 2)
+                      & !((x3 - x2 - 1 > 1) & (x3 - x2 != x1 - x0))                  // '+' line length rule
+                      & (qe + 2 < lim)
+                      & (((e4 >> 14) & FL_AT) != 0) & (x4 >= qe - 1);                // the next call finds e4
+                f0 = x0 + 1; f1 = x1; f3 = x2; f4 = x3 + 1; f5 = qe;
+            }
+            if (act && !usual) {
+                int64_t p0 = 0, p1 = 0, p3 = 0, p4 = 0, p5 = 0;
+                int status = ST_COMPLETE;
                 const long long k = kfirst + r;
                 const int have = nl - i;           // list elements from e0 on (e0 included)
                 // list element i+q: an own entry (the sentinel is element 0 of tile 0) or look-ahead
@@ -420,12 +458,13 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
                     const unsigned long long kk = (unsigned long long)(cls == 3 ? k + 1 : k);
                     atomicMin(&hdr->term_min, (kk << 24) | (unsigned long long)(t & 0xFFFFFF));
                 }
-            }
-            // per tile: the terminal information of the smallest k (lanes are in k order)
-            const unsigned long long tm = __ballot(act && (cls == 2 || cls == 3));
-            if (tm != 0ull && !tile_term_done) {
-                tile_term_done = true;
-                if (lane == __ffsll((long long)tm) - 1) {
+                // (a row that is written has all its fields; they lie within 2^31 of the tile)
+                f0 = (int32_t)(p0 - tbase); f1 = (int32_t)(p1 - tbase); f3 = (int32_t)(p3 - tbase);
+                f4 = (int32_t)(p4 - tbase); f5 = (int32_t)(p5 - tbase);
+                // per tile: the terminal information of the smallest k (lanes are in k order; only
+                // lanes on this path can be terminal, the ballot is among them)
+                const unsigned long long tm = __ballot(cls == 2 || cls == 3);
+                if (tm != 0ull && !tile_term_done && lane == __ffsll((long long)tm) - 1) {
                     TermInfo4 ti;
                     if (cls == 3) {
                         for (int q = 0; q < 6; q++) ti.pos[q] = -1;
@@ -438,18 +477,19 @@ __global__ __launch_bounds__(256) void k_rows4(LineIndex L, const long long *__r
                     tinfo[t] = ti;
                 }
             }
+            if (__ballot(act && (cls == 2 || cls == 3)) != 0ull) tile_term_done = true;      // (wave-uniform)
             // rows: COMPLETE records (cls 0, 3) and the final record
             const bool emit = act && (cls == 0 || cls == 3 || (cls == 2 && fin));
             if (qoff) {
                 // tile-relative offsets of the decoded qualities; k_qfix4 adds the tile's base
-                const uint32_t ql = emit ? (uint32_t)(p5 - p4) : 0u;
+                const uint32_t ql = emit ? (uint32_t)(f5 - f4) : 0u;
                 const uint32_t incl = wave_incl_scan(ql);
                 if (act && kfirst + r < table_cap) qoff[kfirst + r] = (int64_t)(qrun + incl - ql);
                 qrun += (uint32_t)__shfl((int)incl, 63);
             }
             int64_t *mine = s_rows + lane * 6;
-            mine[0] = p0 + add; mine[1] = p1 + add; mine[2] = p1 + 1 + add;
-            mine[3] = p3 + add; mine[4] = p4 + add; mine[5] = p5 + add;
+            mine[0] = tb_add + f0; mine[1] = tb_add + f1; mine[2] = tb_add + f1 + 1;
+            mine[3] = tb_add + f3; mine[4] = tb_add + f4; mine[5] = tb_add + f5;
             wave_sync();
             // rows of one chunk are consecutive in the table: 16-byte pieces, consecutive lanes ->
             // consecutive pieces; a row is written iff its record emits
