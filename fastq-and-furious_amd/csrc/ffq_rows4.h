@@ -228,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
 }
 
 // One wave per tile, four tiles per workgroup (no workgroup barrier).
-__global__ __launch_bounds__(256, 7) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
+__global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap,
                                                int64_t *__restrict__ qoff, TileQ *__restrict__ tileq)
@@ -236,8 +236,10 @@ __global__ __launch_bounds__(256, 7) void k_rows4(LineIndex L, const long long *
     __shared__ __attribute__((aligned(16))) uint16_t s_ent_all[4][R4_LIST];   // the tile's own entries as stored (offset | flags << 14),
                                                                               // then (usually) the first five of the next tile
     __shared__ uint32_t s_la_all[4][8];             // look-ahead entries: position - tile base, flags << 30
-    __shared__ __attribute__((aligned(16))) int64_t s_rows_all[4][64 * 6];
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) int32_t s_rows_all[4][64 * 6];    // row fields relative to the tile
+    // (the wave index through readfirstlane: the compiler then keeps everything derived from the
+    // tile number -- bases, limits, addresses -- in scalar registers)
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= L.ntiles) return;
     // the header words are only TESTED after the tile's own loads have been issued: a branch on
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256, 7) void k_rows4(LineIndex L, const long long *
     const long long j0 = hdr->j0;
     uint16_t *s_ent = s_ent_all[wid];
     uint32_t *s_la = s_la_all[wid];
-    int64_t *s_rows = s_rows_all[wid];
+    int32_t *s_rows = s_rows_all[wid];
     const int64_t len = L.len();
 
     // everything this tile usually needs in ONE memory round trip: its count, its first 256
@@ -487,15 +489,14 @@ __global__ __launch_bounds__(256, 7) void k_rows4(LineIndex L, const long long *
                 if (act && kfirst + r < table_cap) qoff[kfirst + r] = (int64_t)(qrun + incl - ql);
                 qrun += (uint32_t)__shfl((int)incl, 63);
             }
-            int64_t *mine = s_rows + lane * 6;
-            mine[0] = tb_add + f0; mine[1] = tb_add + f1; mine[2] = tb_add + f1 + 1;
-            mine[3] = tb_add + f3; mine[4] = tb_add + f4; mine[5] = tb_add + f5;
+            int2 *mine = reinterpret_cast<int2 *>(s_rows + lane * 6);
+            mine[0] = make_int2(f0, f1); mine[1] = make_int2(f1 + 1, f3); mine[2] = make_int2(f4, f5);
             wave_sync();
             // rows of one chunk are consecutive in the table: 16-byte pieces, consecutive lanes ->
             // consecutive pieces; a row is written iff its record emits
             const unsigned long long em = __ballot(emit);
             const int64_t rowbase = kfirst + r0;
-            const longlong2 *srcr = reinterpret_cast<const longlong2 *>(s_rows);
+            const int2 *srcr = reinterpret_cast<const int2 *>(s_rows);
             longlong2 *dst = reinterpret_cast<longlong2 *>(table + rowbase * 6);
 #pragma unroll
             for (int u = 0; u < 3; u++) {
@@ -504,8 +505,8 @@ __global__ __launch_bounds__(256, 7) void k_rows4(LineIndex L, const long long *
                 if (((em >> row) & 1ull) && rowbase + row < table_cap) {
                     // written once, read by someone else later: non-temporal
                     typedef long long i64x2 __attribute__((ext_vector_type(2)));
-                    const longlong2 vv = srcr[q];
-                    i64x2 t; t.x = vv.x; t.y = vv.y;
+                    const int2 vv = srcr[q];
+                    i64x2 t; t.x = tb_add + vv.x; t.y = tb_add + vv.y;
                     __builtin_nontemporal_store(t, reinterpret_cast<i64x2 *>(dst + q));
                 }
             }
