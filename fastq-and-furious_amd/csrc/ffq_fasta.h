@@ -65,7 +65,7 @@ __device__ bool fa_is_start(const LineIndex &L, int64_t offset, int t, int j)
 
 __global__ __launch_bounds__(256) void k_fa_count(LineIndex L, int64_t offset, unsigned int *__restrict__ cnt_start)
 {
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= L.ntiles) return;
     const uint32_t c = L.cnt[t];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
                                                  const long long *__restrict__ total, int64_t *__restrict__ table,
                                                  int64_t table_cap, FaHdr *hdr)
 {
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= L.ntiles) return;
     const uint32_t c = L.cnt[t];

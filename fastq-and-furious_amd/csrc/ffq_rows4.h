@@ -67,7 +67,7 @@ __device__ __forceinline__ long long tile_ordinal_base(const LineIndex &L, const
 __global__ __launch_bounds__(256) void k_sum64(const uint32_t *__restrict__ src, int stride, int64_t nsrc,
                                                unsigned int *__restrict__ dst, int ndst)
 {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (b >= ndst) return;
     const int64_t i = (int64_t)b * 64 + lane;
     const uint32_t v = (i < nsrc) ? src[i * stride] : 0u;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void k_qfix4(int ntiles, const Fast4Hdr *__res
                                                int64_t *__restrict__ qoff, int64_t table_cap,
                                                int64_t *__restrict__ qdir, int64_t qdir_cap)
 {
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= ntiles || !hdr->attempt) return;
     // the three loads go out together (clamped addresses, masked values): a branch between them

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libffq_hip.so")
+# FFQ_HIP_LIB: another build of the same library (same-box A/B measurements, tools/ab_run.sh)
+LIB_PATH = os.environ.get("FFQ_HIP_LIB") or os.path.join(_HERE, "csrc", "libffq_hip.so")
 
 # status codes (include/ffq.h; reference: _fastqandfurious.c:7-15)
 INVALID = -1
