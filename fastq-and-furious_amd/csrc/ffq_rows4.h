@@ -551,15 +551,16 @@ __global__ __launch_bounds__(256) void k_qfix4(int ntiles, const Fast4Hdr *__res
 {
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
-    if (t >= ntiles || !hdr->attempt) return;
-    // the three loads go out together (clamped addresses, masked values): a branch between them
-    // is a memory round trip each
+    if (t >= ntiles) return;
+    // the loads go out together (clamped addresses, masked values): a branch between them -- the
+    // test of the header word included -- is a memory round trip each
+    const int attempt = hdr->attempt;
     const int t0 = (t / SB_TILES) * SB_TILES;
     const TileQ me = tileq[t];
     const uint32_t bq = tileq[min(t0 + lane, ntiles - 1)].qsum;                  // SB_TILES == 64 lanes
     const long long sbb = sbqbase[t / SB_TILES];
-    asm volatile("" ::"v"(me.kfirst), "v"(me.nrec), "v"(me.qsum), "v"(bq), "v"(sbb));
-    if (me.nrec <= 0) return;
+    asm volatile("" ::"v"(me.kfirst), "v"(me.nrec), "v"(me.qsum), "v"(bq), "v"(sbb), "s"(attempt));
+    if (!attempt || me.nrec <= 0) return;
     const int64_t base = sbb + (int64_t)wave_sum_u32((t0 + lane < t) ? bq : 0u);
     for (int r0 = 0; r0 < me.nrec; r0 += 64) {
         const int r = r0 + lane;
