@@ -577,7 +577,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
             hipLaunchKernelGGL(k_sum64, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, sA,
                                reinterpret_cast<const uint32_t *>(c->tileq) + 3, 4, (int64_t)ntiles, c->sbq, nsb);
             hipLaunchKernelGGL(k_qscan4, dim3(1), dim3(1024), 0, sA, (const unsigned int *)c->sbq, nsb, c->sbqbase);
-            hipLaunchKernelGGL(k_qfix4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, (int)ntiles,
+            hipLaunchKernelGGL(k_qfix4, dim3((unsigned)((ntiles + 7) / 8)), dim3(256), 0, sA, (int)ntiles,
                                (const Fast4Hdr *)c->hdr4, (const TileQ *)c->tileq, (const long long *)c->sbqbase,
                                a.d_qoff, a.table_cap, c->qdir, c->qdir_cap);
             hipLaunchKernelGGL(k_qtotal4, dim3(1), dim3(1), 0, sA, c->dres, (const int64_t *)a.d_table, a.table_cap,
