@@ -492,3 +492,53 @@ def test_wrapped_kilobase_records_are_repaired_not_serialised(gpu_ctx, oracle, L
     assert res.path == 0
     check_same(gpu_ctx, oracle, data[:-1])
     check_same(gpu_ctx, oracle, data, offset=len(data) // 2)
+
+
+def mutate(rng, data, nedits):
+    b = bytearray(data)
+    for _ in range(nedits):
+        kind = int(rng.integers(0, 8))
+        p = int(rng.integers(0, max(1, len(b) - 400)))
+        if kind == 0:
+            b[p] = 10
+        elif kind == 1:
+            b[p] = 64
+        elif kind == 2:
+            b[p] = 43
+        elif kind == 3:
+            del b[p:p + int(rng.integers(1, 40))]
+        elif kind == 4:
+            b[p:p] = bytes(rng.integers(33, 75, size=int(rng.integers(1, 40))).astype(np.uint8))
+        elif kind == 5:
+            q = b.find(b"\n", p)
+            if q > 0:
+                b[q:q + 1] = b"\r\n"
+        elif kind == 6:
+            q = b.find(b"\n+\n", p)
+            if q > 0:
+                b[q:q + 3] = b"\n+extra\n"
+        else:
+            q = b.find(b"\n", p)
+            if q > 0:
+                b[q + 40:q + 40] = b"\n"           # wraps one line
+    return bytes(b)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fast_path_edits(gpu_ctx, hipmod, oracle, seed):
+    """Regular four-line records with a few random edits: the fast path must reproduce the
+    oracle (rows, end state, decoded qualities) or decline; tools/stress_fast4.py is the long run."""
+    rng = np.random.default_rng(9000 + seed)
+    lo, hi = ((100, 160), (20, 60), (250, 400), (1, 30))[seed % 4]
+    data = random_records(rng, int(rng.integers(500, 4000)), lo, hi, wrap=0, repeat_hdr=bool(seed & 1))
+    data = mutate(rng, data, (0, 1, 3, 12)[(seed // 4) % 4])
+    if seed % 3 == 0:
+        data = data[:len(data) - int(rng.integers(1, 300))]
+    for kw in (dict(), dict(eof=False), dict(offset=len(data) // 3), dict(sentinel=False, offset=5)):
+        gpu_ctx.forget()
+        want, end, status, off = oracle.scan(data, **kw)
+        table, res, qual, qoff = gpu_ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL, **kw)
+        assert int(res.end_state) == end and int(res.last_status) == status and int(res.end_offset) == off
+        assert table.shape == want.shape and (table == want).all()
+        wq, wqoff = oracle.decode_quals(data, want)
+        assert (qoff == wqoff).all() and (qual == wq).all()

@@ -1,0 +1,48 @@
+"""Stress of the four-line fast path: regular 4-line records with a few random edits (bytes
+turned into newlines / '@' / '+', bytes deleted or inserted, records wrapped, CRLF, a cut end),
+GPU scan (+decode) vs oracle.  The fast path must either reproduce the oracle or decline.
+tools/stress_fast4.py [seeds]"""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+import fastqandfurious_amd
+from fastqandfurious_amd import hip
+from oracle import ffq_oracle as oracle
+import test_gpu_parity as T
+
+
+def main():
+    ctx = hip.default_context(0)
+    nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    bad = 0
+    paths = {}
+    for seed in range(nseeds):
+        rng = np.random.default_rng(9000 + seed)
+        lo, hi = ((100, 160), (20, 60), (250, 400), (1, 30), (1000, 3000))[seed % 5]
+        nrec = int(rng.integers(200, 6000)) if hi < 1000 else int(rng.integers(50, 600))
+        data = T.random_records(rng, nrec, lo, hi, wrap=0, repeat_hdr=bool(seed & 1))
+        nedits = (0, 1, 2, 5, 20)[(seed // 5) % 5]
+        data = T.mutate(rng, data, nedits)
+        if seed % 3 == 0:
+            data = data[:len(data) - int(rng.integers(1, 300))]
+        ctx.forget()
+        for kw in (dict(), dict(eof=False), dict(offset=len(data) // 3), dict(sentinel=False, offset=5)):
+            want, end, status, off = oracle.scan(data, **kw)
+            table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL, **kw)
+            wq, wqoff = oracle.decode_quals(data, want)
+            ok = (table.shape == want.shape and (table == want).all() and int(res.end_state) == end and
+                  int(res.last_status) == status and int(res.end_offset) == off and (qoff == wqoff).all()
+                  and (qual == wq).all())
+            key = (nedits, int(res.path))
+            paths[key] = paths.get(key, 0) + 1
+            if not ok:
+                bad += 1
+                print("MISMATCH seed", seed, kw, "edits", nedits, "path", res.path, "n", len(want), int(res.n_records),
+                      flush=True)
+            ctx.forget()
+    print("seeds", nseeds, "mismatches", bad, "paths (edits, path) -> count", dict(sorted(paths.items())))
+
+
+if __name__ == "__main__":
+    main()
