@@ -1,7 +1,8 @@
 """Stress of the four-line fast path: regular 4-line records with a few random edits (bytes
 turned into newlines / '@' / '+', bytes deleted or inserted, records wrapped, CRLF, a cut end),
 GPU scan (+decode) vs oracle.  The fast path must either reproduce the oracle or decline.
-tools/stress_fast4.py [seeds]"""
+tools/stress_fast4.py [seeds] [wrapped]   (wrapped: the same edits on records folded at 60-100
+columns -- the general path's kernels, repairs included)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -15,13 +16,15 @@ import test_gpu_parity as T
 def main():
     ctx = hip.default_context(0)
     nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    wrapped = len(sys.argv) > 2 and sys.argv[2] == "wrapped"
     bad = 0
     paths = {}
     for seed in range(nseeds):
         rng = np.random.default_rng(9000 + seed)
         lo, hi = ((100, 160), (20, 60), (250, 400), (1, 30), (1000, 3000))[seed % 5]
         nrec = int(rng.integers(200, 6000)) if hi < 1000 else int(rng.integers(50, 600))
-        data = T.random_records(rng, nrec, lo, hi, wrap=0, repeat_hdr=bool(seed & 1))
+        data = T.random_records(rng, nrec, lo, hi, wrap=int(rng.integers(60, 101)) if wrapped else 0,
+                                repeat_hdr=bool(seed & 1))
         nedits = (0, 1, 2, 5, 20)[(seed // 5) % 5]
         data = T.mutate(rng, data, nedits)
         if seed % 3 == 0:
