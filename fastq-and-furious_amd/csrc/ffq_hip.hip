@@ -1192,6 +1192,8 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         if (r == 2) HIPCHK(hipEventRecord(c->ev[0], c->stream));
         if (mode == 2)
             launch_scan_lines(c, c->stream, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@');
+        else if (mode == 6)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_read_probe<2>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_buf, ntiles, sink);
         else if (mode == 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_read_probe<0>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_buf, ntiles, sink);
         else

@@ -842,6 +842,17 @@ __global__ __launch_bounds__(256) void k_read_probe(const uint8_t *__restrict__ 
         for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const uint4 *>(d + base + w * 4096 + i * 1024 + l * 16);
 #pragma unroll
         for (int i = 0; i < 4; i++) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    } else if (MODE == 2) {
+        // MODE 0 with the scan kernel's non-temporal loads
+        const int64_t base = (int64_t)blockIdx.x << TILE_SHIFT;
+        const int w = tid >> 6, l = tid & 63;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(d + base + w * 4096 + i * 1024 + l * 16));
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
     } else {
         const int64_t nvec = ntiles << (TILE_SHIFT - 4);
         const int64_t stride = (int64_t)gridDim.x * 256;

@@ -248,8 +248,10 @@ int ffq_synth_wrapped(ffq_ctx *ctx, uint8_t *d_out, const int64_t *d_start,
 
 /* Measured streaming-read ceiling of the device in the scan kernel's launch geometry
  * (mode 0) or as a grid-stride loop (mode 1): average ms over `reps` launches of a
- * kernel that only reads n_bytes (rounded down to 16 KiB).  Mode 2: the line-index kernel
- * itself, launched back to back without the rest of a scan.  Diagnostics.               */
+ * kernel that only reads n_bytes (rounded down to 16 KiB); mode 6: mode 0 with non-temporal
+ * loads.  Modes 2 / 3 / 4: the line-index kernel itself without the rest of a scan, launched
+ * back to back / between its own pair of events / the same on a buffer with a ragged last
+ * tile.  Diagnostics.                                                                    */
 int ffq_read_probe(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes, int mode, int reps,
                    float *ms_avg);
 

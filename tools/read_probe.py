@@ -14,6 +14,7 @@ ctx.reserve(n * 322)
 for rnd in range(4):
     a = ctx.read_probe(buf.data_ptr(), n * 322, 0, 10)
     b = ctx.read_probe(buf.data_ptr(), n * 322, 1, 10)
+    nt = ctx.read_probe(buf.data_ptr(), n * 322, 6, 10)
     k = ctx.read_probe(buf.data_ptr(), n * 322, 2, 10)
     k3 = ctx.read_probe(buf.data_ptr(), n * 322, 3, 10)
     k4 = ctx.read_probe(buf.data_ptr(), n * 322, 4, 10)
@@ -26,7 +27,7 @@ for rnd in range(4):
         rc, res = ctx.scan_device(buf.data_ptr(), (n * 322) >> 14 << 14, table.data_ptr(), n + 64)
         idx2.append(res.ms_index)
     gb = n * 322 / 1e9
-    print("round %d: read probe tile/block %.1f us (%.2f TB/s)  grid-stride %.1f us (%.2f TB/s)  k_scan_lines in a step %.1f (mean %.1f) us, alone back to back %.1f us, alone between events %.1f us (ragged variant %.1f us)"
-          % (rnd, a * 1e3, gb / a, b * 1e3, gb / b, min(idx) * 1e3, sum(idx) / len(idx) * 1e3, k * 1e3, k3 * 1e3, k4 * 1e3), flush=True)
+    print("round %d: read probe tile/block %.1f us (%.2f TB/s)  grid-stride %.1f us (%.2f TB/s)  tile/block non-temporal %.1f us (%.2f TB/s)  k_scan_lines in a step %.1f (mean %.1f) us, alone back to back %.1f us, alone between events %.1f us (ragged variant %.1f us)"
+          % (rnd, a * 1e3, gb / a, b * 1e3, gb / b, nt * 1e3, gb / nt, min(idx) * 1e3, sum(idx) / len(idx) * 1e3, k * 1e3, k3 * 1e3, k4 * 1e3), flush=True)
     print("   k_scan_lines of the 5 scans after the probes:", " ".join("%.1f" % (x * 1e3) for x in idx),
           "| whole tiles only:", " ".join("%.1f" % (x * 1e3) for x in idx2))
