@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="single-1g", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle-ms", type=float, default=50.0,
+                    help="untimed steps in front of the warm-up until the GPU has been busy this long "
+                         "(its clocks take ~15 ms of load to settle after an idle spell); 0: none")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--sharded-step", action="store_true",
                     help="N=1 through the synchronous step the N>1 ranks run (diagnostics)")
@@ -281,6 +284,12 @@ def main():
         torch.cuda.synchronize()
 
     ms_index, ms_chain, ms_decode, ms_total = [], [], [], []
+    # Settling: after the set-up above the GPU has idled and its clocks have dropped; the index
+    # kernel of the first ~15 ms of steps runs 5-7 % slower than in steady state
+    # (tools/k1_timeline.py).  The untimed phase therefore starts with as many extra steps as make
+    # ~settle-ms of GPU work -- a count computed from the workload's size, the same on every rank.
+    settle_steps = int(args.settle_ms * 1e-3 / (wl["bytes"] / 4.0e12)) if args.settle_ms > 0 else 0
+    n_untimed = settle_steps + args.warmup
 
     def note(out):
         ms_index.append(out.res.ms_index)
@@ -327,8 +336,8 @@ def main():
                 note(out)
             return out
 
-        if args.warmup:
-            out = run(args.warmup, False)
+        if n_untimed:
+            out = run(n_untimed, False)
         barrier()
         t0 = time.perf_counter()
         out = run(args.steps, True)
@@ -339,7 +348,7 @@ def main():
         def step():
             return shard.scan(table, flags=flags, qual=qual, qoff=qoff)
 
-        for _ in range(args.warmup):
+        for _ in range(n_untimed):
             out = step()
         barrier()
         t0 = time.perf_counter()
@@ -373,8 +382,8 @@ def main():
                 note(out)
             return out
 
-        if args.warmup:
-            out = run(args.warmup, False)
+        if n_untimed:
+            out = run(n_untimed, False)
         barrier()
         t0 = time.perf_counter()
         out = run(args.steps, True)
@@ -417,6 +426,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle_steps,
             "ms_per_step": round(ms_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
