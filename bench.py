@@ -344,6 +344,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         table = tables[(args.steps - 1) & 1]
+        qual, qoff = quals[(args.steps - 1) & 1], qoffs[(args.steps - 1) & 1]
     elif world == 1:
         def step():
             return shard.scan(table, flags=flags, qual=qual, qoff=qoff)
@@ -390,6 +391,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         table = tables[(args.steps - 1) & 1]
+        qual, qoff = quals[(args.steps - 1) & 1], qoffs[(args.steps - 1) & 1]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -403,6 +405,8 @@ def main():
 
     # ---- parity spot check on the measured output (size-independent properties) -----
     shard.verify(table, out)
+    if decode:
+        shard.verify_decode(table, out, qual, qoff)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

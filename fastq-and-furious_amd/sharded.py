@@ -403,3 +403,34 @@ class SyntheticShard:
             assert bool((rows[:, 1] == st[k0:k1] + 17).all())
             assert bool((rows[:, 5] == st[k0 + 1:k1 + 1] - 1).all()), "record ends differ"
             assert bool((rows[:, 5] - rows[:, 4] == rows[:, 3] - rows[:, 2]).all())
+
+    def verify_decode(self, table, out, qual, qoff):
+        """The decode's output at full size, with torch ops only: the CSR offsets must be the
+        running sum of pos5 - pos4 over ALL rows of the scan, and the decoded bytes of a spread of
+        records must be the buffer's bytes [pos4, pos5) minus 33 (int8 arithmetic)."""
+        import torch
+        n = int(out.n_rows)
+        lens = table[:n, 5] - table[:n, 4]
+        assert int(qoff[0].item()) == 0, "quality offsets do not start at 0"
+        assert bool((qoff[1:n + 1] - qoff[:n] == lens).all()), "quality offsets are not the running sum of pos5 - pos4"
+        assert int(qoff[n].item()) == int(out.res.n_qual_bytes), "closing quality offset differs from the reported total"
+        if n == 0:
+            return
+        shift = self.own_lo - self.tail                      # file offset of ext[0]
+        idx = torch.unique(torch.cat([torch.arange(0, min(n, 64), device=table.device),
+                                      torch.linspace(0, n - 1, 4096, device=table.device).long(),
+                                      torch.arange(max(n - 64, 0), n, device=table.device)]))
+        p4 = table[idx, 4] - shift
+        ln = lens[idx]
+        q0 = qoff[idx]
+        if self.kind == "single":
+            assert bool((ln == 150).all())
+            ar = torch.arange(150, device=table.device)
+            src = self.ext[(p4[:, None] + ar[None, :]).reshape(-1)].to(torch.int16) - 33
+            got = qual[(q0[:, None] + ar[None, :]).reshape(-1)].to(torch.int16)
+            assert bool((src == got).all()), "decoded qualities differ from the buffer's bytes - 33"
+        else:
+            for a, l, q in zip(p4[::8].tolist(), ln[::8].tolist(), q0[::8].tolist()):
+                src = (self.ext[a:a + l].to(torch.int16) - 33).to(torch.int8)
+                assert bool((src == qual[q:q + l]).all()), "decoded qualities differ from the buffer's bytes - 33"
+

@@ -542,3 +542,32 @@ def test_fast_path_edits(gpu_ctx, hipmod, oracle, seed):
         assert table.shape == want.shape and (table == want).all()
         wq, wqoff = oracle.decode_quals(data, want)
         assert (qoff == wqoff).all() and (qual == wq).all()
+
+
+@pytest.mark.parametrize("kind", ("single", "wrapped"))
+def test_bench_verifiers_accept_and_reject(gpu_ctx, hipmod, pkg, kind):
+    """bench.py's full-size checks (closed form of the rows; CSR offsets and decoded bytes against
+    the buffer) on a small shard: they pass on the scan's output and fail on a corrupted one."""
+    import torch
+    from fastqandfurious_amd import sharded
+    dev = torch.device("cuda:0")
+    sh = sharded.SyntheticShard(gpu_ctx, kind, 8 << 20, 0, 1, dev)
+    table = torch.empty((sh.max_records + 64, 6), dtype=torch.int64, device=dev)
+    qual = torch.empty(sh.ext.numel(), dtype=torch.int8, device=dev)
+    qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
+    out = sh.scan(table, flags=hipmod.F_DECODE_QUAL, qual=qual, qoff=qoff)
+    sh.verify(table, out)
+    sh.verify_decode(table, out, qual, qoff)
+    n = int(out.n_rows)
+    k = int(qoff[8].item()) + 3            # (a record of the verifier's sample: the first 64 always are)
+    qual[k] += 1
+    with pytest.raises(AssertionError):
+        sh.verify_decode(table, out, qual, qoff)
+    qual[k] -= 1
+    qoff[n // 3] += 1
+    with pytest.raises(AssertionError):
+        sh.verify_decode(table, out, qual, qoff)
+    qoff[n // 3] -= 1
+    table[n // 2, 3] += 1
+    with pytest.raises(AssertionError):
+        sh.verify(table, out)
