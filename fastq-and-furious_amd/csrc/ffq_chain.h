@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(1024) void k_resolve_b(ChainBufs B, int nblk, int e
 __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__restrict__ res, int64_t add,
                                                int64_t *__restrict__ table, int64_t table_cap,
                                                int64_t *__restrict__ qoff, int64_t *__restrict__ qdir,
-                                               int64_t qdir_cap)
+                                               int64_t qdir_cap, int64_t *__restrict__ p4s, int64_t p4_cap)
 {
     __shared__ __attribute__((aligned(16))) int64_t s_rows[64 * 6];
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -1126,6 +1126,7 @@ __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__rest
             const int64_t incl = ((int64_t)hi << 16) + (int64_t)lo;
             const int64_t myq = q0 + incl - ql;
             if (ok && r0 + dd < table_cap) { qoff[r0 + dd] = myq; qdir_mark(qdir, qdir_cap, myq, ql, r0 + dd); }
+            if (ok && r0 + dd < p4_cap) p4s[r0 + dd] = p4;            // compact pos4 for the decode
             q0 += ((int64_t)__shfl((int)hi, 63) << 16) + (int64_t)(uint32_t)__shfl((int)lo, 63);
         }
         int64_t *mine = s_rows + lane * 6;

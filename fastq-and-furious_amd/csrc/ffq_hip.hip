@@ -88,6 +88,8 @@ struct ffq_ctx {
     DevRes *dres = nullptr;
     int64_t *qdir = nullptr;           // directory of the decoded-quality stream (qdir_mark)
     int64_t qdir_cap = 0;
+    int64_t *p4s = nullptr;            // pos4 of every record, compact: what the decode reads instead of the 48-byte rows
+    int64_t p4s_cap = 0;
     // pinned mirrors
     Ctl *h_ctl = nullptr;               // host-mapped pinned: written by the publishing kernel (Pub)
     DevRes *h_res = nullptr;
@@ -211,7 +213,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     free_chain(c);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
-    (void)hipFree(c->qdir);
+    (void)hipFree(c->qdir); (void)hipFree(c->p4s);
     (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_word) (void)hipHostFree(c->h_word);
@@ -302,6 +304,21 @@ static int reserve_qdir(ffq_ctx *c, int64_t blocks)
     hipError_t e = hipMalloc((void **)&c->qdir, (size_t)blocks * sizeof(int64_t));
     if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(qdir) failed: %s", hipGetErrorString(e));
     c->qdir_cap = blocks;
+    return FFQ_OK;
+}
+
+// one int64 per possible record of this scan (a record starts with "\n@" and has three more
+// newlines: no more than a quarter of the bytes), capped by the caller's table
+static int64_t p4s_need(int64_t n_bytes, int64_t table_cap) { return std::min<int64_t>(table_cap, n_bytes / 4 + 2); }
+static int reserve_p4s(ffq_ctx *c, int64_t entries)
+{
+    if (entries <= c->p4s_cap) return FFQ_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->p4s);
+    c->p4s = nullptr; c->p4s_cap = 0;
+    hipError_t e = hipMalloc((void **)&c->p4s, (size_t)entries * sizeof(int64_t));
+    if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(p4s) failed: %s", hipGetErrorString(e));
+    c->p4s_cap = entries;
     return FFQ_OK;
 }
 
@@ -439,8 +456,9 @@ static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st, bool t
     const int64_t nblk = qdir_blocks(a.n_bytes, a.qual_cap);
     static const int ablate = getenv("FFQ_DQ_ABLATE") ? atoi(getenv("FFQ_DQ_ABLATE")) : 0;
     hipLaunchKernelGGL(k_decode_stream, dim3((unsigned)nblk), dim3(256), 0, st, a.d_buf, a.n_bytes, a.s,
-                       (const int64_t *)a.d_table, (const int64_t *)a.d_qoff, (const int64_t *)c->qdir,
-                       (const DevRes *)c->dres, a.table_cap, a.add, a.qual_add, a.d_qual, a.qual_cap, ablate);
+                       (const int64_t *)c->p4s, (const int64_t *)a.d_qoff, (const int64_t *)c->qdir,
+                       (const DevRes *)c->dres, std::min<int64_t>(a.table_cap, c->p4s_cap), a.add, a.qual_add, a.d_qual,
+                       a.qual_cap, ablate);
 }
 
 static Pub make_pub(ffq_ctx *c) { return Pub{c->ctl, c->hm_ctl, c->hm_res}; }
@@ -458,7 +476,8 @@ static int enqueue_resolve(ffq_ctx *c, const ScanArgs &a, const ChainBufs &cb, b
     hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sA, cb);
     hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sA, cb, nblk, a.eof, a.offset, a.add, c->dres);
     hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sA, cb, (const DevRes *)c->dres, a.add, a.d_table,
-                       a.table_cap, qoff, c->qdir, c->qdir_cap);
+                       a.table_cap, qoff, c->qdir, c->qdir_cap, qoff ? c->p4s : (int64_t *)nullptr,
+                       qoff ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sA, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff,
                        make_pub(c));
     c->ctl_clean = true;
@@ -566,7 +585,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         if (decode) HIPCHK(hipMemsetAsync(c->tileq, 0, (size_t)ntiles * sizeof(TileQ), sA));
         hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
-                           decode ? a.d_qoff : (int64_t *)nullptr, c->tileq);
+                           decode ? a.d_qoff : (int64_t *)nullptr, c->tileq, decode ? c->p4s : (int64_t *)nullptr,
+                           decode ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0);
         hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                            a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres,
                            decode ? no_pub(c) : make_pub(c));
@@ -733,7 +753,8 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             path = 1;
             HIPCHK(hipEventRecord(c->ev[4], sA));
             hipLaunchKernelGGL(k_chain_serial, dim3(1), dim3(64), 0, sA, L, a.offset, a.eof, a.add, a.d_table,
-                               a.table_cap, qoff, c->qdir, c->qdir_cap, c->dres);
+                               a.table_cap, qoff, c->qdir, c->qdir_cap, qoff ? c->p4s : (int64_t *)nullptr,
+                               qoff ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0, c->dres);
             hipLaunchKernelGGL(k_finalize_serial, dim3(1), dim3(64), 0, sA, c->dres, a.table_cap, qoff, make_pub(c));
             c->ctl_clean = true;
             if (decode) enqueue_decode(c, a, sA);
@@ -781,6 +802,7 @@ extern "C" int ffq_scan_submit(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
     int rc = reserve_tiles(c, st.ntiles);
     if (!rc) rc = reserve_pool(c, 1ull << 20);
     if (!rc && (flags & FFQ_F_DECODE_QUAL)) rc = reserve_qdir(c, qdir_blocks(n_bytes, qual_cap));
+    if (!rc && (flags & FFQ_F_DECODE_QUAL)) rc = reserve_p4s(c, p4s_need(n_bytes, table_cap));
     if (!rc) {
         st.ngroups = (int)groups_for(st.ntiles);
         rc = enqueue_front(c, st);

@@ -299,7 +299,8 @@ __device__ void wv_record(const LineIndex &L, H k, int64_t Pk, int64_t len, int 
 __global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add,
                                                      int64_t *__restrict__ table, int64_t table_cap,
                                                      int64_t *__restrict__ qoff, int64_t *__restrict__ qdir,
-                                                     int64_t qdir_cap, DevRes *res)
+                                                     int64_t qdir_cap, int64_t *__restrict__ p4s, int64_t p4_cap,
+                                                     DevRes *res)
 {
     if (blockIdx.x != 0) return;
     const int lane = threadIdx.x & 63;
@@ -321,7 +322,10 @@ __global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset
             int64_t *o = table + n * 6;
             o[0] = r.p0 + add; o[1] = r.p1 + add; o[2] = r.p1 + 1 + add;
             o[3] = r.p3 + add; o[4] = r.p4 + add; o[5] = r.p5 + add;
-            if (qoff) { qoff[n] = qb; qdir_mark(qdir, qdir_cap, qb, r.p5 - r.p4, n); }
+            if (qoff) {
+                qoff[n] = qb; qdir_mark(qdir, qdir_cap, qb, r.p5 - r.p4, n);
+                if (n < p4_cap) p4s[n] = r.p4 + add;
+            }
         }
         n++;
         qb += r.p5 - r.p4;
@@ -388,7 +392,9 @@ __global__ void k_publish(DevRes *res, Pub pb)
 // (offset, source) of the records under its block in LDS and gathers every chunk from its
 // record(s) with unaligned 16-byte loads, DQ_PER chunks per thread in flight.  Stores are
 // whole aligned 16-byte pieces, 1 KiB per wave instruction.
-// Algorithmic traffic per record: quality bytes read + written, 16 B of (qoff, pos4) read.
+// Algorithmic traffic per record: quality bytes read + written, 16 B of (qoff, pos4) read
+// (pos4 from the compact copy the row kernels write beside the table: the 48-byte rows would
+// come in whole lines, 1.5 GiB instead of 0.25 per 10 GiB of input).
 // =========================================================================
 constexpr int DQ_PER = 4;                         // chunks per thread and batch
 constexpr int DQ_BLK = 1 << DQ_SHIFT;             // output bytes per workgroup
@@ -456,7 +462,7 @@ __device__ __noinline__ uint4 gather_tail(const uint8_t *__restrict__ d, const i
 }
 
 __global__ __launch_bounds__(256) void k_decode_stream(const uint8_t *__restrict__ d, int64_t nbytes, int s,
-                                                       const int64_t *__restrict__ table,
+                                                       const int64_t *__restrict__ p4s,
                                                        const int64_t *__restrict__ qoff,
                                                        const int64_t *__restrict__ qdir,
                                                        const DevRes *__restrict__ res,
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(256) void k_decode_stream(const uint8_t *__restrict
             // both loads before either is used (the source position of index nrec is not needed:
             // a clamped address keeps the load unconditional)
             const int64_t qraw = qoff[rbase + i];
-            const int64_t p4 = table[(rbase + min(i, nrec - 1)) * 6 + 4];
+            const int64_t p4 = p4s[rbase + min(i, nrec - 1)];            // (pos4 of the rows, compact)
             asm volatile("" ::"v"(qraw), "v"(p4));
             const int64_t q = qraw - ob;
             s_q[i] = (int32_t)min(max(q, (int64_t)-0x7FFFFFFF), (int64_t)0x7FFFFFFF);

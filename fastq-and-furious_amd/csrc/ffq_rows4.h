@@ -231,7 +231,8 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
 __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap,
-                                               int64_t *__restrict__ qoff, TileQ *__restrict__ tileq)
+                                               int64_t *__restrict__ qoff, TileQ *__restrict__ tileq,
+                                               int64_t *__restrict__ p4s, int64_t p4_cap)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_ent_all[4][R4_LIST];   // the tile's own entries as stored (offset | flags << 14),
                                                                               // then (usually) the first five of the next tile
@@ -487,6 +488,8 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                 const uint32_t ql = emit ? (uint32_t)(f5 - f4) : 0u;
                 const uint32_t incl = wave_incl_scan(ql);
                 if (act && kfirst + r < table_cap) qoff[kfirst + r] = (int64_t)(qrun + incl - ql);
+                // pos4 once more, compact: the decode reads 8 bytes per record instead of the row's line
+                if (emit && kfirst + r < p4_cap) p4s[kfirst + r] = tb_add + f4;
                 qrun += (uint32_t)__shfl((int)incl, 63);
             }
             int2 *mine = reinterpret_cast<int2 *>(s_rows + lane * 6);
