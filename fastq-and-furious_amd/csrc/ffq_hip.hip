@@ -90,6 +90,7 @@ struct ffq_ctx {
     int64_t qdir_cap = 0;
     int64_t *p4s = nullptr;            // pos4 of every record, compact: what the decode reads instead of the 48-byte rows
     int64_t p4s_cap = 0;
+    uint32_t *qrel = nullptr;          // tile-relative quality offsets of the fast path (p4s_cap entries)
     // pinned mirrors
     Ctl *h_ctl = nullptr;               // host-mapped pinned: written by the publishing kernel (Pub)
     DevRes *h_res = nullptr;
@@ -213,7 +214,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     free_chain(c);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
-    (void)hipFree(c->qdir); (void)hipFree(c->p4s);
+    (void)hipFree(c->qdir); (void)hipFree(c->p4s); (void)hipFree(c->qrel);
     (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_word) (void)hipHostFree(c->h_word);
@@ -314,9 +315,10 @@ static int reserve_p4s(ffq_ctx *c, int64_t entries)
 {
     if (entries <= c->p4s_cap) return FFQ_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->p4s);
-    c->p4s = nullptr; c->p4s_cap = 0;
+    (void)hipFree(c->p4s); (void)hipFree(c->qrel);
+    c->p4s = nullptr; c->qrel = nullptr; c->p4s_cap = 0;
     hipError_t e = hipMalloc((void **)&c->p4s, (size_t)entries * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->qrel, (size_t)entries * sizeof(uint32_t));
     if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(p4s) failed: %s", hipGetErrorString(e));
     c->p4s_cap = entries;
     return FFQ_OK;
@@ -585,7 +587,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         if (decode) HIPCHK(hipMemsetAsync(c->tileq, 0, (size_t)ntiles * sizeof(TileQ), sA));
         hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
-                           decode ? a.d_qoff : (int64_t *)nullptr, c->tileq, decode ? c->p4s : (int64_t *)nullptr,
+                           decode ? c->qrel : (uint32_t *)nullptr, c->tileq, decode ? c->p4s : (int64_t *)nullptr,
                            decode ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0);
         hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                            a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres,
@@ -599,7 +601,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
             hipLaunchKernelGGL(k_qscan4, dim3(1), dim3(1024), 0, sA, (const unsigned int *)c->sbq, nsb, c->sbqbase);
             hipLaunchKernelGGL(k_qfix4, dim3((unsigned)((ntiles + 7) / 8)), dim3(256), 0, sA, (int)ntiles,
                                (const Fast4Hdr *)c->hdr4, (const TileQ *)c->tileq, (const long long *)c->sbqbase,
-                               a.d_qoff, a.table_cap, c->qdir, c->qdir_cap);
+                               (const uint32_t *)c->qrel, a.d_qoff, std::min<int64_t>(a.table_cap, c->p4s_cap), c->qdir,
+                               c->qdir_cap);
             hipLaunchKernelGGL(k_qtotal4, dim3(1), dim3(1), 0, sA, c->dres, (const int64_t *)a.d_table, a.table_cap,
                                a.d_qoff, make_pub(c));
             enqueue_decode(c, a, sA, true);

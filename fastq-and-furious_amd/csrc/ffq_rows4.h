@@ -231,7 +231,7 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
 __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap,
-                                               int64_t *__restrict__ qoff, TileQ *__restrict__ tileq,
+                                               uint32_t *__restrict__ qrel, TileQ *__restrict__ tileq,
                                                int64_t *__restrict__ p4s, int64_t p4_cap)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_ent_all[4][R4_LIST];   // the tile's own entries as stored (offset | flags << 14),
@@ -483,11 +483,12 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
             if (__ballot(act && (cls == 2 || cls == 3)) != 0ull) tile_term_done = true;      // (wave-uniform)
             // rows: COMPLETE records (cls 0, 3) and the final record
             const bool emit = act && (cls == 0 || cls == 3 || (cls == 2 && fin));
-            if (qoff) {
-                // tile-relative offsets of the decoded qualities; k_qfix4 adds the tile's base
+            if (qrel) {
+                // tile-relative offsets of the decoded qualities (32 bits, scratch); k_qfix4 adds the
+                // tile's base and writes the caller's 64-bit offsets
                 const uint32_t ql = emit ? (uint32_t)(f5 - f4) : 0u;
                 const uint32_t incl = wave_incl_scan(ql);
-                if (act && kfirst + r < table_cap) qoff[kfirst + r] = (int64_t)(qrun + incl - ql);
+                if (act && kfirst + r < p4_cap) qrel[kfirst + r] = qrun + incl - ql;
                 // pos4 once more, compact: the decode reads 8 bytes per record instead of the row's line
                 if (emit && kfirst + r < p4_cap) p4s[kfirst + r] = tb_add + f4;
                 qrun += (uint32_t)__shfl((int)incl, 63);
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
             wave_sync();
         }
     }
-    if (qoff && lane == 0 && nrec_tile > 0) tileq[t] = TileQ{kfirst, nrec_tile, qrun};
+    if (qrel && lane == 0 && nrec_tile > 0) tileq[t] = TileQ{kfirst, nrec_tile, qrun};
 }
 
 // exclusive scan of the per-superblock quality bytes (one workgroup)
@@ -552,8 +553,8 @@ __global__ __launch_bounds__(1024) void k_qscan4(const unsigned int *__restrict_
 __global__ __launch_bounds__(256) void k_qfix4(int ntiles, const Fast4Hdr *__restrict__ hdr,
                                                const TileQ *__restrict__ tileq,
                                                const long long *__restrict__ sbqbase,
-                                               int64_t *__restrict__ qoff, int64_t table_cap,
-                                               int64_t *__restrict__ qdir, int64_t qdir_cap)
+                                               const uint32_t *__restrict__ qrel, int64_t *__restrict__ qoff,
+                                               int64_t table_cap, int64_t *__restrict__ qdir, int64_t qdir_cap)
 {
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int t = (blockIdx.x * 4 + wid) * 2;            // tiles t and t + 1 (same superblock: SB_TILES is even)
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256) void k_qfix4(int ntiles, const Fast4Hdr *__res
     // first 64 records of both tiles: both loads before either is used
     const int64_t i0 = me0.kfirst + lane, i1 = me1.kfirst + lane;
     const bool a0 = lane < me0.nrec && i0 < table_cap, a1 = lane < me1.nrec && i1 < table_cap;
-    const int64_t l0 = a0 ? qoff[i0] : 0, l1 = a1 ? qoff[i1] : 0;
+    const int64_t l0 = a0 ? (int64_t)qrel[i0] : 0, l1 = a1 ? (int64_t)qrel[i1] : 0;
     asm volatile("" ::"v"(l0), "v"(l1));
     auto fix = [&](const TileQ &me, int64_t base, int r0, int64_t loc, bool act) {
         const int r = r0 + lane;
@@ -583,19 +584,17 @@ __global__ __launch_bounds__(256) void k_qfix4(int ntiles, const Fast4Hdr *__res
         // the record's bytes end where the next record's begin
         int64_t nxt = ((int64_t)__shfl((int)(loc >> 32), lane + 1) << 32) | (uint32_t)__shfl((int)(uint32_t)loc, lane + 1);
         if (r + 1 >= me.nrec) nxt = me.qsum;
-        else if (lane == 63) nxt = (idx + 1 < table_cap) ? qoff[idx + 1] : (int64_t)me.qsum;
+        else if (lane == 63) nxt = (idx + 1 < table_cap) ? (int64_t)qrel[idx + 1] : (int64_t)me.qsum;
         if (act) {
             qoff[idx] = base + loc;
             qdir_mark(qdir, qdir_cap, base + loc, nxt - loc, idx);
         }
     };
-    // (lane 63 looks at qoff[idx + 1], the first record of the next chunk, which must still hold
-    // its tile-relative value: chunks go first to last)
     auto rest = [&](const TileQ &me, int64_t base) {
         for (int r0 = 64; r0 < me.nrec; r0 += 64) {
             const int64_t idx = me.kfirst + r0 + lane;
             const bool act = r0 + lane < me.nrec && idx < table_cap;
-            fix(me, base, r0, act ? qoff[idx] : 0, act);
+            fix(me, base, r0, act ? (int64_t)qrel[idx] : 0, act);
         }
     };
     if (me0.nrec > 0) fix(me0, base0, 0, l0, a0);
