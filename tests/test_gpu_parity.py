@@ -571,3 +571,38 @@ def test_bench_verifiers_accept_and_reject(gpu_ctx, hipmod, pkg, kind):
     table[n // 2, 3] += 1
     with pytest.raises(AssertionError):
         sh.verify(table, out)
+
+
+@pytest.mark.parametrize("kind", ("single", "wrapped", "serial"))
+def test_table_too_small_with_decode(gpu_ctx, hipmod, oracle, pkg, kind):
+    """A table with fewer rows than the buffer has records: E_TABLE_FULL with the count needed,
+    the rows that fit are right, nothing is written past the table, the offsets or the quality
+    buffer (the device-side scratch of the decode is sized from the table too); then a retry
+    with enough room gives the whole answer."""
+    import torch
+    from fastqandfurious_amd import synth
+    gpu_ctx.forget()
+    data = synth.single(0, 3000, seed=5) if kind != "wrapped" else synth.wrapped(0, 3000, seed=6)[0]
+    flags = hipmod.F_DECODE_QUAL | (hipmod.F_FORCE_SERIAL if kind == "serial" else 0)
+    want, *_ = oracle.scan(data)
+    wq, wqoff = oracle.decode_quals(data, want)
+    n = len(want)
+    dbuf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    for cap in (1, 7, n // 2, n - 1):
+        table = torch.full((cap + 4, 6), -7, dtype=torch.int64, device="cuda")
+        qoff = torch.full((cap + 1 + 4,), -7, dtype=torch.int64, device="cuda")
+        qbuf = torch.full((wq.size + 64,), 99, dtype=torch.int8, device="cuda")
+        rc, res = gpu_ctx.scan_device(dbuf.data_ptr(), len(data), table.data_ptr(), cap, flags=flags,
+                                      d_qual=qbuf.data_ptr(), qual_cap=wq.size, d_qoff=qoff.data_ptr())
+        assert rc == hipmod.E_TABLE_FULL and int(res.n_records) == n
+        t = table.cpu().numpy()
+        assert (t[:cap] == want[:cap]).all() and (t[cap:] == -7).all()
+        assert (qoff[cap + 1:].cpu().numpy() == -7).all()
+        assert (qbuf[wq.size:].cpu().numpy() == 99).all()
+    table = torch.empty((n, 6), dtype=torch.int64, device="cuda")
+    qoff = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    qbuf = torch.empty(wq.size, dtype=torch.int8, device="cuda")
+    rc, res = gpu_ctx.scan_device(dbuf.data_ptr(), len(data), table.data_ptr(), n, flags=flags,
+                                  d_qual=qbuf.data_ptr(), qual_cap=wq.size, d_qoff=qoff.data_ptr())
+    assert rc == 0 and int(res.n_records) == n
+    assert (table.cpu().numpy() == want).all() and (qoff.cpu().numpy() == wqoff).all() and (qbuf.cpu().numpy() == wq).all()
