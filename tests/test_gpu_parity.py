@@ -606,3 +606,19 @@ def test_table_too_small_with_decode(gpu_ctx, hipmod, oracle, pkg, kind):
                                   d_qual=qbuf.data_ptr(), qual_cap=wq.size, d_qoff=qoff.data_ptr())
     assert rc == 0 and int(res.n_records) == n
     assert (table.cpu().numpy() == want).all() and (qoff.cpu().numpy() == wqoff).all() and (qbuf.cpu().numpy() == wq).all()
+
+
+def test_pool_grows_for_many_dense_tiles(hipmod, oracle):
+    """More pooled index entries than a fresh context's pool holds (1 Mi): the scan sizes the
+    pool for what was asked and runs again; same rows, with and without the decode."""
+    ctx = hipmod.Context(0)                     # a fresh context: its pool is at the initial size
+    rec = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(120000))      # ~2.3 MB, 7 entries per 34 bytes
+    data = b"\n" * (3 << 20) + rec
+    want, end, status, off = oracle.scan(data)
+    assert len(want) == 120000
+    table, res = ctx.scan_host(data, table_cap=130000)       # (one call: no retry for a larger table)
+    assert int(res.end_state) == end and int(res.last_status) == status and int(res.end_offset) == off
+    assert (table == want).all() and res.retries >= 1
+    table, res, qual, qoff = ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL)
+    wq, wqoff = oracle.decode_quals(data, want)
+    assert (table == want).all() and (qoff == wqoff).all() and (qual == wq).all()
