@@ -50,7 +50,15 @@ struct LineIndex {
     const uint32_t *cnt;       // [ntiles]
     const unsigned long long *ovf;   // [ntiles] pool offset of dense tiles
     const uint16_t *pool;
+    unsigned long long pool_cap;     // entries the pool holds
     __device__ __forceinline__ int64_t len() const { return n + s; }
+    // entry j of dense tile t.  A scan whose dense tiles outgrow the pool is run again with a
+    // larger one, but the kernels queued behind the index kernel of the failed attempt still
+    // run: what such a tile did not get to store reads as 0 instead of past the allocation.
+    __device__ __forceinline__ uint32_t pooled(int t, uint32_t j) const {
+        const unsigned long long at = ovf[t] + j;
+        return at < pool_cap ? (uint32_t)pool[at] : 0u;
+    }
 };
 
 // Handle of one line-index entry.  tile == -2: before everything,
@@ -83,8 +91,8 @@ struct GAcc {
             return;
         }
         const uint32_t c = L.cnt[h.tile];
-        const uint32_t e = (c <= (uint32_t)SLOT) ? L.ent[(int64_t)h.tile * SLOT + h.i]
-                                                 : L.pool[L.ovf[h.tile] + h.i];
+        const uint32_t e = (c <= (uint32_t)SLOT) ? (uint32_t)L.ent[(int64_t)h.tile * SLOT + h.i]
+                                                 : L.pooled(h.tile, (uint32_t)h.i);
         P = ((int64_t)h.tile << TILE_SHIFT) + (e & OFF_MASK) + L.s;
         fl = (int)(e >> 14);
     }

@@ -28,7 +28,7 @@ struct FaHdr {
 // flags + position of entry j of tile t (c = its count); tile -1 is the sentinel
 __device__ __forceinline__ uint32_t fa_entry(const LineIndex &L, int t, int j, uint32_t c)
 {
-    return (c <= (uint32_t)SLOT) ? L.ent[(int64_t)t * SLOT + j] : L.pool[L.ovf[t] + j];
+    return (c <= (uint32_t)SLOT) ? (uint32_t)L.ent[(int64_t)t * SLOT + j] : L.pooled(t, (uint32_t)j);
 }
 
 // is the entry before (t, j) a "\n>" at buffer coordinate >= offset?  (tb, jb) = that entry

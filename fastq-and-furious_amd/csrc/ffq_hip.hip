@@ -429,7 +429,7 @@ static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
 {
     LineIndex L;
     L.d = a.d_buf; L.n = a.n_bytes; L.s = a.s; L.ntiles = (int32_t)ntiles; L.ready = (int32_t)ntiles; L.pad_ = 0;
-    L.ent = c->ent; L.cnt = c->cnt; L.ovf = c->ovf; L.pool = c->pool;
+    L.ent = c->ent; L.cnt = c->cnt; L.ovf = c->ovf; L.pool = c->pool; L.pool_cap = c->pool_cap;
     return L;
 }
 
@@ -988,7 +988,8 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
     hipStream_t sA = c->stream;
     ScanArgs a{};
     a.d_buf = d_buf; a.n_bytes = n_bytes; a.s = sentinel ? 1 : 0;
-    for (int attempt = 0;; attempt++) {
+    int attempt = 0;
+    for (;; attempt++) {
         const LineIndex L = make_index(c, a, ntiles);
         if (!c->ctl_clean) HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));
         c->ctl_clean = false;
@@ -1020,7 +1021,7 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); res->ms_index = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[3])); res->ms_chain = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total = ms;
-    fill_result(res, *c->h_res, 4, 0);
+    fill_result(res, *c->h_res, 4, attempt);
     if (res->n_records > table_cap)
         return fail(FFQ_E_TABLE_FULL, "table holds %lld rows, the buffer has %lld FASTA entries", (long long)table_cap,
                     (long long)res->n_records);

@@ -240,7 +240,7 @@ __device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &o
             int64_t P = 0;
             uint32_t e = 0;
             if (j < c) {
-                e = (c <= (uint32_t)SLOT) ? L.ent[(int64_t)t * SLOT + j] : L.pool[L.ovf[t] + j];
+                e = (c <= (uint32_t)SLOT) ? (uint32_t)L.ent[(int64_t)t * SLOT + j] : L.pooled(t, j);
                 P = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
                 ok = (mask == 0 || ((int)(e >> 14) & mask)) && P >= minP;
             }

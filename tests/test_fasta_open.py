@@ -201,3 +201,22 @@ def test_fasta_gpu_plugin_scanner(F, golden, gpu_ctx, pkg):
             break
         assert F.entryfunc_fasta(buf, pos_g, 0) == F.entryfunc_fasta(buf, pos_p, 0)
         off_g, off_p = pos_g[3], pos_p[3]
+
+
+@pytest.mark.gpu
+def test_fasta_dense_tiles_and_pool_growth(oracle, pkg):
+    """Short FASTA lines (tiles over their slot -> pool) and more pooled entries than a fresh
+    context's pool holds: the scan grows the pool and runs again."""
+    import numpy as np
+    from fastqandfurious_amd import hip
+    ctx = hip.Context(0)
+    body = b"".join(b">s%d\nACG\nTT\n" % i for i in range(150000))          # ~2 MB, lines of 3-8 bytes
+    blob = b"\n" * (3 << 20) + body
+    want, st, last, loff = oracle.scan_fasta(blob)
+    table, res = ctx.scan_fasta_host(blob, table_cap=len(want) + 8)
+    assert len(want) >= 149999
+    assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
+    assert res.retries >= 1
+    table, res = ctx.scan_fasta_host(blob, offset=(3 << 20) + 12345)
+    want, st, last, loff = oracle.scan_fasta(blob, offset=(3 << 20) + 12345)
+    assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last

@@ -622,3 +622,20 @@ def test_pool_grows_for_many_dense_tiles(hipmod, oracle):
     table, res, qual, qoff = ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL)
     wq, wqoff = oracle.decode_quals(data, want)
     assert (table == want).all() and (qoff == wqoff).all() and (qual == wq).all()
+
+
+def test_pool_overflow_behind_a_dense_hint(hipmod, oracle):
+    """A context that remembers dense input starts the next scan with the dense-budget chain
+    kernel queued right behind the index kernel; if that scan outgrows the pool, the queued kernel
+    runs on an incomplete index (pooled entries that were not stored read as 0, never past the
+    allocation) and the scan is redone with a larger pool."""
+    ctx = hipmod.Context(0)
+    small = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(30000))        # dense tiles, fits the pool
+    for _ in range(2):
+        t, res = ctx.scan_host(small, table_cap=40000)
+        assert len(t) == 30000
+    big = b"\n" * (3 << 20) + b"".join(b"@q%d\nAC\n+\nII\n" % i for i in range(200000))
+    want, end, status, off = oracle.scan(big)
+    t, res = ctx.scan_host(big, table_cap=len(want) + 8)
+    assert int(res.end_state) == end and int(res.last_status) == status and int(res.end_offset) == off
+    assert (t == want).all() and res.retries >= 1
