@@ -405,6 +405,16 @@ def test_closed_form_at_size(gpu_ctx, pkg, mib):
     k = torch.arange(n, dtype=torch.int64, device="cuda") * 322
     want = torch.stack([k, k + 17, k + 18, k + 168, k + 171, k + 321], dim=1)
     assert bool((table[:n] == want).all())
+    # the same from an offset deep inside (past 2^31 in the large case): the search starts at the
+    # '\n' in front of record k0 (buffer coordinate 322 k0 with the sentinel), rows k0.. follow;
+    # also without eof: the last record is then held back (its quality could go on)
+    k0 = n - n // 17
+    rc, res = gpu_ctx.scan_device(buf.data_ptr(), n * 322, table.data_ptr(), n + 8, offset=322 * k0)
+    assert rc == 0 and int(res.n_records) == n - k0 and int(res.end_state) == 0
+    assert bool((table[:n - k0] == want[k0:]).all())
+    rc, res = gpu_ctx.scan_device(buf.data_ptr(), n * 322, table.data_ptr(), n + 8, offset=322 * k0, eof=False)
+    assert rc == 0 and int(res.n_records) == n - k0 - 1 and int(res.end_state) == 1
+    assert bool((table[:n - k0 - 1] == want[k0:n - 1]).all()) and int(res.end_offset) == 322 * (n - 1) - 1   # pos5 - 1 of the last complete record
     del buf, table, want, k
     torch.cuda.empty_cache()
 
