@@ -312,6 +312,11 @@ __device__ __noinline__ int64_t cand_after(const LineIndex *Lg, const uint32_t *
     const WAcc acc(*Lg, went, nwin, wt1, wpos0, defer, ready);
     WH hb; hb.g = H{0, 0};
     hb.idx = from;
+    // entries of the tiles in front of the one X falls into lie in front of X: a group far in
+    // front of the search offset of the scan goes straight there (entry by entry, every such
+    // group walked the index up to the offset: minutes for an offset GiB into a buffer)
+    const int64_t tX = (X - Lg->s) >> TILE_SHIFT;
+    if (tX >= (int64_t)wt1) { hb.idx = -1; hb.g = H{(int32_t)min(tX, (int64_t)0x7FFFFFF0) - 1, 0x7FFFFFF0}; }
     WH hs; int64_t Ps;
     return find_cand(acc, hb, X, hs, Ps) ? Ps : Y_NOCAND;
 }

@@ -649,3 +649,27 @@ def test_pool_overflow_behind_a_dense_hint(hipmod, oracle):
     t, res = ctx.scan_host(big, table_cap=len(want) + 8)
     assert int(res.end_state) == end and int(res.last_status) == status and int(res.end_offset) == off
     assert (t == want).all() and res.retries >= 1
+
+
+def test_wrapped_at_size_from_a_deep_offset(gpu_ctx, pkg):
+    """S-wrapped, 2.25 GiB, general path: the chain from offset 0 and from the '\\n' in front of a
+    record past 2^31 gives the generator's record starts and ends."""
+    import torch
+    from fastqandfurious_amd import sharded
+    dev = torch.device("cuda:0")
+    gpu_ctx.forget()
+    sh = sharded.SyntheticShard(gpu_ctx, "wrapped", 2304 << 20, 0, 1, dev)
+    n = sh.n_per
+    st = torch.from_numpy(sh.starts).to(dev)
+    table = torch.empty((sh.max_records + 64, 6), dtype=torch.int64, device=dev)
+    nbytes = sh.ext_scanned_bytes
+    rc, res = gpu_ctx.scan_device(sh.ext.data_ptr(), nbytes, table.data_ptr(), table.shape[0])
+    assert rc == 0 and int(res.n_records) == n and res.path == 0 and int(res.end_state) == 0
+    assert bool((table[:n, 0] == st[:n]).all()) and bool((table[:n, 5] == st[1:n + 1] - 1).all())
+    k0 = n - n // 13
+    assert int(sh.starts[k0]) > (1 << 31)
+    rc, res = gpu_ctx.scan_device(sh.ext.data_ptr(), nbytes, table.data_ptr(), table.shape[0], offset=int(sh.starts[k0]))
+    assert rc == 0 and int(res.n_records) == n - k0 and int(res.end_state) == 0
+    assert bool((table[:n - k0, 0] == st[k0:n]).all()) and bool((table[:n - k0, 5] == st[k0 + 1:n + 1] - 1).all())
+    del sh, table, st
+    torch.cuda.empty_cache()
