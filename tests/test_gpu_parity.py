@@ -671,5 +671,15 @@ def test_wrapped_at_size_from_a_deep_offset(gpu_ctx, pkg):
     rc, res = gpu_ctx.scan_device(sh.ext.data_ptr(), nbytes, table.data_ptr(), table.shape[0], offset=int(sh.starts[k0]))
     assert rc == 0 and int(res.n_records) == n - k0 and int(res.end_state) == 0
     assert bool((table[:n - k0, 0] == st[k0:n]).all()) and bool((table[:n - k0, 5] == st[k0 + 1:n + 1] - 1).all())
+    # not at eof (the last record is held back), without the sentinel (a shard that is not the
+    # first one: the first record of the buffer has no newline in front and is not seen)
+    rc, res = gpu_ctx.scan_device(sh.ext.data_ptr(), nbytes, table.data_ptr(), table.shape[0], offset=int(sh.starts[k0]),
+                                  eof=False)
+    assert rc == 0 and int(res.n_records) == n - k0 - 1 and int(res.end_state) == 1
+    assert bool((table[:n - k0 - 1, 0] == st[k0:n - 1]).all())
+    rc, res = gpu_ctx.scan_device(sh.ext.data_ptr(), nbytes, table.data_ptr(), table.shape[0], sentinel=False, add=0,
+                                  eof=False)
+    assert rc == 0 and int(res.n_records) == n - 2 and int(res.end_state) == 1 and res.path == 0
+    assert bool((table[:n - 2, 0] == st[1:n - 1]).all()) and bool((table[:n - 2, 5] == st[2:n] - 1).all())
     del sh, table, st
     torch.cuda.empty_cache()
