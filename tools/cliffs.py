@@ -1,0 +1,39 @@
+"""Timing of 1 GiB of S-single with one local irregularity in the middle (which tier ends up
+doing the work, and how long it takes)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import fastqandfurious_amd
+from fastqandfurious_amd import hip
+ctx = hip.Context(0)
+n = (1 << 30) // 322
+base = torch.empty(n * 322 + (1 << 20), dtype=torch.uint8, device='cuda')
+ctx.synth_single(base.data_ptr(), 0, n, 42)
+table = torch.empty((n + 64, 6), dtype=torch.int64, device='cuda')
+mid = (n // 2) * 322
+cases = {
+    "clean": None,
+    "one wrapped record": ("wrap", None),
+    "100 KB of blank lines": ("blank", 100 << 10),
+    "one record cut short (INVALID)": ("cut", None),
+}
+for name, what in cases.items():
+    buf = base.clone()
+    nb = n * 322
+    if what:
+        kind, arg = what
+        if kind == "wrap":
+            buf[mid + 18 + 75] = 10                 # a newline inside the sequence line
+        elif kind == "blank":
+            buf[mid:mid + arg] = 10                 # records replaced by newlines
+        elif kind == "cut":
+            buf[mid + 171 + 10] = 10                # a newline inside the quality line
+    torch.cuda.synchronize()          # (the scan runs on the context's own stream)
+    ctx.forget()
+    for rep in range(3):
+        t0 = time.perf_counter()
+        rc, res = ctx.scan_device(buf.data_ptr(), nb, table.data_ptr(), n + 64)
+        el = time.perf_counter() - t0
+        print('   rep', rep, 'path', res.path, '%.3f ms' % (el * 1e3), 'index %.3f chain %.3f' % (res.ms_index, res.ms_chain))
+    print("%-32s: %8.3f ms  n %d path %d retries %d end_state %d status %d" % (name, el * 1e3, res.n_records, res.path, res.retries, res.end_state, res.last_status), flush=True)
+    del buf
