@@ -1029,9 +1029,11 @@ __global__ void k_repair_mark(ChainBufs B)
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= B.ng) return;
     int64_t f = FORCE_NONE;
-    if (g > 0 && !(B.flags[g] & 5u)) {
+    if (g > 0 && !(B.flags[g] & 4u)) {
         const int64_t pe = B.exit[g - 1], y = B.y[g];
-        if (pe >= 0 && y != pe) f = pe;
+        // (a group that does not fit k_chain_wave, bit 0, has no guess at all: k_group_walk enters
+        // it at its predecessor's exit once that is known)
+        if (pe >= 0 && (y != pe || (B.flags[g] & 1u))) f = pe;
     }
     B.force[g] = f;
 }

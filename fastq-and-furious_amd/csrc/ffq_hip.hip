@@ -505,6 +505,8 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
                            dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 2, 0);
+    // the groups that do not fit the kernel above (dense tiles) and whose entry is known: walked
+    hipLaunchKernelGGL(k_group_walk, dim3((unsigned)ngroups), dim3(64), 0, sA, L, cb, a.offset, a.eof);
     return enqueue_resolve(c, a, cb, false);
 }
 
@@ -726,11 +728,14 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         if (!serial && !(getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) && !getenv("FFQ_NO_REPAIR")) {
             int prev_bad = -1;
             const int first_bad = c->h_res->bad_group;
+            // (a group that does not FIT the kernel -- bad_irregular -- is walked by k_group_walk in
+            // the same passes; if that cannot take it either, the first bad group does not move)
             for (int round = 0; round < 16 && c->h_res->fallback && c->h_res->bad_group > prev_bad &&
-                                c->h_res->bad_group < st.ngroups && !c->h_res->bad_irregular; round++) {
+                                c->h_res->bad_group < st.ngroups; round++) {
                 // records that span whole groups correct one another only a few groups per round:
                 // the wave walker is the better tool then
-                if (round >= 4 && c->h_res->bad_group - first_bad < round * std::max(st.ngroups / 64, 1)) break;
+                if (round >= 4 && !c->h_res->bad_irregular &&
+                    c->h_res->bad_group - first_bad < round * std::max(st.ngroups / 64, 1)) break;
                 prev_bad = c->h_res->bad_group;
                 HIPCHK(hipEventRecord(c->ev[4], sA));
                 int rc = enqueue_repair(c, a, L, st.dense_cfg, st.ngroups);

@@ -354,6 +354,65 @@ __global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset
     res->n_lines = nl;
 }
 
+// =========================================================================
+// k_group_walk: repair pass for the groups that do not fit k_chain_wave (a DENSE region: more
+// than SLOT newlines in a tile -- a block of blank lines, very short lines).  One wave per such
+// group whose predecessor's exit is known (B.force, k_repair_mark; group 0 starts at the search
+// offset): the walker's searches, from that entry to the first candidate past the group's own
+// tiles, records staged like k_chain_wave's.  What does not fit here either (more records than
+// a group's stage holds, fields 4 GiB away) stays flagged and goes to the later tiers.
+// Without it one such region sent the WHOLE buffer to the serial walker (7.5 s per GiB of
+// short reads).
+// =========================================================================
+__global__ __launch_bounds__(64) void k_group_walk(LineIndex L, ChainBufs B, int64_t offset, int eof)
+{
+    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    if (g >= B.ng || !(B.flags[g] & 1u)) return;
+    const int64_t fpos = B.force[g];
+    if (g > 0 && fpos == FORCE_NONE) return;
+    const int own0 = g * OWN_T, own1 = min(own0 + OWN_T, L.ntiles);
+    const int64_t own_end = ((int64_t)own1 << TILE_SHIFT) + L.s;        // first coordinate past the own tiles
+    const int64_t wpos0 = (int64_t)(own0 > 0 ? own0 - 1 : 0) << TILE_SHIFT;
+    const int64_t len = L.len();
+    StageRec *stg = B.stage + (int64_t)g * B.nmax;
+    H k, hm1;
+    int64_t Pk;
+    int flk;
+    Rec r;
+    r.p0 = r.p1 = r.p3 = r.p4 = r.p5 = -1; r.status = ST_HEAD_BEG; r.final_ = false;
+    uint32_t n = 0;
+    int64_t qsum = 0, Y, EX = Y_UNRES;
+    bool have_term = false;
+    bool have = wv_find(L, H{-2, 0}, FL_AT, g == 0 ? offset : fpos, k, Pk, flk);
+    if (g > 0 && (!have || Pk != fpos)) return;                         // not a candidate: leave it to the later tiers
+    Y = have ? Pk : Y_NOCAND;
+    for (;;) {
+        if (!have) { EX = Y_NOCAND; have_term = true; r.p0 = r.p1 = r.p3 = r.p4 = r.p5 = -1; r.status = ST_HEAD_BEG; break; }
+        if (Pk >= own_end) { EX = Pk; break; }
+        wv_record(L, k, Pk, len, eof, r, hm1);
+        if (r.status == ST_COMPLETE || r.final_) {
+            if (n >= (uint32_t)B.nmax || r.p4 - wpos0 > 0xFFFFFFF0ll) return;
+            if (lane == 0)
+                stg[n] = StageRec{(uint32_t)(r.p0 - wpos0), (uint32_t)(r.p1 - wpos0), (uint32_t)(r.p3 - wpos0),
+                                  (uint32_t)(r.p4 - wpos0)};
+            n++;
+            qsum += r.p5 - r.p4;
+        }
+        if (r.final_) { EX = X_END_FINAL; have_term = true; break; }
+        if (r.status != ST_COMPLETE) { EX = X_END_TERM; have_term = true; break; }
+        have = wv_find(L, hm1, FL_AT, r.p5 - 1, k, Pk, flk);
+    }
+    if (n == 0 && !have_term) Y = EX;                                   // the chain passes over this group
+    if (lane != 0) return;
+    B.y[g] = Y; B.exit[g] = EX; B.cnt[g] = n; B.qb[g] = qsum; B.flags[g] = 0;
+    if (have_term) {
+        GroupTerm &t = B.term[g];
+        t.status = r.status;
+        t.pos[0] = r.p0; t.pos[1] = r.p1; t.pos[2] = (r.p1 >= 0) ? r.p1 + 1 : -1;
+        t.pos[3] = r.p3; t.pos[4] = r.p4; t.pos[5] = r.p5;
+    }
+}
+
 // k_finalize: the iterator's `offset` at exit = pos5 - 1 of the last COMPLETE
 // record (fastqandfurious.py:254), read back from the table; qoff[n].
 __global__ void k_finalize(DevRes *res, const int64_t *__restrict__ table, int64_t table_cap,

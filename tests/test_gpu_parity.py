@@ -683,3 +683,46 @@ def test_wrapped_at_size_from_a_deep_offset(gpu_ctx, pkg):
     assert bool((table[:n - 2, 0] == st[1:n - 1]).all()) and bool((table[:n - 2, 5] == st[2:n] - 1).all())
     del sh, table, st
     torch.cuda.empty_cache()
+
+
+def _with_dense_regions(rng, where, kind):
+    """~3 MiB of regular records (single-line or wrapped) with dense regions -- blank lines or
+    tiny records, more than 1024 newlines per 16 KiB tile -- at the start / in the middle / at
+    the end."""
+    body = random_records(rng, 9000, 100, 160, wrap=(70 if kind == "wrapped" else 0))
+    blank = b"\n" * int(rng.integers(20000, 150000))
+    tiny = b"".join(b"@t%d\nAC\n+\nII\n" % i for i in range(int(rng.integers(3000, 9000))))
+    cut = len(body) // 2
+    cut = body.index(b"\n@", cut) + 1
+    parts = []
+    if "start" in where:
+        parts.append(blank)
+    parts.append(body[:cut])
+    if "middle" in where:
+        parts.append(tiny if "tiny" in where else blank)
+    parts.append(body[cut:])
+    if "end" in where:
+        parts.append(blank if "tiny" not in where else tiny + blank)
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("kind", ("single", "wrapped"))
+@pytest.mark.parametrize("where", ("start", "middle", "end", "start middle end", "middle tiny", "end tiny"))
+def test_dense_regions_are_walked_group_by_group(hipmod, oracle, kind, where):
+    """A dense region (tiles over their slot: no parallel chain kernel takes them) is walked
+    group by group in the repair passes (k_group_walk) instead of sending the whole buffer to the
+    serial walker: same rows, end state and decoded qualities as the oracle, parallel path."""
+    ctx = hipmod.Context(0)
+    rng = np.random.default_rng(len(where) * 7 + len(kind))
+    data = _with_dense_regions(rng, where, kind)
+    for kw in (dict(), dict(eof=False), dict(offset=len(data) // 3)):
+        for trunc in (0, 37):
+            d = data[:len(data) - trunc]
+            want, end, status, off = oracle.scan(d, **kw)
+            table, res, qual, qoff = ctx.scan_host(d, flags=hipmod.F_DECODE_QUAL, table_cap=len(want) + 8, **kw)
+            assert int(res.end_state) == end and int(res.last_status) == status and int(res.end_offset) == off, (kw, trunc)
+            assert table.shape == want.shape and (table == want).all(), (kw, trunc)
+            wq, wqoff = oracle.decode_quals(d, want)
+            assert (qoff == wqoff).all() and (qual == wq).all()
+            if "tiny" not in where:
+                assert res.path in (0, 2), (kw, trunc, res.path)      # not the serial walker
