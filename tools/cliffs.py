@@ -16,6 +16,10 @@ cases = {
     "one wrapped record": ("wrap", None),
     "100 KB of blank lines": ("blank", 100 << 10),
     "one record cut short (INVALID)": ("cut", None),
+    "one 1 MB wrapped record": ("longwrap", 1 << 20),
+    "one 1 MB four-line record": ("long4", 1 << 20),
+    "100 KB of 10-base reads": ("tiny", 100 << 10),
+    "2 MB of blank lines at the end": ("blankend", 2 << 20),
 }
 for name, what in cases.items():
     buf = base.clone()
@@ -28,6 +32,24 @@ for name, what in cases.items():
             buf[mid:mid + arg] = 10                 # records replaced by newlines
         elif kind == "cut":
             buf[mid + 171 + 10] = 10                # a newline inside the quality line
+        elif kind in ("longwrap", "long4"):
+            L = arg // 2
+            w = 80 if kind == "longwrap" else L
+            seq = np.full(L, 65, dtype=np.uint8); q = np.full(L, 73, dtype=np.uint8)
+            fold = lambda a: b"\n".join(a[i:i + w].tobytes() for i in range(0, L, w))
+            rec = b"@long\n" + fold(seq) + b"\n+\n" + fold(q) + b"\n"
+            pad = (-len(rec)) % 322
+            rec = b"@long" + b"x" * pad + rec[5:]
+            assert len(rec) % 322 == 0
+            buf[mid:mid + len(rec)] = torch.from_numpy(np.frombuffer(rec, dtype=np.uint8).copy()).cuda()
+        elif kind == "tiny":
+            rec = b"".join(b"@t%06d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(arg // 32))
+            rec = rec[:len(rec) // 322 * 322 // 32 * 32]
+            m = len(rec) // 322 * 322
+            buf[mid:mid + len(rec)] = torch.from_numpy(np.frombuffer(rec, dtype=np.uint8).copy()).cuda()
+            buf[mid + len(rec):mid + m + 322] = 10  # (blank up to the next record boundary)
+        elif kind == "blankend":
+            buf[nb - arg:nb] = 10
     torch.cuda.synchronize()          # (the scan runs on the context's own stream)
     ctx.forget()
     for rep in range(3):
