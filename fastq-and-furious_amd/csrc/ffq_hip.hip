@@ -90,6 +90,7 @@ struct ffq_ctx {
     int64_t qdir_cap = 0;
     int64_t *p4s = nullptr;            // pos4 of every record, compact: what the decode reads instead of the 48-byte rows
     int64_t p4s_cap = 0;
+    int dense_stride = 0;              // stage stride of the dense tier in use (WALK_STRIDE_DENSE if memory allows)
     uint32_t *qrel = nullptr;          // tile-relative quality offsets of the fast path (p4s_cap entries)
     // pinned mirrors
     Ctl *h_ctl = nullptr;               // host-mapped pinned: written by the publishing kernel (Pub)
@@ -236,6 +237,9 @@ static int64_t groups_for(int64_t ntiles) { return (ntiles + OWN_T - 1) / OWN_T;
 constexpr int PER_FAST = 6, EMAX_FAST = 2048, WPB_FAST = 2;   // k_chain_wave, usual line/record density
 constexpr int PER_DENSE = 15, EMAX_DENSE = NTW * SLOT + 8, WPB_DENSE = 1;   // short records / short lines
 constexpr int NMAX_FAST = PER_FAST * 64, NMAX_DENSE = PER_DENSE * 64;
+// records a group's stage holds in the dense tier: k_group_walk stages the groups of dense tiles
+// there (very short reads: 64 KiB of 16-byte records), k_chain_wave needs NMAX_DENSE of them
+constexpr int WALK_STRIDE_DENSE = 4096;
 
 static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
 {
@@ -493,7 +497,7 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
 {
     ChainBufs cb = c->cb;
     cb.ng = ngroups;
-    cb.nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
+    cb.nmax = dense_cfg ? (c->dense_stride ? c->dense_stride : NMAX_DENSE) : NMAX_FAST;
     cb.prof = nullptr;
     hipStream_t sA = c->stream;
     hipLaunchKernelGGL(k_repair_mark, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, sA, cb);
@@ -506,7 +510,7 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
                            dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 2, 0);
     // the groups that do not fit the kernel above (dense tiles) and whose entry is known: walked
-    hipLaunchKernelGGL(k_group_walk, dim3((unsigned)ngroups), dim3(64), 0, sA, L, cb, a.offset, a.eof);
+    hipLaunchKernelGGL(k_group_walk, dim3((unsigned)ngroups), dim3(64), 0, sA, L, cb, a.offset, a.eof, 0);
     return enqueue_resolve(c, a, cb, false);
 }
 
@@ -514,8 +518,18 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
 static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups,
                            bool timed = false)
 {
-    const int nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
-    int rc = reserve_stage(c, ngroups, nmax);
+    int nmax = NMAX_FAST;
+    int rc;
+    if (dense_cfg) {
+        // room for k_group_walk's records if the memory is there (one input size), else the kernel's own
+        nmax = WALK_STRIDE_DENSE;
+        size_t fr = 0, tot = 0;
+        if ((int64_t)ngroups * nmax > c->stage_cap &&
+            (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < (size_t)ngroups * nmax * sizeof(StageRec) + ((size_t)2 << 30)))
+            nmax = NMAX_DENSE;
+        c->dense_stride = nmax;
+    }
+    rc = reserve_stage(c, ngroups, nmax);
     if (rc) return rc;
     ChainBufs cb = c->cb;
     cb.ng = ngroups;
@@ -538,6 +552,9 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
                            dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
+    // the groups the kernel above declined (dense tiles), each from a guessed entry
+    if (ablate == 0)
+        hipLaunchKernelGGL(k_group_walk, dim3((unsigned)ngroups), dim3(64), 0, sA, L, cb, a.offset, a.eof, 1);
     return enqueue_resolve(c, a, cb, timed);
 }
 

@@ -364,13 +364,14 @@ __global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset
 // Without it one such region sent the WHOLE buffer to the serial walker (7.5 s per GiB of
 // short reads).
 // =========================================================================
-__global__ __launch_bounds__(64) void k_group_walk(LineIndex L, ChainBufs B, int64_t offset, int eof)
+__global__ __launch_bounds__(64) void k_group_walk(LineIndex L, ChainBufs B, int64_t offset, int eof, int speculate)
 {
     const int g = blockIdx.x, lane = threadIdx.x & 63;
     if (g >= B.ng || !(B.flags[g] & 1u)) return;
-    const int64_t fpos = B.force[g];
-    if (g > 0 && fpos == FORCE_NONE) return;
+    const int64_t fpos = speculate ? FORCE_NONE : B.force[g];
+    if (g > 0 && fpos == FORCE_NONE && !speculate) return;
     const int own0 = g * OWN_T, own1 = min(own0 + OWN_T, L.ntiles);
+    const int64_t own_beg = ((int64_t)own0 << TILE_SHIFT) + L.s;        // coordinate of the own tiles' first byte
     const int64_t own_end = ((int64_t)own1 << TILE_SHIFT) + L.s;        // first coordinate past the own tiles
     const int64_t wpos0 = (int64_t)(own0 > 0 ? own0 - 1 : 0) << TILE_SHIFT;
     const int64_t len = L.len();
@@ -381,16 +382,25 @@ __global__ __launch_bounds__(64) void k_group_walk(LineIndex L, ChainBufs B, int
     Rec r;
     r.p0 = r.p1 = r.p3 = r.p4 = r.p5 = -1; r.status = ST_HEAD_BEG; r.final_ = false;
     uint32_t n = 0;
-    int64_t qsum = 0, Y, EX = Y_UNRES;
+    int64_t qsum = 0, Y = Y_UNRES, EX = Y_UNRES;
     bool have_term = false;
-    bool have = wv_find(L, H{-2, 0}, FL_AT, g == 0 ? offset : fpos, k, Pk, flk);
-    if (g > 0 && (!have || Pk != fpos)) return;                         // not a candidate: leave it to the later tiers
-    Y = have ? Pk : Y_NOCAND;
+    // entry: exact for group 0 (the scan's search offset) and in a repair pass (the predecessor's
+    // exit); a GUESS in the first pass -- the first candidate of the run-in, as k_chain_wave does:
+    // a chain started at a false candidate has the run-in to fall in with the true one, and the
+    // verification (y[g] == exit[g-1]) decides.  Records of the run-in are walked, not staged.
+    const bool guess = g > 0 && fpos == FORCE_NONE;
+    const int64_t X = (g == 0) ? offset : guess ? max(own_beg - RUNIN_BYTES, offset) : fpos;
+    bool have = wv_find(L, H{-2, 0}, FL_AT, X, k, Pk, flk);
+    if (g > 0 && !guess && (!have || Pk != fpos)) return;               // not a candidate: leave it to the later tiers
     for (;;) {
         if (!have) { EX = Y_NOCAND; have_term = true; r.p0 = r.p1 = r.p3 = r.p4 = r.p5 = -1; r.status = ST_HEAD_BEG; break; }
         if (Pk >= own_end) { EX = Pk; break; }
+        const bool own = !guess || Pk >= own_beg;
+        if (own && Y == Y_UNRES) Y = Pk;                                // first member in the own tiles
         wv_record(L, k, Pk, len, eof, r, hm1);
-        if (r.status == ST_COMPLETE || r.final_) {
+        if (!own) {
+            if (r.status != ST_COMPLETE) return;                        // the guessed chain ends in the run-in: no guess
+        } else if (r.status == ST_COMPLETE || r.final_) {
             if (n >= (uint32_t)B.nmax || r.p4 - wpos0 > 0xFFFFFFF0ll) return;
             if (lane == 0)
                 stg[n] = StageRec{(uint32_t)(r.p0 - wpos0), (uint32_t)(r.p1 - wpos0), (uint32_t)(r.p3 - wpos0),
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(64) void k_group_walk(LineIndex L, ChainBufs B, int
         if (r.status != ST_COMPLETE) { EX = X_END_TERM; have_term = true; break; }
         have = wv_find(L, hm1, FL_AT, r.p5 - 1, k, Pk, flk);
     }
-    if (n == 0 && !have_term) Y = EX;                                   // the chain passes over this group
+    if (Y == Y_UNRES) Y = EX;                                           // no member in the own tiles: the chain passes over
     if (lane != 0) return;
     B.y[g] = Y; B.exit[g] = EX; B.cnt[g] = n; B.qb[g] = qsum; B.flags[g] = 0;
     if (have_term) {

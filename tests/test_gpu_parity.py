@@ -726,3 +726,30 @@ def test_dense_regions_are_walked_group_by_group(hipmod, oracle, kind, where):
             assert (qoff == wqoff).all() and (qual == wq).all()
             if "tiny" not in where:
                 assert res.path in (0, 2), (kw, trunc, res.path)      # not the serial walker
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_very_short_reads_every_tile_dense(hipmod, oracle, seed):
+    """Reads of a few bases with short headers: under 16 bytes per line, every tile over its slot.
+    The groups are walked in parallel from guessed entries (k_group_walk, dense tier); qualities
+    full of '@' and '+' make false candidates for the guesses.  Same result as the oracle, not
+    through the whole-buffer serial walker."""
+    ctx = hipmod.Context(0)
+    rng = np.random.default_rng(300 + seed)
+    qch = np.frombuffer(b"@+I5@", dtype=np.uint8)
+    parts = []
+    for i in range(90000):
+        L = int(rng.integers(1, 14))
+        q = rng.choice(qch, size=L).tobytes()
+        parts.append(b"@%d\n" % i + b"ACGTN"[:1] * L + b"\n+\n" + q + b"\n")
+    data = b"".join(parts)
+    if seed & 1:
+        data = data[:len(data) - 5]
+    for kw in (dict(), dict(eof=False), dict(offset=len(data) // 2)):
+        want, end, status, off = oracle.scan(data, **kw)
+        table, res, qual, qoff = ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL, table_cap=len(want) + 8, **kw)
+        assert int(res.end_state) == end and int(res.last_status) == status and int(res.end_offset) == off, kw
+        assert table.shape == want.shape and (table == want).all(), kw
+        wq, wqoff = oracle.decode_quals(data, want)
+        assert (qoff == wqoff).all() and (qual == wq).all()
+        assert res.path in (0, 2), (kw, res.path)

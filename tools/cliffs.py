@@ -59,3 +59,16 @@ for name, what in cases.items():
         print('   rep', rep, 'path', res.path, '%.3f ms' % (el * 1e3), 'index %.3f chain %.3f' % (res.ms_index, res.ms_chain))
     print("%-32s: %8.3f ms  n %d path %d retries %d end_state %d status %d" % (name, el * 1e3, res.n_records, res.path, res.retries, res.end_state, res.last_status), flush=True)
     del buf
+
+# a whole buffer of very short reads with short headers (every tile dense)
+for bases, nrec in ((12, 4000000), (18, 3000000)):
+    rec = b"".join(b"@s%d\n%s\n+\n%s\n" % (i, b"ACGTACGTACGTACGTACGT"[:bases], b"IIIIIIIIIIIIIIIIIIII"[:bases]) for i in range(nrec))
+    buf = torch.from_numpy(np.frombuffer(rec, dtype=np.uint8).copy()).cuda()
+    tb = torch.empty((nrec + 64, 6), dtype=torch.int64, device='cuda')
+    torch.cuda.synchronize()
+    ctx.forget()
+    for rep in range(2):
+        t0 = time.perf_counter()
+        rc, res = ctx.scan_device(buf.data_ptr(), len(rec), tb.data_ptr(), nrec + 64)
+        el = time.perf_counter() - t0
+    print("%d MB of %d-base reads, short headers: %9.3f ms (%.2f GB/s)  n %d path %d retries %d" % (len(rec) >> 20, bases, el * 1e3, len(rec) / el / 1e9, res.n_records, res.path, res.retries), flush=True)
