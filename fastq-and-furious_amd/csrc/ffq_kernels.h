@@ -364,9 +364,10 @@ __global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset
 // Without it one such region sent the WHOLE buffer to the serial walker (7.5 s per GiB of
 // short reads).
 // =========================================================================
-__global__ __launch_bounds__(64) void k_group_walk(LineIndex L, ChainBufs B, int64_t offset, int eof, int speculate)
+__global__ __launch_bounds__(256) void k_group_walk(LineIndex L, ChainBufs B, int64_t offset, int eof, int speculate)
 {
-    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    // (four groups per workgroup, one wave each, no barrier: nearly all of them return at once)
+    const int g = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (g >= B.ng || !(B.flags[g] & 1u)) return;
     const int64_t fpos = speculate ? FORCE_NONE : B.force[g];
     if (g > 0 && fpos == FORCE_NONE && !speculate) return;
