@@ -510,7 +510,7 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
                            dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 2, 0);
     // the groups that do not fit the kernel above (dense tiles) and whose entry is known: walked
-    hipLaunchKernelGGL(k_group_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 0);
+    hipLaunchKernelGGL(k_group_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 0, dense_cfg ? 1 : 0);
     return enqueue_resolve(c, a, cb, false);
 }
 
@@ -554,7 +554,7 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
     // the groups the kernel above declined (dense tiles), each from a guessed entry
     if (ablate == 0)
-        hipLaunchKernelGGL(k_group_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 1);
+        hipLaunchKernelGGL(k_group_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 1, dense_cfg ? 1 : 0);
     return enqueue_resolve(c, a, cb, timed);
 }
 

@@ -364,7 +364,8 @@ __global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset
 // Without it one such region sent the WHOLE buffer to the serial walker (7.5 s per GiB of
 // short reads).
 // =========================================================================
-__global__ __launch_bounds__(256) void k_group_walk(LineIndex L, ChainBufs B, int64_t offset, int eof, int speculate)
+__global__ __launch_bounds__(256) void k_group_walk(LineIndex L, ChainBufs B, int64_t offset, int eof, int speculate,
+                                                    int walk_all)
 {
     // (four groups per workgroup, one wave each, no barrier: nearly all of them return at once)
     const int g = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -372,6 +373,14 @@ __global__ __launch_bounds__(256) void k_group_walk(LineIndex L, ChainBufs B, in
     const int64_t fpos = speculate ? FORCE_NONE : B.force[g];
     if (g > 0 && fpos == FORCE_NONE && !speculate) return;
     const int own0 = g * OWN_T, own1 = min(own0 + OWN_T, L.ntiles);
+    if (!walk_all) {
+        // usual configuration: only a group with a DENSE tile in its window is walked here; one
+        // that merely exceeds this configuration's LDS budget (lines of ~32 bytes) is far better
+        // off with the dense configuration of k_chain_wave (1.3 TB/s against 0.17 walked)
+        const int wt0 = own0 > 0 ? own0 - 1 : 0, wt1 = min(own1 + 1, L.ntiles);
+        const bool dense_here = wt0 + lane < wt1 && L.cnt[wt0 + lane] > (uint32_t)SLOT;
+        if (__ballot(dense_here) == 0ull) return;
+    }
     const int64_t own_beg = ((int64_t)own0 << TILE_SHIFT) + L.s;        // coordinate of the own tiles' first byte
     const int64_t own_end = ((int64_t)own1 << TILE_SHIFT) + L.s;        // first coordinate past the own tiles
     const int64_t wpos0 = (int64_t)(own0 > 0 ? own0 - 1 : 0) << TILE_SHIFT;

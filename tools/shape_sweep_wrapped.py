@@ -7,7 +7,8 @@ from fastqandfurious_amd import hip
 ctx = hip.Context(0)
 rng = np.random.default_rng(0)
 size = int(sys.argv[1]) if len(sys.argv) > 1 else (64 << 20)
-for L in (100, 300, 1000, 3000, 5000, 20000, 60000):
+Ls = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (100, 300, 1000, 3000, 5000, 20000, 60000)
+for L in Ls:
     # every record different (a periodic stream keeps a false chain alive for ever)
     n = max(3, size // (2 * L + 2 * (L // 80) + 40))
     qa = np.frombuffer(bytes(range(35, 74)), dtype=np.uint8)
