@@ -753,3 +753,16 @@ def test_very_short_reads_every_tile_dense(hipmod, oracle, seed):
         wq, wqoff = oracle.decode_quals(data, want)
         assert (qoff == wqoff).all() and (qual == wq).all()
         assert res.path in (0, 2), (kw, res.path)
+
+
+def test_short_wrapped_reads_take_the_dense_configuration(hipmod, oracle):
+    """Reads of 100 bases wrapped at 80 columns: ~32 bytes per line, windows over the usual
+    configuration's LDS budget but no dense tile.  They belong to the dense configuration of the
+    chain kernel (path 2), not to the group walker (6x slower on such input)."""
+    ctx = hipmod.Context(0)
+    rng = np.random.default_rng(77)
+    data = random_records(rng, 20000, 100, 100, wrap=80, hdr_hi=12)
+    want, end, status, off = oracle.scan(data)
+    table, res = ctx.scan_host(data, table_cap=len(want) + 8)
+    assert (table == want).all() and int(res.end_state) == end and int(res.last_status) == status
+    assert res.path == 2
