@@ -100,7 +100,7 @@ struct ffq_ctx {
     bool ctl_clean = false;             // the control block is zero (creation, or a publisher ran last)
     int64_t *d_word = nullptr;          // 2 scratch words for the small table queries
     int64_t *h_word = nullptr;          //   and their pinned mirror
-    int64_t *d_cut = nullptr, *h_cut = nullptr;    // ffq_table_cut: 4 words
+    int64_t *d_cut = nullptr, *h_cut = nullptr;    // ffq_table_cut: 6 words
     FaHdr *fa_hdr = nullptr;            // FASTA scan: starts, the last start
     // staging for the host-buffer entry points
     uint8_t *stage_d = nullptr;
@@ -169,9 +169,9 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_L, sizeof(LineIndex));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_word, 16);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_word, 16, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_cut, 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_cut, 48);
     if (e == hipSuccess) e = hipMalloc((void **)&c->fa_hdr, sizeof(FaHdr));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_cut, 32, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_cut, 48, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_L, sizeof(LineIndex), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_res, sizeof(DevRes), hipHostMallocMapped);
@@ -1069,15 +1069,15 @@ extern "C" int ffq_scan_fasta_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_b
 }
 
 extern "C" int ffq_table_cut(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t lo, int64_t hi,
-                             int64_t out[4])
+                             int64_t out[6])
 {
     if (!c || !out || n_rows < 0 || (n_rows > 0 && !d_table)) return fail(FFQ_E_ARG, "ffq_table_cut: bad argument");
     HIPCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(k_table_cut, dim3(1), dim3(64), 0, c->stream, d_table, n_rows, lo, hi, c->d_cut);
-    HIPCHK(hipMemcpyAsync(c->h_cut, c->d_cut, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_cut, c->d_cut, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 4; i++) out[i] = c->h_cut[i];
+    for (int i = 0; i < 6; i++) out[i] = c->h_cut[i];
     return FFQ_OK;
 }
 

@@ -751,8 +751,10 @@ __global__ __launch_bounds__(256) void k_sel_scatter(const int64_t *__restrict__
 }
 
 // The rows of a shard inside the table of its [tail | own | head] scan, one wave, one launch:
-// i0 = first row with pos0 >= lo, i1 = first row with pos0 >= hi (64-ary searches), and pos0
-// of both rows (-1 past the end).  out = {i0, i1, pos0[i0], pos0[i1]}.
+// i0 = first row with pos0 >= lo, i1 = first row with pos0 >= hi (64-ary searches), pos0 of
+// both rows (-1 past the end) and pos5 of the rows in front of them (-1: there is none) -- the
+// chain found row i from offset pos5[i - 1] - 1 (fastqandfurious.py:254).
+// out = {i0, i1, pos0[i0], pos0[i1], pos5[i0 - 1], pos5[i1 - 1]}.
 __global__ __launch_bounds__(64) void k_table_cut(const int64_t *__restrict__ table, int64_t n, int64_t lo,
                                                   int64_t hi, int64_t *__restrict__ out)
 {
@@ -779,6 +781,8 @@ __global__ __launch_bounds__(64) void k_table_cut(const int64_t *__restrict__ ta
         out[1] = res[1];
         out[2] = (res[0] < n) ? table[res[0] * 6] : -1;
         out[3] = (res[1] < n) ? table[res[1] * 6] : -1;
+        out[4] = (res[0] > 0) ? table[(res[0] - 1) * 6 + 5] : -1;
+        out[5] = (res[1] > 0) ? table[(res[1] - 1) * 6 + 5] : -1;
     }
 }
 

@@ -27,6 +27,7 @@ MISSING_QUALHEADER_END = 7
 
 END_OK, END_REFILL, END_ERR_FINAL_QUAL, END_ERR_INCOMPLETE, END_ERR_INVALID = range(5)
 
+ABI_VERSION = 2
 OK = 0
 E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_TABLE_FULL, E_INTERNAL = -1, -2, -3, -4, -5, -6
 
@@ -357,8 +358,9 @@ class Context:
         return ms.value
 
     def table_cut(self, d_table, n_rows, lo, hi):
-        """(i0, i1, pos0[i0], pos0[i1]): first rows with pos0 >= lo / >= hi and their pos0."""
-        out = (ctypes.c_int64 * 4)()
+        """(i0, i1, pos0[i0], pos0[i1], pos5[i0 - 1], pos5[i1 - 1]): first rows with pos0 >= lo / >= hi,
+        their pos0, and pos5 of the rows in front of them (-1: none)."""
+        out = (ctypes.c_int64 * 6)()
         check(lib().ffq_table_cut(self.handle, ctypes.c_void_p(d_table), int(n_rows), int(lo), int(hi), out))
         return [int(x) for x in out]
 

@@ -8,32 +8,48 @@ records are independent.
 Rank r owns the bytes [S_r, S_{r+1}) of the stream and every record whose '@'
 lies in that range.  One process per GPU; per step:
 
-  1. edge hand-off (torch.distributed P2P = RCCL send/recv over xGMI): each
-     rank sends the first HEAD bytes of its range to its left neighbour (so the
-     neighbour can finish the record that straddles the edge) and the last TAIL
-     bytes to its right neighbour (run-in: a chain started anywhere in it has
-     re-synchronised with the true record chain before the range starts);
+  1. halo hand-off (torch.distributed P2P = RCCL send/recv over xGMI): every
+     rank receives the TAIL bytes in front of its range (run-in: a chain started
+     anywhere in it has re-synchronised with the true record chain before the
+     range starts) and the HEAD bytes behind it (to finish the record that
+     straddles the edge), from whichever ranks own them;
   2. one ordinary scan of [tail | own | head] on the local GPU;
   3. the rows with S_r <= pos0 < S_{r+1} are the shard's records;
-  4. verification, 8 bytes per edge: the first record start at/after S_{r+1}
-     as rank r sees it must equal the first row rank r+1 claims.  Together with
-     rank 0's exact start this proves every shard's rows by induction;
-  5. all_gather of the per-rank record counts -> global record ordinals.
+  4. verification, a few words per rank (one all_gather): the first record start
+     at/after S_{r+1} as rank r sees it must equal the first record start rank
+     r+1 sees in its range.  Together with rank 0's exact start this proves
+     every shard's rows by induction;
+  5. the same all_gather carries the per-rank record counts -> global ordinals.
+
+What the reference does with a record that does not fit its buffer -- keep
+`buf[offset:]` and read more until it does (:274-279) -- happens here per edge:
+a rank whose look-ahead ends inside the record that straddles its right edge asks
+for a larger one (doubling, served by however many ranks own those bytes) and
+scans again; a rank whose guessed entry the left neighbour's chain contradicts is
+scanned again from the neighbour's exit (no run-in speculation), and everything
+is verified again.  Each round makes the first unsettled rank exact, so the
+rounds terminate.  Errors of the stream (the iterator's three ValueErrors) are
+raised by every rank together, and only once the failing rank's entry is proven.
 
 No collective touches the data path; traffic is KiB per edge.
 
-The scan engine is injected (`backend`): the product backend is HipBackend
-(libffq_hip.so); tests drive the same host logic on CPU tensors over gloo with
-a checker backend.
+The scan engine and the transport are injected: the product pair is HipBackend
+(libffq_hip.so) + DistTransport (torch.distributed: RCCL on GPUs, gloo in the CPU
+tests); LocalTransport runs k logical ranks as threads of one process (k ranges
+of one resident buffer on one GPU).
 """
-import ctypes
+import contextlib
+import threading
 
 import numpy as np
 
 from . import hip as _hip
 
-TAIL_BYTES = 1 << 20      # run-in taken from the left neighbour
-HEAD_BYTES = 1 << 20      # look-ahead taken from the right neighbour
+TAIL_BYTES = 1 << 20      # run-in taken from the left
+HEAD_BYTES = 1 << 20      # look-ahead taken from the right (grown when a record needs more)
+
+NONE_POS = -1             # no record starts at / after the bound: the view reaches the end of the stream
+UNKNOWN_POS = -2          # not known yet (more look-ahead needed, or the guessed entry led nowhere)
 
 
 def shard_bounds(total_bytes, world):
@@ -43,24 +59,134 @@ def shard_bounds(total_bytes, world):
     return b
 
 
-class ScanOutput:
-    def __init__(self, res, n_rows, row_lo, row_hi, exit_pos, first_pos):
-        self.res = res
-        self.n_rows = n_rows
-        self.row_lo = row_lo
-        self.row_hi = row_hi
-        self.exit_pos = exit_pos
-        self.first_pos = first_pos
-        self.n_own_records = row_hi - row_lo
-        self.record_base = 0          # global ordinal of this shard's first record
+def halo_sizes(bounds, rank, tail_bytes=TAIL_BYTES, head_bytes=HEAD_BYTES):
+    """(tail, head) of rank's first scan: the same rule on every rank, so that each knows what
+    the others need without asking."""
+    lo, hi, total = bounds[rank], bounds[rank + 1], bounds[-1]
+    return min(tail_bytes, lo - bounds[0]), min(head_bytes, total - hi)
 
 
+def range_plan(bounds, dst, lo, hi):
+    """[(src, dst, a, b)]: the pieces of stream bytes [lo, hi) by owner (dst's own bytes left out)."""
+    plan = []
+    for p in range(len(bounds) - 1):
+        a, b = max(lo, bounds[p]), min(hi, bounds[p + 1])
+        if a < b and p != dst:
+            plan.append((p, dst, a, b))
+    return plan
+
+
+def halo_plan(bounds, tail_bytes=TAIL_BYTES, head_bytes=HEAD_BYTES):
+    plan = []
+    for q in range(len(bounds) - 1):
+        t, h = halo_sizes(bounds, q, tail_bytes, head_bytes)
+        plan += range_plan(bounds, q, bounds[q] - t, bounds[q])
+        plan += range_plan(bounds, q, bounds[q + 1], bounds[q + 1] + h)
+    return plan
+
+
+# ---- transports -------------------------------------------------------------------------------
+class SoloTransport:
+    rank, world = 0, 1
+
+    def allgather(self, vals):
+        return [list(vals)]
+
+    def exchange(self, plan, provide, accept):
+        assert not plan
+
+
+class DistTransport:
+    """torch.distributed: backend "nccl" (= RCCL, device tensors move GPU to GPU over xGMI) or
+    gloo (CPU tensors; device tensors are staged through host copies -- the one-GPU dry run)."""
+
+    def __init__(self, dist, group=None, device=None):
+        self.dist, self.group, self.device = dist, group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.gloo = dist.get_backend(group) == "gloo"
+
+    def allgather(self, vals):
+        import torch
+        dev = torch.device("cpu") if self.gloo or self.device is None else self.device
+        mine = torch.tensor([int(v) for v in vals], dtype=torch.int64, device=dev)
+        if dev.type == "cuda":
+            flat = torch.empty(len(vals) * self.world, dtype=torch.int64, device=dev)   # one collective, one copy back
+            self.dist.all_gather_into_tensor(flat, mine, group=self.group)
+            v = flat.tolist()
+            return [v[len(vals) * r:len(vals) * (r + 1)] for r in range(self.world)]
+        allv = [torch.empty(len(vals), dtype=torch.int64) for _ in range(self.world)]
+        self.dist.all_gather(allv, mine, group=self.group)
+        return [[int(x) for x in t.tolist()] for t in allv]
+
+    def exchange(self, plan, provide, accept):
+        dist = self.dist
+        ops, staged = [], []
+        for src, dst, a, b in plan:
+            if src == self.rank:
+                t = provide(a, b)
+                ops.append(dist.P2POp(dist.isend, t.cpu() if (self.gloo and t.is_cuda) else t, dst, self.group))
+            elif dst == self.rank:
+                t = accept(a, b)
+                if self.gloo and t.is_cuda:
+                    h = t.cpu()
+                    staged.append((t, h))
+                    t = h
+                ops.append(dist.P2POp(dist.irecv, t, src, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for t, h in staged:
+            t.copy_(h)
+
+
+class LocalWorld:
+    """k logical ranks as threads of one process (ranges of one resident buffer, one GPU)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.providers = [None] * world
+
+    def transport(self, rank):
+        return LocalTransport(self, rank)
+
+
+class LocalTransport:
+    def __init__(self, lw, rank):
+        self.lw, self.rank, self.world = lw, rank, lw.world
+
+    def allgather(self, vals):
+        lw = self.lw
+        lw.slots[self.rank] = [int(v) for v in vals]
+        lw.barrier.wait()
+        out = [list(v) for v in lw.slots]
+        lw.barrier.wait()
+        return out
+
+    def exchange(self, plan, provide, accept):
+        lw = self.lw
+        lw.providers[self.rank] = provide
+        lw.barrier.wait()
+        last = None
+        for src, dst, a, b in plan:
+            if dst == self.rank:
+                last = accept(a, b)
+                last.copy_(lw.providers[src](a, b))
+        if last is not None and last.is_cuda:
+            import torch
+            torch.cuda.current_stream(last.device).synchronize()      # the sources must stay as they are until read
+        lw.barrier.wait()
+
+
+# ---- scan engine ------------------------------------------------------------------------------
 class HipBackend:
     """Scan engine on the local MI355X through the C ABI."""
 
     def __init__(self, ctx, post_ctx=None):
         self.ctx = ctx
         self.post = post_ctx or ctx     # context (stream) the small table queries run on
+        self._xstream = None
 
     def scan(self, ext, n_bytes, sentinel, offset, eof, add, table, flags=0, qual=None, qoff=None,
              table_cap=None):
@@ -84,175 +210,242 @@ class HipBackend:
     def scan_wait(self):
         return self.ctx.scan_wait()
 
-    def lower_bound(self, table, n_rows, value):
-        return self.ctx.table_lower_bound(table.data_ptr(), n_rows, 0, value)
-
     def cut(self, table, n_rows, lo, hi):
-        """(i0, i1, pos0[i0], pos0[i1]) in one launch and one host wait."""
+        """(i0, i1, pos0[i0], pos0[i1], pos5[i0 - 1], pos5[i1 - 1]) in one launch and one host wait."""
         return self.post.table_cut(table.data_ptr(), n_rows, lo, hi)
 
-    def row(self, table, idx):
-        out = np.empty(6, dtype=np.int64)
-        self.ctx.d2h(out, table.data_ptr() + idx * 48)
-        return [int(x) for x in out]
-
-    def sync_inputs(self):
+    def stream_context(self, ext):
+        """torch work on `ext` (hand-off copies, RCCL send/recv) ordered on the scan's own HIP
+        stream: the scan that follows needs no host synchronisation in between."""
+        if not ext.is_cuda:
+            return contextlib.nullcontext()
         import torch
-        torch.cuda.synchronize()
+        if self._xstream is None:
+            self._xstream = torch.cuda.ExternalStream(self.ctx.stream(), device=ext.device)
+        return torch.cuda.stream(self._xstream)
 
 
-def exchange_edges(dist, ext, tail, n_own, head, rank, world, group=None):
-    """Fill ext[:tail] from the left neighbour's last bytes and
-    ext[tail+n_own : tail+n_own+head] from the right neighbour's first bytes."""
-    if world == 1:
-        return
-    ops = []
-    own = ext[tail:tail + n_own]
-    # a transport that cannot move device memory (gloo: the CPU tests, and the one-GPU dry run
-    # of bench.py) gets the edges through host copies; RCCL moves them GPU to GPU
-    staged = ext.is_cuda and dist.get_backend(group) == "gloo"
-    recv = []
+class ScanOutput:
+    def __init__(self, res, n_rows, row_lo, row_hi, exit_pos, first_pos):
+        self.res = res
+        self.n_rows = n_rows
+        self.row_lo = row_lo
+        self.row_hi = row_hi
+        self.exit_pos = exit_pos
+        self.first_pos = first_pos
+        self.n_own_records = row_hi - row_lo
+        self.record_base = 0          # global ordinal of this shard's first record
+        self.total_records = self.n_own_records
+        self.rounds = 0               # repair rounds of the step (0: the first scan of every rank stood)
+        self.ext = None               # the [tail | own | head] buffer the rows refer to (grown: a new one)
+        self.tail = self.head = 0
 
-    def _send(t, peer):
-        ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, group))
 
-    def _recv(t, peer):
-        if staged:
-            h = t.cpu()
-            recv.append((t, h))
-            t = h
-        ops.append(dist.P2POp(dist.irecv, t, peer, group))
+class _View:
+    """A rank's [tail | own | head] buffer and its coordinates."""
 
-    if rank > 0:
-        _send(own[:min(HEAD_BYTES, n_own)], rank - 1)
-        _recv(ext[:tail], rank - 1)
-    if rank < world - 1:
-        _send(own[n_own - min(TAIL_BYTES, n_own):], rank + 1)
-        _recv(ext[tail + n_own:tail + n_own + head], rank + 1)
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    for t, h in recv:
-        t.copy_(h)
+    def __init__(self, ext, tail, head, lo, hi, total, origin=0):
+        self.ext, self.tail, self.head, self.lo, self.hi, self.total = ext, tail, head, lo, hi, total
+        self.origin = origin                        # offset of the stream's first byte
+        self.start = lo - tail                      # stream offset of ext[0]
+        self.end = hi + head
+        self.sentinel = self.start == origin        # the iterator's b'\n' in front of the stream (:245)
+        self.eof = self.end == total                # the view reaches the end of the stream
+        self.add = self.start - (1 if self.sentinel else 0)
+        self.n_bytes = tail + (hi - lo) + head
+
+
+class _State:
+    pass
+
+
+_ERR_TEXT = {_hip.END_ERR_FINAL_QUAL: "Incomplete final quality string at byte",
+             _hip.END_ERR_INCOMPLETE: "Incomplete entry at byte %i",
+             _hip.END_ERR_INVALID: "Entry is invalid at byte %i"}
+
+
+def raise_stream_error(end_state, byte):
+    """The reference iterator's ValueErrors (fastqandfurious.py:262, :269, :272)."""
+    text = _ERR_TEXT[end_state]
+    raise ValueError(text % byte if "%" in text else text)
 
 
 class ShardScanner:
-    """Steps 2-5 above for one rank."""
+    """Steps 1-5 above for one rank."""
 
-    def __init__(self, backend, rank, world, dist=None, group=None, device=None):
+    def __init__(self, backend, transport, bounds, tail_bytes=TAIL_BYTES, head_bytes=HEAD_BYTES):
         self.backend = backend
-        self.rank = rank
-        self.world = world
-        self.dist = dist
-        self.group = group
-        self.device = device
+        self.tr = transport
+        self.rank, self.world = transport.rank, transport.world
+        self.bounds = list(bounds)
+        assert len(self.bounds) == self.world + 1
+        # (the byte in front of the range must be in view: a record that starts exactly at the
+        # range's first byte is found through the "\n" before it)
+        assert tail_bytes >= 1 and head_bytes >= 1
+        self.tail_bytes, self.head_bytes = tail_bytes, head_bytes
+        self.lo, self.hi, self.total = self.bounds[self.rank], self.bounds[self.rank + 1], self.bounds[-1]
+        self.origin = self.bounds[0]        # offsets count from here on (readfastq_iter's `globaloffset`, :198-242)
+        self._pending = None
 
-    def _start_offset(self, ext, tail, add, table):
-        """A search offset inside the run-in whose chain survives into the own
-        range.  A chain that starts at a false '@' candidate can stop at an
-        INVALID entry right away; step past that candidate and try again."""
-        if self.rank == 0 or tail == 0:
-            return 0
-        probe = min(ext.numel(), tail + (64 << 10))
-        offset = 0
-        for _ in range(32):
-            rc, res = self.backend.scan(ext, probe, False, offset, False, add, table)
-            if res.end_state == _hip.END_REFILL or res.end_offset >= tail:
-                return offset
-            if res.last_pos[0] < 0:
-                break
-            offset = int(res.last_pos[0]) - add      # the '@' of the failing entry: search after it
-        raise RuntimeError("rank %d: no record chain survives the %d-byte run-in" % (self.rank, tail))
+    def halo(self):
+        return halo_sizes(self.bounds, self.rank, self.tail_bytes, self.head_bytes)
 
-    def submit(self, ext, tail, n_own, head, own_lo_file, own_hi_file, table, flags=0, qual=None, qoff=None):
-        """Enqueue the (offset 0) scan of a step and return; finish() completes the step.  With a
-        second ShardScanner on a context that shares the stream, the next step is queued while
-        this one is finished: the GPU does not idle during the host's part of a step."""
-        rank, world = self.rank, self.world
-        sentinel = rank == 0
-        eof = rank == world - 1
-        add = (own_lo_file - tail) - (1 if sentinel else 0)
-        self.backend.scan_submit(ext, tail + n_own + head, sentinel, 0, eof, add, table, flags, qual, qoff)
-        self._pending = (ext, tail, n_own, head, own_lo_file, own_hi_file, table, flags, qual, qoff)
+    # ---- step 1 -------------------------------------------------------------------------------
+    def _serve(self, plan, ext, tail, dst_ext=None, dst_start=None):
+        """One collective exchange: this rank provides its own bytes out of `ext` and receives what
+        the plan sends it into dst_ext (stream offset dst_start at index 0)."""
+        own_lo = self.lo
+        if dst_ext is None:
+            dst_ext, dst_start = ext, own_lo - tail
+
+        def provide(a, b):
+            return ext[tail + a - own_lo:tail + b - own_lo]
+
+        def accept(a, b):
+            return dst_ext[a - dst_start:b - dst_start]
+
+        with self.backend.stream_context(ext):
+            self.tr.exchange(plan, provide, accept)
+
+    def exchange_halo(self, ext, tail, head):
+        """Fill ext[:tail] and ext[tail + n_own:tail + n_own + head] from the ranks that own those bytes."""
+        assert (tail, head) == self.halo()
+        if self.world > 1:
+            self._serve(halo_plan(self.bounds, self.tail_bytes, self.head_bytes), ext, tail)
+
+    # ---- steps 2-3: one local scan and what it says about the two edges -------------------------
+    def _local(self, v, table, flags, qual, qoff, start=None, first=None):
+        """start: stream offset the first "\\n@" search starts at (None: the beginning of the view,
+        i.e. a guess unless the view starts the stream)."""
+        offset = 0 if start is None else max(start, v.start) - v.add
+        if first is not None:
+            rc, res = first                  # the offset-0 scan was submitted ahead (submit / finish)
+        else:
+            rc, res = self.backend.scan(v.ext, v.n_bytes, v.sentinel, offset, v.eof, v.add, table, flags, qual, qoff)
+        if rc != _hip.OK:
+            raise RuntimeError("rank %d: offset table too small (%d records)" % (self.rank, res.n_records))
+        st = _State()
+        st.v, st.res, st.start = v, res, start
+        n = st.n = int(res.n_records)
+        i0, i1, p_i0, p_i1, _q0, q1 = self.backend.cut(table, n, -(1 << 62) if v.lo == v.origin else v.lo,
+                                                       (1 << 62) if v.hi == v.total else v.hi)
+        good = _hip.END_OK if v.eof else _hip.END_REFILL
+        # the entry the chain stops at (incomplete / invalid): a record start like the rows'
+        p_inc = None
+        if res.end_state != _hip.END_OK and res.last_status != _hip.POS_HEAD_BEG and res.last_pos[0] >= 0:
+            p_inc = int(res.last_pos[0])
+        st.row_lo, st.row_hi = i0, i1
+        unknown = NONE_POS if (v.eof and res.end_state == _hip.END_OK) else UNKNOWN_POS
+
+        def edge(idx, p_row, bound):
+            if idx < n:
+                return p_row
+            if p_inc is not None and p_inc >= bound:
+                return p_inc
+            return unknown
+
+        st.first = edge(i0, p_i0, v.lo)
+        st.exit = edge(i1, p_i1, v.hi) if v.hi < v.total else NONE_POS
+        # where the search that found the exit started (the iterator's `offset`, :254): the right
+        # neighbour re-enters there if its own guess does not hold
+        if i1 < n:
+            st.exit_search = (q1 - 1) if i1 > 0 else offset + v.add
+        else:
+            st.exit_search = int(res.end_offset) + v.add
+        st.err, st.err_byte, st.want = 0, 0, 0
+        if res.end_state in (_hip.END_ERR_FINAL_QUAL, _hip.END_ERR_INCOMPLETE, _hip.END_ERR_INVALID):
+            # a stream error: mine if the failing entry starts in my range (or nowhere: no entry at all)
+            if p_inc is None or (v.lo <= p_inc < v.hi) or (v.hi == v.total and p_inc >= v.lo):
+                st.err, st.err_byte = int(res.end_state), int(res.end_offset) + v.add
+            elif p_inc < v.lo:
+                st.first = st.exit = UNKNOWN_POS          # the guessed entry led nowhere
+        elif res.end_state != good:
+            raise RuntimeError("rank %d: end state %d of a scan with eof=%d" % (self.rank, res.end_state, v.eof))
+        if not v.eof and not st.err and st.exit == UNKNOWN_POS and not (p_inc is not None and p_inc < v.lo):
+            if res.end_state == _hip.END_REFILL:
+                # the record that straddles my right edge does not end inside the look-ahead
+                st.want = min(max(2 * v.head, self.head_bytes, 4096), v.total - v.hi)
+        return st
+
+    def _grown_view(self, v, new_head):
+        ext = v.ext.new_empty(v.tail + (v.hi - v.lo) + new_head + 64)
+        with self.backend.stream_context(v.ext):
+            ext[:v.n_bytes] = v.ext[:v.n_bytes]
+        return _View(ext, v.tail, new_head, v.lo, v.hi, v.total, v.origin)
+
+    # ---- steps 4-5 ------------------------------------------------------------------------------
+    def _settle(self, st, table, flags, qual, qoff):
+        W, rank, B = self.world, self.rank, self.bounds
+        rounds = 0
+        while True:
+            allv = self.tr.allgather([st.exit, st.first, st.row_hi - st.row_lo, st.want, st.v.head, st.err,
+                                      st.err_byte, st.exit_search])
+            ex, fi, cnt, want, head, err, errb, exs = (list(c) for c in zip(*allv))
+            grow = [r for r in range(W) if want[r] > 0]
+            force = [r for r in range(1, W) if B[r] > B[0] and ex[r - 1] != UNKNOWN_POS and fi[r] != ex[r - 1]]
+            if not grow and not force:
+                for r in range(W):
+                    if err[r]:
+                        raise_stream_error(err[r], errb[r])      # every rank raises the same error
+                    if ex[r] == UNKNOWN_POS:
+                        raise RuntimeError("sharded scan: rank %d has no exit and nobody can move" % r)
+                return st, cnt, rounds
+            rounds += 1
+            if rounds > 2 * W + 48:
+                raise RuntimeError("sharded scan does not settle (%d rounds)" % rounds)
+            start = st.start
+            v = st.v
+            if grow:
+                plan = []
+                for r in grow:
+                    plan += range_plan(B, r, B[r + 1] + head[r], B[r + 1] + want[r])
+                nv = self._grown_view(v, want[rank]) if rank in grow else None
+                self._serve(plan, v.ext, v.tail, nv.ext if nv else None, nv.start if nv else None)
+                if nv is not None:
+                    v = nv
+            if rank in force:
+                prev = ex[rank - 1]
+                if prev == NONE_POS or prev >= v.hi and v.hi < v.total:
+                    # the chain passes over my whole range (or ends before it): I own nothing
+                    res = st.res
+                    st = _State()
+                    st.v, st.res, st.start, st.n = v, res, exs[rank - 1], 0
+                    st.row_lo = st.row_hi = 0
+                    st.first = st.exit = prev
+                    st.exit_search = exs[rank - 1]
+                    st.err = st.err_byte = st.want = 0
+                    continue
+                start = exs[rank - 1]
+            if rank in grow or rank in force:
+                st = self._local(v, table, flags, qual, qoff, start=start)
+
+    def submit(self, ext, tail, head, table, flags=0, qual=None, qoff=None):
+        """Enqueue the first scan of a step and return; finish() completes the step.  With a second
+        ShardScanner on a context that shares the stream, the next step is queued while this one
+        is finished: the GPU does not idle during the host's part of a step."""
+        v = _View(ext, tail, head, self.lo, self.hi, self.total, self.origin)
+        self.backend.scan_submit(ext, v.n_bytes, v.sentinel, 0, v.eof, v.add, table, flags, qual, qoff)
+        self._pending = (v, table, flags, qual, qoff)
 
     def finish(self):
-        args = self._pending
+        v, table, flags, qual, qoff = self._pending
         self._pending = None
-        return self.scan(*args, first=self.backend.scan_wait())
+        return self._complete(v, table, flags, qual, qoff, self.backend.scan_wait())
 
-    def scan(self, ext, tail, n_own, head, own_lo_file, own_hi_file, table, flags=0, qual=None, qoff=None,
-             first=None):
-        """ext = [tail | own | head] bytes (1-D uint8 tensor); the file offset of
-        ext[tail] is own_lo_file.  Returns ScanOutput; table rows are absolute
-        file offsets."""
-        rank, world = self.rank, self.world
-        sentinel = rank == 0
-        eof = rank == world - 1
-        ext_start = own_lo_file - tail
-        add = ext_start - (1 if sentinel else 0)
-        n_bytes = tail + n_own + head
-        # Start the chain at the first "\n@" of the run-in.  If that is a false candidate the
-        # chain re-synchronises long before the own range starts (the hand-off check below
-        # proves it); only if such a chain stops at an invalid entry inside the run-in is a
-        # start that survives searched for (a scan of the run-in alone) and the scan redone.
-        offset = 0
-        for attempt in range(2):
-            if first is not None:
-                rc, res = first          # the offset-0 scan was submitted ahead (submit / finish)
-                first = None
-            else:
-                rc, res = self.backend.scan(ext, n_bytes, sentinel, offset, eof, add, table, flags, qual, qoff)
-            if rc != _hip.OK:
-                raise RuntimeError("rank %d: offset table too small (%d records)" % (rank, res.n_records))
-            good = res.end_state == (_hip.END_OK if eof else _hip.END_REFILL)
-            if good or rank == 0 or attempt == 1 or res.end_offset >= tail:
-                break
-            offset = self._start_offset(ext, tail, add, table)
-        n = int(res.n_records)
-        if eof:
-            if res.end_state != _hip.END_OK:
-                raise ValueError("stream does not end cleanly (end state %d at byte %d)"
-                                 % (res.end_state, add + res.end_offset))
-        elif res.end_state != _hip.END_REFILL:
-            raise ValueError("rank %d: invalid entry at byte %d" % (rank, add + res.end_offset))
-        cut = getattr(self.backend, "cut", None)
-        if cut is not None:
-            i0, i1, first_pos, exit_pos = cut(table, n, -(1 << 62) if rank == 0 else own_lo_file,
-                                              (1 << 62) if eof else own_hi_file)
-        else:
-            i0 = 0 if rank == 0 else self.backend.lower_bound(table, n, own_lo_file)
-            i1 = n if eof else self.backend.lower_bound(table, n, own_hi_file)
-            first_pos = self.backend.row(table, i0)[0] if i0 < n else -1
-            exit_pos = self.backend.row(table, i1)[0] if i1 < n else -1
-        if not eof and exit_pos < 0:
-            raise RuntimeError("rank %d: no complete record starts after byte %d within the %d-byte "
-                               "look-ahead (record longer than the halo)" % (rank, own_hi_file, head))
-        out = ScanOutput(res, n, i0, i1, exit_pos, first_pos)
-        if world > 1:
-            self._verify_and_count(out)
+    def scan(self, ext, tail, head, table, flags=0, qual=None, qoff=None):
+        """ext = [tail | own | head] bytes (1-D uint8 tensor), halo filled (exchange_halo).  Returns
+        ScanOutput; table rows are absolute stream offsets."""
+        return self._complete(_View(ext, tail, head, self.lo, self.hi, self.total, self.origin), table, flags, qual, qoff, None)
+
+    def _complete(self, v, table, flags, qual, qoff, first):
+        st = self._local(v, table, flags, qual, qoff, first=first)
+        st, cnt, rounds = self._settle(st, table, flags, qual, qoff)
+        out = ScanOutput(st.res, st.n, st.row_lo, st.row_hi, st.exit, st.first)
+        out.record_base = sum(cnt[:self.rank])
+        out.total_records = sum(cnt)
+        out.rounds = rounds
+        out.ext, out.tail, out.head = st.v.ext, st.v.tail, st.v.head
         return out
-
-    def _verify_and_count(self, out):
-        import torch
-        dist, rank, world = self.dist, self.rank, self.world
-        dev = self.device
-        if dist.get_backend(self.group) == "gloo":
-            dev = torch.device("cpu")
-        mine = torch.tensor([out.exit_pos, out.n_own_records], dtype=torch.int64, device=dev)
-        if dev.type == "cuda":
-            # one collective into one tensor, one copy back
-            flat = torch.empty(2 * world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(flat, mine, group=self.group)
-            v = flat.tolist()
-            allv = [v[2 * r:2 * r + 2] for r in range(world)]
-        else:
-            allv = [torch.empty(2, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(allv, mine, group=self.group)
-            allv = [[int(x) for x in t.tolist()] for t in allv]
-        if rank > 0 and allv[rank - 1][0] != out.first_pos:
-            raise RuntimeError("rank %d: edge hand-off mismatch: left neighbour's chain enters this range "
-                               "at byte %d, this rank started at %d" % (rank, allv[rank - 1][0], out.first_pos))
-        out.record_base = sum(v[1] for v in allv[:rank])
-        out.total_records = sum(v[1] for v in allv)
 
 
 class SyntheticShard:
@@ -261,14 +454,17 @@ class SyntheticShard:
     (SURVEY.md 8d); cut points are moved off the record boundaries so that a
     record straddles every edge."""
 
-    def __init__(self, ctx, kind, bytes_per_gpu, rank, world, dev, edge_shift=144):
+    def __init__(self, ctx, kind, bytes_per_gpu, rank, world, dev, edge_shift=144, transport=None):
         import torch
         from . import synth
         self.ctx, self.kind, self.rank, self.world, self.dev = ctx, kind, rank, world, dev
-        self.dist = None
-        if world > 1:
-            import torch.distributed as dist
-            self.dist = dist
+        if transport is None:
+            if world > 1:
+                import torch.distributed as dist
+                transport = DistTransport(dist, None, dev)
+            else:
+                transport = SoloTransport()
+        self.transport = transport
         if kind == "single":
             n_per = bytes_per_gpu // synth.RECORD_BYTES
             blk_bytes = [n_per * synth.RECORD_BYTES] * world
@@ -278,24 +474,17 @@ class SyntheticShard:
             sizes = synth.wrapped_sizes(rank * n_per, n_per + 1, seed=43)
             starts = np.zeros(n_per + 2, dtype=np.int64)
             np.cumsum(sizes, out=starts[1:])
-            mine = int(starts[n_per])
-            if world > 1:
-                t = torch.tensor([mine], dtype=torch.int64, device=dev)
-                allt = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
-                self.dist.all_gather(allt, t)
-                blk_bytes = [int(x.item()) for x in allt]
-            else:
-                blk_bytes = [mine]
+            blk_bytes = [v[0] for v in transport.allgather([int(starts[n_per])])]
         self.n_per = n_per
         B = [0]
         for b in blk_bytes:
             B.append(B[-1] + b)
         total = B[-1]
         S = [0] + [(B[r] + edge_shift) // 16 * 16 for r in range(1, world)] + [total]
+        self.bounds = S
         self.own_lo, self.own_hi = S[rank], S[rank + 1]
         self.n_own_bytes = self.own_hi - self.own_lo
-        self.tail = TAIL_BYTES if rank > 0 else 0
-        self.head = HEAD_BYTES if rank < world - 1 else 0
+        self.tail, self.head = halo_sizes(S, rank)
         self.block_start = B[rank]
 
         # records [rank*n_per, (rank+1)*n_per (+1)) generated record-aligned, then the range is cut out
@@ -319,21 +508,14 @@ class SyntheticShard:
         self.ext_scanned_bytes = self.tail + self.n_own_bytes + self.head
         min_rec = 322 if kind == "single" else 120
         self.max_records = n_per + (self.tail + self.head) // min_rec + 64
-        self.scanner = ShardScanner(HipBackend(ctx), rank, world, self.dist, None, dev)
-        self._xstream = None
+        self.scanner = ShardScanner(HipBackend(ctx), transport, S)
         self._lanes = None
 
     def scan(self, table, flags=0, qual=None, qoff=None):
-        if self.world > 1:
-            # the hand-off runs on the scan's own stream (RCCL orders itself against the current
-            # stream): the scan that follows needs no host synchronisation in between
-            import torch
-            if self._xstream is None:
-                self._xstream = torch.cuda.ExternalStream(self.ctx.stream(), device=self.dev)
-            with torch.cuda.stream(self._xstream):
-                exchange_edges(self.dist, self.ext, self.tail, self.n_own_bytes, self.head, self.rank, self.world)
-        return self.scanner.scan(self.ext, self.tail, self.n_own_bytes, self.head, self.own_lo, self.own_hi,
-                                 table, flags, qual, qoff)
+        # the hand-off runs on the scan's own stream: the scan that follows needs no host
+        # synchronisation in between
+        self.scanner.exchange_halo(self.ext, self.tail, self.head)
+        return self.scanner.scan(self.ext, self.tail, self.head, table, flags, qual, qoff)
 
     # ---- pipelined steps: submit(i + 1) before finish(i) -------------------------------------
     def make_lanes(self, n=2):
@@ -342,24 +524,18 @@ class SyntheticShard:
         behind the next step's kernels."""
         from . import hip
         post = hip.Context(self.ctx.device)
-        lanes = [ShardScanner(HipBackend(self.ctx, post), self.rank, self.world, self.dist, None, self.dev)]
+        lanes = [ShardScanner(HipBackend(self.ctx, post), self.transport, self.bounds)]
         for _ in range(n - 1):
             c = hip.Context(share=self.ctx)
             c.reserve(self.ext.numel())
-            lanes.append(ShardScanner(HipBackend(c, post), self.rank, self.world, self.dist, None, self.dev))
+            lanes.append(ShardScanner(HipBackend(c, post), self.transport, self.bounds))
         self._lanes = lanes
         self._post = post
         return lanes
 
     def submit(self, lane, table, flags=0, qual=None, qoff=None):
-        import torch
-        if self.world > 1:
-            if self._xstream is None:
-                self._xstream = torch.cuda.ExternalStream(self.ctx.stream(), device=self.dev)
-            with torch.cuda.stream(self._xstream):
-                exchange_edges(self.dist, self.ext, self.tail, self.n_own_bytes, self.head, self.rank, self.world)
-        self._lanes[lane].submit(self.ext, self.tail, self.n_own_bytes, self.head, self.own_lo, self.own_hi,
-                                 table, flags, qual, qoff)
+        self._lanes[lane].exchange_halo(self.ext, self.tail, self.head)
+        self._lanes[lane].submit(self.ext, self.tail, self.head, table, flags, qual, qoff)
 
     def finish(self, lane):
         return self._lanes[lane].finish()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FFQ_ABI_VERSION 1
+#define FFQ_ABI_VERSION 2
 
 /* scanner status codes -- identical to the reference's module constants
  * (_fastqandfurious.c:7-15,254-262; fastqandfurious.py:19-27)             */
@@ -182,10 +182,13 @@ int ffq_table_lower_bound(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, 
                           int64_t value, int64_t *idx);
 
 /* The rows of a byte-range shard inside the table of its scan: out = {i0, i1, pos0[i0],
- * pos0[i1]} with i0 / i1 the first rows whose pos0 (column 0) is >= lo / >= hi
- * (n_rows if none; the positions are -1 then).  One launch, one host wait.   */
+ * pos0[i1], pos5[i0 - 1], pos5[i1 - 1]} with i0 / i1 the first rows whose pos0 (column 0) is
+ * >= lo / >= hi (n_rows if none; the positions are -1 then), and pos5 of the rows right in
+ * front of them (-1 if there is none): the record chain found row i searching from
+ * pos5[i - 1] - 1 (fastqandfurious.py:254), which is where a neighbour shard re-enters the
+ * chain.  One launch, one host wait.                                          */
 int ffq_table_cut(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t lo, int64_t hi,
-                  int64_t out[4]);
+                  int64_t out[6]);
 
 /* Rows of a device offset table whose sequence length pos3 - pos2 lies in
  * [min_len, max_len], in order, written to d_out (n_rows rows of room; not

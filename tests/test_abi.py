@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(hip):
 
 
 def test_abi_version_and_status_codes(hip):
-    assert hip.lib().ffq_abi_version() == 1
+    assert hip.lib().ffq_abi_version() == 2
     text = open(os.path.join(ROOT, "include", "ffq.h")).read()
     for name, val in (("FFQ_INVALID", "(-1)"), ("FFQ_COMPLETE", "6"), ("FFQ_MISSING_QUALHEADER_END", "7"),
                       ("FFQ_POS_QUAL_END", "5")):

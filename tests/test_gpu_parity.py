@@ -427,15 +427,17 @@ def test_table_cut(gpu_ctx):
         p0 = np.sort(rng.choice(10 * n + 10, size=n, replace=False)).astype(np.int64) if n else np.zeros(0, np.int64)
         t = np.zeros((max(n, 1), 6), dtype=np.int64)
         t[:n, 0] = p0
+        t[:n, 5] = p0 + 7
         d = torch.from_numpy(t).cuda()
         qs = [-(1 << 62), 0, 1 << 62] + ([int(p0[0]), int(p0[-1]), int(p0[-1]) + 1, int(p0[n // 2]), int(p0[n // 2]) + 1]
                                        if n else [])
         for lo in qs:
             for hi in qs:
-                i0, i1, f0, f1 = gpu_ctx.table_cut(d.data_ptr(), n, lo, hi)
+                i0, i1, f0, f1, q0, q1 = gpu_ctx.table_cut(d.data_ptr(), n, lo, hi)
                 e0, e1 = int(np.searchsorted(p0, lo, side="left")), int(np.searchsorted(p0, hi, side="left"))
                 assert (i0, i1) == (e0, e1), (n, lo, hi)
                 assert f0 == (int(p0[e0]) if e0 < n else -1) and f1 == (int(p0[e1]) if e1 < n else -1)
+                assert q0 == (int(p0[e0 - 1]) + 7 if e0 > 0 else -1) and q1 == (int(p0[e1 - 1]) + 7 if e1 > 0 else -1)
 
 
 def _mess(rng, n, fatal=True):

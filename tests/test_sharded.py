@@ -1,10 +1,24 @@
-"""Byte-range sharding host logic (fastq-and-furious_amd/sharded.py) over gloo,
-world_size 2 and 3, on CPU tensors.  The scan engine is the CPU oracle (test
-infrastructure); what is under test is the edge hand-off, the row ownership
-cut, the 8-byte verification and the record-ordinal all_gather."""
+"""Byte-range sharding (fastq-and-furious_amd/sharded.py).
+
+CPU (`-m "not gpu"`): the host protocol -- halo hand-off by owner, row ownership cut, hand-off
+verification, look-ahead growth for records longer than the halo, re-entry from the left
+neighbour's exit, stream errors raised by every rank -- with the CPU oracle as the scan engine
+(test infrastructure), over gloo (world 2 and 3, separate processes) and over the in-process
+transport (k logical ranks as threads).
+
+GPU (`-m gpu`): the same protocol on the HIP engine -- k in {2, 3, 8} logical ranges of one
+resident buffer through ShardScanner(HipBackend) with the in-process transport, S-single and
+S-wrapped, with and without decode, stream offsets past 2^32 (so that `add` and ffq_table_cut
+see the offsets of BASELINE config 5), records longer than the halo across an edge.  The unit
+that shards is the record chain of /root/reference/src/fastqandfurious.py:251-279; the reference
+grows its buffer until a record fits (:274-279).
+
+Concatenated shard rows must equal the oracle's single-range table, bit for bit."""
+import contextlib
 import os
 import socket
 import sys
+import threading
 import types
 
 import numpy as np
@@ -29,7 +43,7 @@ class OracleBackend:
         table[:n] = torch.from_numpy(t)
         res = types.SimpleNamespace(n_records=n, end_state=end, end_offset=off, last_status=status,
                                     last_pos=[-1] * 6, path=0, n_qual_bytes=0)
-        if end != 0 and end != 1:
+        if end != 0:
             st, pos = self.o.entrypos(np.concatenate([np.array([10], dtype=np.uint8), data])
                                       if sentinel else data, off, 0)
             res.last_pos = [int(p) + add if p >= 0 else -1 for p in pos]
@@ -43,50 +57,262 @@ class OracleBackend:
         a, kw = self._queued
         return self.scan(*a, **kw)
 
-    def lower_bound(self, table, n_rows, value):
-        return int(np.searchsorted(table[:n_rows, 0].numpy(), value, side="left"))
+    def cut(self, table, n_rows, lo, hi):
+        t = table[:n_rows].numpy()
+        i0, i1 = (int(np.searchsorted(t[:, 0], x, side="left")) for x in (lo, hi))
+        return (i0, i1, int(t[i0, 0]) if i0 < n_rows else -1, int(t[i1, 0]) if i1 < n_rows else -1,
+                int(t[i0 - 1, 5]) if i0 > 0 else -1, int(t[i1 - 1, 5]) if i1 > 0 else -1)
 
-    def row(self, table, idx):
-        return [int(x) for x in table[idx]]
-
-    def sync_inputs(self):
-        pass
+    def stream_context(self, ext):
+        return contextlib.nullcontext()
 
 
+# ---- streams ------------------------------------------------------------------------------------
+def _long_record(seq_len, wrap=0):
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[np.arange(seq_len) % 4]
+    q = (33 + (np.arange(seq_len) * 7) % 41).astype(np.uint8)
+    if wrap:
+        def w(a):
+            n = (a.size + wrap - 1) // wrap
+            out = np.full(a.size + n - 1, 10, dtype=np.uint8)
+            idx = np.arange(a.size) + np.arange(a.size) // wrap
+            out[idx] = a
+            return out
+        seq, q = w(seq), w(q)
+    return b"@long/1\n" + seq.tobytes() + b"\n+\n" + q.tobytes() + b"\n"
+
+
+def _fake_fastq_quality(L):
+    """A record whose quality block is itself FASTQ-looking text: guesses that start inside it
+    follow a chain of records that do not exist."""
+    unit = b"@fake\nACGTACGT\n+\nIIIIIIII\n"
+    q = (unit * (L // len(unit) + 1))[:L]
+    if q.endswith(b"\n"):
+        q = q[:-1] + b"I"
+    k, m = divmod(L, 81)
+    if m == 0:
+        k, m = k - 1, 81
+    seq = (b"A" * 80 + b"\n") * k + b"C" * m       # same byte length as the quality block
+    assert len(seq) == L
+    return b"@tricky/1\n" + seq + b"\n+\n" + q + b"\n"
+
+
+def make_stream(kind):
+    import fastqandfurious_amd  # noqa: F401
+    from fastqandfurious_amd import synth
+    if kind == "single":
+        return synth.single(0, 14000, seed=42)
+    if kind == "wrapped":
+        return synth.wrapped(0, 12000, seed=43)[0]
+    if kind == "long":           # a 3 MiB record in the middle: longer than the 1 MiB halo on either side
+        a = synth.single(0, 5000, seed=42).tobytes()
+        b = synth.single(5000, 5000, seed=42).tobytes()
+        return np.frombuffer(a + _long_record(1536 << 10) + b, dtype=np.uint8)
+    if kind == "long-wrapped":
+        a = synth.wrapped(0, 3000, seed=43)[0].tobytes()
+        return np.frombuffer(a + _long_record(1200 << 10, wrap=80) + a, dtype=np.uint8)
+    if kind == "tricky":         # guesses inside the 1.5 MiB quality block are wrong
+        a = synth.single(0, 4000, seed=42).tobytes()
+        b = synth.single(4000, 3000, seed=42).tobytes()
+        return np.frombuffer(a + _fake_fastq_quality(1536 << 10) + b, dtype=np.uint8)
+    if kind == "small":
+        return synth.single(0, 40, seed=42)
+    if kind == "truncated":      # 'Incomplete final quality string at byte'
+        return synth.single(0, 9000, seed=42)[:-100]
+    if kind == "cut-header":     # 'Incomplete entry at byte %i'
+        return synth.single(0, 9000, seed=42)[:-315]
+    if kind == "invalid":        # 'Entry is invalid at byte %i': a '+' line of the wrong length
+        s = synth.single(0, 9000, seed=42).tobytes()
+        k = 6000 * 322
+        return np.frombuffer(s[:k + 169] + b"+SYN\n" + s[k + 171:], dtype=np.uint8)
+    raise KeyError(kind)
+
+
+def expected(oracle, stream, origin=0):
+    from conftest import rows_of  # noqa: F401
+    want, end, st, off = oracle.scan(stream)
+    err = None
+    if end == 2:
+        err = "Incomplete final quality string at byte"
+    elif end == 3:
+        err = "Incomplete entry at byte %i" % (off - 1 + origin)
+    elif end == 4:
+        err = "Entry is invalid at byte %i" % (off - 1 + origin)
+    return want + origin, err
+
+
+# ---- k logical ranks as threads of one process ---------------------------------------------------
+def run_local(stream_t, bounds, make_backend, tail_bytes=None, head_bytes=None, flags=0, lanes=False,
+              table_rows=None, decode=False):
+    """Every rank: ext = [zeros | own bytes | zeros] -> exchange_halo -> scan.  Returns the list of
+    (ScanOutput, table, qual, qoff) per rank, or raises what the ranks raised (all the same)."""
+    from fastqandfurious_amd import sharded
+    world = len(bounds) - 1
+    lw = sharded.LocalWorld(world)
+    kw = {}
+    if tail_bytes is not None:
+        kw = dict(tail_bytes=tail_bytes, head_bytes=head_bytes)
+    results, errors = [None] * world, [None] * world
+    origin = bounds[0]
+    n_rows = table_rows or (stream_t.numel() // 40 + 64)
+
+    def work(rank):
+        try:
+            sc = sharded.ShardScanner(make_backend(rank), lw.transport(rank), bounds, **kw)
+            tail, head = sc.halo()
+            lo, hi = bounds[rank], bounds[rank + 1]
+            ext = torch.zeros(tail + (hi - lo) + head + 64, dtype=torch.uint8, device=stream_t.device)
+            ext[tail:tail + hi - lo] = stream_t[lo - origin:hi - origin]
+            if ext.is_cuda:
+                torch.cuda.synchronize()
+            table = torch.empty((n_rows, 6), dtype=torch.int64, device=stream_t.device)
+            qual = qoff = None
+            if decode:
+                qual = torch.empty(ext.numel() + (8 << 20), dtype=torch.int8, device=stream_t.device)
+                qoff = torch.empty(n_rows + 1, dtype=torch.int64, device=stream_t.device)
+            sc.exchange_halo(ext, tail, head)
+            if ext.is_cuda:
+                torch.cuda.synchronize()
+            got = ext[:tail + hi - lo + head].cpu().numpy()
+            ref = stream_t[lo - tail - origin:hi + head - origin].cpu().numpy()
+            assert (got == ref).all(), "halo bytes differ"
+            if lanes:
+                sc.submit(ext, tail, head, table, flags, qual, qoff)
+                out = sc.finish()
+            else:
+                out = sc.scan(ext, tail, head, table, flags, qual, qoff)
+            results[rank] = (out, table, qual, qoff)
+        except BaseException as e:   # noqa: BLE001
+            errors[rank] = e
+            lw.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    real = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if real:
+        if all(isinstance(e, ValueError) for e in real) and len(real) == world:
+            assert len({str(e) for e in real}) == 1, "ranks disagree on the stream error: %r" % real
+        raise real[0]
+    assert not any(errors), errors
+    return results
+
+
+def check_rows(results, bounds, want):
+    world = len(bounds) - 1
+    parts, base = [], 0
+    for r in range(world):
+        out, table = results[r][0], results[r][1]
+        rows = table[out.row_lo:out.row_hi].cpu().numpy()
+        mine = want[(want[:, 0] >= bounds[r]) & (want[:, 0] < bounds[r + 1])]
+        assert rows.shape == mine.shape and (rows == mine).all(), "rank %d: shard rows differ from the single-range table" % r
+        assert out.record_base == base and out.total_records == len(want)
+        base += len(mine)
+        parts.append(rows)
+    got = np.concatenate(parts) if parts else np.zeros((0, 6), np.int64)
+    assert got.shape == want.shape and (got == want).all()
+
+
+def bounds_for(total, world, origin=0, shift=0):
+    from fastqandfurious_amd import sharded
+    b = sharded.shard_bounds(total, world)
+    b = [b[0]] + [min(max(x + shift, 0), total) // 16 * 16 for x in b[1:-1]] + [b[-1]]
+    return [x + origin for x in b]
+
+
+LOCAL_CASES = [
+    ("single", 2, {}), ("single", 3, {}), ("single", 8, {}),
+    ("wrapped", 2, {}), ("wrapped", 3, {}), ("wrapped", 8, {}),
+    # halos shorter than a record: every edge grows its look-ahead; run-ins too short to synchronise
+    ("single", 3, dict(tail_bytes=64, head_bytes=48)),
+    ("wrapped", 8, dict(tail_bytes=256, head_bytes=64)),
+    ("wrapped", 3, dict(tail_bytes=1, head_bytes=16)),
+    # a 3 MiB record across an edge with the product's 1 MiB halos
+    ("long", 2, {}), ("long", 3, {}), ("long", 8, {}), ("long-wrapped", 2, {}), ("long-wrapped", 8, {}),
+    # ranges that start inside a quality block made of FASTQ-looking text: wrong guesses, re-entry
+    ("tricky", 2, {}), ("tricky", 3, {}), ("tricky", 8, {}),
+    # shards smaller than the halo: the halo comes from several ranks
+    ("small", 8, {}), ("small", 5, dict(tail_bytes=700, head_bytes=900)),
+]
+
+
+@pytest.mark.parametrize("kind,world,kw", LOCAL_CASES)
+def test_local_ranks_oracle_engine(oracle, pkg, kind, world, kw):
+    stream = make_stream(kind)
+    want, err = expected(oracle, stream)
+    assert err is None
+    t = torch.from_numpy(stream.copy())
+    for origin, shift in ((0, 0), (5 * (1 << 32) + 123457, 48)):
+        bounds = bounds_for(stream.size, world, origin, shift)
+        res = run_local(t, bounds, lambda r: OracleBackend(), lanes=(origin != 0), **kw)
+        check_rows(res, bounds, want + origin)
+    if kind in ("long", "long-wrapped") and not kw:
+        assert any(r[0].rounds > 0 and r[0].head > (1 << 20) for r in res), "no rank grew its look-ahead"
+    if kind == "tricky":
+        assert any(r[0].rounds > 0 for r in res)
+
+
+@pytest.mark.parametrize("kind", ("truncated", "cut-header", "invalid"))
+@pytest.mark.parametrize("world", (2, 3, 8))
+def test_local_ranks_stream_errors(oracle, pkg, kind, world):
+    """The iterator's ValueErrors (fastqandfurious.py:262, :269, :272), raised by every rank with
+    the text the single-range scan gives."""
+    stream = make_stream(kind)
+    _want, err = expected(oracle, stream)
+    assert err is not None
+    t = torch.from_numpy(stream.copy())
+    with pytest.raises(ValueError) as ei:
+        run_local(t, bounds_for(stream.size, world), lambda r: OracleBackend())
+    assert str(ei.value) == err
+
+
+def test_local_ranks_empty_and_tiny(oracle, pkg):
+    for n in (0, 1, 17, 100, 322, 323, 700):
+        stream = make_stream("small")[:n]
+        want, err = expected(oracle, stream)
+        t = torch.from_numpy(stream.copy())
+        for world in (2, 4):
+            bounds = bounds_for(stream.size, world)
+            if err is None:
+                check_rows(run_local(t, bounds, lambda r: OracleBackend()), bounds, want)
+            else:
+                with pytest.raises(ValueError) as ei:
+                    run_local(t, bounds, lambda r: OracleBackend())
+                assert str(ei.value) == err
+
+
+# ---- separate processes over gloo -----------------------------------------------------------------
 def _worker(rank, world, port, kind, tmpdir):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import fastqandfurious_amd  # noqa: F401
-        from fastqandfurious_amd import sharded, synth
+        from fastqandfurious_amd import sharded
         from oracle import ffq_oracle
-        if kind == "single":
-            stream = synth.single(0, 14000, seed=42)
-        elif kind == "wrapped":
-            stream, _ = synth.wrapped(0, 12000, seed=43)
-        else:   # a stream whose run-in starts on a false '@' candidate that dies INVALID
-            stream, _ = synth.wrapped(0, 12000, seed=43)
+        stream = make_stream(kind)
         total = stream.size
         S = sharded.shard_bounds(total, world)
         lo, hi = S[rank], S[rank + 1]
-        tail = min(sharded.TAIL_BYTES, S[rank] - S[rank - 1]) if rank > 0 else 0
-        head = min(sharded.HEAD_BYTES, S[rank + 2] - S[rank + 1]) if rank < world - 1 else 0
+        tr = sharded.DistTransport(dist, None, torch.device("cpu"))
+        sc = sharded.ShardScanner(OracleBackend(), tr, S)
+        tail, head = sc.halo()
         ext = torch.zeros(tail + (hi - lo) + head, dtype=torch.uint8)
         ext[tail:tail + hi - lo] = torch.from_numpy(stream[lo:hi].copy())
-        # P2P sizes must agree on both sides: neighbours send min(HEAD/TAIL, their n_own)
-        sharded.exchange_edges(dist, ext, tail, hi - lo, head, rank, world)
-        assert bytes(ext.numpy()) == bytes(stream[lo - tail:hi + head]), "edge bytes differ"
-        table = torch.empty((20000, 6), dtype=torch.int64)
-        sc = sharded.ShardScanner(OracleBackend(), rank, world, dist, None, torch.device("cpu"))
-        out = sc.scan(ext, tail, hi - lo, head, lo, hi, table)
+        sc.exchange_halo(ext, tail, head)
+        assert bytes(ext.numpy()) == bytes(stream[lo - tail:hi + head]), "halo bytes differ"
+        table = torch.empty((100000, 6), dtype=torch.int64)
+        out = sc.scan(ext, tail, head, table)
         # the same step through submit / finish, two lanes, two rounds (the queue bench.py keeps)
-        lanes = [sc, sharded.ShardScanner(OracleBackend(), rank, world, dist, None, torch.device("cpu"))]
+        lanes = [sc, sharded.ShardScanner(OracleBackend(), tr, S)]
         tabs = [table, torch.empty_like(table)]
-        lanes[0].submit(ext, tail, hi - lo, head, lo, hi, tabs[0])
+        lanes[0].submit(ext, tail, head, tabs[0])
         for i in range(1, 4):
-            lanes[i & 1].submit(ext, tail, hi - lo, head, lo, hi, tabs[i & 1])
+            lanes[i & 1].submit(ext, tail, head, tabs[i & 1])
             o2 = lanes[(i - 1) & 1].finish()
             assert (o2.row_lo, o2.row_hi, o2.exit_pos, o2.first_pos, o2.record_base) == \
                    (out.row_lo, out.row_hi, out.exit_pos, out.first_pos, out.record_base)
@@ -99,6 +325,8 @@ def _worker(rank, world, port, kind, tmpdir):
         first = int(np.searchsorted(want[:, 0], lo))
         assert out.record_base == first
         assert out.total_records == len(want)
+        if kind == "long":
+            assert out.rounds > 0
         np.save(os.path.join(tmpdir, "rows_%d.npy" % rank), got)
     finally:
         dist.destroy_process_group()
@@ -112,18 +340,183 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,kind", ((2, "single"), (2, "wrapped"), (3, "wrapped")))
+@pytest.mark.parametrize("world,kind", ((2, "single"), (2, "wrapped"), (3, "wrapped"), (2, "long"), (3, "tricky")))
 def test_sharded_scan_gloo(tmp_path, oracle, world, kind):
     mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
-    import fastqandfurious_amd  # noqa: F401
-    from fastqandfurious_amd import synth
-    stream = synth.single(0, 14000, seed=42) if kind == "single" else synth.wrapped(0, 12000, seed=43)[0]
+    stream = make_stream(kind)
     want, *_ = oracle.scan(stream)
     got = np.concatenate([np.load(os.path.join(str(tmp_path), "rows_%d.npy" % r)) for r in range(world)])
     assert (got == want).all()
+
+
+def _error_worker(rank, world, port, kind, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fastqandfurious_amd  # noqa: F401
+        from fastqandfurious_amd import sharded
+        stream = make_stream(kind)
+        S = sharded.shard_bounds(stream.size, world)
+        lo, hi = S[rank], S[rank + 1]
+        sc = sharded.ShardScanner(OracleBackend(), sharded.DistTransport(dist, None, torch.device("cpu")), S)
+        tail, head = sc.halo()
+        ext = torch.zeros(tail + (hi - lo) + head, dtype=torch.uint8)
+        ext[tail:tail + hi - lo] = torch.from_numpy(stream[lo:hi].copy())
+        sc.exchange_halo(ext, tail, head)
+        msg = "none"
+        try:
+            sc.scan(ext, tail, head, torch.empty((100000, 6), dtype=torch.int64))
+        except ValueError as e:
+            msg = str(e)
+        with open(os.path.join(tmpdir, "err_%d.txt" % rank), "w") as fh:
+            fh.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_stream_error_gloo(tmp_path, oracle):
+    mp.spawn(_error_worker, args=(2, _free_port(), "invalid", str(tmp_path)), nprocs=2, join=True)
+    _want, err = expected(oracle, make_stream("invalid"))
+    for r in range(2):
+        assert open(os.path.join(str(tmp_path), "err_%d.txt" % r)).read() == err
 
 
 def test_shard_bounds(pkg):
     from fastqandfurious_amd import sharded
     b = sharded.shard_bounds(1000003, 4)
     assert b[0] == 0 and b[-1] == 1000003 and all(x % 16 == 0 for x in b[:-1]) and b == sorted(b)
+    # every byte of every halo has exactly one provider
+    plan = sharded.halo_plan([0, 1600, 3200, 4800, 5000], 1000, 2000)
+    for q in range(4):
+        got = sorted((a, c) for s, d, a, c in plan if d == q)
+        lo, hi = [0, 1600, 3200, 4800, 5000][q:q + 2]
+        need = [(max(lo - 1000, 0), lo), (hi, min(hi + 2000, 5000))]
+        covered = sum(c - a for a, c in got)
+        assert covered == sum(c - a for a, c in need)
+        assert all(s != q for s, d, a, c in plan if d == q)
+
+
+# ---- the HIP engine ---------------------------------------------------------------------------------
+def _hip_backends(gpu_ctx):
+    """One context (= stream + scratch) per logical rank: contexts are not shared between threads."""
+    from fastqandfurious_amd import hip, sharded
+    made = {}
+
+    def make(rank):
+        made[rank] = hip.Context(0)
+        return sharded.HipBackend(made[rank])
+    return make, made
+
+
+GPU_CASES = [
+    ("single", 2, {}), ("single", 3, {}), ("single", 8, {}),
+    ("wrapped", 2, {}), ("wrapped", 3, {}), ("wrapped", 8, {}),
+    ("single", 3, dict(tail_bytes=64, head_bytes=48)),
+    ("wrapped", 8, dict(tail_bytes=256, head_bytes=64)),
+    ("long", 2, {}), ("long", 8, {}), ("long-wrapped", 3, {}),
+    ("tricky", 2, {}), ("tricky", 8, {}),
+    ("small", 8, {}),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world,kw", GPU_CASES)
+@pytest.mark.parametrize("decode", (False, True))
+def test_local_ranks_hip_engine(gpu_ctx, oracle, kind, world, kw, decode):
+    from fastqandfurious_amd import hip
+    stream = make_stream(kind)
+    want, err = expected(oracle, stream)
+    assert err is None
+    t = torch.from_numpy(stream.copy()).cuda()
+    wq, wqoff = oracle.decode_quals(stream, want) if decode else (None, None)
+    for origin, shift, lanes in ((0, 0, False), (5 * (1 << 32) + 123457, 48, True)):
+        bounds = bounds_for(stream.size, world, origin, shift)
+        make, made = _hip_backends(gpu_ctx)
+        res = run_local(t, bounds, make, lanes=lanes, decode=decode, flags=hip.F_DECODE_QUAL if decode else 0, **kw)
+        check_rows(res, bounds, want + origin)
+        if decode:
+            # every rank decoded the records of its whole view; its own records' qualities, in
+            # order, are the stream's
+            base = 0
+            for r in range(world):
+                out, table, qual, qoff = res[r]
+                n_own = out.row_hi - out.row_lo
+                qo = qoff[out.row_lo:out.row_hi + 1].cpu().numpy()
+                q = qual[int(qo[0]):int(qo[-1])].cpu().numpy() if n_own else np.zeros(0, np.int8)
+                assert (qo - qo[0] == wqoff[base:base + n_own + 1] - wqoff[base]).all()
+                assert (q == wq[int(wqoff[base]):int(wqoff[base + n_own])]).all(), "rank %d: decoded qualities differ" % r
+                base += n_own
+        for c in made.values():
+            c.close()
+    if kind in ("long", "long-wrapped") and not kw:
+        assert any(r[0].rounds > 0 and r[0].head > (1 << 20) for r in res), "no rank grew its look-ahead"
+    if kind == "tricky":
+        assert any(r[0].rounds > 0 for r in res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("truncated", "cut-header", "invalid"))
+def test_local_ranks_hip_engine_stream_errors(gpu_ctx, oracle, kind):
+    stream = make_stream(kind)
+    _want, err = expected(oracle, stream)
+    t = torch.from_numpy(stream.copy()).cuda()
+    for world in (2, 8):
+        make, made = _hip_backends(gpu_ctx)
+        with pytest.raises(ValueError) as ei:
+            run_local(t, bounds_for(stream.size, world), make)
+        assert str(ei.value) == err
+        for c in made.values():
+            c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("single", "wrapped"))
+def test_synthetic_shards_local_ranks(gpu_ctx, kind):
+    """bench.py's SyntheticShard, k = 4 logical ranks on one GPU (the N > 1 code path of bench.py
+    without RCCL): generation per rank, halo hand-off, pipelined submit / finish lanes, and the
+    closed-form checks bench.py applies to its measured output."""
+    from fastqandfurious_amd import hip, sharded
+    world = 4
+    lw = sharded.LocalWorld(world)
+    dev = torch.device("cuda", 0)
+    errors = [None] * world
+    totals = [None] * world
+
+    def work(rank):
+        try:
+            ctx = hip.Context(0)
+            sh = sharded.SyntheticShard(ctx, kind, 24 << 20, rank, world, dev, transport=lw.transport(rank))
+            ctx.reserve(sh.ext.numel())
+            table = torch.empty((sh.max_records + 64, 6), dtype=torch.int64, device=dev)
+            qual = torch.empty(sh.ext.numel(), dtype=torch.int8, device=dev)
+            qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
+            out = sh.scan(table, flags=hip.F_DECODE_QUAL, qual=qual, qoff=qoff)
+            sh.verify(table, out)
+            sh.verify_decode(table, out, qual, qoff)
+            sh.make_lanes(2)
+            tabs = (table, torch.empty_like(table))
+            sh.submit(0, tabs[0])
+            for i in range(1, 4):
+                sh.submit(i & 1, tabs[i & 1])
+                o2 = sh.finish((i - 1) & 1)
+                sh.verify(tabs[(i - 1) & 1], o2)
+                assert (o2.row_lo, o2.row_hi, o2.record_base) == (out.row_lo, out.row_hi, out.record_base)
+            o2 = sh.finish(3 & 1)
+            totals[rank] = (out.total_records, out.record_base, out.n_own_records)
+        except BaseException as e:   # noqa: BLE001
+            errors[rank] = e
+            lw.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    real = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if real:
+        raise real[0]
+    assert sum(t[2] for t in totals) == totals[0][0]
+    assert [t[1] for t in totals] == [sum(x[2] for x in totals[:r]) for r in range(world)]
