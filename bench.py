@@ -158,7 +158,7 @@ def host_inclusive(ctx, sample_u8, flags):
             "sample": "ffq_scan_host over the first %d bytes, pageable host memory in and out" % sample_u8.size}
 
 
-def stream_inclusive(ctx, sample_u8):
+def stream_inclusive(ctx, sample_u8, fbufsize=1 << 24):
     """File in, offset table out through the native stream front end (ffq_stream_*): chunked
     reads into pinned memory overlapped with H2D + scan + D2H.  The file sits in /dev/shm (page
     cache speed, no disk); like `host_inclusive` this is never `value`."""
@@ -173,7 +173,7 @@ def stream_inclusive(ctx, sample_u8):
         for _ in range(3):
             fd = os.open(path, os.O_RDONLY)
             t0 = time.perf_counter()
-            st = hip.FileStream(ctx, fd, 1 << 24)
+            st = hip.FileStream(ctx, fd, fbufsize)
             recs = sum(rows.shape[0] for rows, _f, _o, _e, _x in st)
             st.close()
             os.close(fd)
@@ -194,7 +194,7 @@ def stream_inclusive(ctx, sample_u8):
         os.unlink(path)
     return {"value": round(sample_u8.size / best / 1e9, 3), "unit": "GB/s",
             "m_reads_per_s": round(recs / best / 1e6, 3),
-            "sample": "ffq_stream over a %d-byte file in %s, 16 MiB chunks, best of 3" % (sample_u8.size, d),
+            "sample": "ffq_stream over a %d-byte file in %s, %d MiB chunks, best of 3" % (sample_u8.size, d, fbufsize >> 20),
             "iterator_m_reads_per_s": round(n_it / el_it / 1e6, 3),
             "iterator_sample": "%d (header, sequence, quality) tuples from readfastq_iter(entryfunc, GPU "
                                "scanner) over the same file, %.1f s" % (n_it, el_it)}

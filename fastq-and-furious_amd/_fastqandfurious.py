@@ -94,11 +94,13 @@ class _GpuEntrypos:
 
     # -- stream protocol: a real file is read, carried and scanned by the library itself -------
     def open_stream(self, fh, fbufsize):
-        from .index import _fileno
-        fd = _fileno(fh)
-        if fd is None:
+        from .index import _fileno, _leave_at
+        f = _fileno(fh)
+        if f is None:
             return None
-        return _hip.FileStream(self._context(), fd, fbufsize)
+        st = _hip.FileStream(self._context(), f[0], fbufsize, start=f[1])
+        st.on_close = lambda: _leave_at(fh, st)
+        return st
 
     # -- batched protocol used by this package's readfastq_iter ------------
     def scan_buffer(self, buf, offset, eof):

@@ -119,6 +119,8 @@ struct ffq_ctx {
     int64_t sel_base_cap = 0;
     int64_t *tab_h = nullptr;      // pinned bounce for rows
     int64_t tab_h_cap = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};    // ffq_scan_host: a staging half has been copied
+    void *stream_cache = nullptr;  // buffers of the last closed ffq_stream (ffq_stream.h), reused by the next one
 };
 
 extern "C" int ffq_abi_version(void) { return FFQ_ABI_VERSION; }
@@ -133,6 +135,7 @@ extern "C" int ffq_device_count(void)
 
 static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out);
 extern "C" void ffq_ctx_destroy(ffq_ctx *c);
+static void stream_cache_drop(ffq_ctx *c);
 
 extern "C" int ffq_ctx_create(int device, ffq_ctx **out) { return ctx_create_impl(device, nullptr, out); }
 
@@ -211,6 +214,8 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    stream_cache_drop(c);
+    for (auto &e : c->stage_ev) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
     free_chain(c);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
@@ -913,9 +918,9 @@ extern "C" int ffq_scan_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, 
         if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
         c->stage_h_cap = 2 * CH;
     }
-    hipEvent_t done[2];
-    HIPCHK(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+    for (auto &e : c->stage_ev)
+        if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t *done = c->stage_ev;
     bool used[2] = {false, false};
     for (int64_t at = 0, k = 0; at < n_bytes; at += CH, k++) {
         const int b = (int)(k & 1);
@@ -927,8 +932,6 @@ extern "C" int ffq_scan_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, 
         used[b] = true;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipEventDestroy(done[0]);
-    (void)hipEventDestroy(done[1]);
 
     rc = ffq_scan_device(c, c->stage_d, n_bytes, sentinel, offset, eof, add, flags, qual_add, c->tab_d,
                          table_cap, decode ? c->qual_d : nullptr, qual_cap, decode ? c->qoff_d : nullptr, res);

@@ -2,159 +2,384 @@
 //   /root/reference/src/fastqandfurious.py:30-36    read(fh, fbufsize): one read, eof := short read
 //   /root/reference/src/fastqandfurious.py:241-279  the refill loop of readfastq_iter: sentinel once,
 //                                                   buf = buf[offset:] + next chunk, globaloffset
-// over a file descriptor.  Chunks are read into pinned memory; the read of chunk i+1 (a helper
-// thread) overlaps the H2D copy, the scan and the D2H copy of fill i.  Each call of
-// ffq_stream_next hands back the rows (absolute stream offsets, what entryfunc_abspos yields,
-// :186-195) of one buffer fill and the fill's bytes for slicing.
+// over a file descriptor, as a three-stage pipeline:
+//
+//   feeder thread   chunk k+2: pread by a pool of helper threads into pinned slot memory, then
+//                   hipMemcpyAsync of the chunk to the slot's device buffer on a COPY stream
+//   copy stream     chunk k+1 on its way over PCIe
+//   caller thread   fill k: the carried tail buf[offset:] of fill k-1 is put in front of chunk k
+//                   (host memcpy + a small H2D on the scan stream), the scan waits for the
+//                   chunk's copy event, rows come back into pinned memory
+//
+// so the file read, the H2D copy and the scan + D2H of three consecutive chunks overlap (the
+// first version overlapped only the read).  A slot is [room | fbufsize] on both sides: the
+// chunk always lands at offset `room`, the carry ends there, and the fill is the contiguous
+// range [room - carry, room + got).  The scan is given the 16-byte aligned address below the
+// fill's first byte and starts its search at the fill's first byte (`offset`), so no byte is
+// moved to align anything.  Each call of ffq_stream_next hands back the rows (absolute stream
+// offsets, what entryfunc_abspos yields, :186-195) of one buffer fill and the fill's bytes for
+// slicing; both stay valid until the next call.
 #pragma once
 #include <errno.h>
 #include <unistd.h>
 
-#include <future>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+// ---- helper threads: a chunk of a seekable descriptor is read in slices -------------------------
+// (one pread loop saturates at the copy rate of a single core, a few GB/s from the page cache)
+struct ReadPool {
+    struct Job { int fd; uint8_t *dst; int64_t n, pos; int64_t *got; };
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::deque<Job> q;
+    int pending = 0;
+    bool stop = false;
+
+    static int64_t read_full(int fd, uint8_t *dst, int64_t n, int64_t pos, bool seekable)
+    {
+        int64_t got = 0;
+        while (got < n) {
+            const ssize_t r = seekable ? pread(fd, dst + got, (size_t)(n - got), (off_t)(pos + got))
+                                       : read(fd, dst + got, (size_t)(n - got));
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                return -1;
+            }
+            if (r == 0) break;
+            got += r;
+        }
+        return got;
+    }
+    void start(int n)
+    {
+        for (int i = 0; i < n; i++)
+            th.emplace_back([this] {
+                for (;;) {
+                    Job j;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_job.wait(lk, [this] { return stop || !q.empty(); });
+                        if (q.empty()) return;
+                        j = q.front(); q.pop_front();
+                    }
+                    *j.got = read_full(j.fd, j.dst, j.n, j.pos, true);
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    ~ReadPool()
+    {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_job.notify_all();
+        for (auto &t : th) t.join();
+    }
+    // the bytes read up to the first short slice -- the same prefix a single read would return
+    int64_t read_chunk(int fd, uint8_t *dst, int64_t n, int64_t pos, bool seekable)
+    {
+        const int64_t SL = 1 << 20;
+        const int nsl = (int)std::min<int64_t>((int64_t)th.size() + 1, n / SL);
+        if (!seekable || nsl < 2) return read_full(fd, dst, n, pos, seekable);
+        const int64_t per = ((n + nsl - 1) / nsl + 4095) & ~(int64_t)4095;
+        int64_t got[64];
+        int used = 0;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (int t = 1; t < nsl; t++) {
+                const int64_t a = (int64_t)t * per;
+                if (a >= n) break;
+                q.push_back(Job{fd, dst + a, std::min(per, n - a), pos + a, &got[t]});
+                pending++;
+                used = t;
+            }
+        }
+        cv_job.notify_all();
+        got[0] = read_full(fd, dst, std::min(per, n), pos, true);      // the caller's own slice
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [this] { return pending == 0; });
+        }
+        int64_t total = 0;
+        for (int t = 0; t <= used; t++) {
+            const int64_t want = std::min(per, n - (int64_t)t * per);
+            if (got[t] < 0) return -1;
+            total += got[t];
+            if (got[t] < want) break;
+        }
+        return total;
+    }
+};
+
+constexpr int STREAM_SLOTS = 3;
+
+struct StreamSlot {
+    uint8_t *h = nullptr;        // pinned  [room | fbufsize (+16)]
+    uint8_t *d = nullptr;        // device  same layout
+    hipEvent_t copied = nullptr; // the chunk's H2D copy is through
+    int64_t got = 0;             // bytes of the chunk (at offset room)
+    bool eof = false;            // a short read: the descriptor is exhausted
+};
+
+// everything a stream allocates; parked in the context when a stream closes so that the next
+// stream of the same chunk size starts without the pinned allocations (milliseconds each)
+struct StreamBufs {
+    int64_t fbufsize = 0, room = 0;
+    StreamSlot slot[STREAM_SLOTS];
+    hipStream_t cs = nullptr;    // copy stream of the chunks
+    int64_t *dtab = nullptr, *htab = nullptr;
+    int64_t tab_cap = 0;
+    int8_t *dqual = nullptr, *hqual = nullptr;
+    int64_t qual_cap = 0;
+    int64_t *dqoff = nullptr, *hqoff = nullptr;
+    int64_t qoff_cap = 0;
+    ReadPool *pool = nullptr;
+};
+
+static void streambufs_free_slots(StreamBufs *b)
+{
+    for (auto &s : b->slot) {
+        if (s.h) (void)hipHostFree(s.h);
+        (void)hipFree(s.d);
+        s.h = nullptr; s.d = nullptr;
+    }
+}
+
+static void streambufs_free(StreamBufs *b)
+{
+    if (!b) return;
+    delete b->pool;
+    streambufs_free_slots(b);
+    for (auto &s : b->slot) if (s.copied) (void)hipEventDestroy(s.copied);
+    if (b->htab) (void)hipHostFree(b->htab);
+    if (b->hqual) (void)hipHostFree(b->hqual);
+    if (b->hqoff) (void)hipHostFree(b->hqoff);
+    (void)hipFree(b->dtab); (void)hipFree(b->dqual); (void)hipFree(b->dqoff);
+    if (b->cs) (void)hipStreamDestroy(b->cs);
+    delete b;
+}
+
+// called by ffq_ctx_destroy
+static void stream_cache_drop(ffq_ctx *c)
+{
+    streambufs_free(static_cast<StreamBufs *>(c->stream_cache));
+    c->stream_cache = nullptr;
+}
+
+static int streambufs_alloc_slots(StreamBufs *b, int64_t room)
+{
+    for (auto &s : b->slot) {
+        if (hipHostMalloc((void **)&s.h, (size_t)(room + b->fbufsize + 16), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&s.d, (size_t)(room + b->fbufsize + 16)) != hipSuccess)
+            return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld-byte chunks with a %lld-byte carry",
+                        (long long)b->fbufsize, (long long)room);
+    }
+    b->room = room;
+    return FFQ_OK;
+}
 
 struct ffq_stream {
     ffq_ctx *c = nullptr;
+    StreamBufs *b = nullptr;
     int fd = -1;
     bool seekable = false;
-    int64_t file_pos = 0;               // next byte to read (pread offset)
-    int64_t fbufsize = 0;
-    int64_t carry_room = 0;             // bytes in front of every chunk for the carried tail
-    uint8_t *hbuf[2] = {nullptr, nullptr};      // pinned: [carry_room | fbufsize]
-    uint8_t *dbuf = nullptr;            // device copy of [carry | chunk]
-    int64_t dcap = 0;
-    int64_t *dtab = nullptr;            // rows on the device / in pinned memory
-    int64_t *htab = nullptr;
-    int64_t tab_cap = 0;
     uint32_t flags = 0;                 // FFQ_F_DECODE_QUAL: qualities decoded per fill
     int qual_add = -33;
-    int8_t *dqual = nullptr, *hqual = nullptr;  // decoded stream of the fill (device / pinned)
-    int64_t qual_cap = 0;
-    int64_t *dqoff = nullptr, *hqoff = nullptr; // CSR offsets, tab_cap + 1 entries
-    int64_t last_nq = 0;
-    std::future<int64_t> rd;            // read-ahead into hbuf[cur ^ 1] + carry_room
-    bool rd_pending = false;
-    int cur = 0;
-    int64_t start = 0, len = 0;         // the current fill is hbuf[cur][start, start + len)
-    bool fill_eof = false;              // its chunk was a short read
-    bool first = true, done = false;
+    // ---- feeder <-> caller (under m) ----
+    std::thread feeder;
+    std::mutex m;
+    std::condition_variable cv;
+    int64_t produced = 0;               // chunks [0, produced) are read and their copy is enqueued
+    int64_t released = 0;               // chunks [0, released) are consumed: their slots may be refilled
+    int64_t file_pos = 0;               // next byte to read
+    bool stop = false, feeder_done = false, pause_req = false, paused = false;
+    int feeder_rc = FFQ_OK;
+    std::string feeder_msg;
+    // ---- caller only ----
+    int64_t cur = -1;                   // chunk of the fill handed out last
+    int64_t fill_start = 0, fill_len = 0;   // that fill is slot.h[fill_start, fill_start + fill_len)
+    int64_t carry_from = 0;             // fill-relative offset the next fill starts with (buf[offset:], :277)
+    bool done = false, failed = false;
     int64_t globaloffset = -1;          // readfastq_iter :242
+    int64_t last_nq = 0;
+    // FFQ_STREAM_PROF=1: where the time of a stream goes (printed when it closes)
+    bool prof = false;
+    double t_read = 0, t_slot = 0, t_feed = 0, t_scan = 0, t_rows = 0;
 };
 
-static int64_t stream_read_full(int fd, uint8_t *dst, int64_t n, int64_t pos, bool seekable)
+static inline double stream_now()
 {
-    int64_t got = 0;
-    while (got < n) {
-        const ssize_t r = seekable ? pread(fd, dst + got, (size_t)(n - got), (off_t)(pos + got))
-                                   : read(fd, dst + got, (size_t)(n - got));
-        if (r < 0) {
-            if (errno == EINTR) continue;
-            return -1;
-        }
-        if (r == 0) break;
-        got += r;
-    }
-    return got;
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// a chunk of a seekable descriptor by several threads (one pread loop saturates at the memcpy
-// rate of a single core, ~10 GB/s from the page cache); the result is the bytes read up to the
-// first short slice -- the same prefix a single read would have returned
-static int64_t stream_read_chunk(int fd, uint8_t *dst, int64_t n, int64_t pos, bool seekable)
+static void stream_feeder(ffq_stream *s)
 {
-    const int64_t SL = 2 << 20;
-    const int nthr = (int)std::min<int64_t>(8, n / SL);
-    if (!seekable || nthr < 2) return stream_read_full(fd, dst, n, pos, seekable);
-    const int64_t per = ((n + nthr - 1) / nthr + 4095) & ~(int64_t)4095;
-    std::future<int64_t> part[8];
-    int used = 0;
-    for (int t = 0; t < nthr; t++) {
-        const int64_t a = (int64_t)t * per;
-        if (a >= n) break;
-        const int64_t m = std::min(per, n - a);
-        part[t] = std::async(std::launch::async, [=] { return stream_read_full(fd, dst + a, m, pos + a, true); });
-        used++;
+    (void)hipSetDevice(s->c->device);
+    StreamBufs *b = s->b;
+    for (int64_t k = 0;; k++) {
+        const double tw0 = s->prof ? stream_now() : 0;
+        {
+            std::unique_lock<std::mutex> lk(s->m);
+            for (;;) {
+                if (s->stop) { s->feeder_done = true; s->cv.notify_all(); return; }
+                if (s->pause_req) {          // the caller reallocates the slots: park here
+                    s->paused = true;
+                    s->cv.notify_all();
+                    s->cv.wait(lk);
+                    continue;
+                }
+                s->paused = false;
+                if (k - s->released < STREAM_SLOTS) break;      // slot k % STREAM_SLOTS is free
+                s->cv.wait(lk);
+            }
+        }
+        StreamSlot &sl = b->slot[k % STREAM_SLOTS];
+        const double tr0 = s->prof ? stream_now() : 0;
+        const int64_t got = b->pool->read_chunk(s->fd, sl.h + b->room, b->fbufsize, s->file_pos, s->seekable);
+        if (s->prof) { const double t = stream_now(); s->t_slot += tr0 - tw0; s->t_read += t - tr0; }
+        int rc = FFQ_OK;
+        std::string msg;
+        if (got < 0) { rc = FFQ_E_ARG; msg = std::string("ffq_stream: read failed: ") + strerror(errno); }
+        else {
+            sl.got = got;
+            sl.eof = got < b->fbufsize;
+            hipError_t e = hipSuccess;
+            if (got > 0) e = hipMemcpyAsync(sl.d + b->room, sl.h + b->room, (size_t)got, hipMemcpyHostToDevice, b->cs);
+            if (e == hipSuccess) e = hipEventRecord(sl.copied, b->cs);
+            if (e != hipSuccess) { rc = FFQ_E_HIP; msg = std::string("ffq_stream: chunk copy failed: ") + hipGetErrorString(e); }
+        }
+        {
+            std::lock_guard<std::mutex> lk(s->m);
+            if (rc) { s->feeder_rc = rc; s->feeder_msg = msg; s->feeder_done = true; }
+            else {
+                s->file_pos += got;
+                s->produced = k + 1;
+                if (sl.eof) s->feeder_done = true;
+            }
+        }
+        s->cv.notify_all();
+        if (rc || sl.eof) return;
     }
-    int64_t got = 0;
-    bool shortread = false, bad = false;
-    for (int t = 0; t < used; t++) {
-        const int64_t g = part[t].get();
-        const int64_t m = std::min(per, n - (int64_t)t * per);
-        if (g < 0) bad = true;
-        else if (!shortread) { got += g; if (g < m) shortread = true; }
-    }
-    return bad ? -1 : got;
+}
+
+static void stream_stop_feeder(ffq_stream *s)
+{
+    if (!s->feeder.joinable()) return;
+    { std::lock_guard<std::mutex> lk(s->m); s->stop = true; }
+    s->cv.notify_all();
+    s->feeder.join();
 }
 
 static void stream_free(ffq_stream *s)
 {
     if (!s) return;
-    if (s->rd_pending) (void)s->rd.get();
-    for (int b = 0; b < 2; b++)
-        if (s->hbuf[b]) (void)hipHostFree(s->hbuf[b]);
-    if (s->htab) (void)hipHostFree(s->htab);
-    if (s->hqual) (void)hipHostFree(s->hqual);
-    if (s->hqoff) (void)hipHostFree(s->hqoff);
-    (void)hipFree(s->dbuf);
-    (void)hipFree(s->dtab);
-    (void)hipFree(s->dqual);
-    (void)hipFree(s->dqoff);
+    stream_stop_feeder(s);
+    if (s->prof)
+        fprintf(stderr, "[ffq stream] %lld fills: reader %.3f ms reading, %.3f ms waiting for a slot; caller %.3f ms waiting "
+                        "for the reader, %.3f ms carry + scan, %.3f ms rows back\n", (long long)(s->cur + 1), s->t_read * 1e3,
+                s->t_slot * 1e3, s->t_feed * 1e3, s->t_scan * 1e3, s->t_rows * 1e3);
+    if (s->b) {
+        if (s->b->cs) (void)hipStreamSynchronize(s->b->cs);
+        if (s->c->stream) (void)hipStreamSynchronize(s->c->stream);
+        // park the buffers in the context for the next stream
+        if (!s->c->stream_cache) s->c->stream_cache = s->b;
+        else streambufs_free(s->b);
+    }
     delete s;
 }
 
 static int stream_alloc_tab(ffq_stream *s, int64_t rows)
 {
-    if (rows <= s->tab_cap) return FFQ_OK;
-    if (s->htab) (void)hipHostFree(s->htab);
-    (void)hipFree(s->dtab);
-    s->htab = nullptr; s->dtab = nullptr; s->tab_cap = 0;
-    if (hipMalloc((void **)&s->dtab, (size_t)rows * 48) != hipSuccess ||
-        hipHostMalloc((void **)&s->htab, (size_t)rows * 48, hipHostMallocDefault) != hipSuccess)
-        return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld rows", (long long)rows);
-    s->tab_cap = rows;
-    if (s->flags & FFQ_F_DECODE_QUAL) {
-        if (s->hqoff) (void)hipHostFree(s->hqoff);
-        (void)hipFree(s->dqoff);
-        s->hqoff = nullptr; s->dqoff = nullptr;
-        if (hipMalloc((void **)&s->dqoff, (size_t)(rows + 1) * 8) != hipSuccess ||
-            hipHostMalloc((void **)&s->hqoff, (size_t)(rows + 1) * 8, hipHostMallocDefault) != hipSuccess)
-            return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld quality offsets", (long long)rows);
+    StreamBufs *b = s->b;
+    if (rows > b->tab_cap) {
+        if (b->htab) (void)hipHostFree(b->htab);
+        (void)hipFree(b->dtab);
+        b->htab = nullptr; b->dtab = nullptr; b->tab_cap = 0;
+        if (hipMalloc((void **)&b->dtab, (size_t)rows * 48) != hipSuccess ||
+            hipHostMalloc((void **)&b->htab, (size_t)rows * 48, hipHostMallocDefault) != hipSuccess)
+            return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld rows", (long long)rows);
+        b->tab_cap = rows;
+    }
+    if ((s->flags & FFQ_F_DECODE_QUAL) && b->qoff_cap < b->tab_cap + 1) {
+        if (b->hqoff) (void)hipHostFree(b->hqoff);
+        (void)hipFree(b->dqoff);
+        b->hqoff = nullptr; b->dqoff = nullptr; b->qoff_cap = 0;
+        if (hipMalloc((void **)&b->dqoff, (size_t)(b->tab_cap + 1) * 8) != hipSuccess ||
+            hipHostMalloc((void **)&b->hqoff, (size_t)(b->tab_cap + 1) * 8, hipHostMallocDefault) != hipSuccess)
+            return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld quality offsets", (long long)b->tab_cap);
+        b->qoff_cap = b->tab_cap + 1;
     }
     return FFQ_OK;
 }
 
 static int stream_alloc_qual(ffq_stream *s, int64_t bytes)
 {
-    if (bytes <= s->qual_cap) return FFQ_OK;
-    if (s->hqual) (void)hipHostFree(s->hqual);
-    (void)hipFree(s->dqual);
-    s->hqual = nullptr; s->dqual = nullptr; s->qual_cap = 0;
-    if (hipMalloc((void **)&s->dqual, (size_t)bytes) != hipSuccess ||
-        hipHostMalloc((void **)&s->hqual, (size_t)bytes, hipHostMallocDefault) != hipSuccess)
+    StreamBufs *b = s->b;
+    if (bytes <= b->qual_cap) return FFQ_OK;
+    if (b->hqual) (void)hipHostFree(b->hqual);
+    (void)hipFree(b->dqual);
+    b->hqual = nullptr; b->dqual = nullptr; b->qual_cap = 0;
+    if (hipMalloc((void **)&b->dqual, (size_t)bytes) != hipSuccess ||
+        hipHostMalloc((void **)&b->hqual, (size_t)bytes, hipHostMallocDefault) != hipSuccess)
         return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld decoded bytes", (long long)bytes);
-    s->qual_cap = bytes;
+    b->qual_cap = bytes;
     return FFQ_OK;
 }
 
-// (re)allocate the pinned pair with `room` bytes of carry space, keeping the current fill and the
-// chunk that has been read ahead (`ahead` bytes at hbuf[cur ^ 1] + carry_room)
-static int stream_grow_room(ffq_stream *s, int64_t room, int64_t ahead)
+// A carry that does not fit in front of a chunk (a record longer than `room`): every slot is
+// reallocated with more room.  The feeder is parked first; chunks it has read ahead are moved
+// and their copy is enqueued again.  Called at the START of ffq_stream_next, before any pointer
+// of the new fill is handed out -- the previous fill's pointers expire with this call anyway.
+static int stream_grow_room(ffq_stream *s, int64_t need)
 {
-    uint8_t *nb[2] = {nullptr, nullptr};
-    for (int b = 0; b < 2; b++)
-        if (hipHostMalloc((void **)&nb[b], (size_t)(room + s->fbufsize + 16), hipHostMallocDefault) != hipSuccess)
-            return fail(FFQ_E_NOMEM, "ffq_stream: no pinned memory for a %lld-byte carry", (long long)room);
-    if (s->hbuf[s->cur]) memcpy(nb[s->cur] + room - (s->carry_room - s->start), s->hbuf[s->cur] + s->start, (size_t)s->len);
-    if (s->hbuf[s->cur ^ 1] && ahead > 0) memcpy(nb[s->cur ^ 1] + room, s->hbuf[s->cur ^ 1] + s->carry_room, (size_t)ahead);
-    s->start = room - (s->carry_room - s->start);
-    for (int b = 0; b < 2; b++) {
-        if (s->hbuf[b]) (void)hipHostFree(s->hbuf[b]);
-        s->hbuf[b] = nb[b];
+    StreamBufs *b = s->b;
+    {
+        std::unique_lock<std::mutex> lk(s->m);
+        s->pause_req = true;
+        s->cv.notify_all();
+        s->cv.wait(lk, [&] { return s->paused || s->feeder_done; });
     }
-    s->carry_room = room;
-    return FFQ_OK;
+    int rc = FFQ_OK;
+    hipError_t e = hipStreamSynchronize(b->cs);
+    if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_stream: %s", hipGetErrorString(e));
+    const int64_t room = (std::max<int64_t>(2 * b->room, need + 4096) + 4095) & ~(int64_t)4095;
+    StreamSlot old[STREAM_SLOTS];
+    for (int i = 0; i < STREAM_SLOTS; i++) { old[i] = b->slot[i]; b->slot[i].h = nullptr; b->slot[i].d = nullptr; }
+    const int64_t old_room = b->room;
+    if (!rc) rc = streambufs_alloc_slots(b, room);
+    if (!rc) {
+        // chunks [released, produced) are alive: the one being carried from (cur, all of its fill)
+        // and the ones read ahead (their chunk bytes)
+        for (int64_t k = std::max<int64_t>(s->released, 0); k < s->produced && !rc; k++) {
+            StreamSlot &n = b->slot[k % STREAM_SLOTS];
+            const StreamSlot &o = old[k % STREAM_SLOTS];
+            if (k == s->cur) {
+                memcpy(n.h + room - (old_room - s->fill_start), o.h + s->fill_start, (size_t)s->fill_len);
+                s->fill_start = room - (old_room - s->fill_start);
+            } else {
+                memcpy(n.h + room, o.h + old_room, (size_t)o.got);
+                if (o.got > 0) e = hipMemcpyAsync(n.d + room, n.h + room, (size_t)o.got, hipMemcpyHostToDevice, b->cs);
+                if (e == hipSuccess) e = hipEventRecord(n.copied, b->cs);
+                if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_stream: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    for (auto &o : old) { if (o.h) (void)hipHostFree(o.h); (void)hipFree(o.d); }
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        s->pause_req = false;
+    }
+    s->cv.notify_all();
+    return rc;
 }
 
-extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t flags, int qual_add,
+extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
                                 ffq_stream **out)
 {
     if (!c || !out || fd < 0 || fbufsize <= 0) return fail(FFQ_E_ARG, "ffq_stream_open: bad argument");
@@ -162,29 +387,57 @@ extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t f
     HIPCHK(hipSetDevice(c->device));
     ffq_stream *s = new (std::nothrow) ffq_stream();
     if (!s) return fail(FFQ_E_NOMEM, "out of host memory");
-    s->c = c; s->fd = fd; s->fbufsize = fbufsize;
+    s->c = c; s->fd = fd;
     s->flags = flags & FFQ_F_DECODE_QUAL; s->qual_add = qual_add;
+    s->prof = getenv("FFQ_STREAM_PROF") != nullptr;
+    // where to read from: `start` (pread; the descriptor's own position is left alone), or the
+    // descriptor's current position if start < 0; a descriptor that cannot seek is read in order
     const off_t at = lseek(fd, 0, SEEK_CUR);
     s->seekable = at != (off_t)-1;
-    s->file_pos = s->seekable ? (int64_t)at : 0;
-    s->carry_room = std::max<int64_t>(1 << 20, 4096);
-    for (int b = 0; b < 2; b++)
-        if (hipHostMalloc((void **)&s->hbuf[b], (size_t)(s->carry_room + fbufsize + 16), hipHostMallocDefault) != hipSuccess) {
-            stream_free(s);
-            return fail(FFQ_E_NOMEM, "ffq_stream_open: no pinned memory for %lld-byte chunks", (long long)fbufsize);
+    s->file_pos = s->seekable ? (start >= 0 ? start : (int64_t)at) : 0;
+    StreamBufs *b = static_cast<StreamBufs *>(c->stream_cache);
+    c->stream_cache = nullptr;
+    if (b && b->fbufsize != fbufsize) { streambufs_free(b); b = nullptr; }
+    int rc = FFQ_OK;
+    if (!b) {
+        b = new (std::nothrow) StreamBufs();
+        if (!b) { delete s; return fail(FFQ_E_NOMEM, "out of host memory"); }
+        b->fbufsize = fbufsize;
+        hipError_t e = hipStreamCreateWithFlags(&b->cs, hipStreamNonBlocking);
+        for (auto &sl : b->slot)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming);
+        if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_stream_open: %s", hipGetErrorString(e));
+        if (!rc) rc = streambufs_alloc_slots(b, 1 << 20);
+        if (!rc) {
+            b->pool = new (std::nothrow) ReadPool();
+            if (!b->pool) rc = fail(FFQ_E_NOMEM, "out of host memory");
+            else {
+                const unsigned hw = std::thread::hardware_concurrency();
+                b->pool->start((int)std::min<unsigned>(11, hw > 2 ? hw - 2 : 1));
+            }
         }
-    int rc = stream_alloc_tab(s, fbufsize / 64 + 1024);
+    }
+    s->b = b;
+    if (!rc) rc = stream_alloc_tab(s, fbufsize / 64 + 1024);
     if (rc) { stream_free(s); return rc; }
+    s->feeder = std::thread(stream_feeder, s);
     *out = s;
     return FFQ_OK;
 }
 
 extern "C" int ffq_stream_open(ffq_ctx *c, int fd, int64_t fbufsize, ffq_stream **out)
 {
-    return ffq_stream_open2(c, fd, fbufsize, 0, 0, out);
+    return ffq_stream_open2(c, fd, fbufsize, 0, 0, -1, out);
 }
 
 extern "C" void ffq_stream_close(ffq_stream *s) { stream_free(s); }
+
+extern "C" int64_t ffq_stream_tell(ffq_stream *s)
+{
+    if (!s) return -1;
+    std::lock_guard<std::mutex> lk(s->m);
+    return s->file_pos;
+}
 
 // decoded qualities of the fill ffq_stream_next has just returned (streams opened with
 // FFQ_F_DECODE_QUAL): int8 stream + CSR offsets (n_rows + 1), pinned, valid until the next call
@@ -192,7 +445,7 @@ extern "C" int ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int6
 {
     if (!s || !h_qual || !h_qoff || !n_qual_bytes) return fail(FFQ_E_ARG, "ffq_stream_quals: NULL argument");
     if (!(s->flags & FFQ_F_DECODE_QUAL)) return fail(FFQ_E_ARG, "ffq_stream_quals: the stream was opened without FFQ_F_DECODE_QUAL");
-    *h_qual = s->hqual; *h_qoff = s->hqoff; *n_qual_bytes = s->last_nq;
+    *h_qual = s->b->hqual; *h_qoff = s->b->hqoff; *n_qual_bytes = s->last_nq;
     return FFQ_OK;
 }
 
@@ -202,104 +455,106 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
 {
     if (!s || !h_rows || !n_rows || !end_state) return fail(FFQ_E_ARG, "ffq_stream_next: NULL argument");
     ffq_ctx *c = s->c;
+    StreamBufs *b = s->b;
     HIPCHK(hipSetDevice(c->device));
-    *h_rows = s->htab; *n_rows = 0; *end_state = FFQ_END_OK;
+    *h_rows = b->htab; *n_rows = 0; *end_state = FFQ_END_OK;
     if (err_offset) *err_offset = -1;
     if (h_bytes) *h_bytes = nullptr;
     if (n_bytes) *n_bytes = 0;
     if (bytes_offset) *bytes_offset = 0;
+    if (s->failed) return fail(FFQ_E_ARG, "ffq_stream_next: the stream has failed");
     if (s->done) return FFQ_OK;
+    s->failed = true;                    // until this call gets through: an error leaves no half-advanced state behind
 
-    if (s->first) {
-        // the first chunk, synchronously
-        const int64_t got = stream_read_chunk(s->fd, s->hbuf[0] + s->carry_room, s->fbufsize, s->file_pos, s->seekable);
-        if (got < 0) return fail(FFQ_E_ARG, "ffq_stream: read failed: %s", strerror(errno));
-        s->file_pos += got;
-        // buf = b'\n' + first chunk (:245): the sentinel is a real byte of the buffer, it is carried
-        // over a refill like any other (a first record longer than fbufsize needs it again)
-        s->hbuf[0][s->carry_room - 1] = (uint8_t)'\n';
-        s->cur = 0; s->start = s->carry_room - 1; s->len = got + 1; s->fill_eof = got < s->fbufsize;
+    // ---- chunk k: wait for the feeder -------------------------------------------------------
+    const int64_t k = s->cur + 1;
+    const double tp0 = s->prof ? stream_now() : 0;
+    {
+        std::unique_lock<std::mutex> lk(s->m);
+        s->cv.wait(lk, [&] { return s->produced > k || s->feeder_done; });
+        if (s->produced <= k) {
+            if (s->feeder_rc) return fail(s->feeder_rc, "%s", s->feeder_msg.c_str());
+            return fail(FFQ_E_INTERNAL, "ffq_stream: the reader stopped early");
+        }
     }
-    // read ahead while this fill is on the GPU
-    if (!s->fill_eof) {
-        uint8_t *dst = s->hbuf[s->cur ^ 1] + s->carry_room;
-        const int fd = s->fd; const int64_t n = s->fbufsize, pos = s->file_pos; const bool sk = s->seekable;
-        s->rd = std::async(std::launch::async, [fd, dst, n, pos, sk] { return stream_read_chunk(fd, dst, n, pos, sk); });
-        s->rd_pending = true;
+    const double tp1 = s->prof ? stream_now() : 0;
+    // ---- buf = buf[offset:] + chunk (:277); the first fill: b'\n' + chunk (:245) -----------------
+    int64_t carry;
+    if (k == 0) carry = 1;
+    else {
+        carry = s->fill_len - s->carry_from;
+        if (carry > b->room) {
+            int rc = stream_grow_room(s, carry);
+            if (rc) return rc;
+        }
+    }
+    StreamSlot &sl = b->slot[k % STREAM_SLOTS];
+    const int64_t room = b->room;
+    if (k == 0) sl.h[room - 1] = (uint8_t)'\n';
+    else {
+        const StreamSlot &pv = b->slot[s->cur % STREAM_SLOTS];
+        memcpy(sl.h + room - carry, pv.h + s->fill_start + s->carry_from, (size_t)carry);
+        // the previous fill's slot goes back to the feeder (the caller's pointers into it expired
+        // with this call)
+        { std::lock_guard<std::mutex> lk(s->m); s->released = k; }
+        s->cv.notify_all();
+    }
+    const int64_t start = room - carry, len = carry + sl.got;
+    const bool fill_eof = sl.eof;
+    HIPCHK(hipMemcpyAsync(sl.d + start, sl.h + start, (size_t)carry, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, sl.copied, 0));
+
+    // ---- scan: from the aligned address below the fill, searching from the fill's first byte ----
+    const int64_t mis = start & 15;
+    const bool decode = (s->flags & FFQ_F_DECODE_QUAL) != 0;
+    if (decode) {
+        int rc2 = stream_alloc_qual(s, len / 2 + 64);      // qualities are at most half of the bytes
+        if (rc2) return rc2;
     }
     ffq_scan_result res;
     memset(&res, 0, sizeof res);
     int rc = FFQ_OK;
-    {
-        if (s->dcap < s->len + 16) {
-            (void)hipFree(s->dbuf);
-            s->dbuf = nullptr; s->dcap = 0;
-            const int64_t want = std::max<int64_t>(s->len + 16, s->carry_room + s->fbufsize + 16);
-            if (hipMalloc((void **)&s->dbuf, (size_t)want) != hipSuccess)
-                return fail(FFQ_E_NOMEM, "ffq_stream: no device memory for a %lld-byte fill", (long long)want);
-            s->dcap = want;
-        }
-        HIPCHK(hipMemcpyAsync(s->dbuf, s->hbuf[s->cur] + s->start, (size_t)s->len, hipMemcpyHostToDevice, c->stream));
-        const bool decode = (s->flags & FFQ_F_DECODE_QUAL) != 0;
-        if (decode) {
-            int rc2 = stream_alloc_qual(s, s->len / 2 + 64);      // qualities are at most half of the bytes
-            if (rc2) return rc2;
-        }
-        for (int attempt = 0; attempt < 2; attempt++) {
-            rc = ffq_scan_device(c, s->dbuf, s->len, 0, 0, s->fill_eof ? 1 : 0, s->globaloffset, s->flags, s->qual_add,
-                                 s->dtab, s->tab_cap, decode ? s->dqual : nullptr, decode ? s->qual_cap : 0,
-                                 decode ? s->dqoff : nullptr, &res);
-            if (rc != FFQ_E_TABLE_FULL) break;
-            int rc2 = stream_alloc_tab(s, res.n_records + 1024);
-            if (rc2) return rc2;
-        }
-        if (rc != FFQ_OK) return rc;
-        if (res.n_records > 0)
-            HIPCHK(hipMemcpyAsync(s->htab, s->dtab, (size_t)res.n_records * 48, hipMemcpyDeviceToHost, c->stream));
-        s->last_nq = 0;
-        if (decode) {
-            s->last_nq = res.n_qual_bytes;
-            if (res.n_qual_bytes > 0)
-                HIPCHK(hipMemcpyAsync(s->hqual, s->dqual, (size_t)res.n_qual_bytes, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(s->hqoff, s->dqoff, (size_t)(res.n_records + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-        }
-        HIPCHK(hipStreamSynchronize(c->stream));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        rc = ffq_scan_device(c, sl.d + start - mis, len + mis, 0, mis, fill_eof ? 1 : 0, s->globaloffset - mis, s->flags,
+                             s->qual_add, b->dtab, b->tab_cap, decode ? b->dqual : nullptr, decode ? b->qual_cap : 0,
+                             decode ? b->dqoff : nullptr, &res);
+        if (rc != FFQ_E_TABLE_FULL) break;
+        int rc2 = stream_alloc_tab(s, res.n_records + 1024);
+        if (rc2) return rc2;
     }
-    *h_rows = s->htab;
+    if (rc != FFQ_OK) return rc;
+    const double tp2 = s->prof ? stream_now() : 0;
+    if (res.n_records > 0)
+        HIPCHK(hipMemcpyAsync(b->htab, b->dtab, (size_t)res.n_records * 48, hipMemcpyDeviceToHost, c->stream));
+    s->last_nq = 0;
+    if (decode) {
+        s->last_nq = res.n_qual_bytes;
+        if (res.n_qual_bytes > 0)
+            HIPCHK(hipMemcpyAsync(b->hqual, b->dqual, (size_t)res.n_qual_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(b->hqoff, b->dqoff, (size_t)(res.n_records + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (s->prof) { const double t = stream_now(); s->t_feed += tp1 - tp0; s->t_scan += tp2 - tp1; s->t_rows += t - tp2; }
+
+    s->cur = k;
+    s->fill_start = start; s->fill_len = len;
+    *h_rows = b->htab;
     *n_rows = res.n_records;
-    if (h_bytes) *h_bytes = s->hbuf[s->cur] + s->start;
-    if (n_bytes) *n_bytes = s->len;
+    if (h_bytes) *h_bytes = sl.h + start;
+    if (n_bytes) *n_bytes = len;
     // byte i of this fill is stream offset globaloffset + i (the sentinel of the first fill is -1)
     if (bytes_offset) *bytes_offset = s->globaloffset;
     *end_state = res.end_state;
+    const int64_t ds = res.end_offset - mis;             // the iterator's `offset` at exit, fill-relative
+    s->failed = false;
     if (res.end_state != FFQ_END_REFILL) {
-        if (res.end_state != FFQ_END_OK && err_offset) *err_offset = s->globaloffset + res.end_offset;
+        if (res.end_state != FFQ_END_OK && err_offset) *err_offset = s->globaloffset + ds;
         s->done = true;
-        if (s->rd_pending) { (void)s->rd.get(); s->rd_pending = false; }
-        s->first = false;
+        stream_stop_feeder(s);
         return FFQ_OK;
     }
-    // refill: buf = buf[offset:] + next chunk (:277), globaloffset += offset (:275)
-    int64_t got = 0;
-    if (s->rd_pending) {
-        got = s->rd.get();
-        s->rd_pending = false;
-        if (got < 0) return fail(FFQ_E_ARG, "ffq_stream: read failed: %s", strerror(errno));
-        s->file_pos += got;
-    }
-    const int64_t ds = res.end_offset;                       // buf[offset:] is carried over
-    const int64_t carry = s->len - ds;
-    if (carry > s->carry_room) {
-        rc = stream_grow_room(s, std::max<int64_t>(2 * s->carry_room, carry + 4096), got);
-        if (rc) return rc;
-    }
-    const int nxt = s->cur ^ 1;
-    memcpy(s->hbuf[nxt] + s->carry_room - carry, s->hbuf[s->cur] + s->start + ds, (size_t)carry);
-    s->globaloffset += res.end_offset;
-    s->cur = nxt;
-    s->start = s->carry_room - carry;
-    s->len = carry + got;
-    s->fill_eof = got < s->fbufsize;
-    s->first = false;
+    // refill at the next call: buf = buf[offset:] + next chunk (:277), globaloffset += offset (:275)
+    s->carry_from = ds;
+    s->globaloffset += ds;
     return FFQ_OK;
 }

@@ -42,7 +42,7 @@ SYMBOLS = (
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
     "ffq_table_select_seqlen", "ffq_table_cut", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
-    "ffq_stream_open2", "ffq_stream_quals", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
+    "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
 )
@@ -143,7 +143,9 @@ def lib():
         L.ffq_stream_close.argtypes = [vp]
         L.ffq_scan_fasta_device.argtypes = [vp, vp, i64, i32, i64, i64, vp, i64, P(ScanResult)]
         L.ffq_scan_fasta_host.argtypes = [vp, vp, i64, i32, i64, i64, vp, i64, P(ScanResult)]
-        L.ffq_stream_open2.argtypes = [vp, i32, i64, u32, i32, P(vp)]
+        L.ffq_stream_open2.argtypes = [vp, i32, i64, u32, i32, i64, P(vp)]
+        L.ffq_stream_tell.argtypes = [vp]
+        L.ffq_stream_tell.restype = i64
         L.ffq_stream_quals.argtypes = [vp, P(vp), P(vp), P(i64)]
         L.ffq_stream_close.restype = None
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
@@ -170,15 +172,23 @@ class Context:
         the two then execute in submission order (see scan_submit / scan_wait)."""
         self._h = ctypes.c_void_p()
         self._parent = share
+        self._children = []          # contexts on this one's streams: they are closed first
         if share is not None:
             self.device = share.device
             check(lib().ffq_ctx_create_shared(share.handle, ctypes.byref(self._h)))
+            import weakref
+            share._children.append(weakref.ref(self))
         else:
             self.device = device
             check(lib().ffq_ctx_create(int(device), ctypes.byref(self._h)))
 
     def close(self):
         if self._h:
+            for ref in self._children:
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             lib().ffq_ctx_destroy(self._h)
             self._h = ctypes.c_void_p()
 
@@ -387,12 +397,18 @@ class FileStream:
     `fill` (uint8 array, fill[i] = stream byte fill_offset + i) are views of memory the stream
     owns -- valid until the next iteration step."""
 
-    def __init__(self, ctx, fd, fbufsize=1 << 24, decode=False, qual_add=-33):
+    def __init__(self, ctx, fd, fbufsize=1 << 24, decode=False, qual_add=-33, start=None):
+        """start: byte of the file the stream begins at (None: the descriptor's current position).
+        A descriptor that can seek is read with pread: its own position does not move."""
         self._ctx = ctx
         self._h = ctypes.c_void_p()
         self.decode = bool(decode)
         check(lib().ffq_stream_open2(ctx.handle, int(fd), int(fbufsize), F_DECODE_QUAL if decode else 0,
-                                     int(qual_add), ctypes.byref(self._h)))
+                                     int(qual_add), -1 if start is None else int(start), ctypes.byref(self._h)))
+
+    def tell(self):
+        """File position behind the last byte the stream has read so far."""
+        return int(lib().ffq_stream_tell(self._h)) if self._h else -1
 
     def quals(self):
         """(qual int8[], qoff int64[n + 1]) of the fill the iteration has just yielded (streams
@@ -405,8 +421,13 @@ class FileStream:
         qoff = np.ctypeslib.as_array((ctypes.c_int64 * (n + 1)).from_address(op.value))
         return qual, qoff
 
+    on_close = None        # called once, before the native stream goes away
+
     def close(self):
         if self._h:
+            if self.on_close is not None:
+                cb, self.on_close = self.on_close, None
+                cb()
             lib().ffq_stream_close(self._h)
             self._h = ctypes.c_void_p()
 

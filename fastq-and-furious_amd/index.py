@@ -21,7 +21,9 @@ ROW_BYTES = 48          # 6 x int64 per record
 
 
 def _fileno(fh):
-    """File descriptor of a real, unbuffered-position-safe binary file object, else None."""
+    """(fd, start) of a plain binary file object -- its descriptor and the position the object is
+    at -- else None.  The descriptor itself is not touched: the native stream reads it with pread
+    from `start` (start None: it cannot seek and is read in order)."""
     import io
     # only plain files: a GzipFile also has a fileno() -- that of the COMPRESSED file
     raw = fh.raw if isinstance(fh, io.BufferedReader) else fh
@@ -32,11 +34,22 @@ def _fileno(fh):
     except (AttributeError, OSError, ValueError):
         return None
     try:
-        import os
-        os.lseek(fd, fh.tell(), os.SEEK_SET)         # the descriptor follows the object's position
+        start = fh.tell() if fh.seekable() else None
     except (OSError, ValueError, AttributeError):
-        return None
-    return fd
+        start = None
+    if start is None and fh is not raw:
+        return None              # a buffered pipe: bytes may already sit in the object's buffer, past the descriptor
+    return fd, start
+
+
+def _leave_at(fh, st):
+    """Leave a shared file object where the stream stopped reading (the reference's loop leaves
+    `fh` behind the last chunk it read, /root/reference/src/fastqandfurious.py:274-277)."""
+    try:
+        if fh.seekable():
+            fh.seek(st.tell())
+    except (OSError, ValueError, AttributeError):
+        pass
 
 
 def iter_tables(fh, fbufsize, scan_buffer):
@@ -73,13 +86,13 @@ def build_index(fh, fh_index, fbufsize=1 << 24, entrypos=None):
     if entrypos is None:
         from . import _fastqandfurious
         entrypos = _fastqandfurious.entrypos
-        fd = _fileno(fh)
-        if fd is not None:
+        f = _fileno(fh)
+        if f is not None:
             # a real file and the GPU scanner: the native stream front end (ffq_stream_*) reads
             # ahead into pinned memory and hands back whole tables; no per-fill Python copies
             from . import hip
             n = 0
-            st = hip.FileStream(hip.default_context(), fd, fbufsize)
+            st = hip.FileStream(hip.default_context(), f[0], fbufsize, start=f[1])
             try:
                 for rows, _fill, _off, end_state, err in st:
                     if rows.shape[0]:
@@ -88,6 +101,7 @@ def build_index(fh, fh_index, fbufsize=1 << 24, entrypos=None):
                     if end_state not in (_F._END_OK, _F._END_REFILL):
                         _F._raise_for_end(end_state, err)
             finally:
+                _leave_at(fh, st)
                 st.close()
             return n
     scan_buffer = getattr(entrypos, 'scan_buffer', None)

@@ -214,26 +214,33 @@ int ffq_scan_fasta_host(ffq_ctx *ctx, const uint8_t *h_buf, int64_t n_bytes, int
 
 /* ---- stream front end (reference: read(), fastqandfurious.py:30-36, and the refill loop of
  * readfastq_iter, :241-279, natively over a file descriptor) ---------------------------------
- * Chunks of fbufsize bytes are read into pinned memory; the read of the next chunk overlaps the
- * copy and the scan of the current buffer fill.  ffq_stream_next returns the rows of ONE fill:
- * absolute stream offsets (what entryfunc_abspos yields, :186-195), in pinned memory owned by
- * the stream and valid until the next call, together with the fill's bytes
+ * A three-stage pipeline: chunks of fbufsize bytes are read into pinned memory by a pool of
+ * helper threads, copied to the device on a copy stream, and scanned; the read of chunk k+2, the
+ * copy of chunk k+1 and the scan + row copy of fill k overlap.  ffq_stream_next returns the rows
+ * of ONE fill: absolute stream offsets (what entryfunc_abspos yields, :186-195), in pinned memory
+ * owned by the stream and valid until the next call, together with the fill's bytes
  * (h_bytes[i] is stream offset bytes_offset + i).  end_state: FFQ_END_REFILL while more
  * follows, FFQ_END_OK with the last fill, FFQ_END_ERR_* (+ err_offset, the byte the reference's
- * ValueError names) when the stream is malformed.  The descriptor is read from its current
- * position (pread when it can seek) and is not closed.                                          */
+ * ValueError names) when the stream is malformed.  A call that fails leaves the stream failed
+ * (every later call fails too).  The descriptor is not closed and, when it can seek, not moved
+ * either (pread).                                                                                */
 typedef struct ffq_stream ffq_stream;
 int  ffq_stream_open(ffq_ctx *ctx, int fd, int64_t fbufsize, ffq_stream **out);
 int  ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n_rows, int *end_state,
                      int64_t *err_offset, const uint8_t **h_bytes, int64_t *n_bytes,
                      int64_t *bytes_offset);
 void ffq_stream_close(ffq_stream *s);
-/* The same with FFQ_F_DECODE_QUAL: every fill's qualities are decoded on the device
- * (array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, qual_add), doc/user-guide.rst:130-141)
+/* The same with options.  flags = FFQ_F_DECODE_QUAL: every fill's qualities are decoded on the
+ * device (array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, qual_add), doc/user-guide.rst:130-141)
  * and ffq_stream_quals hands back the int8 stream and its CSR offsets (n_rows + 1 entries) of
- * the fill ffq_stream_next has just returned; pinned memory, valid until the next call.       */
-int  ffq_stream_open2(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags, int qual_add, ffq_stream **out);
+ * the fill ffq_stream_next has just returned; pinned memory, valid until the next call.
+ * start: byte of the file the stream begins at (< 0: the descriptor's current position); stream
+ * offsets count from there.  ffq_stream_tell: the file position behind the last byte read so far
+ * (where a caller that shares the file object should leave it, as the reference's loop does).  */
+int  ffq_stream_open2(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
+                      ffq_stream **out);
 int  ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int64_t **h_qoff, int64_t *n_qual_bytes);
+int64_t ffq_stream_tell(ffq_stream *s);
 
 /* ---- synthetic FASTQ generators (bench / test inputs) -----
  * Counter-based (splitmix64), so the numpy generator in

@@ -212,3 +212,64 @@ def test_stream_with_decode(mods, gpu_ctx, oracle, tmp_path, pkg, bufsize):
         assert nrows == len(want)
         assert np.array_equal(np.concatenate(quals), wq)
         assert np.array_equal(np.concatenate(lens), np.diff(wqoff))
+
+
+def test_stream_long_record_after_short_ones(mods, gpu_ctx, oracle, tmp_path):
+    """A fill that holds many complete records and ends in the start of a record longer than the
+    carry space: the carry grows (every slot is reallocated) while the previous fill's rows have
+    just been handed out.  Tuples are cut from every fill's bytes, not only rows compared."""
+    from fastqandfurious_amd import synth
+    rng = np.random.default_rng(11)
+    L = 3 << 20
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L).tobytes()
+    qual = rng.choice(np.frombuffer(bytes(range(35, 74)), dtype=np.uint8), size=L).tobytes()
+    short = synth.single(0, 9000, seed=42).tobytes()                  # ~2.9 MB of short records
+    data = short + b"@long\n" + seq + b"\n+\n" + qual + b"\n" + short[:322 * 50]
+    want, *_ = oracle.scan(data)
+    for bufsize in (4 << 20, 1 << 20, 5 << 20):
+        rows, tuples, err = with_file(tmp_path, data, lambda fd: run_stream(mods, gpu_ctx, fd, bufsize))
+        assert err is None and np.array_equal(np.array(rows, dtype=np.int64), want)
+        for r, t in zip(want[8990:9060].tolist(), tuples[8990:9060]):
+            assert t == [data[r[0] + 1:r[1]].hex(), data[r[2]:r[3]].hex(), data[r[4]:r[5]].hex()]
+        h = hashlib.sha256()
+        for t in tuples:
+            h.update(bytes.fromhex(t[2]))
+        h2 = hashlib.sha256()
+        for r in want.tolist():
+            h2.update(data[r[4]:r[5]])
+        assert h.hexdigest() == h2.hexdigest()
+
+
+def test_stream_leaves_the_file_object_where_reading_stopped(mods, gpu_ctx, oracle, tmp_path):
+    """The stream reads with pread from the object's position and does not move the shared
+    descriptor under a BufferedReader; afterwards the object stands at the end of what was read
+    (the reference's loop leaves `fh` at EOF)."""
+    F, hip, index = mods
+    from fastqandfurious_amd import _fastqandfurious as C, synth
+    blob = synth.single(0, 5000, seed=42).tobytes()
+    junk = b"#" * 1000
+    path = str(tmp_path / "pos.fq")
+    open(path, "wb").write(junk + blob)
+    want, *_ = oracle.scan(blob)
+    with open(path, "rb") as fh:
+        assert fh.read(1000) == junk               # the reader's buffer now holds read-ahead data
+        rows = [list(p) for p in F.readfastq_iter(fh, 1 << 16, F.entryfunc_abspos, C.entrypos)]
+        assert np.array_equal(np.array(rows, dtype=np.int64), want)      # offsets count from the start position
+        assert fh.tell() == 1000 + len(blob) and fh.read() == b""
+    with open(path, "rb") as fh:
+        fh.seek(1000)
+        fi = io.BytesIO()
+        assert index.build_index(fh, fi, 1 << 16) == len(want)
+        assert fh.tell() == 1000 + len(blob)
+        assert np.array_equal(np.frombuffer(fi.getvalue(), dtype=np.int64).reshape(-1, 6), want)
+
+
+def test_stream_many_fills_and_reuse(mods, gpu_ctx, oracle, tmp_path):
+    """hundreds of fills through the three-slot pipeline, twice (the second stream takes the
+    first one's parked buffers), at chunk sizes around the slice size of the reader pool"""
+    from fastqandfurious_amd import synth
+    blob = synth.wrapped(0, 60000, seed=43)[0].tobytes()
+    want, *_ = oracle.scan(blob)
+    for bufsize in (1 << 16, (1 << 20) + 4096, 3 << 20, 1 << 16):
+        rows, _, err = with_file(tmp_path, blob, lambda fd: run_stream(mods, gpu_ctx, fd, bufsize))
+        assert err is None and np.array_equal(np.array(rows, dtype=np.int64), want)
