@@ -200,11 +200,11 @@ def stream_inclusive(ctx, sample_u8, fbufsize=1 << 24):
                                "scanner) over the same file, %.1f s" % (n_it, el_it)}
 
 
-def pmc_traffic(workload):
-    """HBM bytes per k_scan_lines launch from the committed rocprofv3 PMC passes of this
+def pmc_traffic(workload, kernel="k_scan_lines<"):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this
     workload (profiles/*/pmc_fetch_write.json): FETCH_SIZE and WRITE_SIZE are KiB; on gfx950
     FETCH_SIZE counts 64 B per 128 B request of a wide streaming read, so it is doubled
-    (MI355X_MICROARCH.md, HBM section).  None if no profile of this workload is committed."""
+    (MI355X_MICROARCH.md, HBM section).  (bytes, file, commit the profile was taken at) or None."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_fetch_write.json"))):
@@ -214,55 +214,29 @@ def pmc_traffic(workload):
             d = json.load(open(f))
         except Exception:
             continue
+        sha = None
+        try:
+            sha = open(os.path.join(os.path.dirname(f), "COMMIT")).read().strip()
+        except OSError:
+            pass
         for k, v in d.items():
-            if "k_scan_lines<" in k and v.get("FETCH_SIZE_KiB_avg_per_launch", 0) > 1024 and "FETCH_SIZE_KiB_avg_per_launch" in v:
+            if kernel in k and v.get("FETCH_SIZE_KiB_avg_per_launch", 0) > 1024:
                 best = (int(2 * v["FETCH_SIZE_KiB_avg_per_launch"] * 1024 +
-                            v.get("WRITE_SIZE_KiB_avg_per_launch", 0) * 1024), os.path.relpath(f, ROOT))
+                            v.get("WRITE_SIZE_KiB_avg_per_launch", 0) * 1024), os.path.relpath(f, ROOT), sha)
     return best
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="single-1g", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--settle-ms", type=float, default=50.0,
-                    help="untimed steps in front of the warm-up until the GPU has been busy this long "
-                         "(its clocks take ~15 ms of load to settle after an idle spell); 0: none")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--sharded-step", action="store_true",
-                    help="N=1 through the synchronous step the N>1 ranks run (diagnostics)")
-    args = ap.parse_args()
+def spread(xs):
+    xs = sorted(float(x) for x in xs)
+    return {"min": round(xs[0], 4), "median": round(xs[len(xs) // 2], 4), "max": round(xs[-1], 4)} if xs else None
 
+
+def run_workload(name, args, ctx, rank, world, dev, dist):
+    """Time `args.steps` passes of the hot path over workload `name`; returns (line dict, closure
+    of what the CPU-side extras need) on rank 0, (None, None) elsewhere."""
     import torch
-    import fastqandfurious_amd  # noqa: F401
-    from fastqandfurious_amd import hip, sharded, synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
-                         % (args.gpus, args.gpus, world))
-    # FFQ_BENCH_DRY_MULTI=1: every rank on GPU 0 over gloo -- a functional dry run of the N > 1
-    # code path on a one-GPU box (its number means nothing; RCCL refuses two ranks per device)
-    dry = os.environ.get("FFQ_BENCH_DRY_MULTI") == "1"
-    if dry:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if dry:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
-
-    wl = WORKLOADS[args.workload]
-    ctx = hip.Context(local_rank)
+    from fastqandfurious_amd import hip, sharded
+    wl = WORKLOADS[name]
     decode = wl["decode"]
     flags = hip.F_DECODE_QUAL if decode else 0
 
@@ -283,7 +257,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ms_index, ms_chain, ms_decode, ms_total = [], [], [], []
+    ms_index, ms_chain, ms_decode, ms_total, t_done = [], [], [], [], []
     # Settling: after the set-up above the GPU has idled and its clocks have dropped; the index
     # kernel of the first ~15 ms of steps runs 5-7 % slower than in steady state
     # (tools/k1_timeline.py).  The untimed phase therefore starts with as many extra steps as make
@@ -296,13 +270,16 @@ def main():
         ms_chain.append(out.res.ms_chain)
         ms_decode.append(out.res.ms_decode)
         ms_total.append(out.res.ms_total)
+        t_done.append(time.perf_counter())
 
+    extra_ctx = []
     if world == 1 and not args.sharded_step:
         # Single range: steps are submitted through two contexts that share their HIP streams,
         # one step ahead (ffq_scan_submit / ffq_scan_wait): while the host waits for step i the
         # kernels of step i+1 are already queued behind it.  Every step is a full scan of the
         # resident buffer into its own output table.
         ctx2 = hip.Context(share=ctx)
+        extra_ctx.append(ctx2)
         ctx2.reserve(shard.ext.numel())
         ctxs = (ctx, ctx2)
         tables = (table, torch.empty_like(table))
@@ -359,10 +336,10 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     else:
-        # Byte-range shards: the same one-step-ahead queue per rank.  A step = edge hand-off
+        # Byte-range shards: the same one-step-ahead queue per rank.  A step = halo hand-off
         # (RCCL send/recv, ordered on the scan stream) + scan of [tail | own | head] + cut of the
-        # own rows + hand-off verification (all_gather of 16 bytes per rank).  submit(i + 1) is
-        # queued before finish(i); finish's small kernel runs on a stream of its own.
+        # own rows + hand-off verification (one all_gather of a few words per rank).  submit(i + 1)
+        # is queued before finish(i); finish's small kernel runs on a stream of its own.
         shard.make_lanes(2)
         tables = (table, torch.empty_like(table))
         quals = (qual, torch.empty_like(qual) if decode else None)
@@ -408,67 +385,131 @@ def main():
     if decode:
         shard.verify_decode(table, out, qual, qoff)
 
+    line = None
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        value = total_bytes / (elapsed / args.steps) / 1e9
-        # dominant kernel: k_scan_lines.  Algorithmic bytes per launch = every byte of the
-        # scanned buffer read once + 2 bytes of line index written per newline.
-        t_idx = float(np.mean(ms_index)) * 1e-3
-        algo = shard.ext_scanned_bytes + 2 * int(out.res.n_lines)
-        achieved = algo / t_idx / 1e9
-        # whole path priced with SURVEY.md 8(d): record bytes + 48 B row (+ decode bytes)
-        t_dev = float(np.mean(ms_total)) * 1e-3
-        algo_path = n_own + 48 * out.n_own_records
+        step_s = elapsed / args.steps
+        value = total_bytes / step_s / 1e9
+        n_rec = out.n_own_records
+        # Dominant kernel of the workload (the longest launch of a step): the Phred decode when
+        # decoding, else the line-index kernel.  Algorithmic bytes per launch:
+        #   k_scan_lines     every byte of the scanned buffer read once + 2 B of index per newline
+        #   k_decode_stream  quality bytes read + written + 16 B of (offset, pos4) per record
         if decode:
-            algo_path += int(out.res.n_qual_bytes) + 8 * out.n_own_records
-        traffic = pmc_traffic(args.workload)
+            dom, t_dom = "k_decode_stream", float(np.mean(ms_decode)) * 1e-3
+            algo = 2 * int(out.res.n_qual_bytes) + 16 * int(out.n_rows)
+            traffic = pmc_traffic(name, "k_decode_stream")
+        else:
+            dom, t_dom = "k_scan_lines", float(np.mean(ms_index)) * 1e-3
+            algo = shard.ext_scanned_bytes + 2 * int(out.res.n_lines)
+            traffic = pmc_traffic(name, "k_scan_lines<")
+        achieved = algo / t_dom / 1e9
+        # whole path priced with SURVEY.md 8(d): record bytes + 48 B row (+ decode bytes), over the
+        # wall-clock step (steps are queued one ahead and their small kernels overlap the next
+        # step's index kernel, so a step's own first-to-last-kernel span is longer than a step)
+        algo_path = n_own + 48 * n_rec
+        if decode:
+            algo_path += int(out.res.n_qual_bytes) + 8 * n_rec
+        steps_ms = np.diff(np.array([t0] + t_done)) * 1e3
         line = {
             "metric": "GB/s FASTQ parsed",
             "value": round(value, 3),
             "unit": "GB/s",
-            "m_reads_per_s": round(total_records / (elapsed / args.steps) / 1e6, 3),
+            "m_reads_per_s": round(total_records / step_s / 1e6, 3),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "settle_steps": settle_steps,
-            "ms_per_step": round(ms_step, 4),
+            "ms_per_step": round(step_s * 1e3, 4),
+            "ms_per_step_spread": spread(steps_ms[1:] if len(steps_ms) > 2 else steps_ms),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": args.workload,
+                "workload": name,
                 "description": "%s synthetic FASTQ, %d bytes/GPU, %d records/GPU%s"
                                % ("S-single 150 bp" if wl["kind"] == "single" else "S-wrapped 50-300 bp",
-                                  n_own, out.n_own_records, ", quality->int8 decode" if decode else ""),
+                                  n_own, n_rec, ", quality->int8 decode" if decode else ""),
                 "bytes_per_gpu": n_own,
-                "records_per_gpu": out.n_own_records,
-                "sharding": "byte ranges, RCCL edge hand-off" if world > 1 else "single range",
+                "records_per_gpu": n_rec,
+                "sharding": "byte ranges, RCCL halo hand-off" if world > 1 else "single range",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_scan_lines",
+                "kernel": dom,
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic[0] if traffic else None,
                 "traffic_source": traffic[1] if traffic else None,
+                "traffic_commit": traffic[2] if traffic else None,
                 "algorithmic_bytes_per_launch": algo,
-                "avg_launch_ms": round(t_idx * 1e3, 4),
+                "avg_launch_ms": round(t_dom * 1e3, 4),
+                "launch_ms_spread": spread(ms_decode if decode else ms_index),
             },
             "path_roofline": {
-                "what": "all kernels of one step, SURVEY.md 8(d) bytes (record bytes + 48 B row%s)"
+                "what": "all kernels of one step over the wall-clock step, SURVEY.md 8(d) bytes (record bytes + 48 B row%s)"
                         % (" + decoded bytes + 8 B CSR offset" if decode else ""),
-                "achieved": round(algo_path / t_dev / 1e9, 2),
-                "frac": round(algo_path / t_dev / 1e9 / HBM_PEAK_GBS, 4),
-                "device_ms": round(t_dev * 1e3, 4),
+                "algorithmic_bytes_per_step": algo_path,
+                "achieved": round(algo_path / step_s / 1e9, 2),
+                "frac": round(algo_path / step_s / 1e9 / HBM_PEAK_GBS, 4),
                 "ms_index": round(float(np.mean(ms_index)), 4),
-                "ms_chain": round(float(np.mean(ms_chain)), 4),
                 "ms_decode": round(float(np.mean(ms_decode)), 4),
+                "step_latency_ms": round(float(np.mean(ms_total)), 4),
             },
         }
+    for c2 in extra_ctx:
+        c2.close()
+    return line, (shard, flags)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="single-1g", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true",
+                    help="N=1: do not also time decode-10g and wrapped-10g (BASELINE configs[2], [3])")
+    ap.add_argument("--settle-ms", type=float, default=50.0,
+                    help="untimed steps in front of the warm-up until the GPU has been busy this long "
+                         "(its clocks take ~15 ms of load to settle after an idle spell); 0: none")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--sharded-step", action="store_true",
+                    help="N=1 through the synchronous step the N>1 ranks run (diagnostics)")
+    args = ap.parse_args()
+
+    import torch
+    import fastqandfurious_amd  # noqa: F401
+    from fastqandfurious_amd import hip
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    # FFQ_BENCH_DRY_MULTI=1: every rank on GPU 0 over gloo -- a functional dry run of the N > 1
+    # code path on a one-GPU box (its number means nothing; RCCL refuses two ranks per device)
+    dry = os.environ.get("FFQ_BENCH_DRY_MULTI") == "1"
+    if dry:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+
+    ctx = hip.Context(local_rank)
+    line, (shard, flags) = run_workload(args.workload, args, ctx, rank, world, dev, dist)
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             sample = shard.host_sample(256 << 20)
             line["cpu_baseline"] = cpu_baseline(sample, args.cpu_seconds)
@@ -477,9 +518,26 @@ def main():
             line["cpu_baseline"]["python_iterator"] = cpu_iterator_rate(sample.tobytes(), 3.0)
             line["cpu_baseline"]["reference_c_extension"] = cpu_reference_c(sample.tobytes(), 3.0)
             line["host_inclusive"] = host_inclusive(ctx, sample, flags)
-            line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, sample)
+            line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, shard.host_sample(1 << 30))
+            del sample
         else:
             line["cpu_baseline"] = None
+    # N = 1, default workload: BASELINE configs[2] and [3] timed the same way, under their own key
+    # (`value` stays configs[1]'s)
+    if world == 1 and args.workload == "single-1g" and not args.no_others and not args.sharded_step:
+        del shard
+        torch.cuda.empty_cache()
+        others = {}
+        for other in ("decode-10g", "wrapped-10g"):
+            ctx_o = hip.Context(local_rank)
+            ol, keep = run_workload(other, args, ctx_o, rank, world, dev, dist)
+            del keep
+            ctx_o.close()
+            torch.cuda.empty_cache()
+            others[other] = {k: ol[k] for k in ("value", "unit", "m_reads_per_s", "ms_per_step", "ms_per_step_spread",
+                                                 "settle_steps", "config", "roofline", "path_roofline")}
+        line["other_workloads"] = others
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -119,6 +119,9 @@ struct ffq_ctx {
     int64_t sel_base_cap = 0;
     int64_t *tab_h = nullptr;      // pinned bounce for rows
     int64_t tab_h_cap = 0;
+    long long *col_sum = nullptr;  // column selection: bytes per block of rows, their scan
+    int64_t col_sum_cap = 0;
+    DevRes *col_res = nullptr;     //   its result block (row count, total bytes)
     hipEvent_t stage_ev[2] = {nullptr, nullptr};    // ffq_scan_host: a staging half has been copied
     void *stream_cache = nullptr;  // buffers of the last closed ffq_stream (ffq_stream.h), reused by the next one
 };
@@ -221,7 +224,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
     (void)hipFree(c->qdir); (void)hipFree(c->p4s); (void)hipFree(c->qrel);
-    (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base);
+    (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base); (void)hipFree(c->col_sum); (void)hipFree(c->col_res);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_word) (void)hipHostFree(c->h_word);
     if (c->h_cut) (void)hipHostFree(c->h_cut);
@@ -1110,6 +1113,57 @@ extern "C" int ffq_table_select_seqlen(ffq_ctx *c, const int64_t *d_table, int64
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     *n_out = c->h_word[0];
+    return FFQ_OK;
+}
+
+// ---- column selection ----------------------------------------------------------------------
+extern "C" int ffq_table_gather_column(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int sentinel, int64_t add,
+                                       const int64_t *d_table, int64_t n_rows, int col_begin, int begin_shift,
+                                       int col_end, int value_add, int8_t *d_out, int64_t out_cap, int64_t *d_off,
+                                       int64_t *n_out_bytes)
+{
+    if (!c || !n_out_bytes || n_rows < 0 || n_bytes < 0 || out_cap < 0 || !d_off || (n_rows > 0 && !d_table))
+        return fail(FFQ_E_ARG, "ffq_table_gather_column: bad argument");
+    if (col_begin < 0 || col_begin > 5 || col_end < 0 || col_end > 5)
+        return fail(FFQ_E_ARG, "ffq_table_gather_column: columns are 0..5");
+    if (c->pend.active) return fail(FFQ_E_ARG, "ffq_table_gather_column: a scan is pending on this context");
+    HIPCHK(hipSetDevice(c->device));
+    *n_out_bytes = 0;
+    hipStream_t st = c->stream;
+    if (n_rows == 0) {
+        const int64_t z = 0;
+        HIPCHK(hipMemcpyAsync(d_off, &z, sizeof z, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return FFQ_OK;
+    }
+    const int64_t nblk = (n_rows + 255) / 256;
+    int rc = grow_dev(c, &c->col_sum, &c->col_sum_cap, nblk);
+    if (!rc && !c->col_res) {
+        hipError_t e = hipMalloc((void **)&c->col_res, sizeof(DevRes));
+        if (e != hipSuccess) rc = fail(FFQ_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    // the copy kernel's scratch: a start per row, the directory of the output stream
+    const int64_t nqb = (out_cap + DQ_BLK - 1) / DQ_BLK + 1;
+    if (!rc) rc = reserve_qdir(c, nqb);
+    if (!rc) rc = reserve_p4s(c, n_rows);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_col_sum, dim3((unsigned)nblk), dim3(256), 0, st, d_table, n_rows, col_begin, begin_shift, col_end,
+                       c->col_sum);
+    hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, st, c->col_sum, nblk, n_rows, c->col_res);
+    hipLaunchKernelGGL(k_col_offsets, dim3((unsigned)nblk), dim3(256), 0, st, d_table, n_rows, col_begin, begin_shift,
+                       col_end, (const long long *)c->col_sum, (const DevRes *)c->col_res, d_off, c->p4s, c->qdir,
+                       c->qdir_cap);
+    if (out_cap > 0)
+        hipLaunchKernelGGL(k_decode_stream, dim3((unsigned)nqb), dim3(256), 0, st, d_buf, n_bytes, sentinel ? 1 : 0,
+                           (const int64_t *)c->p4s, (const int64_t *)d_off, (const int64_t *)c->qdir,
+                           (const DevRes *)c->col_res, n_rows, add, value_add, d_out, out_cap, 0);
+    HIPCHK(hipMemcpyAsync(c->h_word, &c->col_res->n_qual_bytes, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    *n_out_bytes = c->h_word[0];
+    if (*n_out_bytes > out_cap)
+        return fail(FFQ_E_TABLE_FULL, "output holds %lld bytes, the column has %lld", (long long)out_cap,
+                    (long long)*n_out_bytes);
     return FFQ_OK;
 }
 

@@ -750,6 +750,98 @@ __global__ __launch_bounds__(256) void k_sel_scatter(const int64_t *__restrict__
     dst[0] = a; dst[1] = b; dst[2] = c;
 }
 
+// =========================================================================
+// Column selection (push-down of an entryfunc that builds only ONE component of an entry,
+// /root/reference/doc/user-guide.rst:153-180: `buf[posarray[2]:posarray[3]]`; the header as
+// entryfunc cuts it, /root/reference/src/fastqandfurious.py:161-171: `buf[pos[0] + 1:pos[1]]`):
+// the packed stream buf[pos[ca] + shift : pos[cb]] (+ value) of every row and its CSR offsets.
+//   k_col_sum      bytes of the component per block of 256 rows
+//   k_scan_i64v    exclusive scan of those (one workgroup); total -> a result block
+//   k_col_offsets  offsets[i], start[i], directory of the output stream (qdir_mark)
+//   k_decode_stream (above) then copies: it is the Phred decode with another pair of columns
+// =========================================================================
+__device__ __forceinline__ int64_t col_len(const int64_t *__restrict__ table, int64_t i, int64_t n, int ca, int shift,
+                                           int cb, int64_t &start)
+{
+    if (i >= n) { start = 0; return 0; }
+    start = table[i * 6 + ca] + shift;
+    const int64_t len = table[i * 6 + cb] - start;
+    return len > 0 ? min(len, (int64_t)0x7FFFFFF0) : 0;
+}
+
+// exclusive prefix of `len` inside a 256-thread workgroup (lengths below 2^31) and the block's sum
+__device__ __forceinline__ int64_t block_excl_scan_len(int64_t len, int64_t &block_sum)
+{
+    __shared__ long long s_w[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t lo = wave_incl_scan((uint32_t)len & 0xFFFFu), hi = wave_incl_scan((uint32_t)(len >> 16));
+    const long long incl = ((long long)hi << 16) + (long long)lo;
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    long long wpre = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const long long t = s_w[q];
+        if (q < wid) wpre += t;
+        tot += t;
+    }
+    block_sum = tot;
+    return wpre + incl - len;
+}
+
+__global__ __launch_bounds__(256) void k_col_sum(const int64_t *__restrict__ table, int64_t n, int ca, int shift, int cb,
+                                                 long long *__restrict__ bsum)
+{
+    int64_t start, tot;
+    const int64_t len = col_len(table, (int64_t)blockIdx.x * 256 + threadIdx.x, n, ca, shift, cb, start);
+    (void)block_excl_scan_len(len, tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// in-place exclusive scan of int64 values by one workgroup; the total goes to res (n_records = n,
+// n_qual_bytes = total: what k_decode_stream reads)
+__global__ __launch_bounds__(1024) void k_scan_i64v(long long *__restrict__ v, int64_t nv, int64_t n_rows, DevRes *res)
+{
+    __shared__ long long s_v[1024];
+    const int tid = threadIdx.x;
+    long long carry = 0;
+    for (int64_t b0 = 0; b0 < nv; b0 += 1024) {
+        const int64_t b = b0 + tid;
+        const long long x = (b < nv) ? v[b] : 0;
+        s_v[tid] = x;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            long long y = 0;
+            if (tid >= d) y = s_v[tid - d];
+            __syncthreads();
+            s_v[tid] += y;
+            __syncthreads();
+        }
+        if (b < nv) v[b] = carry + s_v[tid] - x;
+        const long long tot = s_v[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (tid == 0) { res->n_records = n_rows; res->n_qual_bytes = carry; res->fallback = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_col_offsets(const int64_t *__restrict__ table, int64_t n, int ca, int shift, int cb,
+                                                     const long long *__restrict__ bbase, const DevRes *__restrict__ res,
+                                                     int64_t *__restrict__ coff, int64_t *__restrict__ starts,
+                                                     int64_t *__restrict__ qdir, int64_t qdir_cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t start, tot;
+    const int64_t len = col_len(table, i, n, ca, shift, cb, start);
+    const int64_t off = bbase[blockIdx.x] + block_excl_scan_len(len, tot);
+    if (i < n) {
+        coff[i] = off;
+        starts[i] = start;
+        qdir_mark(qdir, qdir_cap, off, len, i);
+    }
+    if (i == 0) coff[n] = res->n_qual_bytes;
+}
+
 // The rows of a shard inside the table of its [tail | own | head] scan, one wave, one launch:
 // i0 = first row with pos0 >= lo, i1 = first row with pos0 >= hi (64-ary searches), pos0 of
 // both rows (-1 past the end) and pos5 of the rows in front of them (-1: there is none) -- the

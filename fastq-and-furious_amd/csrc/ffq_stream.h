@@ -30,14 +30,33 @@
 #include <thread>
 
 // ---- helper threads: a chunk of a seekable descriptor is read in slices -------------------------
-// (one pread loop saturates at the copy rate of a single core, a few GB/s from the page cache)
+// (one pread loop saturates at the copy rate of a single core, ~10 GB/s from the page cache).
+// The slices of consecutive chunks go through ONE queue: the helpers never meet at a per-chunk
+// barrier, a chunk is complete when its last slice is (ChunkRead::left).
+struct ChunkRead {
+    int64_t got[64];
+    int64_t want[64];
+    int nsl = 0;
+    int left = 0;                // slices still being read (under ReadPool::m)
+    // the bytes read up to the first short slice -- the same prefix a single read would return
+    int64_t total() const
+    {
+        int64_t t = 0;
+        for (int i = 0; i < nsl; i++) {
+            if (got[i] < 0) return -1;
+            t += got[i];
+            if (got[i] < want[i]) break;
+        }
+        return t;
+    }
+};
+
 struct ReadPool {
-    struct Job { int fd; uint8_t *dst; int64_t n, pos; int64_t *got; };
+    struct Job { int fd; uint8_t *dst; int64_t n, pos; ChunkRead *cr; int idx; };
     std::vector<std::thread> th;
     std::mutex m;
     std::condition_variable cv_job, cv_done;
     std::deque<Job> q;
-    int pending = 0;
     bool stop = false;
 
     static int64_t read_full(int fd, uint8_t *dst, int64_t n, int64_t pos, bool seekable)
@@ -67,10 +86,11 @@ struct ReadPool {
                         if (q.empty()) return;
                         j = q.front(); q.pop_front();
                     }
-                    *j.got = read_full(j.fd, j.dst, j.n, j.pos, true);
+                    const int64_t g = read_full(j.fd, j.dst, j.n, j.pos, true);
                     {
                         std::lock_guard<std::mutex> lk(m);
-                        if (--pending == 0) cv_done.notify_all();
+                        j.cr->got[j.idx] = g;
+                        if (--j.cr->left == 0) cv_done.notify_all();
                     }
                 }
             });
@@ -81,39 +101,31 @@ struct ReadPool {
         cv_job.notify_all();
         for (auto &t : th) t.join();
     }
-    // the bytes read up to the first short slice -- the same prefix a single read would return
-    int64_t read_chunk(int fd, uint8_t *dst, int64_t n, int64_t pos, bool seekable)
+    // queue the slices of one chunk of a seekable descriptor (returns at once)
+    void enqueue(int fd, uint8_t *dst, int64_t n, int64_t pos, ChunkRead *cr)
     {
         const int64_t SL = 1 << 20;
-        const int nsl = (int)std::min<int64_t>((int64_t)th.size() + 1, n / SL);
-        if (!seekable || nsl < 2) return read_full(fd, dst, n, pos, seekable);
+        const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)th.size(), n / SL, (int64_t)64}));
         const int64_t per = ((n + nsl - 1) / nsl + 4095) & ~(int64_t)4095;
-        int64_t got[64];
-        int used = 0;
         {
             std::lock_guard<std::mutex> lk(m);
-            for (int t = 1; t < nsl; t++) {
+            cr->nsl = 0;
+            for (int t = 0; t < nsl; t++) {
                 const int64_t a = (int64_t)t * per;
                 if (a >= n) break;
-                q.push_back(Job{fd, dst + a, std::min(per, n - a), pos + a, &got[t]});
-                pending++;
-                used = t;
+                cr->want[t] = std::min(per, n - a);
+                cr->got[t] = 0;
+                q.push_back(Job{fd, dst + a, cr->want[t], pos + a, cr, t});
+                cr->nsl = t + 1;
             }
+            cr->left = cr->nsl;
         }
         cv_job.notify_all();
-        got[0] = read_full(fd, dst, std::min(per, n), pos, true);      // the caller's own slice
-        {
-            std::unique_lock<std::mutex> lk(m);
-            cv_done.wait(lk, [this] { return pending == 0; });
-        }
-        int64_t total = 0;
-        for (int t = 0; t <= used; t++) {
-            const int64_t want = std::min(per, n - (int64_t)t * per);
-            if (got[t] < 0) return -1;
-            total += got[t];
-            if (got[t] < want) break;
-        }
-        return total;
+    }
+    void wait(ChunkRead *cr)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [cr] { return cr->left == 0; });
     }
 };
 
@@ -125,6 +137,7 @@ struct StreamSlot {
     hipEvent_t copied = nullptr; // the chunk's H2D copy is through
     int64_t got = 0;             // bytes of the chunk (at offset room)
     bool eof = false;            // a short read: the descriptor is exhausted
+    ChunkRead cr;                // its slices while they are being read
 };
 
 // everything a stream allocates; parked in the context when a stream closes so that the next
@@ -210,7 +223,7 @@ struct ffq_stream {
     int64_t last_nq = 0;
     // FFQ_STREAM_PROF=1: where the time of a stream goes (printed when it closes)
     bool prof = false;
-    double t_read = 0, t_slot = 0, t_feed = 0, t_scan = 0, t_rows = 0;
+    double t_read = 0, t_slot = 0, t_feed = 0, t_scan = 0, t_rows = 0, t_copy = 0;
 };
 
 static inline double stream_now()
@@ -218,30 +231,55 @@ static inline double stream_now()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// The feeder: queues the slices of chunk e as soon as slot e % STREAM_SLOTS is free (up to two
+// chunks being read at a time), and completes chunks in order: once the last slice of chunk p is
+// in, its H2D copy goes onto the copy stream and the caller may take it.
 static void stream_feeder(ffq_stream *s)
 {
     (void)hipSetDevice(s->c->device);
     StreamBufs *b = s->b;
-    for (int64_t k = 0;; k++) {
+    const int64_t pos0 = s->file_pos;
+    int64_t e = 0;                        // chunks [0, e) have their slices queued (seekable descriptors)
+    for (int64_t p = 0;; p++) {           // chunk to complete next
         const double tw0 = s->prof ? stream_now() : 0;
-        {
-            std::unique_lock<std::mutex> lk(s->m);
-            for (;;) {
-                if (s->stop) { s->feeder_done = true; s->cv.notify_all(); return; }
-                if (s->pause_req) {          // the caller reallocates the slots: park here
-                    s->paused = true;
-                    s->cv.notify_all();
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(s->m);
+                for (;;) {
+                    if (s->stop) break;
+                    if (s->pause_req && e == p) {          // the caller reallocates the slots: park here (nothing in flight)
+                        s->paused = true;
+                        s->cv.notify_all();
+                        s->cv.wait(lk);
+                        continue;
+                    }
+                    s->paused = false;
+                    if (e > p || (s->seekable ? e : p) - s->released < STREAM_SLOTS) break;   // a read to wait for, or a free slot
                     s->cv.wait(lk);
+                }
+                if (s->stop) {
+                    lk.unlock();
+                    for (int64_t k = p; k < e; k++) b->pool->wait(&b->slot[k % STREAM_SLOTS].cr);   // reads in flight
+                    lk.lock();
+                    s->feeder_done = true;
+                    s->cv.notify_all();
+                    return;
+                }
+                if (s->seekable && !s->pause_req && e - s->released < STREAM_SLOTS && e - p < 2) {
+                    StreamSlot &sq = b->slot[e % STREAM_SLOTS];
+                    lk.unlock();
+                    b->pool->enqueue(s->fd, sq.h + b->room, b->fbufsize, pos0 + e * b->fbufsize, &sq.cr);
+                    e++;
                     continue;
                 }
-                s->paused = false;
-                if (k - s->released < STREAM_SLOTS) break;      // slot k % STREAM_SLOTS is free
-                s->cv.wait(lk);
             }
+            break;
         }
-        StreamSlot &sl = b->slot[k % STREAM_SLOTS];
+        StreamSlot &sl = b->slot[p % STREAM_SLOTS];
         const double tr0 = s->prof ? stream_now() : 0;
-        const int64_t got = b->pool->read_chunk(s->fd, sl.h + b->room, b->fbufsize, s->file_pos, s->seekable);
+        int64_t got;
+        if (s->seekable) { b->pool->wait(&sl.cr); got = sl.cr.total(); }
+        else { got = ReadPool::read_full(s->fd, sl.h + b->room, b->fbufsize, 0, false); e = p + 1; }
         if (s->prof) { const double t = stream_now(); s->t_slot += tr0 - tw0; s->t_read += t - tr0; }
         int rc = FFQ_OK;
         std::string msg;
@@ -249,17 +287,19 @@ static void stream_feeder(ffq_stream *s)
         else {
             sl.got = got;
             sl.eof = got < b->fbufsize;
-            hipError_t e = hipSuccess;
-            if (got > 0) e = hipMemcpyAsync(sl.d + b->room, sl.h + b->room, (size_t)got, hipMemcpyHostToDevice, b->cs);
-            if (e == hipSuccess) e = hipEventRecord(sl.copied, b->cs);
-            if (e != hipSuccess) { rc = FFQ_E_HIP; msg = std::string("ffq_stream: chunk copy failed: ") + hipGetErrorString(e); }
+            hipError_t er = hipSuccess;
+            if (got > 0) er = hipMemcpyAsync(sl.d + b->room, sl.h + b->room, (size_t)got, hipMemcpyHostToDevice, b->cs);
+            if (er == hipSuccess) er = hipEventRecord(sl.copied, b->cs);
+            if (er != hipSuccess) { rc = FFQ_E_HIP; msg = std::string("ffq_stream: chunk copy failed: ") + hipGetErrorString(er); }
         }
+        if (rc || sl.eof)
+            for (int64_t k = p + 1; k < e; k++) b->pool->wait(&b->slot[k % STREAM_SLOTS].cr);    // reads past the end
         {
             std::lock_guard<std::mutex> lk(s->m);
             if (rc) { s->feeder_rc = rc; s->feeder_msg = msg; s->feeder_done = true; }
             else {
                 s->file_pos += got;
-                s->produced = k + 1;
+                s->produced = p + 1;
                 if (sl.eof) s->feeder_done = true;
             }
         }
@@ -282,8 +322,9 @@ static void stream_free(ffq_stream *s)
     stream_stop_feeder(s);
     if (s->prof)
         fprintf(stderr, "[ffq stream] %lld fills: reader %.3f ms reading, %.3f ms waiting for a slot; caller %.3f ms waiting "
-                        "for the reader, %.3f ms carry + scan, %.3f ms rows back\n", (long long)(s->cur + 1), s->t_read * 1e3,
-                s->t_slot * 1e3, s->t_feed * 1e3, s->t_scan * 1e3, s->t_rows * 1e3);
+                        "for the reader, %.3f ms carry + scan (of which %.3f ms waiting for the chunk's copy), %.3f ms rows back\n",
+                (long long)(s->cur + 1), s->t_read * 1e3, s->t_slot * 1e3, s->t_feed * 1e3, s->t_scan * 1e3, s->t_copy * 1e3,
+                s->t_rows * 1e3);
     if (s->b) {
         if (s->b->cs) (void)hipStreamSynchronize(s->b->cs);
         if (s->c->stream) (void)hipStreamSynchronize(s->c->stream);
@@ -413,7 +454,7 @@ extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t f
             if (!b->pool) rc = fail(FFQ_E_NOMEM, "out of host memory");
             else {
                 const unsigned hw = std::thread::hardware_concurrency();
-                b->pool->start((int)std::min<unsigned>(11, hw > 2 ? hw - 2 : 1));
+                b->pool->start((int)std::min<unsigned>(16, hw > 2 ? hw - 2 : 1));
             }
         }
     }
@@ -502,6 +543,11 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
     const int64_t start = room - carry, len = carry + sl.got;
     const bool fill_eof = sl.eof;
     HIPCHK(hipMemcpyAsync(sl.d + start, sl.h + start, (size_t)carry, hipMemcpyHostToDevice, c->stream));
+    if (s->prof) {          // (profiling only: the wait for the chunk's copy on its own)
+        const double t = stream_now();
+        HIPCHK(hipEventSynchronize(sl.copied));
+        s->t_copy += stream_now() - t;
+    }
     HIPCHK(hipStreamWaitEvent(c->stream, sl.copied, 0));
 
     // ---- scan: from the aligned address below the fill, searching from the fill's first byte ----

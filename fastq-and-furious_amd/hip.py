@@ -41,7 +41,7 @@ SYMBOLS = (
     "ffq_pinned_alloc", "ffq_pinned_free", "ffq_copy_h2d", "ffq_copy_d2h", "ffq_sync",
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
-    "ffq_table_select_seqlen", "ffq_table_cut", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
+    "ffq_table_select_seqlen", "ffq_table_cut", "ffq_table_gather_column", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
     "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
@@ -138,6 +138,7 @@ def lib():
         L.ffq_table_lower_bound.argtypes = [vp, vp, i64, i32, i64, P(i64)]
         L.ffq_table_select_seqlen.argtypes = [vp, vp, i64, i64, i64, vp, P(i64)]
         L.ffq_table_cut.argtypes = [vp, vp, i64, i64, i64, P(i64)]
+        L.ffq_table_gather_column.argtypes = [vp, vp, i64, i32, i64, vp, i64, i32, i32, i32, i32, vp, i64, vp, P(i64)]
         L.ffq_stream_open.argtypes = [vp, i32, i64, P(vp)]
         L.ffq_stream_next.argtypes = [vp, P(vp), P(i64), P(i32), P(i64), P(vp), P(i64), P(i64)]
         L.ffq_stream_close.argtypes = [vp]
@@ -381,6 +382,25 @@ class Context:
         check(lib().ffq_table_select_seqlen(self.handle, ctypes.c_void_p(d_table), int(n_rows), int(min_len),
                                             int(max_len), ctypes.c_void_p(d_out), ctypes.byref(k)))
         return k.value
+
+    COLUMNS = {"header": (0, 1, 1), "sequence": (2, 0, 3), "quality": (4, 0, 5)}
+
+    def table_gather_column(self, d_buf, n_bytes, d_table, n_rows, which, d_out, out_cap, d_off, sentinel=True,
+                            add=None, value_add=0):
+        """Packed component `which` ("header" = buf[pos0 + 1:pos1], "sequence", "quality", or a
+        (begin column, shift, end column) triple) of every row of a device table, + value_add per
+        byte, into d_out with CSR offsets d_off (n_rows + 1); raw device pointers.  Returns
+        (rc, bytes of the stream); rc is OK or E_TABLE_FULL (out_cap too small)."""
+        ca, sh, cb = self.COLUMNS[which] if isinstance(which, str) else which
+        if add is None:
+            add = -1 if sentinel else 0
+        nb = ctypes.c_int64(0)
+        rc = lib().ffq_table_gather_column(self.handle, ctypes.c_void_p(d_buf), int(n_bytes), int(bool(sentinel)),
+                                           int(add), ctypes.c_void_p(d_table), int(n_rows), int(ca), int(sh), int(cb),
+                                           int(value_add), ctypes.c_void_p(d_out) if d_out else None, int(out_cap),
+                                           ctypes.c_void_p(d_off), ctypes.byref(nb))
+        check(rc, allow=(E_TABLE_FULL,))
+        return rc, nb.value
 
     def synth_single(self, dptr, first, count, seed=42):
         check(lib().ffq_synth_single(self.handle, ctypes.c_void_p(dptr), int(first), int(count), int(seed)))

@@ -170,3 +170,21 @@ def select_rows_device(ctx, table, min_seq_len=None, max_seq_len=None):
     hi = (1 << 62) if max_seq_len is None else int(max_seq_len)
     k = ctx.table_select_seqlen(table.data_ptr(), n, lo, hi, out.data_ptr()) if n else 0
     return out[:k]
+
+
+def select_column_device(ctx, buf, table, which, sentinel=True, add=None, value_add=0):
+    """One component of every row, packed, on the GPU: `buf` is the CUDA uint8 tensor the rows of
+    `table` (CUDA int64[n][6]) were scanned from; which = "header" | "sequence" | "quality".
+    Returns (int8 tensor with the bytes, int64 tensor with n + 1 offsets): what an entryfunc that
+    builds only that component returns for every entry (doc/user-guide.rst:153-180), before any
+    per-record Python object exists.  With value_add = -33 on "quality": the Phred decode."""
+    import torch
+    n = int(table.shape[0])
+    off = torch.empty(n + 1, dtype=torch.int64, device=table.device)
+    ca, sh, cb = ctx.COLUMNS[which] if isinstance(which, str) else which
+    total = int((table[:, cb] - table[:, ca] - sh).clamp_(min=0).sum().item()) if n else 0
+    out = torch.empty(max(total, 16), dtype=torch.int8, device=table.device)
+    rc, nb = ctx.table_gather_column(buf.data_ptr(), buf.numel(), table.data_ptr(), n, which, out.data_ptr(), total,
+                                     off.data_ptr(), sentinel=sentinel, add=add, value_add=value_add)
+    assert rc == 0 and nb == total
+    return out[:total], off

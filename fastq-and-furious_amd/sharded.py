@@ -472,6 +472,7 @@ class SyntheticShard:
         else:
             n_per = int(bytes_per_gpu // 379.3)
             sizes = synth.wrapped_sizes(rank * n_per, n_per + 1, seed=43)
+            self.w_len, self.w_rep = synth.wrapped_fields(rank * n_per, n_per + 1, seed=43)
             starts = np.zeros(n_per + 2, dtype=np.int64)
             np.cumsum(sizes, out=starts[1:])
             blk_bytes = [v[0] for v in transport.allgather([int(starts[n_per])])]
@@ -575,10 +576,16 @@ class SyntheticShard:
             if self.rank == self.world - 1:
                 k1 = self.n_per
             assert n == k1 - k0, "record count differs from the generator's"
-            assert bool((rows[:, 0] == st[k0:k1]).all()), "record starts differ from the generator's"
-            assert bool((rows[:, 1] == st[k0:k1] + 17).all())
+            # every column from the generator's closed form: 17 header bytes, the read wrapped at 80
+            # columns, '+' (+ 16 repeated header bytes for one record in four), the quality likewise
+            s0 = st[k0:k1]
+            ln = torch.from_numpy(self.w_len[k0:k1]).to(rows.device)
+            rep = torch.from_numpy(self.w_rep[k0:k1]).to(rows.device)
+            p3 = s0 + 18 + ln + (ln + 79) // 80 - 1
+            p4 = p3 + 3 + rep
+            want = torch.stack([s0, s0 + 17, s0 + 18, p3, p4, p4 + p3 - (s0 + 18)], dim=1)
+            assert bool((rows == want).all()), "offset table differs from the generator's closed form"
             assert bool((rows[:, 5] == st[k0 + 1:k1 + 1] - 1).all()), "record ends differ"
-            assert bool((rows[:, 5] - rows[:, 4] == rows[:, 3] - rows[:, 2]).all())
 
     def verify_decode(self, table, out, qual, qoff):
         """The decode's output at full size, with torch ops only: the CSR offsets must be the

@@ -68,6 +68,15 @@ def wrapped_sizes(first, count, seed=43):
     return 18 + length + nl + 1 + rep + 1 + length + nl
 
 
+def wrapped_fields(first, count, seed=43):
+    """(read length, bytes the '+' line repeats of the header: 0 or 16) of S-wrapped records."""
+    idx = np.arange(first, first + count, dtype=np.uint64)
+    h = splitmix64(np.uint64(seed) ^ idx)
+    length = 50 + (h % np.uint64(251)).astype(np.int64)
+    rep = np.where((h >> np.uint64(32)) % np.uint64(4) == 0, 16, 0).astype(np.int64)
+    return length, rep
+
+
 def wrapped(first, count, seed=43):
     """`count` S-wrapped records starting at record `first` (uint8 array)."""
     sizes = wrapped_sizes(first, count, seed)

@@ -198,6 +198,22 @@ int ffq_table_cut(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t 
 int ffq_table_select_seqlen(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t min_len,
                             int64_t max_len, int64_t *d_out, int64_t *n_out);
 
+/* One component of every row of a device offset table as a packed stream + CSR offsets: byte j of
+ * row i's component is d_out[d_off[i] + j] = buf[pos[col_begin] + begin_shift + j] + value_add,
+ * up to pos[col_end].  This is what an entryfunc that builds only one part of an entry returns
+ * (doc/user-guide.rst:153-180: buf[posarray[2]:posarray[3]]; the header as entryfunc cuts it,
+ * fastqandfurious.py:161-171: col_begin 0, begin_shift 1, col_end 1), evaluated for the whole
+ * table on the device; with columns 4 / 5 and value_add = -33 it is the Phred decode
+ * (doc/user-guide.rst:206-214).  d_buf / n_bytes / sentinel / add: the buffer the rows were
+ * scanned from and the `add` of that scan (rows - add are buffer coordinates).  d_off: n_rows + 1
+ * entries.  *n_out_bytes = bytes of the stream; FFQ_E_TABLE_FULL if out_cap is smaller (nothing
+ * is written past out_cap).  After ffq_table_select_seqlen this is the user guide's length-filter
+ * entryfunc in two calls.                                                                     */
+int ffq_table_gather_column(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes, int sentinel, int64_t add,
+                            const int64_t *d_table, int64_t n_rows, int col_begin, int begin_shift,
+                            int col_end, int value_add, int8_t *d_out, int64_t out_cap, int64_t *d_off,
+                            int64_t *n_out_bytes);
+
 /* ---- FASTA (reference: the plug-in scanner entrypos_fasta, fastqandfurious.py:103-143) -------
  * Every COMPLETE entry of a buffer, i.e. the repeated scanner call with offset := pos[3]:
  * rows = pos0 ('>'), pos1 (header end), pos2, pos3 (the "\n" of the next "\n>") + add, -1, -1.

@@ -286,6 +286,38 @@ void ffq_oracle_decode_quals(const uint8_t *base, const int64_t *table, int64_t 
     qoff[n] = w;
 }
 
+/* ---- entryfunc push-down: what an entryfunc that builds only ONE component
+ * of an entry yields, for every row of a table, packed: buf[pos[ca] + shift : pos[cb]] (+ value,
+ * int8 wrap as arrayadd_b) and CSR offsets.  /root/reference/doc/user-guide.rst:153-180 returns
+ * buf[posarray[2]:posarray[3]]; /root/reference/src/fastqandfurious.py:161-171 cuts the header as
+ * buf[pos[0] + 1:pos[1]].                                                                         */
+void ffq_oracle_gather_column(const uint8_t *base, const int64_t *table, int64_t n, int ca, int shift,
+                              int cb, int value, int8_t *out, int64_t *coff)
+{
+    int64_t w = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t a = table[6 * i + ca] + shift, z = table[6 * i + cb];
+        const int64_t len = z > a ? z - a : 0;
+        coff[i] = w;
+        memcpy(out + w, base + a, (size_t)len);
+        ffq_oracle_arrayadd_b(out + w, len, value);
+        w += len;
+    }
+    coff[n] = w;
+}
+
+/* The length filter of /root/reference/doc/user-guide.rst:153-180 (`posarray[3] - posarray[2]`
+ * against a threshold) evaluated on a table: rows with lo <= pos3 - pos2 <= hi, in order.        */
+int64_t ffq_oracle_select_seqlen(const int64_t *table, int64_t n, int64_t lo, int64_t hi, int64_t *out)
+{
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t len = table[6 * i + 3] - table[6 * i + 2];
+        if (len >= lo && len <= hi) { memcpy(out + 6 * k, table + 6 * i, 48); k++; }
+    }
+    return k;
+}
+
 /* ---- FASTA (widening row) ---------------------------------------------
  * One scanner call: /root/reference/src/fastqandfurious.py:103-143 (entrypos_fasta, Python; the
  * reference has no C scanner for FASTA).  No sentinel arithmetic here: d IS the buffer.        */

@@ -59,6 +59,11 @@ def lib():
         L.ffq_oracle_decode_quals.argtypes = [u8p, ctypes.c_void_p, i64, ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p]
         L.ffq_oracle_decode_quals.restype = None
+        L.ffq_oracle_gather_column.argtypes = [u8p, ctypes.c_void_p, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.ffq_oracle_gather_column.restype = None
+        L.ffq_oracle_select_seqlen.argtypes = [ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p]
+        L.ffq_oracle_select_seqlen.restype = i64
         _lib = L
     return _lib
 
@@ -128,6 +133,32 @@ def decode_quals(base, table, value=-33):
     lib().ffq_oracle_decode_quals(b.ctypes.data, t.ctypes.data, n, int(value),
                                   out.ctypes.data, qoff.ctypes.data)
     return out, qoff
+
+
+COLUMNS = {"header": (0, 1, 1), "sequence": (2, 0, 3), "quality": (4, 0, 5)}    # (begin column, shift, end column)
+
+
+def gather_column(base, table, which, value=0):
+    """Packed buf[pos[ca] + shift:pos[cb]] (+ value, int8) of every row + CSR offsets: the
+    component an entryfunc that builds only `which` would return (positions index `base`)."""
+    b = _as_u8(base)
+    t = np.ascontiguousarray(table, dtype=np.int64).reshape(-1, 6)
+    ca, sh, cb = COLUMNS[which]
+    n = t.shape[0]
+    total = int(np.maximum(t[:, cb] - t[:, ca] - sh, 0).sum()) if n else 0
+    out = np.empty(total, dtype=np.int8)
+    coff = np.empty(n + 1, dtype=np.int64)
+    lib().ffq_oracle_gather_column(b.ctypes.data, t.ctypes.data, n, ca, sh, cb, int(value), out.ctypes.data,
+                                   coff.ctypes.data)
+    return out, coff
+
+
+def select_seqlen(table, lo, hi):
+    """Rows with lo <= pos3 - pos2 <= hi, in order (doc/user-guide.rst:153-180 on a table)."""
+    t = np.ascontiguousarray(table, dtype=np.int64).reshape(-1, 6)
+    out = np.empty_like(t)
+    k = lib().ffq_oracle_select_seqlen(t.ctypes.data, t.shape[0], int(lo), int(hi), out.ctypes.data)
+    return out[:k]
 
 
 def entrypos_fasta(buf, offset):

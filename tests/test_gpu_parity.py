@@ -768,3 +768,81 @@ def test_short_wrapped_reads_take_the_dense_configuration(hipmod, oracle):
     table, res = ctx.scan_host(data, table_cap=len(want) + 8)
     assert (table == want).all() and int(res.end_state) == end and int(res.last_status) == status
     assert res.path == 2
+
+
+# ---- BASELINE config sizes (configs[2], configs[3]) under -m gpu ------------------------------------
+def test_decode_at_config_size_past_4g_of_qualities(gpu_ctx, hipmod, pkg):
+    """configs[2]: 10 GiB of S-single with the quality -> int8 decode.  More than 2^32 decoded
+    bytes (64-bit CSR offsets, stream directory, p4 copy); rows against the generator's closed
+    form, offsets against the running sum of pos5 - pos4 over ALL rows, decoded bytes of ~4000
+    records spread over the buffer against the buffer's own bytes - 33."""
+    import torch
+    from fastqandfurious_amd import sharded
+    dev = torch.device("cuda:0")
+    gpu_ctx.forget()
+    sh = sharded.SyntheticShard(gpu_ctx, "single", 10 << 30, 0, 1, dev)
+    table = torch.empty((sh.max_records + 64, 6), dtype=torch.int64, device=dev)
+    qual = torch.empty(sh.n_own_bytes // 2 + 4096, dtype=torch.int8, device=dev)
+    qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
+    out = sh.scan(table, flags=hipmod.F_DECODE_QUAL, qual=qual, qoff=qoff)
+    assert out.res.path == 3 and int(out.n_rows) == sh.n_per == 33346019
+    assert int(out.res.n_qual_bytes) == 150 * sh.n_per > (1 << 32)
+    sh.verify(table, out)
+    sh.verify_decode(table, out, qual, qoff)
+    # the records on either side of the 2^32-th decoded byte
+    k = (1 << 32) // 150
+    for r in range(k - 2, k + 3):
+        a = int(table[r, 4].item())
+        src = (sh.ext[a:a + 150].to(torch.int16) - 33).to(torch.int8)
+        q = int(qoff[r].item())
+        assert q == 150 * r and bool((qual[q:q + 150] == src).all())
+    # column selection at this size: the sequences, 5 GB of them, packed (offsets past 2^32)
+    from fastqandfurious_amd import index
+    n = int(out.n_rows)
+    seqs, soff = index.select_column_device(gpu_ctx, sh.ext, table[:n], "sequence")
+    assert seqs.numel() == 150 * n and bool((soff == 150 * torch.arange(n + 1, device=dev)).all())
+    for r in list(range(k - 2, k + 3)) + [0, n - 1] + torch.randint(0, n, (200,)).tolist():
+        a = int(table[r, 2].item())
+        assert bool((seqs[150 * r:150 * r + 150].view(torch.uint8) == sh.ext[a:a + 150]).all())
+    del seqs, soff
+    # the general kernels on the same buffer (offsets through k_expand): same table, same stream
+    gpu_ctx.forget()
+    import os
+    os.environ["FFQ_NO_FAST4"] = "1"
+    try:
+        t2 = torch.empty_like(table)
+        q2 = torch.empty_like(qual)
+        o2 = torch.empty_like(qoff)
+        out2 = sh.scan(t2, flags=hipmod.F_DECODE_QUAL, qual=q2, qoff=o2)
+    finally:
+        del os.environ["FFQ_NO_FAST4"]
+    n = int(out.n_rows)
+    assert out2.res.path == 0 and int(out2.n_rows) == n
+    assert bool((t2[:n] == table[:n]).all()) and bool((o2[:n + 1] == qoff[:n + 1]).all())
+    nq = int(out.res.n_qual_bytes)
+    assert bool((q2[:nq] == qual[:nq]).all())
+    del sh, table, qual, qoff, t2, q2, o2
+    torch.cuda.empty_cache()
+
+
+def test_wrapped_at_config_size_all_columns(gpu_ctx, hipmod, pkg):
+    """configs[3]: 10 GiB of S-wrapped (50-300 bp, 80-column wrap, general path): all six columns
+    of every row against the generator's closed form, with and without the decode."""
+    import torch
+    from fastqandfurious_amd import sharded
+    dev = torch.device("cuda:0")
+    gpu_ctx.forget()
+    sh = sharded.SyntheticShard(gpu_ctx, "wrapped", 10 << 30, 0, 1, dev)
+    table = torch.empty((sh.max_records + 64, 6), dtype=torch.int64, device=dev)
+    out = sh.scan(table)
+    assert out.res.path == 0 and int(out.n_rows) == sh.n_per
+    sh.verify(table, out)
+    table.zero_()
+    qual = torch.empty(sh.n_own_bytes // 2 + 4096, dtype=torch.int8, device=dev)
+    qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
+    out = sh.scan(table, flags=hipmod.F_DECODE_QUAL, qual=qual, qoff=qoff)
+    assert int(out.res.n_qual_bytes) > (1 << 32)
+    sh.verify(table, out)
+    sh.verify_decode(table, out, qual, qoff)
+    del sh, table, qual, qoff
+    torch.cuda.empty_cache()

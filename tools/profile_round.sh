@@ -7,15 +7,15 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 tag=$1; wl=${2:-single-1g}
 out=$R/gpurun_out/profiles/${tag}_${wl}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --workload $wl > $out/bench.json 2> $out/bench.err
+python $R/bench.py --workload $wl --no-others > $out/bench.json 2> $out/bench.err
 rm -rf /tmp/pr_ks
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pr_ks -o p -- \
-    python $R/bench.py --workload $wl --no-cpu-baseline > $out/bench_under_rocprof.json 2> /dev/null
+    python $R/bench.py --workload $wl --no-cpu-baseline --no-others > $out/bench_under_rocprof.json 2> /dev/null
 cp /tmp/pr_ks/p_kernel_stats.csv $out/rocprofv3_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pr_$c
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pr_$c -o p -- \
-        python $R/bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+        python $R/bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline --no-others > /dev/null 2>&1
 done
 python - "$out" <<'PY'
 import csv, json, sys, collections
@@ -37,4 +37,5 @@ for name, d in agg.items():
     res[name]["launches"] = max(len(v) for v in d.values())
 json.dump(res, open(out + "/pmc_fetch_write.json", "w"), indent=1)
 PY
+git -C $R rev-parse HEAD > $out/COMMIT 2>/dev/null || cp $R/.commit $out/COMMIT 2>/dev/null
 echo "profile written to $out"
