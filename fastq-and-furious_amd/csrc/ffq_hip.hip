@@ -50,6 +50,7 @@ struct ScanState {
     int retries = 0;
     int repairs = 0;          // repair passes of the general kernels (reported with retries)
     bool dense_cfg = false, fast4_failed = false;
+    bool go_ranked = false;   // the front is the index kernel only: the list-ranking tier follows at the wait
     bool index_done = false;  // the line index of this buffer is built (a later tier re-uses it)
     int stage = 0;            // what the pending front consisted of: 1 fast four-line path, 2 general path
     int64_t ntiles = 0;
@@ -63,6 +64,9 @@ struct ffq_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int fast4_skip = 0;                  // scans left that go straight to the general kernels (see scan_finish)
+    int ranked_skip = 0;                 // scans left that go straight to the list-ranking tier (long records)
+    RankBufs rk = {};                    // its scratch (ffq_ranked.h), grow-only
+    int64_t rk_cap_tiles = 0, rk_cap_c = 0;
     int dense_skip = 0;                  // scans left that start with the dense configuration of them
     bool decode_timed = false;           // ev[6] marks the start of the decode kernel of the pending front
     // scratch, grow-only
@@ -220,6 +224,9 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     stream_cache_drop(c);
     for (auto &e : c->stage_ev) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
+    (void)hipFree(c->rk.tbase); (void)hipFree(c->rk.cand); (void)hipFree(c->rk.rec); (void)hipFree(c->rk.succ);
+    (void)hipFree(c->rk.S[0]); (void)hipFree(c->rk.S[1]); (void)hipFree(c->rk.C[0]); (void)hipFree(c->rk.C[1]);
+    (void)hipFree(c->rk.D); (void)hipFree(c->rk.root);
     free_chain(c);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
@@ -349,7 +356,7 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 
 extern "C" void ffq_ctx_forget(ffq_ctx *c)
 {
-    if (c) { c->fast4_skip = 0; c->dense_skip = 0; }
+    if (c) { c->fast4_skip = 0; c->dense_skip = 0; c->ranked_skip = 0; }
 }
 
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
@@ -586,9 +593,11 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     const int nsb = (int)((ntiles + SB_TILES - 1) / SB_TILES);
     // the four-line fast path (ffq_rows4.h) is tried first unless it already failed on this buffer
     // (nor while the context remembers that its recent input was not four-line)
+    if (c->ranked_skip > 0 && !serial && !st.index_done && ablate == 0) { c->ranked_skip--; st.go_ranked = true; }
+    if ((a.flags & FFQ_F_FORCE_RANKED) && !serial) st.go_ranked = true;
     if (c->fast4_skip > 0 && !st.fast4_failed) { c->fast4_skip--; st.fast4_failed = true; }
     if (c->dense_skip > 0 && !st.dense_cfg && !st.index_done) { c->dense_skip--; st.dense_cfg = true; }
-    const bool try_fast4 = !serial && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
+    const bool try_fast4 = !serial && !st.go_ranked && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
                            getenv("FFQ_NO_FAST4") == nullptr;
     const LineIndex L = make_index(c, a, ntiles);
     c->decode_timed = false;
@@ -637,7 +646,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         c->ctl_clean = true;
         st.stage = 1;
     } else {
-        if (!serial) {
+        if (!serial && !st.go_ranked) {
             int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups, true);
             if (rc) return rc;
         } else {
@@ -649,6 +658,89 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     // ev[3]: the last kernel of this front is through (its result block is in host memory)
     HIPCHK(hipEventRecord(c->ev[3], sA));
     HIPCHK(hipGetLastError());
+    return FFQ_OK;
+}
+
+template <class T>
+static int grow_dev(ffq_ctx *c, T **p, int64_t *cap, int64_t need);
+
+// ---- the list-ranking tier (ffq_ranked.h): exact on any input, cost per "\n@" match ----------------
+// Returns FFQ_OK with the result published, 1 if the tier cannot run here (too many candidates for
+// 32-bit ranks, no memory: the caller then takes the one-wave walker), 2 if only_if_sparse is set
+// and the buffer has more than one candidate per 512 bytes.
+static int run_ranked(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, int64_t ntiles, bool only_if_sparse)
+{
+    hipStream_t sA = c->stream;
+    RankBufs &R = c->rk;
+    if (ntiles > c->rk_cap_tiles) {
+        (void)hipFree(R.tbase); R.tbase = nullptr; c->rk_cap_tiles = 0;
+        if (hipMalloc((void **)&R.tbase, (size_t)ntiles * sizeof(long long)) != hipSuccess) return 1;
+        c->rk_cap_tiles = ntiles;
+    }
+    if (!R.root && hipMalloc((void **)&R.root, 16) != hipSuccess) return 1;
+    if (!c->col_res && hipMalloc((void **)&c->col_res, sizeof(DevRes)) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_rk_count, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L, R.tbase);
+    hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, sA, R.tbase, ntiles, (int64_t)0, c->col_res);
+    HIPCHK(hipMemcpyAsync(c->h_word, &c->col_res->n_qual_bytes, sizeof(int64_t), hipMemcpyDeviceToHost, sA));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(sA));
+    const int64_t nc = c->h_word[0];
+    if (nc >= 0x7FFFFFF0ll) return 1;
+    // a context that remembers long records meets short ones again: back to the group kernels
+    if (only_if_sparse && nc * 512 > a.n_bytes) return 2;
+    if (nc > c->rk_cap_c) {
+        (void)hipFree(R.cand); (void)hipFree(R.rec); (void)hipFree(R.succ); (void)hipFree(R.D);
+        for (int i = 0; i < 2; i++) { (void)hipFree(R.S[i]); (void)hipFree(R.C[i]); R.S[i] = R.C[i] = nullptr; }
+        R.cand = nullptr; R.rec = nullptr; R.succ = nullptr; R.D = nullptr; c->rk_cap_c = 0;
+        const size_t n = (size_t)nc + (nc >> 3) + 1024;
+        bool ok = hipMalloc((void **)&R.cand, n * sizeof(H)) == hipSuccess && hipMalloc((void **)&R.rec, n * sizeof(RankRec)) == hipSuccess &&
+                  hipMalloc((void **)&R.succ, n * 4) == hipSuccess && hipMalloc((void **)&R.D, n * 4) == hipSuccess;
+        for (int i = 0; i < 2 && ok; i++)
+            ok = hipMalloc((void **)&R.S[i], n * 4) == hipSuccess && hipMalloc((void **)&R.C[i], n * 4) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); return 1; }
+        c->rk_cap_c = (int64_t)n;
+    }
+    R.nc = nc;
+    const unsigned gthr = (unsigned)std::max<int64_t>((nc + 255) / 256, 1);
+    if (nc > 0) {
+        hipLaunchKernelGGL(k_rk_list, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L, R);
+        hipLaunchKernelGGL(k_rk_succ, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, sA, L, R, a.eof);
+    }
+    hipLaunchKernelGGL(k_rk_root, dim3(1), dim3(1024), 0, sA, L, R, a.offset, c->dres);
+    int rounds = 0;
+    while (((int64_t)1 << rounds) <= nc) rounds++;
+    int cur = 0;
+    for (int k = 0; k < rounds; k++, cur ^= 1)
+        hipLaunchKernelGGL(k_rk_round, dim3(gthr), dim3(256), 0, sA, nc, (const uint32_t *)R.S[cur], (const uint32_t *)R.C[cur],
+                           R.S[cur ^ 1], R.C[cur ^ 1], R.D, k);
+    hipLaunchKernelGGL(k_rk_emit, dim3(gthr), dim3(256), 0, sA, L, R, a.eof, a.offset, a.add, a.d_table, a.table_cap, c->dres);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sA, c->dres, (const int64_t *)a.d_table, a.table_cap, a.add, a.offset,
+                       (int64_t *)nullptr, make_pub(c));
+    c->ctl_clean = true;
+    HIPCHK(hipGetLastError());
+    return FFQ_OK;
+}
+
+// quality offsets of a finished table (n rows known to the host) + the decode: the column kernels
+// with columns 4 / 5 (what the fast path and k_expand do on the way, for the tiers that do not)
+static int enqueue_offsets_and_decode(ffq_ctx *c, const ScanArgs &a, int64_t n_rows)
+{
+    hipStream_t sA = c->stream;
+    if (n_rows <= 0 || n_rows > a.table_cap) {
+        const int64_t z = 0;
+        if (n_rows == 0) HIPCHK(hipMemcpyAsync(a.d_qoff, &z, sizeof z, hipMemcpyHostToDevice, sA));
+        return FFQ_OK;
+    }
+    const int64_t nblk = (n_rows + 255) / 256;
+    int rc = grow_dev(c, &c->col_sum, &c->col_sum_cap, nblk);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_col_sum, dim3((unsigned)nblk), dim3(256), 0, sA, (const int64_t *)a.d_table, n_rows, 4, 0, 5, c->col_sum);
+    // (the scan's totals go into the scan's own result block: the decode kernel and the host read them there)
+    hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, sA, c->col_sum, nblk, n_rows, c->dres);
+    hipLaunchKernelGGL(k_col_offsets, dim3((unsigned)nblk), dim3(256), 0, sA, (const int64_t *)a.d_table, n_rows, 4, 0, 5,
+                       (const long long *)c->col_sum, (const DevRes *)c->dres, a.d_qoff, c->p4s, c->qdir, c->qdir_cap);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, sA, c->dres, make_pub(c));
+    enqueue_decode(c, a, sA);
     return FFQ_OK;
 }
 
@@ -694,6 +786,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         }
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total += ms;
 
+        const bool tiers = !serial && !st.go_ranked;       // the group kernels ran: their fallbacks apply
         if (st.stage == 1) {
             if (!c->h_res->fallback) {
                 fill_result(res, *c->h_res, 3, st.retries);
@@ -713,7 +806,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             res->ms_chain += ms; res->ms_total += ms;
             if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
         }
-        if (!serial && getenv("FFQ_PROF") && c->prof_d) {
+        if (tiers && getenv("FFQ_PROF") && c->prof_d) {
             unsigned long long hp[8];
             HIPCHK(hipMemcpy(hp, c->prof_d, 64, hipMemcpyDeviceToHost));
             if (hp[6])
@@ -724,7 +817,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 fprintf(stderr, "[ffq prof] generic-path nodes per wave %.2f, serial generic rounds per wave %.2f\n",
                         (double)(hp[7] & 0xFFFFFFFFull) / hp[6], (double)(hp[7] >> 32) / hp[6]);
         }
-        if (!serial && getenv("FFQ_DEBUG")) {
+        if (tiers && getenv("FFQ_DEBUG")) {
             const int ng = std::min(st.ngroups, 24);
             std::vector<int64_t> y(ng), ex(ng);
             std::vector<uint32_t> cn(ng), fl(ng);
@@ -741,7 +834,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                         (long long)ex[g], cn[g], fl[g]);
         }
         int path = 0;
-        if (!serial && getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) {
+        if (tiers && getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) {
             // diagnostics build of the pipeline: results are meaningless, only timings count
             fill_result(res, *c->h_res, 0, st.retries);
             return FFQ_OK;
@@ -750,15 +843,20 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         // re-run from their predecessor's exit and everything is verified again.  Every round
         // makes the first rejected group exact, so the first bad group moves forward; a round
         // that does not move it (a group that does not fit the kernel at all) ends the repairs.
-        if (!serial && !(getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) && !getenv("FFQ_NO_REPAIR")) {
+        static const bool no_ranked = getenv("FFQ_NO_RANKED") != nullptr;
+        if (tiers && !(getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) && !getenv("FFQ_NO_REPAIR")) {
             int prev_bad = -1;
             const int first_bad = c->h_res->bad_group;
             // (a group that does not FIT the kernel -- bad_irregular -- is walked by k_group_walk in
             // the same passes; if that cannot take it either, the first bad group does not move)
+            // With list ranking behind them the repair passes only mend sporadic wrong guesses (two
+            // rounds); records that span whole groups correct one another a few groups per round,
+            // and list ranking is the tool for that.
+            // (groups that do not FIT -- dense tiles -- are walked one repair pass after their
+            // predecessor: those passes go on as before)
             for (int round = 0; round < 16 && c->h_res->fallback && c->h_res->bad_group > prev_bad &&
                                 c->h_res->bad_group < st.ngroups; round++) {
-                // records that span whole groups correct one another only a few groups per round:
-                // the wave walker is the better tool then
+                if (!no_ranked && round >= 2 && !c->h_res->bad_irregular) break;
                 if (round >= 4 && !c->h_res->bad_irregular &&
                     c->h_res->bad_group - first_bad < round * std::max(st.ngroups / 64, 1)) break;
                 prev_bad = c->h_res->bad_group;
@@ -774,7 +872,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
             }
         }
-        if (!serial && c->h_res->fallback && !st.dense_cfg && c->h_res->bad_irregular) {
+        if (tiers && c->h_res->fallback && !st.dense_cfg && c->h_res->bad_irregular) {
             // second tier: the same kernels with the LDS budget for short lines / short records
             // (only a group that does not FIT is helped by it; a guess that stays wrong is not)
             st.dense_cfg = true;
@@ -782,7 +880,37 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             continue;
         }
         if (st.dense_cfg) path = 2;
-        if (serial || c->h_res->fallback) {
+        bool walk = serial || (tiers && c->h_res->fallback);
+        if (!serial && !no_ranked && (st.go_ranked || c->h_res->fallback)) {
+            // the group kernels could not prove a chain (records long against a group): list ranking
+            HIPCHK(hipEventRecord(c->ev[4], sA));
+            int rr = run_ranked(c, a, L, st.ntiles, st.go_ranked && !(a.flags & FFQ_F_FORCE_RANKED));
+            if (rr < 0) return rr;
+            if (rr == 2) {
+                c->ranked_skip = 0;
+                c->fast4_skip = 0;           // (the input has changed character: what is remembered of it is void)
+                st.go_ranked = false;
+                st.fast4_failed = false;
+                continue;                    // the usual tiers, from the line index that is there
+            }
+            walk = rr > 0;
+            if (rr == 0) {
+                HIPCHK(hipEventRecord(c->ev[2], sA));
+                HIPCHK(hipEventSynchronize(c->ev[2]));
+                if (decode && !c->h_res->fallback) {
+                    int rc = enqueue_offsets_and_decode(c, a, c->h_res->n_records);
+                    if (rc) return rc;
+                    HIPCHK(hipEventRecord(c->ev[2], sA));
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipEventSynchronize(c->ev[2]));
+                }
+                HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[2]));
+                res->ms_chain += ms; res->ms_total += ms;
+                path = 5;
+                if (!(a.flags & FFQ_F_FORCE_RANKED)) c->ranked_skip = 15;     // and the next scans of this context start there
+            }
+        } else if (st.go_ranked) walk = true;
+        if (walk) {
             path = 1;
             HIPCHK(hipEventRecord(c->ev[4], sA));
             hipLaunchKernelGGL(k_chain_serial, dim3(1), dim3(64), 0, sA, L, a.offset, a.eof, a.add, a.d_table,
@@ -1270,8 +1398,41 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         if (rc) return rc;
     }
     const LineIndex L = make_index(c, a, ntiles);
-    if (mode == 3 || mode == 4) {
-        // (mode 4: the variant for a buffer whose last tile is ragged)
+    if (mode == 7) {
+        // the index kernel with a decoupled look-back over the tile counts riding along (a probe:
+        // what a single-pass design would pay for its prefix sums on this part)
+        int rc = reserve_tiles(c, ntiles);
+        if (rc) return rc;
+        rc = reserve_pool(c, 1ull << 20);
+        if (rc) return rc;
+        float sum = 0;
+        for (int r = 0; r < reps + 2; r++) {
+            HIPCHK(hipMemsetAsync(c->ovf, 0, (size_t)ntiles * 8, c->stream));
+            HIPCHK(hipEventRecord(c->ev[0], c->stream));
+            launch_scan_lines(c, c->stream, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', 8);
+            HIPCHK(hipEventRecord(c->ev[1], c->stream));
+            HIPCHK(hipEventSynchronize(c->ev[1]));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+            if (r >= 2) sum += ms;
+        }
+        *ms_avg = sum / reps;
+        std::vector<uint32_t> hc((size_t)ntiles);
+        unsigned long long last = 0, mid = 0;
+        HIPCHK(hipMemcpy(hc.data(), c->cnt, (size_t)ntiles * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&last, c->ovf + (ntiles - 1), 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&mid, c->ovf + ntiles / 2, 8, hipMemcpyDeviceToHost));
+        unsigned long long tot = 0, totm = 0;
+        for (int64_t t = 0; t < ntiles; t++) { tot += hc[(size_t)t]; if (t <= ntiles / 2) totm += hc[(size_t)t]; }
+        const unsigned long long VM = (1ull << 62) - 1ull;
+        if ((last & VM) != tot || (mid & VM) != totm || (last >> 62) != 2)
+            return fail(FFQ_E_INTERNAL, "look-back probe: prefix %llu / %llu, expected %llu / %llu", (last & VM), (mid & VM), tot, totm);
+        HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return FFQ_OK;
+    }
+    if (mode == 3 || mode == 4 || mode == 8) {
+        // (mode 4: the variant for a buffer whose last tile is ragged; mode 8: non-temporal entry stores)
         if (mode == 4) a.n_bytes -= 5;
         // mode 2's kernel, every launch between its own pair of events (as a scan times it)
         int rc = reserve_tiles(c, ntiles);
@@ -1281,7 +1442,7 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         float sum = 0;
         for (int r = 0; r < reps + 2; r++) {
             HIPCHK(hipEventRecord(c->ev[0], c->stream));
-            launch_scan_lines(c, c->stream, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@');
+            launch_scan_lines(c, c->stream, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', mode == 8 ? 9 : 0);
             HIPCHK(hipEventRecord(c->ev[1], c->stream));
             HIPCHK(hipEventSynchronize(c->ev[1]));
             float ms = 0;

@@ -126,6 +126,35 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
         total += t;
     }
     if (ablate == 5) { if (total + wbase == 0x7777u) cnt[tile] = 1; return; }
+    if (ablate == 8 && w == 0) {
+        // PROBE (ffq_read_probe mode 7): what a decoupled look-back over the tiles' newline counts
+        // costs on this part -- descriptors flag << 62 | value in ovf[] (zeroed before the launch),
+        // relaxed agent-scope loads / stores, no read-modify-write, no fence
+        unsigned long long *desc = ovf;
+        const unsigned long long VM = (1ull << 62) - 1ull;
+        if (tile == 0) {
+            if (l == 0) __hip_atomic_store(desc, (2ull << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (l == 0) __hip_atomic_store(desc + tile, (1ull << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long excl = 0;
+            int64_t pos = tile - 1;
+            for (;;) {
+                const int64_t idx = pos - l;
+                const unsigned long long v = idx >= 0 ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+                const int fl = (int)(v >> 62);
+                const unsigned long long inv = __ballot(fl == 0), inc = __ballot(fl == 2);
+                const int first_inc = inc ? __ffsll((long long)inc) - 1 : 64;
+                const int first_inv = inv ? __ffsll((long long)inv) - 1 : 64;
+                if (first_inv < first_inc) { __builtin_amdgcn_s_sleep(1); continue; }      // a descriptor in between is not there yet
+                const unsigned long long val = (l <= first_inc) ? (v & VM) : 0ull;
+                excl += (unsigned long long)(uint32_t)__shfl((int)wave_incl_scan((uint32_t)(val & 0xFFFFFu)), 63) +
+                        ((unsigned long long)(uint32_t)__shfl((int)wave_incl_scan((uint32_t)(val >> 20)), 63) << 20);
+                if (first_inc < 64) break;
+                pos -= 64;
+            }
+            if (l == 0) __hip_atomic_store(desc + tile, (2ull << 62) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     const bool dense = total > (uint32_t)SLOT;
     if (dense) {   // rare: avg line shorter than 16 bytes over the whole tile
         if (tid == 0) {
@@ -164,10 +193,20 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
     // Each wave stores its own entries, flags looked up on the way, and is done: no second
     // workgroup barrier, no wave waits for another one's store (a workgroup-wide copy of the
     // finished list cost 20 us per GiB in barrier + tail latency).
-    uint16_t *gdst = dense ? pool + pbase : ent + (int64_t)tile * SLOT;
-    if (!dense || pool_ok) {
+    if (!dense) {
+        // (the usual tile on its own: the list comes out of LDS with plain ds reads -- one loop for
+        // both cases reads through a flat pointer)
+        uint16_t *gdst = ent + (int64_t)tile * SLOT;
         for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
-            const uint32_t off = dense ? (uint32_t)gdst[wbase + j] : (uint32_t)s_list[wbase + j];
+            const uint32_t off = (uint32_t)s_list[wbase + j];
+            const uint16_t e = (uint16_t)(off | (entry_flags(s_data, off, nxt, at_char) << 14));
+            if (ablate == 9) __builtin_nontemporal_store(e, gdst + wbase + j);
+            else gdst[wbase + j] = e;
+        }
+    } else if (pool_ok) {
+        uint16_t *gdst = pool + pbase;
+        for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
+            const uint32_t off = (uint32_t)gdst[wbase + j];
             gdst[wbase + j] = (uint16_t)(off | (entry_flags(s_data, off & OFF_MASK, nxt, at_char) << 14));
         }
     }
@@ -1074,3 +1113,5 @@ __global__ void k_selftest(const uint8_t *__restrict__ bytes, uint32_t *__restri
 }
 
 }  // namespace ffq
+
+#include "ffq_ranked.h"

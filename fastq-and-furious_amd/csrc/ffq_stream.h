@@ -134,7 +134,7 @@ constexpr int STREAM_SLOTS = 3;
 struct StreamSlot {
     uint8_t *h = nullptr;        // pinned  [room | fbufsize (+16)]
     uint8_t *d = nullptr;        // device  same layout
-    hipEvent_t copied = nullptr; // the chunk's H2D copy is through
+    hipEvent_t copied[2] = {nullptr, nullptr};   // the chunk's H2D copy is through (one half per copy stream)
     int64_t got = 0;             // bytes of the chunk (at offset room)
     bool eof = false;            // a short read: the descriptor is exhausted
     ChunkRead cr;                // its slices while they are being read
@@ -145,7 +145,8 @@ struct StreamSlot {
 struct StreamBufs {
     int64_t fbufsize = 0, room = 0;
     StreamSlot slot[STREAM_SLOTS];
-    hipStream_t cs = nullptr;    // copy stream of the chunks
+    hipStream_t cs[2] = {nullptr, nullptr};      // copy streams of the chunks: a chunk goes over in two halves, one
+                                                 // per stream (two DMA engines: one did 41-45 GB/s of the link's ~55)
     int64_t *dtab = nullptr, *htab = nullptr;
     int64_t tab_cap = 0;
     int8_t *dqual = nullptr, *hqual = nullptr;
@@ -169,12 +170,12 @@ static void streambufs_free(StreamBufs *b)
     if (!b) return;
     delete b->pool;
     streambufs_free_slots(b);
-    for (auto &s : b->slot) if (s.copied) (void)hipEventDestroy(s.copied);
+    for (auto &s : b->slot) for (auto &e : s.copied) if (e) (void)hipEventDestroy(e);
     if (b->htab) (void)hipHostFree(b->htab);
     if (b->hqual) (void)hipHostFree(b->hqual);
     if (b->hqoff) (void)hipHostFree(b->hqoff);
     (void)hipFree(b->dtab); (void)hipFree(b->dqual); (void)hipFree(b->dqoff);
-    if (b->cs) (void)hipStreamDestroy(b->cs);
+    for (auto &st : b->cs) if (st) (void)hipStreamDestroy(st);
     delete b;
 }
 
@@ -195,6 +196,19 @@ static int streambufs_alloc_slots(StreamBufs *b, int64_t room)
     }
     b->room = room;
     return FFQ_OK;
+}
+
+// the H2D copy of a slot's chunk: two halves, two streams, two events
+static hipError_t stream_copy_chunk(StreamBufs *b, StreamSlot &sl, int64_t got)
+{
+    const int64_t half = ((got / 2) + 4095) & ~(int64_t)4095;
+    hipError_t e = hipSuccess;
+    for (int h = 0; h < 2 && e == hipSuccess; h++) {
+        const int64_t a = h ? std::min(half, got) : 0, z = h ? got : std::min(half, got);
+        if (z > a) e = hipMemcpyAsync(sl.d + b->room + a, sl.h + b->room + a, (size_t)(z - a), hipMemcpyHostToDevice, b->cs[h]);
+        if (e == hipSuccess) e = hipEventRecord(sl.copied[h], b->cs[h]);
+    }
+    return e;
 }
 
 struct ffq_stream {
@@ -287,9 +301,7 @@ static void stream_feeder(ffq_stream *s)
         else {
             sl.got = got;
             sl.eof = got < b->fbufsize;
-            hipError_t er = hipSuccess;
-            if (got > 0) er = hipMemcpyAsync(sl.d + b->room, sl.h + b->room, (size_t)got, hipMemcpyHostToDevice, b->cs);
-            if (er == hipSuccess) er = hipEventRecord(sl.copied, b->cs);
+            const hipError_t er = stream_copy_chunk(b, sl, got);
             if (er != hipSuccess) { rc = FFQ_E_HIP; msg = std::string("ffq_stream: chunk copy failed: ") + hipGetErrorString(er); }
         }
         if (rc || sl.eof)
@@ -326,7 +338,7 @@ static void stream_free(ffq_stream *s)
                 (long long)(s->cur + 1), s->t_read * 1e3, s->t_slot * 1e3, s->t_feed * 1e3, s->t_scan * 1e3, s->t_copy * 1e3,
                 s->t_rows * 1e3);
     if (s->b) {
-        if (s->b->cs) (void)hipStreamSynchronize(s->b->cs);
+        for (auto &st : s->b->cs) if (st) (void)hipStreamSynchronize(st);
         if (s->c->stream) (void)hipStreamSynchronize(s->c->stream);
         // park the buffers in the context for the next stream
         if (!s->c->stream_cache) s->c->stream_cache = s->b;
@@ -387,7 +399,8 @@ static int stream_grow_room(ffq_stream *s, int64_t need)
         s->cv.wait(lk, [&] { return s->paused || s->feeder_done; });
     }
     int rc = FFQ_OK;
-    hipError_t e = hipStreamSynchronize(b->cs);
+    hipError_t e = hipStreamSynchronize(b->cs[0]);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->cs[1]);
     if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_stream: %s", hipGetErrorString(e));
     const int64_t room = (std::max<int64_t>(2 * b->room, need + 4096) + 4095) & ~(int64_t)4095;
     StreamSlot old[STREAM_SLOTS];
@@ -405,8 +418,7 @@ static int stream_grow_room(ffq_stream *s, int64_t need)
                 s->fill_start = room - (old_room - s->fill_start);
             } else {
                 memcpy(n.h + room, o.h + old_room, (size_t)o.got);
-                if (o.got > 0) e = hipMemcpyAsync(n.d + room, n.h + room, (size_t)o.got, hipMemcpyHostToDevice, b->cs);
-                if (e == hipSuccess) e = hipEventRecord(n.copied, b->cs);
+                e = stream_copy_chunk(b, n, o.got);
                 if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_stream: %s", hipGetErrorString(e));
             }
         }
@@ -444,9 +456,12 @@ extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t f
         b = new (std::nothrow) StreamBufs();
         if (!b) { delete s; return fail(FFQ_E_NOMEM, "out of host memory"); }
         b->fbufsize = fbufsize;
-        hipError_t e = hipStreamCreateWithFlags(&b->cs, hipStreamNonBlocking);
+        hipError_t e = hipSuccess;
+        for (auto &st : b->cs)
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         for (auto &sl : b->slot)
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming);
+            for (auto &ev : sl.copied)
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_stream_open: %s", hipGetErrorString(e));
         if (!rc) rc = streambufs_alloc_slots(b, 1 << 20);
         if (!rc) {
@@ -545,10 +560,12 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
     HIPCHK(hipMemcpyAsync(sl.d + start, sl.h + start, (size_t)carry, hipMemcpyHostToDevice, c->stream));
     if (s->prof) {          // (profiling only: the wait for the chunk's copy on its own)
         const double t = stream_now();
-        HIPCHK(hipEventSynchronize(sl.copied));
+        HIPCHK(hipEventSynchronize(sl.copied[0]));
+        HIPCHK(hipEventSynchronize(sl.copied[1]));
         s->t_copy += stream_now() - t;
     }
-    HIPCHK(hipStreamWaitEvent(c->stream, sl.copied, 0));
+    HIPCHK(hipStreamWaitEvent(c->stream, sl.copied[0], 0));
+    HIPCHK(hipStreamWaitEvent(c->stream, sl.copied[1], 0));
 
     // ---- scan: from the aligned address below the fill, searching from the fill's first byte ----
     const int64_t mis = start & 15;

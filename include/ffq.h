@@ -65,6 +65,7 @@ extern "C" {
 /* flags for the scan calls */
 #define FFQ_F_DECODE_QUAL   1u     /* also emit Phred-decoded qualities (value added = qual_add) */
 #define FFQ_F_FORCE_SERIAL  2u     /* debugging/tests: use the single-wave chain walker */
+#define FFQ_F_FORCE_RANKED  4u     /* debugging/tests: use the list-ranking tier */
 
 typedef struct ffq_ctx ffq_ctx;
 
@@ -79,7 +80,8 @@ typedef struct ffq_scan_result {
     int32_t last_status;    /* status of that last call                                   */
     int32_t end_state;      /* FFQ_END_*                                                  */
     int32_t path;           /* 3 = four-line fast path, 0 = general chain kernels, 2 = the
-                               same with the dense LDS budget, 1 = serial walker          */
+                               same with the dense LDS budget, 5 = list ranking over the
+                               "\n@" matches (long records), 1 = serial walker            */
     int32_t retries;        /* internal re-runs (line-index pool growth)                  */
     int64_t n_lines;        /* newline count seen by the line-index kernel                */
     float   ms_index;       /* device time of the line-index kernel (hipEvent)            */

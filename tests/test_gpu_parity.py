@@ -32,19 +32,24 @@ def check_same(ctx, oracle, data, flags=0, **kw):
     return table, res
 
 
+def tier_flags(hipmod, tier):
+    """False: the usual tiers; True: the one-wave walker; "ranked": the list-ranking tier"""
+    return hipmod.F_FORCE_RANKED if tier == "ranked" else (hipmod.F_FORCE_SERIAL if tier else 0)
+
+
 def test_selftest(gpu_ctx):
     gpu_ctx.selftest()
 
 
 @pytest.mark.parametrize("fn", FILES)
-@pytest.mark.parametrize("serial", (False, True))
+@pytest.mark.parametrize("serial", (False, True, "ranked"))
 def test_golden_files(gpu_ctx, hipmod, golden, oracle, fn, serial):
     data = golden_file(fn)
-    flags = hipmod.F_FORCE_SERIAL if serial else 0
+    flags = tier_flags(hipmod, serial)
     table, res = check_same(gpu_ctx, oracle, data, flags=flags)
     assert rows_of(table) == golden["files"][fn]["bufsizes"]["65536"]["c"]["rows"]
     # four-line files take the fast path, the wrapped one the general kernels
-    assert res.path == (1 if serial else (0 if fn == "test_multiline.fq" else 3))
+    assert res.path == (5 if serial == "ranked" else 1 if serial else (0 if fn == "test_multiline.fq" else 3))
 
 
 def test_template_prefix_curves_entrypos(gpu_ctx, golden):
@@ -62,9 +67,9 @@ def test_template_prefix_curves_entrypos(gpu_ctx, golden):
     assert n > 300
 
 
-@pytest.mark.parametrize("serial", (False, True))
+@pytest.mark.parametrize("serial", (False, True, "ranked"))
 def test_edge_corpus(gpu_ctx, hipmod, golden, oracle, serial, chain_path):
-    flags = hipmod.F_FORCE_SERIAL if serial else 0
+    flags = tier_flags(hipmod, serial)
     for name, ent in golden["edge"].items():
         data = bytes.fromhex(ent["data"])
         table, res = check_same(gpu_ctx, oracle, data, flags=flags)
@@ -73,9 +78,9 @@ def test_edge_corpus(gpu_ctx, hipmod, golden, oracle, serial, chain_path):
         assert end_matches(run, int(res.end_state), int(res.end_offset)), name
 
 
-@pytest.mark.parametrize("serial", (False, True))
+@pytest.mark.parametrize("serial", (False, True, "ranked"))
 def test_fuzz_corpus(gpu_ctx, hipmod, golden, oracle, serial, chain_path):
-    flags = hipmod.F_FORCE_SERIAL if serial else 0
+    flags = tier_flags(hipmod, serial)
     for i, ent in enumerate(golden["fuzz"]):
         data = bytes.fromhex(ent["data"])
         table, res = check_same(gpu_ctx, oracle, data, flags=flags)
@@ -188,9 +193,9 @@ def test_decode_quals(gpu_ctx, hipmod, oracle, pkg, chain_path):
 
 
 @pytest.mark.parametrize("fn", FILES)
-@pytest.mark.parametrize("serial", (False, True))
+@pytest.mark.parametrize("serial", (False, True, "ranked"))
 def test_decode_golden_files(gpu_ctx, hipmod, oracle, fn, serial):
-    decode_same(gpu_ctx, hipmod, oracle, golden_file(fn), flags=hipmod.F_FORCE_SERIAL if serial else 0)
+    decode_same(gpu_ctx, hipmod, oracle, golden_file(fn), flags=tier_flags(hipmod, serial))
 
 
 @pytest.mark.parametrize("shape", ("tiny", "short", "illumina", "mixed", "long", "wrapped", "huge"))
@@ -501,9 +506,52 @@ def test_wrapped_kilobase_records_are_repaired_not_serialised(gpu_ctx, oracle, L
     rng = np.random.default_rng(L)
     data = random_records(rng, (6 << 20) // (2 * L), L, L, wrap=80, hdr_hi=10)
     table, res = check_same(gpu_ctx, oracle, data)
-    assert res.path == 0
+    assert res.path in (0, 5)            # repaired, or ranked: never the one-wave walker
     check_same(gpu_ctx, oracle, data[:-1])
     check_same(gpu_ctx, oracle, data, offset=len(data) // 2)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_differential_mess_ranked(gpu_ctx, hipmod, oracle, seed):
+    """The hostile streams of test_differential_mess through the list-ranking tier (forced): the
+    same chain, decode included; from a later offset, not at eof, without the sentinel."""
+    rng = np.random.default_rng(1000 + seed)
+    data = _mess(rng, 20000, fatal=seed >= 4)
+    want, end, status, off = oracle.scan(data)
+    fl = hipmod.F_FORCE_RANKED
+    table, res, qual, qoff = gpu_ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL | fl)
+    assert res.path == 5
+    assert int(res.end_state) == end and int(res.last_status) == status and int(res.end_offset) == off
+    assert (table == want).all()
+    wq, wqoff = oracle.decode_quals(data, want)
+    assert (qoff == wqoff).all() and (qual == wq).all()
+    cut = len(data) // 3
+    for kw in (dict(offset=cut), dict(eof=False), dict(sentinel=False, offset=7, eof=False)):
+        check_same(gpu_ctx, oracle, data[:len(data) - 11], flags=fl, **kw)
+    for n in (0, 1, 2, 5, 40, 41, 1000):
+        check_same(gpu_ctx, oracle, data[:n], flags=fl)
+        check_same(gpu_ctx, oracle, data[:n], flags=fl, eof=False)
+
+
+@pytest.mark.parametrize("L", (5000, 20000, 60000))
+def test_long_wrapped_records_take_the_ranked_tier(gpu_ctx, hipmod, oracle, L):
+    """Wrapped records of 10-120 KB: a group of tiles lies inside one record, entry guesses are
+    worthless.  The chain comes from list ranking over the "\\n@" matches (path 5), exact, and
+    the context then starts its next scans there; short records afterwards send it back."""
+    rng = np.random.default_rng(L)
+    data = random_records(rng, (8 << 20) // (2 * L), L // 2, L, wrap=80, hdr_hi=10)
+    gpu_ctx.forget()
+    table, res = check_same(gpu_ctx, oracle, data)
+    assert res.path == 5
+    table, res = check_same(gpu_ctx, oracle, data[:-1])          # no trailing newline: the final-record rule
+    assert res.path == 5
+    check_same(gpu_ctx, oracle, data[:len(data) * 2 // 3])       # cut inside a record
+    check_same(gpu_ctx, oracle, data, offset=len(data) // 2, eof=False)
+    decode_same(gpu_ctx, hipmod, oracle, data)
+    short = random_records(rng, 20000, 50, 150)
+    table, res = check_same(gpu_ctx, oracle, short)
+    assert res.path == 3
+    gpu_ctx.forget()
 
 
 def mutate(rng, data, nedits):
@@ -585,7 +633,7 @@ def test_bench_verifiers_accept_and_reject(gpu_ctx, hipmod, pkg, kind):
         sh.verify(table, out)
 
 
-@pytest.mark.parametrize("kind", ("single", "wrapped", "serial"))
+@pytest.mark.parametrize("kind", ("single", "wrapped", "serial", "ranked"))
 def test_table_too_small_with_decode(gpu_ctx, hipmod, oracle, pkg, kind):
     """A table with fewer rows than the buffer has records: E_TABLE_FULL with the count needed,
     the rows that fit are right, nothing is written past the table, the offsets or the quality
@@ -595,7 +643,7 @@ def test_table_too_small_with_decode(gpu_ctx, hipmod, oracle, pkg, kind):
     from fastqandfurious_amd import synth
     gpu_ctx.forget()
     data = synth.single(0, 3000, seed=5) if kind != "wrapped" else synth.wrapped(0, 3000, seed=6)[0]
-    flags = hipmod.F_DECODE_QUAL | (hipmod.F_FORCE_SERIAL if kind == "serial" else 0)
+    flags = hipmod.F_DECODE_QUAL | (hipmod.F_FORCE_SERIAL if kind == "serial" else hipmod.F_FORCE_RANKED if kind == "ranked" else 0)
     want, *_ = oracle.scan(data)
     wq, wqoff = oracle.decode_quals(data, want)
     n = len(want)

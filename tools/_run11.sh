@@ -1,0 +1,1 @@
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -6

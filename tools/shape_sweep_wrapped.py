@@ -24,7 +24,7 @@ for L in Ls:
     table = torch.empty((cap, 6), dtype=torch.int64, device="cuda")
     ctx.reserve(d.numel()); ctx.forget()
     ms = []
-    for i in range(3):
+    for i in range(4):
         rc, res = ctx.scan_device(d.data_ptr(), d.numel(), table.data_ptr(), cap)
         ms.append(res.ms_total)
     assert int(res.n_records) == n, (res.n_records, n)
