@@ -7,7 +7,8 @@
 // a "\n>" entry starts a record unless the entry right before it is itself a record start (the
 // search for the end of a sequence skips the header's own newline, :133) -- so inside a run of
 // consecutive "\n>" entries every other one is a start, counted from the run's first entry at
-// or after `offset`.  No speculation, no chain walk:
+// or after `offset` (its parity comes from a wave-wide look at the entries in front, 64 per step).
+// No speculation, no chain walk:
 //   k_fa_count   one wave per tile: record starts per tile
 //   k_scan_i64   exclusive scan of those counts (ffq_kernels.h)
 //   k_fa_rows    one wave per tile: pos0, pos1, pos2 of every start at its rank
@@ -31,36 +32,66 @@ __device__ __forceinline__ uint32_t fa_entry(const LineIndex &L, int t, int j, u
     return (c <= (uint32_t)SLOT) ? (uint32_t)L.ent[(int64_t)t * SLOT + j] : L.pooled(t, (uint32_t)j);
 }
 
-// is the entry before (t, j) a "\n>" at buffer coordinate >= offset?  (tb, jb) = that entry
-__device__ bool fa_prev_is_at(const LineIndex &L, int64_t offset, int t, int j, int &tb, int &jb)
+// is entry j of tile t (count c) an eligible "\n>": the flag, at buffer coordinate >= offset
+__device__ __forceinline__ bool fa_eligible(const LineIndex &L, int64_t offset, int t, uint32_t j, uint32_t c)
 {
-    tb = t; jb = j - 1;
-    if (jb < 0) {
-        tb = t - 1;
-        while (tb >= 0 && L.cnt[tb] == 0) tb--;
-        if (tb < 0) {
-            // before tile 0 there is only the sentinel (coordinate 0)
-            if (!L.s) return false;
-            tb = -1; jb = 0;
-            return L.n > 0 && L.d[0] == '>' && 0 >= offset;
-        }
-        jb = (int)L.cnt[tb] - 1;
-    }
-    const uint32_t e = fa_entry(L, tb, jb, L.cnt[tb]);
-    const int64_t P = ((int64_t)tb << TILE_SHIFT) + (e & OFF_MASK) + L.s;
+    if (j >= c) return false;
+    const uint32_t e = fa_entry(L, t, (int)j, c);
+    const int64_t P = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
     return ((e >> 14) & FL_AT) && P >= offset;
 }
 
-// is entry (t, j) with flags/pos already known to be an eligible "\n>" a record START?
-__device__ bool fa_is_start(const LineIndex &L, int64_t offset, int t, int j)
+// Parity of the run of eligible "\n>" entries that ends right in front of tile t's first entry
+// (wave-uniform; the wave looks at 64 entries per step, so a run of n entries costs n / 64 steps
+// per tile -- a lane-by-lane walk back from every entry was quadratic in the run's length).
+__device__ int fa_run_parity_before(const LineIndex &L, int64_t offset, int t)
 {
-    int r = 0, tb, jb;
-    int tt = t, jj = j;
-    while (tt >= 0 && fa_prev_is_at(L, offset, tt, jj, tb, jb)) {
-        r++;
-        tt = tb; jj = jb;
+    const int lane = threadIdx.x & 63;
+    int par = 0;
+    for (int tt = t - 1;; tt--) {
+        while (tt >= 0 && L.cnt[tt] == 0) tt--;
+        if (tt < 0) {
+            // before tile 0 there is only the sentinel (coordinate 0)
+            if (L.s && L.n > 0 && L.d[0] == '>' && 0 >= offset) par ^= 1;
+            return par;
+        }
+        const uint32_t c = L.cnt[tt];
+        for (int64_t jend = c; jend > 0; jend -= 64) {
+            const int nvalid = (int)min((int64_t)64, jend);
+            // lane i looks at entry jend - 1 - i: lane 0 is the entry nearest to tile t
+            const bool at = lane < nvalid && fa_eligible(L, offset, tt, (uint32_t)(jend - 1 - lane), c);
+            const unsigned long long m = __ballot(at);
+            const int k = (~m == 0ull) ? 64 : (__ffsll((long long)~m) - 1);      // consecutive ones from lane 0
+            par ^= min(k, nvalid) & 1;
+            if (k < nvalid) return par;
+        }
     }
-    return (r & 1) == 0;
+}
+
+// Starts among entries [j0, j0 + 64) of tile t: a "\n>" entry starts a record iff the run of
+// eligible entries right in front of it has even length.  carry = parity of the run that ends in
+// front of j0 (updated for the next chunk).  Returns this lane's answer.
+__device__ __forceinline__ bool fa_chunk_starts(const LineIndex &L, int64_t offset, int t, uint32_t j0, uint32_t c,
+                                                int &carry)
+{
+    const int lane = threadIdx.x & 63;
+    const int nvalid = (int)min((uint32_t)64, c - j0);
+    const bool at = fa_eligible(L, offset, t, j0 + (uint32_t)lane, c);
+    const unsigned long long m = __ballot(at);
+    // eligible entries right below this lane's bit
+    int k = 0;
+    if (lane > 0) {
+        const unsigned long long y = m << (64 - lane);          // bit lane-1 on top
+        k = (~y == 0ull) ? 64 : __clzll((long long)~y);
+        k = min(k, lane);
+    }
+    const bool st = at && (((k + (k == lane ? carry : 0)) & 1) == 0);
+    // the run at the end of this chunk
+    const unsigned long long z = m << (64 - nvalid);
+    int k2 = (~z == 0ull) ? 64 : __clzll((long long)~z);
+    k2 = min(k2, nvalid);
+    carry = (k2 == nvalid) ? (carry ^ (nvalid & 1)) : (k2 & 1);
+    return st;
 }
 
 __global__ __launch_bounds__(256) void k_fa_count(LineIndex L, int64_t offset, unsigned int *__restrict__ cnt_start)
@@ -70,16 +101,12 @@ __global__ __launch_bounds__(256) void k_fa_count(LineIndex L, int64_t offset, u
     if (t >= L.ntiles) return;
     const uint32_t c = L.cnt[t];
     uint32_t n = 0;
+    int carry = c ? fa_run_parity_before(L, offset, t) : 0;
     for (uint32_t j0 = 0; j0 < c; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        bool st = false;
-        if (j < c) {
-            const uint32_t e = fa_entry(L, t, (int)j, c);
-            const int64_t P = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
-            if (((e >> 14) & FL_AT) && P >= offset) st = fa_is_start(L, offset, t, (int)j);
-        }
+        const bool st = fa_chunk_starts(L, offset, t, j0, c, carry);
         n += (uint32_t)__popcll(__ballot(st));
     }
+    (void)lane;
     // the sentinel (a virtual "\n" at coordinate 0) belongs to tile 0's count
     if (t == 0 && L.s && L.n > 0 && L.d[0] == '>' && offset <= 0) n += 1;
     if (lane == 0) cnt_start[t] = n;
@@ -115,15 +142,12 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
         }
         rank += 1;
     }
+    int carry = c ? fa_run_parity_before(L, offset, t) : 0;
     for (uint32_t j0 = 0; j0 < c; j0 += 64) {
         const uint32_t j = j0 + lane;
-        bool st = false;
+        const bool st = fa_chunk_starts(L, offset, t, j0, c, carry);
         int64_t P = 0;
-        if (j < c) {
-            const uint32_t e = fa_entry(L, t, (int)j, c);
-            P = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
-            if (((e >> 14) & FL_AT) && P >= offset) st = fa_is_start(L, offset, t, (int)j);
-        }
+        if (st) P = ((int64_t)t << TILE_SHIFT) + (fa_entry(L, t, (int)j, c) & OFF_MASK) + L.s;
         const unsigned long long m = __ballot(st);
         if (st) {
             const long long r = rank + __popcll(m & ((1ull << lane) - 1ull));

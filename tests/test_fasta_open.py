@@ -220,3 +220,32 @@ def test_fasta_dense_tiles_and_pool_growth(oracle, pkg):
     table, res = ctx.scan_fasta_host(blob, offset=(3 << 20) + 12345)
     want, st, last, loff = oracle.scan_fasta(blob, offset=(3 << 20) + 12345)
     assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
+
+
+@pytest.mark.gpu
+def test_fasta_long_header_runs(gpu_ctx, oracle, pkg):
+    """Runs of consecutive "\\n>" lines of every length, across chunk (64 entries) and tile
+    borders, and a hostile buffer that is ONE run of a million of them (the parity of a run is
+    looked up 64 entries at a time: a lane-by-lane walk back was quadratic in the run's length)."""
+    import time
+    import numpy as np
+    rng = np.random.default_rng(23)
+    parts = [b"\n"]
+    for i in range(400):
+        run = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 1000, 5000]))
+        parts.append(b"".join(b">r%d\n" % k for k in range(run)))
+        parts.append(b"ACGT" * int(rng.integers(0, 50)) + b"\n")
+    blob = b"".join(parts)
+    for off in (0, 1, len(blob) // 3, len(blob) - 100):
+        want, st, last, loff = oracle.scan_fasta(blob, offset=off)
+        table, res = gpu_ctx.scan_fasta_host(blob, offset=off)
+        assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
+    want, st, last, loff = oracle.scan_fasta(b"\n" + blob[1:], add=-1)
+    table, res = gpu_ctx.scan_fasta_host(blob[1:], sentinel=True, add=-1)
+    assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
+    for hostile in (b"\n" + b">\n" * 1000001, b">\n" * 1000000, b"\n" + b">\n" * 999999 + b">"):
+        want, st, last, loff = oracle.scan_fasta(hostile)
+        t0 = time.perf_counter()
+        table, res = gpu_ctx.scan_fasta_host(hostile, table_cap=len(want) + 8)
+        assert time.perf_counter() - t0 < 5.0
+        assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
