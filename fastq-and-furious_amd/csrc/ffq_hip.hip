@@ -5,6 +5,7 @@
 #include "../../include/ffq.h"
 #include "ffq_kernels.h"
 #include "ffq_fasta.h"
+#include "ffq_pool.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -126,7 +127,12 @@ struct ffq_ctx {
     long long *col_sum = nullptr;  // column selection: bytes per block of rows, their scan
     int64_t col_sum_cap = 0;
     DevRes *col_res = nullptr;     //   its result block (row count, total bytes)
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};    // ffq_scan_host: a staging half has been copied
+    // ffq_scan_host: pageable memory goes through three pinned staging slots, copied in by the
+    // helper threads and out over two copy streams (and back the same way)
+    hipEvent_t stage_ev[3][2] = {};
+    hipStream_t stage_cs[2] = {nullptr, nullptr};
+    ChunkRead stage_cr[3];
+    ReadPool *helpers = nullptr;   // helper threads (ffq_pool.h), started on first use
     void *stream_cache = nullptr;  // buffers of the last closed ffq_stream (ffq_stream.h), reused by the next one
 };
 
@@ -222,7 +228,9 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     stream_cache_drop(c);
-    for (auto &e : c->stage_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &r : c->stage_ev) for (auto &e : r) if (e) (void)hipEventDestroy(e);
+    for (auto &st : c->stage_cs) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    delete c->helpers;
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf); (void)hipFree(c->pool);
     (void)hipFree(c->rk.tbase); (void)hipFree(c->rk.cand); (void)hipFree(c->rk.rec); (void)hipFree(c->rk.succ);
     (void)hipFree(c->rk.S[0]); (void)hipFree(c->rk.S[1]); (void)hipFree(c->rk.C[0]); (void)hipFree(c->rk.C[1]);
@@ -246,6 +254,18 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
 }
 
 extern "C" void *ffq_ctx_stream(ffq_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+static ReadPool *ctx_pool(ffq_ctx *c)
+{
+    if (!c->helpers) {
+        c->helpers = new (std::nothrow) ReadPool();
+        if (c->helpers) {
+            const unsigned hw = std::thread::hardware_concurrency();
+            c->helpers->start((int)std::min<unsigned>(16, hw > 2 ? hw - 2 : 1));
+        }
+    }
+    return c->helpers;
+}
 
 static int64_t tiles_for(int64_t n) { return (n + TILE - 1) >> TILE_SHIFT; }
 static int64_t groups_for(int64_t ntiles) { return (ntiles + OWN_T - 1) / OWN_T; }
@@ -1022,6 +1042,60 @@ static int grow_dev(ffq_ctx *c, T **p, int64_t *cap, int64_t need)
     return FFQ_OK;
 }
 
+// ---- staging of the host-buffer entry points --------------------------------------------------
+constexpr int64_t STAGE_CH = 8 << 20;
+
+static int stage_setup(ffq_ctx *c)
+{
+    if (c->stage_h_cap < 3 * STAGE_CH) {
+        if (c->stage_h) (void)hipHostFree(c->stage_h);
+        c->stage_h = nullptr; c->stage_h_cap = 0;
+        hipError_t e = hipHostMalloc((void **)&c->stage_h, (size_t)(3 * STAGE_CH), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+        c->stage_h_cap = 3 * STAGE_CH;
+    }
+    for (auto &st : c->stage_cs)
+        if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto &r : c->stage_ev)
+        for (auto &e : r)
+            if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!ctx_pool(c)) return fail(FFQ_E_NOMEM, "out of host memory");
+    return FFQ_OK;
+}
+
+// device -> pageable host memory: chunks over the link into the pinned slots (after whatever the
+// scan stream holds), out of them by the helper threads; the copy out of chunk k runs while chunk
+// k+1 is on the link
+static int stage_d2h(ffq_ctx *c, void *h_dst, const void *d_src, int64_t bytes)
+{
+    if (bytes <= 0) return FFQ_OK;
+    int rc = stage_setup(c);
+    if (rc) return rc;
+    uint8_t *dst = static_cast<uint8_t *>(h_dst);
+    const uint8_t *src = static_cast<const uint8_t *>(d_src);
+    const int64_t nch = (bytes + STAGE_CH - 1) / STAGE_CH;
+    bool busy[3] = {false, false, false};               // a host copy out of the slot is in flight
+    for (int64_t k = 0; k <= nch; k++) {
+        if (k < nch) {
+            const int b = (int)(k % 3);
+            if (busy[b]) { c->helpers->wait(&c->stage_cr[b]); busy[b] = false; }
+            const int64_t at = k * STAGE_CH, m = std::min<int64_t>(STAGE_CH, bytes - at);
+            HIPCHK(hipMemcpyAsync(c->stage_h + b * STAGE_CH, src + at, (size_t)m, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipEventRecord(c->stage_ev[b][0], c->stream));
+        }
+        if (k > 0) {
+            const int b = (int)((k - 1) % 3);
+            const int64_t at = (k - 1) * STAGE_CH, m = std::min<int64_t>(STAGE_CH, bytes - at);
+            HIPCHK(hipEventSynchronize(c->stage_ev[b][0]));
+            c->helpers->enqueue_copy(dst + at, c->stage_h + b * STAGE_CH, m, &c->stage_cr[b]);
+            busy[b] = true;
+        }
+    }
+    for (int b = 0; b < 3; b++)
+        if (busy[b]) c->helpers->wait(&c->stage_cr[b]);
+    return FFQ_OK;
+}
+
 extern "C" int ffq_scan_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, int sentinel,
                              int64_t offset, int eof, int64_t add, uint32_t flags, int qual_add,
                              int64_t *h_table, int64_t table_cap, int8_t *h_qual, int64_t qual_cap,
@@ -1040,43 +1114,49 @@ extern "C" int ffq_scan_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, 
         if ((rc = grow_dev(c, &c->qual_d, &c->qual_d_cap, std::max<int64_t>(qual_cap, 16)))) return rc;
         if ((rc = grow_dev(c, &c->qoff_d, &c->qoff_d_cap, table_cap + 1))) return rc;
     }
-    // pinned staging, chunked so the H2D copy of chunk i overlaps the host memcpy of chunk i+1
-    const int64_t CH = 8 << 20;
-    if (c->stage_h_cap < 2 * CH) {
-        if (c->stage_h) (void)hipHostFree(c->stage_h);
-        c->stage_h = nullptr; c->stage_h_cap = 0;
-        hipError_t e = hipHostMalloc((void **)&c->stage_h, (size_t)(2 * CH), hipHostMallocDefault);
-        if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
-        c->stage_h_cap = 2 * CH;
-    }
-    for (auto &e : c->stage_ev)
-        if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipEvent_t *done = c->stage_ev;
-    bool used[2] = {false, false};
-    for (int64_t at = 0, k = 0; at < n_bytes; at += CH, k++) {
-        const int b = (int)(k & 1);
-        const int64_t m = std::min<int64_t>(CH, n_bytes - at);
-        if (used[b]) HIPCHK(hipEventSynchronize(done[b]));
-        memcpy(c->stage_h + b * CH, h_buf + at, (size_t)m);
-        HIPCHK(hipMemcpyAsync(c->stage_d + at, c->stage_h + b * CH, (size_t)m, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipEventRecord(done[b], c->stream));
+    // pageable -> device: three pinned staging slots, filled by the helper threads (slices of a
+    // chunk in parallel), emptied over two copy streams (half a chunk each): the host copy of chunk
+    // k+1 runs while chunk k is on the link
+    rc = stage_setup(c);
+    if (rc) return rc;
+    bool used[3] = {false, false, false};
+    const int64_t nch = (n_bytes + STAGE_CH - 1) / STAGE_CH;
+    for (int64_t k_enq = 0, k = 0; k < nch; k++) {
+        // keep the helper threads fed: the host copies of up to three chunks are queued at a time
+        // (a slot is free again once the link copy out of it, three chunks back, is through)
+        for (; k_enq < nch && k_enq - k < 3; k_enq++) {
+            const int b = (int)(k_enq % 3);
+            if (used[b]) { HIPCHK(hipEventSynchronize(c->stage_ev[b][0])); HIPCHK(hipEventSynchronize(c->stage_ev[b][1])); }
+            const int64_t at = k_enq * STAGE_CH;
+            c->helpers->enqueue_copy(c->stage_h + b * STAGE_CH, h_buf + at, std::min<int64_t>(STAGE_CH, n_bytes - at), &c->stage_cr[b]);
+        }
+        const int b = (int)(k % 3);
+        const int64_t at = k * STAGE_CH, m = std::min<int64_t>(STAGE_CH, n_bytes - at);
+        c->helpers->wait(&c->stage_cr[b]);
+        const int64_t half = ((m / 2) + 4095) & ~(int64_t)4095;
+        for (int h = 0; h < 2; h++) {
+            const int64_t a = h ? std::min(half, m) : 0, z = h ? m : std::min(half, m);
+            if (z > a)
+                HIPCHK(hipMemcpyAsync(c->stage_d + at + a, c->stage_h + b * STAGE_CH + a, (size_t)(z - a), hipMemcpyHostToDevice,
+                                      c->stage_cs[h]));
+            HIPCHK(hipEventRecord(c->stage_ev[b][h], c->stage_cs[h]));
+        }
         used[b] = true;
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // the scan stream waits for the copies (the last event of each copy stream covers the earlier ones)
+    for (int b = 0; b < 3; b++)
+        if (used[b]) { HIPCHK(hipStreamWaitEvent(c->stream, c->stage_ev[b][0], 0)); HIPCHK(hipStreamWaitEvent(c->stream, c->stage_ev[b][1], 0)); }
 
     rc = ffq_scan_device(c, c->stage_d, n_bytes, sentinel, offset, eof, add, flags, qual_add, c->tab_d,
                          table_cap, decode ? c->qual_d : nullptr, qual_cap, decode ? c->qoff_d : nullptr, res);
     if (rc != FFQ_OK && rc != FFQ_E_TABLE_FULL) return rc;
     const int64_t rows = std::min<int64_t>(res->n_records, table_cap);
-    if (rows > 0) HIPCHK(hipMemcpyAsync(h_table, c->tab_d, (size_t)rows * 48, hipMemcpyDeviceToHost, c->stream));
-    if (decode) {
-        const int64_t qb = std::min<int64_t>(res->n_qual_bytes, qual_cap);
-        if (qb > 0) HIPCHK(hipMemcpyAsync(h_qual, c->qual_d, (size_t)qb, hipMemcpyDeviceToHost, c->stream));
-        if (res->n_records <= table_cap)
-            HIPCHK(hipMemcpyAsync(h_qoff, c->qoff_d, (size_t)(rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    int rc2 = stage_d2h(c, h_table, c->tab_d, rows * 48);
+    if (!rc2 && decode) {
+        rc2 = stage_d2h(c, h_qual, c->qual_d, std::min<int64_t>(res->n_qual_bytes, qual_cap));
+        if (!rc2 && res->n_records <= table_cap) rc2 = stage_d2h(c, h_qoff, c->qoff_d, (rows + 1) * 8);
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return rc;
+    return rc2 ? rc2 : rc;
 }
 
 extern "C" int ffq_entrypos(ffq_ctx *c, const uint8_t *h_buf, int64_t len, int64_t offset, int64_t *pos,

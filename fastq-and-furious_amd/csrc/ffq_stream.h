@@ -29,106 +29,6 @@
 #include <mutex>
 #include <thread>
 
-// ---- helper threads: a chunk of a seekable descriptor is read in slices -------------------------
-// (one pread loop saturates at the copy rate of a single core, ~10 GB/s from the page cache).
-// The slices of consecutive chunks go through ONE queue: the helpers never meet at a per-chunk
-// barrier, a chunk is complete when its last slice is (ChunkRead::left).
-struct ChunkRead {
-    int64_t got[64];
-    int64_t want[64];
-    int nsl = 0;
-    int left = 0;                // slices still being read (under ReadPool::m)
-    // the bytes read up to the first short slice -- the same prefix a single read would return
-    int64_t total() const
-    {
-        int64_t t = 0;
-        for (int i = 0; i < nsl; i++) {
-            if (got[i] < 0) return -1;
-            t += got[i];
-            if (got[i] < want[i]) break;
-        }
-        return t;
-    }
-};
-
-struct ReadPool {
-    struct Job { int fd; uint8_t *dst; int64_t n, pos; ChunkRead *cr; int idx; };
-    std::vector<std::thread> th;
-    std::mutex m;
-    std::condition_variable cv_job, cv_done;
-    std::deque<Job> q;
-    bool stop = false;
-
-    static int64_t read_full(int fd, uint8_t *dst, int64_t n, int64_t pos, bool seekable)
-    {
-        int64_t got = 0;
-        while (got < n) {
-            const ssize_t r = seekable ? pread(fd, dst + got, (size_t)(n - got), (off_t)(pos + got))
-                                       : read(fd, dst + got, (size_t)(n - got));
-            if (r < 0) {
-                if (errno == EINTR) continue;
-                return -1;
-            }
-            if (r == 0) break;
-            got += r;
-        }
-        return got;
-    }
-    void start(int n)
-    {
-        for (int i = 0; i < n; i++)
-            th.emplace_back([this] {
-                for (;;) {
-                    Job j;
-                    {
-                        std::unique_lock<std::mutex> lk(m);
-                        cv_job.wait(lk, [this] { return stop || !q.empty(); });
-                        if (q.empty()) return;
-                        j = q.front(); q.pop_front();
-                    }
-                    const int64_t g = read_full(j.fd, j.dst, j.n, j.pos, true);
-                    {
-                        std::lock_guard<std::mutex> lk(m);
-                        j.cr->got[j.idx] = g;
-                        if (--j.cr->left == 0) cv_done.notify_all();
-                    }
-                }
-            });
-    }
-    ~ReadPool()
-    {
-        { std::lock_guard<std::mutex> lk(m); stop = true; }
-        cv_job.notify_all();
-        for (auto &t : th) t.join();
-    }
-    // queue the slices of one chunk of a seekable descriptor (returns at once)
-    void enqueue(int fd, uint8_t *dst, int64_t n, int64_t pos, ChunkRead *cr)
-    {
-        const int64_t SL = 1 << 20;
-        const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)th.size(), n / SL, (int64_t)64}));
-        const int64_t per = ((n + nsl - 1) / nsl + 4095) & ~(int64_t)4095;
-        {
-            std::lock_guard<std::mutex> lk(m);
-            cr->nsl = 0;
-            for (int t = 0; t < nsl; t++) {
-                const int64_t a = (int64_t)t * per;
-                if (a >= n) break;
-                cr->want[t] = std::min(per, n - a);
-                cr->got[t] = 0;
-                q.push_back(Job{fd, dst + a, cr->want[t], pos + a, cr, t});
-                cr->nsl = t + 1;
-            }
-            cr->left = cr->nsl;
-        }
-        cv_job.notify_all();
-    }
-    void wait(ChunkRead *cr)
-    {
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [cr] { return cr->left == 0; });
-    }
-};
-
 constexpr int STREAM_SLOTS = 3;
 
 struct StreamSlot {
@@ -153,7 +53,7 @@ struct StreamBufs {
     int64_t qual_cap = 0;
     int64_t *dqoff = nullptr, *hqoff = nullptr;
     int64_t qoff_cap = 0;
-    ReadPool *pool = nullptr;
+    ReadPool *pool = nullptr;    // the context's helper threads (not owned)
 };
 
 static void streambufs_free_slots(StreamBufs *b)
@@ -168,7 +68,6 @@ static void streambufs_free_slots(StreamBufs *b)
 static void streambufs_free(StreamBufs *b)
 {
     if (!b) return;
-    delete b->pool;
     streambufs_free_slots(b);
     for (auto &s : b->slot) for (auto &e : s.copied) if (e) (void)hipEventDestroy(e);
     if (b->htab) (void)hipHostFree(b->htab);
@@ -464,15 +363,8 @@ extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t f
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_stream_open: %s", hipGetErrorString(e));
         if (!rc) rc = streambufs_alloc_slots(b, 1 << 20);
-        if (!rc) {
-            b->pool = new (std::nothrow) ReadPool();
-            if (!b->pool) rc = fail(FFQ_E_NOMEM, "out of host memory");
-            else {
-                const unsigned hw = std::thread::hardware_concurrency();
-                b->pool->start((int)std::min<unsigned>(16, hw > 2 ? hw - 2 : 1));
-            }
-        }
     }
+    if (!rc && !(b->pool = ctx_pool(c))) rc = fail(FFQ_E_NOMEM, "out of host memory");
     s->b = b;
     if (!rc) rc = stream_alloc_tab(s, fbufsize / 64 + 1024);
     if (rc) { stream_free(s); return rc; }
