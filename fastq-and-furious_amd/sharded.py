@@ -50,6 +50,7 @@ HEAD_BYTES = 1 << 20      # look-ahead taken from the right (grown when a record
 
 NONE_POS = -1             # no record starts at / after the bound: the view reaches the end of the stream
 UNKNOWN_POS = -2          # not known yet (more look-ahead needed, or the guessed entry led nowhere)
+ERR_TABLE_FULL = 100      # (beside the END_ERR_* codes of the stream) the caller's table cannot hold a rank's rows
 
 
 def shard_bounds(total_bytes, world):
@@ -322,11 +323,17 @@ class ShardScanner:
             rc, res = first                  # the offset-0 scan was submitted ahead (submit / finish)
         else:
             rc, res = self.backend.scan(v.ext, v.n_bytes, v.sentinel, offset, v.eof, v.add, table, flags, qual, qoff)
-        if rc != _hip.OK:
-            raise RuntimeError("rank %d: offset table too small (%d records)" % (self.rank, res.n_records))
         st = _State()
         st.v, st.res, st.start = v, res, start
         n = st.n = int(res.n_records)
+        if rc != _hip.OK:
+            # the caller's table is too small: every rank learns it with the next all_gather and
+            # raises (a rank that raised on its own would leave the others waiting in a collective)
+            st.n = st.row_lo = st.row_hi = 0
+            st.first = st.exit = UNKNOWN_POS
+            st.exit_search = 0
+            st.err, st.err_byte, st.want = ERR_TABLE_FULL, n, 0
+            return st
         i0, i1, p_i0, p_i1, _q0, q1 = self.backend.cut(table, n, -(1 << 62) if v.lo == v.origin else v.lo,
                                                        (1 << 62) if v.hi == v.total else v.hi)
         good = _hip.END_OK if v.eof else _hip.END_REFILL
@@ -381,6 +388,9 @@ class ShardScanner:
             allv = self.tr.allgather([st.exit, st.first, st.row_hi - st.row_lo, st.want, st.v.head, st.err,
                                       st.err_byte, st.exit_search])
             ex, fi, cnt, want, head, err, errb, exs = (list(c) for c in zip(*allv))
+            for r in range(W):
+                if err[r] == ERR_TABLE_FULL:
+                    raise RuntimeError("rank %d: offset table too small (%d records in its view)" % (r, errb[r]))
             grow = [r for r in range(W) if want[r] > 0]
             force = [r for r in range(1, W) if B[r] > B[0] and ex[r - 1] != UNKNOWN_POS and fi[r] != ex[r - 1]]
             if not grow and not force:

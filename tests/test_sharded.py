@@ -193,8 +193,8 @@ def run_local(stream_t, bounds, make_backend, tail_bytes=None, head_bytes=None, 
         t.join()
     real = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)]
     if real:
-        if all(isinstance(e, ValueError) for e in real) and len(real) == world:
-            assert len({str(e) for e in real}) == 1, "ranks disagree on the stream error: %r" % real
+        if all(isinstance(e, (ValueError, RuntimeError)) for e in real) and len(real) == world:
+            assert len({str(e) for e in real}) == 1, "ranks disagree on the error: %r" % real
         raise real[0]
     assert not any(errors), errors
     return results
@@ -266,6 +266,21 @@ def test_local_ranks_stream_errors(oracle, pkg, kind, world):
     with pytest.raises(ValueError) as ei:
         run_local(t, bounds_for(stream.size, world), lambda r: OracleBackend())
     assert str(ei.value) == err
+
+
+def test_local_ranks_table_too_small(oracle, pkg):
+    """one rank's table cannot hold its rows: every rank raises, nobody is left in a collective"""
+    stream = make_stream("single")
+    t = torch.from_numpy(stream.copy())
+    with pytest.raises(RuntimeError) as ei:
+        run_local(t, bounds_for(stream.size, 3), lambda r: OracleBackendSmall() if r == 1 else OracleBackend())
+    assert "offset table too small" in str(ei.value)
+
+
+class OracleBackendSmall(OracleBackend):
+    def scan(self, ext, n_bytes, sentinel, offset, eof, add, table, *a, **kw):
+        rc, res = OracleBackend.scan(self, ext, n_bytes, sentinel, offset, eof, add, torch.empty((20000, 6), dtype=torch.int64))
+        return -5, res              # E_TABLE_FULL, as the HIP engine reports it
 
 
 def test_local_ranks_empty_and_tiny(oracle, pkg):
