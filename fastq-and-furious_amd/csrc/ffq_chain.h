@@ -105,6 +105,8 @@ struct Pub {
     Ctl *ctl;
     Ctl *h_ctl;        // nullptr: this kernel is not the publisher
     DevRes *h_res;
+    unsigned long long *h_seq;     // host-mapped word the host polls (FFQ_F_POLL_RESULT), or nullptr
+    unsigned long long seq;        // the value that says "this scan's result block is there"
 };
 __device__ __forceinline__ void publish(const Pub &pb, const DevRes *res)
 {
@@ -114,6 +116,8 @@ __device__ __forceinline__ void publish(const Pub &pb, const DevRes *res)
     pb.h_ctl->pool_head = pb.ctl->pool_head;
     pb.ctl->err = 0;
     pb.ctl->pool_head = 0;
+    // last, and after everything above has left for host memory
+    if (pb.h_seq) __hip_atomic_store(pb.h_seq, pb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // window accessor: flat LDS index while inside the window, global index beyond

@@ -51,6 +51,7 @@ struct ScanState {
     int retries = 0;
     int repairs = 0;          // repair passes of the general kernels (reported with retries)
     bool dense_cfg = false, fast4_failed = false;
+    unsigned long long poll_seq = 0;   // FFQ_F_POLL_RESULT: the front ends in a publisher that writes this number; no end event
     bool go_ranked = false;   // the front is the index kernel only: the list-ranking tier follows at the wait
     bool index_done = false;  // the line index of this buffer is built (a later tier re-uses it)
     int stage = 0;            // what the pending front consisted of: 1 fast four-line path, 2 general path
@@ -102,6 +103,9 @@ struct ffq_ctx {
     DevRes *h_res = nullptr;
     Ctl *hm_ctl = nullptr;              // device addresses of the two
     DevRes *hm_res = nullptr;
+    unsigned long long *h_seq = nullptr, *hm_seq = nullptr;   // completion word of FFQ_F_POLL_RESULT (host-mapped) and its device address
+    unsigned long long seq = 0;         // last number handed out
+    unsigned long long pub_seq = 0;     // what the publisher being enqueued writes (0: nothing)
     bool ctl_clean = false;             // the control block is zero (creation, or a publisher ran last)
     int64_t *d_word = nullptr;          // 2 scratch words for the small table queries
     int64_t *h_word = nullptr;          //   and their pinned mirror
@@ -191,6 +195,8 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_L, sizeof(LineIndex), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_res, sizeof(DevRes), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_seq, 64, hipHostMallocMapped);
+    if (e == hipSuccess) { *c->h_seq = 0; e = hipHostGetDevicePointer((void **)&c->hm_seq, c->h_seq, 0); }
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->hm_ctl, c->h_ctl, 0);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->hm_res, c->h_res, 0);
     if (e != hipSuccess) {
@@ -244,6 +250,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     if (c->h_word) (void)hipHostFree(c->h_word);
     if (c->h_cut) (void)hipHostFree(c->h_cut);
     (void)hipFree(c->d_word); (void)hipFree(c->d_cut); (void)hipFree(c->fa_hdr);
+    if (c->h_seq) (void)hipHostFree(c->h_seq);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->stage_h) (void)hipHostFree(c->stage_h);
@@ -502,8 +509,27 @@ static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st, bool t
                        a.qual_cap, ablate);
 }
 
-static Pub make_pub(ffq_ctx *c) { return Pub{c->ctl, c->hm_ctl, c->hm_res}; }
-static Pub no_pub(ffq_ctx *c) { return Pub{c->ctl, nullptr, nullptr}; }
+static Pub make_pub(ffq_ctx *c) { return Pub{c->ctl, c->hm_ctl, c->hm_res, c->pub_seq ? c->hm_seq : nullptr, c->pub_seq}; }
+static Pub no_pub(ffq_ctx *c) { return Pub{c->ctl, nullptr, nullptr, nullptr, 0}; }
+
+// FFQ_F_POLL_RESULT: wait for the publisher of a front by polling the host-mapped completion word
+// (every event record on the stream is a few microseconds of idle GPU; a front that ends in a
+// publisher needs none to say that it is through)
+static int poll_seq(ffq_ctx *c, unsigned long long want)
+{
+    for (uint64_t spins = 1;; spins++) {
+        if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) >= want) return FFQ_OK;
+        if ((spins & 0x7FFF) == 0) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) {           // the stream has drained: the publisher has run, or never will
+                if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) >= want) return FFQ_OK;
+                return fail(FFQ_E_INTERNAL, "the result block was not published");
+            }
+            if (e != hipErrorNotReady) return fail(FFQ_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        }
+        __builtin_ia32_pause();
+    }
+}
 
 // verification + scan of the group counts, rows, result block (publishes) [-> decode]
 static int enqueue_resolve(ffq_ctx *c, const ScanArgs &a, const ChainBufs &cb, bool timed)
@@ -621,6 +647,9 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
                            getenv("FFQ_NO_FAST4") == nullptr;
     const LineIndex L = make_index(c, a, ntiles);
     c->decode_timed = false;
+    // without the decode every front ends in a publisher: it can say "done" itself
+    st.poll_seq = ((a.flags & FFQ_F_POLL_RESULT) && !decode) ? ++c->seq : 0;
+    c->pub_seq = st.poll_seq;
     if (!c->ctl_clean) HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));    // first scan, or an abandoned front
     c->ctl_clean = false;
 
@@ -676,7 +705,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         st.stage = 2;
     }
     // ev[3]: the last kernel of this front is through (its result block is in host memory)
-    HIPCHK(hipEventRecord(c->ev[3], sA));
+    c->pub_seq = 0;                       // (publishers of later tiers, enqueued at the wait, signal with events)
+    if (!st.poll_seq) HIPCHK(hipEventRecord(c->ev[3], sA));
     HIPCHK(hipGetLastError());
     return FFQ_OK;
 }
@@ -780,7 +810,12 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         front_done = false;
         // wait for THIS scan's front only: the stream may already hold the next scan of a
         // context that shares it
-        HIPCHK(hipEventSynchronize(c->ev[3]));
+        if (st.poll_seq) {
+            int rc = poll_seq(c, st.poll_seq);
+            if (rc) return rc;
+            // (the GPU is past this mark; the wait only lets the runtime note it before the mark is read)
+            HIPCHK(hipEventSynchronize(c->ev[1]));
+        } else HIPCHK(hipEventSynchronize(c->ev[3]));
         const LineIndex L = make_index(c, a, st.ntiles);
 
         if (c->h_ctl->err & ERR_POOL) {
@@ -797,14 +832,16 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         if (!st.index_done) res->ms_index = ms;
         st.index_done = true;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[3])); res->ms_chain += ms;
         res->ms_decode = 0;
-        if (c->decode_timed) {
-            // the decode kernel is the tail of the front: split it off the chain time
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[3]));
-            res->ms_decode = ms; res->ms_chain -= ms;
+        if (!st.poll_seq) {                // (a polled front has no end mark: its tail is not timed)
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[3])); res->ms_chain += ms;
+            if (c->decode_timed) {
+                // the decode kernel is the tail of the front: split it off the chain time
+                HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[3]));
+                res->ms_decode = ms; res->ms_chain -= ms;
+            }
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total += ms;
         }
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); res->ms_total += ms;
 
         const bool tiers = !serial && !st.go_ranked;       // the group kernels ran: their fallbacks apply
         if (st.stage == 1) {

@@ -34,6 +34,7 @@ E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_TABLE_FULL, E_INTERNAL = -1, -2, -3, -4, -5
 F_DECODE_QUAL = 1
 F_FORCE_SERIAL = 2
 F_FORCE_RANKED = 4
+F_POLL_RESULT = 8
 
 # every symbol include/ffq.h declares (tests check the library exports them all)
 SYMBOLS = (

@@ -894,3 +894,37 @@ def test_wrapped_at_config_size_all_columns(gpu_ctx, hipmod, pkg):
     sh.verify_decode(table, out, qual, qoff)
     del sh, table, qual, qoff
     torch.cuda.empty_cache()
+
+
+def test_poll_result_instead_of_an_end_event(gpu_ctx, hipmod, golden, oracle, pkg):
+    """FFQ_F_POLL_RESULT: the last kernel of a scan says "done" through host-mapped memory and
+    ffq_scan_wait polls; same results on every tier, alone and with two contexts one scan ahead."""
+    import torch
+    from fastqandfurious_amd import synth
+    fl = hipmod.F_POLL_RESULT
+    for fn in FILES:
+        check_same(gpu_ctx, oracle, golden_file(fn), flags=fl)
+        check_same(gpu_ctx, oracle, golden_file(fn), flags=fl | hipmod.F_FORCE_SERIAL)
+        check_same(gpu_ctx, oracle, golden_file(fn), flags=fl | hipmod.F_FORCE_RANKED)
+        decode_same(gpu_ctx, hipmod, oracle, golden_file(fn), flags=fl)        # (ignored with the decode)
+    for name, ent in list(golden["edge"].items()):
+        check_same(gpu_ctx, oracle, bytes.fromhex(ent["data"]), flags=fl)
+    for ent in golden["fuzz"][:120]:
+        check_same(gpu_ctx, oracle, bytes.fromhex(ent["data"]), flags=fl)
+    datas = [synth.single(0, 40000, seed=42), synth.wrapped(0, 30000, seed=43)[0], synth.single(7, 25000, seed=5)[:-50]]
+    wants = [oracle.scan(d) for d in datas]
+    ctx2 = hipmod.Context(share=gpu_ctx)
+    ctxs = (gpu_ctx, ctx2)
+    bufs = [torch.from_numpy(np.array(d)).cuda() for d in datas]
+    tabs = [torch.empty((60000, 6), dtype=torch.int64, device="cuda") for _ in range(2)]
+    order = [i % 3 for i in range(12)]
+    ctxs[0].scan_submit(bufs[order[0]].data_ptr(), len(datas[order[0]]), tabs[0].data_ptr(), 60000, flags=fl)
+    for i in range(1, len(order) + 1):
+        if i < len(order):
+            ctxs[i & 1].scan_submit(bufs[order[i]].data_ptr(), len(datas[order[i]]), tabs[i & 1].data_ptr(), 60000, flags=fl)
+        rc, res = ctxs[(i - 1) & 1].scan_wait()
+        want, end, status, off = wants[order[i - 1]]
+        assert rc == 0 and int(res.n_records) == len(want) and int(res.end_state) == end and int(res.end_offset) == off
+        assert (tabs[(i - 1) & 1][:len(want)].cpu().numpy() == want).all()
+        assert res.ms_index > 0
+    ctx2.close()
