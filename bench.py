@@ -387,6 +387,15 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     if decode:
         shard.verify_decode(table, out, qual, qoff)
 
+    # what this box's memory system delivers to a pure streaming read of the same buffer in the scan
+    # kernel's launch geometry (16 B per lane, non-temporal), right behind the timed region: boxes of
+    # the pool differ, and a throttled one shows here first
+    probe_gbs = None
+    if rank == 0 and world == 1:
+        nprobe = min(shard.n_own_bytes, 2 * GIB) & ~((1 << 14) - 1)
+        if nprobe >= (1 << 14):
+            probe_gbs = nprobe / (ctx.read_probe(shard.ext.data_ptr(), nprobe, 6, 10) * 1e-3) / 1e9
+
     line = None
     if rank == 0:
         step_s = elapsed / args.steps
@@ -451,6 +460,9 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 "avg_launch_ms": round(t_dom * 1e3, 4),
                 "launch_ms_spread": spread(ms_decode if decode else ms_index),
             },
+            "hbm_read_probe": None if probe_gbs is None else {
+                "value": round(probe_gbs, 1), "unit": "GB/s", "frac_of_peak": round(probe_gbs / HBM_PEAK_GBS, 4),
+                "what": "pure non-temporal 16 B/lane read of the same resident buffer (k_read_probe), this box, this run"},
             "path_roofline": {
                 "what": "all kernels of one step over the wall-clock step, SURVEY.md 8(d) bytes (record bytes + 48 B row%s)"
                         % (" + decoded bytes + 8 B CSR offset" if decode else ""),
@@ -537,7 +549,7 @@ def main():
             ctx_o.close()
             torch.cuda.empty_cache()
             others[other] = {k: ol[k] for k in ("value", "unit", "m_reads_per_s", "ms_per_step", "ms_per_step_spread",
-                                                 "settle_steps", "config", "roofline", "path_roofline")}
+                                                 "settle_steps", "config", "roofline", "hbm_read_probe", "path_roofline")}
         line["other_workloads"] = others
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -33,7 +33,29 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+ENTRIES_SRC = os.path.join(CSRC, "ffq_entries.c")
+ENTRIES_LIB = os.path.join(CSRC, "_ffq_entries.so")
+
+
+def build_entries(force=False, verbose=False):
+    """The batched default entryfunc (csrc/ffq_entries.c, CPython C API): host glue of the iterator,
+    compiled with the C compiler against this interpreter's headers."""
+    import sysconfig
+    if not force and os.path.exists(ENTRIES_LIB) and os.path.getmtime(ENTRIES_LIB) >= os.path.getmtime(ENTRIES_SRC):
+        return ENTRIES_LIB
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        raise RuntimeError("no C compiler: _ffq_entries.so cannot be built")
+    cmd = [cc, "-O2", "-std=c99", "-Wall", "-Wextra", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"],
+           "-o", ENTRIES_LIB, ENTRIES_SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return ENTRIES_LIB
+
+
 def build(force=False, verbose=False):
+    build_entries(force, verbose)
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",

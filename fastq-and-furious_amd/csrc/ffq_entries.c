@@ -1,0 +1,81 @@
+/* ffq_entries.c -- the default entryfunc of readfastq_iter, applied to a whole offset table.
+ *
+ * The reference builds one entry per scanner call,
+ *     entryfunc(buf, pos, globaloffset) = (buf[pos[0]+1:pos[1]], buf[pos[2]:pos[3]], buf[pos[4]:pos[5]])
+ * (/root/reference/src/fastqandfurious.py:161-171), in the interpreter.  Here the scanner hands back
+ * the table of a whole buffer fill; this module cuts the three slices of every row in one call and
+ * returns the list of tuples the iterator then yields from.  Host glue only (CPython C API, as the
+ * reference's own extension is): nothing of the scan runs here, and readfastq_iter falls back to
+ * the same slices in Python when the module is not built.
+ *
+ *     entries(buf, rows, shift=0, hskip=1) -> [(header, sequence, quality), ...]
+ *
+ * buf    any C-contiguous buffer of bytes (bytes, memoryview, the pinned fill of the stream front end)
+ * rows   C-contiguous buffer of int64, six per record (the table of ffq_scan_*)
+ * shift  subtracted from every position first (rows in stream coordinates, buf one fill of it)
+ * hskip  the header slice starts at pos[0] + hskip: 1 drops the '@' as entryfunc does; 0 keeps it, as
+ *        the reference's index replay does (/root/reference/src/demo/benchmark.py:62-71)
+ *
+ * Slices follow Python's rules (negative positions count from the end, bounds are clamped, an
+ * inverted range is empty), so the result equals the Python expression above for ANY row.
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+
+static PyObject *cut(const char *base, Py_ssize_t len, int64_t a, int64_t b)
+{
+    Py_ssize_t start = (Py_ssize_t)a, stop = (Py_ssize_t)b;
+    const Py_ssize_t n = PySlice_AdjustIndices(len, &start, &stop, 1);
+    return PyBytes_FromStringAndSize(base + start, n);
+}
+
+static PyObject *entries(PyObject *self, PyObject *args)
+{
+    Py_buffer buf, rows;
+    long long shift = 0, hskip = 1;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "y*y*|LL", &buf, &rows, &shift, &hskip)) return NULL;
+    PyObject *list = NULL;
+    if (rows.len % 48 != 0 || (rows.itemsize != 8 && rows.itemsize != 1)) {
+        PyErr_SetString(PyExc_ValueError, "rows must hold six int64 positions per record");
+        goto done;
+    }
+    {
+        const Py_ssize_t n = rows.len / 48;
+        const int64_t *p = (const int64_t *)rows.buf;
+        const char *base = (const char *)buf.buf;
+        list = PyList_New(n);
+        if (!list) goto done;
+        for (Py_ssize_t i = 0; i < n; i++, p += 6) {
+            PyObject *h = cut(base, buf.len, p[0] - shift + hskip, p[1] - shift);
+            PyObject *s = cut(base, buf.len, p[2] - shift, p[3] - shift);
+            PyObject *q = cut(base, buf.len, p[4] - shift, p[5] - shift);
+            PyObject *t = (h && s && q) ? PyTuple_New(3) : NULL;
+            if (!t) {
+                Py_XDECREF(h); Py_XDECREF(s); Py_XDECREF(q);
+                Py_CLEAR(list);
+                goto done;
+            }
+            PyTuple_SET_ITEM(t, 0, h);
+            PyTuple_SET_ITEM(t, 1, s);
+            PyTuple_SET_ITEM(t, 2, q);
+            PyList_SET_ITEM(list, i, t);
+        }
+    }
+done:
+    PyBuffer_Release(&buf);
+    PyBuffer_Release(&rows);
+    return list;
+}
+
+static PyMethodDef methods[] = {
+    {"entries", entries, METH_VARARGS,
+     "entries(buf, rows, shift=0, hskip=1) -> list of (header, sequence, quality) bytes tuples, one per row of six int64 positions"},
+    {NULL, NULL, 0, NULL}};
+
+static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_ffq_entries",
+                                    "entry tuples of a whole offset table (default entryfunc, batched)", -1, methods,
+                                    NULL, NULL, NULL, NULL};
+
+PyMODINIT_FUNC PyInit__ffq_entries(void) { return PyModule_Create(&moddef); }

@@ -27,6 +27,8 @@ import importlib
 import os
 import typing
 
+from . import entries as _entries
+
 CHAR_AT: int = ord(b'@')
 CHAR_PLUS: int = ord(b'+')
 CHAR_NEWLINE: int = ord(b'\n')
@@ -164,6 +166,20 @@ def _raise_for_end(end_state: int, where: int):
     raise RuntimeError('unknown end state %r' % (end_state,))
 
 
+_ENTRY_CHUNK = 1024     # rows per native call: the tuples of one chunk are consumed (and their memory
+                        # reused) before the next is built -- a whole fill at once is 3 x slower
+
+
+def _default_entries(buf, rows, shift):
+    """The default entryfunc (:161-171) over a table: (header, sequence, quality) of every row of
+    `rows` (C-contiguous int64, six per record; positions minus `shift` index `buf`)."""
+    cut = _entries.native().entries
+    mv = memoryview(rows).cast('B')
+    step = 48 * _ENTRY_CHUNK
+    for at in range(0, len(mv), step):
+        yield from cut(buf, mv[at:at + step], shift)
+
+
 def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
     """readfastq_iter with a batched scanner: one scan per buffer fill.
 
@@ -178,7 +194,9 @@ def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
     buf = b'\n' + buf
     while True:
         rows, end_state, end_offset = scan_buffer(buf, offset, eof)
-        if entryfunc is _ENTRYFUNC:
+        if entryfunc is _ENTRYFUNC and _entries.native() is not None:
+            yield from _default_entries(buf, rows, 0)
+        elif entryfunc is _ENTRYFUNC:
             it = iter(rows)                      # the default entryfunc inlined (see _iter_stream)
             for p0, p1, p2, p3, p4, p5 in zip(it, it, it, it, it, it):
                 yield (buf[p0 + 1:p1], buf[p2:p3], buf[p4:p5])
@@ -204,7 +222,12 @@ def _iter_stream(st, entryfunc):
     exactly what the reference's loop passes to entryfunc (:252-255), globaloffset included."""
     try:
         for rows, fill, fill_offset, end_state, err_offset in st:
-            if rows.shape[0]:
+            if rows.shape[0] and entryfunc is _ENTRYFUNC and _entries.native() is not None:
+                # the default entryfunc over the whole table, natively (csrc/ffq_entries.c): the slices
+                # are cut straight out of the stream's own (pinned) fill -- no bytes copy of the fill,
+                # no posbuffer and no interpreter loop per record
+                yield from _default_entries(fill, rows, fill_offset)
+            elif rows.shape[0]:
                 buf = fill.tobytes()
                 rel = array('q')
                 rel.frombytes((rows - fill_offset).tobytes())

@@ -15,6 +15,7 @@ from array import array
 
 import numpy as np
 
+from . import entries as _entries
 from . import fastqandfurious as _F
 
 ROW_BYTES = 48          # 6 x int64 per record
@@ -140,6 +141,13 @@ def iter_indexed(fh, fh_index, chunk_records=1 << 16):
         hi = int(t[:, 5].max())
         fh.seek(lo)
         buf = fh.read(hi - lo + 1)
+        if _entries.native() is not None:
+            # arrayadd_q(posarray, -offset) and the three slices of every row, natively
+            # (csrc/ffq_entries.c; a thousand rows per call so that consumed tuples are reused)
+            t = np.ascontiguousarray(t)
+            for at in range(0, t.shape[0], 1024):
+                yield from _entries.entries(buf, t[at:at + 1024], lo, 0)
+            continue
         rel = (t - lo).tolist()                 # arrayadd_q(posarray, -offset), whole chunk
         for p0, p1, p2, p3, p4, p5 in rel:
             yield (buf[p0:p1], buf[p2:p3], buf[p4:p5])

@@ -1,0 +1,94 @@
+"""The batched default entryfunc (csrc/ffq_entries.c) against the reference's expression
+    (buf[pos[0]+1:pos[1]], buf[pos[2]:pos[3]], buf[pos[4]:pos[5]])      fastqandfurious.py:161-171
+on the golden tuples captured from the reference, on arbitrary rows (Python's slice rules), and
+through both batched iterators.  CPU only: host glue."""
+import io
+from array import array
+
+import numpy as np
+import pytest
+
+from conftest import golden_file
+
+FILES = ("test.fq", "test_longqualityheader.fq", "test_multiline.fq")
+
+
+@pytest.fixture(scope="module")
+def E(pkg):
+    from fastqandfurious_amd import build, entries
+    build.build_entries()
+    assert entries.native() is not None, "csrc/_ffq_entries.so did not build / load"
+    return entries
+
+
+def slices(buf, rows):
+    return [(buf[r[0] + 1:r[1]], buf[r[2]:r[3]], buf[r[4]:r[5]]) for r in rows]
+
+
+@pytest.mark.parametrize("fn", FILES)
+def test_native_entries_equal_reference_tuples(E, golden, oracle, fn):
+    data = golden_file(fn)
+    buf = b"\n" + data
+    want, *_ = oracle.scan(data, add=0)            # buffer coordinates (the sentinel is byte 0)
+    got = E.entries(buf, np.ascontiguousarray(want))
+    ref = [tuple(bytes.fromhex(x) for x in t) for t in golden["files"][fn]["tuples"]]      # captured from the reference
+    assert got == ref == slices(buf, want.tolist())
+    assert E.entries_python(buf, array("q", want.reshape(-1).tolist())) == ref
+
+
+def test_any_row_follows_python_slicing(E):
+    rng = np.random.default_rng(5)
+    buf = bytes(rng.integers(0, 256, size=300, dtype=np.uint8))
+    rows = rng.integers(-400, 400, size=(5000, 6), dtype=np.int64)
+    rows[:50] = rng.integers(-2**62, 2**62, size=(50, 6), dtype=np.int64)
+    want = slices(buf, rows.tolist())
+    assert E.entries(buf, rows) == want
+    # every kind of buffer, and stream coordinates with a shift
+    assert E.entries(memoryview(buf), rows) == want
+    assert E.entries(np.frombuffer(buf, dtype=np.uint8), rows) == want
+    assert E.entries(bytearray(buf), array("q", rows.reshape(-1).tolist())) == want
+    small = rows[50:]
+    assert E.entries(buf, small + 12345, 12345) == slices(buf, small.tolist())
+    # hskip = 0: the header slice keeps the '@' (index replay, benchmark.py:62-71)
+    assert E.entries(buf, small, 0, 0) == [(buf[r[0]:r[1]], buf[r[2]:r[3]], buf[r[4]:r[5]]) for r in small.tolist()]
+    assert E.entries_python(buf, array("q", small.reshape(-1).tolist()), 0, 0) == E.entries(buf, small, 0, 0)
+    assert E.entries(buf, np.zeros((0, 6), dtype=np.int64)) == []
+    with pytest.raises(ValueError):
+        E.entries(buf, np.zeros(7, dtype=np.int64))
+    with pytest.raises(TypeError):
+        E.entries("text", rows)
+
+
+def test_iterators_use_the_native_entries_and_agree_with_python(E, oracle, pkg, monkeypatch):
+    """More rows than one native call takes (_ENTRY_CHUNK), through the batched iterator, with and
+    without the compiled module."""
+    from fastqandfurious_amd import fastqandfurious as F, synth
+    data = synth.single(0, 5000, seed=3).tobytes()
+
+    class Scanner:
+        def __call__(self, *a):
+            raise AssertionError("per-record protocol not expected")
+
+        def scan_buffer(self, buf, offset, eof):
+            table, end, st, off = oracle.scan(buf, sentinel=False, offset=offset, eof=eof, add=0)
+            rows = array("q")
+            rows.frombytes(np.ascontiguousarray(table).tobytes())
+            return rows, int(end), int(off)
+
+    calls = []
+    real = E.native().entries
+
+    class Spy:
+        @staticmethod
+        def entries(buf, rows, shift=0):
+            calls.append(len(rows) // 48)
+            return real(buf, rows, shift)
+
+    monkeypatch.setattr(E, "_native", Spy)
+    got = list(F.readfastq_iter(io.BytesIO(data), 200000, entrypos=Scanner()))
+    assert calls and max(calls) <= F._ENTRY_CHUNK and sum(calls) == 5000
+    monkeypatch.setattr(E, "_native", None)
+    plain = list(F.readfastq_iter(io.BytesIO(data), 200000, entrypos=Scanner()))
+    assert got == plain and len(got) == 5000
+    ref = list(F.readfastq_iter(io.BytesIO(data), 200000))          # the pure-Python scanner, per record
+    assert got == ref
