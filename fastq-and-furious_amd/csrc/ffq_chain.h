@@ -336,7 +336,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
 {
     constexpr int NMAX = PER * 64;
     constexpr int ND = DOUBLING ? NMAX : 1;
-    __shared__ uint32_t went_all[WPB][EMAX];
+    __shared__ uint32_t went_all[WPB][EMAX + 4];     // (+4: a lane's words past the last entry, see the window loop)
     __shared__ uint16_t nidx_all[WPB][NMAX];   // node -> window entry index of its "\n@"
     __shared__ uint16_t nx16_all[WPB][NMAX];   // node -> successor node / SN_*
     __shared__ uint32_t pk_all[WPB][NMAX];     // node -> run end | successor of the run end << 16
@@ -460,18 +460,31 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                 id = (uint32_t)ncomp + incl - nc;
                 ncomp += (int)__shfl((int)incl, 63);
             }
+            // One test per lane, no branch per entry: a lane whose first entry exists writes all four
+            // window words (what lies past the tile's count -- at most three words, never a node -- is
+            // overwritten by the next tile's entries, written later, or lies past nwin, within the
+            // padding of the array, and is never read); the nodes among them, one in seven entries on
+            // wrapped reads, are registered by a loop over the set bits.
+            const int j0 = p * 256 + 4 * lane;
+            if (j0 < c) {
+                uint32_t *wdst = went + tb[k] + j0;
+                uint32_t idc = id;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int j = p * 256 + 4 * lane + i;
-                if (j < c) {
-                    uint32_t nid = NO_NODE;
-                    if ((isn >> i) & 1u) {
-                        if (id < (uint32_t)(NMAX - 1)) {
-                            nid = id; nidx[id] = (uint16_t)(tb[k] + j); npos[id] = relb + (x[i] & OFF_MASK);
-                        }
-                        id++;
-                    }
-                    went[tb[k] + j] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | (nid << WN_SHIFT);
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t bit = (isn >> i) & 1u;
+                    wdst[i] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | ((bit ? idc : NO_NODE) << WN_SHIFT);
+                    idc += bit;
+                }
+                uint32_t mrem = isn;
+                while (mrem) {
+                    const int i = __ffs((int)mrem) - 1;
+                    mrem &= mrem - 1u;
+                    const uint32_t half = (i & 2) ? ev[k][p].y : ev[k][p].x;
+                    const uint32_t off = ((i & 1) ? (half >> 16) : half) & OFF_MASK;
+                    const uint32_t idw = min(id, (uint32_t)(NMAX - 1));     // (NMAX - 1 is reserved: such a group is given up below)
+                    nidx[idw] = (uint16_t)(tb[k] + j0 + i);
+                    npos[idw] = relb + off;
+                    id++;
                 }
             }
         }
