@@ -1515,7 +1515,7 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         if (rc) return rc;
     }
     const LineIndex L = make_index(c, a, ntiles);
-    if (mode == 7) {
+    if (mode == 7 || mode >= 100) {
         // the index kernel with a decoupled look-back over the tile counts riding along (a probe:
         // what a single-pass design would pay for its prefix sums on this part)
         int rc = reserve_tiles(c, ntiles);
@@ -1526,7 +1526,7 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         for (int r = 0; r < reps + 2; r++) {
             HIPCHK(hipMemsetAsync(c->ovf, 0, (size_t)ntiles * 8, c->stream));
             HIPCHK(hipEventRecord(c->ev[0], c->stream));
-            launch_scan_lines(c, c->stream, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', 8);
+            launch_scan_lines(c, c->stream, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', mode == 7 ? 8 : mode);
             HIPCHK(hipEventRecord(c->ev[1], c->stream));
             HIPCHK(hipEventSynchronize(c->ev[1]));
             float ms = 0;
@@ -1535,15 +1535,26 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         }
         *ms_avg = sum / reps;
         std::vector<uint32_t> hc((size_t)ntiles);
-        unsigned long long last = 0, mid = 0;
         HIPCHK(hipMemcpy(hc.data(), c->cnt, (size_t)ntiles * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&last, c->ovf + (ntiles - 1), 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&mid, c->ovf + ntiles / 2, 8, hipMemcpyDeviceToHost));
-        unsigned long long tot = 0, totm = 0;
-        for (int64_t t = 0; t < ntiles; t++) { tot += hc[(size_t)t]; if (t <= ntiles / 2) totm += hc[(size_t)t]; }
-        const unsigned long long VM = (1ull << 62) - 1ull;
-        if ((last & VM) != tot || (mid & VM) != totm || (last >> 62) != 2)
-            return fail(FFQ_E_INTERNAL, "look-back probe: prefix %llu / %llu, expected %llu / %llu", (last & VM), (mid & VM), tot, totm);
+        std::vector<unsigned long long> hd((size_t)ntiles);
+        HIPCHK(hipMemcpy(hd.data(), c->ovf, (size_t)ntiles * 8, hipMemcpyDeviceToHost));
+        const int variant = mode >= 100 ? ((mode - 100) >> 5) & 7 : 0;
+        if (mode >= 100) {
+            // rounds / retries of the look-backs, as the inclusive descriptors carry them
+            const int64_t nd = variant == 3 ? ntiles >> 2 : ntiles;
+            double rounds = 0, retries = 0;
+            for (int64_t t = 1; t < nd; t++) { rounds += (double)((hd[(size_t)t] >> 40) & 0xFF); retries += (double)((hd[(size_t)t] >> 48) & 0x3FFF); }
+            fprintf(stderr, "[ffq probe] mode %d: %.2f rounds, %.2f retries per look-back\n", mode, rounds / std::max<int64_t>(nd - 1, 1),
+                    retries / std::max<int64_t>(nd - 1, 1));
+        }
+        if (variant == 0 || variant == 4) {
+            const unsigned long long VM = mode >= 100 ? (1ull << 40) - 1ull : (1ull << 62) - 1ull;
+            unsigned long long tot = 0, totm = 0;
+            for (int64_t t = 0; t < ntiles; t++) { tot += hc[(size_t)t]; if (t <= ntiles / 2) totm += hc[(size_t)t]; }
+            const unsigned long long last = hd[(size_t)(ntiles - 1)], mid = hd[(size_t)(ntiles / 2)];
+            if ((last & VM) != tot || (mid & VM) != totm || (last >> 62) != 2)
+                return fail(FFQ_E_INTERNAL, "look-back probe: prefix %llu / %llu, expected %llu / %llu", (last & VM), (mid & VM), tot, totm);
+        }
         HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         return FFQ_OK;

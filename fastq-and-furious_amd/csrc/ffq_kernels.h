@@ -155,6 +155,71 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
             if (l == 0) __hip_atomic_store(desc + tile, (2ull << 62) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (ablate >= 100) {
+        // PROBE (ffq_read_probe modes 100 + K + 16 * barrier + 32 * variant; tools/lookback_probe.py): the
+        // same look-back with a window of 64 * K descriptors per round trip (lane l reads the descriptors
+        // at distance l + 64 k, K loads in flight), optionally with the other waves waiting behind a barrier.
+        // variant 1: the two stores only; 2: stores + ONE window load, nothing waited for; 3: only every 4th
+        // tile takes part (descriptor tile >> 2: the traffic of 64 KiB super-tiles); 4: longer sleeps between
+        // polls; 6: variant 2 with plain cached loads; 7: variant 2 with sc0 loads (coherent in this XCD's L2
+        // only).  The inclusive descriptor carries the rounds (bits 40..47) and retries (48..61) of its look-back.
+        const int K = (ablate - 100) & 15, variant = ((ablate - 100) >> 5) & 7;
+        const bool part = variant != 3 || (tile & 3) == 3;
+        if (w == 0 && part) {
+            unsigned long long *desc = ovf;
+            const int64_t me = variant == 3 ? (tile >> 2) : tile;
+            const unsigned long long VM = (1ull << 40) - 1ull;
+            const bool waits = variant == 0 || variant == 3 || variant == 4;
+            if (me == 0) {
+                if (l == 0) __hip_atomic_store(desc, (2ull << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (l == 0) __hip_atomic_store(desc + me, (1ull << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long excl = 0, rounds = 0, retries = 0;
+                int64_t pos = me - 1;
+                if (variant != 1)
+                for (;;) {
+                    unsigned long long vv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int64_t idx = pos - l - 64 * k;
+                        if (variant == 6) vv[k] = (k < K && idx >= 0) ? desc[idx] : 0ull;
+                        else if (variant == 7) {
+                            unsigned long long x = 0;
+                            if (k < K && idx >= 0) asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(desc + idx) : "memory");
+                            vv[k] = x;
+                        }
+                        else vv[k] = (k < K) ? (idx >= 0 ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62)) : 0ull;
+                    }
+                    rounds++;
+                    unsigned long long add = 0;
+                    bool retry = false, done = false;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (k < K && !retry && !done) {
+                            const int fl = (int)(vv[k] >> 62);
+                            const unsigned long long inv = __ballot(fl == 0), inc = __ballot(fl == 2);
+                            const int first_inc = inc ? __ffsll((long long)inc) - 1 : 64;
+                            const int first_inv = inv ? __ffsll((long long)inv) - 1 : 64;
+                            if (first_inv < first_inc && waits) retry = true;
+                            else {
+                                const unsigned long long val = (l <= first_inc) ? (vv[k] & VM) : 0ull;
+                                add += (unsigned long long)(uint32_t)__shfl((int)wave_incl_scan((uint32_t)(val & 0xFFFFFu)), 63) +
+                                       ((unsigned long long)(uint32_t)__shfl((int)wave_incl_scan((uint32_t)(val >> 20)), 63) << 20);
+                                if (first_inc < 64) done = true;
+                            }
+                        }
+                    }
+                    if (retry) { retries++; if (variant == 4) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1); continue; }
+                    excl += add;
+                    if (done || !waits) break;
+                    pos -= 64 * K;
+                }
+                if (l == 0) __hip_atomic_store(desc + me, (2ull << 62) | ((excl + total) & VM) | (min(rounds, 255ull) << 40) | (min(retries, 16383ull) << 48),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if ((ablate - 100) & 16) __syncthreads();
+    }
     const bool dense = total > (uint32_t)SLOT;
     if (dense) {   // rare: avg line shorter than 16 bytes over the whole tile
         if (tid == 0) {
