@@ -468,13 +468,15 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             const int j0 = p * 256 + 4 * lane;
             if (j0 < c) {
                 uint32_t *wdst = went + tb[k] + j0;
-                uint32_t idc = id;
+                // every word as "not a node" first: offset and flags moved into place with a shift, a
+                // bit-field insert and a mask; the window base and the node field come in one add
+                const uint32_t wconst = relb + (NO_NODE << WN_SHIFT);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint32_t bit = (isn >> i) & 1u;
-                    wdst[i] = (relb + (x[i] & OFF_MASK)) | ((x[i] >> 14) << WF_SHIFT) | ((bit ? idc : NO_NODE) << WN_SHIFT);
-                    idc += bit;
+                    const uint32_t f = (((x[i] << 4) & ~OFF_MASK) | (x[i] & OFF_MASK)) & ((3u << WF_SHIFT) | OFF_MASK);
+                    wdst[i] = wconst + f;        // (relb + offset stays below 2^18: no carry into the flags)
                 }
+                // the nodes among them (a "\n@" match: AT set, PLUS clear) get their word again, with the id
                 uint32_t mrem = isn;
                 while (mrem) {
                     const int i = __ffs((int)mrem) - 1;
@@ -484,6 +486,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                     const uint32_t idw = min(id, (uint32_t)(NMAX - 1));     // (NMAX - 1 is reserved: such a group is given up below)
                     nidx[idw] = (uint16_t)(tb[k] + j0 + i);
                     npos[idw] = relb + off;
+                    wdst[i] = (relb + off) | ((uint32_t)FL_AT << WF_SHIFT) | (idw << WN_SHIFT);
                     id++;
                 }
             }
