@@ -275,7 +275,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
         t_done.append(time.perf_counter())
 
     extra_ctx = []
-    if world == 1 and not args.sharded_step:
+    if world == 1 and not args.sharded_step and not args.lanes_step:
         # Single range: steps are submitted through two contexts that share their HIP streams,
         # one step ahead (ffq_scan_submit / ffq_scan_wait): while the host waits for step i the
         # kernels of step i+1 are already queued behind it.  Every step is a full scan of the
@@ -324,7 +324,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
         elapsed = time.perf_counter() - t0
         table = tables[(args.steps - 1) & 1]
         qual, qoff = quals[(args.steps - 1) & 1], qoffs[(args.steps - 1) & 1]
-    elif world == 1:
+    elif world == 1 and not args.lanes_step:
         def step():
             return shard.scan(table, flags=flags, qual=qual, qoff=qoff)
 
@@ -494,6 +494,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--sharded-step", action="store_true",
                     help="N=1 through the synchronous step the N>1 ranks run (diagnostics)")
+    ap.add_argument("--lanes-step", action="store_true",
+                    help="N=1 through the pipelined step of the N>1 ranks (two lanes, hand-off with no peers): "
+                         "what the host side of a sharded step costs (diagnostics)")
     args = ap.parse_args()
 
     import torch
@@ -538,7 +541,7 @@ def main():
             line["cpu_baseline"] = None
     # N = 1, default workload: BASELINE configs[2] and [3] timed the same way, under their own key
     # (`value` stays configs[1]'s)
-    if world == 1 and args.workload == "single-1g" and not args.no_others and not args.sharded_step:
+    if world == 1 and args.workload == "single-1g" and not args.no_others and not args.sharded_step and not args.lanes_step:
         del shard
         torch.cuda.empty_cache()
         others = {}
