@@ -81,7 +81,7 @@ struct ChainBufs {
     int64_t *rloc;       // [ng] exclusive prefix of cnt inside the resolve block
     int64_t *qloc;       // [ng] same for qb
     int64_t *part;       // [nblk][4] block totals (cnt, qb, lines, -) -> exclusive prefixes
-    int32_t *mins;       // [2] first terminating group, first bad group
+    int32_t *mins;       // [4] first terminating group, first bad group, number of bad groups (from the fill value 0x7F7F7F7F up)
     int64_t *force;      // [ng] repair pass: the "\n@" the chain enters the group with (FORCE_NONE: leave alone)
     unsigned long long *prof;   // optional: per-phase cycle sums of k_chain_wave (diagnostics)
     int32_t nmax;
@@ -95,7 +95,8 @@ struct DevRes {
     int32_t has_final;
     int32_t bad_group;   // first group whose guess was not confirmed (fallback only; 0x7F7F7F7F: none)
     int32_t bad_irregular;   // that group does not fit this configuration's LDS budget (vs a wrong guess)
-    int32_t pad2;
+    int32_t n_bad;       // groups whose guess was not confirmed (or that did not fit), all of them
+    int64_t approx_records;   // records the groups counted, confirmed or not (how long the records are, roughly)
 };
 
 // Result hand-over.  The last result-writing kernel of a scan copies the result block and the
@@ -1000,11 +1001,11 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
 __global__ __launch_bounds__(RES_BLOCK) void k_resolve_a(ChainBufs B)
 {
     __shared__ long long s_c[RES_BLOCK], s_q[RES_BLOCK];
-    __shared__ int s_term, s_bad;
+    __shared__ int s_term, s_bad, s_nbad;
     __shared__ unsigned long long s_lines;
     const int tid = threadIdx.x;
     const int g = blockIdx.x * RES_BLOCK + tid;
-    if (tid == 0) { s_term = 0x7FFFFFFF; s_bad = 0x7FFFFFFF; s_lines = 0; }
+    if (tid == 0) { s_term = 0x7FFFFFFF; s_bad = 0x7FFFFFFF; s_nbad = 0; s_lines = 0; }
     __syncthreads();
     long long c = 0, q = 0;
     if (g < B.ng) {
@@ -1016,7 +1017,7 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve_a(ChainBufs B)
             const int64_t pe = B.exit[g - 1];
             if (pe >= 0 && y != pe) bad = true;
         }
-        if (bad) atomicMin(&s_bad, g);
+        if (bad) { atomicMin(&s_bad, g); atomicAdd(&s_nbad, 1); }
         atomicAdd(&s_lines, (unsigned long long)B.lines[g]);
     }
     s_c[tid] = c; s_q[tid] = q;
@@ -1037,6 +1038,7 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve_a(ChainBufs B)
         B.part[blockIdx.x * 4 + 2] = (long long)s_lines;
         if (s_term != 0x7FFFFFFF) atomicMin(&B.mins[0], s_term);
         if (s_bad != 0x7FFFFFFF) atomicMin(&B.mins[1], s_bad);
+        if (s_nbad) atomicAdd(reinterpret_cast<unsigned int *>(&B.mins[2]), (unsigned int)s_nbad);     // (counts up from the fill value)
     }
 }
 
@@ -1089,6 +1091,8 @@ __global__ __launch_bounds__(1024) void k_resolve_b(ChainBufs B, int nblk, int e
         res->n_lines = carry_l;
         res->fallback = fallback ? 1 : 0;
         res->bad_group = tbad;
+        res->n_bad = (int32_t)((unsigned int)B.mins[2] - 0x7F7F7F7Fu);
+        res->approx_records = carry_c;
         res->bad_irregular = (tbad >= 0 && tbad < B.ng && (B.flags[tbad] & 5u)) ? 1 : 0;
         res->term_group = fallback ? -1 : tterm;
         res->end_offset = offset;

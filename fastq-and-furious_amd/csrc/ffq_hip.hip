@@ -914,6 +914,12 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             for (int round = 0; round < 16 && c->h_res->fallback && c->h_res->bad_group > prev_bad &&
                                 c->h_res->bad_group < st.ngroups; round++) {
                 if (!no_ranked && round >= 2 && !c->h_res->bad_irregular) break;
+                // a guess in eight did not stand and the records are long (2.5 KB and more on average:
+                // wrapped reads from ~1.2 kb): repair passes would mend them a pass at a time; list ranking
+                // needs no guess and, at one wave per "\n@" match, costs less than two such passes there
+                // (tools/shape_sweep_wrapped.py: 1.5-3 kb reads 0.75-0.46 -> TB/s figures in DESIGN.md)
+                if (!no_ranked && !c->h_res->bad_irregular && (int64_t)c->h_res->n_bad * 8 > (int64_t)st.ngroups &&
+                    c->h_res->approx_records * 2560 < a.n_bytes) break;
                 if (round >= 4 && !c->h_res->bad_irregular &&
                     c->h_res->bad_group - first_bad < round * std::max(st.ngroups / 64, 1)) break;
                 prev_bad = c->h_res->bad_group;
