@@ -121,56 +121,6 @@ __device__ __forceinline__ void publish(const Pub &pb, const DevRes *res)
     if (pb.h_seq) __hip_atomic_store(pb.h_seq, pb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// window accessor: flat LDS index while inside the window, global index beyond
-struct WH {
-    int32_t idx;     // >= 0: window entry; -1: use g; -2: before the window's first entry
-    H g;
-};
-struct WAcc {
-    typedef WH Hd;
-    const LineIndex &L;
-    const uint32_t *went;
-    int32_t nwin;
-    int32_t wt1;          // first tile after the window
-    int64_t wpos0;        // buffer coordinate of window-relative position 0
-    uint32_t *defer;      // group flag word: bit 2 is set when a lookup needs index tiles that
-                          // are not computed yet (the scan kernel runs chunk by chunk ahead of us)
-    int32_t ready;        // index tiles [0, ready) are valid
-    __device__ WAcc(const LineIndex &l, const uint32_t *we, int32_t nw, int32_t t1, int64_t p0, uint32_t *df,
-                    int32_t rdy)
-        : L(l), went(we), nwin(nw), wt1(t1), wpos0(p0), defer(df), ready(rdy) {}
-    __device__ bool next(Hd &h) const {
-        if (h.idx != -1) {
-            const int32_t j = (h.idx == -2) ? 0 : h.idx + 1;
-            if (j < nwin) { h.idx = j; return true; }
-            h.idx = -1;
-            h.g = H{wt1 - 1, 0x7FFFFFF0};     // "after the last entry of tile wt1-1"
-        }
-        if (h.g.tile >= 0 && h.g.i != 0x7FFFFFF0 && h.g.i + 1 < (int32_t)L.cnt[h.g.tile]) {
-            h.g.i++;
-            return true;
-        }
-        int32_t t = h.g.tile + 1;
-        if (t < 0) t = 0;
-        while (t < ready && L.cnt[t] == 0) t++;
-        if (t >= ready) {
-            if (ready < L.ntiles && defer) atomicOr(defer, 4u);
-            return false;
-        }
-        h.g.tile = t; h.g.i = 0;
-        return true;
-    }
-    __device__ void get(const Hd &h, int64_t &P, int &fl) const {
-        if (h.idx >= 0) {
-            const uint32_t e = went[h.idx];
-            P = wpos0 + (int64_t)(e & WP_MASK);
-            fl = (int)((e >> WF_SHIFT) & 3u);
-            return;
-        }
-        GAcc(L).get(h.g, P, fl);
-    }
-};
-
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
 #pragma unroll
@@ -246,84 +196,30 @@ __device__ __forceinline__ int count_below(const unsigned long long (&m)[PER], i
     return n;
 }
 
-// ---- the generic (entry by entry) scanner call of a window node, out of line --------------
-// The fast path of k_chain_wave covers records whose lines all lie within the next 12
-// index entries; everything else (long wrapped records, window / buffer edges, records
-// that continue beyond the window) goes through these two functions.  They are kept
-// out of line on purpose: inlined at every use they made the kernel ~100 KB of code.
-// Everything is passed and returned BY VALUE (registers): a struct whose address is taken
-// in the kernel lives in per-lane scratch memory, which cost ~160 B of HBM writes per lane.
-// Lg points to a copy of the LineIndex in global memory for the same reason.
-struct NodeOut {
-    uint32_t st, nxn, sx, f0, f1, f3, f4, ext;
-};
 struct FollowOut {
     Rec r;
     int64_t after;
 };
 
-__device__ __noinline__ NodeOut node_generic(const LineIndex *Lg, const uint32_t *went, int nwin, int wt1,
-                                             int own_hi, int eof, int ready, int64_t wpos0, int64_t len,
-                                             uint32_t *defer, int k)
+// ---- the generic scanner call of a window node, by the WHOLE WAVE (wave-uniform arguments) ---------
+// The fast path of k_chain_wave covers records whose lines all lie within the next entries of the
+// window; everything else (long wrapped records, window / buffer edges, records that continue beyond
+// the window) comes here, one node at a time: the scanner call of the node whose "\n@" is index
+// entry `hk` at coordinate Pk, and the candidate the chain continues with, through the wave-wide
+// searches of the walkers (wv_find / wv_record, ffq_dev.h) -- a handful of memory round trips
+// whatever the record's length.  (Until round 2 every lane walked its own node entry by entry:
+// 13 k dependent loads, 20 ms, for ONE wrapped 1 MB record in a buffer of short reads; tools/cliffs.py.)
+// Out of line on purpose (code size); the LineIndex through a pointer to its copy in global memory.
+__device__ __noinline__ FollowOut node_wave(const LineIndex *Lg, H hk, int64_t Pk, int eof)
 {
-    const WAcc acc(*Lg, went, nwin, wt1, wpos0, defer, ready);
-    WH hk; hk.idx = k; hk.g = H{0, 0};
-    WH hm, hm1;
-    Rec r;
-    compute_record(acc, hk, wpos0 + (int64_t)(went[k] & WP_MASK), len, eof, r, hm, hm1);
-    NodeOut o;
-    o.st = (uint32_t)(r.final_ ? ST_FINAL : r.status);
-    o.nxn = 0xFFFDu; o.sx = 0; o.f0 = o.f1 = o.f3 = o.f4 = 0; o.ext = 0;
-    if ((r.status == ST_COMPLETE) || r.final_) {
-        const int64_t q0 = r.p0 - wpos0, q1 = r.p1 - wpos0, q3 = r.p3 - wpos0, q4 = r.p4 - wpos0;
-        if (q4 > 0xFFFFFFF0ll) o.ext = 1;
-        o.f0 = (uint32_t)q0; o.f1 = (uint32_t)q1; o.f3 = (uint32_t)q3; o.f4 = (uint32_t)q4;
-    }
-    if (r.status == ST_COMPLETE) {
-        WH hs; int64_t Ps;
-        if (find_cand(acc, hm1, r.p5 - 1, hs, Ps)) {
-            if (hs.idx >= 0) {
-                const uint32_t wj = went[hs.idx];
-                const uint32_t nid = (wj >> WN_SHIFT) & WN_MASK;
-                if (hs.idx < own_hi && nid != NO_NODE) o.nxn = nid;
-                else { o.nxn = 0xFFFCu; o.sx = wj & WP_MASK; }
-            } else o.nxn = 0xFFFFu;
-        } else o.nxn = 0xFFFEu;
-    }
-    return o;
-}
-
-// the scanner call of node k again (all of it: posbuffer, status) and the candidate the
-// chain continues with after it (Y_NOCAND if none) -- used once per group at most
-__device__ __noinline__ FollowOut node_followup(const LineIndex *Lg, const uint32_t *went, int nwin, int wt1,
-                                                int eof, int ready, int64_t wpos0, int64_t len,
-                                                uint32_t *defer, int k)
-{
-    const WAcc acc(*Lg, went, nwin, wt1, wpos0, defer, ready);
-    WH hk; hk.idx = k; hk.g = H{0, 0};
-    WH hm, hm1, hs;
-    int64_t Ps;
     FollowOut f;
-    compute_record(acc, hk, wpos0 + (int64_t)(went[k] & WP_MASK), len, eof, f.r, hm, hm1);
+    H hm1, hs;
+    int64_t Ps;
+    int fls;
+    wv_record(*Lg, hk, Pk, Lg->len(), eof, f.r, hm1);
     f.after = Y_NOCAND;
-    if (f.r.status == ST_COMPLETE && find_cand(acc, hm1, f.r.p5 - 1, hs, Ps)) f.after = Ps;
+    if (f.r.status == ST_COMPLETE && wv_find(*Lg, hm1, FL_AT, f.r.p5 - 1, hs, Ps, fls)) f.after = Ps;
     return f;
-}
-
-// first "\n@" match at >= X among the window/global entries after window index `from`
-__device__ __noinline__ int64_t cand_after(const LineIndex *Lg, const uint32_t *went, int nwin, int wt1,
-                                           int ready, int64_t wpos0, uint32_t *defer, int from, int64_t X)
-{
-    const WAcc acc(*Lg, went, nwin, wt1, wpos0, defer, ready);
-    WH hb; hb.g = H{0, 0};
-    hb.idx = from;
-    // entries of the tiles in front of the one X falls into lie in front of X: a group far in
-    // front of the search offset of the scan goes straight there (entry by entry, every such
-    // group walked the index up to the offset: minutes for an offset GiB into a buffer)
-    const int64_t tX = (X - Lg->s) >> TILE_SHIFT;
-    if (tX >= (int64_t)wt1) { hb.idx = -1; hb.g = H{(int32_t)min(tX, (int64_t)0x7FFFFFF0) - 1, 0x7FFFFFF0}; }
-    WH hs; int64_t Ps;
-    return find_cand(acc, hb, X, hs, Ps) ? Ps : Y_NOCAND;
 }
 
 // PER: node slots per lane (NMAX = 64*PER nodes per group); EMAX: window entries;
@@ -555,8 +451,6 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
 
     if (prof) ts[3] = clock64();
     // ---- one scanner call + successor search per node (node c = u*64 + lane) -------------
-    uint32_t *const defer = B.flags + g;
-    const int ready = L.ready;
     // per node ONE register: successor (16 bits) | status (5 bits, biased by 1) << 16 |
     // mi << 21 (batch index of the "\n+" entry) | sj << 25 (batch index of the successor) |
     // fast << 29 (set: fields are re-read from the window when the record is staged)
@@ -706,17 +600,52 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     }
     // nodes the fast path could not finish (long wrapped records, window / buffer edges)
     if (prof) { const uint32_t np = wave_sum_u32((uint32_t)__popc(pend)); if (lane == 0) atomicAdd(&B.prof[7], (unsigned long long)np | ((unsigned long long)wave_max_u32((uint32_t)__popc(pend)) << 32)); }
-    while (__ballot(pend != 0u)) {
-        if (pend) {
-            const int u = __ffs((int)pend) - 1;
-            pend &= pend - 1u;
-            const NodeOut o = node_generic(Lg, went, nwin, wt1, own_hi, eof, ready, wpos0, len, defer,
-                                           nidx[u * 64 + lane]);
-            const uint32_t v = o.nxn | ((o.st + 1u) << 16) | (o.ext ? (1u << 30) : 0u);
+    // (one node at a time, by the whole wave: node_wave)
+    const int64_t own_end_pos = ((int64_t)own1 << TILE_SHIFT) + L.s;      // first coordinate past the own tiles
+    const int64_t win_end_pos = ((int64_t)wt1 << TILE_SHIFT) + L.s;       //                   past the window
+    auto node_handle = [&](int k) -> H {          // window entry index -> handle in the global index
+        if (sent && k == 0) return H{-1, 0};
+        int kk = 0;
 #pragma unroll
-            for (int q = 0; q < PER; q++) if (q == u) info[q] = v;
+        for (int q = 1; q < NTW; q++) if (k >= tb[q]) kk = q;
+        return H{wt0 + kk, k - tb[kk]};
+    };
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        unsigned long long pm = __ballot((pend >> u) & 1u);
+        while (pm) {
+            const int ln = __ffsll((long long)pm) - 1;
+            pm &= pm - 1ull;
+            const int c = u * 64 + ln;
+            const int k = nidx[c];
+            const int64_t Pk = wpos0 + (int64_t)(went[k] & WP_MASK);
+            const FollowOut f = node_wave(Lg, node_handle(k), Pk, eof);
+            uint32_t nxn = SN_STOP, ext = 0;
+            if ((f.r.status == ST_COMPLETE || f.r.final_) && f.r.p4 - wpos0 > 0xFFFFFFF0ll) ext = 1;
+            if (f.r.status == ST_COMPLETE) {
+                if (f.after == Y_NOCAND) nxn = SN_NOCAND;
+                else if (f.after >= win_end_pos) nxn = SN_OUT;
+                else {
+                    // inside the window: a node if it lies in front of the own tiles' end (every "\n@"
+                    // there at or behind the offset is one), else a candidate of the look-ahead tile
+                    nxn = SN_AHEAD;
+                    if (f.after < own_end_pos) {
+                        const uint32_t rel = (uint32_t)(f.after - wpos0);
+#pragma unroll
+                        for (int q = 0; q < PER; q++) {
+                            const int cq = q * 64 + lane;
+                            const unsigned long long hit = __ballot(cq < ncomp && npos[cq] == rel);
+                            if (hit) nxn = (uint32_t)(q * 64 + (__ffsll((long long)hit) - 1));
+                        }
+                    }
+                }
+            }
+            const uint32_t st = (uint32_t)(f.r.final_ ? ST_FINAL : f.r.status);
+            const uint32_t v = nxn | ((st + 1u) << 16) | (ext ? (1u << 30) : 0u);
+            if (lane == ln) info[u] = v;
         }
     }
+    pend = 0;
     if (ablate == 3) { if (lane == 0) B.lines[g] = lines + info[0]; return; }
     int e_forced = -1;
     if (fpos != FORCE_NONE) {
@@ -875,30 +804,43 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     tr.p0 = tr.p1 = tr.p3 = tr.p4 = tr.p5 = -1; tr.status = 0; tr.final_ = false;
     if (!unresolved) {
         if (ncomp == 0) {
+            // no candidate in the run-in tail / own tiles: the chain passes over this group.  The next
+            // "\n@" behind the own tiles by the whole wave, 64 index entries per step (a lane walking
+            // entry by entry took 20 ms over the 13 k lines of one wrapped 1 MB record; tools/cliffs.py)
+            H hs; int64_t Ps; int fls;
+            const bool found = wv_find(L, H{own1 - 1, 0x7FFFFFF0}, FL_AT, offset, hs, Ps, fls);
             if (lane == 0) {
-                // no candidate in the run-in tail / own tiles: the chain passes over this group
-                Y = cand_after(Lg, went, nwin, wt1, ready, wpos0, defer, (own_hi > 0) ? own_hi - 1 : -2, offset);
+                Y = found ? Ps : Y_NOCAND;
                 EX = Y;
-                if (Y == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
+                if (!found) { have_term = true; tstatus = ST_HEAD_BEG; }
             }
         } else {
             const uint32_t li = read_node<PER>(info, lastn);
             const int st = (int)((li >> 16) & 31u) - 1;
             const uint32_t nx = li & 0xFFFFu;
+            // what the chain does behind its last node of this group: known from the node word, or the
+            // node's call once more by the whole wave (its successor lies beyond the window, the chain
+            // stops there and the posbuffer of that call is wanted, or it is a generic node)
+            const bool from_word = st == ST_COMPLETE &&
+                                   (nx == SN_NOCAND || (nx == SN_AHEAD && (li >> 29 & 1u) && !(li >> 31) && ((li >> 25) & 15u) != 15u));
+            FollowOut fo;
+            fo.after = Y_NOCAND;
+            fo.r = tr;
+            if (!from_word) {
+                const int kl = nidx[lastn];
+                fo = node_wave(Lg, node_handle(kl), wpos0 + (int64_t)(went[kl] & WP_MASK), eof);
+            }
             if (lane == 0) {
                 if (st == ST_COMPLETE) {
                     int64_t after;
                     if (nx == SN_NOCAND) after = Y_NOCAND;
-                    else if (nx == SN_AHEAD && (li >> 29 & 1u) && !(li >> 31) && ((li >> 25) & 15u) != 15u)
-                        after = wpos0 + (int64_t)(went[nidx[lastn] + ((li >> 25) & 15u)] & WP_MASK);
-                    else {   // beyond the window (or a generic node): through the global index
-                        after = node_followup(Lg, went, nwin, wt1, eof, ready, wpos0, len, defer, nidx[lastn]).after;
-                    }
+                    else if (from_word) after = wpos0 + (int64_t)(went[nidx[lastn] + ((li >> 25) & 15u)] & WP_MASK);
+                    else after = fo.after;
                     EX = after;
                     if (after == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
                 } else {
                     // the chain stops at lastn: keep the scanner's posbuffer of that call
-                    tr = node_followup(Lg, went, nwin, wt1, eof, ready, wpos0, len, defer, nidx[lastn]).r;
+                    tr = fo.r;
                     EX = (st == ST_FINAL) ? X_END_FINAL : X_END_TERM;
                     have_term = true; tstatus = tr.status;
                 }
@@ -946,18 +888,25 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             stg[rank] = o;
             qsum += (unsigned long long)(o.p3 - o.p1 - 1);
         }
-        while (__ballot(pend != 0u)) {
-            if (pend) {
-                const int u = __ffs((int)pend) - 1;
-                pend &= pend - 1u;
-                const int c = u * 64 + lane;
-                const NodeOut no = node_generic(Lg, went, nwin, wt1, own_hi, eof, ready, wpos0, len, defer, nidx[c]);
-                StageRec o;
-                o.p0 = no.f0; o.p1 = no.f1; o.p3 = no.f3; o.p4 = no.f4;
-                stg[count_below<PER>(MB, c) - d0] = o;
-                qsum += (unsigned long long)(o.p3 - o.p1 - 1);
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            unsigned long long pm = __ballot((pend >> u) & 1u);
+            while (pm) {
+                const int ln = __ffsll((long long)pm) - 1;
+                pm &= pm - 1ull;
+                const int c = u * 64 + ln;
+                const int k = nidx[c];
+                const FollowOut f = node_wave(Lg, node_handle(k), wpos0 + (int64_t)(went[k] & WP_MASK), eof);
+                if (lane == ln) {
+                    StageRec o;
+                    o.p0 = (uint32_t)(f.r.p0 - wpos0); o.p1 = (uint32_t)(f.r.p1 - wpos0);
+                    o.p3 = (uint32_t)(f.r.p3 - wpos0); o.p4 = (uint32_t)(f.r.p4 - wpos0);
+                    stg[count_below<PER>(MB, c) - d0] = o;
+                    qsum += (unsigned long long)(o.p3 - o.p1 - 1);
+                }
             }
         }
+        pend = 0;
     }
     const uint32_t qlo = wave_sum_u32((uint32_t)(qsum & 0xFFFFFu)), qhi = wave_sum_u32((uint32_t)(qsum >> 20));
     const bool anybad = __ballot(bad_range) != 0ull;

@@ -98,72 +98,101 @@ struct GAcc {
     }
 };
 
-// One scanner call, restated over the line index.
+// One scanner call over the line index (wv_record below): the posbuffer fields, the status, and
+// whether the final-record rule of the iterator (fastqandfurious.py:259-266) accepted it at eof.
 //   /root/reference/src/_fastqandfurious.c:25-153  (C extension entrypos)
-// k = handle of the "\n@" newline (P = its buffer coordinate).  The final-
-// record rule of the iterator (fastqandfurious.py:259-266) is applied here
-// when eof is set: status 5 with qualend < len becomes `final`.
 struct Rec {
     int64_t p0, p1, p3, p4, p5;
     int32_t status;
     bool final_;
 };
 
-template <class A>
-__device__ void compute_record(const A &a, typename A::Hd k, int64_t Pk, int64_t len, int eof,
-                               Rec &r, typename A::Hd &hm, typename A::Hd &hm1)
+// ---- wave-wide search over the global index ---------------------------------
+// The chain is sequential, but each of its searches is not: the wave looks at 64 index entries (or
+// 64 tile counts) per step and jumps straight to the tile a position bound falls into.
+// first entry after `from` whose flags meet `mask` (0: any entry) at buffer coordinate >= minP;
+// wave-uniform arguments and result
+__device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &out, int64_t &Pout, int &flout)
 {
+    const int lane = threadIdx.x & 63;
+    int t, i;
+    if (from.tile == -2) {
+        if (L.s) {
+            const uint8_t b = L.n > 0 ? L.d[0] : 0;
+            const int fl = (b == '@') ? FL_AT : (b == '+') ? FL_PLUS : 0;
+            if ((mask == 0 || (fl & mask)) && 0 >= minP) { out = H{-1, 0}; Pout = 0; flout = fl; return true; }
+        }
+        t = 0; i = 0;
+    } else if (from.tile == -1) { t = 0; i = 0; }
+    else { t = from.tile; i = from.i + 1; }
+    // entries of the tiles in front of the one minP falls into lie in front of minP
+    const int64_t tmin = (minP - L.s) >> TILE_SHIFT;
+    if (tmin > (int64_t)t) { t = (int)min(tmin, (int64_t)L.ready); i = 0; }
+    while (t < L.ready) {
+        const uint32_t c = L.cnt[t];
+        for (uint32_t j0 = (uint32_t)i; j0 < c; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            bool ok = false;
+            int64_t P = 0;
+            uint32_t e = 0;
+            if (j < c) {
+                e = (c <= (uint32_t)SLOT) ? (uint32_t)L.ent[(int64_t)t * SLOT + j] : L.pooled(t, j);
+                P = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
+                ok = (mask == 0 || ((int)(e >> 14) & mask)) && P >= minP;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (m) {
+                const int w = __ffsll((long long)m) - 1;
+                out = H{t, (int32_t)(j0 + w)};
+                Pout = ((int64_t)__shfl((int)(P >> 32), w) << 32) | (uint32_t)__shfl((int)(uint32_t)P, w);
+                flout = __shfl((int)(e >> 14), w);
+                return true;
+            }
+        }
+        // next non-empty tile, 64 counts at a time
+        t++; i = 0;
+        while (t < L.ready) {
+            const uint32_t cl = (t + lane < L.ready) ? L.cnt[t + lane] : 1u;
+            const unsigned long long m = __ballot(cl != 0u);
+            if (m) { t += __ffsll((long long)m) - 1; break; }
+            t += 64;
+        }
+    }
+    return false;
+}
+
+
+// compute_record (ffq_dev.h) with the wave's searches: same rules, same order
+__device__ void wv_record(const LineIndex &L, H k, int64_t Pk, int64_t len, int eof, Rec &r, H &hm1)
+{
+    const int64_t NONE = -(1ll << 62);
     r.p0 = Pk + 1; r.p1 = r.p3 = r.p4 = r.p5 = -1; r.final_ = false;
-    hm = k; hm1 = k;
+    hm1 = k;
     int64_t P; int fl;
-    typename A::Hd j = k;
-    // header end: memchr(pos0+1, '\n', len-(pos0+1)-1) -- last byte excluded (:70-71)
-    if (!a.next(j)) { r.status = ST_HEAD_END; return; }
-    a.get(j, P, fl);
+    H j = k;
+    if (!wv_find(L, j, 0, NONE, j, P, fl)) { r.status = ST_HEAD_END; return; }          // :70-71
     if (P > len - 2) { r.status = ST_HEAD_END; return; }
     r.p1 = P;
     const int64_t p2 = P + 1;
-    // sequence end: memmem(pos2+1, "\n+") (:87-88)
-    for (;;) {
-        if (!a.next(j)) { r.status = ST_SEQ_END; return; }
-        a.get(j, P, fl);
-        if ((fl & FL_PLUS) && P >= p2 + 1) break;
-    }
-    r.p3 = P; hm = j;
+    if (!wv_find(L, j, FL_PLUS, p2 + 1, j, P, fl)) { r.status = ST_SEQ_END; return; }   // :87-88
+    r.p3 = P;
     if (P + 2 >= len) { r.status = ST_QUALHEAD_END; return; }
-    // '+' line end: memchr(se+2, '\n', len-(se+2)-1) (:102-103)
-    if (!a.next(j)) { r.status = ST_QUALHEAD_END; return; }
-    a.get(j, P, fl);
+    if (!wv_find(L, j, 0, NONE, j, P, fl)) { r.status = ST_QUALHEAD_END; return; }      // :102-103
     if (P > len - 2) { r.status = ST_QUALHEAD_END; return; }
     hm1 = j;
     const int64_t qhe = P, se = r.p3, he = r.p1;
-    // '+' line LENGTH rule (:109-117)
-    if ((qhe - se - 1 > 1) && (qhe - se != he - r.p0 + 1)) { r.status = ST_INVALID; return; }
+    if ((qhe - se - 1 > 1) && (qhe - se != he - r.p0 + 1)) { r.status = ST_INVALID; return; }   // :109-117
     r.p4 = qhe + 1;
-    const int64_t qe = r.p4 + se - he - 1;     // (:129)
-    if (qe + 2 >= len) {                       // (:130-133)
+    const int64_t qe = r.p4 + se - he - 1;                                               // :129
+    if (qe + 2 >= len) {                                                                 // :130-133
         r.status = ST_QUAL_END;
-        if (eof && qe < len) { r.p5 = qe; r.final_ = true; }   // fastqandfurious.py:259-266
+        if (eof && qe < len) { r.p5 = qe; r.final_ = true; }                             // fastqandfurious.py:259-266
         return;
     }
     r.p5 = qe;
     r.status = ST_COMPLETE;
 }
 
-// first "\n@" match at buffer coordinate >= X among the entries AFTER `from`
-// (memmem(blob+offset, "\n@"), _fastqandfurious.c:62).
-template <class A>
-__device__ bool find_cand(const A &a, typename A::Hd from, int64_t X, typename A::Hd &out,
-                          int64_t &Pout)
-{
-    typename A::Hd j = from;
-    int64_t P; int fl;
-    while (a.next(j)) {
-        a.get(j, P, fl);
-        if ((fl & FL_AT) && P >= X) { out = j; Pout = P; return true; }
-    }
-    return false;
-}
 
 // ---- wave64 helpers -------------------------------------------------------
 // inclusive prefix sum over the 64 lanes: six v_add_u32 with the DPP shift ON the add (row

@@ -319,88 +319,8 @@ namespace ffq {
 // bound falls into, so a record costs a handful of memory round trips whatever its length
 // (a single lane walking entry by entry paid one per line: 0.3 GB/s on long wrapped records).
 // =========================================================================
-// first entry after `from` whose flags meet `mask` (0: any entry) at buffer coordinate >= minP;
-// wave-uniform arguments and result
-__device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &out, int64_t &Pout, int &flout)
-{
-    const int lane = threadIdx.x & 63;
-    int t, i;
-    if (from.tile == -2) {
-        if (L.s) {
-            const uint8_t b = L.n > 0 ? L.d[0] : 0;
-            const int fl = (b == '@') ? FL_AT : (b == '+') ? FL_PLUS : 0;
-            if ((mask == 0 || (fl & mask)) && 0 >= minP) { out = H{-1, 0}; Pout = 0; flout = fl; return true; }
-        }
-        t = 0; i = 0;
-    } else if (from.tile == -1) { t = 0; i = 0; }
-    else { t = from.tile; i = from.i + 1; }
-    // entries of the tiles in front of the one minP falls into lie in front of minP
-    const int64_t tmin = (minP - L.s) >> TILE_SHIFT;
-    if (tmin > (int64_t)t) { t = (int)min(tmin, (int64_t)L.ready); i = 0; }
-    while (t < L.ready) {
-        const uint32_t c = L.cnt[t];
-        for (uint32_t j0 = (uint32_t)i; j0 < c; j0 += 64) {
-            const uint32_t j = j0 + lane;
-            bool ok = false;
-            int64_t P = 0;
-            uint32_t e = 0;
-            if (j < c) {
-                e = (c <= (uint32_t)SLOT) ? (uint32_t)L.ent[(int64_t)t * SLOT + j] : L.pooled(t, j);
-                P = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
-                ok = (mask == 0 || ((int)(e >> 14) & mask)) && P >= minP;
-            }
-            const unsigned long long m = __ballot(ok);
-            if (m) {
-                const int w = __ffsll((long long)m) - 1;
-                out = H{t, (int32_t)(j0 + w)};
-                Pout = ((int64_t)__shfl((int)(P >> 32), w) << 32) | (uint32_t)__shfl((int)(uint32_t)P, w);
-                flout = __shfl((int)(e >> 14), w);
-                return true;
-            }
-        }
-        // next non-empty tile, 64 counts at a time
-        t++; i = 0;
-        while (t < L.ready) {
-            const uint32_t cl = (t + lane < L.ready) ? L.cnt[t + lane] : 1u;
-            const unsigned long long m = __ballot(cl != 0u);
-            if (m) { t += __ffsll((long long)m) - 1; break; }
-            t += 64;
-        }
-    }
-    return false;
-}
-
-// compute_record (ffq_dev.h) with the wave's searches: same rules, same order
-__device__ void wv_record(const LineIndex &L, H k, int64_t Pk, int64_t len, int eof, Rec &r, H &hm1)
-{
-    const int64_t NONE = -(1ll << 62);
-    r.p0 = Pk + 1; r.p1 = r.p3 = r.p4 = r.p5 = -1; r.final_ = false;
-    hm1 = k;
-    int64_t P; int fl;
-    H j = k;
-    if (!wv_find(L, j, 0, NONE, j, P, fl)) { r.status = ST_HEAD_END; return; }          // :70-71
-    if (P > len - 2) { r.status = ST_HEAD_END; return; }
-    r.p1 = P;
-    const int64_t p2 = P + 1;
-    if (!wv_find(L, j, FL_PLUS, p2 + 1, j, P, fl)) { r.status = ST_SEQ_END; return; }   // :87-88
-    r.p3 = P;
-    if (P + 2 >= len) { r.status = ST_QUALHEAD_END; return; }
-    if (!wv_find(L, j, 0, NONE, j, P, fl)) { r.status = ST_QUALHEAD_END; return; }      // :102-103
-    if (P > len - 2) { r.status = ST_QUALHEAD_END; return; }
-    hm1 = j;
-    const int64_t qhe = P, se = r.p3, he = r.p1;
-    if ((qhe - se - 1 > 1) && (qhe - se != he - r.p0 + 1)) { r.status = ST_INVALID; return; }   // :109-117
-    r.p4 = qhe + 1;
-    const int64_t qe = r.p4 + se - he - 1;                                               // :129
-    if (qe + 2 >= len) {                                                                 // :130-133
-        r.status = ST_QUAL_END;
-        if (eof && qe < len) { r.p5 = qe; r.final_ = true; }                             // fastqandfurious.py:259-266
-        return;
-    }
-    r.p5 = qe;
-    r.status = ST_COMPLETE;
-}
-
+// (wv_find, the wave-wide search over the global index, lives in ffq_dev.h: the group kernel uses it too)
+// (wv_record, the scanner call with the wave's searches, lives in ffq_dev.h beside wv_find)
 __global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset, int eof, int64_t add,
                                                      int64_t *__restrict__ table, int64_t table_cap,
                                                      int64_t *__restrict__ qoff, int64_t *__restrict__ qdir,
