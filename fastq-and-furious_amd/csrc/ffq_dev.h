@@ -130,6 +130,10 @@ __device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &o
     if (tmin > (int64_t)t) { t = (int)min(tmin, (int64_t)L.ready); i = 0; }
     while (t < L.ready) {
         const uint32_t c = L.cnt[t];
+        // (dense tile searched for a flag, after a step without a hit: see below)
+        const bool wide = mask != 0 && c > (uint32_t)SLOT;
+        const unsigned long long at0 = wide ? L.ovf[t] : 0ull;
+        const uint32_t fm = ((uint32_t)mask << 14) * 0x00010001u;           // the flag bits of both halves of a dword
         for (uint32_t j0 = (uint32_t)i; j0 < c; j0 += 64) {
             const uint32_t j = j0 + lane;
             bool ok = false;
@@ -148,6 +152,19 @@ __device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &o
                 flout = __shfl((int)(e >> 14), w);
                 return true;
             }
+            if (wide) {
+                // 64 entries of a dense tile without the flag: from here on 512 pooled entries per step
+                // (eight per lane, one 16-byte load), stepping over the stretches where no entry carries
+                // it -- a block of blank lines is nothing else; the step that holds a flagged entry goes
+                // back to the exact one above.  (2 MB of blank lines at the end of a buffer: 14 -> 2 ms;
+                // short records, found within the first step, do not come here; tools/cliffs.py)
+                while (j0 + 64u + 512u <= c && at0 + j0 + 64u + 512u <= L.pool_cap) {
+                    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(2)));
+                    const u32x4u v = *reinterpret_cast<const u32x4u *>(L.pool + at0 + j0 + 64u + 8u * (uint32_t)lane);
+                    if (__ballot(((v.x | v.y | v.z | v.w) & fm) != 0u)) break;
+                    j0 += 512u;
+                }
+            }
         }
         // next non-empty tile, 64 counts at a time
         t++; i = 0;
@@ -161,8 +178,7 @@ __device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &o
     return false;
 }
 
-
-// compute_record (ffq_dev.h) with the wave's searches: same rules, same order
+// the scanner call (/root/reference/src/_fastqandfurious.c:25-153) with the wave's searches: same rules, same order
 __device__ void wv_record(const LineIndex &L, H k, int64_t Pk, int64_t len, int eof, Rec &r, H &hm1)
 {
     const int64_t NONE = -(1ll << 62);
