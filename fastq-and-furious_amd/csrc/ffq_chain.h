@@ -12,7 +12,8 @@
 //   2. makes every "\n@" match of the run-in tail and the own tiles a NODE and
 //      computes that node's scanner call and successor (thread per node: the entries
 //      after the candidate read independently, the successor from the positions of
-//      the next three nodes; an entry-by-entry walk only for what does not fit);
+//      the next three nodes; what does not fit goes, one node at a time, through the walkers'
+//      wave-wide searches: node_wave);
 //   3. follows the successor links from the window's earliest node: a chain is a
 //      union of runs of consecutive nodes joined by jumps, walked run by run with
 //      one LDS read per run (pointer doubling in the dense configuration);
