@@ -39,6 +39,7 @@ tests); LocalTransport runs k logical ranks as threads of one process (k ranges
 of one resident buffer on one GPU).
 """
 import contextlib
+import os
 import threading
 
 import numpy as np
@@ -188,6 +189,7 @@ class HipBackend:
         self.ctx = ctx
         self.post = post_ctx or ctx     # context (stream) the small table queries run on
         self._xstream = None
+        self._comm = None               # stream of the overlapped hand-offs (comm_context)
 
     def scan(self, ext, n_bytes, sentinel, offset, eof, add, table, flags=0, qual=None, qoff=None,
              table_cap=None):
@@ -224,6 +226,25 @@ class HipBackend:
         if self._xstream is None:
             self._xstream = torch.cuda.ExternalStream(self.ctx.stream(), device=ext.device)
         return torch.cuda.stream(self._xstream)
+
+    @contextlib.contextmanager
+    def comm_context(self, ext):
+        """torch work on `ext` on a stream of its own, the scan stream made to wait for its end: a
+        hand-off whose buffers no scan in flight touches (a step's own [tail | own | head] buffer)
+        then runs beside the previous step's scan instead of behind it.  The caller vouches for that."""
+        if not ext.is_cuda:
+            yield
+            return
+        import torch
+        if self._xstream is None:
+            self._xstream = torch.cuda.ExternalStream(self.ctx.stream(), device=ext.device)
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=ext.device)
+        with torch.cuda.stream(self._comm):
+            yield
+            done = torch.cuda.Event()
+            done.record(self._comm)
+        self._xstream.wait_event(done)
 
 
 class ScanOutput:
@@ -292,9 +313,10 @@ class ShardScanner:
         return halo_sizes(self.bounds, self.rank, self.tail_bytes, self.head_bytes)
 
     # ---- step 1 -------------------------------------------------------------------------------
-    def _serve(self, plan, ext, tail, dst_ext=None, dst_start=None):
+    def _serve(self, plan, ext, tail, dst_ext=None, dst_start=None, overlap=False):
         """One collective exchange: this rank provides its own bytes out of `ext` and receives what
-        the plan sends it into dst_ext (stream offset dst_start at index 0)."""
+        the plan sends it into dst_ext (stream offset dst_start at index 0).  overlap: on the
+        backend's hand-off stream instead of the scan stream (see HipBackend.comm_context)."""
         own_lo = self.lo
         if dst_ext is None:
             dst_ext, dst_start = ext, own_lo - tail
@@ -305,14 +327,17 @@ class ShardScanner:
         def accept(a, b):
             return dst_ext[a - dst_start:b - dst_start]
 
-        with self.backend.stream_context(ext):
+        comm = getattr(self.backend, "comm_context", None) if overlap else None
+        with (comm(ext) if comm is not None else self.backend.stream_context(ext)):
             self.tr.exchange(plan, provide, accept)
 
-    def exchange_halo(self, ext, tail, head):
-        """Fill ext[:tail] and ext[tail + n_own:tail + n_own + head] from the ranks that own those bytes."""
+    def exchange_halo(self, ext, tail, head, overlap=False):
+        """Fill ext[:tail] and ext[tail + n_own:tail + n_own + head] from the ranks that own those bytes.
+        overlap=True: beside whatever the scan stream is doing -- only for a buffer no scan in flight
+        reads (bench.py's pipelined steps give every lane its own)."""
         assert (tail, head) == self.halo()
         if self.world > 1:
-            self._serve(halo_plan(self.bounds, self.tail_bytes, self.head_bytes), ext, tail)
+            self._serve(halo_plan(self.bounds, self.tail_bytes, self.head_bytes), ext, tail, overlap=overlap)
 
     # ---- steps 2-3: one local scan and what it says about the two edges -------------------------
     def _local(self, v, table, flags, qual, qoff, start=None, first=None):
@@ -542,11 +567,17 @@ class SyntheticShard:
             lanes.append(ShardScanner(HipBackend(c, post), self.transport, self.bounds))
         self._lanes = lanes
         self._post = post
+        # With peers every lane gets a [tail | own | head] buffer of its own, as consecutive steps of
+        # a real stream have: the hand-off of step i + 1 then writes no byte the scan of step i reads
+        # and runs beside it, on the hand-off stream (FFQ_SHARD_OVERLAP=0: behind it, on the scan stream).
+        self._overlap = self.world > 1 and os.environ.get("FFQ_SHARD_OVERLAP", "1") != "0"
+        self._exts = [self.ext] + [self.ext.clone() if self._overlap else self.ext for _ in range(n - 1)]
         return lanes
 
     def submit(self, lane, table, flags=0, qual=None, qoff=None):
-        self._lanes[lane].exchange_halo(self.ext, self.tail, self.head)
-        self._lanes[lane].submit(self.ext, self.tail, self.head, table, flags, qual, qoff)
+        ext = self._exts[lane]
+        self._lanes[lane].exchange_halo(ext, self.tail, self.head, overlap=self._overlap)
+        self._lanes[lane].submit(ext, self.tail, self.head, table, flags, qual, qoff)
 
     def finish(self, lane):
         return self._lanes[lane].finish()

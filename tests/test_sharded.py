@@ -512,6 +512,14 @@ def test_synthetic_shards_local_ranks(gpu_ctx, kind):
             sh.verify(table, out)
             sh.verify_decode(table, out, qual, qoff)
             sh.make_lanes(2)
+            # with peers every lane has a buffer of its own and its hand-off runs on the hand-off stream,
+            # beside the other lane's scan: wipe the halos, so that rows can only come out right if
+            # each lane's hand-off has landed before its scan reads them
+            assert sh._overlap and sh._exts[0].data_ptr() != sh._exts[1].data_ptr()
+            for e in sh._exts:
+                e[:sh.tail].zero_()
+                e[sh.tail + sh.n_own_bytes:].zero_()
+            torch.cuda.synchronize()
             tabs = (table, torch.empty_like(table))
             sh.submit(0, tabs[0])
             for i in range(1, 4):
