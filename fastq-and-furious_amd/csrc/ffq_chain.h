@@ -217,10 +217,18 @@ __device__ __noinline__ FollowOut node_wave(const LineIndex *Lg, H hk, int64_t P
     H hm1, hs;
     int64_t Ps;
     int fls;
-    wv_record(*Lg, hk, Pk, Lg->len(), eof, f.r, hm1);
+    wv_record_t<false>(*Lg, hk, Pk, Lg->len(), eof, f.r, hm1);
     f.after = Y_NOCAND;
-    if (f.r.status == ST_COMPLETE && wv_find(*Lg, hm1, FL_AT, f.r.p5 - 1, hs, Ps, fls)) f.after = Ps;
+    if (f.r.status == ST_COMPLETE && wv_find_t<false>(*Lg, hm1, FL_AT, f.r.p5 - 1, hs, Ps, fls)) f.after = Ps;
     return f;
+}
+
+// first "\n@" match at coordinate >= X behind tile t1 - 1, by the whole wave (Y_NOCAND: none); out of line
+// like node_wave (the search inlined into the kernel costs it registers it has no use for elsewhere)
+__device__ __noinline__ int64_t cand_after_wave(const LineIndex *Lg, int t1, int64_t X)
+{
+    H hs; int64_t Ps; int fls;
+    return wv_find_t<true>(*Lg, H{t1 - 1, 0x7FFFFFF0}, FL_AT, X, hs, Ps, fls) ? Ps : Y_NOCAND;
 }
 
 // PER: node slots per lane (NMAX = 64*PER nodes per group); EMAX: window entries;
@@ -808,12 +816,11 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             // no candidate in the run-in tail / own tiles: the chain passes over this group.  The next
             // "\n@" behind the own tiles by the whole wave, 64 index entries per step (a lane walking
             // entry by entry took 20 ms over the 13 k lines of one wrapped 1 MB record; tools/cliffs.py)
-            H hs; int64_t Ps; int fls;
-            const bool found = wv_find(L, H{own1 - 1, 0x7FFFFFF0}, FL_AT, offset, hs, Ps, fls);
+            const int64_t Ps = cand_after_wave(Lg, own1, offset);
             if (lane == 0) {
-                Y = found ? Ps : Y_NOCAND;
+                Y = Ps;
                 EX = Y;
-                if (!found) { have_term = true; tstatus = ST_HEAD_BEG; }
+                if (Ps == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
             }
         } else {
             const uint32_t li = read_node<PER>(info, lastn);

@@ -112,7 +112,11 @@ struct Rec {
 // 64 tile counts) per step and jumps straight to the tile a position bound falls into.
 // first entry after `from` whose flags meet `mask` (0: any entry) at buffer coordinate >= minP;
 // wave-uniform arguments and result
-__device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &out, int64_t &Pout, int &flout)
+// WIDE: with the 512-entry steps over unflagged stretches of dense tiles (below).  The walkers take it;
+// the group kernel's generic node path does not -- its registers bound that kernel's occupancy, and a
+// dense region is not its business (such groups go to k_group_walk).
+template <bool WIDE>
+__device__ __forceinline__ bool wv_find_t(const LineIndex &L, H from, int mask, int64_t minP, H &out, int64_t &Pout, int &flout)
 {
     const int lane = threadIdx.x & 63;
     int t, i;
@@ -131,7 +135,7 @@ __device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &o
     while (t < L.ready) {
         const uint32_t c = L.cnt[t];
         // (dense tile searched for a flag, after a step without a hit: see below)
-        const bool wide = mask != 0 && c > (uint32_t)SLOT;
+        const bool wide = WIDE && mask != 0 && c > (uint32_t)SLOT;
         const unsigned long long at0 = wide ? L.ovf[t] : 0ull;
         const uint32_t fm = ((uint32_t)mask << 14) * 0x00010001u;           // the flag bits of both halves of a dword
         for (uint32_t j0 = (uint32_t)i; j0 < c; j0 += 64) {
@@ -178,22 +182,28 @@ __device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &o
     return false;
 }
 
+__device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &out, int64_t &Pout, int &flout)
+{
+    return wv_find_t<true>(L, from, mask, minP, out, Pout, flout);
+}
+
 // the scanner call (/root/reference/src/_fastqandfurious.c:25-153) with the wave's searches: same rules, same order
-__device__ void wv_record(const LineIndex &L, H k, int64_t Pk, int64_t len, int eof, Rec &r, H &hm1)
+template <bool WIDE>
+__device__ __forceinline__ void wv_record_t(const LineIndex &L, H k, int64_t Pk, int64_t len, int eof, Rec &r, H &hm1)
 {
     const int64_t NONE = -(1ll << 62);
     r.p0 = Pk + 1; r.p1 = r.p3 = r.p4 = r.p5 = -1; r.final_ = false;
     hm1 = k;
     int64_t P; int fl;
     H j = k;
-    if (!wv_find(L, j, 0, NONE, j, P, fl)) { r.status = ST_HEAD_END; return; }          // :70-71
+    if (!wv_find_t<WIDE>(L, j, 0, NONE, j, P, fl)) { r.status = ST_HEAD_END; return; }          // :70-71
     if (P > len - 2) { r.status = ST_HEAD_END; return; }
     r.p1 = P;
     const int64_t p2 = P + 1;
-    if (!wv_find(L, j, FL_PLUS, p2 + 1, j, P, fl)) { r.status = ST_SEQ_END; return; }   // :87-88
+    if (!wv_find_t<WIDE>(L, j, FL_PLUS, p2 + 1, j, P, fl)) { r.status = ST_SEQ_END; return; }   // :87-88
     r.p3 = P;
     if (P + 2 >= len) { r.status = ST_QUALHEAD_END; return; }
-    if (!wv_find(L, j, 0, NONE, j, P, fl)) { r.status = ST_QUALHEAD_END; return; }      // :102-103
+    if (!wv_find_t<WIDE>(L, j, 0, NONE, j, P, fl)) { r.status = ST_QUALHEAD_END; return; }      // :102-103
     if (P > len - 2) { r.status = ST_QUALHEAD_END; return; }
     hm1 = j;
     const int64_t qhe = P, se = r.p3, he = r.p1;
@@ -207,6 +217,11 @@ __device__ void wv_record(const LineIndex &L, H k, int64_t Pk, int64_t len, int 
     }
     r.p5 = qe;
     r.status = ST_COMPLETE;
+}
+
+__device__ void wv_record(const LineIndex &L, H k, int64_t Pk, int64_t len, int eof, Rec &r, H &hm1)
+{
+    wv_record_t<true>(L, k, Pk, len, eof, r, hm1);
 }
 
 
