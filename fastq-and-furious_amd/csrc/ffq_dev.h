@@ -112,9 +112,10 @@ struct Rec {
 // 64 tile counts) per step and jumps straight to the tile a position bound falls into.
 // first entry after `from` whose flags meet `mask` (0: any entry) at buffer coordinate >= minP;
 // wave-uniform arguments and result
-// WIDE: with the 512-entry steps over unflagged stretches of dense tiles (below).  The walkers take it;
-// the group kernel's generic node path does not -- its registers bound that kernel's occupancy, and a
-// dense region is not its business (such groups go to k_group_walk).
+// WIDE: with the 512-entry steps over unflagged stretches of dense tiles (below).  k_group_walk -- the
+// kernel dense regions go to -- and the group kernel's search behind a group without candidates take it;
+// the others do not: inlined into the group kernel's generic node path it cost that kernel a wave of
+// occupancy (118 -> 133 VGPRs), and the list-ranking and serial tiers ran 5-7 % slower per record with it.
 template <bool WIDE>
 __device__ __forceinline__ bool wv_find_t(const LineIndex &L, H from, int mask, int64_t minP, H &out, int64_t &Pout, int &flout)
 {
@@ -184,7 +185,7 @@ __device__ __forceinline__ bool wv_find_t(const LineIndex &L, H from, int mask, 
 
 __device__ bool wv_find(const LineIndex &L, H from, int mask, int64_t minP, H &out, int64_t &Pout, int &flout)
 {
-    return wv_find_t<true>(L, from, mask, minP, out, Pout, flout);
+    return wv_find_t<false>(L, from, mask, minP, out, Pout, flout);
 }
 
 // the scanner call (/root/reference/src/_fastqandfurious.c:25-153) with the wave's searches: same rules, same order
@@ -221,7 +222,7 @@ __device__ __forceinline__ void wv_record_t(const LineIndex &L, H k, int64_t Pk,
 
 __device__ void wv_record(const LineIndex &L, H k, int64_t Pk, int64_t len, int eof, Rec &r, H &hm1)
 {
-    wv_record_t<true>(L, k, Pk, len, eof, r, hm1);
+    wv_record_t<false>(L, k, Pk, len, eof, r, hm1);
 }
 
 

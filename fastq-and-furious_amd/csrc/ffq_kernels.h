@@ -425,14 +425,14 @@ __global__ __launch_bounds__(256) void k_group_walk(LineIndex L, ChainBufs B, in
     // verification (y[g] == exit[g-1]) decides.  Records of the run-in are walked, not staged.
     const bool guess = g > 0 && fpos == FORCE_NONE;
     const int64_t X = (g == 0) ? offset : guess ? max(own_beg - RUNIN_BYTES, offset) : fpos;
-    bool have = wv_find(L, H{-2, 0}, FL_AT, X, k, Pk, flk);
+    bool have = wv_find_t<true>(L, H{-2, 0}, FL_AT, X, k, Pk, flk);
     if (g > 0 && !guess && (!have || Pk != fpos)) return;               // not a candidate: leave it to the later tiers
     for (;;) {
         if (!have) { EX = Y_NOCAND; have_term = true; r.p0 = r.p1 = r.p3 = r.p4 = r.p5 = -1; r.status = ST_HEAD_BEG; break; }
         if (Pk >= own_end) { EX = Pk; break; }
         const bool own = !guess || Pk >= own_beg;
         if (own && Y == Y_UNRES) Y = Pk;                                // first member in the own tiles
-        wv_record(L, k, Pk, len, eof, r, hm1);
+        wv_record_t<true>(L, k, Pk, len, eof, r, hm1);
         if (!own) {
             if (r.status != ST_COMPLETE) return;                        // the guessed chain ends in the run-in: no guess
         } else if (r.status == ST_COMPLETE || r.final_) {
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_group_walk(LineIndex L, ChainBufs B, in
         }
         if (r.final_) { EX = X_END_FINAL; have_term = true; break; }
         if (r.status != ST_COMPLETE) { EX = X_END_TERM; have_term = true; break; }
-        have = wv_find(L, hm1, FL_AT, r.p5 - 1, k, Pk, flk);
+        have = wv_find_t<true>(L, hm1, FL_AT, r.p5 - 1, k, Pk, flk);
     }
     if (Y == Y_UNRES) Y = EX;                                           // no member in the own tiles: the chain passes over
     if (lane != 0) return;
