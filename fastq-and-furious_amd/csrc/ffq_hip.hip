@@ -1521,6 +1521,54 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         if (rc) return rc;
     }
     const LineIndex L = make_index(c, a, ntiles);
+    if (mode >= 200 && mode < 210) {
+        // the persistent streaming loop with a lagged two-level prefix (k_pipe_probe): lag = mode - 200
+        int rc = reserve_tiles(c, ntiles);
+        if (rc) return rc;
+        rc = reserve_pool(c, 1ull << 20);
+        if (rc) return rc;
+        const int G = 1024, lag = mode - 200;
+        const int64_t niter = (ntiles + G - 1) / G;
+        PipeArgs pa{};
+        pa.d = d_buf; pa.ntiles = ntiles; pa.lag = lag;
+        HIPCHK(hipMalloc((void **)&pa.descA, (size_t)niter * G * 8));
+        HIPCHK(hipMalloc((void **)&pa.descG, (size_t)niter * (G / PP_GROUP) * 8));
+        HIPCHK(hipMalloc((void **)&pa.prefix, (size_t)niter * G * 8));
+        HIPCHK(hipMalloc((void **)&pa.err, 8));
+        // the tile counts to check the prefixes against
+        launch_scan_lines(c, c->stream, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', 0);
+        float sum = 0;
+        for (int r = 0; r < reps + 2; r++) {
+            HIPCHK(hipMemsetAsync(pa.descA, 0, (size_t)niter * G * 8, c->stream));
+            HIPCHK(hipMemsetAsync(pa.descG, 0, (size_t)niter * (G / PP_GROUP) * 8, c->stream));
+            HIPCHK(hipMemsetAsync(pa.err, 0, 8, c->stream));
+            HIPCHK(hipEventRecord(c->ev[0], c->stream));
+            hipLaunchKernelGGL(k_pipe_probe, dim3(G), dim3(256), 0, c->stream, pa, sink);
+            HIPCHK(hipEventRecord(c->ev[1], c->stream));
+            HIPCHK(hipEventSynchronize(c->ev[1]));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+            if (r >= 2) sum += ms;
+        }
+        *ms_avg = sum / reps;
+        int bad = 0;
+        uint32_t herr2[2] = {0, 0};
+        HIPCHK(hipMemcpy(herr2, pa.err, 8, hipMemcpyDeviceToHost));
+        const uint32_t herr = herr2[0];
+        if (lag) {
+            std::vector<uint32_t> hc((size_t)ntiles);
+            std::vector<long long> hp((size_t)ntiles);
+            HIPCHK(hipMemcpy(hc.data(), c->cnt, (size_t)ntiles * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(hp.data(), pa.prefix, (size_t)ntiles * 8, hipMemcpyDeviceToHost));
+            long long run = 0;
+            for (int64_t t = 0; t < ntiles; t++) { if (hp[(size_t)t] != run) bad++; run += hc[(size_t)t]; }
+        }
+        (void)hipFree(pa.descA); (void)hipFree(pa.descG); (void)hipFree(pa.prefix); (void)hipFree(pa.err);
+        HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (herr || bad) return fail(FFQ_E_INTERNAL, "pipe probe: %d wrong prefixes, poll gave up: %u", bad, herr);
+        return FFQ_OK;
+    }
     if (mode == 7 || mode >= 100) {
         // the index kernel with a decoupled look-back over the tile counts riding along (a probe:
         // what a single-pass design would pay for its prefix sums on this part)

@@ -1030,6 +1030,113 @@ __global__ __launch_bounds__(256) void k_synth_wrapped(uint8_t *__restrict__ out
 }
 
 // =========================================================================
+// k_pipe_probe (ffq_read_probe modes 200 + lag; tools/pipe_probe.py): what a single-pass design would have to
+// be built on -- PERSISTENT workgroups that keep streaming tiles (workgroup b takes tiles b, b + G, b + 2G, ...;
+// the next tile's loads are issued before this one is counted) while the prefix over all earlier tiles is
+// resolved `lag` iterations later from a two-level tree of descriptors: every workgroup publishes its
+// tile's count, the last workgroup of each group of 32 sums its group's counts one iteration later, and
+// `lag` iterations later every workgroup reads the 32 group sums and the counts of its own group in ONE
+// round trip and carries the running base itself.  Nothing is decoded: the question is what the prefix
+// costs when no tile waits for it with its loads still to come.  LDS is allocated as the real thing would
+// (four workgroups per CU).  lag 0: no prefix at all (the streaming loop alone).
+// =========================================================================
+constexpr int PP_GROUP = 32;
+struct PipeArgs {
+    const uint8_t *d;
+    int64_t ntiles;
+    unsigned long long *descA;      // [niter * G] flag << 62 | newlines of the tile
+    unsigned long long *descG;      // [niter * G / 32] flag << 62 | newlines of the group
+    long long *prefix;              // [niter * G] out: newlines in front of the tile
+    uint32_t *err;                  // set when a poll gave up
+    int lag;
+};
+
+__device__ __forceinline__ unsigned long long pp_poll(const unsigned long long *p, bool need, uint32_t *err)
+{
+    unsigned long long v = need ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1ull << 62);
+    for (int spins = 0; __ballot((v >> 62) == 0ull) != 0ull; spins++) {
+        if (spins > (1 << 18)) { if ((threadIdx.x & 63) == 0) atomicOr(err, 1u); break; }      // never hang the GPU
+        __builtin_amdgcn_s_sleep(2);
+        if ((v >> 62) == 0ull) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return v & ((1ull << 62) - 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_pipe_probe(PipeArgs a, uint32_t *__restrict__ sink)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_pad[36 * 1024];      // the residency of the real thing
+    __shared__ uint32_t s_w[2][4];
+    const int G = (int)gridDim.x, b = (int)blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int ngroups = G / PP_GROUP, g = b / PP_GROUP, bi = b % PP_GROUP;
+    const int64_t niter = (a.ntiles + G - 1) / G;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 cur[4], nxt[4];
+    auto issue = [&](u32x4 (&v)[4], int64_t t) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            v[i] = u32x4{0, 0, 0, 0};
+            if (t < a.ntiles)
+                v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.d + (t << TILE_SHIFT) + w * 4096 + i * 1024 + l * 16));
+        }
+    };
+    issue(cur, b);
+    long long base = 0;
+    uint32_t acc = 0;
+    if (tid == 0) s_pad[b & 1023] = 1;
+    const int lag = a.lag;
+    for (int64_t it = 0; it < niter + lag; it++) {
+        const int64_t T = it * G + b;
+        // the descriptor loads FIRST, the next tile's loads behind them: loads return in order, and a
+        // wait for the descriptors must not be a wait for 16 KiB of tile (with the order reversed the
+        // loop ran at half speed: one tile in flight per workgroup instead of two)
+        bool lead = a.lag && w == 0 && bi == PP_GROUP - 1 && it >= 1 && it - 1 < niter;
+        bool res = a.lag && w == 0 && it >= lag && it - lag < niter;
+        int64_t j = it - lag;
+        const bool isg = l < 32;
+        const unsigned long long *pl = a.descA + (it - 1) * G + g * PP_GROUP + (l & 31);
+        const unsigned long long *pr = isg ? a.descG + j * ngroups + min(l, ngroups - 1) : a.descA + j * G + g * PP_GROUP + (l - 32);
+        const bool needr = isg ? (l < ngroups) : (l - 32 < bi);
+        unsigned long long vl = 1ull << 62, vr = 1ull << 62;
+        if (lead && l < PP_GROUP) vl = __hip_atomic_load(pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (res && needr) vr = __hip_atomic_load(pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (it + 1 < niter) issue(nxt, T + G);
+        if (it < niter) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) c += (uint32_t)__popc(nl_mask16(make_uint4(cur[i].x, cur[i].y, cur[i].z, cur[i].w)));
+            const uint32_t ws = (uint32_t)__shfl((int)wave_incl_scan(c), 63);
+            if (l == 0) s_w[it & 1][w] = ws;
+            __syncthreads();
+            const uint32_t total = s_w[it & 1][0] + s_w[it & 1][1] + s_w[it & 1][2] + s_w[it & 1][3];
+            acc += total;
+            if (a.lag && tid == 0)
+                __hip_atomic_store(a.descA + T, (1ull << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const int64_t lit = it;
+        if (lead) {
+            // the last workgroup of a group: that group's sum of the iteration before
+            pl = a.descA + (lit - 1) * G + g * PP_GROUP + (l & 31);
+            if (__ballot((vl >> 62) == 0ull)) vl = (1ull << 62) | pp_poll(pl, l < PP_GROUP, a.err);
+            const uint32_t sum = (uint32_t)__shfl((int)wave_incl_scan(l < PP_GROUP ? (uint32_t)vl : 0u), 63);
+            if (l == 0)
+                __hip_atomic_store(a.descG + (it - 1) * ngroups + g, (1ull << 62) | (unsigned long long)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (res) {
+            // everyone: the prefix of the tile taken `lag` iterations ago
+            if (__ballot((vr >> 62) == 0ull)) vr = (1ull << 62) | pp_poll(pr, needr, a.err);
+            const uint32_t val = needr ? (uint32_t)vr : 0u;
+            const uint32_t all_g = (uint32_t)__shfl((int)wave_incl_scan(isg ? val : 0u), 63);
+            const uint32_t before = (uint32_t)__shfl((int)wave_incl_scan((isg && l < g) || !isg ? val : 0u), 63);
+            if (l == 0 && j * G + b < a.ntiles) a.prefix[j * G + b] = base + (long long)before;
+            base += (long long)all_g;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = nxt[i];
+    }
+    if (acc == 0x12345678u && s_pad[tid] == 77) sink[0] = acc;
+}
+
+// =========================================================================
 // k_read_probe: pure streaming read in the launch geometry of k_scan_lines (one 16 KiB
 // tile per 256-thread workgroup, four 16-byte loads per lane) or as a grid-stride loop.
 // The measured ceiling the scan kernel is compared with (tools/read_probe.py).
