@@ -1521,13 +1521,14 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         if (rc) return rc;
     }
     const LineIndex L = make_index(c, a, ntiles);
-    if (mode >= 200 && mode < 210) {
+    if (mode >= 200 && mode < 220) {
         // the persistent streaming loop with a lagged two-level prefix (k_pipe_probe): lag = mode - 200
         int rc = reserve_tiles(c, ntiles);
         if (rc) return rc;
         rc = reserve_pool(c, 1ull << 20);
         if (rc) return rc;
-        const int G = 1024, lag = mode - 200;
+        const bool big = mode >= 210;                  // 72 KiB of LDS per workgroup, two per CU
+        const int G = big ? 512 : 1024, lag = big ? mode - 210 : mode - 200;
         const int64_t niter = (ntiles + G - 1) / G;
         PipeArgs pa{};
         pa.d = d_buf; pa.ntiles = ntiles; pa.lag = lag;
@@ -1543,7 +1544,8 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
             HIPCHK(hipMemsetAsync(pa.descG, 0, (size_t)niter * (G / PP_GROUP) * 8, c->stream));
             HIPCHK(hipMemsetAsync(pa.err, 0, 8, c->stream));
             HIPCHK(hipEventRecord(c->ev[0], c->stream));
-            hipLaunchKernelGGL(k_pipe_probe, dim3(G), dim3(256), 0, c->stream, pa, sink);
+            if (big) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_probe<72>), dim3(G), dim3(256), 0, c->stream, pa, sink);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_probe<36>), dim3(G), dim3(256), 0, c->stream, pa, sink);
             HIPCHK(hipEventRecord(c->ev[1], c->stream));
             HIPCHK(hipEventSynchronize(c->ev[1]));
             float ms = 0;

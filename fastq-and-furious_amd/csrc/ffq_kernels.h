@@ -1062,9 +1062,11 @@ __device__ __forceinline__ unsigned long long pp_poll(const unsigned long long *
     return v & ((1ull << 62) - 1ull);
 }
 
+// KIB: LDS per workgroup (36: four workgroups per CU, 72: two); the tile is parked in one of KIB / 16 slots
+template <int KIB>
 __global__ __launch_bounds__(256) void k_pipe_probe(PipeArgs a, uint32_t *__restrict__ sink)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_pad[36 * 1024];      // the residency of the real thing
+    __shared__ __attribute__((aligned(16))) uint8_t s_pad[KIB * 1024];      // the residency of the real thing
     __shared__ uint32_t s_w[2][4];
     const int G = (int)gridDim.x, b = (int)blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int ngroups = G / PP_GROUP, g = b / PP_GROUP, bi = b % PP_GROUP;
@@ -1103,7 +1105,10 @@ __global__ __launch_bounds__(256) void k_pipe_probe(PipeArgs a, uint32_t *__rest
         if (it < niter) {
             uint32_t c = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) c += (uint32_t)__popc(nl_mask16(make_uint4(cur[i].x, cur[i].y, cur[i].z, cur[i].w)));
+            for (int i = 0; i < 4; i++) {
+                c += (uint32_t)__popc(nl_mask16(make_uint4(cur[i].x, cur[i].y, cur[i].z, cur[i].w)));
+                *reinterpret_cast<u32x4 *>(s_pad + (it % (KIB / 16)) * TILE + w * 4096 + i * 1024 + l * 16) = cur[i];      // parked, as the real thing would
+            }
             const uint32_t ws = (uint32_t)__shfl((int)wave_incl_scan(c), 63);
             if (l == 0) s_w[it & 1][w] = ws;
             __syncthreads();

@@ -15,6 +15,8 @@ for rnd in range(3):
     k3 = ctx.read_probe(buf.data_ptr(), n * 322, 3, 10)
     nt = ctx.read_probe(buf.data_ptr(), n * 322, 6, 10)
     print("round %d: index kernel alone %.1f us, pure non-temporal read %.1f us" % (rnd, k3 * 1e3, nt * 1e3), flush=True)
-    for lag in (0, 1, 2, 3, 4, 6):
-        t = ctx.read_probe(buf.data_ptr(), n * 322, 200 + lag, 10)
-        print("   persistent loop, %s: %.1f us" % ("no prefix" if lag == 0 else "prefix resolved %d iterations later" % lag, t * 1e3), flush=True)
+    for big in (0, 10):
+        for lag in (0, 1, 2, 3, 4, 6):
+            t = ctx.read_probe(buf.data_ptr(), n * 322, 200 + big + lag, 10)
+            print("   persistent loop, %s per CU, %s: %.1f us" % ("two workgroups (72 KiB of LDS)" if big else "four workgroups (36 KiB of LDS)",
+                  "no prefix" if lag == 0 else "prefix resolved %d iterations later" % lag, t * 1e3), flush=True)
