@@ -8,13 +8,15 @@
  * reference's own extension is): nothing of the scan runs here, and readfastq_iter falls back to
  * the same slices in Python when the module is not built.
  *
- *     entries(buf, rows, shift=0, hskip=1) -> [(header, sequence, quality), ...]
+ *     entries(buf, rows, shift=0, hskip=1, cls=None) -> [(header, sequence, quality), ...]
  *
  * buf    any C-contiguous buffer of bytes (bytes, memoryview, the pinned fill of the stream front end)
  * rows   C-contiguous buffer of int64, six per record (the table of ffq_scan_*)
  * shift  subtracted from every position first (rows in stream coordinates, buf one fill of it)
  * hskip  the header slice starts at pos[0] + hskip: 1 drops the '@' as entryfunc does; 0 keeps it, as
  *        the reference's index replay does (/root/reference/src/demo/benchmark.py:62-71)
+ * cls    a tuple subclass with three fields and no state of its own (the reference's `Entry`
+ *        namedtuple, entryfunc_namedtuple, :146-158): the entries are instances of it
  *
  * Slices follow Python's rules (negative positions count from the end, bounds are clamped, an
  * inverted range is empty), so the result equals the Python expression above for ANY row.
@@ -34,9 +36,19 @@ static PyObject *entries(PyObject *self, PyObject *args)
 {
     Py_buffer buf, rows;
     long long shift = 0, hskip = 1;
+    PyObject *cls = Py_None;
     (void)self;
-    if (!PyArg_ParseTuple(args, "y*y*|LL", &buf, &rows, &shift, &hskip)) return NULL;
+    if (!PyArg_ParseTuple(args, "y*y*|LLO", &buf, &rows, &shift, &hskip, &cls)) return NULL;
     PyObject *list = NULL;
+    PyTypeObject *tp = &PyTuple_Type;
+    if (cls != Py_None) {
+        if (!PyType_Check(cls) || !PyType_IsSubtype((PyTypeObject *)cls, &PyTuple_Type) ||
+            ((PyTypeObject *)cls)->tp_basicsize != PyTuple_Type.tp_basicsize || ((PyTypeObject *)cls)->tp_itemsize != PyTuple_Type.tp_itemsize) {
+            PyErr_SetString(PyExc_TypeError, "cls must be a tuple subclass without fields of its own (a namedtuple)");
+            goto done;
+        }
+        tp = (PyTypeObject *)cls;
+    }
     if (rows.len % 48 != 0 || (rows.itemsize != 8 && rows.itemsize != 1)) {
         PyErr_SetString(PyExc_ValueError, "rows must hold six int64 positions per record");
         goto done;
@@ -51,7 +63,7 @@ static PyObject *entries(PyObject *self, PyObject *args)
             PyObject *h = cut(base, buf.len, p[0] - shift + hskip, p[1] - shift);
             PyObject *s = cut(base, buf.len, p[2] - shift, p[3] - shift);
             PyObject *q = cut(base, buf.len, p[4] - shift, p[5] - shift);
-            PyObject *t = (h && s && q) ? PyTuple_New(3) : NULL;
+            PyObject *t = !(h && s && q) ? NULL : (tp == &PyTuple_Type) ? PyTuple_New(3) : tp->tp_alloc(tp, 3);
             if (!t) {
                 Py_XDECREF(h); Py_XDECREF(s); Py_XDECREF(q);
                 Py_CLEAR(list);
@@ -71,7 +83,7 @@ done:
 
 static PyMethodDef methods[] = {
     {"entries", entries, METH_VARARGS,
-     "entries(buf, rows, shift=0, hskip=1) -> list of (header, sequence, quality) bytes tuples, one per row of six int64 positions"},
+     "entries(buf, rows, shift=0, hskip=1, cls=None) -> list of (header, sequence, quality) bytes tuples, one per row of six int64 positions"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_ffq_entries",

@@ -38,14 +38,16 @@ def entries_python(buf, rows, shift=0, hskip=1):
             for p0, p1, p2, p3, p4, p5 in zip(it, it, it, it, it, it)]
 
 
-def entries(buf, rows, shift=0, hskip=1):
+def entries(buf, rows, shift=0, hskip=1, cls=None):
     """List of (header, sequence, quality) `bytes` tuples, one per row of six int64 positions.
     `rows`: a C-contiguous buffer of int64 (array('q'), numpy); positions minus `shift` index `buf`;
-    the header slice starts at pos[0] + hskip (1: without the '@', as entryfunc cuts it)."""
+    the header slice starts at pos[0] + hskip (1: without the '@', as entryfunc cuts it); cls: a namedtuple
+    class the entries are instances of (entryfunc_namedtuple's `Entry`)."""
     mod = native()
     if mod is not None:
-        return mod.entries(buf, rows, shift, hskip)
+        return mod.entries(buf, rows, shift, hskip, cls)
     if not isinstance(buf, bytes):
         buf = bytes(buf)
     flat = memoryview(rows).cast("B").cast("q")
-    return entries_python(buf, flat, shift, hskip)
+    out = entries_python(buf, flat, shift, hskip)
+    return out if cls is None else [cls(*t) for t in out]

@@ -170,14 +170,15 @@ _ENTRY_CHUNK = 1024     # rows per native call: the tuples of one chunk are cons
                         # reused) before the next is built -- a whole fill at once is 3 x slower
 
 
-def _default_entries(buf, rows, shift):
+def _default_entries(buf, rows, shift, cls=None):
     """The default entryfunc (:161-171) over a table: (header, sequence, quality) of every row of
-    `rows` (C-contiguous int64, six per record; positions minus `shift` index `buf`)."""
+    `rows` (C-contiguous int64, six per record; positions minus `shift` index `buf`); cls=Entry: what
+    entryfunc_namedtuple (:146-158) builds."""
     cut = _entries.native().entries
     mv = memoryview(rows).cast('B')
     step = 48 * _ENTRY_CHUNK
     for at in range(0, len(mv), step):
-        yield from cut(buf, mv[at:at + step], shift)
+        yield from cut(buf, mv[at:at + step], shift, 1, cls)
 
 
 def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
@@ -194,8 +195,8 @@ def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
     buf = b'\n' + buf
     while True:
         rows, end_state, end_offset = scan_buffer(buf, offset, eof)
-        if entryfunc is _ENTRYFUNC and _entries.native() is not None:
-            yield from _default_entries(buf, rows, 0)
+        if (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
+            yield from _default_entries(buf, rows, 0, None if entryfunc is _ENTRYFUNC else Entry)
         elif entryfunc is _ENTRYFUNC:
             it = iter(rows)                      # the default entryfunc inlined (see _iter_stream)
             for p0, p1, p2, p3, p4, p5 in zip(it, it, it, it, it, it):
@@ -222,11 +223,11 @@ def _iter_stream(st, entryfunc):
     exactly what the reference's loop passes to entryfunc (:252-255), globaloffset included."""
     try:
         for rows, fill, fill_offset, end_state, err_offset in st:
-            if rows.shape[0] and entryfunc is _ENTRYFUNC and _entries.native() is not None:
+            if rows.shape[0] and (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
                 # the default entryfunc over the whole table, natively (csrc/ffq_entries.c): the slices
                 # are cut straight out of the stream's own (pinned) fill -- no bytes copy of the fill,
                 # no posbuffer and no interpreter loop per record
-                yield from _default_entries(fill, rows, fill_offset)
+                yield from _default_entries(fill, rows, fill_offset, None if entryfunc is _ENTRYFUNC else Entry)
             elif rows.shape[0]:
                 buf = fill.tobytes()
                 rel = array('q')

@@ -80,9 +80,9 @@ def test_iterators_use_the_native_entries_and_agree_with_python(E, oracle, pkg, 
 
     class Spy:
         @staticmethod
-        def entries(buf, rows, shift=0):
+        def entries(buf, rows, shift=0, hskip=1, cls=None):
             calls.append(len(rows) // 48)
-            return real(buf, rows, shift)
+            return real(buf, rows, shift, hskip, cls)
 
     monkeypatch.setattr(E, "_native", Spy)
     got = list(F.readfastq_iter(io.BytesIO(data), 200000, entrypos=Scanner()))
@@ -92,3 +92,13 @@ def test_iterators_use_the_native_entries_and_agree_with_python(E, oracle, pkg, 
     assert got == plain and len(got) == 5000
     ref = list(F.readfastq_iter(io.BytesIO(data), 200000))          # the pure-Python scanner, per record
     assert got == ref
+    # entryfunc_namedtuple (:146-158): Entry instances, natively and in Python
+    monkeypatch.setattr(E, "_native", Spy)
+    del calls[:]
+    nt = list(F.readfastq_iter(io.BytesIO(data), 200000, entryfunc=F.entryfunc_namedtuple, entrypos=Scanner()))
+    assert sum(calls) == 5000 and all(type(e) is F.Entry for e in nt)
+    assert nt == got and nt[7].header == got[7][0] and nt[7].quality == got[7][2]
+    ref_nt = list(F.readfastq_iter(io.BytesIO(data), 200000, entryfunc=F.entryfunc_namedtuple))
+    assert nt == ref_nt and type(ref_nt[0]) is F.Entry
+    with pytest.raises(TypeError):
+        E.entries(b"abc", np.zeros((1, 6), dtype=np.int64), 0, 1, dict)
