@@ -11,9 +11,13 @@ Workloads (BASELINE.json configs):
     single-1g    1 GiB S-single, 150 bp, Phred+33            (configs[1], default)
     decode-10g   10 GiB S-single + quality -> int8 decode     (configs[2])
     wrapped-10g  10 GiB S-wrapped, 50-300 bp, 80-col wrap     (configs[3])
+    single-100g  ONE 100 GiB S-single stream cut into N byte ranges (configs[4]; strong scaling:
+                 12.5 GiB per GPU at N = 8, all of it on one GPU at N = 1)
 For N > 1 the same per-GPU workload is one byte range of a single logical
 stream N times as long (weak scaling); ranks exchange only the bytes around
-their range edges (RCCL send/recv) and verify the hand-off.
+their range edges (RCCL send/recv) and verify the hand-off.  `--gpus N` without a
+launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).  The default
+run reports single-100g (and at N = 1 decode-10g, wrapped-10g) under `other_workloads`.
 """
 import argparse
 import json
@@ -37,6 +41,11 @@ WORKLOADS = {
     "wrapped-64m": dict(kind="wrapped", bytes=64 << 20, decode=False),
     "decode-64m": dict(kind="single", bytes=64 << 20, decode=True),
     "single-10g": dict(kind="single", bytes=10 * GIB, decode=False),
+    # BASELINE configs[4]: ONE 100 GiB stream (107 374 182 146 B, 333 460 193 records) cut into `world` byte
+    # ranges -- 12.5 GiB per GPU at N = 8, the whole stream on one GPU at N = 1 (it fits): total work is
+    # fixed, so this entry is the strong-scaling figure (`value`, the metric's weak-scaling line, stays configs[1]'s)
+    "single-100g": dict(kind="single", bytes=100 * GIB, decode=False, split=True),
+    "single-4g-split": dict(kind="single", bytes=4 * GIB, decode=False, split=True),      # (quick check of the same path)
 }
 
 
@@ -125,6 +134,31 @@ def cpu_reference_c(sample_bytes, budget_s=3.0):
             "kind": "reference",
             "sample": "%d entrypos() calls of the reference C extension (bare scanner calls in a Python loop), "
                       "%.1f s" % (n, el)}
+
+
+def cpu_reference_iter(sample_bytes, budget_s=3.0, fbufsize=50000):
+    """The reference's C scanner driven the way the reference drives it: one entrypos() + one entryfunc()
+    per record inside the refill loop (this package's readfastq_iter, the mirror of
+    /root/reference/src/fastqandfurious.py:251-279, takes that per-record path for any scanner
+    without a batched protocol), fbufsize = the reference benchmark's default 50 000 (benchmark.py:415)."""
+    import io
+    from oracle import refload
+    from fastqandfurious_amd import fastqandfurious as F
+    if not refload.have_reference_ext():
+        return None
+    ext = refload.load_ext()
+    n, nbytes = 0, 0
+    t0 = time.perf_counter()
+    for h, sq, q in F.readfastq_iter(io.BytesIO(sample_bytes), fbufsize, F.entryfunc, ext.entrypos):
+        n += 1
+        nbytes += len(h) + len(sq) + len(q) + 6
+        if (n & 4095) == 0 and time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"value": round(nbytes / el / 1e9, 5), "unit": "GB/s", "m_reads_per_s": round(n / el / 1e6, 4), "cores": 1,
+            "kind": "reference", "fbufsize": fbufsize,
+            "sample": "%d (header, sequence, quality) tuples: the reference C extension's entrypos + entryfunc per record "
+                      "inside the readfastq_iter refill loop, %.1f s" % (n, el)}
 
 
 def cpu_iterator_rate(sample_bytes, budget_s=3.0):
@@ -243,7 +277,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     flags = hip.F_DECODE_QUAL if decode else hip.F_POLL_RESULT
 
     # ---- this rank's byte range of the logical stream, generated in HBM ----------
-    shard = sharded.SyntheticShard(ctx, wl["kind"], wl["bytes"], rank, world, dev)
+    split = bool(wl.get("split"))                   # the workload's bytes are the whole job's, not one GPU's
+    shard = sharded.SyntheticShard(ctx, wl["kind"], wl["bytes"] // world if split else wl["bytes"], rank, world, dev)
     n_own = shard.n_own_bytes
     ctx.reserve(shard.ext.numel())
     table = torch.empty((shard.max_records + 64, 6), dtype=torch.int64, device=dev)
@@ -264,7 +299,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     # kernel of the first ~15 ms of steps runs 5-7 % slower than in steady state
     # (tools/k1_timeline.py).  The untimed phase therefore starts with as many extra steps as make
     # ~settle-ms of GPU work -- a count computed from the workload's size, the same on every rank.
-    settle_steps = int(args.settle_ms * 1e-3 / (wl["bytes"] / 4.0e12)) if args.settle_ms > 0 else 0
+    settle_steps = int(args.settle_ms * 1e-3 / ((wl["bytes"] // world if split else wl["bytes"]) / 4.0e12)) if args.settle_ms > 0 else 0
     n_untimed = settle_steps + args.warmup
 
     def note(out):
@@ -382,6 +417,24 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
         total_records, total_bytes = out.n_own_records, n_own
     assert out.res.path in (0, 3), "a parallel chain path must be the one measured (got path %d)" % out.res.path
 
+    # The same step once more OUTSIDE the timed region, one at a time and with an end event instead of
+    # the polled completion word: the device span first kernel -> last kernel of ONE step (res.ms_total,
+    # HIP events on the scan stream) -- round 1's definition of the whole-path time, kept so that rounds
+    # compare like for like.  (Wall-clock steps are shorter: the next step's index kernel starts behind
+    # this step's last kernel with no idle gap, and host-side waits are hidden.)
+    span_ms = []
+    if world == 1 and not args.sharded_step and not args.lanes_step:
+        for _ in range(5):
+            ctxs[0].scan_submit(shard.ext.data_ptr(), shard.n_own_bytes, tables[0].data_ptr(), tables[0].shape[0],
+                                sentinel=True, eof=True, flags=flags & ~hip.F_POLL_RESULT,
+                                d_qual=quals[0].data_ptr() if decode else None,
+                                qual_cap=quals[0].numel() if decode else 0,
+                                d_qoff=qoffs[0].data_ptr() if decode else None)
+            rc, res = ctxs[0].scan_wait()
+            assert rc == hip.OK
+            span_ms.append(float(res.ms_total))
+        torch.cuda.synchronize()
+
     # ---- parity spot check on the measured output (size-independent properties) -----
     shard.verify(table, out)
     if decode:
@@ -394,7 +447,12 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     if rank == 0 and world == 1:
         nprobe = min(shard.n_own_bytes, 2 * GIB) & ~((1 << 14) - 1)
         if nprobe >= (1 << 14):
-            probe_gbs = nprobe / (ctx.read_probe(shard.ext.data_ptr(), nprobe, 6, 10) * 1e-3) / 1e9
+            try:
+                rp = hip.ReadProbe(ctx.device)              # the instrumented build, beside the product library
+                probe_gbs = nprobe / (rp.read_ms(shard.ext.data_ptr(), nprobe, 6, 10) * 1e-3) / 1e9
+                rp.close()
+            except Exception as e:      # noqa: BLE001  (diagnostics only: never fails the bench line)
+                sys.stderr.write("hbm_read_probe skipped: %s\n" % (e,))
 
     line = None
     if rank == 0:
@@ -433,10 +491,11 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
             "ms_per_step": round(step_s * 1e3, 4),
             "ms_per_step_spread": spread(steps_ms[1:] if len(steps_ms) > 2 else steps_ms),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if split else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
+            "build_id": hip.build_id(),
             "config": {
                 "workload": name,
                 "description": "%s synthetic FASTQ, %d bytes/GPU, %d records/GPU%s"
@@ -444,6 +503,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                                   n_own, n_rec, ", quality->int8 decode" if decode else ""),
                 "bytes_per_gpu": n_own,
                 "records_per_gpu": n_rec,
+                "total_bytes": total_bytes,
+                "total_records": total_records,
                 "sharding": "byte ranges, RCCL halo hand-off" if world > 1 else "single range",
             },
             "roofline": {
@@ -462,7 +523,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
             },
             "hbm_read_probe": None if probe_gbs is None else {
                 "value": round(probe_gbs, 1), "unit": "GB/s", "frac_of_peak": round(probe_gbs / HBM_PEAK_GBS, 4),
-                "what": "pure non-temporal 16 B/lane read of the same resident buffer (k_read_probe), this box, this run"},
+                "what": "pure non-temporal 16 B/lane read of the same resident buffer (k_read_probe of libffq_probe.so, "
+                        "the instrumented build; not part of the product library), this box, this run"},
             "path_roofline": {
                 "what": "all kernels of one step over the wall-clock step, SURVEY.md 8(d) bytes (record bytes + 48 B row%s)"
                         % (" + decoded bytes + 8 B CSR offset" if decode else ""),
@@ -471,7 +533,12 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 "frac": round(algo_path / step_s / 1e9 / HBM_PEAK_GBS, 4),
                 "ms_index": round(float(np.mean(ms_index)), 4),
                 "ms_decode": round(float(np.mean(ms_decode)), 4),
-                "step_latency_ms": round(float(np.mean(ms_total)), 4) if float(np.mean(ms_total)) > 0 else None,
+                "basis": "throughput: wall-clock time per step with steps queued one ahead (what the driver recomputes "
+                         "from ms_per_step); device_span_* below is the round-1 definition",
+                "device_span_ms": round(float(np.median(span_ms)), 4) if span_ms else None,
+                "device_span_frac": round(algo_path / (float(np.median(span_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if span_ms else None,
+                "device_span_what": "median of 5 unpipelined steps after the timed region: first kernel -> last kernel "
+                                    "of one step by HIP events on the scan stream (ffq_scan_result.ms_total)",
             },
         }
     for c2 in extra_ctx:
@@ -506,9 +573,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start one rank per GPU ourselves (the driver's own command line does the same)
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
-                         % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     # FFQ_BENCH_DRY_MULTI=1: every rank on GPU 0 over gloo -- a functional dry run of the N > 1
     # code path on a one-GPU box (its number means nothing; RCCL refuses two ranks per device)
     dry = os.environ.get("FFQ_BENCH_DRY_MULTI") == "1"
@@ -533,7 +610,11 @@ def main():
             line["cpu_baseline"]["host_cores_available"] = os.cpu_count()
             line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(sample[:64 << 20], args.cpu_seconds / 2)
             line["cpu_baseline"]["python_iterator"] = cpu_iterator_rate(sample.tobytes(), 3.0)
+            line["cpu_baseline"]["what"] = ("`value` is the PORT (oracle/ffq_oracle.c, whole-buffer chain, no interpreter); "
+                                            "reference_c_extension = the reference's own compiled scanner, bare calls; "
+                                            "reference_c_iterator = the same scanner inside the per-record iterator loop")
             line["cpu_baseline"]["reference_c_extension"] = cpu_reference_c(sample.tobytes(), 3.0)
+            line["cpu_baseline"]["reference_c_iterator"] = cpu_reference_iter(sample.tobytes(), 3.0)
             line["host_inclusive"] = host_inclusive(ctx, sample, flags)
             line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, shard.host_sample(1 << 30))
             del sample
@@ -541,19 +622,26 @@ def main():
             line["cpu_baseline"] = None
     # N = 1, default workload: BASELINE configs[2] and [3] timed the same way, under their own key
     # (`value` stays configs[1]'s)
-    if world == 1 and args.workload == "single-1g" and not args.no_others and not args.sharded_step and not args.lanes_step:
+    # (at every N also BASELINE configs[4]: the one 100 GiB stream cut into `world` ranges)
+    if args.workload == "single-1g" and not args.no_others and not args.sharded_step and not args.lanes_step:
         del shard
         torch.cuda.empty_cache()
         others = {}
-        for other in ("decode-10g", "wrapped-10g"):
+        names = ("decode-10g", "wrapped-10g", "single-100g") if world == 1 else ("single-100g",)
+        if os.environ.get("FFQ_BENCH_DRY_MULTI") == "1":
+            names = ("single-4g-split",)             # (the dry run shares ONE GPU between the ranks)
+        for other in names:
             ctx_o = hip.Context(local_rank)
             ol, keep = run_workload(other, args, ctx_o, rank, world, dev, dist)
             del keep
             ctx_o.close()
             torch.cuda.empty_cache()
-            others[other] = {k: ol[k] for k in ("value", "unit", "m_reads_per_s", "ms_per_step", "ms_per_step_spread",
-                                                 "settle_steps", "config", "roofline", "hbm_read_probe", "path_roofline")}
-        line["other_workloads"] = others
+            if rank == 0:
+                others[other] = {k: ol[k] for k in ("value", "unit", "m_reads_per_s", "n_gpus", "scaling", "ms_per_step",
+                                                     "ms_per_step_spread", "settle_steps", "config", "roofline",
+                                                     "hbm_read_probe", "path_roofline")}
+        if rank == 0:
+            line["other_workloads"] = others
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

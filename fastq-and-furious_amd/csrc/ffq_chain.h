@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     const int64_t wpos0 = (int64_t)wt0 << TILE_SHIFT;
     const int64_t len = L.len();
 
-    const bool prof = B.prof != nullptr;
+    const bool prof = PROBES && B.prof != nullptr;
     long long ts[6] = {0, 0, 0, 0, 0, 0};
     if (prof) ts[0] = clock64();
     // ---- window directory + first FPE entries of every tile, one memory round trip ----
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             if (runin_tile) n_runin = ncomp;
         }
     }
-    if (ablate == 1) { if (lane == 0) B.lines[g] = lines + ncomp; return; }
+    if (PROBES && ablate == 1) { if (lane == 0) B.lines[g] = lines + ncomp; return; }
     int own_hi = 0;                                    // entry index just past the own tiles
 #pragma unroll
     for (int k = 0; k <= NTW; k++)
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         return;
     }
     wave_sync();
-    if (ablate == 2) { if (lane == 0) B.lines[g] = lines + ncomp; return; }
+    if (PROBES && ablate == 2) { if (lane == 0) B.lines[g] = lines + ncomp; return; }
 
     if (prof) ts[3] = clock64();
     // ---- one scanner call + successor search per node (node c = u*64 + lane) -------------
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         }
     }
     pend = 0;
-    if (ablate == 3) { if (lane == 0) B.lines[g] = lines + info[0]; return; }
+    if (PROBES && ablate == 3) { if (lane == 0) B.lines[g] = lines + info[0]; return; }
     int e_forced = -1;
     if (fpos != FORCE_NONE) {
         if (fpos >= ((int64_t)own1 << TILE_SHIFT) + L.s) {
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         if (nxt >= n_runin || attempt == 3) { unresolved = true; break; }
         e0 = nxt;
     }
-    if (ablate == 4) { if (lane == 0) B.lines[g] = lines + lastn; return; }
+    if (PROBES && ablate == 4) { if (lane == 0) B.lines[g] = lines + lastn; return; }
 
     if (prof) ts[5] = clock64();
     // ---- summary + staging of the own tiles' records ---------------------------------------------

@@ -17,6 +17,15 @@
 
 namespace ffq {
 
+// Diagnostics (ablation switches of the kernels, look-back / pipeline / read probes) exist only in the
+// instrumented build of this library, libffq_probe.so (-DFFQ_PROBES; tools/ only).  In the product build
+// every `PROBES && ...` test is constant-false and the code behind it is not compiled.
+#ifdef FFQ_PROBES
+constexpr bool PROBES = true;
+#else
+constexpr bool PROBES = false;
+#endif
+
 constexpr int TILE_SHIFT = 14;
 constexpr int TILE = 1 << TILE_SHIFT;          // bytes per line-index tile
 constexpr int SLOT = 1024;                     // u16 entries per tile slot

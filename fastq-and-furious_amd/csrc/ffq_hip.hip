@@ -3,6 +3,9 @@
 // kernel sequencing on one HIP stream, pinned staging for host buffers.
 // No CPU fallback: every compute entry point needs a live gfx950 device.
 #include "../../include/ffq.h"
+#ifdef FFQ_PROBES
+#include "../../include/ffq_probe.h"
+#endif
 #include "ffq_kernels.h"
 #include "ffq_fasta.h"
 #include "ffq_pool.h"
@@ -66,6 +69,8 @@ struct ffq_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int fast4_skip = 0;                  // scans left that go straight to the general kernels (see scan_finish)
+    int fast4_backoff = 15;              // how many the next failed attempt sets: doubles per consecutive failure (a stream
+                                         // of wrapped records retries the fast path ever more rarely), back to 15 on success
     int ranked_skip = 0;                 // scans left that go straight to the list-ranking tier (long records)
     RankBufs rk = {};                    // its scratch (ffq_ranked.h), grow-only
     int64_t rk_cap_tiles = 0, rk_cap_c = 0;
@@ -141,6 +146,16 @@ struct ffq_ctx {
 };
 
 extern "C" int ffq_abi_version(void) { return FFQ_ABI_VERSION; }
+// hash of the sources this binary was compiled from (csrc/*, include/*.h), baked in by build.py
+#ifndef FFQ_BUILD_ID
+#define FFQ_BUILD_ID "unknown"
+#endif
+#ifdef FFQ_PROBES
+static const char g_build_tag[] = "FFQ_BUILD_ID=" FFQ_BUILD_ID "+probes";      // (build.py reads the tag out of the file)
+#else
+static const char g_build_tag[] = "FFQ_BUILD_ID=" FFQ_BUILD_ID;
+#endif
+extern "C" const char *ffq_build_id(void) { return g_build_tag + 13; }
 extern "C" const char *ffq_last_error(void) { return g_err.c_str(); }
 
 extern "C" int ffq_device_count(void)
@@ -383,7 +398,7 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 
 extern "C" void ffq_ctx_forget(ffq_ctx *c)
 {
-    if (c) { c->fast4_skip = 0; c->dense_skip = 0; c->ranked_skip = 0; }
+    if (c) { c->fast4_skip = 0; c->fast4_backoff = 15; c->dense_skip = 0; c->ranked_skip = 0; }
 }
 
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
@@ -502,7 +517,7 @@ static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st, bool t
 {
     if (timed) { (void)hipEventRecord(c->ev[6], st); c->decode_timed = true; }
     const int64_t nblk = qdir_blocks(a.n_bytes, a.qual_cap);
-    static const int ablate = getenv("FFQ_DQ_ABLATE") ? atoi(getenv("FFQ_DQ_ABLATE")) : 0;
+    static const int ablate = (PROBES && getenv("FFQ_DQ_ABLATE")) ? atoi(getenv("FFQ_DQ_ABLATE")) : 0;
     hipLaunchKernelGGL(k_decode_stream, dim3((unsigned)nblk), dim3(256), 0, st, a.d_buf, a.n_bytes, a.s,
                        (const int64_t *)c->p4s, (const int64_t *)a.d_qoff, (const int64_t *)c->qdir,
                        (const DevRes *)c->dres, std::min<int64_t>(a.table_cap, c->p4s_cap), a.add, a.qual_add, a.d_qual,
@@ -597,9 +612,9 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     cb.nmax = nmax;
     cb.prof = nullptr;
     hipStream_t sA = c->stream;
-    const char *abl = getenv("FFQ_ABLATE");
+    const char *abl = PROBES ? getenv("FFQ_ABLATE") : nullptr;
     const int ablate = abl ? atoi(abl) : 0;
-    if (getenv("FFQ_PROF")) {
+    if (PROBES && getenv("FFQ_PROF")) {
         if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 64));
         HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sA));
         cb.prof = c->prof_d;
@@ -631,9 +646,9 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     const ScanArgs &a = st.a;
     const bool serial = (a.flags & FFQ_F_FORCE_SERIAL) != 0;
     const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
-    const char *abl = getenv("FFQ_ABLATE");
+    const char *abl = PROBES ? getenv("FFQ_ABLATE") : nullptr;
     const int ablate = abl ? atoi(abl) : 0;
-    const int k1abl = getenv("FFQ_K1_ABLATE") ? atoi(getenv("FFQ_K1_ABLATE")) : 0;
+    const int k1abl = (PROBES && getenv("FFQ_K1_ABLATE")) ? atoi(getenv("FFQ_K1_ABLATE")) : 0;
     hipStream_t sA = c->stream;
     const int64_t ntiles = st.ntiles;
     const int nsb = (int)((ntiles + SB_TILES - 1) / SB_TILES);
@@ -777,8 +792,7 @@ static int enqueue_offsets_and_decode(ffq_ctx *c, const ScanArgs &a, int64_t n_r
 {
     hipStream_t sA = c->stream;
     if (n_rows <= 0 || n_rows > a.table_cap) {
-        const int64_t z = 0;
-        if (n_rows == 0) HIPCHK(hipMemcpyAsync(a.d_qoff, &z, sizeof z, hipMemcpyHostToDevice, sA));
+        if (n_rows == 0) HIPCHK(hipMemsetAsync(a.d_qoff, 0, sizeof(int64_t), sA));     // qoff[0] = 0
         return FFQ_OK;
     }
     const int64_t nblk = (n_rows + 255) / 256;
@@ -847,12 +861,14 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         if (st.stage == 1) {
             if (!c->h_res->fallback) {
                 fill_result(res, *c->h_res, 3, st.retries);
+                c->fast4_backoff = 15;
                 break;
             }
             // not plain four-line input: the general kernels, from the same line index.  The next
             // scans of this context skip the attempt (and the host round trip it costs here).
             st.fast4_failed = true;
-            c->fast4_skip = 15;
+            c->fast4_skip = c->fast4_backoff;
+            c->fast4_backoff = std::min(2 * c->fast4_backoff + 1, 4095);
             HIPCHK(hipEventRecord(c->ev[4], sA));
             int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups);
             if (rc) return rc;
@@ -863,7 +879,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             res->ms_chain += ms; res->ms_total += ms;
             if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
         }
-        if (tiers && getenv("FFQ_PROF") && c->prof_d) {
+        if (PROBES && tiers && getenv("FFQ_PROF") && c->prof_d) {
             unsigned long long hp[8];
             HIPCHK(hipMemcpy(hp, c->prof_d, 64, hipMemcpyDeviceToHost));
             if (hp[6])
@@ -874,7 +890,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 fprintf(stderr, "[ffq prof] generic-path nodes per wave %.2f, serial generic rounds per wave %.2f\n",
                         (double)(hp[7] & 0xFFFFFFFFull) / hp[6], (double)(hp[7] >> 32) / hp[6]);
         }
-        if (tiers && getenv("FFQ_DEBUG")) {
+        if (PROBES && tiers && getenv("FFQ_DEBUG")) {
             const int ng = std::min(st.ngroups, 24);
             std::vector<int64_t> y(ng), ex(ng);
             std::vector<uint32_t> cn(ng), fl(ng);
@@ -891,7 +907,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                         (long long)ex[g], cn[g], fl[g]);
         }
         int path = 0;
-        if (tiers && getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) {
+        if (PROBES && tiers && getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) {
             // diagnostics build of the pipeline: results are meaningless, only timings count
             fill_result(res, *c->h_res, 0, st.retries);
             return FFQ_OK;
@@ -901,7 +917,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         // makes the first rejected group exact, so the first bad group moves forward; a round
         // that does not move it (a group that does not fit the kernel at all) ends the repairs.
         static const bool no_ranked = getenv("FFQ_NO_RANKED") != nullptr;
-        if (tiers && !(getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) && !getenv("FFQ_NO_REPAIR")) {
+        if (tiers && !(PROBES && getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) && !getenv("FFQ_NO_REPAIR")) {
             int prev_bad = -1;
             const int first_bad = c->h_res->bad_group;
             // (a group that does not FIT the kernel -- bad_irregular -- is walked by k_group_walk in
@@ -1050,8 +1066,7 @@ extern "C" int ffq_scan_wait(ffq_ctx *c, ffq_scan_result *res)
         res->end_offset = st.a.offset;
         for (int i = 0; i < 6; i++) res->last_pos[i] = -1;
         if ((st.a.flags & FFQ_F_DECODE_QUAL) != 0) {
-            const int64_t z = 0;
-            HIPCHK(hipMemcpyAsync(st.a.d_qoff, &z, sizeof z, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemsetAsync(st.a.d_qoff, 0, sizeof(int64_t), c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
         }
         return FFQ_OK;
@@ -1382,8 +1397,7 @@ extern "C" int ffq_table_gather_column(ffq_ctx *c, const uint8_t *d_buf, int64_t
     *n_out_bytes = 0;
     hipStream_t st = c->stream;
     if (n_rows == 0) {
-        const int64_t z = 0;
-        HIPCHK(hipMemcpyAsync(d_off, &z, sizeof z, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(d_off, 0, sizeof(int64_t), st));
         HIPCHK(hipStreamSynchronize(st));
         return FFQ_OK;
     }
@@ -1505,6 +1519,8 @@ extern "C" int ffq_synth_wrapped(ffq_ctx *c, uint8_t *d_out, const int64_t *d_st
     return FFQ_OK;
 }
 
+#ifdef FFQ_PROBES
+// ---- probes: only in the instrumented build, libffq_probe.so (include/ffq_probe.h; tools/) ----------
 extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int mode, int reps, float *ms_avg)
 {
     if (!c || !d_buf || !ms_avg || n_bytes < TILE || reps < 1) return fail(FFQ_E_ARG, "ffq_read_probe: bad argument");
@@ -1657,6 +1673,8 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
     if (mode == 2) { HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
     return FFQ_OK;
 }
+
+#endif  // FFQ_PROBES
 
 // ---- diagnostics ---------------------------------------------------------------------
 extern "C" int ffq_selftest(ffq_ctx *c)

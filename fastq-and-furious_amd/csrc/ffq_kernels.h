@@ -105,7 +105,7 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
         m[i] = nl_mask16(v[i]);
         c[i] = __popc(m[i]);
     }
-    if (ablate == 3) { if ((c[0] + c[1] + c[2] + c[3]) == 77u) cnt[tile] = 1; return; }
+    if (PROBES && ablate == 3) { if ((c[0] + c[1] + c[2] + c[3]) == 77u) cnt[tile] = 1; return; }
     // wave prefix sums of the four row counts, two 16-bit fields per register
     const uint32_t s01 = wave_incl_scan(c[0] | (c[1] << 16));
     const uint32_t s23 = wave_incl_scan(c[2] | (c[3] << 16));
@@ -125,7 +125,8 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
         if (q < w) wbase += t;
         total += t;
     }
-    if (ablate == 5) { if (total + wbase == 0x7777u) cnt[tile] = 1; return; }
+    if (PROBES && ablate == 5) { if (total + wbase == 0x7777u) cnt[tile] = 1; return; }
+#ifdef FFQ_PROBES
     if (ablate == 8 && w == 0) {
         // PROBE (ffq_read_probe mode 7): what a decoupled look-back over the tiles' newline counts
         // costs on this part -- descriptors flag << 62 | value in ovf[] (zeroed before the launch),
@@ -220,6 +221,7 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
         }
         if ((ablate - 100) & 16) __syncthreads();
     }
+#endif
     const bool dense = total > (uint32_t)SLOT;
     if (dense) {   // rare: avg line shorter than 16 bytes over the whole tile
         if (tid == 0) {
@@ -248,13 +250,13 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
         }
         rb += rowtot[i];
     }
-    if (tid == 0 && ablate != 7) {
+    if (tid == 0 && !(PROBES && ablate == 7)) {
         // no atomics here: an agent-scope atomic of 64 tiles on one address costs more than the
         // whole scan (measured: +45 us per GiB); the per-superblock sums are a kernel of their own
         cnt[tile] = total;
         if (dense) ovf[tile] = pbase;                       // read only for tiles with cnt > SLOT
     }
-    if (ablate == 6 || ablate == 7) return;
+    if (PROBES && (ablate == 6 || ablate == 7)) return;
     // Each wave stores its own entries, flags looked up on the way, and is done: no second
     // workgroup barrier, no wave waits for another one's store (a workgroup-wide copy of the
     // finished list cost 20 us per GiB in barrier + tail latency).
@@ -266,7 +268,7 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
             const uint32_t off = (uint32_t)s_list[wbase + j];
             const uint16_t e = (uint16_t)(off | (entry_flags(s_data, off, nxt, at_char) << 14));
             // written once, read by the row / chain kernels from HBM later: non-temporal (-4...10 us per GiB)
-            if (ablate == 9) gdst[wbase + j] = e;
+            if (PROBES && ablate == 9) gdst[wbase + j] = e;
             else __builtin_nontemporal_store(e, gdst + wbase + j);
         }
     } else if (pool_ok) {
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256) void k_decode_stream(const uint8_t *__restrict
 #pragma unroll
             for (int j = 0; j < DQ_PER; j++) {
                 xa[j] = xb[j] = make_uint4(0, 0, 0, 0);
-                if (ci[j] < 0 || (ablate & 4)) continue;
+                if (ci[j] < 0 || (PROBES && (ablate & 4))) continue;
                 const int clo = 16 * (k0 + j * 256 + tid) - shiftA;
                 xa[j] = load16_any(d, nbytes, s_adj[ci[j]] + clo);
                 if (h1[j] > h0[j]) xb[j] = load16_any(d, nbytes, s_adj[ci[j] + 1] + clo);
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(256) void k_decode_stream(const uint8_t *__restrict
                 }
 #pragma unroll
                 for (int w = 0; w < 4; w++) y[w] = addb4(y[w], vv);
-                if (ablate & 2) { if (y[0] == 0x12345678u && y[1] == 77u) outb[0] = 1; }
+                if (PROBES && (ablate & 2)) { if (y[0] == 0x12345678u && y[1] == 77u) outb[0] = 1; }
                 else if (vhi - vlo == 16) {
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     u32x4 t; t.x = y[0]; t.y = y[1]; t.z = y[2]; t.w = y[3];
@@ -1029,6 +1031,7 @@ __global__ __launch_bounds__(256) void k_synth_wrapped(uint8_t *__restrict__ out
     }
 }
 
+#ifdef FFQ_PROBES
 // =========================================================================
 // k_pipe_probe (ffq_read_probe modes 200 + lag; tools/pipe_probe.py): what a single-pass design would have to
 // be built on -- PERSISTENT workgroups that keep streaming tiles (workgroup b takes tiles b, b + G, b + 2G, ...;
@@ -1185,6 +1188,8 @@ __global__ __launch_bounds__(256) void k_read_probe(const uint8_t *__restrict__ 
     }
     if (acc == 0x12345678u) sink[0] = acc;      // never true in practice: keeps the loads alive
 }
+
+#endif  // FFQ_PROBES
 
 // =========================================================================
 // self-test kernel: wave scan and newline mask against scalar code

@@ -11,23 +11,29 @@ import importlib.machinery
 import importlib.util
 import os
 
+import sysconfig
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "csrc", "_ffq_entries.so")
+# the interpreter's ABI tag is part of the file name (build.entries_lib): another Python's build is not loaded
+_LIB = os.path.join(_HERE, "csrc", "_ffq_entries" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 _native = None
 _tried = False
 
 
 def native():
-    """The compiled module, or None when csrc/_ffq_entries.so is not there (build.build_entries())."""
+    """The compiled module, or None when csrc/_ffq_entries<EXT_SUFFIX> is not there or does not load (build.build_entries())."""
     global _native, _tried
     if not _tried:
         _tried = True
         if os.path.exists(_LIB):
-            loader = importlib.machinery.ExtensionFileLoader("_ffq_entries", _LIB)
-            spec = importlib.util.spec_from_loader("_ffq_entries", loader)
-            mod = importlib.util.module_from_spec(spec)
-            loader.exec_module(mod)
-            _native = mod
+            try:
+                loader = importlib.machinery.ExtensionFileLoader("_ffq_entries", _LIB)
+                spec = importlib.util.spec_from_loader("_ffq_entries", loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+                _native = mod
+            except ImportError:
+                _native = None           # not loadable here: the Python slices below do the same
     return _native
 
 

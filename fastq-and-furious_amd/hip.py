@@ -27,7 +27,7 @@ MISSING_QUALHEADER_END = 7
 
 END_OK, END_REFILL, END_ERR_FINAL_QUAL, END_ERR_INCOMPLETE, END_ERR_INVALID = range(5)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK = 0
 E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_TABLE_FULL, E_INTERNAL = -1, -2, -3, -4, -5, -6
 
@@ -38,7 +38,7 @@ F_POLL_RESULT = 8
 
 # every symbol include/ffq.h declares (tests check the library exports them all)
 SYMBOLS = (
-    "ffq_abi_version", "ffq_last_error", "ffq_device_count", "ffq_ctx_create", "ffq_ctx_create_shared",
+    "ffq_abi_version", "ffq_build_id", "ffq_last_error", "ffq_device_count", "ffq_ctx_create", "ffq_ctx_create_shared",
     "ffq_ctx_destroy", "ffq_ctx_reserve", "ffq_ctx_forget", "ffq_ctx_stream", "ffq_dev_alloc", "ffq_dev_free",
     "ffq_pinned_alloc", "ffq_pinned_free", "ffq_copy_h2d", "ffq_copy_d2h", "ffq_sync",
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
@@ -46,7 +46,7 @@ SYMBOLS = (
     "ffq_table_select_seqlen", "ffq_table_cut", "ffq_table_gather_column", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
     "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
-    "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_read_probe", "ffq_selftest",
+    "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
 )
 
 
@@ -75,6 +75,7 @@ class FFQError(RuntimeError):
 
 
 _lib = None
+_probe = False      # use_probe_build(): tools load the instrumented build instead of the product library
 
 
 def _share_torch_hip_runtime():
@@ -94,11 +95,52 @@ def _share_torch_hip_runtime():
         pass
 
 
+def use_probe_build():
+    """tools/ only: load libffq_probe.so (the same sources compiled with -DFFQ_PROBES: ablation
+    switches, read / look-back / pipeline probes; include/ffq_probe.h) in place of the product
+    library.  Must be called before the first use of lib()."""
+    global _probe, LIB_PATH
+    assert _lib is None, "use_probe_build() must come before the library is loaded"
+    from . import build as _build
+    _probe = True
+    LIB_PATH = _build.build_probe()
+
+
+def _checked_build():
+    """The in-tree library must be the build of the sources in the tree: compare the id baked
+    into it (ffq_build_id) with the hash of csrc/ + include/ and rebuild on a mismatch; if that
+    is not possible, refuse.  (FFQ_HIP_LIB names another build on purpose: not checked.)"""
+    if os.environ.get("FFQ_HIP_LIB") or _probe:
+        return
+    from . import build as _build
+    want = _build.source_id()
+    if os.path.exists(LIB_PATH) and _build.built_id(LIB_PATH) == want:
+        return
+    try:
+        _build.build()
+    except Exception as e:      # noqa: BLE001
+        raise FFQError(E_NODEVICE,
+                       "%s is missing or was not built from the sources in this tree (build id %s, "
+                       "sources %s) and cannot be rebuilt here: %s.  Build it with `python "
+                       "fastq-and-furious_amd/build.py` (there is no CPU fallback for the scan path)"
+                       % (LIB_PATH, _build.built_id(LIB_PATH), want, e))
+    if _build.built_id(LIB_PATH) != want:
+        raise FFQError(E_INTERNAL, "%s does not carry the build id of its sources after a rebuild" % LIB_PATH)
+
+
+def build_id():
+    """The source hash baked into the loaded library (== build.source_id() of this tree)."""
+    return lib().ffq_build_id().decode("ascii")
+
+
 def lib():
-    """The loaded library.  Raises if it has not been built."""
+    """The loaded library.  Raises if it has not been built and cannot be."""
     global _lib
     if _lib is None:
+        if os.environ.get("FFQ_USE_PROBE_BUILD") == "1" and not _probe:
+            use_probe_build()            # (tools/*.sh: the ablation switches live in the instrumented build)
         _share_torch_hip_runtime()
+        _checked_build()
         if not os.path.exists(LIB_PATH):
             raise FFQError(E_NODEVICE,
                            "%s is missing: build it with `python fastq-and-furious_amd/build.py` "
@@ -108,6 +150,7 @@ def lib():
                                   ctypes.c_uint64)
         P = ctypes.POINTER
         L.ffq_abi_version.restype = i32
+        L.ffq_build_id.restype = ctypes.c_char_p
         L.ffq_last_error.restype = ctypes.c_char_p
         L.ffq_device_count.restype = i32
         L.ffq_ctx_create.argtypes = [i32, P(vp)]
@@ -155,7 +198,8 @@ def lib():
         L.ffq_synth_wrapped_size.argtypes = [i64, u64]
         L.ffq_synth_wrapped_size.restype = i64
         L.ffq_synth_wrapped.argtypes = [vp, vp, vp, i64, i64, u64]
-        L.ffq_read_probe.argtypes = [vp, vp, i64, i32, i32, P(ctypes.c_float)]
+        if _probe:
+            L.ffq_read_probe.argtypes = [vp, vp, i64, i32, i32, P(ctypes.c_float)]
         L.ffq_selftest.argtypes = [vp]
         _lib = L
     return _lib
@@ -365,6 +409,9 @@ class Context:
         return idx.value
 
     def read_probe(self, dptr, n_bytes, mode=0, reps=10):
+        """Instrumented build only (use_probe_build(); include/ffq_probe.h)."""
+        if not _probe:
+            raise FFQError(E_ARG, "ffq_read_probe exists only in libffq_probe.so: call hip.use_probe_build() first (tools)")
         ms = ctypes.c_float(0)
         check(lib().ffq_read_probe(self.handle, ctypes.c_void_p(dptr), int(n_bytes), int(mode), int(reps),
                                    ctypes.byref(ms)))
@@ -488,3 +535,37 @@ def default_context(device=None):
         ctx = Context(device)
         _default_ctx[device] = ctx
     return ctx
+
+
+class ReadProbe:
+    """bench.py's `hbm_read_probe`: what this box's memory system gives a pure streaming read, measured
+    by the INSTRUMENTED build (libffq_probe.so, include/ffq_probe.h) loaded beside the product library
+    -- its own handle, its own context; the product library has no such entry point."""
+
+    def __init__(self, device=0):
+        from . import build as _build
+        _share_torch_hip_runtime()
+        self._L = ctypes.CDLL(_build.build_probe())
+        L = self._L
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        L.ffq_last_error.restype = ctypes.c_char_p
+        L.ffq_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+        L.ffq_ctx_destroy.argtypes = [vp]
+        L.ffq_ctx_destroy.restype = None
+        L.ffq_read_probe.argtypes = [vp, vp, i64, i32, i32, ctypes.POINTER(ctypes.c_float)]
+        self._h = vp()
+        rc = L.ffq_ctx_create(int(device), ctypes.byref(self._h))
+        if rc != OK:
+            raise FFQError(rc, L.ffq_last_error().decode("utf-8", "replace"))
+
+    def read_ms(self, dptr, n_bytes, mode=6, reps=10):
+        ms = ctypes.c_float(0)
+        rc = self._L.ffq_read_probe(self._h, ctypes.c_void_p(dptr), int(n_bytes), int(mode), int(reps), ctypes.byref(ms))
+        if rc != OK:
+            raise FFQError(rc, self._L.ffq_last_error().decode("utf-8", "replace"))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            self._L.ffq_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()

@@ -127,7 +127,7 @@ class DistTransport:
             if src == self.rank:
                 t = provide(a, b)
                 ops.append(dist.P2POp(dist.isend, t.cpu() if (self.gloo and t.is_cuda) else t, dst, self.group))
-            elif dst == self.rank:
+            if dst == self.rank:         # (src == dst only in the world-1 transport test: both ops, one group)
                 t = accept(a, b)
                 if self.gloo and t.is_cuda:
                     h = t.cpu()
@@ -523,23 +523,29 @@ class SyntheticShard:
         self.tail, self.head = halo_sizes(S, rank)
         self.block_start = B[rank]
 
-        # records [rank*n_per, (rank+1)*n_per (+1)) generated record-aligned, then the range is cut out
+        # records [rank*n_per, (rank+1)*n_per (+1)) are generated record-aligned straight into the
+        # [tail | own | head] buffer, placed so that the range's first byte lands at ext[tail] (a 100 GiB
+        # range has no room for a second copy); what the generator leaves in the halos is wiped -- they
+        # are filled by the hand-off
         n_gen = n_per + (1 if rank < world - 1 else 0)
+        a = self.own_lo - self.block_start              # the range starts `a` bytes into its first generated record
+        assert 0 <= a <= self.tail or (a == 0 and self.tail == 0)
         if kind == "single":
             gen_bytes = n_gen * synth.RECORD_BYTES
-            tmp = torch.empty(gen_bytes + 64, dtype=torch.uint8, device=dev)
-            ctx.synth_single(tmp.data_ptr(), rank * n_per, n_gen, seed=42)
         else:
             gen_bytes = int(starts[n_gen])
-            tmp = torch.empty(gen_bytes + 64, dtype=torch.uint8, device=dev)
+        room = max(self.tail + self.n_own_bytes + self.head, self.tail - a + gen_bytes) + 64
+        self.ext = torch.empty(room, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        if kind == "single":
+            ctx.synth_single(self.ext.data_ptr() + self.tail - a, rank * n_per, n_gen, seed=42)
+        else:
             dstart = torch.from_numpy(starts[:n_gen + 1].copy()).to(dev)
             torch.cuda.synchronize()
-            ctx.synth_wrapped(tmp.data_ptr(), dstart.data_ptr(), rank * n_per, n_gen, seed=43)
+            ctx.synth_wrapped(self.ext.data_ptr() + self.tail - a, dstart.data_ptr(), rank * n_per, n_gen, seed=43)
             self.starts = starts
-        self.ext = torch.zeros(self.tail + self.n_own_bytes + self.head + 64, dtype=torch.uint8, device=dev)
-        a = self.own_lo - self.block_start
-        self.ext[self.tail:self.tail + self.n_own_bytes] = tmp[a:a + self.n_own_bytes]
-        del tmp
+        self.ext[:self.tail].zero_()
+        self.ext[self.tail + self.n_own_bytes:].zero_()
         torch.cuda.synchronize()
         self.ext_scanned_bytes = self.tail + self.n_own_bytes + self.head
         min_rec = 322 if kind == "single" else 120
@@ -606,10 +612,12 @@ class SyntheticShard:
         # ownership is by '@' position: the first owned record is the first whose start >= own_lo
         if self.kind == "single":
             k0 = -(-self.own_lo // 322)
-            k = torch.arange(k0, k0 + n, dtype=torch.int64, device=rows.device) * 322
-            want = torch.stack([k, k + 17, k + 18, k + 168, k + 171, k + 321], dim=1)
             assert n == -(-self.own_hi // 322) - k0, "record count differs from the closed form"
-            assert bool((rows == want).all()), "offset table differs from the closed form"
+            col = torch.tensor([0, 17, 18, 168, 171, 321], dtype=torch.int64, device=rows.device)
+            for c0 in range(0, n, 1 << 24):            # (in pieces: at 100 GiB the table is 16 GB)
+                c1 = min(n, c0 + (1 << 24))
+                k = torch.arange(k0 + c0, k0 + c1, dtype=torch.int64, device=rows.device) * 322
+                assert bool((rows[c0:c1] == k[:, None] + col[None, :]).all()), "offset table differs from the closed form"
         else:
             st = torch.from_numpy(self.starts).to(rows.device) + self.block_start
             k0 = int(np.searchsorted(self.starts + self.block_start, self.own_lo, side="left"))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FFQ_ABI_VERSION 2
+#define FFQ_ABI_VERSION 3
 
 /* scanner status codes -- identical to the reference's module constants
  * (_fastqandfurious.c:7-15,254-262; fastqandfurious.py:19-27)             */
@@ -97,6 +97,11 @@ typedef struct ffq_scan_result {
 
 /* ---- library / context ------------------------------------------------ */
 int         ffq_abi_version(void);
+/* Hash (16 hex digits) of the sources this binary was compiled from: csrc/ and include/ of this
+ * repository, computed by build.py and baked in at compile time.  The Python host recomputes it
+ * from the tree and rebuilds (or refuses to run) when the two differ, so a stale in-tree .so
+ * cannot stand in for the sources.                                                             */
+const char *ffq_build_id(void);
 const char *ffq_last_error(void);
 int         ffq_device_count(void);
 /* device = HIP ordinal.  Fails (FFQ_E_NODEVICE) if it is not a gfx950 part. */
@@ -278,15 +283,6 @@ int ffq_synth_single(ffq_ctx *ctx, uint8_t *d_out, int64_t first, int64_t count,
 int64_t ffq_synth_wrapped_size(int64_t i, uint64_t seed);
 int ffq_synth_wrapped(ffq_ctx *ctx, uint8_t *d_out, const int64_t *d_start,
                       int64_t first, int64_t count, uint64_t seed);
-
-/* Measured streaming-read ceiling of the device in the scan kernel's launch geometry
- * (mode 0) or as a grid-stride loop (mode 1): average ms over `reps` launches of a
- * kernel that only reads n_bytes (rounded down to 16 KiB); mode 6: mode 0 with non-temporal
- * loads.  Modes 2 / 3 / 4: the line-index kernel itself without the rest of a scan, launched
- * back to back / between its own pair of events / the same on a buffer with a ragged last
- * tile.  Diagnostics.                                                                    */
-int ffq_read_probe(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes, int mode, int reps,
-                   float *ms_avg);
 
 /* ---- diagnostics ---------------------------------------------------------
  * Runs the device self-checks (wave scan, newline mask) and returns FFQ_OK.  */

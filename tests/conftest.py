@@ -38,7 +38,8 @@ def pkg():
 @pytest.fixture(scope="session")
 def gpu_ctx(pkg):
     from fastqandfurious_amd import build, hip
-    build.build()
+    build.build()                                    # (rebuilds iff the in-tree library's build id is not the sources')
+    assert hip.build_id() == build.source_id(), "libffq_hip.so was not built from the sources in this tree"
     ctx = hip.default_context(0)
     return ctx
 

@@ -1,0 +1,72 @@
+"""Worker of tests/test_config5.py: one process, backend nccl (= RCCL), world size 1."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+import fastqandfurious_amd  # noqa: F401
+from fastqandfurious_amd import hip, sharded
+
+
+def main(mode):
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend="nccl", device_id=dev)
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    tr = sharded.DistTransport(dist, None, dev)
+    assert not tr.gloo
+    if mode == "transport":
+        # the eight hand-off words through all_gather_into_tensor on device tensors
+        words = [5 * (1 << 32) + 7, -1, -2, 0, 1 << 20, 0, 0, (1 << 40) + 3]
+        assert tr.allgather(words) == [words]
+        tr.exchange([], None, None)                  # no peers: no P2P op, no hang
+        # a sharded step of bench.py's shard over this transport (world 1), plain and pipelined
+        ctx = hip.Context(0)
+        sh = sharded.SyntheticShard(ctx, "single", 256 << 20, 0, 1, dev, transport=tr)
+        ctx.reserve(sh.ext.numel())
+        table = torch.empty((sh.max_records + 64, 6), dtype=torch.int64, device=dev)
+        out = sh.scan(table)
+        sh.verify(table, out)
+        assert out.record_base == 0 and out.total_records == out.n_own_records
+        sh.make_lanes(2)
+        tabs = (table, torch.empty_like(table))
+        sh.submit(0, tabs[0])
+        for i in range(1, 4):
+            sh.submit(i & 1, tabs[i & 1])
+            sh.verify(tabs[(i - 1) & 1], sh.finish((i - 1) & 1))
+        sh.verify(tabs[1], sh.finish(1))
+        # ordering: an RCCL collective on the hand-off stream writes the first MiB of the buffer, the
+        # scan stream waits for its end event (HipBackend.comm_context) -- the rows can only come out
+        # right if the scan read what the collective wrote
+        be = sharded.HipBackend(ctx)
+        good = sh.ext[:1 << 20].clone()
+        for rep in range(8):
+            sh.ext[:1 << 20].zero_()
+            torch.cuda.synchronize()
+            with be.comm_context(sh.ext):
+                dist.all_gather_into_tensor(sh.ext[:1 << 20], good)
+            rc, res = ctx.scan_device(sh.ext.data_ptr(), sh.n_own_bytes, table.data_ptr(), table.shape[0])
+            assert rc == hip.OK and int(res.n_records) == out.n_own_records, (rep, int(res.n_records))
+            k = torch.arange(0, 4096, dtype=torch.int64, device=dev) * 322
+            assert bool((table[:4096, 0] == k).all()), "the scan ran ahead of the collective on the hand-off stream"
+        print("nccl transport ok", flush=True)
+    else:
+        a = torch.arange(1 << 20, dtype=torch.uint8, device=dev) if False else (torch.arange(1 << 20, device=dev) % 251).to(torch.uint8)
+        b = torch.zeros_like(a)
+        try:
+            tr.exchange([(0, 0, 0, 1 << 20)], lambda lo, hi: a[lo:hi], lambda lo, hi: b[lo:hi])
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001
+            print("self-p2p unsupported: %r" % (e,), flush=True)
+            sys.exit(3)
+        assert bool((a == b).all())
+        print("nccl self p2p ok", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -31,8 +31,47 @@ def test_library_exports_every_declared_symbol(hip):
     assert sorted(hip.SYMBOLS) == names
 
 
+def test_probe_library_exports_its_header(hip):
+    """include/ffq_probe.h is served by the instrumented build only (tools; bench.py's hbm_read_probe)."""
+    from fastqandfurious_amd import build
+    text = open(os.path.join(ROOT, "include", "ffq_probe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(ffq_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["ffq_read_probe"]
+    L = ctypes.CDLL(build.build_probe())
+    for name in names + declared_symbols():
+        assert hasattr(L, name), name
+    L.ffq_build_id.restype = ctypes.c_char_p
+    assert L.ffq_build_id().decode() == build.source_id() + "+probes"
+
+
+def test_build_id_is_the_hash_of_the_sources(hip, tmp_path):
+    """ffq_build_id() = hash of csrc/ + include/ baked in at compile time; the loader rebuilds or refuses
+    on a mismatch, so the GPU box cannot run a stale in-tree binary in place of the sources."""
+    from fastqandfurious_amd import build
+    want = build.source_id()
+    assert len(want) == 16 and build.built_id(hip.LIB_PATH) == want
+    assert hip.lib().ffq_build_id().decode() == want == hip.build_id()
+    # a library built from other sources is recognised without loading it
+    other = tmp_path / "libother.so"
+    blob = open(hip.LIB_PATH, "rb").read()
+    other.write_bytes(blob.replace(b"FFQ_BUILD_ID=" + want.encode(), b"FFQ_BUILD_ID=" + b"0" * 16))
+    assert build.built_id(str(other)) == "0" * 16 and build.needs_build(str(other))
+
+
+def test_probes_are_not_in_the_product_library(hip):
+    """Probe kernels / entry points live in libffq_probe.so (include/ffq_probe.h), not in the product."""
+    L = ctypes.CDLL(hip.LIB_PATH)
+    assert not hasattr(L, "ffq_read_probe")
+    blob = open(hip.LIB_PATH, "rb").read()
+    for name in (b"k_pipe_probe", b"k_read_probe"):
+        assert name not in blob, name
+    text = open(os.path.join(ROOT, "include", "ffq.h")).read()
+    assert "ffq_read_probe" not in text
+
+
 def test_abi_version_and_status_codes(hip):
-    assert hip.lib().ffq_abi_version() == 2
+    assert hip.lib().ffq_abi_version() == hip.ABI_VERSION
     text = open(os.path.join(ROOT, "include", "ffq.h")).read()
     for name, val in (("FFQ_INVALID", "(-1)"), ("FFQ_COMPLETE", "6"), ("FFQ_MISSING_QUALHEADER_END", "7"),
                       ("FFQ_POS_QUAL_END", "5")):

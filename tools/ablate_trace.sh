@@ -1,4 +1,5 @@
 #!/bin/bash
+export FFQ_USE_PROBE_BUILD=1   # the ablation switches exist only in libffq_probe.so
 # per-kernel time of the scan pipeline under each ablation level of k_chain_wave
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp

@@ -3,6 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import fastqandfurious_amd
 from fastqandfurious_amd import hip, synth
+hip.use_probe_build()          # the instrumented build (libffq_probe.so): probes and ablation switches live there
 os.environ['FFQ_DEBUG'] = '1'
 ctx = hip.Context(0)
 data, start = synth.wrapped(0, 2000, seed=43)

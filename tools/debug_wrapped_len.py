@@ -3,6 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import fastqandfurious_amd
 from fastqandfurious_amd import hip
+hip.use_probe_build()          # the instrumented build (libffq_probe.so): probes and ablation switches live there
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 size = 4 << 20
 rng = np.random.default_rng(0)

@@ -5,6 +5,7 @@ import numpy as np
 import torch
 import fastqandfurious_amd
 from fastqandfurious_amd import hip
+hip.use_probe_build()          # the instrumented build (libffq_probe.so): probes and ablation switches live there
 levels = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7".split(","))]
 nbytes = int(float(sys.argv[2])) if len(sys.argv) > 2 else (1 << 30)
 ctx = hip.Context(0)

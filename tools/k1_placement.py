@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import fastqandfurious_amd
 from fastqandfurious_amd import hip
+hip.use_probe_build()          # the instrumented build (libffq_probe.so): probes and ablation switches live there
 nbytes = int(float(sys.argv[1])) if len(sys.argv) > 1 else (1 << 30)
 n = nbytes // 322
 c0 = hip.Context(0)

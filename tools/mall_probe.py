@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import fastqandfurious_amd
 from fastqandfurious_amd import hip
+hip.use_probe_build()          # the instrumented build (libffq_probe.so): probes and ablation switches live there
 ctx = hip.Context(0)
 MIB = 1 << 20
 big = torch.empty(2048 * MIB + 64, dtype=torch.uint8, device='cuda')

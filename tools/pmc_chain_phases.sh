@@ -1,4 +1,5 @@
 #!/bin/bash
+export FFQ_USE_PROBE_BUILD=1   # the ablation switches exist only in libffq_probe.so
 # VALU / SALU / LDS instructions per wave of k_chain_wave cut short after each phase (FFQ_ABLATE 1..4, 0 = whole)
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp

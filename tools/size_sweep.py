@@ -5,6 +5,7 @@ import numpy as np
 import torch
 import fastqandfurious_amd
 from fastqandfurious_amd import hip
+hip.use_probe_build()          # the instrumented build (libffq_probe.so): probes and ablation switches live there
 ctx = hip.Context(0)
 nmax = (10 << 30) // 322
 buf = torch.empty(nmax * 322 + 64, dtype=torch.uint8, device='cuda')
