@@ -234,6 +234,61 @@ def stream_inclusive(ctx, sample_u8, fbufsize=1 << 24):
                                "scanner) over the same file, %.1f s" % (n_it, el_it)}
 
 
+def iterator_rates(sample_u8, budget_s=3.0):
+    """The drop-in iterator as a user of the reference calls it -- readfastq_iter(fh, fbufsize, entryfunc,
+    entrypos) with this package's GPU scanner -- at the reference's own buffer size (50 000 bytes:
+    /root/reference/src/demo/benchmark.py:415; reads are coalesced into k * fbufsize per device call)
+    and at 16 MiB, over a plain file and over a gzip file (inflated by the library's reader thread),
+    with the default entryfunc and with entryfunc_phred (the user guide's decode, from the device's
+    bulk decode).  M reads/s of Python tuples on one host core; beside each gzip figure the
+    reference's own C scanner through the per-record loop over the same gzip file (oracle/_ref),
+    when that binary is there."""
+    import gzip
+    import tempfile
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    plain = os.path.join(d, "ffq_iter_%d.fq" % os.getpid())
+    gz = plain + ".gz"
+    n_gz = min(sample_u8.size, 96 << 20) // 322 * 322
+    with open(plain, "wb") as fh:
+        fh.write(sample_u8.tobytes())
+    with gzip.open(gz, "wb", compresslevel=1) as fh:
+        fh.write(sample_u8[:n_gz].tobytes())
+
+    def rate(opener, fbufsize, entryfunc, scanner):
+        n, t0 = 0, time.perf_counter()
+        with opener() as fh:
+            for _e in F.readfastq_iter(fh, fbufsize, entryfunc, scanner):
+                n += 1
+                if (n & 0xFFFF) == 0 and time.perf_counter() - t0 > budget_s:
+                    break
+        return round(n / (time.perf_counter() - t0) / 1e6, 3)
+
+    out = {"unit": "M reads/s", "cores": 1,
+           "what": "readfastq_iter(fh, fbufsize, entryfunc, GPU scanner): Python tuples per second, one host core; "
+                   "plain = %d-byte file in %s, gzip = its first %d bytes at level 1" % (sample_u8.size, d, n_gz)}
+    try:
+        for tag, opener in (("plain", lambda: open(plain, "rb")), ("gzip", lambda: gzip.open(gz, "rb"))):
+            for fb in (50000, 1 << 24):
+                out["%s_fbufsize_%d" % (tag, fb)] = rate(opener, fb, F.entryfunc, C.entrypos)
+            out["%s_phred_fbufsize_50000" % tag] = rate(opener, 50000, F.entryfunc_phred, C.entrypos)
+        try:
+            from oracle import refload
+            if refload.have_reference_ext():
+                ext = refload.load_ext()
+                out["reference_c_plain_fbufsize_50000"] = rate(lambda: open(plain, "rb"), 50000, F.entryfunc, ext.entrypos)
+                out["reference_c_gzip_fbufsize_50000"] = rate(lambda: gzip.open(gz, "rb"), 50000, F.entryfunc, ext.entrypos)
+        except Exception as e:      # noqa: BLE001
+            out["reference_c_error"] = repr(e)
+    finally:
+        for f in (plain, gz):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+    return out
+
+
 def pmc_traffic(workload, kernel="k_scan_lines<"):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this
     workload (profiles/*/pmc_fetch_write.json): FETCH_SIZE and WRITE_SIZE are KiB; on gfx950
@@ -278,7 +333,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
 
     # ---- this rank's byte range of the logical stream, generated in HBM ----------
     split = bool(wl.get("split"))                   # the workload's bytes are the whole job's, not one GPU's
-    shard = sharded.SyntheticShard(ctx, wl["kind"], wl["bytes"] // world if split else wl["bytes"], rank, world, dev)
+    shard = sharded.SyntheticShard(ctx, wl["kind"], wl["bytes"] // world if split else wl["bytes"], rank, world, dev,
+                                   total_records=wl["bytes"] // 322 if split else None)
     n_own = shard.n_own_bytes
     ctx.reserve(shard.ext.numel())
     table = torch.empty((shard.max_records + 64, 6), dtype=torch.int64, device=dev)
@@ -617,6 +673,7 @@ def main():
             line["cpu_baseline"]["reference_c_iterator"] = cpu_reference_iter(sample.tobytes(), 3.0)
             line["host_inclusive"] = host_inclusive(ctx, sample, flags)
             line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, shard.host_sample(1 << 30))
+            line["host_inclusive"]["iterator"] = iterator_rates(sample)
             del sample
         else:
             line["cpu_baseline"] = None

@@ -92,15 +92,39 @@ class _GpuEntrypos:
         self._next_offset = None        # the chain has ended: rescan on the next call
         return status
 
-    # -- stream protocol: a real file is read, carried and scanned by the library itself -------
-    def open_stream(self, fh, fbufsize):
+    # -- stream protocol: the source is read, carried and scanned by the library itself ----------
+    # Buffer fills are scanned whole, and the entries do not depend on how the stream is cut into fills
+    # (fastqandfurious.py:274-279 carries every unfinished entry over): reads of the reference's
+    # advised 20-50 kB (fastqandfurious.py:229, benchmark.py:415) are therefore COALESCED -- the
+    # library reads k * fbufsize bytes per fill, the smallest multiple that reaches this many bytes --
+    # instead of paying a host-to-device copy, four kernel launches and a copy back per 150 records.
+    coalesce_bytes = 8 << 20
+
+    def chunk_bytes(self, fbufsize):
+        fbufsize = max(int(fbufsize), 1)
+        if fbufsize >= self.coalesce_bytes:
+            return fbufsize
+        return fbufsize * -(-self.coalesce_bytes // fbufsize)
+
+    def open_stream(self, fh, fbufsize, decode=False):
+        """The native stream front end over `fh`, or None (no read() at all):
+        a plain file -> the library reads the descriptor itself (reader threads, pread);
+        a fresh GzipFile over a plain file -> the library inflates it itself (zlib in the reader thread);
+        anything else with readinto() / read() -> chunks are read here, straight into pinned memory.
+        decode: every fill's qualities are decoded on the device (FileStream.quals())."""
         from .index import _fileno, _leave_at
+        chunk = self.chunk_bytes(fbufsize)
         f = _fileno(fh)
-        if f is None:
+        if f is not None:
+            st = _hip.FileStream(self._context(), f[0], chunk, decode=decode, start=f[1])
+            st.on_close = lambda: _leave_at(fh, st)
+            return st
+        g = _gzip_fileno(fh)
+        if g is not None:
+            return _hip.FileStream(self._context(), g[0], chunk, decode=decode, start=g[1], gzip=True)
+        if getattr(fh, "readinto", None) is None and getattr(fh, "read", None) is None:
             return None
-        st = _hip.FileStream(self._context(), f[0], fbufsize, start=f[1])
-        st.on_close = lambda: _leave_at(fh, st)
-        return st
+        return _hip.PushStream(self._context(), fh, chunk, decode=decode)
 
     # -- batched protocol used by this package's readfastq_iter ------------
     def scan_buffer(self, buf, offset, eof):
@@ -108,6 +132,25 @@ class _GpuEntrypos:
         rows = array('q')
         rows.frombytes(np.ascontiguousarray(table).tobytes())
         return rows, int(res.end_state), int(res.end_offset)
+
+
+def _gzip_fileno(fh):
+    """(fd, start) of the COMPRESSED file under a gzip.GzipFile that has not been read from yet and
+    sits on a plain file -- what gzip.open(path) / FORMAT_OPENERS['gz'] return -- else None."""
+    import gzip
+    import io
+    if not isinstance(fh, gzip.GzipFile) or getattr(fh, "mode", None) != gzip.READ:
+        return None
+    raw = getattr(fh, "fileobj", None)
+    base = raw.raw if isinstance(raw, io.BufferedReader) else raw
+    if not isinstance(base, io.FileIO):
+        return None
+    try:
+        if fh.tell() != 0:                       # (decompressed position: something was consumed already)
+            return None
+        return raw.fileno(), raw.tell()
+    except (OSError, ValueError, AttributeError):
+        return None
 
 
 entrypos = _GpuEntrypos()

@@ -102,7 +102,7 @@ def _compile(out, extra, verbose):
     sid = source_id()
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wall", "-Wno-unused-function", '-DFFQ_BUILD_ID="%s"' % sid] + extra + \
-          ["-o", out + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+          ["-o", out + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz"]      # zlib: the gzip feeder (ffq_stream.h)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

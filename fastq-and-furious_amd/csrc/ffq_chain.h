@@ -98,6 +98,8 @@ struct DevRes {
     int32_t bad_irregular;   // that group does not fit this configuration's LDS budget (vs a wrong guess)
     int32_t n_bad;       // groups whose guess was not confirmed (or that did not fit), all of them
     int64_t approx_records;   // records the groups counted, confirmed or not (how long the records are, roughly)
+    int32_t fast4_hint;  // written by k_finalize4 only: 1 = the four-line fast path stood on this buffer (probe scans)
+    int32_t pad_;
 };
 
 // Result hand-over.  The last result-writing kernel of a scan copies the result block and the

@@ -81,7 +81,65 @@ done:
     return list;
 }
 
+/* entries_phred(buf, rows, shift, qual, qoff, array_type) -> [(header, sequence, array('b')), ...]
+ * What the reference's documented decode builds per record in an entryfunc of the user's own,
+ *     quality = array('b'); quality.frombytes(buf[pos[4]:pos[5]]); arrayadd_b(quality, -33)
+ * (/root/reference/doc/user-guide.rst:126-141, :206-214), for a whole table at once: the decoded
+ * bytes come from the stream's bulk decode on the device -- qual (int8) with CSR offsets qoff
+ * (int64, one more than rows) -- and are only wrapped here.  array_type: array.array.            */
+static PyObject *entries_phred(PyObject *self, PyObject *args)
+{
+    Py_buffer buf, rows, qual, qoff;
+    long long shift = 0;
+    PyObject *atype = NULL;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "y*y*Ly*y*O", &buf, &rows, &shift, &qual, &qoff, &atype)) return NULL;
+    PyObject *list = NULL;
+    const Py_ssize_t n = rows.len / 48;
+    if (rows.len % 48 != 0 || qoff.len < (n + 1) * 8) {
+        PyErr_SetString(PyExc_ValueError, "rows must hold six int64 positions per record and qoff one offset more than rows");
+        goto done;
+    }
+    {
+        const int64_t *p = (const int64_t *)rows.buf;
+        const int64_t *o = (const int64_t *)qoff.buf;
+        const char *base = (const char *)buf.buf;
+        list = PyList_New(n);
+        if (!list) goto done;
+        for (Py_ssize_t i = 0; i < n; i++, p += 6) {
+            if (o[i] < 0 || o[i + 1] < o[i] || o[i + 1] > (int64_t)qual.len) {
+                PyErr_SetString(PyExc_ValueError, "quality offsets do not fit the decoded stream");
+                Py_CLEAR(list);
+                goto done;
+            }
+            PyObject *h = cut(base, buf.len, p[0] - shift + 1, p[1] - shift);
+            PyObject *s = cut(base, buf.len, p[2] - shift, p[3] - shift);
+            PyObject *qb = PyBytes_FromStringAndSize((const char *)qual.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]));
+            PyObject *q = qb ? PyObject_CallFunction(atype, "sO", "b", qb) : NULL;
+            Py_XDECREF(qb);
+            PyObject *t = !(h && s && q) ? NULL : PyTuple_New(3);
+            if (!t) {
+                Py_XDECREF(h); Py_XDECREF(s); Py_XDECREF(q);
+                Py_CLEAR(list);
+                goto done;
+            }
+            PyTuple_SET_ITEM(t, 0, h);
+            PyTuple_SET_ITEM(t, 1, s);
+            PyTuple_SET_ITEM(t, 2, q);
+            PyList_SET_ITEM(list, i, t);
+        }
+    }
+done:
+    PyBuffer_Release(&buf);
+    PyBuffer_Release(&rows);
+    PyBuffer_Release(&qual);
+    PyBuffer_Release(&qoff);
+    return list;
+}
+
 static PyMethodDef methods[] = {
+    {"entries_phred", entries_phred, METH_VARARGS,
+     "entries_phred(buf, rows, shift, qual, qoff, array_type) -> list of (header, sequence, array('b') of decoded qualities)"},
     {"entries", entries, METH_VARARGS,
      "entries(buf, rows, shift=0, hskip=1, cls=None) -> list of (header, sequence, quality) bytes tuples, one per row of six int64 positions"},
     {NULL, NULL, 0, NULL}};

@@ -54,6 +54,7 @@ struct ScanState {
     int retries = 0;
     int repairs = 0;          // repair passes of the general kernels (reported with retries)
     bool dense_cfg = false, fast4_failed = false;
+    bool probe4 = false;      // the front carries the fast path's kernels as a probe (see ffq_ctx::fast4_skip)
     unsigned long long poll_seq = 0;   // FFQ_F_POLL_RESULT: the front ends in a publisher that writes this number; no end event
     bool go_ranked = false;   // the front is the index kernel only: the list-ranking tier follows at the wait
     bool index_done = false;  // the line index of this buffer is built (a later tier re-uses it)
@@ -68,9 +69,11 @@ struct ffq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int fast4_skip = 0;                  // scans left that go straight to the general kernels (see scan_finish)
-    int fast4_backoff = 15;              // how many the next failed attempt sets: doubles per consecutive failure (a stream
-                                         // of wrapped records retries the fast path ever more rarely), back to 15 on success
+    bool fast4_remember = false;         // the recent input was not plain four-line: scans start with the general kernels
+    int fast4_skip = 0;                  //   ... and this many of them do so without asking again; the one after is a PROBE
+                                         //   scan: general kernels as before, the fast path's kernels in front of them just
+                                         //   to see whether they would have stood (DevRes::fast4_hint) -- no host round trip,
+                                         //   no second front, whichever way it comes out
     int ranked_skip = 0;                 // scans left that go straight to the list-ranking tier (long records)
     RankBufs rk = {};                    // its scratch (ffq_ranked.h), grow-only
     int64_t rk_cap_tiles = 0, rk_cap_c = 0;
@@ -398,7 +401,7 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 
 extern "C" void ffq_ctx_forget(ffq_ctx *c)
 {
-    if (c) { c->fast4_skip = 0; c->fast4_backoff = 15; c->dense_skip = 0; c->ranked_skip = 0; }
+    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->ranked_skip = 0; }
 }
 
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
@@ -656,7 +659,12 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     // (nor while the context remembers that its recent input was not four-line)
     if (c->ranked_skip > 0 && !serial && !st.index_done && ablate == 0) { c->ranked_skip--; st.go_ranked = true; }
     if ((a.flags & FFQ_F_FORCE_RANKED) && !serial) st.go_ranked = true;
-    if (c->fast4_skip > 0 && !st.fast4_failed) { c->fast4_skip--; st.fast4_failed = true; }
+    st.probe4 = false;
+    if (c->fast4_remember && !st.fast4_failed) {
+        st.fast4_failed = true;
+        if (c->fast4_skip > 0) c->fast4_skip--;
+        else st.probe4 = !serial && !st.go_ranked && !st.index_done && ablate == 0;
+    }
     if (c->dense_skip > 0 && !st.dense_cfg && !st.index_done) { c->dense_skip--; st.dense_cfg = true; }
     const bool try_fast4 = !serial && !st.go_ranked && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
                            getenv("FFQ_NO_FAST4") == nullptr;
@@ -710,6 +718,23 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         c->ctl_clean = true;
         st.stage = 1;
     } else {
+        if (st.probe4) {
+            // has the input turned plain four-line again?  The fast path's kernels (rows into the caller's
+            // table, which the general kernels then write again; no decode tail), their verdict left in
+            // DevRes::fast4_hint for the publisher of the general path to carry out
+            const unsigned int *presum = nullptr;
+            if (nsb > 2048) {
+                hipLaunchKernelGGL(k_sum64, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, sA, (const uint32_t *)c->cnt, 1,
+                                   (int64_t)ntiles, c->sbq, nsb);
+                presum = c->sbq;
+            }
+            hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
+            hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
+                               (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
+                               (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, (int64_t)0);
+            hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
+                               a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres, no_pub(c));
+        }
         if (!serial && !st.go_ranked) {
             int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups, true);
             if (rc) return rc;
@@ -858,17 +883,22 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         }
 
         const bool tiers = !serial && !st.go_ranked;       // the group kernels ran: their fallbacks apply
+        if (st.probe4) {
+            // the probe's verdict: the next scan starts with the fast path again, or 15 more do not ask
+            st.probe4 = false;
+            if (c->h_res->fast4_hint == 1) { c->fast4_remember = false; c->fast4_skip = 0; }
+            else c->fast4_skip = 15;
+        }
         if (st.stage == 1) {
             if (!c->h_res->fallback) {
                 fill_result(res, *c->h_res, 3, st.retries);
-                c->fast4_backoff = 15;
                 break;
             }
             // not plain four-line input: the general kernels, from the same line index.  The next
             // scans of this context skip the attempt (and the host round trip it costs here).
             st.fast4_failed = true;
-            c->fast4_skip = c->fast4_backoff;
-            c->fast4_backoff = std::min(2 * c->fast4_backoff + 1, 4095);
+            c->fast4_remember = true;
+            c->fast4_skip = 15;
             HIPCHK(hipEventRecord(c->ev[4], sA));
             int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups);
             if (rc) return rc;
@@ -968,6 +998,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             if (rr == 2) {
                 c->ranked_skip = 0;
                 c->fast4_skip = 0;           // (the input has changed character: what is remembered of it is void)
+                c->fast4_remember = false;
                 st.go_ranked = false;
                 st.fast4_failed = false;
                 continue;                    // the usual tiers, from the line index that is there

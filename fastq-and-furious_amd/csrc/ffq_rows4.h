@@ -629,8 +629,9 @@ __global__ void k_finalize4(LineIndex L, Fast4Hdr *hdr, const TermInfo4 *__restr
     res->has_final = 0;
     const unsigned long long tm = hdr->term_min, im = hdr->irr_min;
     const unsigned long long tk = tm >> 24;
-    if (!hdr->attempt || tm == ~0ull || (im != ~0ull && im <= tk)) { res->fallback = 1; publish(pb, res); return; }
+    if (!hdr->attempt || tm == ~0ull || (im != ~0ull && im <= tk)) { res->fallback = 1; res->fast4_hint = 0; publish(pb, res); return; }
     res->fallback = 0;
+    res->fast4_hint = 1;
     const int tt = (int)(tm & 0xFFFFFF);
     const TermInfo4 ti = tinfo[tt];
     const int status = ti.status;

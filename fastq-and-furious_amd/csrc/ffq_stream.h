@@ -19,9 +19,22 @@
 // moved to align anything.  Each call of ffq_stream_next hands back the rows (absolute stream
 // offsets, what entryfunc_abspos yields, :186-195) of one buffer fill and the fill's bytes for
 // slicing; both stay valid until the next call.
+//
+// Three kinds of source feed the same slots:
+//   a descriptor        the feeder thread: pread in parallel slices (regular files), or read()
+//                       behind poll() (pipes: interruptible, and a chunk is handed over short when
+//                       nothing more has arrived for a while -- a short chunk is not the end)
+//   a gzip descriptor   the feeder thread inflates (zlib; concatenated members) straight into the
+//                       pinned slot: decompression is the feeder stage, no interpreter involved
+//                       (reference: FORMAT_OPENERS / automagic_open, fastqandfurious.py:282-334)
+//   pushed chunks       no feeder thread: the host writes every chunk into the slot's pinned memory
+//                       itself (ffq_stream_push_buffer / ffq_stream_push) -- any Python file-like
+//                       object (BytesIO, bz2, lzma ...) read with readinto(), no bytes copy
 #pragma once
 #include <errno.h>
+#include <poll.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -36,7 +49,8 @@ struct StreamSlot {
     uint8_t *d = nullptr;        // device  same layout
     hipEvent_t copied[2] = {nullptr, nullptr};   // the chunk's H2D copy is through (one half per copy stream)
     int64_t got = 0;             // bytes of the chunk (at offset room)
-    bool eof = false;            // a short read: the descriptor is exhausted
+    bool eof = false;            // the source is exhausted behind this chunk
+    int64_t end_pos = 0;         // position of the source behind this chunk (ffq_stream_tell)
     ChunkRead cr;                // its slices while they are being read
 };
 
@@ -110,11 +124,22 @@ static hipError_t stream_copy_chunk(StreamBufs *b, StreamSlot &sl, int64_t got)
     return e;
 }
 
+constexpr int SRC_FD = 0, SRC_GZIP = 1, SRC_PUSH = 2;
+constexpr int64_t GZ_IN = 1 << 20;      // compressed bytes read per refill
+
 struct ffq_stream {
     ffq_ctx *c = nullptr;
     StreamBufs *b = nullptr;
     int fd = -1;
+    int src = SRC_FD;
     bool seekable = false;
+    // ---- gzip source (feeder thread only) ----
+    z_stream zs;
+    bool z_init = false, z_member = false, z_in_eof = false;
+    uint8_t *zin = nullptr;
+    int64_t zin_len = 0, zin_pos = 0, z_filepos = 0;
+    std::string z_msg;
+    int64_t handed_pos = 0;             // position of the source behind the last chunk handed out
     uint32_t flags = 0;                 // FFQ_F_DECODE_QUAL: qualities decoded per fill
     int qual_add = -33;
     // ---- feeder <-> caller (under m) ----
@@ -144,6 +169,79 @@ static inline double stream_now()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// One chunk from a descriptor that cannot seek (a pipe, a socket): read() behind poll(), so that a
+// request to stop or to park (stream_grow_room) is seen within 50 ms even when the writer keeps the
+// pipe open and idle.  Returns the bytes read; *eof: read() returned 0.  A chunk is handed over SHORT
+// (not eof) when something was read and then nothing arrived for 50 ms, or a pause was asked for:
+// records reach the caller as they come in.  -2: asked to stop / park before anything was read.
+// -1: error (errno).
+static int64_t stream_fd_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
+{
+    int64_t got = 0;
+    *eof = false;
+    while (got < n) {
+        bool stop, pause;
+        { std::lock_guard<std::mutex> lk(s->m); stop = s->stop; pause = s->pause_req; }
+        if (stop || pause) return got > 0 ? got : -2;
+        struct pollfd pf = {s->fd, POLLIN, 0};
+        const int pr = poll(&pf, 1, 50);
+        if (pr < 0) { if (errno == EINTR) continue; return -1; }
+        if (pr == 0) { if (got > 0) return got; continue; }
+        const ssize_t r = read(s->fd, dst + got, (size_t)(n - got));
+        if (r < 0) { if (errno == EINTR || errno == EAGAIN) continue; return -1; }
+        if (r == 0) { *eof = true; break; }
+        got += r;
+    }
+    return got;
+}
+
+// One chunk of the DECOMPRESSED stream of a gzip file (RFC 1952; members may be concatenated, as
+// bgzip and `cat a.gz b.gz` produce them; zero padding behind the last member is ignored).  Fills
+// dst completely unless the stream ends (*eof).  -1: error, s->z_msg says what.
+static int64_t stream_gz_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
+{
+    int64_t got = 0;
+    *eof = false;
+    while (got < n) {
+        { std::lock_guard<std::mutex> lk(s->m); if (s->stop) break; }
+        if (s->zin_pos == s->zin_len && !s->z_in_eof) {
+            const int64_t r = ReadPool::read_full(s->fd, s->zin, GZ_IN, s->z_filepos, s->seekable);
+            if (r < 0) { s->z_msg = std::string("read failed: ") + strerror(errno); return -1; }
+            s->z_filepos += r;
+            s->zin_len = r; s->zin_pos = 0;
+            if (r < GZ_IN) s->z_in_eof = true;
+        }
+        if (!s->z_member) {
+            // between members: zero padding, then the next member or the end of the file
+            while (s->zin_pos < s->zin_len && s->zin[s->zin_pos] == 0) s->zin_pos++;
+            if (s->zin_pos == s->zin_len) {
+                if (s->z_in_eof) { *eof = true; break; }
+                continue;
+            }
+            if (inflateReset(&s->zs) != Z_OK) { s->z_msg = "inflateReset failed"; return -1; }
+            s->z_member = true;
+        } else if (s->zin_pos == s->zin_len && s->z_in_eof) {
+            s->z_msg = "compressed file ended before the end-of-stream marker was reached";
+            return -1;
+        }
+        s->zs.next_in = s->zin + s->zin_pos;
+        s->zs.avail_in = (uInt)(s->zin_len - s->zin_pos);
+        s->zs.next_out = dst + got;
+        s->zs.avail_out = (uInt)std::min<int64_t>(n - got, 1 << 30);
+        const uInt out0 = s->zs.avail_out;
+        const int zr = inflate(&s->zs, Z_NO_FLUSH);
+        s->zin_pos = s->zin_len - (int64_t)s->zs.avail_in;
+        got += (int64_t)(out0 - s->zs.avail_out);
+        if (zr == Z_STREAM_END) s->z_member = false;
+        else if (zr != Z_OK && zr != Z_BUF_ERROR) {
+            s->z_msg = s->zs.msg ? s->zs.msg : (zr == Z_DATA_ERROR ? "not a gzip file / corrupt data" : "inflate failed");
+            return -1;
+        }
+    }
+    if (got == n && !*eof && s->zin_pos == s->zin_len && s->z_in_eof && !s->z_member) *eof = true;   // ended exactly at the chunk's end
+    return got;
+}
+
 // The feeder: queues the slices of chunk e as soon as slot e % STREAM_SLOTS is free (up to two
 // chunks being read at a time), and completes chunks in order: once the last slice of chunk p is
 // in, its H2D copy goes onto the copy stream and the caller may take it.
@@ -167,7 +265,7 @@ static void stream_feeder(ffq_stream *s)
                         continue;
                     }
                     s->paused = false;
-                    if (e > p || (s->seekable ? e : p) - s->released < STREAM_SLOTS) break;   // a read to wait for, or a free slot
+                    if (e > p || ((s->seekable && s->src == SRC_FD) ? e : p) - s->released < STREAM_SLOTS) break;   // a read to wait for, or a free slot
                     s->cv.wait(lk);
                 }
                 if (s->stop) {
@@ -178,7 +276,7 @@ static void stream_feeder(ffq_stream *s)
                     s->cv.notify_all();
                     return;
                 }
-                if (s->seekable && !s->pause_req && e - s->released < STREAM_SLOTS && e - p < 2) {
+                if (s->seekable && s->src == SRC_FD && !s->pause_req && e - s->released < STREAM_SLOTS && e - p < 2) {
                     StreamSlot &sq = b->slot[e % STREAM_SLOTS];
                     lk.unlock();
                     b->pool->enqueue(s->fd, sq.h + b->room, b->fbufsize, pos0 + e * b->fbufsize, &sq.cr);
@@ -191,15 +289,23 @@ static void stream_feeder(ffq_stream *s)
         StreamSlot &sl = b->slot[p % STREAM_SLOTS];
         const double tr0 = s->prof ? stream_now() : 0;
         int64_t got;
-        if (s->seekable) { b->pool->wait(&sl.cr); got = sl.cr.total(); }
-        else { got = ReadPool::read_full(s->fd, sl.h + b->room, b->fbufsize, 0, false); e = p + 1; }
+        bool src_eof = false;
+        if (s->seekable && s->src == SRC_FD) { b->pool->wait(&sl.cr); got = sl.cr.total(); src_eof = got < b->fbufsize; }
+        else if (s->src == SRC_GZIP) { got = stream_gz_read(s, sl.h + b->room, b->fbufsize, &src_eof); e = p + 1; }
+        else {
+            got = stream_fd_read(s, sl.h + b->room, b->fbufsize, &src_eof);
+            if (got == -2) { p--; continue; }      // stop / pause asked for with nothing read yet: back to the parking loop
+            e = p + 1;
+        }
         if (s->prof) { const double t = stream_now(); s->t_slot += tr0 - tw0; s->t_read += t - tr0; }
         int rc = FFQ_OK;
         std::string msg;
-        if (got < 0) { rc = FFQ_E_ARG; msg = std::string("ffq_stream: read failed: ") + strerror(errno); }
-        else {
+        if (got < 0) {
+            rc = FFQ_E_ARG;
+            msg = s->src == SRC_GZIP ? std::string("ffq_stream: gzip: ") + s->z_msg : std::string("ffq_stream: read failed: ") + strerror(errno);
+        } else {
             sl.got = got;
-            sl.eof = got < b->fbufsize;
+            sl.eof = src_eof;
             const hipError_t er = stream_copy_chunk(b, sl, got);
             if (er != hipSuccess) { rc = FFQ_E_HIP; msg = std::string("ffq_stream: chunk copy failed: ") + hipGetErrorString(er); }
         }
@@ -209,7 +315,8 @@ static void stream_feeder(ffq_stream *s)
             std::lock_guard<std::mutex> lk(s->m);
             if (rc) { s->feeder_rc = rc; s->feeder_msg = msg; s->feeder_done = true; }
             else {
-                s->file_pos += got;
+                s->file_pos = s->src == SRC_GZIP ? s->z_filepos - (s->zin_len - s->zin_pos) : s->file_pos + got;
+                sl.end_pos = s->file_pos;
                 s->produced = p + 1;
                 if (sl.eof) s->feeder_done = true;
             }
@@ -236,6 +343,8 @@ static void stream_free(ffq_stream *s)
                         "for the reader, %.3f ms carry + scan (of which %.3f ms waiting for the chunk's copy), %.3f ms rows back\n",
                 (long long)(s->cur + 1), s->t_read * 1e3, s->t_slot * 1e3, s->t_feed * 1e3, s->t_scan * 1e3, s->t_copy * 1e3,
                 s->t_rows * 1e3);
+    if (s->z_init) (void)inflateEnd(&s->zs);
+    free(s->zin);
     if (s->b) {
         for (auto &st : s->b->cs) if (st) (void)hipStreamSynchronize(st);
         if (s->c->stream) (void)hipStreamSynchronize(s->c->stream);
@@ -291,7 +400,7 @@ static int stream_alloc_qual(ffq_stream *s, int64_t bytes)
 static int stream_grow_room(ffq_stream *s, int64_t need)
 {
     StreamBufs *b = s->b;
-    {
+    if (s->src != SRC_PUSH) {
         std::unique_lock<std::mutex> lk(s->m);
         s->pause_req = true;
         s->cv.notify_all();
@@ -331,22 +440,36 @@ static int stream_grow_room(ffq_stream *s, int64_t need)
     return rc;
 }
 
-extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
-                                ffq_stream **out)
+static int stream_open_impl(ffq_ctx *c, int src, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
+                            ffq_stream **out)
 {
-    if (!c || !out || fd < 0 || fbufsize <= 0) return fail(FFQ_E_ARG, "ffq_stream_open: bad argument");
+    if (!c || !out || (src != SRC_PUSH && fd < 0) || fbufsize <= 0) return fail(FFQ_E_ARG, "ffq_stream_open: bad argument");
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));
     ffq_stream *s = new (std::nothrow) ffq_stream();
     if (!s) return fail(FFQ_E_NOMEM, "out of host memory");
-    s->c = c; s->fd = fd;
+    s->c = c; s->fd = fd; s->src = src;
     s->flags = flags & FFQ_F_DECODE_QUAL; s->qual_add = qual_add;
     s->prof = getenv("FFQ_STREAM_PROF") != nullptr;
-    // where to read from: `start` (pread; the descriptor's own position is left alone), or the
-    // descriptor's current position if start < 0; a descriptor that cannot seek is read in order
-    const off_t at = lseek(fd, 0, SEEK_CUR);
-    s->seekable = at != (off_t)-1;
-    s->file_pos = s->seekable ? (start >= 0 ? start : (int64_t)at) : 0;
+    if (src == SRC_PUSH) s->feeder_done = true;          // there is no reader thread: chunks are pushed
+    else {
+        // where to read from: `start` (pread; the descriptor's own position is left alone), or the
+        // descriptor's current position if start < 0; a descriptor that cannot seek is read in order
+        const off_t at = lseek(fd, 0, SEEK_CUR);
+        s->seekable = at != (off_t)-1;
+        s->file_pos = s->seekable ? (start >= 0 ? start : (int64_t)at) : 0;
+        s->handed_pos = s->file_pos;
+    }
+    if (src == SRC_GZIP) {
+        memset(&s->zs, 0, sizeof s->zs);
+        s->zin = static_cast<uint8_t *>(malloc((size_t)GZ_IN));
+        if (!s->zin || inflateInit2(&s->zs, 15 + 16) != Z_OK) {      // 16: gzip wrapper (header, CRC-32, length)
+            free(s->zin); delete s;
+            return fail(FFQ_E_NOMEM, "ffq_stream_open: zlib could not be initialised");
+        }
+        s->z_init = true;
+        s->z_filepos = s->file_pos;
+    }
     StreamBufs *b = static_cast<StreamBufs *>(c->stream_cache);
     c->stream_cache = nullptr;
     if (b && b->fbufsize != fbufsize) { streambufs_free(b); b = nullptr; }
@@ -368,14 +491,60 @@ extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t f
     s->b = b;
     if (!rc) rc = stream_alloc_tab(s, fbufsize / 64 + 1024);
     if (rc) { stream_free(s); return rc; }
-    s->feeder = std::thread(stream_feeder, s);
+    if (src != SRC_PUSH) s->feeder = std::thread(stream_feeder, s);
     *out = s;
     return FFQ_OK;
 }
 
+extern "C" int ffq_stream_open2(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
+                                ffq_stream **out)
+{
+    return stream_open_impl(c, SRC_FD, fd, fbufsize, flags, qual_add, start, out);
+}
+
 extern "C" int ffq_stream_open(ffq_ctx *c, int fd, int64_t fbufsize, ffq_stream **out)
 {
-    return ffq_stream_open2(c, fd, fbufsize, 0, 0, -1, out);
+    return stream_open_impl(c, SRC_FD, fd, fbufsize, 0, 0, -1, out);
+}
+
+extern "C" int ffq_stream_open_gzip(ffq_ctx *c, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
+                                    ffq_stream **out)
+{
+    return stream_open_impl(c, SRC_GZIP, fd, fbufsize, flags, qual_add, start, out);
+}
+
+extern "C" int ffq_stream_open_push(ffq_ctx *c, int64_t fbufsize, uint32_t flags, int qual_add, ffq_stream **out)
+{
+    return stream_open_impl(c, SRC_PUSH, -1, fbufsize, flags, qual_add, -1, out);
+}
+
+// push mode: where the next chunk's bytes go (pinned memory, fbufsize bytes of room) ...
+extern "C" int ffq_stream_push_buffer(ffq_stream *s, uint8_t **dst, int64_t *cap)
+{
+    if (!s || !dst || !cap || s->src != SRC_PUSH) return fail(FFQ_E_ARG, "ffq_stream_push_buffer: not a push stream");
+    if (s->failed || s->done) return fail(FFQ_E_ARG, "ffq_stream_push_buffer: the stream has %s", s->failed ? "failed" : "ended");
+    if (s->produced - s->released >= STREAM_SLOTS) return fail(FFQ_E_ARG, "ffq_stream_push_buffer: every slot holds an unconsumed chunk");
+    *dst = s->b->slot[s->produced % STREAM_SLOTS].h + s->b->room;
+    *cap = s->b->fbufsize;
+    return FFQ_OK;
+}
+
+// ... and: n bytes are there now; eof: nothing follows.  The chunk's copy to the device is enqueued.
+extern "C" int ffq_stream_push(ffq_stream *s, int64_t n, int eof)
+{
+    if (!s || s->src != SRC_PUSH) return fail(FFQ_E_ARG, "ffq_stream_push: not a push stream");
+    if (n < 0 || n > s->b->fbufsize) return fail(FFQ_E_ARG, "ffq_stream_push: %lld bytes do not fit a chunk of %lld", (long long)n, (long long)s->b->fbufsize);
+    if (s->failed || s->done) return fail(FFQ_E_ARG, "ffq_stream_push: the stream has %s", s->failed ? "failed" : "ended");
+    if (s->produced - s->released >= STREAM_SLOTS) return fail(FFQ_E_ARG, "ffq_stream_push: every slot holds an unconsumed chunk");
+    HIPCHK(hipSetDevice(s->c->device));
+    StreamSlot &sl = s->b->slot[s->produced % STREAM_SLOTS];
+    sl.got = n; sl.eof = eof != 0;
+    s->file_pos += n;
+    sl.end_pos = s->file_pos;
+    const hipError_t e = stream_copy_chunk(s->b, sl, n);
+    if (e != hipSuccess) { s->failed = true; return fail(FFQ_E_HIP, "ffq_stream_push: chunk copy failed: %s", hipGetErrorString(e)); }
+    s->produced++;
+    return FFQ_OK;
 }
 
 extern "C" void ffq_stream_close(ffq_stream *s) { stream_free(s); }
@@ -383,8 +552,9 @@ extern "C" void ffq_stream_close(ffq_stream *s) { stream_free(s); }
 extern "C" int64_t ffq_stream_tell(ffq_stream *s)
 {
     if (!s) return -1;
-    std::lock_guard<std::mutex> lk(s->m);
-    return s->file_pos;
+    // behind the last chunk HANDED OUT (the reader runs up to two chunks ahead of that): where the
+    // reference's loop would have left the file after the same fills
+    return s->handed_pos;
 }
 
 // decoded qualities of the fill ffq_stream_next has just returned (streams opened with
@@ -422,6 +592,7 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
         s->cv.wait(lk, [&] { return s->produced > k || s->feeder_done; });
         if (s->produced <= k) {
             if (s->feeder_rc) return fail(s->feeder_rc, "%s", s->feeder_msg.c_str());
+            if (s->src == SRC_PUSH) { s->failed = false; return fail(FFQ_E_ARG, "ffq_stream_next: no chunk has been pushed"); }
             return fail(FFQ_E_INTERNAL, "ffq_stream: the reader stopped early");
         }
     }
@@ -492,6 +663,7 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
     if (s->prof) { const double t = stream_now(); s->t_feed += tp1 - tp0; s->t_scan += tp2 - tp1; s->t_rows += t - tp2; }
 
     s->cur = k;
+    s->handed_pos = sl.end_pos;
     s->fill_start = start; s->fill_len = len;
     *h_rows = b->htab;
     *n_rows = res.n_records;

@@ -148,6 +148,24 @@ def entryfunc(buf: bytes, pos, globaloffset: int) -> EntryType:
 _ENTRYFUNC = entryfunc          # (readfastq_iter's parameter shadows the name)
 
 
+def entryfunc_phred(buf: bytes, pos, globaloffset: int):
+    """(header, sequence, quality) with the quality as an array('b') of Phred scores: the entryfunc the
+    reference's user guide writes for this (doc/user-guide.rst:126-141, :206-214; benchmark.py:155-168),
+
+        quality = array('b'); quality.frombytes(buf[pos[4]:pos[5]]); arrayadd_b(quality, -33)
+
+    Called per record (any scanner) it does exactly that, through this package's arrayadd_b -- one
+    device round trip per record.  readfastq_iter RECOGNISES it when the scanner is the GPU one: the
+    stream front end then decodes the qualities of a whole buffer fill on the device, together with
+    the scan (FFQ_F_DECODE_QUAL, k_decode_stream), and the iterator only wraps the decoded bytes --
+    the same entries, without a call per record."""
+    from . import _fastqandfurious as _C
+    quality = array('b')
+    quality.frombytes(buf[pos[4]:pos[5]])
+    _C.arrayadd_b(quality, -33)
+    return (buf[(pos[0] + 1):pos[1]], buf[pos[2]:pos[3]], quality)
+
+
 def entryfunc_abspos(buf: bytes, pos, globaloffset: int):
     """Absolute stream positions: pos[i] += globaloffset, in place; returns
     the same `pos` object (reference :186-195)."""
@@ -181,6 +199,23 @@ def _default_entries(buf, rows, shift, cls=None):
         yield from cut(buf, mv[at:at + step], shift, 1, cls)
 
 
+def _phred_entries(st, fill, rows, shift):
+    """entryfunc_phred over a whole table, from the stream's bulk decode of that fill."""
+    qual, qoff = st.quals()
+    nat = _entries.native()
+    if nat is not None and hasattr(nat, "entries_phred"):
+        mv, mo = memoryview(rows).cast('B'), memoryview(qoff).cast('B')
+        step = _ENTRY_CHUNK
+        for at in range(0, rows.shape[0], step):
+            yield from nat.entries_phred(fill, mv[48 * at:48 * (at + step)], shift, qual, mo[8 * at:8 * (at + step + 1)], array)
+        return
+    buf = fill.tobytes()
+    qb = qual.tobytes()
+    offs = qoff.tolist()
+    for i, (p0, p1, p2, p3, _p4, _p5) in enumerate((rows - shift).tolist()):
+        yield (buf[p0 + 1:p1], buf[p2:p3], array('b', qb[offs[i]:offs[i + 1]]))
+
+
 def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
     """readfastq_iter with a batched scanner: one scan per buffer fill.
 
@@ -189,6 +224,11 @@ def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
     sentinel, globaloffset and the error texts follow the reference loop
     (:241-279) step for step.
     """
+    # a scanner may name a number of bytes below which reads are coalesced into k * fbufsize per scan
+    # (the entries do not depend on where the stream is cut into fills)
+    co = getattr(getattr(scan_buffer, '__self__', None), 'coalesce_bytes', 0) or 0
+    if 0 < fbufsize < co:
+        fbufsize *= -(-co // fbufsize)
     globaloffset = -1
     offset = 0
     buf, eof = read(fh, fbufsize)
@@ -223,7 +263,9 @@ def _iter_stream(st, entryfunc):
     exactly what the reference's loop passes to entryfunc (:252-255), globaloffset included."""
     try:
         for rows, fill, fill_offset, end_state, err_offset in st:
-            if rows.shape[0] and (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
+            if rows.shape[0] and entryfunc is entryfunc_phred and st.decode:
+                yield from _phred_entries(st, fill, rows, fill_offset)
+            elif rows.shape[0] and (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
                 # the default entryfunc over the whole table, natively (csrc/ffq_entries.c): the slices
                 # are cut straight out of the stream's own (pinned) fill -- no bytes copy of the fill,
                 # no posbuffer and no interpreter loop per record
@@ -266,7 +308,9 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
     """
     open_stream = getattr(entrypos, 'open_stream', None)
     if open_stream is not None:
-        st = open_stream(fh, fbufsize)           # None unless fh is a real file
+        # the native stream front end: a real file, a gzip file, or anything with readinto() / read();
+        # with entryfunc_phred the qualities of every fill are decoded on the device
+        st = open_stream(fh, fbufsize, entryfunc is entryfunc_phred) if entryfunc is entryfunc_phred else open_stream(fh, fbufsize)
         if st is not None:
             yield from _iter_stream(st, entryfunc)
             return

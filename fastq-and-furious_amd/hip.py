@@ -44,7 +44,8 @@ SYMBOLS = (
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
     "ffq_table_select_seqlen", "ffq_table_cut", "ffq_table_gather_column", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
-    "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
+    "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_stream_open_gzip", "ffq_stream_open_push",
+    "ffq_stream_push_buffer", "ffq_stream_push", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
 )
@@ -190,6 +191,10 @@ def lib():
         L.ffq_scan_fasta_device.argtypes = [vp, vp, i64, i32, i64, i64, vp, i64, P(ScanResult)]
         L.ffq_scan_fasta_host.argtypes = [vp, vp, i64, i32, i64, i64, vp, i64, P(ScanResult)]
         L.ffq_stream_open2.argtypes = [vp, i32, i64, u32, i32, i64, P(vp)]
+        L.ffq_stream_open_gzip.argtypes = [vp, i32, i64, u32, i32, i64, P(vp)]
+        L.ffq_stream_open_push.argtypes = [vp, i64, u32, i32, P(vp)]
+        L.ffq_stream_push_buffer.argtypes = [vp, P(vp), P(i64)]
+        L.ffq_stream_push.argtypes = [vp, i64, i32]
         L.ffq_stream_tell.argtypes = [vp]
         L.ffq_stream_tell.restype = i64
         L.ffq_stream_quals.argtypes = [vp, P(vp), P(vp), P(i64)]
@@ -466,14 +471,17 @@ class FileStream:
     `fill` (uint8 array, fill[i] = stream byte fill_offset + i) are views of memory the stream
     owns -- valid until the next iteration step."""
 
-    def __init__(self, ctx, fd, fbufsize=1 << 24, decode=False, qual_add=-33, start=None):
+    def __init__(self, ctx, fd, fbufsize=1 << 24, decode=False, qual_add=-33, start=None, gzip=False):
         """start: byte of the file the stream begins at (None: the descriptor's current position).
-        A descriptor that can seek is read with pread: its own position does not move."""
+        A descriptor that can seek is read with pread: its own position does not move.
+        gzip: the descriptor is a gzip file; the stream's reader thread inflates it into the pinned
+        chunk buffers (fbufsize and every offset count DECOMPRESSED bytes)."""
         self._ctx = ctx
         self._h = ctypes.c_void_p()
         self.decode = bool(decode)
-        check(lib().ffq_stream_open2(ctx.handle, int(fd), int(fbufsize), F_DECODE_QUAL if decode else 0,
-                                     int(qual_add), -1 if start is None else int(start), ctypes.byref(self._h)))
+        opener = lib().ffq_stream_open_gzip if gzip else lib().ffq_stream_open2
+        check(opener(ctx.handle, int(fd), int(fbufsize), F_DECODE_QUAL if decode else 0,
+                     int(qual_add), -1 if start is None else int(start), ctypes.byref(self._h)))
 
     def tell(self):
         """File position behind the last byte the stream has read so far."""
@@ -506,21 +514,74 @@ class FileStream:
         except Exception:
             pass
 
-    def __iter__(self):
+    def _next(self):
+        """One fill: (rows, fill, fill_offset, end_state, err_offset)."""
         rows_p, fill_p = ctypes.c_void_p(), ctypes.c_void_p()
         n, nb, off, err = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         end = ctypes.c_int32()
+        check(lib().ffq_stream_next(self._h, ctypes.byref(rows_p), ctypes.byref(n), ctypes.byref(end),
+                                    ctypes.byref(err), ctypes.byref(fill_p), ctypes.byref(nb), ctypes.byref(off)))
+        self._last_rows = n.value
+        rows = (np.ctypeslib.as_array((ctypes.c_int64 * (n.value * 6)).from_address(rows_p.value)).reshape(-1, 6)
+                if n.value else np.zeros((0, 6), dtype=np.int64))
+        fill = (np.ctypeslib.as_array((ctypes.c_uint8 * nb.value).from_address(fill_p.value))
+                if nb.value else np.zeros(0, dtype=np.uint8))
+        return rows, fill, off.value, end.value, err.value
+
+    def __iter__(self):
         while True:
-            check(lib().ffq_stream_next(self._h, ctypes.byref(rows_p), ctypes.byref(n), ctypes.byref(end),
-                                        ctypes.byref(err), ctypes.byref(fill_p), ctypes.byref(nb), ctypes.byref(off)))
-            self._last_rows = n.value
-            rows = (np.ctypeslib.as_array((ctypes.c_int64 * (n.value * 6)).from_address(rows_p.value)).reshape(-1, 6)
-                    if n.value else np.zeros((0, 6), dtype=np.int64))
-            fill = (np.ctypeslib.as_array((ctypes.c_uint8 * nb.value).from_address(fill_p.value))
-                    if nb.value else np.zeros(0, dtype=np.uint8))
-            yield rows, fill, off.value, end.value, err.value
-            if end.value != END_REFILL:
+            t = self._next()
+            yield t
+            if t[3] != END_REFILL:
                 return
+
+
+class PushStream(FileStream):
+    """The stream front end over any object with readinto() / read() -- BytesIO, bz2 / lzma / gzip
+    file objects, sockets: no reader thread; every chunk is read by THIS thread straight into the
+    stream's pinned chunk buffer (ffq_stream_push_buffer / ffq_stream_push; no bytes object, no
+    copy), then scanned.  Iterates like FileStream."""
+
+    def __init__(self, ctx, fh, fbufsize=1 << 23, decode=False, qual_add=-33):   # noqa: super().__init__ not called on purpose
+        self._ctx = ctx
+        self._h = ctypes.c_void_p()
+        self.decode = bool(decode)
+        self._fh = fh
+        self._readinto = getattr(fh, "readinto", None)
+        check(lib().ffq_stream_open_push(ctx.handle, int(fbufsize), F_DECODE_QUAL if decode else 0, int(qual_add),
+                                         ctypes.byref(self._h)))
+
+    def tell(self):
+        return -1
+
+    def _pump(self):
+        """One chunk of the source into the next slot (reference read(), fastqandfurious.py:30-36: the
+        source is exhausted when it returns less than was asked for -- here after asking again until
+        the chunk is full or nothing comes)."""
+        dst, cap = ctypes.c_void_p(), ctypes.c_int64()
+        check(lib().ffq_stream_push_buffer(self._h, ctypes.byref(dst), ctypes.byref(cap)))
+        mv = memoryview((ctypes.c_uint8 * cap.value).from_address(dst.value)).cast("B")
+        got = 0
+        while got < cap.value:
+            if self._readinto is not None:
+                n = self._readinto(mv[got:]) or 0
+            else:
+                data = self._fh.read(cap.value - got)
+                n = len(data)
+                mv[got:got + n] = data
+            if n <= 0:
+                break
+            got += n
+        check(lib().ffq_stream_push(self._h, got, 1 if got < cap.value else 0))
+
+    def __iter__(self):
+        self._pump()
+        while True:
+            t = self._next()
+            yield t
+            if t[3] != END_REFILL:
+                return
+            self._pump()
 
 
 _default_ctx = {}

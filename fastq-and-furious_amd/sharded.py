@@ -421,7 +421,20 @@ class ShardScanner:
             if not grow and not force:
                 for r in range(W):
                     if err[r]:
-                        raise_stream_error(err[r], errb[r])      # every rank raises the same error
+                        # The byte the iterator names is its `offset` when the failing search started:
+                        # pos5 - 1 of the last COMPLETE record in front of the failing entry (:254, :275).
+                        # A rank that owns no row in front of that entry does not know it -- its scan
+                        # started at a guess, or at rows of the run-in that nothing has proven: the
+                        # record in question straddles in from the left, and the nearest rank to the
+                        # left that owns a row (or rank 0, whose start is exact) has it as the start of
+                        # the search that found its exit.
+                        byte = errb[r]
+                        if r > 0 and cnt[r] == 0:
+                            q = r - 1
+                            while q > 0 and cnt[q] == 0:
+                                q -= 1
+                            byte = exs[q]
+                        raise_stream_error(err[r], byte)         # every rank raises the same error
                     if ex[r] == UNKNOWN_POS:
                         raise RuntimeError("sharded scan: rank %d has no exit and nobody can move" % r)
                 return st, cnt, rounds
@@ -489,7 +502,10 @@ class SyntheticShard:
     (SURVEY.md 8d); cut points are moved off the record boundaries so that a
     record straddles every edge."""
 
-    def __init__(self, ctx, kind, bytes_per_gpu, rank, world, dev, edge_shift=144, transport=None):
+    def __init__(self, ctx, kind, bytes_per_gpu, rank, world, dev, edge_shift=144, transport=None, total_records=None):
+        """total_records (S-single only): the whole stream has exactly this many records, dealt out as
+        evenly as they go (BASELINE configs[4]: 333 460 193 records = 107 374 182 146 B over 8 ranges);
+        bytes_per_gpu is ignored then."""
         import torch
         from . import synth
         self.ctx, self.kind, self.rank, self.world, self.dev = ctx, kind, rank, world, dev
@@ -500,9 +516,15 @@ class SyntheticShard:
             else:
                 transport = SoloTransport()
         self.transport = transport
+        first_rec = None
         if kind == "single":
-            n_per = bytes_per_gpu // synth.RECORD_BYTES
-            blk_bytes = [n_per * synth.RECORD_BYTES] * world
+            if total_records is not None:
+                per = [total_records // world + (1 if r < total_records % world else 0) for r in range(world)]
+            else:
+                per = [bytes_per_gpu // synth.RECORD_BYTES] * world
+            n_per = per[rank]
+            first_rec = sum(per[:rank])
+            blk_bytes = [n * synth.RECORD_BYTES for n in per]
             starts = None
         else:
             n_per = int(bytes_per_gpu // 379.3)
@@ -538,7 +560,7 @@ class SyntheticShard:
         self.ext = torch.empty(room, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         if kind == "single":
-            ctx.synth_single(self.ext.data_ptr() + self.tail - a, rank * n_per, n_gen, seed=42)
+            ctx.synth_single(self.ext.data_ptr() + self.tail - a, first_rec, n_gen, seed=42)
         else:
             dstart = torch.from_numpy(starts[:n_gen + 1].copy()).to(dev)
             torch.cuda.synchronize()

@@ -263,12 +263,32 @@ void ffq_stream_close(ffq_stream *s);
  * and ffq_stream_quals hands back the int8 stream and its CSR offsets (n_rows + 1 entries) of
  * the fill ffq_stream_next has just returned; pinned memory, valid until the next call.
  * start: byte of the file the stream begins at (< 0: the descriptor's current position); stream
- * offsets count from there.  ffq_stream_tell: the file position behind the last byte read so far
- * (where a caller that shares the file object should leave it, as the reference's loop does).  */
+ * offsets count from there.  ffq_stream_tell: the file position behind the last chunk HANDED OUT by
+ * ffq_stream_next (the reader itself runs ahead of that): where a caller that shares the file object
+ * should leave it, as the reference's loop does.  A descriptor that cannot seek (a pipe) is read
+ * behind poll(): closing the stream never waits for a writer that keeps the pipe open and idle, and a
+ * chunk is handed over short -- which is not the end of the stream -- when nothing more has arrived
+ * for 50 ms.                                                                                       */
 int  ffq_stream_open2(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
                       ffq_stream **out);
 int  ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int64_t **h_qoff, int64_t *n_qual_bytes);
 int64_t ffq_stream_tell(ffq_stream *s);
+/* The same over a gzip-compressed file (what FORMAT_OPENERS['gz'] / automagic_open hand to
+ * readfastq_iter, fastqandfurious.py:282-334): the stream's reader thread inflates (zlib; concatenated
+ * members, zero padding behind the last one) straight into the pinned chunk buffers -- decompression
+ * is the feeder stage of the pipeline, fbufsize counts DECOMPRESSED bytes, stream offsets are offsets
+ * of the decompressed stream.  start: byte of the compressed file the first member begins at.      */
+int  ffq_stream_open_gzip(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
+                          ffq_stream **out);
+/* The same without a reader thread, for sources only the host can read (any object with a read() /
+ * readinto(): BytesIO, bz2, lzma, sockets ...): the host asks where the next chunk goes
+ * (ffq_stream_push_buffer: pinned memory, *cap = fbufsize bytes of room), writes up to *cap bytes
+ * there itself and says how many it wrote and whether the source is exhausted (ffq_stream_push: the
+ * reference's read(), fastqandfurious.py:30-36, with eof decided by the caller); ffq_stream_next then
+ * scans that fill.  Up to two chunks may be pushed ahead of the one being consumed.               */
+int  ffq_stream_open_push(ffq_ctx *ctx, int64_t fbufsize, uint32_t flags, int qual_add, ffq_stream **out);
+int  ffq_stream_push_buffer(ffq_stream *s, uint8_t **dst, int64_t *cap);
+int  ffq_stream_push(ffq_stream *s, int64_t n, int eof);
 
 /* ---- synthetic FASTQ generators (bench / test inputs) -----
  * Counter-based (splitmix64), so the numpy generator in

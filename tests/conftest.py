@@ -50,6 +50,10 @@ def _forget_input_history(request):
     memory of the previous test's input."""
     if request.node.get_closest_marker("gpu") is not None:
         request.getfixturevalue("gpu_ctx").forget()
+        # the tests choose fbufsize to exercise the refill / carry logic: reads are not coalesced
+        # unless a test asks for it (tests/test_iter_decode.py does)
+        from fastqandfurious_amd import _fastqandfurious as C
+        C.entrypos.coalesce_bytes = 0
     yield
 
 

@@ -40,7 +40,8 @@ def test_config5_eight_logical_ranges_full_size(gpu_ctx):
     def work(rank):
         try:
             ctx = hip.Context(0)
-            sh = sharded.SyntheticShard(ctx, "single", per, rank, world, dev, transport=lw.transport(rank))
+            sh = sharded.SyntheticShard(ctx, "single", per, rank, world, dev, transport=lw.transport(rank),
+                                        total_records=RECORDS_100G)
             ctx.reserve(sh.ext.numel())
             table = torch.empty((sh.max_records + 64, 6), dtype=torch.int64, device=dev)
             out = sh.scan(table)                 # halo hand-off + scan + cut + the eight-word all_gather

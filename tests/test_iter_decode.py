@@ -1,0 +1,189 @@
+"""Iterator-level Phred decode, coalesced reads and the three kinds of stream source.
+
+The reference's documented decode is an entryfunc of the user's own (doc/user-guide.rst:126-141,
+:206-214): array('b').frombytes(buf[pos4:pos5]); arrayadd_b(quality, -33).  tests/golden/phred.json
+holds what the REAL reference yields with that entryfunc (make_golden_phred.py: reference iterator,
+reference C scanner, reference arrayadd_b).  Here `entryfunc_phred` must yield the same entries
+through the GPU stream's bulk decode -- from a plain file, a gzip file (inflated by the library's
+reader thread), and from objects only Python can read (BytesIO, bz2, lzma: chunks pushed into
+pinned memory) -- at the reference's own buffer sizes (20-50 kB, coalesced) and at tiny ones (every
+fill carries an unfinished entry over).
+"""
+import bz2
+import gzip
+import hashlib
+import io
+import json
+import lzma
+import os
+from array import array
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, golden_file
+
+
+@pytest.fixture(scope="module")
+def phred():
+    with open(os.path.join(GOLDEN_DIR, "phred.json")) as fh:
+        return json.load(fh)
+
+
+def _hexed(entries):
+    return [[h.hex(), s.hex(), q.tobytes().hex()] for h, s, q in entries]
+
+
+def _digest(entries):
+    h = hashlib.sha256()
+    for a, b, c in entries:
+        for x in (a, b, c.tobytes()):
+            h.update(len(x).to_bytes(8, "little"))
+            h.update(x)
+    return h.hexdigest()
+
+
+def _sources(tmp_path, data, tag):
+    """(name, opener) pairs: every kind of stream source over the same bytes."""
+    plain = tmp_path / ("%s.fq" % tag)
+    plain.write_bytes(data)
+    gz = tmp_path / ("%s.fq.gz" % tag)
+    with gzip.open(gz, "wb") as fh:
+        fh.write(data)
+    # two members + zero padding, as `cat a.gz b.gz` / bgzip produce
+    gz2 = tmp_path / ("%s.2.fq.gz" % tag)
+    cut = len(data) // 2
+    gz2.write_bytes(gzip.compress(data[:cut]) + gzip.compress(data[cut:]) + b"\0" * 37)
+    bz = tmp_path / ("%s.fq.bz2" % tag)
+    bz.write_bytes(bz2.compress(data))
+    xz = tmp_path / ("%s.fq.xz" % tag)
+    xz.write_bytes(lzma.compress(data))
+    return [("file", lambda: open(plain, "rb")), ("gzip", lambda: gzip.open(gz, "rb")),
+            ("gzip-members", lambda: gzip.open(gz2, "rb")), ("bytesio", lambda: io.BytesIO(data)),
+            ("bz2", lambda: bz2.open(bz, "rb")), ("xz", lambda: lzma.open(xz, "rb")),
+            ("gzip-over-bytesio", lambda: gzip.GzipFile(fileobj=io.BytesIO(gz.read_bytes())))]
+
+
+def test_entryfunc_phred_per_record_shape(pkg):
+    """The per-record form is the user guide's entryfunc (it needs the device for arrayadd_b: here only
+    that it is wired to this package's arrayadd_b and cuts the same slices)."""
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C
+    import inspect
+    src = inspect.getsource(F.entryfunc_phred)
+    assert "arrayadd_b(quality, -33)" in src and "frombytes(buf[pos[4]:pos[5]])" in src
+    assert C.entrypos.chunk_bytes(50000) % 50000 == 0 and C.entrypos.chunk_bytes(50000) >= C.entrypos.coalesce_bytes
+    assert C.entrypos.chunk_bytes(1 << 26) == 1 << 26
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("coalesce", (0, 8 << 20))
+def test_phred_goldens_every_source(gpu_ctx, phred, tmp_path, coalesce):
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C
+    C.entrypos.coalesce_bytes = coalesce
+    cases = [(fn, golden_file(fn), g) for fn, g in phred["files"].items()]
+    cases += [(name, bytes.fromhex(g["data"]), g) for name, g in phred["edge"].items()]
+    for name, data, g in cases:
+        for src, opener in _sources(tmp_path, data, name.replace(".", "_")):
+            for bs in ((100, 600, 20000) if not coalesce else (20000,)):
+                got, err = [], None
+                try:
+                    with opener() as fh:
+                        for e in F.readfastq_iter(fh, bs, F.entryfunc_phred, C.entrypos):
+                            assert isinstance(e[2], array) and e[2].typecode == "b"
+                            got.append(e)
+                except ValueError as e:
+                    err = str(e)
+                want_err = g["error"]
+                if want_err == "hang":              # INVALID at eof: the reference never leaves its loop; this build raises
+                    assert err is not None and err.startswith("Entry is invalid at byte"), (name, src, bs, err)
+                else:
+                    assert err == want_err, (name, src, bs, err)
+                assert _hexed(got) == g["entries"], (name, src, bs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,maker", (("single_3000", lambda s: s.single(0, 3000, seed=42)),
+                                        ("wrapped_3000", lambda s: s.wrapped(0, 3000, seed=43)[0]),
+                                        ("single_3000_at_7", lambda s: s.single(7, 3000, seed=42))))
+def test_phred_synthetic_streams(gpu_ctx, phred, tmp_path, name, maker):
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C, synth
+    data = maker(synth).tobytes()
+    g = phred["synth"][name]
+    for coalesce in (0, 8 << 20):
+        C.entrypos.coalesce_bytes = coalesce
+        for src, opener in _sources(tmp_path, data, name):
+            for bs in (50000, 20000, 3000):
+                with opener() as fh:
+                    got = list(F.readfastq_iter(fh, bs, F.entryfunc_phred, C.entrypos))
+                assert len(got) == g["n"] and _digest(got) == g["sha256"], (name, src, bs, coalesce)
+                assert [x.hex() for x in (got[0][0], got[0][1], got[0][2].tobytes())] == g["first"]
+                assert [x.hex() for x in (got[-1][0], got[-1][1], got[-1][2].tobytes())] == g["last"]
+
+
+@pytest.mark.gpu
+def test_default_entryfunc_every_source_and_coalescing(gpu_ctx, golden, tmp_path):
+    """The default entryfunc through every kind of source, coalesced and not: the golden tuples of the
+    reference's fixtures (captured from the reference, golden.json)."""
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C
+    for fn, g in golden["files"].items():
+        data = golden_file(fn)
+        for coalesce in (0, 8 << 20):
+            C.entrypos.coalesce_bytes = coalesce
+            for src, opener in _sources(tmp_path, data, fn.replace(".", "_")):
+                for bs in (100, 700, 50000):
+                    with opener() as fh:
+                        got = [[h.hex(), s.hex(), q.hex()] for h, s, q in F.readfastq_iter(fh, bs, F.entryfunc, C.entrypos)]
+                    assert got == g["tuples"], (fn, src, bs, coalesce)
+                    with opener() as fh:
+                        rows = [list(p) for p in F.readfastq_iter(fh, bs, F.entryfunc_abspos, C.entrypos)]
+                    assert rows == g["bufsizes"]["65536"]["c"]["rows"], (fn, src, bs, coalesce)
+
+
+@pytest.mark.gpu
+def test_gzip_errors_and_pipe_stop(gpu_ctx, tmp_path):
+    """A truncated / corrupt gzip file raises (it does not hang or return a short stream); a pipe whose
+    writer stays open and idle does not block close()."""
+    import time
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C, hip, synth
+    data = synth.single(0, 2000, seed=42).tobytes()
+    blob = gzip.compress(data)
+    bad = tmp_path / "cut.fq.gz"
+    bad.write_bytes(blob[:len(blob) // 2])
+    with pytest.raises(hip.FFQError, match="gzip"):
+        with gzip.open(bad, "rb") as fh:
+            list(F.readfastq_iter(fh, 50000, F.entryfunc, C.entrypos))
+    notgz = tmp_path / "not.fq.gz"
+    notgz.write_bytes(data)
+    with pytest.raises(hip.FFQError, match="gzip"):
+        st = hip.FileStream(gpu_ctx, os.open(notgz, os.O_RDONLY), 1 << 20, gzip=True)
+        list(st)
+    # an idle pipe: some records arrive, the writer keeps the pipe open; the first fill is handed over
+    # short (not the end of the stream) and close() returns at once
+    r, w = os.pipe()
+    os.write(w, data[:322 * 10])
+    st = hip.FileStream(gpu_ctx, r, 1 << 20)
+    t0 = time.time()
+    rows, fill, off, end, err = st._next()
+    assert rows.shape[0] == 9 and end == hip.END_REFILL            # the tenth record may still grow: carried over
+    st.close()
+    assert time.time() - t0 < 5.0
+    os.close(w)
+    os.close(r)
+
+
+@pytest.mark.gpu
+def test_stream_tell_is_behind_the_last_fill_handed_out(gpu_ctx, tmp_path):
+    """ffq_stream_tell = end of the last chunk handed out, not of the read-ahead: an iterator closed
+    early leaves the file where the reference's loop would (fastqandfurious.py:274-277)."""
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C, synth
+    data = synth.single(0, 20000, seed=42).tobytes()
+    p = tmp_path / "t.fq"
+    p.write_bytes(data)
+    C.entrypos.coalesce_bytes = 0
+    bs = 1 << 20
+    with open(p, "rb") as fh:
+        it = F.readfastq_iter(fh, bs, F.entryfunc, C.entrypos)
+        for _ in range(5000):           # inside the second fill
+            next(it)
+        it.close()
+        assert fh.tell() == 2 * bs

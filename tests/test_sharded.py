@@ -268,6 +268,34 @@ def test_local_ranks_stream_errors(oracle, pkg, kind, world):
     assert str(ei.value) == err
 
 
+def test_local_ranks_stream_error_byte_with_tiny_halos(oracle, pkg):
+    """The byte a stream error names is the iterator's `offset` (pos5 - 1 of the last COMPLETE record,
+    fastqandfurious.py:254, :269).  When that record straddles in from the left and the failing rank
+    owns no row of its own, the byte must come from the left neighbour's chain, not from the failing
+    rank's scan start (9 of 1100 fuzzed streams named the wrong byte)."""
+    import fastqandfurious_amd  # noqa: F401
+    from fastqandfurious_amd import synth
+    rng = np.random.default_rng(20260929)
+    checked = 0
+    for it in range(160):
+        nrec = int(rng.integers(1, 12))
+        data = synth.wrapped(int(rng.integers(0, 1000)), nrec, seed=43)[0] if it & 1 else synth.single(int(rng.integers(0, 1000)), nrec, seed=42)
+        cut = int(rng.integers(1, min(data.size, 700)))
+        stream = np.ascontiguousarray(data[:data.size - cut])
+        _want, err = expected(oracle, stream)
+        if err is None:
+            continue
+        t = torch.from_numpy(stream.copy())
+        for world in (2, 3, 5):
+            for tail, head in ((1, 16), (64, 48), (256, 64)):
+                with pytest.raises(ValueError) as ei:
+                    run_local(t, bounds_for(stream.size, world, 0, int(rng.integers(-40, 40))), lambda r: OracleBackend(),
+                              tail_bytes=tail, head_bytes=head)
+                assert str(ei.value) == err, (it, world, tail, head)
+                checked += 1
+    assert checked > 300
+
+
 def test_local_ranks_table_too_small(oracle, pkg):
     """one rank's table cannot hold its rows: every rank raises, nobody is left in a collective"""
     stream = make_stream("single")

@@ -6,7 +6,7 @@ d = tempfile.mkdtemp()
 extra = ["-DFFQ_PROBES=1"] if "--probe" in sys.argv else []
 flt = [a for a in sys.argv[1:] if not a.startswith("--")]
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", '-DFFQ_BUILD_ID="x"',
-                "--save-temps", "-o", d + "/lib.so", R + "/fastq-and-furious_amd/csrc/ffq_hip.hip"] + extra,
+                "--save-temps", "-o", d + "/lib.so", R + "/fastq-and-furious_amd/csrc/ffq_hip.hip", "-lz"] + extra,
                cwd=d, check=True, stderr=subprocess.DEVNULL)
 s = open(glob.glob(d + "/*gfx950*.s")[0]).read()
 for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, flags=re.S):
