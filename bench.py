@@ -330,6 +330,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     # without the decode a step's last kernel publishes the result block and the host polls it:
     # no event record behind the step (each is a few microseconds of idle GPU)
     flags = hip.F_DECODE_QUAL if decode else hip.F_POLL_RESULT
+    if decode and args.single_pass:
+        flags |= hip.F_SINGLE_PASS               # (opt-in: csrc/ffq_fused.h -- less traffic, more time on this part)
 
     # ---- this rank's byte range of the logical stream, generated in HBM ----------
     split = bool(wl.get("split"))                   # the workload's bytes are the whole job's, not one GPU's
@@ -471,7 +473,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
         total_records, total_bytes = int(tot[0].item()), int(tot[1].item())
     else:
         total_records, total_bytes = out.n_own_records, n_own
-    assert out.res.path in (0, 3), "a parallel chain path must be the one measured (got path %d)" % out.res.path
+    assert out.res.path in (0, 3, 6), "a parallel chain path must be the one measured (got path %d)" % out.res.path
 
     # The same step once more OUTSIDE the timed region, one at a time and with an end event instead of
     # the polled completion word: the device span first kernel -> last kernel of ONE step (res.ms_total,
@@ -519,7 +521,13 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
         # decoding, else the line-index kernel.  Algorithmic bytes per launch:
         #   k_scan_lines     every byte of the scanned buffer read once + 2 B of index per newline
         #   k_decode_stream  quality bytes read + written + 16 B of (offset, pos4) per record
-        if decode:
+        if decode and out.res.path == 6:
+            # single pass (ffq_fused.h): the index kernel also writes the decoded stream -- every byte of the
+            # buffer read once, 2 B of index per newline and the decoded bytes written
+            dom, t_dom = "k_scan_fused", float(np.mean(ms_index)) * 1e-3
+            algo = shard.ext_scanned_bytes + 2 * int(out.res.n_lines) + int(out.res.n_qual_bytes)
+            traffic = pmc_traffic(name, "k_scan_fused")
+        elif decode:
             dom, t_dom = "k_decode_stream", float(np.mean(ms_decode)) * 1e-3
             algo = 2 * int(out.res.n_qual_bytes) + 16 * int(out.n_rows)
             traffic = pmc_traffic(name, "k_decode_stream")
@@ -575,7 +583,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 "traffic_commit": traffic[2] if traffic else None,
                 "algorithmic_bytes_per_launch": algo,
                 "avg_launch_ms": round(t_dom * 1e3, 4),
-                "launch_ms_spread": spread(ms_decode if decode else ms_index),
+                "launch_ms_spread": spread(ms_decode if dom == "k_decode_stream" else ms_index),
             },
             "hbm_read_probe": None if probe_gbs is None else {
                 "value": round(probe_gbs, 1), "unit": "GB/s", "frac_of_peak": round(probe_gbs / HBM_PEAK_GBS, 4),
@@ -615,6 +623,9 @@ def main():
                     help="untimed steps in front of the warm-up until the GPU has been busy this long "
                          "(its clocks take ~15 ms of load to settle after an idle spell); 0: none")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--single-pass", action="store_true",
+                    help="decode workloads: the index pass writes the decoded stream itself (FFQ_F_SINGLE_PASS; the input "
+                         "is read once -- measured slower than the two passes on MI355X, see DESIGN.md)")
     ap.add_argument("--sharded-step", action="store_true",
                     help="N=1 through the synchronous step the N>1 ranks run (diagnostics)")
     ap.add_argument("--lanes-step", action="store_true",

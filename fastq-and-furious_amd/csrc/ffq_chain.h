@@ -99,7 +99,7 @@ struct DevRes {
     int32_t n_bad;       // groups whose guess was not confirmed (or that did not fit), all of them
     int64_t approx_records;   // records the groups counted, confirmed or not (how long the records are, roughly)
     int32_t fast4_hint;  // written by k_finalize4 only: 1 = the four-line fast path stood on this buffer (probe scans)
-    int32_t pad_;
+    int32_t fused_bad;   // written by k_finalize4 only: FZ_BAD_* of the single-pass decode (ffq_fused.h), 0 = it stood
 };
 
 // Result hand-over.  The last result-writing kernel of a scan copies the result block and the

@@ -55,6 +55,8 @@ struct ScanState {
     int repairs = 0;          // repair passes of the general kernels (reported with retries)
     bool dense_cfg = false, fast4_failed = false;
     bool probe4 = false;      // the front carries the fast path's kernels as a probe (see ffq_ctx::fast4_skip)
+    bool fused = false;       // the front is the single-pass index + decode kernel (ffq_fused.h)
+    bool no_fused = false;    // ... which did not stand on this buffer: the two-pass kernels take it
     unsigned long long poll_seq = 0;   // FFQ_F_POLL_RESULT: the front ends in a publisher that writes this number; no end event
     bool go_ranked = false;   // the front is the index kernel only: the list-ranking tier follows at the wait
     bool index_done = false;  // the line index of this buffer is built (a later tier re-uses it)
@@ -78,6 +80,15 @@ struct ffq_ctx {
     RankBufs rk = {};                    // its scratch (ffq_ranked.h), grow-only
     int64_t rk_cap_tiles = 0, rk_cap_c = 0;
     int dense_skip = 0;                  // scans left that start with the dense configuration of them
+    // single-pass index + decode (ffq_fused.h): descriptors, per-tile prefixes / phases, verdict; grow-only
+    unsigned long long *fz_descA = nullptr, *fz_descG = nullptr;
+    int64_t fz_desc_cap = 0, fz_descg_cap = 0;
+    long long *fz_qbase = nullptr;
+    uint8_t *fz_qphase = nullptr;
+    int64_t fz_tiles_cap = 0;
+    uint32_t *fz_bad = nullptr;
+    int fz_grid = -1;                    // persistent workgroups that are resident together (-1: not asked yet, 0: cannot run)
+    int fused_skip = 0, fused_backoff = 15;   // scans left that do not try it (it failed: long lines, odd records), and the next count
     bool decode_timed = false;           // ev[6] marks the start of the decode kernel of the pending front
     // scratch, grow-only
     int64_t cap_tiles = 0;
@@ -260,6 +271,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->rk.S[0]); (void)hipFree(c->rk.S[1]); (void)hipFree(c->rk.C[0]); (void)hipFree(c->rk.C[1]);
     (void)hipFree(c->rk.D); (void)hipFree(c->rk.root);
     free_chain(c);
+    (void)hipFree(c->fz_descA); (void)hipFree(c->fz_descG); (void)hipFree(c->fz_qbase); (void)hipFree(c->fz_qphase); (void)hipFree(c->fz_bad);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
     (void)hipFree(c->qdir); (void)hipFree(c->p4s); (void)hipFree(c->qrel);
@@ -401,7 +413,7 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 
 extern "C" void ffq_ctx_forget(ffq_ctx *c)
 {
-    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->ranked_skip = 0; }
+    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->ranked_skip = 0; c->fused_skip = 0; c->fused_backoff = 15; }
 }
 
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
@@ -527,6 +539,77 @@ static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st, bool t
                        a.qual_cap, ablate);
 }
 
+// ---- the single-pass index + decode front (ffq_fused.h) ---------------------------------------------
+// persistent workgroups that fit the device together (every one of them must be resident: they wait for one another)
+static int fused_grid(ffq_ctx *c)
+{
+    if (c->fz_grid < 0) {
+        int occ = 0;
+        hipDeviceProp_t prop;
+        c->fz_grid = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_scan_fused, 256, 0) == hipSuccess && occ > 0 &&
+            hipGetDeviceProperties(&prop, c->device) == hipSuccess)
+            c->fz_grid = std::min(1024, occ * prop.multiProcessorCount) / FZ_GROUP * FZ_GROUP;
+        (void)hipGetLastError();
+    }
+    return c->fz_grid;
+}
+
+template <class T>
+static int grow_dev(ffq_ctx *c, T **p, int64_t *cap, int64_t need);
+
+static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles);
+
+static int enqueue_fused_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles, int *grid_out)
+{
+    const int Gmax = fused_grid(c);
+    int G = (int)std::min<int64_t>(Gmax, (ntiles + FZ_GROUP - 1) / FZ_GROUP * FZ_GROUP);
+    if (PROBES && getenv("FFQ_FZ_GRID")) G = std::min(std::max(atoi(getenv("FFQ_FZ_GRID")) / FZ_GROUP * FZ_GROUP, FZ_GROUP), 1024);
+    const int64_t niter = (ntiles + G - 1) / G;
+    int rc = grow_dev(c, &c->fz_descA, &c->fz_desc_cap, niter * G);
+    if (!rc) rc = grow_dev(c, &c->fz_descG, &c->fz_descg_cap, niter * (G / FZ_GROUP));
+    if (!rc && ntiles > c->fz_tiles_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->fz_qbase); (void)hipFree(c->fz_qphase);
+        c->fz_qbase = nullptr; c->fz_qphase = nullptr; c->fz_tiles_cap = 0;
+        if (hipMalloc((void **)&c->fz_qbase, (size_t)ntiles * 8) != hipSuccess || hipMalloc((void **)&c->fz_qphase, (size_t)ntiles) != hipSuccess)
+            return fail(FFQ_E_NOMEM, "hipMalloc(fused scratch) failed");
+        c->fz_tiles_cap = ntiles;
+    }
+    if (!rc && !c->fz_bad && hipMalloc((void **)&c->fz_bad, 16) != hipSuccess) rc = fail(FFQ_E_NOMEM, "hipMalloc failed");
+    if (rc) return rc;
+    hipStream_t sA = c->stream;
+    HIPCHK(hipMemsetAsync(c->fz_descA, 0, (size_t)(niter * G) * 8, sA));
+    HIPCHK(hipMemsetAsync(c->fz_descG, 0, (size_t)(niter * (G / FZ_GROUP)) * 8, sA));
+    HIPCHK(hipMemsetAsync(c->fz_bad, 0, 16, sA));
+    FuseArgs fa{};
+    fa.d = a.d_buf; fa.n = a.n_bytes; fa.s = a.s; fa.ntiles = (int32_t)ntiles;
+    fa.ent = c->ent; fa.cnt = c->cnt;
+    fa.descA = c->fz_descA; fa.descG = c->fz_descG; fa.qbase = c->fz_qbase; fa.qphase = c->fz_qphase; fa.bad = c->fz_bad;
+    fa.out = a.d_qual; fa.out_cap = a.qual_cap; fa.qadd = a.qual_add; fa.at_char = (uint32_t)'@';
+    fa.Lval = make_index(c, a, ntiles); fa.d_L = c->d_L;      // (the device copy of the index descriptor, as k_scan_lines leaves it)
+    fa.ablate = (PROBES && getenv("FFQ_FZ_ABLATE")) ? atoi(getenv("FFQ_FZ_ABLATE")) : 0;
+    fa.prof = nullptr;
+    if (PROBES && getenv("FFQ_FZ_PROF")) {
+        if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 128));
+        HIPCHK(hipMemsetAsync(c->prof_d, 0, 128, sA));
+        fa.prof = c->prof_d;
+    }
+    HIPCHK(hipEventRecord(c->ev[0], sA));
+    hipLaunchKernelGGL(k_scan_fused, dim3((unsigned)G), dim3(256), 0, sA, fa);
+    HIPCHK(hipEventRecord(c->ev[1], sA));
+    if (PROBES && fa.prof) {
+        unsigned long long hp[16];
+        HIPCHK(hipMemcpy(hp, c->prof_d, 128, hipMemcpyDeviceToHost));
+        const char *nm[11] = {"issue", "park+scan", "B1", "list+entries", "B2", "phase+table", "gather", "desc+prefix", "B4", "write-out", "wait-next-tile"};
+        fprintf(stderr, "[ffq fused prof] G %d, per workgroup iteration (cycles):", G);
+        for (int k = 0; k < 11; k++) fprintf(stderr, " %s %.0f", nm[k], (double)hp[k] / (double)std::max<unsigned long long>(hp[11], 1));
+        fprintf(stderr, "\n");
+    }
+    *grid_out = G;
+    return FFQ_OK;
+}
+
 static Pub make_pub(ffq_ctx *c) { return Pub{c->ctl, c->hm_ctl, c->hm_res, c->pub_seq ? c->hm_seq : nullptr, c->pub_seq}; }
 static Pub no_pub(ffq_ctx *c) { return Pub{c->ctl, nullptr, nullptr, nullptr, 0}; }
 
@@ -618,7 +701,7 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     const char *abl = PROBES ? getenv("FFQ_ABLATE") : nullptr;
     const int ablate = abl ? atoi(abl) : 0;
     if (PROBES && getenv("FFQ_PROF")) {
-        if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 64));
+        if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 128));
         HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sA));
         cb.prof = c->prof_d;
     }
@@ -676,6 +759,39 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     if (!c->ctl_clean) HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));    // first scan, or an abandoned front
     c->ctl_clean = false;
 
+    // ---- four-line input with the decode: index AND decoded stream in one pass over the bytes ---------
+    st.fused = false;
+    if (decode && (a.flags & FFQ_F_SINGLE_PASS) && try_fast4 && !st.index_done && !st.no_fused && a.offset < 16) {
+        if (c->fused_skip > 0) c->fused_skip--;
+        else if (fused_grid(c) >= FZ_GROUP) st.fused = true;
+    }
+    if (st.fused) {
+        int G = 0;
+        int rc = enqueue_fused_index(c, a, ntiles, &G);
+        if (rc) return rc;
+        const unsigned int *presum = nullptr;
+        if (nsb > 2048) {
+            hipLaunchKernelGGL(k_sum64, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, sA, (const uint32_t *)c->cnt, 1,
+                               (int64_t)ntiles, c->sbq, nsb);
+            presum = c->sbq;
+        }
+        hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
+        hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
+                           (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
+                           (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, a.table_cap,
+                           (const long long *)c->fz_qbase, (const uint8_t *)c->fz_qphase, a.d_qoff);
+        hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
+                           a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres, no_pub(c), (const uint32_t *)c->fz_bad);
+        hipLaunchKernelGGL(k_qtotal4, dim3(1), dim3(1), 0, sA, c->dres, (const int64_t *)a.d_table, a.table_cap,
+                           a.d_qoff, make_pub(c));
+        c->ctl_clean = true;
+        st.stage = 1;
+        c->pub_seq = 0;
+        if (!st.poll_seq) HIPCHK(hipEventRecord(c->ev[3], sA));
+        HIPCHK(hipGetLastError());
+        return FFQ_OK;
+    }
+
     // ---- line index --------------------------------------------------------------------
     HIPCHK(hipEventRecord(c->ev[0], sA));
     if (!st.index_done)          // (a later tier of the same scan: the index is there already)
@@ -696,7 +812,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            decode ? c->qrel : (uint32_t *)nullptr, c->tileq, decode ? c->p4s : (int64_t *)nullptr,
-                           decode ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0);
+                           decode ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0,
+                           (const long long *)nullptr, (const uint8_t *)nullptr, (int64_t *)nullptr);
         hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                            a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres,
                            decode ? no_pub(c) : make_pub(c));
@@ -731,7 +848,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
             hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
             hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                                (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
-                               (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, (int64_t)0);
+                               (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, (int64_t)0,
+                               (const long long *)nullptr, (const uint8_t *)nullptr, (int64_t *)nullptr);
             hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                                a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres, no_pub(c));
         }
@@ -891,8 +1009,27 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         }
         if (st.stage == 1) {
             if (!c->h_res->fallback) {
-                fill_result(res, *c->h_res, 3, st.retries);
+                fill_result(res, *c->h_res, st.fused ? 6 : 3, st.retries);
+                if (st.fused) c->fused_backoff = 15;
                 break;
+            }
+            if (st.fused) {
+                // the single pass did not stand (lines longer than a tile, a quality line that is not as
+                // long as its sequence line, text in front of the first record, not four-line input at
+                // all ...): the two-pass kernels, from the index it built if that is whole
+                if (PROBES && getenv("FFQ_DEBUG")) {
+                    Fast4Hdr hh;
+                    HIPCHK(hipMemcpy(&hh, c->hdr4, sizeof hh, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[ffq debug] single pass refused: fused_bad %d attempt %d j0 %lld irr_min %llu term_min %llu\n",
+                            c->h_res->fused_bad, hh.attempt, hh.j0, hh.irr_min, hh.term_min);
+                }
+                st.no_fused = true;
+                st.fused = false;
+                c->fused_skip = c->fused_backoff;
+                c->fused_backoff = std::min(4 * c->fused_backoff + 3, 1023);
+                st.index_done = !(c->h_res->fused_bad & (int32_t)FZ_BAD_INDEX);
+                st.retries++;
+                continue;
             }
             // not plain four-line input: the general kernels, from the same line index.  The next
             // scans of this context skip the attempt (and the host round trip it costs here).

@@ -1217,4 +1217,5 @@ __global__ void k_selftest(const uint8_t *__restrict__ bytes, uint32_t *__restri
 
 }  // namespace ffq
 
+#include "ffq_fused.h"
 #include "ffq_ranked.h"

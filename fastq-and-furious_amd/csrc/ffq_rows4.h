@@ -232,8 +232,16 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap,
                                                uint32_t *__restrict__ qrel, TileQ *__restrict__ tileq,
-                                               int64_t *__restrict__ p4s, int64_t p4_cap)
+                                               int64_t *__restrict__ p4s, int64_t p4_cap,
+                                               const long long *__restrict__ fz_qbase, const uint8_t *__restrict__ fz_phase,
+                                               int64_t *__restrict__ fz_qoff)
 {
+    // fz_*: the decoded stream was written by the index pass itself (k_scan_fused, ffq_fused.h) on the
+    // assumption that every fourth line is a record's quality, whole: this kernel then only has to say
+    // where each record's bytes START in it (fz_qoff) -- the quality bytes in front of the tile that holds
+    // pos4 (fz_qbase) plus those of the tile's earlier lines -- and to verify the assumption, per tile (the
+    // lines taken for quality lines, fz_phase, against the newline ordinals) and per record (the quality
+    // line is exactly as long as the sequence line; the chain starts at the buffer's first newline).
     __shared__ __attribute__((aligned(16))) uint16_t s_ent_all[4][R4_LIST];   // the tile's own entries as stored (offset | flags << 14),
                                                                               // then (usually) the first five of the next tile
     __shared__ uint32_t s_la_all[4][8];             // look-ahead entries: position - tile base, flags << 30
@@ -267,10 +275,14 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
     const uint2 vla_raw = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)tn * SLOT + 4 * (lane & 1));
     const uint32_t cb_raw = L.cnt[min(t0 + lane, L.ntiles - 1)];     // SB_TILES == 64 lanes
     const long long sbb = sbbase[sb];
+    const bool fused = fz_qbase != nullptr;
+    long long fzb0 = 0, fzb1 = 0;
+    uint32_t fzph = 0;
+    if (fused) { fzb0 = fz_qbase[t]; fzb1 = fz_qbase[tn]; fzph = fz_phase[t]; }
     // pin the loads here: without a use in front of the early exits below the compiler sinks
     // each load behind the branch that precedes its first use
     asm volatile("" ::"v"(c_raw), "v"(v0.x), "v"(v0.y), "v"(c1_raw), "v"(vla_raw.x), "v"(vla_raw.y), "v"(cb_raw),
-                 "v"(sbb), "s"(attempt), "s"(j0));
+                 "v"(sbb), "s"(attempt), "s"(j0), "v"(fzb0), "v"(fzb1), "v"(fzph));
     const int c = (int)c_raw;
     const bool have_next = t + 1 < L.ntiles;
     const int c1 = have_next ? (int)c1_raw : 0;
@@ -281,6 +293,14 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
     if (c > SLOT) {                    // dense tile: leave it to the general path
         if (lane == 0) atomicMin(&hdr->irr_min, 0ull);
         return;
+    }
+    if (fused) {
+        // the lines the index pass took for quality lines: those that follow entries = phase (mod 4); by the
+        // ordinals a quality line follows entry e iff ordinal(e) = j0 + 3 (mod 4), ordinal(e) = ob + e.  A
+        // tile without a newline has no phase and no place in this scheme.  The chain must start at the
+        // buffer's very first newline (nothing in front of it that could pass for a quality line).
+        const uint32_t want = (uint32_t)(((j0 + 3 - ob) % 4 + 4) % 4);
+        if ((c == 0 || fzph != want || j0 != 0) && lane == 0) atomicMin(&hdr->irr_min, 0ull);
     }
     // the sentinel is entry -1 of tile 0 (ordinal 0): give tile 0 a list that starts with it
     const int pre = (t == 0 && L.s) ? 1 : 0;
@@ -398,6 +418,8 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                       & (qe + 2 < lim)
                       & (((e4 >> 14) & FL_AT) != 0) & (x4 >= qe - 1);                // the next call finds e4
                 f0 = x0 + 1; f1 = x1; f3 = x2; f4 = x3 + 1; f5 = qe;
+                // the single pass decoded the whole quality LINE: it must end where pos5 says
+                if (fused && usual && x4 != qe) atomicMin(&hdr->irr_min, (unsigned long long)(kfirst + r));
             }
             if (act && !usual) {
                 int64_t p0 = 0, p1 = 0, p3 = 0, p4 = 0, p5 = 0;
@@ -454,6 +476,7 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                         }
                     }
                 }
+                if (fused && (cls == 0 || cls == 3 || (cls == 2 && fin)) && !(have >= 5 && POS(4) == p5)) cls = 1;   // (see above)
                 if (cls == 1) atomicMin(&hdr->irr_min, (unsigned long long)k);
                 else if (cls == 2 || cls == 3) {
                     // where the chain ends: cls 2 -> at record k (status of its call); cls 3 -> after
@@ -483,7 +506,28 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
             if (__ballot(act && (cls == 2 || cls == 3)) != 0ull) tile_term_done = true;      // (wave-uniform)
             // rows: COMPLETE records (cls 0, 3) and the final record
             const bool emit = act && (cls == 0 || cls == 3 || (cls == 2 && fin));
-            if (qrel) {
+            if (fused) {
+                // start of the record's bytes in the decoded stream = quality bytes in front of pos4
+                const uint32_t ql = emit ? (uint32_t)(f5 - f4) : 0u;
+                const uint32_t incl = wave_incl_scan(ql);
+                if (emit && kfirst + r < p4_cap) {
+                    long long q;
+                    if (f4 < TILE) {
+                        // in this tile: what the tile holds of an earlier record's quality line (it ends at this
+                        // tile's first record start), then the tile's own records in front of this one
+                        int32_t head = 0;
+                        if (kfirst > 0) {
+                            const int e0 = (int)i0 - pre;            // physical entry of the tile's first record start
+                            const int32_t a0 = (int32_t)(s_ent[e0 + pre] & OFF_MASK);
+                            head = a0 - (e0 >= 1 ? (int32_t)(s_ent[e0 - 1 + pre] & OFF_MASK) + 1 : 0);
+                        }
+                        q = fzb0 + head + (long long)(qrun + incl - ql);
+                    } else if (f4 < 2 * TILE) q = fzb1;
+                    else q = fz_qbase[min((int64_t)t + (f4 >> TILE_SHIFT), (int64_t)L.ntiles - 1)];
+                    fz_qoff[kfirst + r] = q;
+                }
+                qrun += (uint32_t)__shfl((int)incl, 63);
+            } else if (qrel) {
                 // tile-relative offsets of the decoded qualities (32 bits, scratch); k_qfix4 adds the
                 // tile's base and writes the caller's 64-bit offsets
                 const uint32_t ql = emit ? (uint32_t)(f5 - f4) : 0u;
@@ -620,7 +664,7 @@ __global__ void k_qtotal4(DevRes *res, const int64_t *__restrict__ table, int64_
 // validity + result block (end state per fastqandfurious.py:256-279)
 __global__ void k_finalize4(LineIndex L, Fast4Hdr *hdr, const TermInfo4 *__restrict__ tinfo, int eof,
                             int64_t offset, int64_t add, const int64_t *__restrict__ table, int64_t table_cap,
-                            DevRes *res, Pub pb)
+                            DevRes *res, Pub pb, const uint32_t *__restrict__ fz_bad = nullptr)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     res->n_lines = hdr->n_lines;
@@ -629,7 +673,8 @@ __global__ void k_finalize4(LineIndex L, Fast4Hdr *hdr, const TermInfo4 *__restr
     res->has_final = 0;
     const unsigned long long tm = hdr->term_min, im = hdr->irr_min;
     const unsigned long long tk = tm >> 24;
-    if (!hdr->attempt || tm == ~0ull || (im != ~0ull && im <= tk)) { res->fallback = 1; res->fast4_hint = 0; publish(pb, res); return; }
+    res->fused_bad = fz_bad ? (int32_t)*fz_bad : 0;
+    if (!hdr->attempt || tm == ~0ull || (im != ~0ull && im <= tk) || (fz_bad && *fz_bad)) { res->fallback = 1; res->fast4_hint = 0; publish(pb, res); return; }
     res->fallback = 0;
     res->fast4_hint = 1;
     const int tt = (int)(tm & 0xFFFFFF);

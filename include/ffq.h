@@ -72,6 +72,14 @@ extern "C" {
                                       marker less per scan (~3 us of idle GPU); ms_chain / ms_total are
                                       not measured then.  Ignored with FFQ_F_DECODE_QUAL.              */
 
+#define FFQ_F_SINGLE_PASS  16u     /* with FFQ_F_DECODE_QUAL on plain four-line input: the line-index pass itself writes the
+                                      decoded stream (csrc/ffq_fused.h; res.path 6), so that the input is read ONCE -- HBM
+                                      traffic 1.0 x the algorithmic bytes instead of 1.5 x.  Opt-in: on MI355X it is SLOWER
+                                      than the two passes (the index pass is already at 70 % of its VALU issue rate; with the
+                                      compaction of the quality bytes on top it becomes instruction-bound: 7.6 ms against 5.1
+                                      per 10 GiB).  Same result bit for bit; input it cannot vouch for
+                                      (lines longer than a tile, a quality line longer than its read) goes to the two passes. */
+
 typedef struct ffq_ctx ffq_ctx;
 
 typedef struct ffq_scan_result {
@@ -84,9 +92,10 @@ typedef struct ffq_scan_result {
                                rule, the final record's row                              */
     int32_t last_status;    /* status of that last call                                   */
     int32_t end_state;      /* FFQ_END_*                                                  */
-    int32_t path;           /* 3 = four-line fast path, 0 = general chain kernels, 2 = the
-                               same with the dense LDS budget, 5 = list ranking over the
-                               "\n@" matches (long records), 1 = serial walker            */
+    int32_t path;           /* 3 = four-line fast path, 6 = the same with the Phred decode done by
+                               the index pass itself (one pass over the input), 0 = general chain
+                               kernels, 2 = the same with the dense LDS budget, 5 = list ranking
+                               over the "\n@" matches (long records), 1 = serial walker   */
     int32_t retries;        /* internal re-runs (line-index pool growth)                  */
     int64_t n_lines;        /* newline count seen by the line-index kernel                */
     float   ms_index;       /* device time of the line-index kernel (hipEvent)            */

@@ -2,7 +2,7 @@
  * ffq_probe.h -- entry points that exist ONLY in the instrumented build of the library,
  * libffq_probe.so (the same sources compiled with -DFFQ_PROBES; fastq-and-furious_amd/build.py
  * build_probe()).  Nothing here is part of the drop-in boundary (include/ffq.h) and nothing in the
- * product loads that library: it serves tools/*.py and the `hbm_read_probe` figure of bench.py.
+ * product loads that library: it serves the scripts under tools/ and the `hbm_read_probe` figure of bench.py.
  * The instrumented build also honours the ablation switches FFQ_ABLATE / FFQ_K1_ABLATE /
  * FFQ_DQ_ABLATE / FFQ_PROF / FFQ_DEBUG (environment), which the product build does not compile.
  */

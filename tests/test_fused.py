@@ -1,0 +1,142 @@
+"""The single-pass index + decode (csrc/ffq_fused.h) against the oracle, and its refusals.
+
+On plain four-line input with FFQ_F_DECODE_QUAL | FFQ_F_SINGLE_PASS the index kernel itself writes the
+decoded stream (res.path == 6; opt-in: on MI355X it saves a third of the HBM traffic and costs time).  That is speculation -- every fourth line is a record's quality, whole -- verified by
+the row kernel; whatever it cannot vouch for must come out of the two-pass kernels instead
+(path 3 / 0), with the same table, offsets and bytes as the oracle's restatement of
+array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, -33)  (/root/reference/doc/user-guide.rst:126-141).
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import decode_same as _decode_same, random_records
+
+pytestmark = pytest.mark.gpu
+
+
+def decode_same(ctx, hipmod, oracle, data, flags=0, **kw):
+    return _decode_same(ctx, hipmod, oracle, data, flags=flags | hipmod.F_SINGLE_PASS, **kw)
+
+
+@pytest.fixture
+def hipmod(pkg):
+    from fastqandfurious_amd import hip
+    return hip
+
+
+@pytest.mark.parametrize("nrec,first", ((1, 0), (3, 5), (50, 7), (51, 0), (2000, 0), (12345, 1000), (60000, 5), (400000, 0)))
+def test_fused_synth_single(gpu_ctx, hipmod, oracle, nrec, first):
+    from fastqandfurious_amd import synth
+    data = synth.single(first, nrec, seed=42)
+    res = decode_same(gpu_ctx, hipmod, oracle, data)
+    # (a tile -- here: the short last one -- without a sequence line followed by a '+' line inside it gives the
+    # single pass nothing to tell the line types by: such a buffer goes to the two passes)
+    tail = len(data) % 16384
+    if nrec > 1 and (tail == 0 or tail > 700):
+        assert res.path == 6
+    else:
+        assert res.path in (3, 6)
+    gpu_ctx.forget()
+    assert _decode_same(gpu_ctx, hipmod, oracle, data).path == 3          # without the flag: the two passes
+
+
+def test_fused_shapes(gpu_ctx, hipmod, oracle):
+    rng = np.random.default_rng(77)
+    for name, mk, want in (
+            ("illumina-repeat-header", lambda: random_records(rng, 30000, 151, 151, repeat_hdr=True), 6),
+            ("variable", lambda: random_records(rng, 30000, 20, 400), 6),
+            ("short-lines", lambda: random_records(rng, 40000, 1, 40, hdr_hi=8), None),       # lines under 16 bytes: byte-wise tails
+            ("kilobase", lambda: random_records(rng, 600, 2000, 6000), None),                # few lines per tile
+            ("lines-longer-than-a-tile", lambda: random_records(rng, 40, 30000, 90000), 3),
+            ("wrapped", lambda: random_records(rng, 5000, 1, 700, wrap=61), 0)):
+        data = mk()
+        gpu_ctx.forget()
+        res = decode_same(gpu_ctx, hipmod, oracle, data)
+        if want is not None:
+            assert res.path == want, (name, res.path)
+        gpu_ctx.forget()
+        decode_same(gpu_ctx, hipmod, oracle, data[:-1])                      # no trailing newline: 'Incomplete final quality string'
+        gpu_ctx.forget()
+        decode_same(gpu_ctx, hipmod, oracle, data[:len(data) * 2 // 3], eof=False)
+        gpu_ctx.forget()
+        decode_same(gpu_ctx, hipmod, oracle, data[:len(data) * 2 // 3], eof=True)
+
+
+def test_fused_refuses_what_it_cannot_vouch_for(gpu_ctx, hipmod, oracle):
+    """Valid for the reference, not for the single pass: each must come out right through the other kernels."""
+    rng = np.random.default_rng(78)
+    good = random_records(rng, 20000, 100, 150)
+    cases = {
+        # a quality line LONGER than its sequence line: the reference cuts it at pos5 = pos4 + len(seq)
+        # (_fastqandfurious.c:129) and finds the next "\n@" behind it -- the single pass decoded the whole line
+        "long-quality-line": good[:3000000].rsplit(b"\n@", 1)[0] + b"\n@odd\nACGT\n+\nIIIIIIII\n" + good[:1000000],
+        # text in front of the first record that could pass for lines of one
+        "leading-text": b"# produced by a tool\n# and a second line\n# third\n# fourth\n# fifth\n" + good,
+        # a blank line between two records
+        "blank-line": good[:2000000].rsplit(b"\n@", 1)[0] + b"\n\n" + good[:500000],
+        # one wrapped record among thousands of plain ones
+        "one-wrapped": good[:1500000].rsplit(b"\n@", 1)[0] + b"\n@w\nACGTAC\nGTAC\n+\nIIIIII\nIIII\n" + good[:700000],
+    }
+    for name, data in cases.items():
+        gpu_ctx.forget()
+        res = decode_same(gpu_ctx, hipmod, oracle, data)
+        assert res.path != 6, name
+        # (the context remembers the refusal: the next scan goes to the two passes directly and is right too)
+        decode_same(gpu_ctx, hipmod, oracle, data)
+
+
+def test_fused_search_offsets_and_sentinel(gpu_ctx, hipmod, oracle):
+    from fastqandfurious_amd import synth
+    data = synth.single(3, 5000, seed=42).tobytes()
+    for kw in (dict(sentinel=False, add=0), dict(sentinel=False, add=0, offset=1), dict(sentinel=False, add=0, offset=15),
+               dict(sentinel=True, offset=1), dict(sentinel=False, add=0, offset=400)):
+        gpu_ctx.forget()
+        decode_same(gpu_ctx, hipmod, oracle, data, **kw)
+    # what the stream front end scans: the fill starts with the last byte of the previous record's quality
+    carry = b"I\n" + data
+    gpu_ctx.forget()
+    res = decode_same(gpu_ctx, hipmod, oracle, carry, sentinel=False, add=0)
+    assert res.path == 6
+
+
+def test_fused_remembers_and_recovers(gpu_ctx, hipmod, oracle):
+    """After a refusal the context skips the attempt for a while, then tries again."""
+    from fastqandfurious_amd import synth
+    rng = np.random.default_rng(79)
+    longs = random_records(rng, 30, 40000, 60000)
+    plain = synth.single(0, 20000, seed=42)
+    gpu_ctx.forget()
+    assert decode_same(gpu_ctx, hipmod, oracle, longs).path == 3
+    paths = [decode_same(gpu_ctx, hipmod, oracle, plain).path for _ in range(18)]
+    assert paths[0] == 3 and paths[-1] == 6
+
+
+def test_fused_steps_aside_for_other_work_on_the_device(gpu_ctx, hipmod, oracle):
+    """Its workgroups wait for one another and must all be resident; kernels of another stream that hold
+    compute units when it starts can keep some out.  It must notice (50 ms), step aside, and the two
+    passes must deliver the same result -- never hang, never a wrong byte."""
+    import time
+    import torch
+    from fastqandfurious_amd import synth
+    data = synth.single(0, 2000000, seed=42)              # 644 MB
+    want, *_ = oracle.scan(data)
+    wq, wqoff = oracle.decode_quals(data, want)
+    dbuf = torch.from_numpy(data.copy()).cuda()
+    n = len(want)
+    table = torch.empty((n + 8, 6), dtype=torch.int64, device="cuda")
+    qual = torch.empty(wq.size + 64, dtype=torch.int8, device="cuda")
+    qoff = torch.empty(n + 9, dtype=torch.int64, device="cuda")
+    big = torch.empty(4 << 30, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        gpu_ctx.forget()
+        for _ in range(4):
+            big.fill_(rep)                                  # torch's stream: beside the scan, not in front of it
+        t0 = time.time()
+        rc, res = gpu_ctx.scan_device(dbuf.data_ptr(), data.size, table.data_ptr(), n + 8, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS,
+                                      d_qual=qual.data_ptr(), qual_cap=qual.numel(), d_qoff=qoff.data_ptr())
+        assert time.time() - t0 < 5.0
+        torch.cuda.synchronize()
+        assert rc == 0 and res.path in (3, 6) and int(res.n_records) == n
+        assert (table[:n].cpu().numpy() == want).all() and (qoff[:n + 1].cpu().numpy() == wqoff).all()
+        assert (qual[:wq.size].cpu().numpy() == wq).all()
