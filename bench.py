@@ -361,7 +361,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     n_untimed = settle_steps + args.warmup
 
     def note(out):
-        ms_index.append(out.res.ms_index)
+        if out.res.ms_index > 0:                       # (steps submitted with FFQ_F_NO_TIMING carry no marks)
+            ms_index.append(out.res.ms_index)
         ms_chain.append(out.res.ms_chain)
         ms_decode.append(out.res.ms_decode)
         ms_total.append(out.res.ms_total)
@@ -382,10 +383,16 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
         qoffs = (qoff, torch.empty_like(qoff) if decode else None)
         torch.cuda.synchronize()
 
+        # The index kernel is timed (HIP events around it, on the scan stream) on every TIME_EVERY-th step; the
+        # other steps carry no stream marker at all (FFQ_F_NO_TIMING: each marker is a barrier packet with a
+        # few microseconds of idle GPU around it, and without one the index kernel starts while the previous
+        # step's last one-workgroup kernel is still running).  --time-every 1: marks on every step.
+        te = max(1, args.time_every) if not decode else 1
+
         def submit(i):
             k = i & 1
             ctxs[k].scan_submit(shard.ext.data_ptr(), shard.n_own_bytes, tables[k].data_ptr(), tables[k].shape[0],
-                                sentinel=True, eof=True, flags=flags,
+                                sentinel=True, eof=True, flags=flags | (hip.F_NO_TIMING if (i % te) else 0),
                                 d_qual=quals[k].data_ptr() if decode else None,
                                 qual_cap=quals[k].numel() if decode else 0,
                                 d_qoff=qoffs[k].data_ptr() if decode else None)
@@ -583,6 +590,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 "traffic_commit": traffic[2] if traffic else None,
                 "algorithmic_bytes_per_launch": algo,
                 "avg_launch_ms": round(t_dom * 1e3, 4),
+                "launches_timed": len(ms_decode if dom == "k_decode_stream" else ms_index),
                 "launch_ms_spread": spread(ms_decode if dom == "k_decode_stream" else ms_index),
             },
             "hbm_read_probe": None if probe_gbs is None else {
@@ -623,6 +631,9 @@ def main():
                     help="untimed steps in front of the warm-up until the GPU has been busy this long "
                          "(its clocks take ~15 ms of load to settle after an idle spell); 0: none")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="N=1, no decode: HIP-event marks around the index kernel on every n-th step only (default 4; "
+                         "1: every step)")
     ap.add_argument("--single-pass", action="store_true",
                     help="decode workloads: the index pass writes the decoded stream itself (FFQ_F_SINGLE_PASS; the input "
                          "is read once -- measured slower than the two passes on MI355X, see DESIGN.md)")

@@ -11,6 +11,7 @@
 #include "ffq_pool.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -55,6 +56,8 @@ struct ScanState {
     int repairs = 0;          // repair passes of the general kernels (reported with retries)
     bool dense_cfg = false, fast4_failed = false;
     bool probe4 = false;      // the front carries the fast path's kernels as a probe (see ffq_ctx::fast4_skip)
+    bool untimed = false;     // FFQ_F_NO_TIMING: no marks around the index kernel, which may start beside the previous front's last kernel
+
     bool fused = false;       // the front is the single-pass index + decode kernel (ffq_fused.h)
     bool no_fused = false;    // ... which did not stand on this buffer: the two-pass kernels take it
     unsigned long long poll_seq = 0;   // FFQ_F_POLL_RESULT: the front ends in a publisher that writes this number; no end event
@@ -126,6 +129,7 @@ struct ffq_ctx {
     unsigned long long seq = 0;         // last number handed out
     unsigned long long pub_seq = 0;     // what the publisher being enqueued writes (0: nothing)
     bool ctl_clean = false;             // the control block is zero (creation, or a publisher ran last)
+    bool ctl_was_clean = false;         //   ... as it was when the front being enqueued began (no memset in front of it)
     int64_t *d_word = nullptr;          // 2 scratch words for the small table queries
     int64_t *h_word = nullptr;          //   and their pinned mirror
     int64_t *d_cut = nullptr, *h_cut = nullptr;    // ffq_table_cut: 6 words
@@ -512,11 +516,19 @@ static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
 // The line-index launch: one workgroup per whole tile; the ragged last tile (if any) rides along
 // as workgroup 0's second tile.  A buffer shorter than a tile is one workgroup.
 static void launch_scan_lines(ffq_ctx *c, hipStream_t st, const uint8_t *d_buf, int64_t n_bytes, int64_t ntiles,
-                              const LineIndex &L, uint32_t at_char, int ablate = 0)
+                              const LineIndex &L, uint32_t at_char, int ablate = 0, bool any_order = false)
 {
     const int64_t nfull = n_bytes >> TILE_SHIFT;
     const int ragged = ntiles > nfull ? (int)nfull : -1;
-    if (nfull > 0)
+    if (nfull > 0 && any_order)
+        // No barrier in front of this dispatch: it may start while the kernel queued before it (the previous
+        // scan's last, one-workgroup kernel -- another context's, on the same stream) is still running.  The
+        // index kernel reads the caller's bytes and writes this context's own scratch, nothing the previous
+        // scan touches; the kernels behind it are ordinary launches and wait for everything in front of them.
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)nfull), dim3(256), 0, st, nullptr, nullptr,
+                              hipExtAnyOrderLaunch, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0,
+                              ablate, L, c->d_L, at_char, ragged);
+    else if (nfull > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)nfull), dim3(256), 0, st, d_buf,
                            n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, ablate, L, c->d_L,
                            at_char, ragged);
@@ -756,6 +768,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     // without the decode every front ends in a publisher: it can say "done" itself
     st.poll_seq = ((a.flags & FFQ_F_POLL_RESULT) && !decode) ? ++c->seq : 0;
     c->pub_seq = st.poll_seq;
+    c->ctl_was_clean = c->ctl_clean;
     if (!c->ctl_clean) HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), sA));    // first scan, or an abandoned front
     c->ctl_clean = false;
 
@@ -793,10 +806,13 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     }
 
     // ---- line index --------------------------------------------------------------------
-    HIPCHK(hipEventRecord(c->ev[0], sA));
+    // (FFQ_F_NO_TIMING with the polled completion: no stream marker anywhere in the front -- each is a barrier
+    // packet with a few microseconds of idle GPU around it)
+    st.untimed = (a.flags & FFQ_F_NO_TIMING) && st.poll_seq && !st.index_done && c->ctl_was_clean;
+    if (!st.untimed) HIPCHK(hipEventRecord(c->ev[0], sA));
     if (!st.index_done)          // (a later tier of the same scan: the index is there already)
-        launch_scan_lines(c, sA, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', k1abl);
-    HIPCHK(hipEventRecord(c->ev[1], sA));
+        launch_scan_lines(c, sA, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', k1abl, st.untimed);
+    if (!st.untimed) HIPCHK(hipEventRecord(c->ev[1], sA));
 
     if (try_fast4) {
         // ---- plain four-line records: rows straight from newline ordinals, then validated -----
@@ -971,7 +987,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             int rc = poll_seq(c, st.poll_seq);
             if (rc) return rc;
             // (the GPU is past this mark; the wait only lets the runtime note it before the mark is read)
-            HIPCHK(hipEventSynchronize(c->ev[1]));
+            if (!st.untimed) HIPCHK(hipEventSynchronize(c->ev[1]));
         } else HIPCHK(hipEventSynchronize(c->ev[3]));
         const LineIndex L = make_index(c, a, st.ntiles);
 
@@ -986,8 +1002,9 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         }
         if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
         float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        if (!st.untimed) HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         if (!st.index_done) res->ms_index = ms;
+        st.untimed = false;
         st.index_done = true;
         res->ms_decode = 0;
         if (!st.poll_seq) {                // (a polled front has no end mark: its tail is not timed)

@@ -36,6 +36,7 @@ F_FORCE_SERIAL = 2
 F_FORCE_RANKED = 4
 F_POLL_RESULT = 8
 F_SINGLE_PASS = 16
+F_NO_TIMING = 32
 
 # every symbol include/ffq.h declares (tests check the library exports them all)
 SYMBOLS = (

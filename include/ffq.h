@@ -80,6 +80,15 @@ extern "C" {
                                       per 10 GiB).  Same result bit for bit; input it cannot vouch for
                                       (lines longer than a tile, a quality line longer than its read) goes to the two passes. */
 
+#define FFQ_F_NO_TIMING    32u     /* with FFQ_F_POLL_RESULT: no timing marks around the line-index kernel either (ms_index is
+                                      0 for this scan).  The front then holds no stream marker at all, and its index kernel is
+                                      dispatched without a barrier: queued behind another context's scan on the same stream it
+                                      starts while that scan's last, one-workgroup kernel is still running.  THE CALLER VOUCHES
+                                      that nothing queued on the stream in front of this scan writes the scanned bytes (a copy
+                                      or a hand-off into the buffer must be waited for first: the index kernel no longer is
+                                      ordered behind it).  A host that times every n-th scan loses nothing but the marks' idle
+                                      microseconds on the others.                                                           */
+
 typedef struct ffq_ctx ffq_ctx;
 
 typedef struct ffq_scan_result {
