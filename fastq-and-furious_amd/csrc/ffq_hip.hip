@@ -789,7 +789,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
             presum = c->sbq;
         }
         hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
-        hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, a.table_cap,
                            (const long long *)c->fz_qbase, (const uint8_t *)c->fz_qphase, a.d_qoff);
@@ -825,7 +825,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         }
         hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
         if (decode) HIPCHK(hipMemsetAsync(c->tileq, 0, (size_t)ntiles * sizeof(TileQ), sA));
-        hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            decode ? c->qrel : (uint32_t *)nullptr, c->tileq, decode ? c->p4s : (int64_t *)nullptr,
                            decode ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0,
@@ -862,7 +862,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
                 presum = c->sbq;
             }
             hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
-            hipLaunchKernelGGL(k_rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                                (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                                (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, (int64_t)0,
                                (const long long *)nullptr, (const uint8_t *)nullptr, (int64_t *)nullptr);

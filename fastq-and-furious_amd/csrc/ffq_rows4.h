@@ -228,6 +228,9 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
 }
 
 // One wave per tile, four tiles per workgroup (no workgroup barrier).
+// FUSED: the variant behind the single-pass index + decode kernel (ffq_fused.h); a template parameter so that the
+// usual instantiation carries none of it (as a run-time test it cost the kernel 3 VGPRs and 4 us per GiB).
+template <bool FUSED>
 __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap,
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
     const uint2 vla_raw = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)tn * SLOT + 4 * (lane & 1));
     const uint32_t cb_raw = L.cnt[min(t0 + lane, L.ntiles - 1)];     // SB_TILES == 64 lanes
     const long long sbb = sbbase[sb];
-    const bool fused = fz_qbase != nullptr;
+    constexpr bool fused = FUSED;
     long long fzb0 = 0, fzb1 = 0;
     uint32_t fzph = 0;
     if (fused) { fzb0 = fz_qbase[t]; fzb1 = fz_qbase[tn]; fzph = fz_phase[t]; }
