@@ -466,27 +466,17 @@ class Context:
                                       int(first), int(count), int(seed)))
 
 
-class FileStream:
-    """The native stream front end (ffq_stream_*): buffer fills of a file descriptor, read ahead
-    into pinned memory while the previous fill is scanned.  Iterating yields
+class _Stream:
+    """What the native stream front ends (ffq_stream_*) have in common.  Iterating yields
     (rows, fill, fill_offset, end_state, err_offset): `rows` int64[n][6] absolute offsets and
     `fill` (uint8 array, fill[i] = stream byte fill_offset + i) are views of memory the stream
     owns -- valid until the next iteration step."""
-
-    def __init__(self, ctx, fd, fbufsize=1 << 24, decode=False, qual_add=-33, start=None, gzip=False):
-        """start: byte of the file the stream begins at (None: the descriptor's current position).
-        A descriptor that can seek is read with pread: its own position does not move.
-        gzip: the descriptor is a gzip file; the stream's reader thread inflates it into the pinned
-        chunk buffers (fbufsize and every offset count DECOMPRESSED bytes)."""
-        self._ctx = ctx
-        self._h = ctypes.c_void_p()
-        self.decode = bool(decode)
-        opener = lib().ffq_stream_open_gzip if gzip else lib().ffq_stream_open2
-        check(opener(ctx.handle, int(fd), int(fbufsize), F_DECODE_QUAL if decode else 0,
-                     int(qual_add), -1 if start is None else int(start), ctypes.byref(self._h)))
+    _h = None
+    decode = False
+    on_close = None        # called once, before the native stream goes away
 
     def tell(self):
-        """File position behind the last byte the stream has read so far."""
+        """File position behind the last chunk handed out (-1: the source has none)."""
         return int(lib().ffq_stream_tell(self._h)) if self._h else -1
 
     def quals(self):
@@ -499,8 +489,6 @@ class FileStream:
                 else np.zeros(0, dtype=np.int8))
         qoff = np.ctypeslib.as_array((ctypes.c_int64 * (n + 1)).from_address(op.value))
         return qual, qoff
-
-    on_close = None        # called once, before the native stream goes away
 
     def close(self):
         if self._h:
@@ -530,6 +518,23 @@ class FileStream:
                 if nb.value else np.zeros(0, dtype=np.uint8))
         return rows, fill, off.value, end.value, err.value
 
+
+class FileStream(_Stream):
+    """The stream front end over a file descriptor: buffer fills read ahead into pinned memory (reader
+    threads; a gzip file is inflated by them) while the previous fill is scanned."""
+
+    def __init__(self, ctx, fd, fbufsize=1 << 24, decode=False, qual_add=-33, start=None, gzip=False):
+        """start: byte of the file the stream begins at (None: the descriptor's current position).
+        A descriptor that can seek is read with pread: its own position does not move.
+        gzip: the descriptor is a gzip file; the stream's reader thread inflates it into the pinned
+        chunk buffers (fbufsize and every offset count DECOMPRESSED bytes)."""
+        self._ctx = ctx
+        self._h = ctypes.c_void_p()
+        self.decode = bool(decode)
+        opener = lib().ffq_stream_open_gzip if gzip else lib().ffq_stream_open2
+        check(opener(ctx.handle, int(fd), int(fbufsize), F_DECODE_QUAL if decode else 0,
+                     int(qual_add), -1 if start is None else int(start), ctypes.byref(self._h)))
+
     def __iter__(self):
         while True:
             t = self._next()
@@ -538,13 +543,13 @@ class FileStream:
                 return
 
 
-class PushStream(FileStream):
+class PushStream(_Stream):
     """The stream front end over any object with readinto() / read() -- BytesIO, bz2 / lzma / gzip
     file objects, sockets: no reader thread; every chunk is read by THIS thread straight into the
     stream's pinned chunk buffer (ffq_stream_push_buffer / ffq_stream_push; no bytes object, no
     copy), then scanned.  Iterates like FileStream."""
 
-    def __init__(self, ctx, fh, fbufsize=1 << 23, decode=False, qual_add=-33):   # noqa: super().__init__ not called on purpose
+    def __init__(self, ctx, fh, fbufsize=1 << 23, decode=False, qual_add=-33):
         self._ctx = ctx
         self._h = ctypes.c_void_p()
         self.decode = bool(decode)
@@ -552,9 +557,6 @@ class PushStream(FileStream):
         self._readinto = getattr(fh, "readinto", None)
         check(lib().ffq_stream_open_push(ctx.handle, int(fbufsize), F_DECODE_QUAL if decode else 0, int(qual_add),
                                          ctypes.byref(self._h)))
-
-    def tell(self):
-        return -1
 
     def _pump(self):
         """One chunk of the source into the next slot (reference read(), fastqandfurious.py:30-36: the

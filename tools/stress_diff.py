@@ -7,6 +7,7 @@ import fastqandfurious_amd
 from fastqandfurious_amd import hip
 from oracle import ffq_oracle as oracle
 import test_gpu_parity as T
+EXTRA = int(os.environ.get("FFQ_STRESS_FLAGS", "0"))      # e.g. 16 = FFQ_F_SINGLE_PASS: the same inputs through the single-pass kernel
 ctx = hip.default_context(0)
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bad = 0
@@ -30,7 +31,7 @@ for seed in range(nseeds):
     for kw, extra in ((dict(), 0), (dict(eof=False), 0), (dict(offset=len(data) // 3), 0), (dict(), hip.F_FORCE_SERIAL),
                       (dict(eof=False, offset=7), hip.F_FORCE_SERIAL)):
         want, end, status, off = oracle.scan(data, **kw)
-        table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL | extra, **kw)
+        table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL | extra | EXTRA, **kw)
         wq, wqoff = oracle.decode_quals(data, want)
         ok = (table.shape == want.shape and (table == want).all() and int(res.end_state) == end and
               int(res.last_status) == status and int(res.end_offset) == off and (qoff == wqoff).all() and (qual == wq).all())

@@ -11,6 +11,7 @@ import fastqandfurious_amd
 from fastqandfurious_amd import hip
 from oracle import ffq_oracle as oracle
 import test_gpu_parity as T
+EXTRA = int(os.environ.get("FFQ_STRESS_FLAGS", "0"))      # e.g. 16 = FFQ_F_SINGLE_PASS: the same inputs through the single-pass kernel
 
 
 def main():
@@ -32,7 +33,7 @@ def main():
         ctx.forget()
         for kw in (dict(), dict(eof=False), dict(offset=len(data) // 3), dict(sentinel=False, offset=5)):
             want, end, status, off = oracle.scan(data, **kw)
-            table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL, **kw)
+            table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL | EXTRA, **kw)
             wq, wqoff = oracle.decode_quals(data, want)
             ok = (table.shape == want.shape and (table == want).all() and int(res.end_state) == end and
                   int(res.last_status) == status and int(res.end_offset) == off and (qoff == wqoff).all()
