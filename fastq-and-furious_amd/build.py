@@ -102,11 +102,11 @@ def _compile(out, extra, verbose):
     sid = source_id()
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wall", "-Wno-unused-function", '-DFFQ_BUILD_ID="%s"' % sid] + extra + \
-          ["-o", out + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz"]      # zlib: the gzip feeder (ffq_stream.h)
+          ["-o", out + ".tmp.%d" % os.getpid()] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz"]      # zlib: the gzip feeder (ffq_stream.h)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    os.replace(out + ".tmp", out)
+    os.replace(out + ".tmp.%d" % os.getpid(), out)      # (a name of its own per process: ranks that rebuild together do not write into one file)
     return out
 
 

@@ -55,7 +55,11 @@ def _forget_input_history(request):
         # the tests choose fbufsize to exercise the refill / carry logic: reads are not coalesced
         # unless a test asks for it (tests/test_iter_decode.py does)
         from fastqandfurious_amd import _fastqandfurious as C
+        default = type(C.entrypos).coalesce_bytes
         C.entrypos.coalesce_bytes = 0
+        yield
+        C.entrypos.coalesce_bytes = default
+        return
     yield
 
 
