@@ -91,7 +91,7 @@ static PyObject *entries_phred(PyObject *self, PyObject *args)
 {
     Py_buffer buf, rows, qual, qoff;
     long long shift = 0;
-    PyObject *atype = NULL;
+    PyObject *atype = NULL, *big = NULL;
     (void)self;
     if (!PyArg_ParseTuple(args, "y*y*Ly*y*O", &buf, &rows, &shift, &qual, &qoff, &atype)) return NULL;
     PyObject *list = NULL;
@@ -100,23 +100,32 @@ static PyObject *entries_phred(PyObject *self, PyObject *args)
         PyErr_SetString(PyExc_ValueError, "rows must hold six int64 positions per record and qoff one offset more than rows");
         goto done;
     }
-    {
+    if (n > 0) {
         const int64_t *p = (const int64_t *)rows.buf;
         const int64_t *o = (const int64_t *)qoff.buf;
         const char *base = (const char *)buf.buf;
+        const int64_t q0 = o[0];
+        if (q0 < 0 || o[n] < q0 || o[n] > (int64_t)qual.len) {
+            PyErr_SetString(PyExc_ValueError, "quality offsets do not fit the decoded stream");
+            goto done;
+        }
+        /* the decoded bytes of all these rows as ONE array('b'); a record's array is a slice of it (the
+         * array type's own slicing: no constructor call with a typecode per record) */
+        PyObject *allb = PyBytes_FromStringAndSize((const char *)qual.buf + q0, (Py_ssize_t)(o[n] - q0));
+        big = allb ? PyObject_CallFunction(atype, "sO", "b", allb) : NULL;
+        Py_XDECREF(allb);
+        if (!big) goto done;
         list = PyList_New(n);
         if (!list) goto done;
         for (Py_ssize_t i = 0; i < n; i++, p += 6) {
-            if (o[i] < 0 || o[i + 1] < o[i] || o[i + 1] > (int64_t)qual.len) {
+            if (o[i] < q0 || o[i + 1] < o[i] || o[i + 1] > o[n]) {
                 PyErr_SetString(PyExc_ValueError, "quality offsets do not fit the decoded stream");
                 Py_CLEAR(list);
                 goto done;
             }
             PyObject *h = cut(base, buf.len, p[0] - shift + 1, p[1] - shift);
             PyObject *s = cut(base, buf.len, p[2] - shift, p[3] - shift);
-            PyObject *qb = PyBytes_FromStringAndSize((const char *)qual.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]));
-            PyObject *q = qb ? PyObject_CallFunction(atype, "sO", "b", qb) : NULL;
-            Py_XDECREF(qb);
+            PyObject *q = PySequence_GetSlice(big, (Py_ssize_t)(o[i] - q0), (Py_ssize_t)(o[i + 1] - q0));
             PyObject *t = !(h && s && q) ? NULL : PyTuple_New(3);
             if (!t) {
                 Py_XDECREF(h); Py_XDECREF(s); Py_XDECREF(q);
@@ -129,7 +138,9 @@ static PyObject *entries_phred(PyObject *self, PyObject *args)
             PyList_SET_ITEM(list, i, t);
         }
     }
+    else list = PyList_New(0);
 done:
+    Py_XDECREF(big);
     PyBuffer_Release(&buf);
     PyBuffer_Release(&rows);
     PyBuffer_Release(&qual);

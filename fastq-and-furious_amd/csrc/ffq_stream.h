@@ -205,11 +205,18 @@ static int64_t stream_gz_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
     while (got < n) {
         { std::lock_guard<std::mutex> lk(s->m); if (s->stop) break; }
         if (s->zin_pos == s->zin_len && !s->z_in_eof) {
-            const int64_t r = ReadPool::read_full(s->fd, s->zin, GZ_IN, s->z_filepos, s->seekable);
+            int64_t r;
+            bool in_eof = false;
+            if (s->seekable) { r = ReadPool::read_full(s->fd, s->zin, GZ_IN, s->z_filepos, true); in_eof = r >= 0 && r < GZ_IN; }
+            else {
+                // a pipe: behind poll(), like the uncompressed case (a stop request is seen within 50 ms)
+                r = stream_fd_read(s, s->zin, GZ_IN, &in_eof);
+                if (r == -2) break;                                  // asked to stop / park with nothing read
+            }
             if (r < 0) { s->z_msg = std::string("read failed: ") + strerror(errno); return -1; }
             s->z_filepos += r;
             s->zin_len = r; s->zin_pos = 0;
-            if (r < GZ_IN) s->z_in_eof = true;
+            if (in_eof) s->z_in_eof = true;
         }
         if (!s->z_member) {
             // between members: zero padding, then the next member or the end of the file

@@ -102,3 +102,34 @@ def test_iterators_use_the_native_entries_and_agree_with_python(E, oracle, pkg, 
     assert nt == ref_nt and type(ref_nt[0]) is F.Entry
     with pytest.raises(TypeError):
         E.entries(b"abc", np.zeros((1, 6), dtype=np.int64), 0, 1, dict)
+
+
+def test_entries_phred_native_equals_the_user_guide_entryfunc(oracle, pkg):
+    """csrc/ffq_entries.c::entries_phred wraps a bulk decode (here: the oracle's) into what the reference's
+    documented decoding entryfunc builds per record (doc/user-guide.rst:126-141): (header, sequence, array('b'))."""
+    from array import array
+    from fastqandfurious_amd import entries, synth
+    nat = entries.native()
+    assert nat is not None and hasattr(nat, "entries_phred")
+    for data in (synth.single(0, 700, seed=42), synth.wrapped(3, 500, seed=43)[0]):
+        buf = data.tobytes()
+        table, *_ = oracle.scan(data)
+        qual, qoff = oracle.decode_quals(data, table)
+        want = []
+        for p in table:
+            q = array("b")
+            q.frombytes(buf[p[4]:p[5]])
+            oracle.arrayadd_b(q, -33)
+            want.append((buf[p[0] + 1:p[1]], buf[p[2]:p[3]], q))
+        rows = np.ascontiguousarray(table)
+        got = []
+        for at in range(0, len(table), 256):          # (in pieces, as the iterator calls it: offsets not starting at 0)
+            got += nat.entries_phred(buf, memoryview(rows[at:at + 256]).cast("B"), 0, qual,
+                                     memoryview(np.ascontiguousarray(qoff[at:at + 257])).cast("B"), array)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g[0] == w[0] and g[1] == w[1] and isinstance(g[2], array) and g[2].typecode == "b" and g[2] == w[2]
+    assert nat.entries_phred(b"", b"", 0, np.zeros(0, np.int8), memoryview(np.zeros(1, np.int64)).cast("B"), array) == []
+    with pytest.raises(ValueError):
+        nat.entries_phred(b"x", memoryview(np.zeros((1, 6), np.int64)).cast("B"), 0, np.zeros(4, np.int8),
+                          memoryview(np.array([0, 9], np.int64)).cast("B"), array)
