@@ -187,3 +187,52 @@ def test_stream_tell_is_behind_the_last_fill_handed_out(gpu_ctx, tmp_path):
             next(it)
         it.close()
         assert fh.tell() == 2 * bs
+
+
+@pytest.mark.gpu
+def test_edge_and_fuzz_corpora_through_pushed_and_gzip_sources(gpu_ctx, golden, tmp_path):
+    """The reference-captured runs of the edge corpus (29 inputs x 4 buffer sizes) and of the fuzz corpus (400
+    seeded inputs, half of them mutated) -- rows and ValueError texts of the reference iterator with its C
+    scanner -- through the sources that are not plain files: chunks pushed from a BytesIO, a gzip file inflated by
+    the library's reader thread, gzip over BytesIO (pushed).  Every fill boundary falls somewhere else than in
+    the reference's own runs; the entries must not care."""
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C
+
+    def run(opener, bs):
+        rows, err = [], None
+        try:
+            with opener() as fh:
+                for p in F.readfastq_iter(fh, bs, F.entryfunc_abspos, C.entrypos):
+                    rows.append([int(x) for x in p])
+        except ValueError as e:
+            err = str(e)
+        return rows, err
+
+    def check(data, want, tag, sizes):
+        if want.get("hang") or want.get("skipped"):
+            return 0
+        gz = tmp_path / "c.gz"
+        gz.write_bytes(gzip.compress(data, 1))
+        n = 0
+        for src, opener in (("bytesio", lambda: io.BytesIO(data)), ("gzip", lambda: gzip.open(gz, "rb")),
+                            ("gzip-bytesio", lambda: gzip.GzipFile(fileobj=io.BytesIO(gz.read_bytes())))):
+            for bs in sizes:
+                rows, err = run(opener, bs)
+                assert rows == want["rows"] and err == want["error"], (tag, src, bs, err, want["error"])
+                n += 1
+        return n
+
+    n = 0
+    C.entrypos.coalesce_bytes = 0
+    for name, ent in golden["edge"].items():
+        data = bytes.fromhex(ent["data"])
+        for bs, runs in ent["runs"].items():
+            n += check(data, runs["c"], name, (int(bs),))
+    for i, ent in enumerate(golden["fuzz"]):
+        if "c" in ent:
+            n += check(bytes.fromhex(ent["data"]), ent["c"], "fuzz%d" % i, (64, 1000) if i % 8 == 0 else (257,))
+    C.entrypos.coalesce_bytes = 8 << 20
+    for i, ent in enumerate(golden["fuzz"][:60]):
+        if "c" in ent:
+            n += check(bytes.fromhex(ent["data"]), ent["c"], "fuzz%d-coalesced" % i, (50000,))
+    assert n > 1500
