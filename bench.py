@@ -9,7 +9,8 @@ already resident in HBM.  Prints ONE JSON line (rank 0).
 
 Workloads (BASELINE.json configs):
     single-1g    1 GiB S-single, 150 bp, Phred+33            (configs[1], default)
-    decode-10g   10 GiB S-single + quality -> int8 decode     (configs[2])
+    decode-10g   10 GiB S-single + quality -> int8 decode     (configs[2]; single pass, segmented output)
+    decode-10g-packed  the same with the packed CSR stream of rounds 1-2 (two passes over the input)
     wrapped-10g  10 GiB S-wrapped, 50-300 bp, 80-col wrap     (configs[3])
     single-100g  ONE 100 GiB S-single stream cut into N byte ranges (configs[4]; strong scaling:
                  12.5 GiB per GPU at N = 8, all of it on one GPU at N = 1)
@@ -34,7 +35,11 @@ GIB = 1 << 30
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 WORKLOADS = {
     "single-1g": dict(kind="single", bytes=1 * GIB, decode=False),
-    "decode-10g": dict(kind="single", bytes=10 * GIB, decode=True),
+    # the decode through the single pass: the caller accepts the qualities SEGMENTED (FFQ_F_SINGLE_PASS: record i =
+    # qual[qoff[i] : qoff[i] + pos5 - pos4], gaps between records) and the index kernel writes them itself
+    "decode-10g": dict(kind="single", bytes=10 * GIB, decode=True, single_pass=True),
+    # ... and as rounds 1-2 measured it: packed CSR stream, two passes over the input
+    "decode-10g-packed": dict(kind="single", bytes=10 * GIB, decode=True),
     "wrapped-10g": dict(kind="wrapped", bytes=10 * GIB, decode=False),
     # small variants for quick checks
     "single-64m": dict(kind="single", bytes=64 << 20, decode=False),
@@ -330,7 +335,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     # without the decode a step's last kernel publishes the result block and the host polls it:
     # no event record behind the step (each is a few microseconds of idle GPU)
     flags = hip.F_DECODE_QUAL if decode else hip.F_POLL_RESULT
-    if decode and args.single_pass:
+    if decode and (args.single_pass or wl.get("single_pass")) and not args.packed:
         flags |= hip.F_SINGLE_PASS               # (opt-in: csrc/ffq_fused.h -- less traffic, more time on this part)
 
     # ---- this rank's byte range of the logical stream, generated in HBM ----------
@@ -342,7 +347,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     table = torch.empty((shard.max_records + 64, 6), dtype=torch.int64, device=dev)
     qual = qoff = None
     if decode:
-        qual = torch.empty(shard.ext.numel(), dtype=torch.int8, device=dev)
+        # (room for the segmented layout of --single-pass too: 8704 bytes per 16 KiB tile)
+        qual = torch.empty(max(shard.ext.numel(), ((shard.ext.numel() + 16383) >> 14) * hip.SEG_STRIDE), dtype=torch.int8, device=dev)
         qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
@@ -529,11 +535,12 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
         #   k_scan_lines     every byte of the scanned buffer read once + 2 B of index per newline
         #   k_decode_stream  quality bytes read + written + 16 B of (offset, pos4) per record
         if decode and out.res.path == 6:
-            # single pass (ffq_fused.h): the index kernel also writes the decoded stream -- every byte of the
-            # buffer read once, 2 B of index per newline and the decoded bytes written
-            dom, t_dom = "k_scan_fused", float(np.mean(ms_index)) * 1e-3
-            algo = shard.ext_scanned_bytes + 2 * int(out.res.n_lines) + int(out.res.n_qual_bytes)
-            traffic = pmc_traffic(name, "k_scan_fused")
+            # single pass (ffq_fused.h): the index kernel also writes the decoded qualities (segmented) -- every byte
+            # of the buffer read once, 2 B of index per newline and the decoded bytes written
+            dom, t_dom = "k_scan_seg", float(np.mean(ms_index)) * 1e-3
+            nq = int((table[:n_rec, 5] - table[:n_rec, 4]).sum().item())
+            algo = shard.ext_scanned_bytes + 2 * int(out.res.n_lines) + nq
+            traffic = pmc_traffic(name, "k_scan_seg")
         elif decode:
             dom, t_dom = "k_decode_stream", float(np.mean(ms_decode)) * 1e-3
             algo = 2 * int(out.res.n_qual_bytes) + 16 * int(out.n_rows)
@@ -548,7 +555,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
         # step's index kernel, so a step's own first-to-last-kernel span is longer than a step)
         algo_path = n_own + 48 * n_rec
         if decode:
-            algo_path += int(out.res.n_qual_bytes) + 8 * n_rec
+            algo_path += int((table[:n_rec, 5] - table[:n_rec, 4]).sum().item()) + 8 * n_rec
         steps_ms = np.diff(np.array([t0] + t_done)) * 1e3
         line = {
             "metric": "GB/s FASTQ parsed",
@@ -571,7 +578,9 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 "workload": name,
                 "description": "%s synthetic FASTQ, %d bytes/GPU, %d records/GPU%s"
                                % ("S-single 150 bp" if wl["kind"] == "single" else "S-wrapped 50-300 bp",
-                                  n_own, n_rec, ", quality->int8 decode" if decode else ""),
+                                  n_own, n_rec, "" if not decode else
+                                  (", quality->int8 decode, segmented output (record i = qual[qoff[i] : qoff[i] + pos5 - pos4]), one pass"
+                                   if out.res.path == 6 else ", quality->int8 decode, packed CSR stream, two passes")),
                 "bytes_per_gpu": n_own,
                 "records_per_gpu": n_rec,
                 "total_bytes": total_bytes,
@@ -631,12 +640,14 @@ def main():
                     help="untimed steps in front of the warm-up until the GPU has been busy this long "
                          "(its clocks take ~15 ms of load to settle after an idle spell); 0: none")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--packed", action="store_true",
+                    help="decode workloads: the packed CSR stream of rounds 1-2 (two passes) even where the workload asks for the single pass")
     ap.add_argument("--time-every", type=int, default=4,
                     help="N=1, no decode: HIP-event marks around the index kernel on every n-th step only (default 4; "
                          "1: every step)")
     ap.add_argument("--single-pass", action="store_true",
-                    help="decode workloads: the index pass writes the decoded stream itself (FFQ_F_SINGLE_PASS; the input "
-                         "is read once -- measured slower than the two passes on MI355X, see DESIGN.md)")
+                    help="decode workloads: the caller accepts the qualities segmented (FFQ_F_SINGLE_PASS) and the index pass "
+                         "writes them itself: the input is read once")
     ap.add_argument("--sharded-step", action="store_true",
                     help="N=1 through the synchronous step the N>1 ranks run (diagnostics)")
     ap.add_argument("--lanes-step", action="store_true",
@@ -706,7 +717,7 @@ def main():
         del shard
         torch.cuda.empty_cache()
         others = {}
-        names = ("decode-10g", "wrapped-10g", "single-100g") if world == 1 else ("single-100g",)
+        names = ("decode-10g", "decode-10g-packed", "wrapped-10g", "single-100g") if world == 1 else ("single-100g",)
         if os.environ.get("FFQ_BENCH_DRY_MULTI") == "1":
             names = ("single-4g-split",)             # (the dry run shares ONE GPU between the ranks)
         for other in names:

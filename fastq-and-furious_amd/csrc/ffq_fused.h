@@ -1,104 +1,71 @@
 // ffq_fused.h -- ONE pass over the input for plain four-line FASTQ with the Phred decode:
-// line index AND decoded quality stream from the same read of every byte.
+// line index AND decoded qualities from the same read of every byte.
 //
 // What is computed is unchanged:
 //   rows      the record chain of /root/reference/src/fastqandfurious.py:251-279 with the scanner of
 //             /root/reference/src/_fastqandfurious.c:25-153 (k_rows4, from the index, as before)
-//   qualities array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, qual_add) of every record, packed
+//   qualities array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, qual_add) of every record
 //             (/root/reference/doc/user-guide.rst:126-141; _fastqandfurious.c:161-185)
-// Until round 3 the decode was a second pass (k_decode_stream re-read the whole input to pick the
-// quality bytes out of it: 1.5 x its algorithmic traffic).  Here the kernel that builds the line index
-// also writes the decoded bytes, so the input is read once.
+// In the two-pass path the decode is a kernel of its own that reads the whole input again to pick the
+// quality bytes out of it (1.5 x its algorithmic traffic).  Here the kernel that builds the line index
+// also writes the decoded bytes.
 //
 // Why that is possible without knowing the rows first.  On four-line input whose quality line is as
 // long as its sequence line (k_rows4 checks both, per record), buf[pos4:pos5] is exactly the CONTENT
 // OF EVERY FOURTH LINE.  Which lines those are can be told from the tile's own bytes: with line types
 // H S P Q cycling, "starts with '@'" holds for every H (and some Q), "starts with '+'" for every P (and
 // some Q), neither for any S -- so two consecutive lines flagged [none][+] are S P and nothing else
-// (Q is followed by H, which starts with '@'; H and P themselves are flagged).  The packed stream is in file order, so a quality byte's place in it is the number of quality
-// bytes in front of it: a tile needs ONE number from the rest of the buffer -- the quality bytes in
-// front of the tile -- and only to know where to write.
+// (Q is followed by H, which starts with '@'; H and P themselves are flagged).
 //
-// How that number arrives without stalling the stream (one dependent load behind a
-// tile's own costs +52 %).  PERSISTENT workgroups: workgroup b takes tiles b, b + G, b + 2G, ...; the
-// next tile's loads are in flight while this one is worked on; a tile's decoded bytes stay in REGISTERS
-// (two 16-byte pieces per lane) for LAG iterations; its prefix is resolved LAG iterations later from a
-// two-level tree of descriptors (every workgroup publishes its tile's count; the last workgroup of each
-// group of 32 sums its group one iteration later; LAG iterations later every workgroup reads the group
-// sums and its own group's counts in one round trip and carries the running base itself: no chain of
-// dependent waits from iteration to iteration, no polling in the common case).  Measured skeleton:
-// tools/pipe_probe.py (round 2).
+// WHERE the bytes go is what decides the design.  Round 3 first built the packed stream (a tile needs the
+// count of quality bytes in front of it: persistent workgroups, pending bytes in registers, a lagged
+// two-level prefix): correct, 1.0 x the algorithmic traffic -- and 7.6 ms per 10 GiB against 5.07 for the
+// two passes, bound by instruction issue at the four waves per SIMD such a kernel gets, and void whenever
+// another queue kept part of its grid from becoming resident (DESIGN.md section 8;
+// profiles/r03_probes/fused_ablate.txt; git history: k_scan_fused).  This version asks for nothing from the
+// rest of the buffer: the output is SEGMENTED -- every 16 KiB tile of the input owns SG_STRIDE bytes of
+// the output and writes the quality lines that START behind one of its newlines there, packed within the
+// segment, in file order.  One workgroup per tile exactly like k_scan_lines, eight per CU, no waiting, no
+// co-residency.  A record's bytes are contiguous (the line that runs over the tile's end is finished from
+// the first SG_EXT bytes of the next tile, loaded with the tile); its start, qoff[i], is exact (k_rows4:
+// the segment of the tile that holds the newline in front of pos4 + the lengths of the segment's earlier
+// lines); its length is pos5 - pos4 of its row.  Between segments there are gaps: the stream is NOT
+// packed and qoff[i + 1] - qoff[i] is not a length.  Callers ask for this layout (FFQ_F_SINGLE_PASS).
 //
 // Everything here is speculation that k_rows4 / k_finalize4 verify (phase of every tile against the
 // newline ordinals, quality line length == sequence line length per record, chain starts at the
-// buffer's first newline): if anything does not hold the result is discarded and the two-pass kernels
-// redo the scan, bit-exact as before.
+// buffer's first newline): if anything does not hold -- or a line is longer than a segment can take --
+// the result is discarded and the two-pass kernels redo the scan (their output is packed, which is a
+// special case of the same contract).
 #pragma once
-// (included at the end of ffq_kernels.h: scan_tile's helpers, lt_mask, addb4, wave_sync are in scope)
+// (included at the end of ffq_kernels.h: scan_tile's helpers, lt_mask, addb4 are in scope)
 
 namespace ffq {
 
-constexpr int FZ_GROUP = 32;             // workgroups per descriptor group
-constexpr int FZ_LAG = 3;                // iterations between a tile's count and its prefix
-constexpr int FZ_MAXQ = 8192;            // decoded bytes a tile can hold back: 2 x 16 B per lane
+constexpr int SG_EXT = 512;                      // bytes of the next tile a workgroup sees (the line that runs over its end)
+constexpr int SG_STRIDE = TILE / 2 + SG_EXT;     // output bytes a tile owns (a multiple of 16: segments start aligned)
 constexpr uint8_t FZ_NOPHASE = 0xFF;
 // bits of *bad
-constexpr uint32_t FZ_BAD_SHAPE = 1u;    // a tile the speculation cannot take (no H S P pattern, dense, too many quality bytes)
-constexpr uint32_t FZ_BAD_POLL = 2u;     // a descriptor never arrived (workgroups not co-resident?)
+constexpr uint32_t FZ_BAD_SHAPE = 1u;    // a tile the speculation cannot take (no S P pattern, dense, a line longer than SG_EXT behind
+                                         // the tile, more quality bytes than a segment holds, the caller's buffer too small)
 constexpr uint32_t FZ_BAD_INDEX = 4u;    // ... and the line index of that tile was not written (dense tile): rebuild it
 
-struct FuseArgs {
+struct SegArgs {
     const uint8_t *d;
     int64_t n;
-    int32_t s;                     // virtual sentinel in front (only shifts nothing here: tile offsets are data offsets)
+    int32_t s;
     int32_t ntiles;
     uint16_t *ent;                 // line index, as k_scan_lines writes it
     uint32_t *cnt;
-    unsigned long long *descA;     // [niter * G]       flag << 62 | quality bytes of the tile
-    unsigned long long *descG;     // [niter * G / 32]  flag << 62 | quality bytes of the group
-    long long *qbase;              // [ntiles] out: quality bytes in front of the tile
-    uint8_t *qphase;               // [ntiles] out: which lines of the tile were taken for quality lines
+    uint8_t *qphase;               // [ntiles] out: which lines of the tile were taken for quality lines (FZ_NOPHASE: none)
     uint32_t *bad;                 // out: FZ_BAD_*
-    int8_t *out;                   // decoded stream
+    int8_t *out;                   // decoded qualities, segmented: tile t owns [t * SG_STRIDE, (t + 1) * SG_STRIDE)
     int64_t out_cap;
     int32_t qadd;
     uint32_t at_char;
     LineIndex Lval;                // the index descriptor, copied to *d_L for the kernels that take it by pointer
     LineIndex *d_L;
-    int32_t ablate;                // (instrumented build only: bit 0 no gather, 1 no quality table, 2 no write-out, 3 no prefix, 4 no index stores)
-    unsigned long long *prof;      // (instrumented build only: cycles per phase, summed over workgroups and iterations)
 };
-
-#ifdef FFQ_PROBES
-#define FZ_T(k) do { if (a.prof && tid == 0) { const long long t__ = clock64(); tacc[k] += t__ - tlast; tlast = t__; } } while (0)
-#else
-#define FZ_T(k) do { } while (0)
-#endif
-
-__device__ __forceinline__ unsigned long long fz_poll(const unsigned long long *p, bool need, uint32_t *bad)
-{
-    unsigned long long v = need ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1ull << 62);
-    unsigned long long t0 = 0;
-    for (int spins = 0; __ballot((v >> 62) == 0ull) != 0ull; spins++) {
-        // never hang the GPU: give up after 50 ms of wall clock, and at once when somebody else already has given
-        // up (the scan is void then; the two-pass kernels redo it).  The workgroups wait for one another, so all
-        // of them must be resident together: the grid is sized for that on an otherwise idle device, and work
-        // of another queue that occupies compute units when this kernel starts can keep some of them out for
-        // good (measured: torch fill kernels running beside it -> the descriptors of the late workgroups never
-        // arrive).  A persistent-grid kernel cannot rule that out; it can only notice and step aside.
-        if ((spins & 63) == 63) {
-            const unsigned long long now = wall_clock64();               // constant 100 MHz
-            if (t0 == 0) t0 = now;
-            if (now - t0 > 5000000ull || (__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FZ_BAD_POLL)) {
-                if ((threadIdx.x & 63) == 0) atomicOr(bad, FZ_BAD_POLL);
-                break;
-            }
-        }
-        __builtin_amdgcn_s_sleep(2);
-        if ((v >> 62) == 0ull) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return v & ((1ull << 62) - 1ull);
-}
 
 // 16 bytes at an arbitrary LDS address (the hardware runs LDS in unaligned-access mode)
 __device__ __forceinline__ uint4 lds_load16(const uint8_t *p)
@@ -127,293 +94,211 @@ __device__ __noinline__ uint4 fz_gather_tail(const uint8_t *s_data, const uint16
     return make_uint4(y[0], y[1], y[2], y[3]);
 }
 
-__device__ __noinline__ void fz_store_part(int8_t *__restrict__ o, uint4 v, int nb)
+__global__ __launch_bounds__(256, 8) void k_scan_seg(SegArgs a)
 {
-    const uint32_t y[4] = {v.x, v.y, v.z, v.w};
-    for (int kb = 0; kb < nb; kb++) {
-        uint32_t wv = y[0];
-#pragma unroll
-        for (int w = 1; w < 4; w++)
-            if ((kb >> 2) == w) wv = y[w];
-        o[kb] = (int8_t)(uint8_t)(wv >> (8 * (kb & 3)));
-    }
-}
-
-__global__ __launch_bounds__(256, 4) void k_scan_fused(FuseArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_data[TILE + 32];
-    __shared__ __attribute__((aligned(16))) uint16_t s_list[SLOT + 8];
-    __shared__ uint16_t s_qs[4][SLOT / 4 + 4];      // per wave (each builds the tile's table itself: no barrier for it)
-    __shared__ uint16_t s_src[4][SLOT / 4 + 4];
-    __shared__ uint32_t s_wtot[2][4];
-    __shared__ long long s_qb[2];
-    const int G = (int)gridDim.x, b = (int)blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int ngroups = G / FZ_GROUP, g = b / FZ_GROUP, bi = b % FZ_GROUP;
-    const int64_t ntiles = a.ntiles;
-    const int64_t niter = (ntiles + G - 1) / G;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 cur[4], nxt[4];
-    uint32_t cur_nb = 0, nxt_nb = 0;              // first byte of the tile behind (flags of a newline at offset TILE - 1)
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[TILE + SG_EXT + 32];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[SLOT];
+    __shared__ uint16_t s_qs[SLOT / 4 + 4];       // packed start of quality line m inside the segment; [NQ] = their total
+    __shared__ uint16_t s_src[SLOT / 4 + 4];      // offset of its first byte in s_data
+    __shared__ uint32_t s_wtot[4], s_wq[4], s_ext;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int64_t T = blockIdx.x;
+    const int64_t tbase = T << TILE_SHIFT;
+    if (T == 0 && tid == 0 && a.d_L) *a.d_L = a.Lval;
     uint32_t o4[4];
+    uint4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) o4[i] = (uint32_t)(w * 4096 + i * 1024 + l * 16);
-    auto issue = [&](u32x4 (&v)[4], uint32_t &nb, int64_t t) {
-        nb = 0;
+    if (tbase + TILE <= a.n) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = u32x4{0, 0, 0, 0};
-        if (t >= ntiles) return;
-        const int64_t base = t << TILE_SHIFT;
-        if (base + TILE <= a.n) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.d + base + o4[i]));
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint4 t4 = load_tail16(a.d, a.n, base + o4[i]);
-                v[i] = u32x4{t4.x, t4.y, t4.z, t4.w};
-            }
+        for (int i = 0; i < 4; i++) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.d + tbase + o4[i]));
+            v[i] = make_uint4(t.x, t.y, t.z, t.w);
         }
-        if (base + TILE < a.n) nb = (uint32_t)a.d[base + TILE];
-    };
-    issue(cur, cur_nb, b);
-    if (b == 0 && tid == 0 && a.d_L) *a.d_L = a.Lval;
-    long long base = 0;                              // (wave 0) quality bytes in front of iteration it - LAG
-    uint4 pend[FZ_LAG][2];                           // decoded pieces of the tiles taken 1 .. LAG iterations ago
-    int pend_cnt[FZ_LAG];
+    } else {
 #pragma unroll
-    for (int k = 0; k < FZ_LAG; k++) { pend[k][0] = pend[k][1] = make_uint4(0, 0, 0, 0); pend_cnt[k] = 0; }
-    const uint32_t vv = (uint32_t)(uint8_t)a.qadd * 0x01010101u;
-#ifdef FFQ_PROBES
-    long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-#endif
+        for (int i = 0; i < 4; i++) v[i] = load_tail16(a.d, a.n, tbase + o4[i]);
+    }
+    // the first SG_EXT bytes of the next tile (zero past the end of the buffer): 32 lanes of wave 0
+    uint4 xe = make_uint4(0, 0, 0, 0);
+    if (tid < SG_EXT / 16) {
+        const int64_t at = tbase + TILE + 16 * tid;
+        if (at + 16 <= a.n) xe = *reinterpret_cast<const uint4 *>(a.d + at);
+        else xe = load_tail16(a.d, a.n, at);
+    }
+    const int nvalid = (int)min((int64_t)(TILE + SG_EXT), a.n - tbase);     // bytes of s_data that exist
 
-    for (int64_t it = 0; it < niter + FZ_LAG; it++) {
-        const int64_t T = it * G + b;
-        const bool have = it < niter && T < ntiles;             // (workgroup-uniform)
-        // ---- descriptor loads FIRST, the next tile's loads behind them (loads return in order) ----
-        const bool lead = w == 0 && bi == FZ_GROUP - 1 && it >= 1 && it - 1 < niter;
-        const bool res = w == 0 && it >= FZ_LAG && it - FZ_LAG < niter;
-        const int64_t j = it - FZ_LAG;
-        const bool isg = l < 32;
-        const unsigned long long *pl = a.descA + (it - 1) * G + g * FZ_GROUP + (l & 31);
-        const unsigned long long *pr = isg ? a.descG + j * ngroups + min(l, ngroups - 1) : a.descA + j * G + g * FZ_GROUP + (l - 32);
-        const bool needr = isg ? (l < ngroups) : (l - 32 < bi);
-        unsigned long long vl = 1ull << 62, vr = 1ull << 62;
-        if (lead && l < FZ_GROUP) vl = __hip_atomic_load(pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (res && needr) vr = __hip_atomic_load(pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (it + 1 < niter) issue(nxt, nxt_nb, T + G);
-        FZ_T(0);
-
-        uint4 newp[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-        int qcount = 0;
-        if (have) {
-            // ---- the line index of this tile, as scan_tile (ffq_kernels.h) builds it ----------------
-            const int64_t tbase = T << TILE_SHIFT;
-            const int nvalid = (int)min((int64_t)TILE, a.n - tbase);
-            uint32_t m[4], c[4];
+    uint32_t m[4], c[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint4 v4 = make_uint4(cur[i].x, cur[i].y, cur[i].z, cur[i].w);
-                *reinterpret_cast<uint4 *>(s_data + o4[i]) = v4;
-                m[i] = nl_mask16(v4);
-                c[i] = __popc(m[i]);
+    for (int i = 0; i < 4; i++) {
+        *reinterpret_cast<uint4 *>(s_data + o4[i]) = v[i];
+        m[i] = nl_mask16(v[i]);
+        c[i] = __popc(m[i]);
+    }
+    if (w == 0) {
+        // where the line that runs over the tile's end stops: the first newline of the extension
+        uint32_t me = 0;
+        if (tid < SG_EXT / 16) { *reinterpret_cast<uint4 *>(s_data + TILE + 16 * tid) = xe; me = nl_mask16(xe); }
+        const unsigned long long hit = __ballot(me != 0u);
+        uint32_t ext = 0xFFFFu;
+        if (hit) {
+            const int fl = __ffsll((long long)hit) - 1;
+            ext = (uint32_t)(16 * fl) + ((uint32_t)__ffs(__shfl((int)me, fl)) - 1u);
+        }
+        if (l == 0) s_ext = ext;
+    }
+    const uint32_t s01 = wave_incl_scan(c[0] | (c[1] << 16));
+    const uint32_t s23 = wave_incl_scan(c[2] | (c[3] << 16));
+    const uint32_t t01 = (uint32_t)__shfl((int)s01, 63), t23 = (uint32_t)__shfl((int)s23, 63);
+    uint32_t ex[4], rowtot[4];
+    ex[0] = (s01 & 0xFFFFu) - c[0];  rowtot[0] = t01 & 0xFFFFu;
+    ex[1] = (s01 >> 16) - c[1];      rowtot[1] = t01 >> 16;
+    ex[2] = (s23 & 0xFFFFu) - c[2];  rowtot[2] = t23 & 0xFFFFu;
+    ex[3] = (s23 >> 16) - c[3];      rowtot[3] = t23 >> 16;
+    const uint32_t wtot = rowtot[0] + rowtot[1] + rowtot[2] + rowtot[3];
+    if (l == 0) s_wtot[w] = wtot;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t t = s_wtot[q];
+        if (q < w) wbase += t;
+        total += t;
+    }
+    const bool dense = total > (uint32_t)SLOT;
+    if (!dense) {
+        uint32_t rb = wbase;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t mm = m[i];
+            uint32_t idx = rb + ex[i];
+            while (mm) {
+                const uint32_t p = (uint32_t)__ffs((int)mm) - 1u;
+                mm &= mm - 1u;
+                s_list[idx] = (uint16_t)(o4[i] + p);
+                idx++;
             }
-            const uint32_t s01 = wave_incl_scan(c[0] | (c[1] << 16));
-            const uint32_t s23 = wave_incl_scan(c[2] | (c[3] << 16));
-            const uint32_t t01 = (uint32_t)__shfl((int)s01, 63), t23 = (uint32_t)__shfl((int)s23, 63);
-            uint32_t ex[4], rowtot[4];
-            ex[0] = (s01 & 0xFFFFu) - c[0];  rowtot[0] = t01 & 0xFFFFu;
-            ex[1] = (s01 >> 16) - c[1];      rowtot[1] = t01 >> 16;
-            ex[2] = (s23 & 0xFFFFu) - c[2];  rowtot[2] = t23 & 0xFFFFu;
-            ex[3] = (s23 >> 16) - c[3];      rowtot[3] = t23 >> 16;
-            const uint32_t wtot = rowtot[0] + rowtot[1] + rowtot[2] + rowtot[3];
-            if (l == 0) s_wtot[it & 1][w] = wtot;
-            FZ_T(1);
-            __syncthreads();
-            FZ_T(2);
-            uint32_t wbase = 0, total = 0;
+            rb += rowtot[i];
+        }
+        // this wave's entries: flags looked up (the byte behind a newline at the tile's last offset is the
+        // extension's first), stored to the index, and left in the list
+        uint16_t *gdst = a.ent + T * SLOT;
+        for (uint32_t jj = (uint32_t)l; jj < wtot; jj += 64) {
+            const uint32_t off = (uint32_t)s_list[wbase + jj];
+            const uint32_t nb = (uint32_t)s_data[off + 1u];
+            const uint32_t fl = (nb == a.at_char) ? (uint32_t)FL_AT : (nb == '+') ? (uint32_t)FL_PLUS : 0u;
+            const uint16_t e = (uint16_t)(off | (fl << 14));
+            s_list[wbase + jj] = e;
+            __builtin_nontemporal_store(e, gdst + wbase + jj);
+        }
+    }
+    if (tid == 0) {
+        a.cnt[T] = total;
+        if (dense) atomicOr(a.bad, FZ_BAD_SHAPE | FZ_BAD_INDEX);
+    }
+    __syncthreads();                                   // the list, flags included, is complete
+    // ---- which lines are quality lines: [none][+] = S P, from the first 64 entries --------------------
+    const int tot = dense ? 0 : (int)total;
+    uint8_t phase = FZ_NOPHASE;
+    {
+        const uint32_t f1 = (uint32_t)s_list[min(l, max(tot - 1, 0))] >> 14;
+        const uint32_t f2 = (uint32_t)s_list[min(l + 1, max(tot - 1, 0))] >> 14;
+        const unsigned long long hit = __ballot(l + 1 < tot && f1 == 0u && f2 == (uint32_t)FL_PLUS);
+        if (hit) phase = (uint8_t)((__ffsll((long long)hit) - 1 + 2) & 3);     // the line behind entry i is S: Q lines follow entries = i + 2 (mod 4)
+    }
+    if (phase == FZ_NOPHASE && tot > 0 && T > 0) {
+        // RARE (a short last tile; a tile of a few long lines): no S P pair among the tile's own lines -- look for
+        // one among the lines in front of it.  Every lane walks the same bytes back from the tile's first (a scalar
+        // loop in effect, a few microseconds for the one workgroup it concerns): newline -1, -2, ... with the
+        // class of the byte behind each; [none][+] at entries (e, e + 1) makes the line behind e the sequence line.
+        uint32_t fnext = (uint32_t)s_list[0] >> 14;            // flags of entry e + 1, starting with entry 0
+        int e = -1;
+        for (int64_t p = tbase - 1; p >= 0 && p >= tbase - 4096 && phase == FZ_NOPHASE; p--) {
+            if (a.d[p] != '\n') continue;
+            const uint32_t nb = (uint32_t)a.d[p + 1];          // (p + 1 <= tbase < n)
+            const uint32_t fl = (nb == a.at_char) ? (uint32_t)FL_AT : (nb == '+') ? (uint32_t)FL_PLUS : 0u;
+            if (fl == 0u && fnext == (uint32_t)FL_PLUS) phase = (uint8_t)(((e + 2) % 4 + 4) % 4);
+            fnext = fl;
+            e--;
+        }
+    }
+    // (a tile without any newline starts no line: nothing to decode, nothing to vouch for)
+    bool shape_bad = dense || (phase == FZ_NOPHASE && tot > 0);
+    int NQ = (phase != FZ_NOPHASE && tot - 1 >= (int)phase) ? (tot - 1 - (int)phase) / 4 + 1 : 0;
+    if (NQ > SLOT / 4) { shape_bad = true; NQ = 0; }
+    // ---- the tile's quality lines: those that start behind entries phase, phase + 4, ... -----------------
+    int st = 0, len = 0;
+    if (tid < NQ) {
+        const int e = (int)phase + 4 * tid;
+        st = (int)(s_list[e] & OFF_MASK) + 1;
+        int en;
+        if (e + 1 < tot) en = (int)(s_list[e + 1] & OFF_MASK);
+        else {
+            // the tile's last line: it ends at the extension's first newline; at the buffer's end if that comes
+            // first; a line longer than the extension is more than a segment can take
+            const uint32_t ext = s_ext;
+            if (ext != 0xFFFFu) en = TILE + (int)ext;
+            else if (nvalid < TILE + SG_EXT) en = nvalid;
+            else { en = st; shape_bad = true; }
+        }
+        len = max(en - st, 0);
+    }
+    const uint32_t incl = wave_incl_scan((uint32_t)len);
+    if (l == 63) s_wq[w] = incl;
+    const bool any_bad = __syncthreads_or(shape_bad ? 1 : 0) != 0;
+    uint32_t wpre = 0, qtot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t t = s_wq[q];
+        if (q < w) wpre += t;
+        qtot += t;
+    }
+    const int qcount = (int)qtot;
+    const bool bad_here = any_bad || qcount > SG_STRIDE || (T + 1) * (int64_t)SG_STRIDE > a.out_cap;
+    if (tid < NQ) { s_qs[tid] = (uint16_t)(wpre + incl - (uint32_t)len); s_src[tid] = (uint16_t)st; }
+    if (tid == 0) {
+        s_qs[NQ] = (uint16_t)min(qcount, 0xFFFF);
+        a.qphase[T] = (any_bad || phase == FZ_NOPHASE) ? FZ_NOPHASE : phase;
+        if (bad_here) atomicOr(a.bad, FZ_BAD_SHAPE);
+    }
+    __syncthreads();
+    if (bad_here || qcount <= 0) return;
+    // ---- gather: every lane takes 16-byte pieces of the segment; whole aligned stores (the bytes behind the
+    //      segment's last piece belong to nobody) ---------------------------------------------------------------
+    const uint32_t vv = (uint32_t)(uint8_t)a.qadd * 0x01010101u;
+    const float inv = (float)NQ / (float)qcount;
+    int8_t *seg = a.out + T * (int64_t)SG_STRIDE;
+    for (int lo = 16 * tid; lo < qcount; lo += 16 * 256) {
+        int mm = min(max((int)((float)lo * inv), 0), NQ - 1);
+        while ((int)s_qs[mm] > lo) mm--;
+        while ((int)s_qs[mm + 1] <= lo) mm++;
+        const int kend = min(16, qcount - lo);
+        const int h0 = min((int)s_qs[mm + 1] - lo, kend);
+        const uint4 A = lds_load16(s_data + (int)s_src[mm] + (lo - (int)s_qs[mm]));
+        uint32_t y[4] = {A.x, A.y, A.z, A.w};
+        if (h0 < kend) {
+            int m2 = mm + 1;
+            while ((int)s_qs[m2 + 1] == (int)s_qs[m2]) m2++;            // (empty quality lines)
+            const int h1 = min((int)s_qs[m2 + 1] - lo, kend);
+            const uint4 B = lds_load16(s_data + (int)s_src[m2] - h0);
+            const uint32_t Bw[4] = {B.x, B.y, B.z, B.w};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t t = s_wtot[it & 1][q];
-                if (q < w) wbase += t;
-                total += t;
+                const uint32_t mk = lt_mask(h0, q);
+                y[q] = (y[q] & mk) | (Bw[q] & ~mk);
             }
-            const bool dense = total > (uint32_t)SLOT;
-            uint32_t rb = wbase;
-            if (!dense) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    uint32_t mm = m[i];
-                    uint32_t idx = rb + ex[i];
-                    while (mm) {
-                        const uint32_t p = (uint32_t)__ffs((int)mm) - 1u;
-                        mm &= mm - 1u;
-                        s_list[idx] = (uint16_t)(o4[i] + p);
-                        idx++;
-                    }
-                    rb += rowtot[i];
-                }
-                // this wave's entries: flags looked up, stored to the index, and left in the list
-                uint16_t *gdst = a.ent + T * SLOT;
-                for (uint32_t jj = (uint32_t)l; jj < wtot; jj += 64) {
-                    const uint32_t off = (uint32_t)s_list[wbase + jj];
-                    const uint16_t e = (uint16_t)(off | (entry_flags(s_data, off, cur_nb, a.at_char) << 14));
-                    s_list[wbase + jj] = e;
-                    if (!(PROBES && (a.ablate & 16))) __builtin_nontemporal_store(e, gdst + wbase + jj);
-                }
-            }
-            if (tid == 0) {
-                a.cnt[T] = total;
-                if (dense) atomicOr(a.bad, FZ_BAD_SHAPE | FZ_BAD_INDEX);
-            }
-            FZ_T(3);
-            __syncthreads();                                   // the list, flags included, is complete
-            FZ_T(4);
-            // ---- which lines are quality lines: [@][none][+] = H S P, from the first 64 entries ------
-            const int tot = dense ? 0 : (int)total;
-            uint8_t phase = FZ_NOPHASE;
-            {
-                // (two lines are enough: [none][+] can only be S P -- H starts with '@', P with '+', and Q is followed by H)
-                const uint32_t f1 = (uint32_t)s_list[min(l, max(tot - 1, 0))] >> 14;
-                const uint32_t f2 = (uint32_t)s_list[min(l + 1, max(tot - 1, 0))] >> 14;
-                const unsigned long long hit = __ballot(l + 1 < tot && f1 == 0u && f2 == (uint32_t)FL_PLUS);
-                if (hit) phase = (uint8_t)((__ffsll((long long)hit) - 1 + 2) & 3);     // line after entry i is S: Q lines follow entries = i + 2 (mod 4)
-            }
-            int NQ = 0;
-            const int eq0 = (phase == 3) ? -1 : (int)phase;     // first entry index >= -1 that a quality line follows
-            if (phase != FZ_NOPHASE) NQ = (tot - 1 >= eq0) ? (tot - 1 - eq0) / 4 + 1 : 0;
-            if (PROBES && (a.ablate & 2)) NQ = 0;
-            bool shape_bad = phase == FZ_NOPHASE || NQ > SLOT / 4;
-            if (NQ > SLOT / 4) NQ = SLOT / 4;
-            // ---- table of the tile's quality lines (start in the tile, start in the packed bytes): every
-            //      wave builds all of it for itself, 64 lines per step -----------------------------------
-            uint16_t *qs = s_qs[w], *src = s_src[w];
-            int run = 0;
-            for (int m0 = 0; m0 < NQ; m0 += 64) {
-                const int mq = m0 + l, e = eq0 + 4 * mq;
-                int st = 0, en = 0;
-                if (mq < NQ) {
-                    st = e < 0 ? 0 : (int)(s_list[e] & OFF_MASK) + 1;
-                    en = (e + 1 < tot) ? (int)(s_list[e + 1] & OFF_MASK) : nvalid;
-                    if (e < 0 && T == 0) en = st;               // bytes in front of the buffer's first newline belong to no record
-                }
-                const int len = max(en - st, 0);
-                const uint32_t incl = wave_incl_scan((uint32_t)len);
-                if (mq < NQ) { qs[mq] = (uint16_t)min(run + (int)incl - len, 0xFFFF); src[mq] = (uint16_t)st; }
-                run += (int)__shfl((int)incl, 63);
-            }
-            qcount = run;
-            if (l == 0) qs[NQ] = (uint16_t)min(run, 0xFFFF);
-            if (qcount > FZ_MAXQ) { shape_bad = true; qcount = 0; }
-            if (shape_bad) { qcount = 0; NQ = 0; }
-            if (tid == 0) {
-                a.qphase[T] = shape_bad ? FZ_NOPHASE : phase;
-                if (shape_bad) atomicOr(a.bad, FZ_BAD_SHAPE);
-            }
-            wave_sync();
-            FZ_T(5);
-            // ---- gather: lane takes packed pieces tid and tid + 256 -----------------------------------
-            if (qcount > 0 && !(PROBES && (a.ablate & 1))) {
-                const float inv = (float)NQ / (float)qcount;
-#pragma unroll
-                for (int jp = 0; jp < 2; jp++) {
-                    const int lo = 16 * (tid + 256 * jp);
-                    if (lo >= qcount) continue;
-                    int mm = min(max((int)((float)lo * inv), 0), NQ - 1);
-                    while ((int)qs[mm] > lo) mm--;
-                    while ((int)qs[mm + 1] <= lo) mm++;
-                    const int kend = min(16, qcount - lo);
-                    const int h0 = min((int)qs[mm + 1] - lo, kend);
-                    const uint4 A = lds_load16(s_data + (int)src[mm] + (lo - (int)qs[mm]));
-                    uint32_t y[4] = {A.x, A.y, A.z, A.w};
-                    if (h0 < kend) {
-                        int m2 = mm + 1;
-                        while ((int)qs[m2 + 1] == (int)qs[m2]) m2++;            // (empty quality lines)
-                        const int h1 = min((int)qs[m2 + 1] - lo, kend);
-                        const uint4 B = lds_load16(s_data + (int)src[m2] - h0);
-                        const uint32_t Bw[4] = {B.x, B.y, B.z, B.w};
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const uint32_t mk = lt_mask(h0, q);
-                            y[q] = (y[q] & mk) | (Bw[q] & ~mk);
-                        }
-                        if (h1 < kend) {
-                            const uint4 t4 = fz_gather_tail(s_data, qs, src, make_uint4(y[0], y[1], y[2], y[3]), m2 + 1, h1, kend, lo);
-                            y[0] = t4.x; y[1] = t4.y; y[2] = t4.z; y[3] = t4.w;
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) y[q] = addb4(y[q], vv);
-                    newp[jp] = make_uint4(y[0], y[1], y[2], y[3]);
-                }
-            }
-        }
-        FZ_T(6);
-        if (it < niter && tid == 0)
-            __hip_atomic_store(a.descA + T, (1ull << 62) | (unsigned long long)qcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (PROBES && (a.ablate & 8)) {
-            if (res && l == 0) s_qb[it & 1] = (long long)(j * G + b) * 7000;
-        } else {
-        if (lead) {
-            // the last workgroup of a group: that group's sum of the iteration before
-            if (__ballot((vl >> 62) == 0ull)) vl = (1ull << 62) | fz_poll(pl, l < FZ_GROUP, a.bad);
-            const uint32_t sum = (uint32_t)__shfl((int)wave_incl_scan(l < FZ_GROUP ? (uint32_t)vl : 0u), 63);
-            if (l == 0)
-                __hip_atomic_store(a.descG + (it - 1) * ngroups + g, (1ull << 62) | (unsigned long long)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (res) {
-            // everyone: the prefix of the tile taken LAG iterations ago
-            if (__ballot((vr >> 62) == 0ull)) vr = (1ull << 62) | fz_poll(pr, needr, a.bad);
-            const uint32_t val = needr ? (uint32_t)vr : 0u;
-            const uint32_t all_g = (uint32_t)__shfl((int)wave_incl_scan(isg ? val : 0u), 63);
-            const uint32_t before = (uint32_t)__shfl((int)wave_incl_scan((isg && l < g) || !isg ? val : 0u), 63);
-            if (l == 0) {
-                s_qb[it & 1] = base + (long long)before;
-                if (j * G + b < ntiles) a.qbase[j * G + b] = base + (long long)before;
-            }
-            base += (long long)all_g;
-        }
-        }
-        FZ_T(7);
-        __syncthreads();                       // the prefix is there; the tile's LDS may be written again
-        FZ_T(8);
-        // ---- the decoded bytes of the tile taken LAG iterations ago go where they belong ------------
-        if (it >= FZ_LAG && pend_cnt[FZ_LAG - 1] > 0 && !(PROBES && (a.ablate & 4))) {
-            const long long qb = s_qb[it & 1];
-            const int cntl = pend_cnt[FZ_LAG - 1];
-#pragma unroll
-            for (int jp = 0; jp < 2; jp++) {
-                const int lo = 16 * (tid + 256 * jp);
-                if (lo >= cntl) continue;
-                const int nb = (int)min((long long)min(16, cntl - lo), a.out_cap - (qb + lo));      // (a stream that is too small keeps what fits)
-                if (nb <= 0) continue;
-                int8_t *dst = a.out + qb + lo;
-                const uint4 p = pend[FZ_LAG - 1][jp];
-                if (nb == 16) {
-                    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
-                    u32x4u t; t.x = p.x; t.y = p.y; t.z = p.z; t.w = p.w;
-                    __builtin_nontemporal_store(t, reinterpret_cast<u32x4u *>(dst));
-                } else fz_store_part(dst, p, nb);
+            if (h1 < kend) {
+                const uint4 t4 = fz_gather_tail(s_data, s_qs, s_src, make_uint4(y[0], y[1], y[2], y[3]), m2 + 1, h1, kend, lo);
+                y[0] = t4.x; y[1] = t4.y; y[2] = t4.z; y[3] = t4.w;
             }
         }
 #pragma unroll
-        for (int k = FZ_LAG - 1; k > 0; k--) { pend[k][0] = pend[k - 1][0]; pend[k][1] = pend[k - 1][1]; pend_cnt[k] = pend_cnt[k - 1]; }
-        pend[0][0] = newp[0]; pend[0][1] = newp[1]; pend_cnt[0] = qcount;
-        FZ_T(9);
-#pragma unroll
-        for (int i = 0; i < 4; i++) cur[i] = nxt[i];
-        cur_nb = nxt_nb;
-#ifdef FFQ_PROBES
-        if (a.prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        FZ_T(10);
+        for (int q = 0; q < 4; q++) y[q] = addb4(y[q], vv);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 t; t.x = y[0]; t.y = y[1]; t.z = y[2]; t.w = y[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(seg + lo));
     }
-#ifdef FFQ_PROBES
-    if (a.prof && tid == 0) {
-        for (int k = 0; k < 11; k++) atomicAdd(a.prof + k, (unsigned long long)tacc[k]);
-        atomicAdd(a.prof + 11, (unsigned long long)(niter + FZ_LAG));
-    }
-#endif
 }
 
 }  // namespace ffq

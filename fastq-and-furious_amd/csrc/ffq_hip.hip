@@ -83,14 +83,10 @@ struct ffq_ctx {
     RankBufs rk = {};                    // its scratch (ffq_ranked.h), grow-only
     int64_t rk_cap_tiles = 0, rk_cap_c = 0;
     int dense_skip = 0;                  // scans left that start with the dense configuration of them
-    // single-pass index + decode (ffq_fused.h): descriptors, per-tile prefixes / phases, verdict; grow-only
-    unsigned long long *fz_descA = nullptr, *fz_descG = nullptr;
-    int64_t fz_desc_cap = 0, fz_descg_cap = 0;
-    long long *fz_qbase = nullptr;
+    // single-pass index + decode (ffq_fused.h): per-tile phases, verdict; grow-only
     uint8_t *fz_qphase = nullptr;
     int64_t fz_tiles_cap = 0;
     uint32_t *fz_bad = nullptr;
-    int fz_grid = -1;                    // persistent workgroups that are resident together (-1: not asked yet, 0: cannot run)
     int fused_skip = 0, fused_backoff = 15;   // scans left that do not try it (it failed: long lines, odd records), and the next count
     bool decode_timed = false;           // ev[6] marks the start of the decode kernel of the pending front
     // scratch, grow-only
@@ -275,7 +271,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->rk.S[0]); (void)hipFree(c->rk.S[1]); (void)hipFree(c->rk.C[0]); (void)hipFree(c->rk.C[1]);
     (void)hipFree(c->rk.D); (void)hipFree(c->rk.root);
     free_chain(c);
-    (void)hipFree(c->fz_descA); (void)hipFree(c->fz_descG); (void)hipFree(c->fz_qbase); (void)hipFree(c->fz_qphase); (void)hipFree(c->fz_bad);
+    (void)hipFree(c->fz_qphase); (void)hipFree(c->fz_bad);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
     (void)hipFree(c->qdir); (void)hipFree(c->p4s); (void)hipFree(c->qrel);
@@ -552,73 +548,31 @@ static void enqueue_decode(ffq_ctx *c, const ScanArgs &a, hipStream_t st, bool t
 }
 
 // ---- the single-pass index + decode front (ffq_fused.h) ---------------------------------------------
-// persistent workgroups that fit the device together (every one of them must be resident: they wait for one another)
-static int fused_grid(ffq_ctx *c)
-{
-    if (c->fz_grid < 0) {
-        int occ = 0;
-        hipDeviceProp_t prop;
-        c->fz_grid = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_scan_fused, 256, 0) == hipSuccess && occ > 0 &&
-            hipGetDeviceProperties(&prop, c->device) == hipSuccess)
-            c->fz_grid = std::min(1024, occ * prop.multiProcessorCount) / FZ_GROUP * FZ_GROUP;
-        (void)hipGetLastError();
-    }
-    return c->fz_grid;
-}
-
-template <class T>
-static int grow_dev(ffq_ctx *c, T **p, int64_t *cap, int64_t need);
-
 static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles);
 
-static int enqueue_fused_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles, int *grid_out)
+static_assert(SG_STRIDE == FFQ_SEG_STRIDE, "include/ffq.h and csrc/ffq_fused.h disagree on the segment stride");
+
+static int enqueue_fused_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
 {
-    const int Gmax = fused_grid(c);
-    int G = (int)std::min<int64_t>(Gmax, (ntiles + FZ_GROUP - 1) / FZ_GROUP * FZ_GROUP);
-    if (PROBES && getenv("FFQ_FZ_GRID")) G = std::min(std::max(atoi(getenv("FFQ_FZ_GRID")) / FZ_GROUP * FZ_GROUP, FZ_GROUP), 1024);
-    const int64_t niter = (ntiles + G - 1) / G;
-    int rc = grow_dev(c, &c->fz_descA, &c->fz_desc_cap, niter * G);
-    if (!rc) rc = grow_dev(c, &c->fz_descG, &c->fz_descg_cap, niter * (G / FZ_GROUP));
-    if (!rc && ntiles > c->fz_tiles_cap) {
+    if (ntiles > c->fz_tiles_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->fz_qbase); (void)hipFree(c->fz_qphase);
-        c->fz_qbase = nullptr; c->fz_qphase = nullptr; c->fz_tiles_cap = 0;
-        if (hipMalloc((void **)&c->fz_qbase, (size_t)ntiles * 8) != hipSuccess || hipMalloc((void **)&c->fz_qphase, (size_t)ntiles) != hipSuccess)
-            return fail(FFQ_E_NOMEM, "hipMalloc(fused scratch) failed");
+        (void)hipFree(c->fz_qphase);
+        c->fz_qphase = nullptr; c->fz_tiles_cap = 0;
+        if (hipMalloc((void **)&c->fz_qphase, (size_t)ntiles) != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(fused scratch) failed");
         c->fz_tiles_cap = ntiles;
     }
-    if (!rc && !c->fz_bad && hipMalloc((void **)&c->fz_bad, 16) != hipSuccess) rc = fail(FFQ_E_NOMEM, "hipMalloc failed");
-    if (rc) return rc;
+    if (!c->fz_bad && hipMalloc((void **)&c->fz_bad, 16) != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc failed");
     hipStream_t sA = c->stream;
-    HIPCHK(hipMemsetAsync(c->fz_descA, 0, (size_t)(niter * G) * 8, sA));
-    HIPCHK(hipMemsetAsync(c->fz_descG, 0, (size_t)(niter * (G / FZ_GROUP)) * 8, sA));
     HIPCHK(hipMemsetAsync(c->fz_bad, 0, 16, sA));
-    FuseArgs fa{};
+    SegArgs fa{};
     fa.d = a.d_buf; fa.n = a.n_bytes; fa.s = a.s; fa.ntiles = (int32_t)ntiles;
     fa.ent = c->ent; fa.cnt = c->cnt;
-    fa.descA = c->fz_descA; fa.descG = c->fz_descG; fa.qbase = c->fz_qbase; fa.qphase = c->fz_qphase; fa.bad = c->fz_bad;
+    fa.qphase = c->fz_qphase; fa.bad = c->fz_bad;
     fa.out = a.d_qual; fa.out_cap = a.qual_cap; fa.qadd = a.qual_add; fa.at_char = (uint32_t)'@';
     fa.Lval = make_index(c, a, ntiles); fa.d_L = c->d_L;      // (the device copy of the index descriptor, as k_scan_lines leaves it)
-    fa.ablate = (PROBES && getenv("FFQ_FZ_ABLATE")) ? atoi(getenv("FFQ_FZ_ABLATE")) : 0;
-    fa.prof = nullptr;
-    if (PROBES && getenv("FFQ_FZ_PROF")) {
-        if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 128));
-        HIPCHK(hipMemsetAsync(c->prof_d, 0, 128, sA));
-        fa.prof = c->prof_d;
-    }
     HIPCHK(hipEventRecord(c->ev[0], sA));
-    hipLaunchKernelGGL(k_scan_fused, dim3((unsigned)G), dim3(256), 0, sA, fa);
+    hipLaunchKernelGGL(k_scan_seg, dim3((unsigned)ntiles), dim3(256), 0, sA, fa);
     HIPCHK(hipEventRecord(c->ev[1], sA));
-    if (PROBES && fa.prof) {
-        unsigned long long hp[16];
-        HIPCHK(hipMemcpy(hp, c->prof_d, 128, hipMemcpyDeviceToHost));
-        const char *nm[11] = {"issue", "park+scan", "B1", "list+entries", "B2", "phase+table", "gather", "desc+prefix", "B4", "write-out", "wait-next-tile"};
-        fprintf(stderr, "[ffq fused prof] G %d, per workgroup iteration (cycles):", G);
-        for (int k = 0; k < 11; k++) fprintf(stderr, " %s %.0f", nm[k], (double)hp[k] / (double)std::max<unsigned long long>(hp[11], 1));
-        fprintf(stderr, "\n");
-    }
-    *grid_out = G;
     return FFQ_OK;
 }
 
@@ -774,13 +728,14 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
 
     // ---- four-line input with the decode: index AND decoded stream in one pass over the bytes ---------
     st.fused = false;
-    if (decode && (a.flags & FFQ_F_SINGLE_PASS) && try_fast4 && !st.index_done && !st.no_fused && a.offset < 16) {
+    // (the segmented layout needs SG_STRIDE bytes of the caller's buffer per tile)
+    if (decode && (a.flags & FFQ_F_SINGLE_PASS) && try_fast4 && !st.index_done && !st.no_fused && a.offset < 16 &&
+        a.qual_cap >= ntiles * (int64_t)SG_STRIDE) {
         if (c->fused_skip > 0) c->fused_skip--;
-        else if (fused_grid(c) >= FZ_GROUP) st.fused = true;
+        else st.fused = true;
     }
     if (st.fused) {
-        int G = 0;
-        int rc = enqueue_fused_index(c, a, ntiles, &G);
+        int rc = enqueue_fused_index(c, a, ntiles);
         if (rc) return rc;
         const unsigned int *presum = nullptr;
         if (nsb > 2048) {
@@ -792,7 +747,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, a.table_cap,
-                           (const long long *)c->fz_qbase, (const uint8_t *)c->fz_qphase, a.d_qoff);
+                           (int64_t)SG_STRIDE, (const uint8_t *)c->fz_qphase, a.d_qoff);
         hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                            a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres, no_pub(c), (const uint32_t *)c->fz_bad);
         hipLaunchKernelGGL(k_qtotal4, dim3(1), dim3(1), 0, sA, c->dres, (const int64_t *)a.d_table, a.table_cap,
@@ -829,7 +784,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            decode ? c->qrel : (uint32_t *)nullptr, c->tileq, decode ? c->p4s : (int64_t *)nullptr,
                            decode ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0,
-                           (const long long *)nullptr, (const uint8_t *)nullptr, (int64_t *)nullptr);
+                           (int64_t)0, (const uint8_t *)nullptr, (int64_t *)nullptr);
         hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                            a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres,
                            decode ? no_pub(c) : make_pub(c));
@@ -865,7 +820,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                                (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                                (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, (int64_t)0,
-                               (const long long *)nullptr, (const uint8_t *)nullptr, (int64_t *)nullptr);
+                               (int64_t)0, (const uint8_t *)nullptr, (int64_t *)nullptr);
             hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                                a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres, no_pub(c));
         }

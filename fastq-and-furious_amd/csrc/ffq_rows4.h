@@ -236,15 +236,16 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                                                int64_t *__restrict__ table, int64_t table_cap,
                                                uint32_t *__restrict__ qrel, TileQ *__restrict__ tileq,
                                                int64_t *__restrict__ p4s, int64_t p4_cap,
-                                               const long long *__restrict__ fz_qbase, const uint8_t *__restrict__ fz_phase,
+                                               int64_t fz_stride, const uint8_t *__restrict__ fz_phase,
                                                int64_t *__restrict__ fz_qoff)
 {
-    // fz_*: the decoded stream was written by the index pass itself (k_scan_fused, ffq_fused.h) on the
-    // assumption that every fourth line is a record's quality, whole: this kernel then only has to say
-    // where each record's bytes START in it (fz_qoff) -- the quality bytes in front of the tile that holds
-    // pos4 (fz_qbase) plus those of the tile's earlier lines -- and to verify the assumption, per tile (the
-    // lines taken for quality lines, fz_phase, against the newline ordinals) and per record (the quality
-    // line is exactly as long as the sequence line; the chain starts at the buffer's first newline).
+    // fz_*: the decoded qualities were written by the index pass itself (k_scan_seg, ffq_fused.h) on the
+    // assumption that every fourth line is a record's quality, whole -- each line into the output segment
+    // (fz_stride bytes per tile) of the tile that holds the newline in front of it.  This kernel then only
+    // has to say where each record's bytes START (fz_qoff): that segment + the lengths of the segment's
+    // earlier lines -- and to verify the assumption, per tile (the lines taken for quality lines, fz_phase,
+    // against the newline ordinals) and per record (the quality line is exactly as long as the sequence
+    // line; the chain starts at the buffer's first newline).
     __shared__ __attribute__((aligned(16))) uint16_t s_ent_all[4][R4_LIST];   // the tile's own entries as stored (offset | flags << 14),
                                                                               // then (usually) the first five of the next tile
     __shared__ uint32_t s_la_all[4][8];             // look-ahead entries: position - tile base, flags << 30
@@ -279,13 +280,12 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
     const uint32_t cb_raw = L.cnt[min(t0 + lane, L.ntiles - 1)];     // SB_TILES == 64 lanes
     const long long sbb = sbbase[sb];
     constexpr bool fused = FUSED;
-    long long fzb0 = 0, fzb1 = 0;
     uint32_t fzph = 0;
-    if (fused) { fzb0 = fz_qbase[t]; fzb1 = fz_qbase[tn]; fzph = fz_phase[t]; }
+    if (fused) fzph = fz_phase[t];
     // pin the loads here: without a use in front of the early exits below the compiler sinks
     // each load behind the branch that precedes its first use
     asm volatile("" ::"v"(c_raw), "v"(v0.x), "v"(v0.y), "v"(c1_raw), "v"(vla_raw.x), "v"(vla_raw.y), "v"(cb_raw),
-                 "v"(sbb), "s"(attempt), "s"(j0), "v"(fzb0), "v"(fzb1), "v"(fzph));
+                 "v"(sbb), "s"(attempt), "s"(j0), "v"(fzph));
     const int c = (int)c_raw;
     const bool have_next = t + 1 < L.ntiles;
     const int c1 = have_next ? (int)c1_raw : 0;
@@ -299,11 +299,11 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
     }
     if (fused) {
         // the lines the index pass took for quality lines: those that follow entries = phase (mod 4); by the
-        // ordinals a quality line follows entry e iff ordinal(e) = j0 + 3 (mod 4), ordinal(e) = ob + e.  A
-        // tile without a newline has no phase and no place in this scheme.  The chain must start at the
+        // ordinals a quality line follows entry e iff ordinal(e) = j0 + 3 (mod 4), ordinal(e) = ob + e.  (A
+        // tile without a newline starts no line: nothing was decoded for it.)  The chain must start at the
         // buffer's very first newline (nothing in front of it that could pass for a quality line).
         const uint32_t want = (uint32_t)(((j0 + 3 - ob) % 4 + 4) % 4);
-        if ((c == 0 || fzph != want || j0 != 0) && lane == 0) atomicMin(&hdr->irr_min, 0ull);
+        if (((c > 0 && fzph != want) || j0 != 0) && lane == 0) atomicMin(&hdr->irr_min, 0ull);
     }
     // the sentinel is entry -1 of tile 0 (ordinal 0): give tile 0 a list that starts with it
     const int pre = (t == 0 && L.s) ? 1 : 0;
@@ -514,19 +514,20 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                 const uint32_t ql = emit ? (uint32_t)(f5 - f4) : 0u;
                 const uint32_t incl = wave_incl_scan(ql);
                 if (emit && kfirst + r < p4_cap) {
-                    long long q;
-                    if (f4 < TILE) {
-                        // in this tile: what the tile holds of an earlier record's quality line (it ends at this
-                        // tile's first record start), then the tile's own records in front of this one
+                    // the newline in front of pos4 (the '+' line's end) lies at tile-relative f4 - 1: in this tile, or
+                    // in a later one -- whose earlier bytes then all belong to this record: its segment's first line
+                    const int32_t x3 = f4 - 1;
+                    long long q = ((long long)t + (x3 >> TILE_SHIFT)) * fz_stride;
+                    if (x3 < TILE) {
+                        // this tile's segment: first the quality line of an earlier record whose '+' line ends in
+                        // this tile (the entry in front of the tile's first record start), then the tile's own
+                        // records in front of this one
                         int32_t head = 0;
-                        if (kfirst > 0) {
-                            const int e0 = (int)i0 - pre;            // physical entry of the tile's first record start
-                            const int32_t a0 = (int32_t)(s_ent[e0 + pre] & OFF_MASK);
-                            head = a0 - (e0 >= 1 ? (int32_t)(s_ent[e0 - 1 + pre] & OFF_MASK) + 1 : 0);
-                        }
-                        q = fzb0 + head + (long long)(qrun + incl - ql);
-                    } else if (f4 < 2 * TILE) q = fzb1;
-                    else q = fz_qbase[min((int64_t)t + (f4 >> TILE_SHIFT), (int64_t)L.ntiles - 1)];
+                        const int e0 = (int)i0 - pre;            // physical entry of the tile's first record start
+                        if (kfirst > 0 && e0 >= 1)
+                            head = (int32_t)(s_ent[e0 + pre] & OFF_MASK) - (int32_t)(s_ent[e0 - 1 + pre] & OFF_MASK) - 1;
+                        q += head + (long long)(qrun + incl - ql);
+                    }
                     fz_qoff[kfirst + r] = q;
                 }
                 qrun += (uint32_t)__shfl((int)incl, 63);

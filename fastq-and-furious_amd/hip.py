@@ -36,6 +36,7 @@ F_FORCE_SERIAL = 2
 F_FORCE_RANKED = 4
 F_POLL_RESULT = 8
 F_SINGLE_PASS = 16
+SEG_STRIDE = 8704            # FFQ_F_SINGLE_PASS: bytes of the quality buffer every 16 KiB tile of the input owns (include/ffq.h)
 F_NO_TIMING = 32
 
 # every symbol include/ffq.h declares (tests check the library exports them all)
@@ -338,7 +339,10 @@ class Context:
         cap = int(table_cap) if table_cap is not None else max(a.size // 64 + 16, 16)
         while True:
             table = np.empty((cap, 6), dtype=np.int64)
-            qual = np.empty(a.size if decode else 0, dtype=np.int8)
+            nq = a.size if decode else 0
+            if decode and (flags & F_SINGLE_PASS):
+                nq = max(nq, ((a.size + 16383) >> 14) * SEG_STRIDE)        # the segmented layout: room for every tile's segment
+            qual = np.empty(nq, dtype=np.int8)
             qoff = np.empty(cap + 1 if decode else 0, dtype=np.int64)
             res = ScanResult()
             rc = lib().ffq_scan_host(self.handle, a.ctypes.data if a.size else None, a.size,

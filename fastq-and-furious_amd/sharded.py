@@ -660,13 +660,19 @@ class SyntheticShard:
 
     def verify_decode(self, table, out, qual, qoff):
         """The decode's output at full size, with torch ops only: the CSR offsets must be the
-        running sum of pos5 - pos4 over ALL rows of the scan, and the decoded bytes of a spread of
-        records must be the buffer's bytes [pos4, pos5) minus 33 (int8 arithmetic)."""
+        running sum of pos5 - pos4 over ALL rows of the scan (segmented output, res.path 6: every
+        record's bytes behind the previous record's, the last offset where the last record ends), and
+        the decoded bytes of a spread of records must be the buffer's bytes [pos4, pos5) minus 33
+        (int8 arithmetic)."""
         import torch
         n = int(out.n_rows)
         lens = table[:n, 5] - table[:n, 4]
-        assert int(qoff[0].item()) == 0, "quality offsets do not start at 0"
-        assert bool((qoff[1:n + 1] - qoff[:n] == lens).all()), "quality offsets are not the running sum of pos5 - pos4"
+        if out.res.path == 6:
+            assert bool((qoff[1:n] >= qoff[:n - 1] + lens[:n - 1]).all()), "records' decoded bytes overlap or are out of order"
+            assert n == 0 or int(qoff[n].item()) == int((qoff[n - 1] + lens[n - 1]).item())
+        else:
+            assert int(qoff[0].item()) == 0, "quality offsets do not start at 0"
+            assert bool((qoff[1:n + 1] - qoff[:n] == lens).all()), "quality offsets are not the running sum of pos5 - pos4"
         assert int(qoff[n].item()) == int(out.res.n_qual_bytes), "closing quality offset differs from the reported total"
         if n == 0:
             return

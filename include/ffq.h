@@ -72,14 +72,18 @@ extern "C" {
                                       marker less per scan (~3 us of idle GPU); ms_chain / ms_total are
                                       not measured then.  Ignored with FFQ_F_DECODE_QUAL.              */
 
-#define FFQ_F_SINGLE_PASS  16u     /* with FFQ_F_DECODE_QUAL on plain four-line input: the line-index pass itself writes the
-                                      decoded stream (csrc/ffq_fused.h; res.path 6), so that the input is read ONCE -- HBM
-                                      traffic 1.0 x the algorithmic bytes instead of 1.5 x.  Opt-in: on MI355X it is SLOWER
-                                      than the two passes (the index pass is already at 70 % of its VALU issue rate; with the
-                                      compaction of the quality bytes on top it becomes instruction-bound: 7.6 ms against 5.1
-                                      per 10 GiB).  Same result bit for bit; input it cannot vouch for
-                                      (lines longer than a tile, a quality line longer than its read) goes to the two passes. */
-
+#define FFQ_F_SINGLE_PASS  16u     /* with FFQ_F_DECODE_QUAL: the caller accepts the decoded qualities SEGMENTED instead of packed --
+                                      the bytes of record i are d_qual[d_qoff[i] : d_qoff[i] + (pos5 - pos4)], contiguous and in
+                                      file order, but there may be gaps between records (d_qoff[i + 1] - d_qoff[i] is NOT a
+                                      length; n_qual_bytes = where the last record's bytes end).  On plain four-line input the
+                                      line-index pass itself then writes them (csrc/ffq_fused.h; res.path 6): every 16 KiB of
+                                      input owns FFQ_SEG_STRIDE bytes of d_qual, the input is read ONCE -- HBM traffic 1.0 x the
+                                      algorithmic bytes instead of 1.5 x.  qual_cap must be at least FFQ_SEG_STRIDE per 16 KiB
+                                      tile of the buffer (rounded up), else -- or when the input is not what the single pass can
+                                      vouch for: wrapped records, lines longer than 512 bytes behind a tile's end, a quality line
+                                      longer than its read -- the two passes run and the output is packed (a special case of
+                                      the same contract).                                                                      */
+#define FFQ_SEG_STRIDE     8704
 #define FFQ_F_NO_TIMING    32u     /* with FFQ_F_POLL_RESULT: no timing marks around the line-index kernel either (ms_index is
                                       0 for this scan).  The front then holds no stream marker at all, and its index kernel is
                                       dispatched without a barrier: queued behind another context's scan on the same stream it

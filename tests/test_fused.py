@@ -1,10 +1,12 @@
 """The single-pass index + decode (csrc/ffq_fused.h) against the oracle, and its refusals.
 
-On plain four-line input with FFQ_F_DECODE_QUAL | FFQ_F_SINGLE_PASS the index kernel itself writes the
-decoded stream (res.path == 6; opt-in: on MI355X it saves a third of the HBM traffic and costs time).  That is speculation -- every fourth line is a record's quality, whole -- verified by
-the row kernel; whatever it cannot vouch for must come out of the two-pass kernels instead
-(path 3 / 0), with the same table, offsets and bytes as the oracle's restatement of
-array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, -33)  (/root/reference/doc/user-guide.rst:126-141).
+With FFQ_F_DECODE_QUAL | FFQ_F_SINGLE_PASS the caller accepts the decoded qualities SEGMENTED (record i =
+qual[qoff[i] : qoff[i] + pos5 - pos4], gaps between records allowed); on plain four-line input the index
+kernel itself then writes them (res.path == 6).  That is speculation -- every fourth line is a record's
+quality, whole -- verified by the row kernel; whatever it cannot vouch for must come out of the two-pass
+kernels instead (path 3 / 0, packed), with the same table and the same bytes per record as the oracle's
+restatement of array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, -33)
+(/root/reference/doc/user-guide.rst:126-141).
 """
 import numpy as np
 import pytest
@@ -15,7 +17,22 @@ pytestmark = pytest.mark.gpu
 
 
 def decode_same(ctx, hipmod, oracle, data, flags=0, **kw):
-    return _decode_same(ctx, hipmod, oracle, data, flags=flags | hipmod.F_SINGLE_PASS, **kw)
+    """Table, offsets of every record's bytes and the bytes themselves against the oracle; the stream may have gaps."""
+    want, *_ = oracle.scan(data, **kw)
+    wq, wqoff = oracle.decode_quals(data, want)
+    table, res, qual, qoff = ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS | flags, **kw)
+    assert table.shape == want.shape and (table == want).all()
+    n = len(want)
+    lens = want[:, 5] - want[:, 4] if n else np.zeros(0, np.int64)
+    assert qoff.shape[0] == n + 1
+    if n:
+        assert (qoff[1:n] >= qoff[:n - 1] + lens[:n - 1]).all(), "records overlap or are out of order"
+        assert int(qoff[n]) == int(qoff[n - 1] + lens[n - 1]) == int(res.n_qual_bytes)
+        idx = np.repeat(qoff[:n] - wqoff[:n], lens) + np.arange(wq.size)
+        assert (qual[idx] == wq).all(), "decoded bytes differ"
+    if res.path != 6:                                 # the two passes: packed
+        assert (qoff == wqoff).all()
+    return res
 
 
 @pytest.fixture
@@ -36,6 +53,7 @@ def test_fused_synth_single(gpu_ctx, hipmod, oracle, nrec, first):
         assert res.path == 6
     else:
         assert res.path in (3, 6)
+    assert hipmod.SEG_STRIDE == 8704
     gpu_ctx.forget()
     assert _decode_same(gpu_ctx, hipmod, oracle, data).path == 3          # without the flag: the two passes
 
@@ -111,10 +129,9 @@ def test_fused_remembers_and_recovers(gpu_ctx, hipmod, oracle):
     assert paths[0] == 3 and paths[-1] == 6
 
 
-def test_fused_steps_aside_for_other_work_on_the_device(gpu_ctx, hipmod, oracle):
-    """Its workgroups wait for one another and must all be resident; kernels of another stream that hold
-    compute units when it starts can keep some out.  It must notice (50 ms), step aside, and the two
-    passes must deliver the same result -- never hang, never a wrong byte."""
+def test_fused_beside_other_work_on_the_device(gpu_ctx, hipmod, oracle):
+    """Kernels of another stream running beside it (the persistent-grid version of round 3 deadlocked there
+    until its timeout): one workgroup per tile waits for nobody."""
     import time
     import torch
     from fastqandfurious_amd import synth
@@ -124,7 +141,7 @@ def test_fused_steps_aside_for_other_work_on_the_device(gpu_ctx, hipmod, oracle)
     dbuf = torch.from_numpy(data.copy()).cuda()
     n = len(want)
     table = torch.empty((n + 8, 6), dtype=torch.int64, device="cuda")
-    qual = torch.empty(wq.size + 64, dtype=torch.int8, device="cuda")
+    qual = torch.empty(((data.size + 16383) >> 14) * hipmod.SEG_STRIDE, dtype=torch.int8, device="cuda")
     qoff = torch.empty(n + 9, dtype=torch.int64, device="cuda")
     big = torch.empty(4 << 30, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
@@ -137,6 +154,8 @@ def test_fused_steps_aside_for_other_work_on_the_device(gpu_ctx, hipmod, oracle)
                                       d_qual=qual.data_ptr(), qual_cap=qual.numel(), d_qoff=qoff.data_ptr())
         assert time.time() - t0 < 5.0
         torch.cuda.synchronize()
-        assert rc == 0 and res.path in (3, 6) and int(res.n_records) == n
-        assert (table[:n].cpu().numpy() == want).all() and (qoff[:n + 1].cpu().numpy() == wqoff).all()
-        assert (qual[:wq.size].cpu().numpy() == wq).all()
+        assert rc == 0 and res.path == 6 and int(res.n_records) == n
+        assert (table[:n].cpu().numpy() == want).all()
+        qo = qoff[:n].cpu().numpy()
+        idx = np.repeat(qo - wqoff[:n], want[:, 5] - want[:, 4]) + np.arange(wq.size)
+        assert (qual.cpu().numpy()[idx] == wq).all()

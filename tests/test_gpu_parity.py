@@ -869,15 +869,21 @@ def test_decode_at_config_size_past_4g_of_qualities(gpu_ctx, hipmod, pkg):
     assert bool((t2[:n] == table[:n]).all()) and bool((o2[:n + 1] == qoff[:n + 1]).all())
     nq = int(out.res.n_qual_bytes)
     assert bool((q2[:nq] == qual[:nq]).all())
-    # ... and the single pass (FFQ_F_SINGLE_PASS, csrc/ffq_fused.h: the index kernel writes the decoded
-    # stream itself; the input is read once): same table, same offsets, same 5 GB of decoded bytes
+    # ... and the single pass (FFQ_F_SINGLE_PASS, csrc/ffq_fused.h: the index kernel writes the decoded bytes
+    # itself, segmented; the input is read once): same table, and for EVERY record the same 150 bytes
     gpu_ctx.forget()
-    t2.zero_(); q2.zero_(); o2.zero_()
-    torch.cuda.synchronize()      # (its persistent workgroups must all be resident: nothing else may hold compute units)
-    out3 = sh.scan(t2, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS, qual=q2, qoff=o2)
-    assert out3.res.path == 6 and int(out3.n_rows) == n and int(out3.res.n_qual_bytes) == nq
-    assert bool((t2[:n] == table[:n]).all()) and bool((o2[:n + 1] == qoff[:n + 1]).all())
-    assert bool((q2[:nq] == qual[:nq]).all())
+    q3 = torch.zeros(((sh.ext.numel() + 16383) >> 14) * hipmod.SEG_STRIDE, dtype=torch.int8, device=dev)
+    t2.zero_(); o2.zero_()
+    out3 = sh.scan(t2, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS, qual=q3, qoff=o2)
+    assert out3.res.path == 6 and int(out3.n_rows) == n
+    assert bool((t2[:n] == table[:n]).all())
+    sh.verify_decode(t2, out3, q3, o2)
+    ar = torch.arange(150, device=dev)
+    for c0 in range(0, n, 1 << 20):
+        c1 = min(n, c0 + (1 << 20))
+        got = q3[(o2[c0:c1, None] + ar[None, :]).reshape(-1)]
+        assert bool((got == qual[150 * c0:150 * c1]).all()), "segmented decode differs from the packed stream"
+    del q3
     del sh, table, qual, qoff, t2, q2, o2
     torch.cuda.empty_cache()
 
