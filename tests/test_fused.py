@@ -159,3 +159,34 @@ def test_fused_beside_other_work_on_the_device(gpu_ctx, hipmod, oracle):
         qo = qoff[:n].cpu().numpy()
         idx = np.repeat(qo - wqoff[:n], want[:, 5] - want[:, 4]) + np.arange(wq.size)
         assert (qual.cpu().numpy()[idx] == wq).all()
+
+
+@pytest.mark.parametrize("world", (2, 8))
+def test_fused_in_byte_range_shards(gpu_ctx, hipmod, oracle, world):
+    """The single pass inside the sharded scan: every logical rank scans its [tail | own | head] view with
+    FFQ_F_SINGLE_PASS; the rows it owns carry exact starts into ITS OWN segmented quality buffer."""
+    import torch
+    from test_sharded import make_stream, expected, run_local, check_rows, bounds_for, _hip_backends
+    stream = make_stream("single")
+    want, err = expected(oracle, stream)
+    assert err is None
+    wq, wqoff = oracle.decode_quals(stream, want)
+    t = torch.from_numpy(stream.copy()).cuda()
+    bounds = bounds_for(stream.size, world, 0, 48)
+    make, made = _hip_backends(gpu_ctx)
+    res = run_local(t, bounds, make, decode=True, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS)
+    check_rows(res, bounds, want)
+    base = 0
+    for r in range(world):
+        out, table, qual, qoff = res[r]
+        assert out.res.path == 6
+        n_own = out.row_hi - out.row_lo
+        rows = table[out.row_lo:out.row_hi].cpu().numpy()
+        lens = rows[:, 5] - rows[:, 4]
+        qo = qoff[out.row_lo:out.row_hi].cpu().numpy()
+        q = qual.cpu().numpy()
+        idx = np.repeat(qo - (wqoff[base:base + n_own] - wqoff[base]), lens) + np.arange(int(lens.sum()))
+        assert (q[idx] == wq[int(wqoff[base]):int(wqoff[base + n_own])]).all(), "rank %d: decoded qualities differ" % r
+        base += n_own
+    for c in made.values():
+        c.close()
