@@ -239,7 +239,7 @@ def stream_inclusive(ctx, sample_u8, fbufsize=1 << 24):
                                "scanner) over the same file, %.1f s" % (n_it, el_it)}
 
 
-def iterator_rates(sample_u8, budget_s=3.0):
+def iterator_rates(sample_u8, n_gz, budget_s=3.0):
     """The drop-in iterator as a user of the reference calls it -- readfastq_iter(fh, fbufsize, entryfunc,
     entrypos) with this package's GPU scanner -- at the reference's own buffer size (50 000 bytes:
     /root/reference/src/demo/benchmark.py:415; reads are coalesced into k * fbufsize per device call)
@@ -247,14 +247,13 @@ def iterator_rates(sample_u8, budget_s=3.0):
     with the default entryfunc and with entryfunc_phred (the user guide's decode, from the device's
     bulk decode).  M reads/s of Python tuples on one host core; beside each gzip figure the
     reference's own C scanner through the per-record loop over the same gzip file (oracle/_ref),
-    when that binary is there."""
+    when that binary is there.  n_gz: how many bytes of the sample go into the gzip file (whole records)"""
     import gzip
     import tempfile
     from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C
     d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     plain = os.path.join(d, "ffq_iter_%d.fq" % os.getpid())
     gz = plain + ".gz"
-    n_gz = min(sample_u8.size, 96 << 20) // 322 * 322
     with open(plain, "wb") as fh:
         fh.write(sample_u8.tobytes())
     with gzip.open(gz, "wb", compresslevel=1) as fh:
@@ -706,7 +705,7 @@ def main():
             line["cpu_baseline"]["reference_c_iterator"] = cpu_reference_iter(sample.tobytes(), 3.0)
             line["host_inclusive"] = host_inclusive(ctx, sample, flags)
             line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, shard.host_sample(1 << 30))
-            line["host_inclusive"]["iterator"] = iterator_rates(sample)
+            line["host_inclusive"]["iterator"] = iterator_rates(sample, int(shard.host_sample(96 << 20).size))
             del sample
         else:
             line["cpu_baseline"] = None
