@@ -239,7 +239,7 @@ def stream_inclusive(ctx, sample_u8, fbufsize=1 << 24):
                                "scanner) over the same file, %.1f s" % (n_it, el_it)}
 
 
-def iterator_rates(sample_u8, n_gz, budget_s=3.0):
+def iterator_rates(ctx, sample_u8, n_gz, budget_s=3.0):
     """The drop-in iterator as a user of the reference calls it -- readfastq_iter(fh, fbufsize, entryfunc,
     entrypos) with this package's GPU scanner -- at the reference's own buffer size (50 000 bytes:
     /root/reference/src/demo/benchmark.py:415; reads are coalesced into k * fbufsize per device call)
@@ -258,6 +258,12 @@ def iterator_rates(sample_u8, n_gz, budget_s=3.0):
         fh.write(sample_u8.tobytes())
     with gzip.open(gz, "wb", compresslevel=1) as fh:
         fh.write(sample_u8[:n_gz].tobytes())
+    # the same bytes as bgzip writes them (BGZF: members that carry their length; the library's reader
+    # inflates them side by side, FFQ_GZ_THREADS)
+    from fastqandfurious_amd import bgzf, hip
+    bg = plain + ".bgz"
+    with open(bg, "wb") as fh:
+        fh.write(bgzf.compress(sample_u8[:n_gz].tobytes(), level=1))
 
     def rate(opener, fbufsize, entryfunc, scanner):
         n, t0 = 0, time.perf_counter()
@@ -270,9 +276,30 @@ def iterator_rates(sample_u8, n_gz, budget_s=3.0):
 
     out = {"unit": "M reads/s", "cores": 1,
            "what": "readfastq_iter(fh, fbufsize, entryfunc, GPU scanner): Python tuples per second, one host core; "
-                   "plain = %d-byte file in %s, gzip = its first %d bytes at level 1" % (sample_u8.size, d, n_gz)}
+                   "plain = %d-byte file in %s, gzip = its first %d bytes at level 1, bgzf = the same bytes in BGZF members "
+                   "(inflated side by side); *_stream_gb_s = decompressed GB/s of the stream front end alone (tables, no "
+                   "tuples)" % (sample_u8.size, d, n_gz)}
+    def table_rate(path):
+        # decompressed GB/s through the stream front end alone: offset tables out, no Python object per record
+        best = None
+        for _ in range(2):
+            fd = os.open(path, os.O_RDONLY)
+            t0 = time.perf_counter()
+            st = hip.FileStream(ctx, fd, 1 << 24, gzip=True)
+            n = sum(rows.shape[0] for rows, _f, _o, _e, _x in st)
+            st.close()
+            os.close(fd)
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        assert n > 0
+        return round(n_gz / best / 1e9, 3)
+
     try:
-        for tag, opener in (("plain", lambda: open(plain, "rb")), ("gzip", lambda: gzip.open(gz, "rb"))):
+        out["gzip_stream_gb_s"] = table_rate(gz)
+        out["bgzf_stream_gb_s"] = table_rate(bg)
+        out["bgzf_threads"] = int(os.environ.get("FFQ_GZ_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+        for tag, opener in (("plain", lambda: open(plain, "rb")), ("gzip", lambda: gzip.open(gz, "rb")),
+                            ("bgzf", lambda: gzip.open(bg, "rb"))):
             for fb in (50000, 1 << 24):
                 out["%s_fbufsize_%d" % (tag, fb)] = rate(opener, fb, F.entryfunc, C.entrypos)
             out["%s_phred_fbufsize_50000" % tag] = rate(opener, 50000, F.entryfunc_phred, C.entrypos)
@@ -285,7 +312,7 @@ def iterator_rates(sample_u8, n_gz, budget_s=3.0):
         except Exception as e:      # noqa: BLE001
             out["reference_c_error"] = repr(e)
     finally:
-        for f in (plain, gz):
+        for f in (plain, gz, bg):
             try:
                 os.unlink(f)
             except OSError:
@@ -705,7 +732,7 @@ def main():
             line["cpu_baseline"]["reference_c_iterator"] = cpu_reference_iter(sample.tobytes(), 3.0)
             line["host_inclusive"] = host_inclusive(ctx, sample, flags)
             line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, shard.host_sample(1 << 30))
-            line["host_inclusive"]["iterator"] = iterator_rates(sample, int(shard.host_sample(96 << 20).size))
+            line["host_inclusive"]["iterator"] = iterator_rates(ctx, sample, int(shard.host_sample(96 << 20).size))
             del sample
         else:
             line["cpu_baseline"] = None

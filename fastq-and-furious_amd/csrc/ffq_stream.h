@@ -36,11 +36,13 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 constexpr int STREAM_SLOTS = 3;
 
@@ -125,7 +127,110 @@ static hipError_t stream_copy_chunk(StreamBufs *b, StreamSlot &sl, int64_t got)
 }
 
 constexpr int SRC_FD = 0, SRC_GZIP = 1, SRC_PUSH = 2;
-constexpr int64_t GZ_IN = 1 << 20;      // compressed bytes read per refill
+constexpr int64_t GZ_IN = 4 << 20;      // compressed bytes held at a time
+
+// ---- BGZF members inflated side by side ------------------------------------------------------------
+// A gzip member says how long it is only if its writer put that into the header: bgzip does (the "BC"
+// extra field of the BGZF format, SAM specification section 4.1: BSIZE = length of the member - 1, at
+// most 64 KiB of data per member, the uncompressed length in the member's last four bytes).  Members of
+// such a file are found without inflating anything and inflated independently, each straight into its
+// place in the pinned chunk.  Anything else -- and any member that does not hold what its header and
+// trailer promise -- goes through the one-member-at-a-time inflate below, which has the last word.
+struct GzJob {
+    const uint8_t *src;     // raw deflate data of the member
+    uint32_t clen;
+    uint8_t *dst;
+    uint32_t isize, crc;    // from the member's trailer
+};
+
+struct GzPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    const GzJob *jobs = nullptr;
+    int njobs = 0, active = 0;
+    std::atomic<int> next{0}, failed{0};
+    uint64_t gen = 0;
+    bool quit = false;
+
+    static bool inflate_one(z_stream *z, const GzJob &j)
+    {
+        uint8_t none[8];
+        if (inflateReset(z) != Z_OK) return false;
+        z->next_in = const_cast<Bytef *>(j.src);
+        z->avail_in = j.clen;
+        z->next_out = j.isize ? j.dst : none;
+        z->avail_out = j.isize ? j.isize : (uInt)sizeof none;
+        const int r = inflate(z, Z_FINISH);
+        if (r != Z_STREAM_END || z->avail_in != 0 || z->total_out != j.isize) return false;
+        return (uint32_t)crc32(crc32(0L, Z_NULL, 0), j.dst, j.isize) == j.crc;
+    }
+    void work(z_stream *z)
+    {
+        for (;;) {
+            const int j = next.fetch_add(1);
+            if (j >= njobs) break;
+            if (!inflate_one(z, jobs[j])) failed.store(1);
+        }
+    }
+    void worker()
+    {
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        const bool ok = inflateInit2(&z, -15) == Z_OK;      // raw deflate: header and trailer are read by the parser
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_go.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) break;
+                seen = gen;
+            }
+            if (ok) work(&z);
+            std::lock_guard<std::mutex> lk(m);
+            if (--active == 0) cv_done.notify_one();
+        }
+        if (ok) (void)inflateEnd(&z);
+    }
+    bool start(int nthreads)
+    {
+        try {
+            for (int i = 0; i < nthreads; i++) th.emplace_back(&GzPool::worker, this);
+        } catch (...) {}
+        return !th.empty();
+    }
+    // all jobs, by the pool's threads and the caller's (own: the caller's raw-deflate state); false: a member
+    // did not inflate to what its trailer says
+    bool run(const GzJob *js, int n, z_stream *own)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            jobs = js; njobs = n; next.store(0); failed.store(0);
+            active = (int)th.size();
+            gen++;
+        }
+        cv_go.notify_all();
+        work(own);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return active == 0; });
+        return failed.load() == 0;
+    }
+    ~GzPool()
+    {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+
+// threads that inflate (FFQ_GZ_THREADS; default: the host's cores, at most 16): 1 = no pool
+static int gz_threads_default()
+{
+    const char *e = getenv("FFQ_GZ_THREADS");
+    if (e && atoi(e) > 0) return std::min(atoi(e), 256);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(std::max<unsigned>(hw, 1u), 16u);
+}
 
 struct ffq_stream {
     ffq_ctx *c = nullptr;
@@ -139,6 +244,13 @@ struct ffq_stream {
     uint8_t *zin = nullptr;
     int64_t zin_len = 0, zin_pos = 0, z_filepos = 0;
     std::string z_msg;
+    int gz_threads = 1;                 // > 1: BGZF members are inflated side by side
+    bool bgzf_ok = true;                // cleared when a member did not hold what it promised: one at a time from there
+    GzPool *gz_pool = nullptr;
+    z_stream zraw;                      // the reader thread's own raw-deflate state (it takes jobs too)
+    bool zraw_init = false;
+    std::vector<GzJob> gz_jobs;
+    int64_t bgzf_members = 0;           // members inflated by the pool (statistics)
     int64_t handed_pos = 0;             // position of the source behind the last chunk handed out
     uint32_t flags = 0;                 // FFQ_F_DECODE_QUAL: qualities decoded per fill
     int qual_add = -33;
@@ -198,6 +310,95 @@ static int64_t stream_fd_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
 // One chunk of the DECOMPRESSED stream of a gzip file (RFC 1952; members may be concatenated, as
 // bgzip and `cat a.gz b.gz` produce them; zero padding behind the last member is ignored).  Fills
 // dst completely unless the stream ends (*eof).  -1: error, s->z_msg says what.
+// More compressed bytes behind what is left in zin (moved to the front).  1: something was added, 0: nothing
+// (end of the file, or zin is full), -1: error (z_msg), -2: asked to stop / park with nothing read.
+static int gz_more_input(ffq_stream *s)
+{
+    const int64_t rem = s->zin_len - s->zin_pos;
+    if (s->z_in_eof || rem >= GZ_IN) return 0;
+    if (rem > 0 && s->zin_pos > 0) memmove(s->zin, s->zin + s->zin_pos, (size_t)rem);
+    s->zin_pos = 0; s->zin_len = rem;
+    int64_t r;
+    bool in_eof = false;
+    if (s->seekable) { r = ReadPool::read_full(s->fd, s->zin + rem, GZ_IN - rem, s->z_filepos, true); in_eof = r >= 0 && r < GZ_IN - rem; }
+    else {
+        // a pipe: behind poll(), like the uncompressed case (a stop request is seen within 50 ms)
+        r = stream_fd_read(s, s->zin + rem, GZ_IN - rem, &in_eof);
+        if (r == -2) return -2;
+    }
+    if (r < 0) { s->z_msg = std::string("read failed: ") + strerror(errno); return -1; }
+    s->z_filepos += r;
+    s->zin_len += r;
+    if (in_eof) s->z_in_eof = true;
+    return r > 0 ? 1 : 0;
+}
+
+// Length of the BGZF member at p; 0: not one; -1: its header is not all there yet.  A BGZF member: gzip magic,
+// deflate, FLG = FEXTRA alone, a "BC" subfield of two bytes.  *xlen: length of the extra field.
+static int64_t bgzf_member_len(const uint8_t *p, int64_t avail, int *xlen)
+{
+    if (avail >= 4 && !(p[0] == 0x1f && p[1] == 0x8b && p[2] == 8 && p[3] == 4)) return 0;
+    if (avail < 12) return -1;
+    const int xl = p[10] | (p[11] << 8);
+    if (avail < 12 + xl) return -1;
+    for (int q = 0; q + 4 <= xl;) {
+        const uint8_t *f = p + 12 + q;
+        const int sl = f[2] | (f[3] << 8);
+        if (f[0] == 'B' && f[1] == 'C' && sl == 2 && q + 6 <= xl) {
+            const int64_t total = (int64_t)(f[4] | (f[5] << 8)) + 1;
+            *xlen = xl;
+            return total >= xl + 20 ? total : 0;
+        }
+        q += 4 + sl;
+    }
+    return 0;
+}
+
+// At a member boundary: as many whole BGZF members as zin holds and dst has room for, inflated side by side.
+// Returns the bytes written (zin_pos is behind those members then), 0 if there is nothing to do here (not
+// BGZF, a member that is not all there at the end of the file, no room for even one: the serial inflate
+// takes it from the same place), -1 / -2 as gz_more_input.
+static int64_t gz_bgzf_batch(ffq_stream *s, uint8_t *dst, int64_t room)
+{
+    int xl = 0;
+    for (;;) {        // the first member whole in zin
+        const int64_t avail = s->zin_len - s->zin_pos;
+        const int64_t total = bgzf_member_len(s->zin + s->zin_pos, avail, &xl);
+        if (total == 0) return 0;
+        if (total > 0 && total <= avail) break;
+        const int r = gz_more_input(s);
+        if (r <= 0) return r;
+    }
+    std::vector<GzJob> &jobs = s->gz_jobs;
+    jobs.clear();
+    int64_t p = s->zin_pos, out = 0;
+    while (p < s->zin_len) {
+        const int64_t total = bgzf_member_len(s->zin + p, s->zin_len - p, &xl);
+        if (total <= 0 || total > s->zin_len - p) break;
+        const uint8_t *e = s->zin + p + total;
+        const uint32_t crc = (uint32_t)e[-8] | ((uint32_t)e[-7] << 8) | ((uint32_t)e[-6] << 16) | ((uint32_t)e[-5] << 24);
+        const uint32_t isz = (uint32_t)e[-4] | ((uint32_t)e[-3] << 8) | ((uint32_t)e[-2] << 16) | ((uint32_t)e[-1] << 24);
+        if ((int64_t)isz > room - out) break;
+        jobs.push_back(GzJob{s->zin + p + 12 + xl, (uint32_t)(total - xl - 20), dst + out, isz, crc});
+        out += isz;
+        p += total;
+    }
+    if (jobs.size() < 2) return 0;            // (one member: the serial inflate is as good)
+    if (!s->gz_pool) {
+        s->gz_pool = new (std::nothrow) GzPool();
+        if (!s->gz_pool || !s->gz_pool->start(s->gz_threads - 1)) { delete s->gz_pool; s->gz_pool = nullptr; s->bgzf_ok = false; return 0; }
+    }
+    if (!s->zraw_init) {
+        memset(&s->zraw, 0, sizeof s->zraw);
+        if (inflateInit2(&s->zraw, -15) != Z_OK) { s->bgzf_ok = false; return 0; }
+        s->zraw_init = true;
+    }
+    if (!s->gz_pool->run(jobs.data(), (int)jobs.size(), &s->zraw)) { s->bgzf_ok = false; return 0; }
+    s->bgzf_members += (int64_t)jobs.size();
+    s->zin_pos = p;
+    return out;
+}
+
 static int64_t stream_gz_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
 {
     int64_t got = 0;
@@ -205,18 +406,9 @@ static int64_t stream_gz_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
     while (got < n) {
         { std::lock_guard<std::mutex> lk(s->m); if (s->stop) break; }
         if (s->zin_pos == s->zin_len && !s->z_in_eof) {
-            int64_t r;
-            bool in_eof = false;
-            if (s->seekable) { r = ReadPool::read_full(s->fd, s->zin, GZ_IN, s->z_filepos, true); in_eof = r >= 0 && r < GZ_IN; }
-            else {
-                // a pipe: behind poll(), like the uncompressed case (a stop request is seen within 50 ms)
-                r = stream_fd_read(s, s->zin, GZ_IN, &in_eof);
-                if (r == -2) break;                                  // asked to stop / park with nothing read
-            }
-            if (r < 0) { s->z_msg = std::string("read failed: ") + strerror(errno); return -1; }
-            s->z_filepos += r;
-            s->zin_len = r; s->zin_pos = 0;
-            if (in_eof) s->z_in_eof = true;
+            const int r = gz_more_input(s);
+            if (r == -2) break;                                  // asked to stop / park with nothing read
+            if (r < 0) return -1;
         }
         if (!s->z_member) {
             // between members: zero padding, then the next member or the end of the file
@@ -224,6 +416,12 @@ static int64_t stream_gz_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
             if (s->zin_pos == s->zin_len) {
                 if (s->z_in_eof) { *eof = true; break; }
                 continue;
+            }
+            if (s->gz_threads > 1 && s->bgzf_ok) {
+                const int64_t r = gz_bgzf_batch(s, dst + got, n - got);
+                if (r == -2) break;
+                if (r < 0) return -1;
+                if (r > 0) { got += r; continue; }
             }
             if (inflateReset(&s->zs) != Z_OK) { s->z_msg = "inflateReset failed"; return -1; }
             s->z_member = true;
@@ -351,6 +549,8 @@ static void stream_free(ffq_stream *s)
                 (long long)(s->cur + 1), s->t_read * 1e3, s->t_slot * 1e3, s->t_feed * 1e3, s->t_scan * 1e3, s->t_copy * 1e3,
                 s->t_rows * 1e3);
     if (s->z_init) (void)inflateEnd(&s->zs);
+    delete s->gz_pool;
+    if (s->zraw_init) (void)inflateEnd(&s->zraw);
     free(s->zin);
     if (s->b) {
         for (auto &st : s->b->cs) if (st) (void)hipStreamSynchronize(st);
@@ -476,6 +676,7 @@ static int stream_open_impl(ffq_ctx *c, int src, int fd, int64_t fbufsize, uint3
         }
         s->z_init = true;
         s->z_filepos = s->file_pos;
+        s->gz_threads = gz_threads_default();
     }
     StreamBufs *b = static_cast<StreamBufs *>(c->stream_cache);
     c->stream_cache = nullptr;
@@ -518,6 +719,43 @@ extern "C" int ffq_stream_open_gzip(ffq_ctx *c, int fd, int64_t fbufsize, uint32
                                     ffq_stream **out)
 {
     return stream_open_impl(c, SRC_GZIP, fd, fbufsize, flags, qual_add, start, out);
+}
+
+// The gzip reader on its own: the file behind fd (from its current position; a pipe works), inflated into
+// host memory chunk by chunk as the stream's reader thread does it.  Returns the bytes written, or FFQ_E_*.
+extern "C" int64_t ffq_gunzip_fd(int fd, uint8_t *h_dst, int64_t cap, int64_t chunk, int threads, int64_t *n_parallel_members)
+{
+    if (fd < 0 || (!h_dst && cap > 0) || cap < 0 || chunk <= 0) return fail(FFQ_E_ARG, "ffq_gunzip_fd: bad argument");
+    ffq_stream *s = new (std::nothrow) ffq_stream();
+    if (!s) return fail(FFQ_E_NOMEM, "out of host memory");
+    s->fd = fd; s->src = SRC_GZIP;
+    const off_t at = lseek(fd, 0, SEEK_CUR);
+    s->seekable = at != (off_t)-1;
+    s->z_filepos = s->seekable ? (int64_t)at : 0;
+    memset(&s->zs, 0, sizeof s->zs);
+    s->zin = static_cast<uint8_t *>(malloc((size_t)GZ_IN));
+    int64_t rc = FFQ_OK, got = 0;
+    if (!s->zin || inflateInit2(&s->zs, 15 + 16) != Z_OK) rc = fail(FFQ_E_NOMEM, "ffq_gunzip_fd: zlib could not be initialised");
+    else {
+        s->z_init = true;
+        s->gz_threads = threads > 0 ? std::min(threads, 256) : gz_threads_default();
+        bool eof = false;
+        uint8_t one[1];
+        while (!eof) {
+            const bool full = got == cap;
+            const int64_t r = stream_gz_read(s, full ? one : h_dst + got, full ? 1 : std::min(chunk, cap - got), &eof);
+            if (r < 0) { rc = fail(FFQ_E_ARG, "ffq_gunzip_fd: gzip: %s", s->z_msg.c_str()); break; }
+            if (full && r > 0) { rc = fail(FFQ_E_TABLE_FULL, "ffq_gunzip_fd: the file inflates to more than %lld bytes", (long long)cap); break; }
+            got += full ? 0 : r;
+        }
+    }
+    if (n_parallel_members) *n_parallel_members = s->bgzf_members;
+    if (s->z_init) (void)inflateEnd(&s->zs);
+    delete s->gz_pool;
+    if (s->zraw_init) (void)inflateEnd(&s->zraw);
+    free(s->zin);
+    delete s;
+    return rc ? rc : got;
 }
 
 extern "C" int ffq_stream_open_push(ffq_ctx *c, int64_t fbufsize, uint32_t flags, int qual_add, ffq_stream **out)

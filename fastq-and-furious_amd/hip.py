@@ -47,7 +47,7 @@ SYMBOLS = (
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
     "ffq_table_select_seqlen", "ffq_table_cut", "ffq_table_gather_column", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
-    "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_stream_open_gzip", "ffq_stream_open_push",
+    "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_stream_open_push",
     "ffq_stream_push_buffer", "ffq_stream_push", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
@@ -195,6 +195,8 @@ def lib():
         L.ffq_scan_fasta_host.argtypes = [vp, vp, i64, i32, i64, i64, vp, i64, P(ScanResult)]
         L.ffq_stream_open2.argtypes = [vp, i32, i64, u32, i32, i64, P(vp)]
         L.ffq_stream_open_gzip.argtypes = [vp, i32, i64, u32, i32, i64, P(vp)]
+        L.ffq_gunzip_fd.argtypes = [i32, vp, i64, i64, i32, P(i64)]
+        L.ffq_gunzip_fd.restype = i64
         L.ffq_stream_open_push.argtypes = [vp, i64, u32, i32, P(vp)]
         L.ffq_stream_push_buffer.argtypes = [vp, P(vp), P(i64)]
         L.ffq_stream_push.argtypes = [vp, i64, i32]
@@ -593,6 +595,19 @@ class PushStream(_Stream):
 
 
 _default_ctx = {}
+
+
+def gunzip_fd(fd, cap, chunk=16 << 20, threads=0):
+    """The stream front end's gzip reader on its own (ffq_gunzip_fd; host only, no device): the file behind
+    `fd` inflated into a new uint8 array of at most `cap` bytes, `chunk` bytes per call of the reader.
+    Returns (array, members inflated side by side)."""
+    import numpy as np
+    out = np.empty(max(int(cap), 1), dtype=np.uint8)
+    npar = ctypes.c_int64(0)
+    n = lib().ffq_gunzip_fd(int(fd), out.ctypes.data, int(cap), int(chunk), int(threads), ctypes.byref(npar))
+    if n < 0:
+        check(int(n))
+    return out[:n], int(npar.value)
 
 
 def default_context(device=None):

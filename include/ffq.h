@@ -302,6 +302,18 @@ int64_t ffq_stream_tell(ffq_stream *s);
  * of the decompressed stream.  start: byte of the compressed file the first member begins at.      */
 int  ffq_stream_open_gzip(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
                           ffq_stream **out);
+/* Members that say how long they are -- the BGZF blocks bgzip writes ("BC" extra field, SAM specification
+ * section 4.1) -- are located without inflating anything and inflated side by side by FFQ_GZ_THREADS threads
+ * (default: the host's cores, at most 16; 1 = one member at a time), each straight into its place in the
+ * chunk; every member is checked against the length and CRC-32 of its trailer, and a file that is not what
+ * its headers promise goes through the one-at-a-time inflate from that member on (same bytes or same error).
+ *
+ * ffq_gunzip_fd: that reader on its own, no device involved -- the file behind fd (from its current
+ * position; a pipe works) inflated into h_dst in calls of `chunk` bytes as the stream's reader thread makes
+ * them.  threads <= 0: the default.  Returns the number of bytes written, FFQ_E_TABLE_FULL if the file holds
+ * more than cap, FFQ_E_ARG for corrupt input (ffq_last_error says what); *n_parallel_members (optional):
+ * how many members were inflated side by side.                                                         */
+int64_t ffq_gunzip_fd(int fd, uint8_t *h_dst, int64_t cap, int64_t chunk, int threads, int64_t *n_parallel_members);
 /* The same without a reader thread, for sources only the host can read (any object with a read() /
  * readinto(): BytesIO, bz2, lzma, sockets ...): the host asks where the next chunk goes
  * (ffq_stream_push_buffer: pinned memory, *cap = fbufsize bytes of room), writes up to *cap bytes

@@ -54,12 +54,17 @@ def _sources(tmp_path, data, tag):
     gz2 = tmp_path / ("%s.2.fq.gz" % tag)
     cut = len(data) // 2
     gz2.write_bytes(gzip.compress(data[:cut]) + gzip.compress(data[cut:]) + b"\0" * 37)
+    # BGZF (bgzip): members that say how long they are -- the library inflates them side by side
+    from fastqandfurious_amd import bgzf
+    bg = tmp_path / ("%s.fq.bgz" % tag)
+    bg.write_bytes(bgzf.compress(data, block_bytes=min(65280, max(64, len(data) // 7))))
     bz = tmp_path / ("%s.fq.bz2" % tag)
     bz.write_bytes(bz2.compress(data))
     xz = tmp_path / ("%s.fq.xz" % tag)
     xz.write_bytes(lzma.compress(data))
     return [("file", lambda: open(plain, "rb")), ("gzip", lambda: gzip.open(gz, "rb")),
-            ("gzip-members", lambda: gzip.open(gz2, "rb")), ("bytesio", lambda: io.BytesIO(data)),
+            ("gzip-members", lambda: gzip.open(gz2, "rb")), ("bgzf", lambda: gzip.open(bg, "rb")),
+            ("bytesio", lambda: io.BytesIO(data)),
             ("bz2", lambda: bz2.open(bz, "rb")), ("xz", lambda: lzma.open(xz, "rb")),
             ("gzip-over-bytesio", lambda: gzip.GzipFile(fileobj=io.BytesIO(gz.read_bytes())))]
 
