@@ -728,9 +728,10 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
 
     // ---- four-line input with the decode: index AND decoded stream in one pass over the bytes ---------
     st.fused = false;
-    // (the segmented layout needs SG_STRIDE bytes of the caller's buffer per tile)
+    // (the segmented layout needs SG_STRIDE bytes of the caller's buffer per tile and is written in whole 16-byte pieces: an
+    // unaligned d_qual gets the packed stream)
     if (decode && (a.flags & FFQ_F_SINGLE_PASS) && try_fast4 && !st.index_done && !st.no_fused && a.offset < 16 &&
-        a.qual_cap >= ntiles * (int64_t)SG_STRIDE) {
+        a.qual_cap >= ntiles * (int64_t)SG_STRIDE && (reinterpret_cast<uintptr_t>(a.d_qual) & 15) == 0) {
         if (c->fused_skip > 0) c->fused_skip--;
         else st.fused = true;
     }

@@ -190,3 +190,34 @@ def test_fused_in_byte_range_shards(gpu_ctx, hipmod, oracle, world):
         base += n_own
     for c in made.values():
         c.close()
+
+
+@pytest.mark.parametrize("shift", (1, 7, 8))
+def test_unaligned_quality_buffer_gets_the_packed_stream(gpu_ctx, hipmod, oracle, shift):
+    """The segmented output is written in whole 16-byte pieces: a d_qual that is not 16-byte aligned is served by
+    the two passes (packed, any alignment) even if the single pass was asked for."""
+    from fastqandfurious_amd import synth
+    data = synth.single(0, 20000, seed=42)
+    want, *_ = oracle.scan(data)
+    wq, wqoff = oracle.decode_quals(data, want)
+    n, nb = len(want), data.size
+    cap = (nb // 16384 + 1) * hipmod.SEG_STRIDE + 64
+    ctx = gpu_ctx
+    d_buf, d_tab = ctx.dev_alloc(nb + 16), ctx.dev_alloc(48 * (n + 8))
+    d_qual, d_qoff = ctx.dev_alloc(cap + 32), ctx.dev_alloc(8 * (n + 9))
+    try:
+        ctx.h2d(d_buf, data)
+        ctx.forget()
+        for flags in (hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS, hipmod.F_DECODE_QUAL):
+            rc, res = ctx.scan_device(d_buf, nb, d_tab, n + 8, flags=flags, d_qual=d_qual + shift, qual_cap=cap, d_qoff=d_qoff)
+            assert rc == 0 and res.path != 6 and res.n_records == n
+            qual, qoff, table = np.empty(wq.size, np.int8), np.empty(n + 1, np.int64), np.empty((n, 6), np.int64)
+            ctx.d2h(qual, d_qual + shift); ctx.d2h(qoff, d_qoff); ctx.d2h(table, d_tab)
+            assert (table == want).all() and (qoff == wqoff).all() and (qual == wq).all()
+        # aligned: the single pass
+        rc, res = ctx.scan_device(d_buf, nb, d_tab, n + 8, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS, d_qual=d_qual,
+                                  qual_cap=cap, d_qoff=d_qoff)
+        assert rc == 0 and res.path == 6
+    finally:
+        for p in (d_buf, d_tab, d_qual, d_qoff):
+            ctx.dev_free(p)
