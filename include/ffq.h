@@ -141,7 +141,11 @@ int         ffq_ctx_reserve(ffq_ctx *ctx, int64_t max_bytes);
  * then starts the following scans with the kernels that fit (results are the
  * same either way).  This forgets that history.                             */
 void        ffq_ctx_forget(ffq_ctx *ctx);
-/* The HIP stream all of this context's work is enqueued on (hipStream_t).   */
+/* The HIP stream all of this context's work is enqueued on (hipStream_t): a stream of the
+ * context's own, created hipStreamNonBlocking -- it does NOT wait for the legacy default stream or
+ * for any other stream.  Whatever fills d_buf (or clears the output buffers) on another stream must
+ * be complete, or ordered in front of this stream by the caller (an event recorded there and waited
+ * for here), before a scan is submitted.                                                           */
 void       *ffq_ctx_stream(ffq_ctx *ctx);
 
 /* ---- memory plumbing (so a ctypes host needs nothing else) ------------ */

@@ -238,6 +238,7 @@ def test_decode_unaligned_destination_and_small_buffer(gpu_ctx, hipmod, oracle, 
     qbuf = torch.zeros(wq.size + 64, dtype=torch.int8, device="cuda")
     for shift in (0, 1, 7, 15):
         qbuf.fill_(99)
+        torch.cuda.synchronize()      # (torch's stream is not the context's)
         rc, res = gpu_ctx.scan_device(dbuf.data_ptr(), len(data), table.data_ptr(), cap, flags=hipmod.F_DECODE_QUAL,
                                       d_qual=qbuf.data_ptr() + shift, qual_cap=wq.size, d_qoff=qoff.data_ptr())
         assert rc == 0 and int(res.n_qual_bytes) == wq.size
@@ -247,6 +248,7 @@ def test_decode_unaligned_destination_and_small_buffer(gpu_ctx, hipmod, oracle, 
         assert (qoff[:len(want) + 1].cpu().numpy() == wqoff).all()
     small = wq.size // 2 + 5
     qbuf.fill_(99)
+    torch.cuda.synchronize()
     rc, res = gpu_ctx.scan_device(dbuf.data_ptr(), len(data), table.data_ptr(), cap, flags=hipmod.F_DECODE_QUAL,
                                   d_qual=qbuf.data_ptr(), qual_cap=small, d_qoff=qoff.data_ptr())
     assert rc == hipmod.E_TABLE_FULL and int(res.n_qual_bytes) == wq.size
@@ -874,6 +876,7 @@ def test_decode_at_config_size_past_4g_of_qualities(gpu_ctx, hipmod, pkg):
     gpu_ctx.forget()
     q3 = torch.zeros(((sh.ext.numel() + 16383) >> 14) * hipmod.SEG_STRIDE, dtype=torch.int8, device=dev)
     t2.zero_(); o2.zero_()
+    torch.cuda.synchronize()      # (torch's fills run on torch's stream, the scan on the context's: they must be through)
     out3 = sh.scan(t2, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS, qual=q3, qoff=o2)
     assert out3.res.path == 6 and int(out3.n_rows) == n
     assert bool((t2[:n] == table[:n]).all())
@@ -901,6 +904,7 @@ def test_wrapped_at_config_size_all_columns(gpu_ctx, hipmod, pkg):
     assert out.res.path == 0 and int(out.n_rows) == sh.n_per
     sh.verify(table, out)
     table.zero_()
+    torch.cuda.synchronize()
     qual = torch.empty(sh.n_own_bytes // 2 + 4096, dtype=torch.int8, device=dev)
     qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
     out = sh.scan(table, flags=hipmod.F_DECODE_QUAL, qual=qual, qoff=qoff)
