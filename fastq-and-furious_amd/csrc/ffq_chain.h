@@ -244,7 +244,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
 {
     constexpr int NMAX = PER * 64;
     constexpr int ND = DOUBLING ? NMAX : 1;
-    __shared__ uint32_t went_all[WPB][EMAX + 4];     // (+4: a lane's words past the last entry, see the window loop)
+    __shared__ uint32_t went_all[WPB][EMAX + 8];     // (+8: a lane's words past the last entry, see the window loop)
     __shared__ uint16_t nidx_all[WPB][NMAX];   // node -> window entry index of its "\n@"
     __shared__ uint16_t nx16_all[WPB][NMAX];   // node -> successor node / SN_*
     __shared__ uint32_t pk_all[WPB][NMAX];     // node -> run end | successor of the run end << 16
@@ -280,17 +280,23 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     long long ts[6] = {0, 0, 0, 0, 0, 0};
     if (prof) ts[0] = clock64();
     // ---- window directory + first FPE entries of every tile, one memory round trip ----
-    constexpr int FP = 2, FPE = FP * 256;        // 512 entries: lines of 32 bytes or more on average
+    // EPL entries per lane and pass: a pass costs ~25 instructions whatever it holds and ~20 per entry, and a tile of
+    // wrapped reads has ~320 lines (80 columns, 50-300 bases: 51 bytes per line) -- with four entries per lane every
+    // tile took a second pass for its last 64 entries (16 of 64 lanes busy)
+    constexpr int EPL = 6, EPW = EPL / 2, PASS = 64 * EPL;
+    constexpr int FP = 2, FPE = FP * PASS;        // 768 entries: lines of 22 bytes or more on average
     int tc[NTW];
-    uint2 ev[NTW][FP];
+    uint32_t ev[NTW][FP][EPW];
 #pragma unroll
     for (int k = 0; k < NTW; k++) {
         tc[k] = (k < nwt) ? (int)L.cnt[wt0 + k] : 0;
 #pragma unroll
         for (int p = 0; p < FP; p++) {
-            ev[k][p] = make_uint2(0, 0);
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+            u32x3 t = {0u, 0u, 0u};
             if (k < nwt)
-                ev[k][p] = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)(wt0 + k) * SLOT + p * 256 + 4 * lane);
+                t = *reinterpret_cast<const u32x3 *>(L.ent + (int64_t)(wt0 + k) * SLOT + p * PASS + EPL * lane);
+            ev[k][p][0] = t.x; ev[k][p][1] = t.y; ev[k][p][2] = t.z;
         }
     }
     int tb[NTW + 1];
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     int maxc = 0;
 #pragma unroll
     for (int k = 0; k < NTW; k++) {
-        // first FPE entries of tile k (already in registers), 4 per lane and pass
+        // first FPE entries of tile k (already in registers), EPL per lane and pass
         const int c = min(tc[k], FPE);
         maxc = max(maxc, tc[k]);
         const uint32_t relb = (uint32_t)(k << TILE_SHIFT) + (uint32_t)L.s;
@@ -343,20 +349,24 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         const bool node_tile = runin_tile || (k >= kown0 && k < kown1);
 #pragma unroll
         for (int p = 0; p < FP; p++) {
-            if (p * 256 >= c) continue;          // wave-uniform
-            const uint32_t x[4] = {ev[k][p].x & 0xFFFFu, ev[k][p].x >> 16, ev[k][p].y & 0xFFFFu, ev[k][p].y >> 16};
+            if (p * PASS >= c) continue;          // wave-uniform
+            uint32_t x[EPL];
+#pragma unroll
+            for (int i = 0; i < EPL; i++) x[i] = (i & 1) ? (ev[k][p][i >> 1] >> 16) : (ev[k][p][i >> 1] & 0xFFFFu);
             uint32_t isn = 0;      // bit i: entry i of this lane becomes a node
             if (node_tile && !runin_tile && relb >= offrel) {
                 // an own tile that lies entirely at or behind `offset`: every "\n@" of it is a node
-                const int nv = min(max(c - p * 256 - 4 * lane, 0), 4);
-                const uint32_t at = ((ev[k][p].x >> 14) & 1u) | ((ev[k][p].x >> 29) & 2u) |
-                                    ((ev[k][p].y >> 12) & 4u) | ((ev[k][p].y >> 27) & 8u);
+                const int nv = min(max(c - p * PASS - EPL * lane, 0), EPL);
+                uint32_t at = 0;
+#pragma unroll
+                for (int h = 0; h < EPW; h++)
+                    at |= (((ev[k][p][h] >> 14) & 1u) | ((ev[k][p][h] >> 29) & 2u)) << (2 * h);
                 isn = at & ((1u << nv) - 1u);
             } else if (node_tile) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < EPL; i++) {
                     const uint32_t off = x[i] & OFF_MASK;
-                    if (p * 256 + 4 * lane + i < c && ((x[i] >> 14) & FL_AT) && relb + off >= offrel &&
+                    if (p * PASS + EPL * lane + i < c && ((x[i] >> 14) & FL_AT) && relb + off >= offrel &&
                         (!runin_tile || off >= (uint32_t)(TILE - RUNIN_BYTES)))
                         isn |= 1u << i;
                 }
@@ -368,19 +378,19 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                 id = (uint32_t)ncomp + incl - nc;
                 ncomp += (int)__shfl((int)incl, 63);
             }
-            // One test per lane, no branch per entry: a lane whose first entry exists writes all four
-            // window words (what lies past the tile's count -- at most three words, never a node -- is
+            // One test per lane, no branch per entry: a lane whose first entry exists writes all its
+            // window words (what lies past the tile's count -- at most EPL - 1 words, never a node -- is
             // overwritten by the next tile's entries, written later, or lies past nwin, within the
             // padding of the array, and is never read); the nodes among them, one in seven entries on
             // wrapped reads, are registered by a loop over the set bits.
-            const int j0 = p * 256 + 4 * lane;
+            const int j0 = p * PASS + EPL * lane;
             if (j0 < c) {
                 uint32_t *wdst = went + tb[k] + j0;
                 // every word as "not a node" first: offset and flags moved into place with a shift, a
                 // bit-field insert and a mask; the window base and the node field come in one add
                 const uint32_t wconst = relb + (NO_NODE << WN_SHIFT);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < EPL; i++) {
                     const uint32_t f = (((x[i] << 4) & ~OFF_MASK) | (x[i] & OFF_MASK)) & ((3u << WF_SHIFT) | OFF_MASK);
                     wdst[i] = wconst + f;        // (relb + offset stays below 2^18: no carry into the flags)
                 }
@@ -389,7 +399,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                 while (mrem) {
                     const int i = __ffs((int)mrem) - 1;
                     mrem &= mrem - 1u;
-                    const uint32_t half = (i & 2) ? ev[k][p].y : ev[k][p].x;
+                    uint32_t half = ev[k][p][0];
+#pragma unroll
+                    for (int h = 1; h < EPW; h++) if ((i >> 1) == h) half = ev[k][p][h];
                     const uint32_t off = ((i & 1) ? (half >> 16) : half) & OFF_MASK;
                     const uint32_t idw = min(id, (uint32_t)(NMAX - 1));     // (NMAX - 1 is reserved: such a group is given up below)
                     nidx[idw] = (uint16_t)(tb[k] + j0 + i);
