@@ -390,10 +390,10 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                 // bit-field insert and a mask; the window base and the node field come in one add
                 const uint32_t wconst = relb + (NO_NODE << WN_SHIFT);
 #pragma unroll
-                for (int i = 0; i < EPL; i++) {
-                    const uint32_t f = (((x[i] << 4) & ~OFF_MASK) | (x[i] & OFF_MASK)) & ((3u << WF_SHIFT) | OFF_MASK);
-                    wdst[i] = wconst + f;        // (relb + offset stays below 2^18: no carry into the flags)
-                }
+                for (int i = 0; i < EPL; i++)
+                    // offset stays, the two flag bits move up by WF_SHIFT - 14: x + flags * (2^18 - 2^14), one multiply-add
+                    // (relb + offset stays below 2^18: no carry into the flags)
+                    wdst[i] = __umul24(x[i] >> 14, (1u << WF_SHIFT) - (1u << 14)) + (x[i] + wconst);
                 // the nodes among them (a "\n@" match: AT set, PLUS clear) get their word again, with the id
                 uint32_t mrem = isn;
                 while (mrem) {
@@ -529,8 +529,8 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             if (wpos0 + (int64_t)(w12 & WP_MASK) + 4 < len) {
                 uint32_t plusmask = 0;
 #pragma unroll
-                for (int i = 2; i <= 9; i++)
-                    if (((w[i] >> WF_SHIFT) & FL_PLUS) && (w[i] & WP_MASK) >= r1 + 2) plusmask |= 1u << i;
+                for (int i = 2; i <= 9; i++)      // (entry 2 may end an EMPTY line right behind the header's; the later ones lie further on)
+                    if (((w[i] >> WF_SHIFT) & FL_PLUS) && (i > 2 || (w[i] & WP_MASK) >= r1 + 2)) plusmask |= 1u << i;
                 if (plusmask) {
                     const int mi = __ffs((int)plusmask) - 1;
                     const uint32_t r3 = went[k + mi] & WP_MASK, rm1 = went[k + mi + 1] & WP_MASK;
