@@ -469,8 +469,12 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         }
         return;
     }
+    // behind the last node: three positions no successor test can accept (position + 1 >= qe never holds for 0)
+    if (lane < 3 && ncomp + lane <= NMAX - 1) npos[ncomp + lane] = 0u;
     wave_sync();
     if (PROBES && ablate == 2) { if (lane == 0) B.lines[g] = lines + ncomp; return; }
+    // the buffer's end as a window position (32-bit tests below)
+    const uint32_t lenrel = (uint32_t)min(len - wpos0, (int64_t)0x7FFFFFF0);
 
     if (prof) ts[3] = clock64();
     // ---- one scanner call + successor search per node (node c = u*64 + lane) -------------
@@ -521,12 +525,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             const uint32_t w12 = went[k + 12];
             uint32_t np[3];
 #pragma unroll
-            for (int q = 0; q < 3; q++) np[q] = npos[min(c + 1 + q, NMAX - 1)];
-#pragma unroll
-            for (int q = 0; q < 3; q++)
-                if (c + 1 + q >= ncomp) np[q] = 0xFFFFFFFEu;          // no such node: never >= qe - 1
+            for (int q = 0; q < 3; q++) np[q] = npos[min(c + 1 + q, NMAX - 1)];      // (0 behind the last node: never >= qe - 1)
             const uint32_t r0 = w[0] & WP_MASK, r1 = w[1] & WP_MASK;
-            if (wpos0 + (int64_t)(w12 & WP_MASK) + 4 < len) {
+            if ((w12 & WP_MASK) + 4 < lenrel) {
                 uint32_t plusmask = 0;
 #pragma unroll
                 for (int i = 2; i <= 9; i++)      // (entry 2 may end an EMPTY line right behind the header's; the later ones lie further on)
@@ -537,9 +538,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                     const bool invalid = (rm1 - r3 - 1 > 1) && (rm1 - r3 != r1 - r0);
                     const uint32_t qe = rm1 + 1 + r3 - r1 - 1;
                     int dn = 0;                       // successor = node c + dn (0: not among the next three)
-                    if (np[2] != 0xFFFFFFFEu && np[2] + 1 >= qe) dn = 3;
-                    if (np[1] != 0xFFFFFFFEu && np[1] + 1 >= qe) dn = 2;
-                    if (np[0] != 0xFFFFFFFEu && np[0] + 1 >= qe) dn = 1;
+                    if (np[2] + 1 >= qe) dn = 3;
+                    if (np[1] + 1 >= qe) dn = 2;
+                    if (np[0] + 1 >= qe) dn = 1;
                     if (invalid) {
                         info[u] = SN_STOP | ((uint32_t)(ST_INVALID + 1) << 16);
                         done = true;
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                             info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
                                       ((uint32_t)j << 25) | (1u << 29);
                             done = true;
-                        } else if (wpos0 + (int64_t)qe + 2 < len) {
+                        } else if (qe + 2 < lenrel) {
                             // the record is COMPLETE but its successor lies beyond the batch (a
                             // candidate inside a wrapped quality block "reads" several records as
                             // one).  sj = 15: not encoded.
@@ -596,17 +597,17 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
                     }
                     if (mi) {
                         const uint32_t r3 = went[k + mi] & WP_MASK, rm1 = went[k + mi + 1] & WP_MASK;
-                        if (wpos0 + (int64_t)rm1 + 2 <= len) {      // the '+' line end lies inside the scanner's memchr range
+                        if (rm1 + 2 <= lenrel) {      // the '+' line end lies inside the scanner's memchr range
                             const bool invalid = (rm1 - r3 - 1 > 1) && (rm1 - r3 != r1 - r0);
                             const uint32_t qe = rm1 + 1 + r3 - r1 - 1;
                             if (invalid) {
                                 info[u] = SN_STOP | ((uint32_t)(ST_INVALID + 1) << 16);
                                 done = true;
-                            } else if (wpos0 + (int64_t)qe + 2 < len) {
+                            } else if (qe + 2 < lenrel) {
                                 uint32_t nx = 0xFFFFFFFFu;
-                                if (np[0] != 0xFFFFFFFEu && np[0] + 1 >= qe) nx = (uint32_t)(c + 1);
-                                else if (np[1] != 0xFFFFFFFEu && np[1] + 1 >= qe) nx = (uint32_t)(c + 2);
-                                else if (np[2] != 0xFFFFFFFEu && np[2] + 1 >= qe) nx = (uint32_t)(c + 3);
+                                if (np[0] + 1 >= qe) nx = (uint32_t)(c + 1);
+                                else if (np[1] + 1 >= qe) nx = (uint32_t)(c + 2);
+                                else if (np[2] + 1 >= qe) nx = (uint32_t)(c + 3);
                                 else nx = far_successor(k + mi + 2, qe);
                                 if (nx != 0xFFFFFFFFu) {
                                     info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
