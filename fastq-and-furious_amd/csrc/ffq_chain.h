@@ -199,6 +199,16 @@ __device__ __forceinline__ int count_below(const unsigned long long (&m)[PER], i
     return n;
 }
 
+// set bits of a wave-wide mask below this lane (v_mbcnt: two instructions, no 64-bit shift); this lane's own bit
+__device__ __forceinline__ int bits_below_lane(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ bool bit_of_lane(unsigned long long m, int lane)
+{
+    return (((lane & 32) ? (uint32_t)(m >> 32) : (uint32_t)m) >> (lane & 31)) & 1u;
+}
+
 struct FollowOut {
     Rec r;
     int64_t after;
@@ -745,9 +755,8 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             for (int u = 0; u < PER; u++) {
                 const unsigned long long sw = (unsigned long long)sbits[2 * u] | ((unsigned long long)sbits[2 * u + 1] << 32);
                 const unsigned long long ew = (unsigned long long)ebits[2 * u] | ((unsigned long long)ebits[2 * u + 1] << 32);
-                const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-                const int s_le = sb + __popcll(sw & le);
-                const int e_lt = eb + __popcll(ew & ((1ull << lane) - 1ull));
+                const int s_le = sb + bits_below_lane(sw) + (bit_of_lane(sw, lane) ? 1 : 0);
+                const int e_lt = eb + bits_below_lane(ew);
                 MB[u] = __ballot(s_le > e_lt);
                 sb += __popcll(sw); eb += __popcll(ew);
             }
@@ -881,7 +890,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     for (int u = 0; u < PER; u++) {
         const int c = u * 64 + lane;
         const int st = (int)((info[u] >> 16) & 31u) - 1;
-        const bool rec = !unresolved && have_y && c < ncomp && c >= n_runin && ((MB[u] >> lane) & 1ull) &&
+        const bool rec = !unresolved && have_y && c < ncomp && c >= n_runin && bit_of_lane(MB[u], lane) &&
                          (st == ST_COMPLETE || st == ST_FINAL);
         if (rec && ((info[u] >> 30) & 1u)) bad_range = true;
         RM[u] = __ballot(rec && !((info[u] >> 30) & 1u));
@@ -893,9 +902,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int c = u * 64 + lane;
-            const int rank = mbase + __popcll(MB[u] & ((1ull << lane) - 1ull)) - d0;
+            const int rank = mbase + bits_below_lane(MB[u]) - d0;
             mbase += __popcll(MB[u]);
-            if (!((RM[u] >> lane) & 1ull)) continue;
+            if (!bit_of_lane(RM[u], lane)) continue;
             StageRec o;
             if ((info[u] >> 29) & 1u) {
                 const int k = nidx[c];
