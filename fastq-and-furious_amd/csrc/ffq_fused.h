@@ -45,6 +45,9 @@ namespace ffq {
 constexpr int SG_EXT = 512;                      // bytes of the next tile a workgroup sees (the line that runs over its end)
 constexpr int SG_STRIDE = TILE / 2 + SG_EXT;     // output bytes a tile owns (a multiple of 16: segments start aligned)
 constexpr uint8_t FZ_NOPHASE = 0xFF;
+constexpr int FZ_TAB_AT = 576;                   // byte offset of the mask table inside the (dead) entry list; the piece -> line bytes lie in front
+static_assert(SG_STRIDE / 16 <= FZ_TAB_AT && FZ_TAB_AT % 16 == 0 && FZ_TAB_AT + 17 * 16 <= SLOT * 2, "tables must fit the entry list");
+static_assert(SLOT / 4 <= 256, "a quality line's number must fit a byte");
 // bits of *bad
 constexpr uint32_t FZ_BAD_SHAPE = 1u;    // a tile the speculation cannot take (no S P pattern, dense, a line longer than SG_EXT behind
                                          // the tile, more quality bytes than a segment holds, the caller's buffer too small)
@@ -256,7 +259,19 @@ __global__ __launch_bounds__(256, 8) void k_scan_seg(SegArgs a)
     }
     const int qcount = (int)qtot;
     const bool bad_here = any_bad || qcount > SG_STRIDE || (T + 1) * (int64_t)SG_STRIDE > a.out_cap;
-    if (tid < NQ) { s_qs[tid] = (uint16_t)(wpre + incl - (uint32_t)len); s_src[tid] = (uint16_t)st; }
+    // s_list is through (its last readers were the line table's lanes, in front of the barrier above): its memory now holds
+    //   s_piece[p]  the quality line that holds byte 16 p of the segment (every lane of the gather looks its line up
+    //               instead of searching the table of starts: interpolation + two loops were 30 instructions per piece)
+    //   s_tab[h]    the 16-byte mask "bytes below h" (a piece that spans two lines is a select under it)
+    uint8_t *s_piece = reinterpret_cast<uint8_t *>(s_list);
+    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_list) + FZ_TAB_AT / 4;
+    if (tid < NQ) {
+        const int qs = (int)(wpre + incl - (uint32_t)len);
+        s_qs[tid] = (uint16_t)qs; s_src[tid] = (uint16_t)st;
+        if (!bad_here)
+            for (int pz = (qs + 15) >> 4; 16 * pz < qs + len; pz++) s_piece[pz] = (uint8_t)tid;
+    }
+    if (tid >= 128 && tid < 128 + 17 * 4) s_tab[tid - 128] = lt_mask((tid - 128) >> 2, (tid - 128) & 3);
     if (tid == 0) {
         s_qs[NQ] = (uint16_t)min(qcount, 0xFFFF);
         a.qphase[T] = (any_bad || phase == FZ_NOPHASE) ? FZ_NOPHASE : phase;
@@ -267,12 +282,9 @@ __global__ __launch_bounds__(256, 8) void k_scan_seg(SegArgs a)
     // ---- gather: every lane takes 16-byte pieces of the segment; whole aligned stores (the bytes behind the
     //      segment's last piece belong to nobody) ---------------------------------------------------------------
     const uint32_t vv = (uint32_t)(uint8_t)a.qadd * 0x01010101u;
-    const float inv = (float)NQ / (float)qcount;
     int8_t *seg = a.out + T * (int64_t)SG_STRIDE;
     for (int lo = 16 * tid; lo < qcount; lo += 16 * 256) {
-        int mm = min(max((int)((float)lo * inv), 0), NQ - 1);
-        while ((int)s_qs[mm] > lo) mm--;
-        while ((int)s_qs[mm + 1] <= lo) mm++;
+        const int mm = (int)s_piece[lo >> 4];
         const int kend = min(16, qcount - lo);
         const int h0 = min((int)s_qs[mm + 1] - lo, kend);
         const uint4 A = lds_load16(s_data + (int)s_src[mm] + (lo - (int)s_qs[mm]));
@@ -283,11 +295,10 @@ __global__ __launch_bounds__(256, 8) void k_scan_seg(SegArgs a)
             const int h1 = min((int)s_qs[m2 + 1] - lo, kend);
             const uint4 B = lds_load16(s_data + (int)s_src[m2] - h0);
             const uint32_t Bw[4] = {B.x, B.y, B.z, B.w};
+            const uint4 mk4 = *reinterpret_cast<const uint4 *>(s_tab + 4 * h0);
+            const uint32_t mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t mk = lt_mask(h0, q);
-                y[q] = (y[q] & mk) | (Bw[q] & ~mk);
-            }
+            for (int q = 0; q < 4; q++) y[q] = (y[q] & mk[q]) | (Bw[q] & ~mk[q]);
             if (h1 < kend) {
                 const uint4 t4 = fz_gather_tail(s_data, s_qs, s_src, make_uint4(y[0], y[1], y[2], y[3]), m2 + 1, h1, kend, lo);
                 y[0] = t4.x; y[1] = t4.y; y[2] = t4.z; y[3] = t4.w;
