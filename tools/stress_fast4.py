@@ -37,7 +37,7 @@ def main():
     bad = 0
     paths = {}
     for seed in range(nseeds):
-        rng = np.random.default_rng(9000 + seed)
+        rng = np.random.default_rng(9000 + int(os.environ.get("FFQ_STRESS_SEED0", "0")) + seed)
         lo, hi = ((100, 160), (20, 60), (250, 400), (1, 30), (1000, 3000))[seed % 5]
         nrec = int(rng.integers(200, 6000)) if hi < 1000 else int(rng.integers(50, 600))
         data = T.random_records(rng, nrec, lo, hi, wrap=int(rng.integers(60, 101)) if wrapped else 0,
