@@ -11,9 +11,10 @@
 // No speculation, no chain walk:
 //   k_fa_count   one wave per tile: record starts per tile
 //   k_scan_i64   exclusive scan of those counts (ffq_kernels.h)
-//   k_fa_rows    one wave per tile: pos0, pos1, pos2 of every start at its rank
-//   k_fa_fix     pos3 of record r = pos0 of record r + 1, minus one; status and posbuffer of
-//                the last start, which the buffer's end cuts short (it is never COMPLETE)
+//   k_fa_rows    one wave per tile: pos0, pos1, pos2 of every start at its rank, and pos3 (= pos0 of the
+//                next start, minus one) of every start but the tile's last
+//   k_fa_fix     pos3 of each tile's last start, from the row behind it (one thread per tile); status and
+//                posbuffer of the last start, which the buffer's end cuts short (it is never COMPLETE)
 #pragma once
 #include "ffq_chain.h"
 
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
     const uint32_t c = L.cnt[t];
     const long long ntot = *total;
     long long rank = base[t];
+    long long pend = -1;                  // rank of the start whose pos3 is still open (wave-uniform)
     const int64_t len = L.len();
     if (t == 0 && lane == 0) hdr->n_starts = ntot;
     // the sentinel start (rank 0 of tile 0)
@@ -136,10 +138,11 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
             const int64_t p1 = has ? ((int64_t)tn << TILE_SHIFT) + (fa_entry(L, tn, 0, L.cnt[tn]) & OFF_MASK) + L.s : -1;
             if (rank < table_cap) {
                 int64_t *o = table + rank * 6;
-                o[0] = 1 + add; o[1] = p1 + add; o[2] = p1 + 1 + add; o[3] = -1; o[4] = -1; o[5] = -1;
+                o[0] = 1 + add; o[1] = p1 + add; o[2] = p1 + 1 + add; o[4] = -1; o[5] = -1;
             }
             if (rank == ntot - 1) { hdr->last_p0 = 1; hdr->last_p1 = p1; hdr->last_has_next = has ? 1 : 0; }
         }
+        pend = rank;
         rank += 1;
     }
     int carry = c ? fa_run_parity_before(L, offset, t) : 0;
@@ -149,6 +152,16 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
         int64_t P = 0;
         if (st) P = ((int64_t)t << TILE_SHIFT) + (fa_entry(L, t, (int)j, c) & OFF_MASK) + L.s;
         const unsigned long long m = __ballot(st);
+        // pos3 of a start = the newline in front of the NEXT start's '>': the next start of this chunk (its P from that
+        // lane); the chunk's last start waits for the first start of a later chunk (pend = its rank, wave-uniform)
+        const unsigned long long above = (lane == 63) ? 0ull : (m & ~((2ull << lane) - 1ull));
+        const int nl = above ? __ffsll((long long)above) - 1 : lane;
+        const int64_t Pn = ((int64_t)__shfl((int)(P >> 32), nl) << 32) | (uint32_t)__shfl((int)(uint32_t)P, nl);
+        if (m != 0ull && pend >= 0) {
+            const int fl = __ffsll((long long)m) - 1;
+            if (lane == fl && pend < table_cap) table[pend * 6 + 3] = P + add;
+            pend = -1;
+        }
         if (st) {
             const long long r = rank + __popcll(m & ((1ull << lane) - 1ull));
             // header end: the next entry (the following tiles when this is the tile's last)
@@ -162,23 +175,31 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
             const int64_t p1 = has ? ((int64_t)tn << TILE_SHIFT) + (fa_entry(L, tn, jn, L.cnt[tn]) & OFF_MASK) + L.s : -1;
             if (r < table_cap) {
                 int64_t *o = table + r * 6;
-                o[0] = P + 1 + add; o[1] = p1 + add; o[2] = p1 + 1 + add; o[3] = -1; o[4] = -1; o[5] = -1;
+                o[0] = P + 1 + add; o[1] = p1 + add; o[2] = p1 + 1 + add; o[4] = -1; o[5] = -1;
+                if (above) o[3] = Pn + add;
             }
             if (r == ntot - 1) { hdr->last_p0 = P + 1; hdr->last_p1 = p1; hdr->last_has_next = has ? 1 : 0; }
         }
+        if (m != 0ull) pend = rank + __popcll(m) - 1;          // the chunk's last start
         rank += __popcll(m);
     }
+    // the tile's last start: its successor lies in a later tile (k_fa_fix), or there is none
+    if (pend >= 0 && lane == 0 && pend < table_cap) table[pend * 6 + 3] = -1;
     (void)len;
 }
 
 // pos3 of every COMPLETE entry, and the result block
 __global__ __launch_bounds__(256) void k_fa_fix(LineIndex L, int64_t offset, int64_t add, const FaHdr *__restrict__ hdr,
+                                                const unsigned int *__restrict__ cnt_start, const long long *__restrict__ base,
                                                 int64_t *__restrict__ table, int64_t table_cap, DevRes *res, Pub pb)
 {
     const long long ntot = hdr->n_starts;
     const long long ncomplete = ntot > 0 ? ntot - 1 : 0;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ncomplete && i + 1 < table_cap) table[i * 6 + 3] = table[(i + 1) * 6 + 0] - 1;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // a tile
+    if (i < L.ntiles && cnt_start[i] > 0) {
+        const long long r = base[i] + (long long)cnt_start[i] - 1;             // the tile's last start
+        if (r < ncomplete && r + 1 < table_cap) table[r * 6 + 3] = table[(r + 1) * 6 + 0] - 1;
+    }
     if (i != 0) return;
     // block 0 thread 0: the last call of the chain (never COMPLETE: no "\n>" follows it)
     const int64_t len = L.len();

@@ -1437,9 +1437,9 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
                            (long long *)c->d_word);
         hipLaunchKernelGGL(k_fa_rows, dim3(tb), dim3(256), 0, sA, L, offset, add, (const long long *)c->sel_base,
                            (const long long *)c->d_word, d_table, table_cap, c->fa_hdr);
-        const int64_t fix_rows = std::max<int64_t>(std::min<int64_t>(table_cap, n_bytes / 2 + 2), 1);
-        hipLaunchKernelGGL(k_fa_fix, dim3((unsigned)((fix_rows + 255) / 256)), dim3(256), 0, sA, L, offset, add,
-                           (const FaHdr *)c->fa_hdr, d_table, table_cap, c->dres, make_pub(c));
+        hipLaunchKernelGGL(k_fa_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sA, L, offset, add,
+                           (const FaHdr *)c->fa_hdr, (const unsigned int *)c->sel_cnt, (const long long *)c->sel_base, d_table,
+                           table_cap, c->dres, make_pub(c));
         c->ctl_clean = true;
         HIPCHK(hipEventRecord(c->ev[3], sA));
         HIPCHK(hipGetLastError());

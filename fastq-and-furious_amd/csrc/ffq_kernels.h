@@ -731,13 +731,35 @@ __global__ __launch_bounds__(256) void k_sel_count(const int64_t *__restrict__ t
 __global__ __launch_bounds__(1024) void k_scan_i64(const unsigned int *__restrict__ v, int64_t nv,
                                                    long long *__restrict__ base, long long *__restrict__ total)
 {
+    // Exclusive scan of u32 counts into i64, one workgroup.  A thread owns 32 CONSECUTIVE values (eight 16-byte
+    // loads in flight, a sum in registers), the 1024 thread sums are scanned once per 32768 values, and the thread
+    // writes its 32 results -- one barrier round per 32768 values (a round per 1024 values took 65 us for the
+    // 65536 tiles of a GiB, 1 us each).
     __shared__ long long s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     long long carry = 0;
-    for (int64_t b0 = 0; b0 < nv; b0 += 1024) {
-        const int64_t b = b0 + tid;
-        const uint32_t x = (b < nv) ? v[b] : 0u;                 // <= 256 each: wave sums fit 32 bits
-        const uint32_t incl = wave_incl_scan(x);
+    const bool vec = (reinterpret_cast<uintptr_t>(v) & 15) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0;
+    for (int64_t c0 = 0; c0 < nv; c0 += 32768) {
+        const int64_t b0 = c0 + (int64_t)tid * 32;
+        uint32_t x[32];
+        if (vec && b0 + 32 <= nv) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(v + b0 + 4 * k);
+                x[4 * k] = t.x; x[4 * k + 1] = t.y; x[4 * k + 2] = t.z; x[4 * k + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; k++) x[k] = (b0 + k < nv) ? v[b0 + k] : 0u;
+        }
+        // (values are counts per tile / block: 32 of them and a wave's 64 sums fit 32 bits ... the running total
+        // of a thread is kept in 64 bits all the same)
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) mine += x[k];
+        // scan of the thread sums: within the wave in two 32-bit halves, the 16 wave totals through LDS
+        const uint32_t lo = wave_incl_scan((uint32_t)(mine & 0xFFFFFFu)), hi = wave_incl_scan((uint32_t)(mine >> 24));
+        const unsigned long long incl = ((unsigned long long)hi << 24) + lo;
         if (lane == 63) s_w[wid] = (long long)incl;
         __syncthreads();
         long long wpre = 0, tot = 0;
@@ -747,7 +769,22 @@ __global__ __launch_bounds__(1024) void k_scan_i64(const unsigned int *__restric
             if (q < wid) wpre += t;
             tot += t;
         }
-        if (b < nv) base[b] = carry + wpre + (long long)(incl - x);
+        long long run = carry + wpre + (long long)(incl - mine);
+        if (vec && b0 + 32 <= nv) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                longlong2 o;
+                o.x = run; run += x[2 * k];
+                o.y = run; run += x[2 * k + 1];
+                *reinterpret_cast<longlong2 *>(base + b0 + 2 * k) = o;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                if (b0 + k < nv) base[b0 + k] = run;
+                run += x[k];
+            }
+        }
         __syncthreads();
         carry += tot;
     }
