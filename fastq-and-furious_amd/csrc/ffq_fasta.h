@@ -72,12 +72,17 @@ __device__ int fa_run_parity_before(const LineIndex &L, int64_t offset, int t)
 // Starts among entries [j0, j0 + 64) of tile t: a "\n>" entry starts a record iff the run of
 // eligible entries right in front of it has even length.  carry = parity of the run that ends in
 // front of j0 (updated for the next chunk).  Returns this lane's answer.
+__device__ __forceinline__ bool fa_chunk_starts_of(bool at, uint32_t j0, uint32_t c, int &carry);
 __device__ __forceinline__ bool fa_chunk_starts(const LineIndex &L, int64_t offset, int t, uint32_t j0, uint32_t c,
                                                 int &carry)
 {
+    return fa_chunk_starts_of(fa_eligible(L, offset, t, j0 + (uint32_t)(threadIdx.x & 63), c), j0, c, carry);
+}
+// (at: this lane's entry j0 + lane is an eligible "\n>")
+__device__ __forceinline__ bool fa_chunk_starts_of(bool at, uint32_t j0, uint32_t c, int &carry)
+{
     const int lane = threadIdx.x & 63;
     const int nvalid = (int)min((uint32_t)64, c - j0);
-    const bool at = fa_eligible(L, offset, t, j0 + (uint32_t)lane, c);
     const unsigned long long m = __ballot(at);
     // eligible entries right below this lane's bit
     int k = 0;
@@ -123,6 +128,8 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
     if (t >= L.ntiles) return;
     const uint32_t c = L.cnt[t];
     const long long ntot = *total;
+    __shared__ __attribute__((aligned(16))) int64_t s_rows_all[4][64 * 6];       // a chunk's rows, compact
+    int64_t *s_rows = s_rows_all[wid];
     long long rank = base[t];
     long long pend = -1;                  // rank of the start whose pos3 is still open (wave-uniform)
     const int64_t len = L.len();
@@ -146,42 +153,62 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
         rank += 1;
     }
     int carry = c ? fa_run_parity_before(L, offset, t) : 0;
+    const int64_t tbase = ((int64_t)t << TILE_SHIFT) + L.s;
     for (uint32_t j0 = 0; j0 < c; j0 += 64) {
         const uint32_t j = j0 + lane;
-        const bool st = fa_chunk_starts(L, offset, t, j0, c, carry);
-        int64_t P = 0;
-        if (st) P = ((int64_t)t << TILE_SHIFT) + (fa_entry(L, t, (int)j, c) & OFF_MASK) + L.s;
+        // this lane's entry, once: eligibility, position, and (through the neighbour lane) the header's end
+        const uint32_t e = (j < c) ? fa_entry(L, t, (int)j, c) : 0u;
+        const int64_t Pe = tbase + (e & OFF_MASK);
+        const bool st = fa_chunk_starts_of(j < c && ((e >> 14) & FL_AT) && Pe >= offset, j0, c, carry);
+        const int64_t P = st ? Pe : 0;
         const unsigned long long m = __ballot(st);
         // pos3 of a start = the newline in front of the NEXT start's '>': the next start of this chunk (its P from that
         // lane); the chunk's last start waits for the first start of a later chunk (pend = its rank, wave-uniform)
         const unsigned long long above = (lane == 63) ? 0ull : (m & ~((2ull << lane) - 1ull));
         const int nl = above ? __ffsll((long long)above) - 1 : lane;
         const int64_t Pn = ((int64_t)__shfl((int)(P >> 32), nl) << 32) | (uint32_t)__shfl((int)(uint32_t)P, nl);
+        const uint32_t e_next = (uint32_t)__shfl((int)e, min(lane + 1, 63));       // entry j + 1, if it is in this chunk
         if (m != 0ull && pend >= 0) {
             const int fl = __ffsll((long long)m) - 1;
             if (lane == fl && pend < table_cap) table[pend * 6 + 3] = P + add;
             pend = -1;
         }
+        const int below = __popcll(m & ((1ull << lane) - 1ull));
         if (st) {
-            const long long r = rank + __popcll(m & ((1ull << lane) - 1ull));
+            const long long r = rank + below;
             // header end: the next entry (the following tiles when this is the tile's last)
-            int tn = t, jn = (int)j + 1;
+            int64_t p1;
             bool has = true;
-            if (jn >= (int)c) {
-                tn = t + 1; jn = 0;
-                while (tn < L.ntiles && L.cnt[tn] == 0) tn++;
-                has = tn < L.ntiles;
+            if (lane < 63 && j + 1 < c) p1 = tbase + (e_next & OFF_MASK);
+            else {
+                int tn = t, jn = (int)j + 1;
+                if (jn >= (int)c) {
+                    tn = t + 1; jn = 0;
+                    while (tn < L.ntiles && L.cnt[tn] == 0) tn++;
+                    has = tn < L.ntiles;
+                }
+                p1 = has ? ((int64_t)tn << TILE_SHIFT) + (fa_entry(L, tn, jn, L.cnt[tn]) & OFF_MASK) + L.s : -1;
             }
-            const int64_t p1 = has ? ((int64_t)tn << TILE_SHIFT) + (fa_entry(L, tn, jn, L.cnt[tn]) & OFF_MASK) + L.s : -1;
-            if (r < table_cap) {
-                int64_t *o = table + r * 6;
-                o[0] = P + 1 + add; o[1] = p1 + add; o[2] = p1 + 1 + add; o[4] = -1; o[5] = -1;
-                if (above) o[3] = Pn + add;
-            }
+            // the row, compact in LDS (row `below` of this chunk)
+            int64_t *o = s_rows + below * 6;
+            o[0] = P + 1 + add; o[1] = p1 + add; o[2] = p1 + 1 + add; o[3] = Pn + add; o[4] = -1; o[5] = -1;
             if (r == ntot - 1) { hdr->last_p0 = P + 1; hdr->last_p1 = p1; hdr->last_has_next = has ? 1 : 0; }
         }
-        if (m != 0ull) pend = rank + __popcll(m) - 1;          // the chunk's last start
-        rank += __popcll(m);
+        wave_sync();
+        // rows of a chunk are consecutive in the table: 16-byte pieces, consecutive lanes -> consecutive pieces.  The piece
+        // that holds pos3 of the chunk's LAST start (still open) is not written: its pos2 goes out alone.
+        const int nst = __popcll(m);
+        for (int q = lane; q < 3 * nst; q += 64) {
+            const int row = q / 3, part = q - 3 * row;
+            if (rank + row >= table_cap) continue;
+            const longlong2 vv = *reinterpret_cast<const longlong2 *>(s_rows + row * 6 + 2 * part);
+            int64_t *dst = table + (rank + row) * 6 + 2 * part;
+            if (row == nst - 1 && part == 1) dst[0] = vv.x;
+            else *reinterpret_cast<longlong2 *>(dst) = vv;
+        }
+        wave_sync();
+        if (m != 0ull) pend = rank + nst - 1;          // the chunk's last start
+        rank += nst;
     }
     // the tile's last start: its successor lies in a later tile (k_fa_fix), or there is none
     if (pend >= 0 && lane == 0 && pend < table_cap) table[pend * 6 + 3] = -1;

@@ -1401,6 +1401,7 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
     if (n_bytes < 0 || offset < 0 || table_cap < 0) return fail(FFQ_E_ARG, "ffq_scan_fasta: negative size");
     if (n_bytes > 0 && !d_buf) return fail(FFQ_E_ARG, "ffq_scan_fasta: d_buf is NULL");
     if ((reinterpret_cast<uintptr_t>(d_buf) & 15) != 0) return fail(FFQ_E_ARG, "ffq_scan_fasta: d_buf must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d_table) & 15) != 0) return fail(FFQ_E_ARG, "ffq_scan_fasta: d_table must be 16-byte aligned");
     if (table_cap > 0 && !d_table) return fail(FFQ_E_ARG, "ffq_scan_fasta: d_table is NULL");
     if (c->pend.active) return fail(FFQ_E_ARG, "ffq_scan_fasta: a scan is pending on this context");
     memset(res, 0, sizeof *res);
