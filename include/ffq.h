@@ -258,7 +258,8 @@ int ffq_table_gather_column(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes,
  * res->n_records = COMPLETE entries; res->last_status / last_pos = the last call (the entry
  * the end of the buffer cuts short: MISSING_SEQ_END with pos3 = end of the buffer, or an
  * earlier MISSING_* code; MISSING_SEQHEADER_BEGIN if there was no entry at all);
- * res->end_offset = the offset of that last call.  sentinel: a virtual "\n" in front.        */
+ * res->end_offset = the offset of that last call.  sentinel: a virtual "\n" in front.  d_buf and
+ * d_table must be 16-byte aligned.                                                             */
 int ffq_scan_fasta_device(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes, int sentinel,
                           int64_t offset, int64_t add, int64_t *d_table, int64_t table_cap,
                           ffq_scan_result *res);
