@@ -221,3 +221,29 @@ def test_unaligned_quality_buffer_gets_the_packed_stream(gpu_ctx, hipmod, oracle
     finally:
         for p in (d_buf, d_tab, d_qual, d_qoff):
             ctx.dev_free(p)
+
+
+@pytest.mark.parametrize("value", (0, 1, -1, 31, -128, 127, 200, -129))
+def test_quality_add_values_wrap_like_arrayadd_b(gpu_ctx, hipmod, oracle, value):
+    """arrayadd_b adds (int8)value with two's-complement wrap (/root/reference/src/_fastqandfurious.c:161-185) to
+    ANY byte: quality lines that hold every byte value but '\\n', through the single pass and the two passes."""
+    rng = np.random.default_rng(1234 + value)
+    recs = []
+    for i in range(3000):
+        n = int(rng.integers(1, 200))
+        q = rng.integers(0, 256, size=n, dtype=np.uint8)
+        q[q == 10] = 11
+        if q[0] in (ord("@"), ord("+")) and i % 3:
+            q[0] = 200
+        recs.append(b"@r%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)) + b"\n+\n" + q.tobytes() + b"\n")
+    data = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    want, *_ = oracle.scan(data)
+    assert len(want) == 3000
+    wq, wqoff = oracle.decode_quals(data, want, value)
+    lens = want[:, 5] - want[:, 4]
+    for flags in (hipmod.F_SINGLE_PASS, 0):
+        gpu_ctx.forget()
+        table, res, qual, qoff = gpu_ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL | flags, qual_add=value)
+        assert (table == want).all() and res.path == (6 if flags else 3)
+        idx = np.repeat(qoff[:3000] - wqoff[:3000], lens) + np.arange(wq.size)
+        assert (qual[idx] == wq).all()
