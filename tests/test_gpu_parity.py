@@ -947,3 +947,25 @@ def test_poll_result_instead_of_an_end_event(gpu_ctx, hipmod, golden, oracle, pk
         assert (tabs[(i - 1) & 1][:len(want)].cpu().numpy() == want).all()
         assert res.ms_index > 0
     ctx2.close()
+
+
+@pytest.mark.parametrize("wrap,hdr_hi", ((8, 4), (12, 4), (20, 8), (30, 8), (40, 20), (45, 40), (60, 40), (80, 40)))
+def test_wrap_widths_through_the_group_kernel(gpu_ctx, hipmod, oracle, wrap, hdr_hi):
+    """Wrapped records at line lengths from 9 to 81 bytes: 200 to 1800 index entries per 16 KiB tile.  The group
+    kernel takes a tile's entries 384 per pass (six per lane): one pass (up to 384 entries), two (up to 768), the
+    redo loop (more), and the dense configuration beyond 1024 -- rows, end state and the decoded qualities
+    against the oracle, with quality lines that start with '@' and '+' mixed in."""
+    rng = np.random.default_rng(wrap * 131 + hdr_hi)
+    blob = bytearray(random_records(rng, 6000, 50, 300, wrap=wrap, hdr_hi=hdr_hi, repeat_hdr=(wrap % 3 == 0)))
+    # quality lines that begin with '@' / '+': overwrite the first byte of some lines in front of which no '+' line ends
+    nl = np.flatnonzero(np.frombuffer(bytes(blob), dtype=np.uint8) == 10)
+    for p in rng.choice(nl[:-2], size=400, replace=False):
+        b = blob[p + 1]
+        if b not in (ord("@"), ord("+"), 10) and 35 <= b < 74 and chr(b) not in "ACGTN":
+            blob[p + 1] = ord("@") if rng.integers(2) else ord("+")
+    data = np.frombuffer(bytes(blob), dtype=np.uint8)
+    gpu_ctx.forget()
+    res = decode_same(gpu_ctx, hipmod, oracle, data)
+    assert res.path in (0, 2, 5)
+    gpu_ctx.forget()
+    decode_same(gpu_ctx, hipmod, oracle, data, eof=False)
