@@ -259,7 +259,8 @@ int ffq_table_gather_column(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes,
  * the end of the buffer cuts short: MISSING_SEQ_END with pos3 = end of the buffer, or an
  * earlier MISSING_* code; MISSING_SEQHEADER_BEGIN if there was no entry at all);
  * res->end_offset = the offset of that last call.  sentinel: a virtual "\n" in front.  d_buf and
- * d_table must be 16-byte aligned.                                                             */
+ * d_table must be 16-byte aligned.  FFQ_E_TABLE_FULL (res->n_records = the rows needed): rows
+ * [0, table_cap - 1) are complete; pos3 of row table_cap - 1 may be -1 (its end is the next row's start). */
 int ffq_scan_fasta_device(ffq_ctx *ctx, const uint8_t *d_buf, int64_t n_bytes, int sentinel,
                           int64_t offset, int64_t add, int64_t *d_table, int64_t table_cap,
                           ffq_scan_result *res);
