@@ -175,6 +175,16 @@ def test_fasta_device_scan(gpu_ctx, oracle, golden, pkg):
     want, st, last, loff = oracle.scan_fasta(big)
     table, res = gpu_ctx.scan_fasta_host(big)
     assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
+    # a table that is too small: the rows it holds are the first rows, all but the last one complete (include/ffq.h)
+    many = _fasta_blob(rng, 5000)
+    want, st, last, loff = oracle.scan_fasta(many)
+    for cap in (1, 2, 63, 64, 65, len(want) // 2, len(want) - 1, len(want)):
+        table, res = gpu_ctx.scan_fasta_host(many, table_cap=cap)
+        assert int(res.n_records) == len(want) and len(table) == cap
+        assert np.array_equal(table[:cap - 1], want[:cap - 1]), cap
+        assert np.array_equal(table[cap - 1, :3], want[cap - 1, :3]) and int(table[cap - 1, 3]) in (-1, int(want[cap - 1, 3])), cap
+        if cap == len(want):
+            assert np.array_equal(table, want)
 
 
 @pytest.mark.gpu
