@@ -424,7 +424,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
         if (runin_tile && tc[k] <= FPE) n_runin = ncomp;
     }
     if (maxc > FPE) {
-        // tiles with more than FPE lines (average line under 32 bytes).  Node ids must
+        // tiles with more than FPE lines (average line under 22 bytes).  Node ids must
         // follow entry order, so redo the numbering from the first such tile on.
         ncomp = 0; n_runin = 0;
         if (sent) ncomp = (((went[0] >> WN_SHIFT) & WN_MASK) != NO_NODE) ? 1 : 0;
