@@ -357,6 +357,7 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
 FORMAT_OPENERS: typing.Dict[str, typing.Tuple[typing.Union[str, object], str, list]] = {
     'gz': ('gzip', 'open', list()),
     'gzip': ('gzip', 'open', list()),
+    'bgz': ('gzip', 'open', list()),        # (bgzip's output is a gzip file: members that carry their length)
     'bz2': ('bz2', 'open', list()),
     'lzma': ('lzma', 'open', list()),
     'xz': ('lzma', 'open', list()),
