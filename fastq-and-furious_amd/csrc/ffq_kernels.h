@@ -64,48 +64,21 @@ struct ScanLds {
     unsigned long long ovf;
 };
 
-template <bool FULL>
-__device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uint8_t *__restrict__ d, int64_t n,
-                                          uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
-                                          unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
-                                          unsigned long long pool_cap, Ctl *ctl, int ablate, uint32_t at_char)
+// What follows the loads of a tile: m[] / c[] are the newline masks and counts of this lane's four
+// 16-byte pieces at tile offsets o[], already parked in sm.data; nxt is the first byte behind the tile.
+// Returns a lower bound of the vector-memory instructions the wave issued on the way (k_scan_lines_p).
+__device__ __forceinline__ uint32_t scan_tile_rest(ScanLds &sm, const int tile, const uint32_t (&m)[4], const uint32_t (&c)[4],
+                                               const uint32_t (&o)[4], const uint32_t nxt,
+                                               uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
+                                               unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
+                                               unsigned long long pool_cap, Ctl *ctl, int ablate, uint32_t at_char)
 {
     uint8_t *const s_data = sm.data;
     uint16_t *const s_list = sm.list;
     uint32_t *const s_wtot = sm.wtot;
     unsigned long long &s_ovf = sm.ovf;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int64_t base = (int64_t)tile << TILE_SHIFT;
-
-    uint4 v[4];
-    uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) o[i] = (uint32_t)(w * 4096 + i * 1024 + l * 16);
-    if (FULL) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            // non-temporal: the input streams through once; keeping it out of the L2's way lets the
-            // index lines this kernel writes leave for HBM in bulk instead of trickling out between
-            // the reads (-7 us per GiB)
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(d + base + o[i]));
-            v[i] = make_uint4(t.x, t.y, t.z, t.w);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = load_tail16(d, n, base + o[i]);
-    }
-    // first byte of the next tile (workgroup-uniform): the flags of a newline at offset TILE-1
-    const uint32_t nxt = (base + TILE < n) ? (uint32_t)d[base + TILE] : 0u;
-
-    uint32_t m[4], c[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        *reinterpret_cast<uint4 *>(s_data + o[i]) = v[i];
-        m[i] = nl_mask16(v[i]);
-        c[i] = __popc(m[i]);
-    }
-    if (PROBES && ablate == 3) { if ((c[0] + c[1] + c[2] + c[3]) == 77u) cnt[tile] = 1; return; }
+    if (PROBES && ablate == 3) { if ((c[0] + c[1] + c[2] + c[3]) == 77u) cnt[tile] = 1; return 0u; }
     // wave prefix sums of the four row counts, two 16-bit fields per register
     const uint32_t s01 = wave_incl_scan(c[0] | (c[1] << 16));
     const uint32_t s23 = wave_incl_scan(c[2] | (c[3] << 16));
@@ -125,7 +98,7 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
         if (q < w) wbase += t;
         total += t;
     }
-    if (PROBES && ablate == 5) { if (total + wbase == 0x7777u) cnt[tile] = 1; return; }
+    if (PROBES && ablate == 5) { if (total + wbase == 0x7777u) cnt[tile] = 1; return 0u; }
 #ifdef FFQ_PROBES
     if (ablate == 8 && w == 0) {
         // PROBE (ffq_read_probe mode 7): what a decoupled look-back over the tiles' newline counts
@@ -256,20 +229,22 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
         cnt[tile] = total;
         if (dense) ovf[tile] = pbase;                       // read only for tiles with cnt > SLOT
     }
-    if (PROBES && (ablate == 6 || ablate == 7)) return;
+    if (PROBES && (ablate == 6 || ablate == 7)) return 0u;
     // Each wave stores its own entries, flags looked up on the way, and is done: no second
     // workgroup barrier, no wave waits for another one's store (a workgroup-wide copy of the
     // finished list cost 20 us per GiB in barrier + tail latency).
     if (!dense) {
         // (the usual tile on its own: the list comes out of LDS with plain ds reads -- one loop for
         // both cases reads through a flat pointer)
-        uint16_t *gdst = ent + (int64_t)tile * SLOT;
+        // (the slot's address as a scalar + a 32-bit lane offset, spelled out: left to itself the compiler keeps a
+        // 64-bit vector address per lane alive across the persistent kernel's whole loop)
+        const uint16_t *gdst = ent + (int64_t)__builtin_amdgcn_readfirstlane(tile) * SLOT;
         for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
             const uint32_t off = (uint32_t)s_list[wbase + j];
-            const uint16_t e = (uint16_t)(off | (entry_flags(s_data, off, nxt, at_char) << 14));
+            const uint32_t e = off | (entry_flags(s_data, off, nxt, at_char) << 14);
             // written once, read by the row / chain kernels from HBM later: non-temporal (-4...10 us per GiB)
-            if (PROBES && ablate == 9) gdst[wbase + j] = e;
-            else __builtin_nontemporal_store(e, gdst + wbase + j);
+            if (PROBES && ablate == 9) const_cast<uint16_t *>(gdst)[wbase + j] = (uint16_t)e;
+            else if (ablate != 31 && ablate != 33) asm volatile("global_store_short %0, %1, %2 nt" : : "v"((wbase + j) * 2u), "v"(e), "s"(gdst) : "memory");
         }
     } else if (pool_ok) {
         uint16_t *gdst = pool + pbase;
@@ -278,6 +253,49 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
             gdst[wbase + j] = (uint16_t)(off | (entry_flags(s_data, off & OFF_MASK, nxt, at_char) << 14));
         }
     }
+    // for the persistent kernel: a number of vector-memory instructions this wave has certainly issued
+    // since the caller's prefetch (the entry stores of the usual tile; 0 = make no assumption)
+    return dense ? 0u : (wtot + 63u) >> 6;
+}
+
+template <bool FULL>
+__device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uint8_t *__restrict__ d, int64_t n,
+                                          uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
+                                          unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
+                                          unsigned long long pool_cap, Ctl *ctl, int ablate, uint32_t at_char)
+{
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int64_t base = (int64_t)tile << TILE_SHIFT;
+
+    uint4 v[4];
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (uint32_t)(w * 4096 + i * 1024 + l * 16);
+    if (FULL) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // non-temporal: the input streams through once; keeping it out of the L2's way lets the
+            // index lines this kernel writes leave for HBM in bulk instead of trickling out between
+            // the reads (-7 us per GiB)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(d + base + o[i]));
+            v[i] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = load_tail16(d, n, base + o[i]);
+    }
+    // first byte of the next tile (workgroup-uniform): the flags of a newline at offset TILE-1
+    const uint32_t nxt = (base + TILE < n) ? (uint32_t)d[base + TILE] : 0u;
+
+    uint32_t m[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        *reinterpret_cast<uint4 *>(sm.data + o[i]) = v[i];
+        m[i] = nl_mask16(v[i]);
+        c[i] = __popc(m[i]);
+    }
+    scan_tile_rest(sm, tile, m, c, o, nxt, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
 }
 
 // The launch: workgroup b takes whole tile tile0 + b.  Only the last tile of a buffer can be
@@ -303,6 +321,83 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
             scan_tile<false>(sm, ragged_tile, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
         }
         // the device copy of the index descriptor (out-of-line device functions take it by pointer)
+        if (threadIdx.x == 0 && d_L) *d_L = Lval;
+    }
+}
+
+// The same index by PERSISTENT workgroups: workgroup b takes whole tiles b, b + G, b + 2 G, ... (G = the
+// workgroups the chip holds at once), and the loads of its NEXT tile are issued as soon as the current
+// tile's bytes are parked in LDS -- into the registers that just became free.  A workgroup slot of the
+// one-tile kernel spends the ~0.4 us of its scans, compaction and stores (and the start of the next
+// workgroup in it) with no load in flight; here the next 16 KiB are on their way during that time.  The
+// grid-stride order keeps the chip's reads one contiguous window moving through the buffer, as the one-tile
+// launch does.  One more barrier per tile (LDS is reused), taken while the loads are awaited anyway.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void k_scan_lines_p(const uint8_t *__restrict__ d, int64_t n,
+                                                            uint16_t *__restrict__ ent,
+                                                            uint32_t *__restrict__ cnt,
+                                                            unsigned long long *__restrict__ ovf,
+                                                            uint16_t *__restrict__ pool,
+                                                            unsigned long long pool_cap, Ctl *ctl, int nfull,
+                                                            LineIndex Lval, LineIndex *__restrict__ d_L,
+                                                            uint32_t at_char, int ragged_tile, int exp_)
+{
+    __shared__ ScanLds sm;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int G = (int)gridDim.x;
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (uint32_t)(w * 4096 + i * 1024 + l * 16);
+    // two register sets: the loads of tile k + 1 go out the moment tile k's bytes have arrived, before
+    // anything is computed on them and before any barrier (the last tile's prefetch re-reads that tile)
+    u32x4 va[4], vb[4];
+    uint32_t na = 0, nb = 0;
+    const int nall = nfull + (ragged_tile >= 0 ? 1 : 0);       // tiles of the buffer, the ragged one included
+    auto issue = [&](u32x4 (&v)[4], uint32_t &nx, int t) {
+        t = min(t, nfull - 1);
+        // (scalar tile address + 32-bit lane offset; opaque, or the compiler keeps d + lane offset as a
+        // 64-bit vector across the loop)
+        const uint8_t *tb = d + ((int64_t)t << TILE_SHIFT);
+        asm volatile("" : "+s"(tb));
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4 *)(tb + o[i]));
+        nx = (uint32_t)((const __attribute__((address_space(1))) uint8_t *)tb)[t + 1 < nall ? TILE : 0];
+    };
+    auto process = [&](const u32x4 (&v)[4], uint32_t nx, int t, bool first) {
+        uint32_t m[4], c[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            m[i] = nl_mask16(make_uint4(v[i].x, v[i].y, v[i].z, v[i].w));
+            c[i] = __popc(m[i]);
+        }
+        if (!first && exp_ != 32 && exp_ != 33) __syncthreads();            // every wave is through with the previous tile's bytes and list
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4 *>(sm.data + o[i]) = v[i];
+        const uint32_t nxt = (t + 1 < nall) ? nx : 0u;
+        scan_tile_rest(sm, t, m, c, o, nxt, ent, cnt, ovf, pool, pool_cap, ctl, exp_, at_char);
+    };
+    int tile = (int)blockIdx.x;
+    issue(va, na, tile);
+    for (bool first = true;; first = false) {
+        // (an explicit wait: behind the store loops of the previous tile the compiler would wait for ALL
+        // loads at the first use of the current tile's bytes, the prefetch included)
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this tile's bytes are here
+        issue(vb, nb, tile + G);
+        process(va, na, tile, first);
+        tile += G;
+        if (tile >= nfull) break;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        issue(va, na, tile + G);
+        process(vb, nb, tile, false);
+        tile += G;
+        if (tile >= nfull) break;
+    }
+    if (blockIdx.x == 0) {
+        if (ragged_tile >= 0) {
+            __syncthreads();
+            scan_tile<false>(sm, ragged_tile, d, n, ent, cnt, ovf, pool, pool_cap, ctl, 0, at_char);
+        }
         if (threadIdx.x == 0 && d_L) *d_L = Lval;
     }
 }
