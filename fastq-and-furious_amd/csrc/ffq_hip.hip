@@ -516,17 +516,16 @@ static void launch_scan_lines(ffq_ctx *c, hipStream_t st, const uint8_t *d_buf, 
 {
     const int64_t nfull = n_bytes >> TILE_SHIFT;
     const int ragged = ntiles > nfull ? (int)nfull : -1;
-    const int persist = getenv("FFQ_SCAN_PERSIST") ? atoi(getenv("FFQ_SCAN_PERSIST")) : 0;
-    const int pexp = getenv("FFQ_SCAN_PEXP") ? atoi(getenv("FFQ_SCAN_PEXP")) : 0;
-    if (persist > 0 && ablate == 0 && nfull >= 2 * (int64_t)persist) {
+    static const bool lm = getenv("FFQ_SCAN_LM") != nullptr;
+    if (nfull > 0 && lm && ablate == 0) {
         if (any_order)
-            hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines_p<8>), dim3((unsigned)persist), dim3(256), 0, st, nullptr, nullptr,
-                                  hipExtAnyOrderLaunch, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl,
-                                  (int)nfull, L, c->d_L, at_char, ragged, pexp);
+            hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8, true>), dim3((unsigned)nfull), dim3(256), 0, st, nullptr, nullptr,
+                                  hipExtAnyOrderLaunch, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0,
+                                  ablate, L, c->d_L, at_char, ragged);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines_p<8>), dim3((unsigned)persist), dim3(256), 0, st, d_buf,
-                               n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, (int)nfull, L, c->d_L,
-                               at_char, ragged, pexp);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8, true>), dim3((unsigned)nfull), dim3(256), 0, st, d_buf,
+                               n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, ablate, L, c->d_L,
+                               at_char, ragged);
     } else if (nfull > 0 && any_order)
         // No barrier in front of this dispatch: it may start while the kernel queued before it (the previous
         // scan's last, one-workgroup kernel -- another context's, on the same stream) is still running.  The

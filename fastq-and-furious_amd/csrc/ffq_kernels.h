@@ -64,10 +64,52 @@ struct ScanLds {
     unsigned long long ovf;
 };
 
+// The last phase of a tile: the count, then each wave stores its own entries (ranks [wbase, wbase + wtot) of the
+// tile, offsets in sm.list or -- dense tile -- in the pool), the AT / PLUS flags looked up on the way.
+__device__ __forceinline__ void scan_tile_store(ScanLds &sm, const int tile, const uint32_t wbase, const uint32_t wtot,
+                                                const uint32_t total, const bool dense, const unsigned long long pbase,
+                                                const bool pool_ok, const uint32_t nxt,
+                                                uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
+                                                unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
+                                                int ablate, uint32_t at_char)
+{
+    uint8_t *const s_data = sm.data;
+    uint16_t *const s_list = sm.list;
+    const int tid = threadIdx.x, l = tid & 63;
+    if (tid == 0 && !(PROBES && ablate == 7)) {
+        // no atomics here: an agent-scope atomic of 64 tiles on one address costs more than the
+        // whole scan (measured: +45 us per GiB); the per-superblock sums are a kernel of their own
+        cnt[tile] = total;
+        if (dense) ovf[tile] = pbase;                       // read only for tiles with cnt > SLOT
+    }
+    if (PROBES && (ablate == 6 || ablate == 7)) return;
+    // Each wave stores its own entries, flags looked up on the way, and is done: no second
+    // workgroup barrier, no wave waits for another one's store (a workgroup-wide copy of the
+    // finished list cost 20 us per GiB in barrier + tail latency).
+    if (!dense) {
+        // (the usual tile on its own: the list comes out of LDS with plain ds reads -- one loop for
+        // both cases reads through a flat pointer)
+        // (the slot's address as a scalar + a 32-bit lane offset, spelled out)
+        const uint16_t *gdst = ent + (int64_t)__builtin_amdgcn_readfirstlane(tile) * SLOT;
+        for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
+            const uint32_t off = (uint32_t)s_list[wbase + j];
+            const uint32_t e = off | (entry_flags(s_data, off, nxt, at_char) << 14);
+            // written once, read by the row / chain kernels from HBM later: non-temporal (-4...10 us per GiB)
+            if (PROBES && ablate == 9) const_cast<uint16_t *>(gdst)[wbase + j] = (uint16_t)e;
+            else asm volatile("global_store_short %0, %1, %2 nt" : : "v"((wbase + j) * 2u), "v"(e), "s"(gdst) : "memory");
+        }
+    } else if (pool_ok) {
+        uint16_t *gdst = pool + pbase;
+        for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
+            const uint32_t off = (uint32_t)gdst[wbase + j];
+            gdst[wbase + j] = (uint16_t)(off | (entry_flags(s_data, off & OFF_MASK, nxt, at_char) << 14));
+        }
+    }
+}
+
 // What follows the loads of a tile: m[] / c[] are the newline masks and counts of this lane's four
 // 16-byte pieces at tile offsets o[], already parked in sm.data; nxt is the first byte behind the tile.
-// Returns a lower bound of the vector-memory instructions the wave issued on the way (k_scan_lines_p).
-__device__ __forceinline__ uint32_t scan_tile_rest(ScanLds &sm, const int tile, const uint32_t (&m)[4], const uint32_t (&c)[4],
+__device__ __forceinline__ void scan_tile_rest(ScanLds &sm, const int tile, const uint32_t (&m)[4], const uint32_t (&c)[4],
                                                const uint32_t (&o)[4], const uint32_t nxt,
                                                uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
                                                unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
@@ -78,7 +120,7 @@ __device__ __forceinline__ uint32_t scan_tile_rest(ScanLds &sm, const int tile, 
     uint32_t *const s_wtot = sm.wtot;
     unsigned long long &s_ovf = sm.ovf;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    if (PROBES && ablate == 3) { if ((c[0] + c[1] + c[2] + c[3]) == 77u) cnt[tile] = 1; return 0u; }
+    if (PROBES && ablate == 3) { if ((c[0] + c[1] + c[2] + c[3]) == 77u) cnt[tile] = 1; return; }
     // wave prefix sums of the four row counts, two 16-bit fields per register
     const uint32_t s01 = wave_incl_scan(c[0] | (c[1] << 16));
     const uint32_t s23 = wave_incl_scan(c[2] | (c[3] << 16));
@@ -98,7 +140,7 @@ __device__ __forceinline__ uint32_t scan_tile_rest(ScanLds &sm, const int tile, 
         if (q < w) wbase += t;
         total += t;
     }
-    if (PROBES && ablate == 5) { if (total + wbase == 0x7777u) cnt[tile] = 1; return 0u; }
+    if (PROBES && ablate == 5) { if (total + wbase == 0x7777u) cnt[tile] = 1; return; }
 #ifdef FFQ_PROBES
     if (ablate == 8 && w == 0) {
         // PROBE (ffq_read_probe mode 7): what a decoupled look-back over the tiles' newline counts
@@ -223,39 +265,7 @@ __device__ __forceinline__ uint32_t scan_tile_rest(ScanLds &sm, const int tile, 
         }
         rb += rowtot[i];
     }
-    if (tid == 0 && !(PROBES && ablate == 7)) {
-        // no atomics here: an agent-scope atomic of 64 tiles on one address costs more than the
-        // whole scan (measured: +45 us per GiB); the per-superblock sums are a kernel of their own
-        cnt[tile] = total;
-        if (dense) ovf[tile] = pbase;                       // read only for tiles with cnt > SLOT
-    }
-    if (PROBES && (ablate == 6 || ablate == 7)) return 0u;
-    // Each wave stores its own entries, flags looked up on the way, and is done: no second
-    // workgroup barrier, no wave waits for another one's store (a workgroup-wide copy of the
-    // finished list cost 20 us per GiB in barrier + tail latency).
-    if (!dense) {
-        // (the usual tile on its own: the list comes out of LDS with plain ds reads -- one loop for
-        // both cases reads through a flat pointer)
-        // (the slot's address as a scalar + a 32-bit lane offset, spelled out: left to itself the compiler keeps a
-        // 64-bit vector address per lane alive across the persistent kernel's whole loop)
-        const uint16_t *gdst = ent + (int64_t)__builtin_amdgcn_readfirstlane(tile) * SLOT;
-        for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
-            const uint32_t off = (uint32_t)s_list[wbase + j];
-            const uint32_t e = off | (entry_flags(s_data, off, nxt, at_char) << 14);
-            // written once, read by the row / chain kernels from HBM later: non-temporal (-4...10 us per GiB)
-            if (PROBES && ablate == 9) const_cast<uint16_t *>(gdst)[wbase + j] = (uint16_t)e;
-            else if (ablate != 31 && ablate != 33) asm volatile("global_store_short %0, %1, %2 nt" : : "v"((wbase + j) * 2u), "v"(e), "s"(gdst) : "memory");
-        }
-    } else if (pool_ok) {
-        uint16_t *gdst = pool + pbase;
-        for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
-            const uint32_t off = (uint32_t)gdst[wbase + j];
-            gdst[wbase + j] = (uint16_t)(off | (entry_flags(s_data, off & OFF_MASK, nxt, at_char) << 14));
-        }
-    }
-    // for the persistent kernel: a number of vector-memory instructions this wave has certainly issued
-    // since the caller's prefetch (the entry stores of the usual tile; 0 = make no assumption)
-    return dense ? 0u : (wtot + 63u) >> 6;
+    scan_tile_store(sm, tile, wbase, wtot, total, dense, pbase, pool_ok, nxt, ent, cnt, ovf, pool, ablate, at_char);
 }
 
 template <bool FULL>
@@ -298,12 +308,95 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
     scan_tile_rest(sm, tile, m, c, o, nxt, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
 }
 
+// The same tile LANE-MAJOR: the wave's 4 KiB are loaded as before (four coalesced 1 KiB rows) and parked in LDS, then
+// every lane reads back its own 64 CONSECUTIVE bytes (four ds_read_b128; the order of the four pieces rotates
+// with the lane's quad so that the 16 lanes the LDS serves per cycle hit 64 different banks).  Position order is
+// lane order then: ONE 64-bit mask, ONE count and ONE wave prefix sum per lane instead of four of each per row, and
+// the compaction walks two 32-bit halves instead of four 16-bit rows (FASTQ has a "\n+\n" in almost every
+// kilobyte: every row loop ran twice).  Same entries, same slots; ~25 % fewer VALU instructions, the resource
+// the kernel shares its time with (k_scan_lines holds the VALU busy 70 % of its run).
+__device__ __forceinline__ void scan_tile_lm(ScanLds &sm, const int tile, const uint8_t *__restrict__ d, int64_t n,
+                                             uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
+                                             unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
+                                             unsigned long long pool_cap, Ctl *ctl, uint32_t at_char)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint8_t *const s_data = sm.data;
+    uint16_t *const s_list = sm.list;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int64_t base = (int64_t)tile << TILE_SHIFT;
+    const uint32_t ro = (uint32_t)(w * 4096 + l * 16);
+    {
+        u32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(d + base + ro + i * 1024));
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4 *>(s_data + ro + i * 1024) = v[i];
+    }
+    const uint32_t nxt = (base + TILE < n) ? (uint32_t)d[base + TILE] : 0u;
+    // this lane's 64 bytes: tile offsets [lo, lo + 64); piece k of the read is piece (k + q) & 3 of them
+    const uint32_t lo = (uint32_t)(w * 4096 + l * 64);
+    const uint32_t q = ((uint32_t)l >> 2) & 3u;
+    uint32_t mk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32x4 r = *reinterpret_cast<const u32x4 *>(s_data + lo + (((uint32_t)k + q) & 3u) * 16u);
+        mk[k] = nl_mask16(make_uint4(r.x, r.y, r.z, r.w));
+    }
+    // rotate the four 16-bit masks back into position: a 64-bit rotate left by 16 q
+    uint32_t m0 = mk[0] | (mk[1] << 16), m1 = mk[2] | (mk[3] << 16);
+    {
+        const uint32_t a0 = __builtin_amdgcn_alignbit(m0, m1, 16), a1 = __builtin_amdgcn_alignbit(m1, m0, 16);
+        const uint32_t b0 = (q & 1u) ? a0 : m0, b1 = (q & 1u) ? a1 : m1;
+        m0 = (q & 2u) ? b1 : b0;
+        m1 = (q & 2u) ? b0 : b1;
+    }
+    const uint32_t c = (uint32_t)__popc(m0) + (uint32_t)__popc(m1);
+    const uint32_t incl = wave_incl_scan(c);
+    const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (l == 0) sm.wtot[w] = wtot;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t t = sm.wtot[k];
+        if (k < w) wbase += t;
+        total += t;
+    }
+    const bool dense = total > (uint32_t)SLOT;
+    if (dense) {   // rare: avg line shorter than 16 bytes over the whole tile
+        if (tid == 0) {
+            const unsigned long long at = atomicAdd(&ctl->pool_head, (unsigned long long)total);
+            sm.ovf = at;
+            if (at + total > pool_cap) atomicOr(&ctl->err, ERR_POOL);
+        }
+        __syncthreads();
+    }
+    const unsigned long long pbase = dense ? sm.ovf : 0ull;
+    const bool pool_ok = dense && (pbase + total <= pool_cap);
+    // newline offsets in position order; this lane's entries are ranks wbase + (incl - c) ... of the tile
+    uint32_t idx = wbase + incl - c;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        uint32_t mm = h ? m1 : m0;
+        const uint32_t ob = lo + 32u * (uint32_t)h;
+        while (mm) {
+            const uint32_t p = (uint32_t)__ffs((int)mm) - 1u;
+            mm &= mm - 1u;
+            if (!dense) s_list[idx] = (uint16_t)(ob + p);
+            else if (pool_ok) pool[pbase + idx] = (uint16_t)(ob + p);
+            idx++;
+        }
+    }
+    scan_tile_store(sm, tile, wbase, wtot, total, dense, pbase, pool_ok, nxt, ent, cnt, ovf, pool, 0, at_char);
+}
+
 // The launch: workgroup b takes whole tile tile0 + b.  Only the last tile of a buffer can be
 // ragged; it is workgroup 0's second tile (ragged_tile >= 0), with bounds-checked loads: a
 // variant of the whole kernel with a ragged test in front of the loads ran 3-8 us per GiB slower
 // on every tile, and workgroup 0 is long done when the last round of the grid starts.
 // WHOLE = false: no whole tile at all (a buffer shorter than a tile), one workgroup.
-template <bool WHOLE, int MINW>
+template <bool WHOLE, int MINW, bool LM = false>
 __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restrict__ d, int64_t n,
                                                     uint16_t *__restrict__ ent,
                                                     uint32_t *__restrict__ cnt,
@@ -314,90 +407,16 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
                                                     uint32_t at_char, int ragged_tile)
 {
     __shared__ ScanLds sm;
-    if (WHOLE) scan_tile<true>(sm, tile0 + (int)blockIdx.x, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
+    if (WHOLE) {
+        if (LM) scan_tile_lm(sm, tile0 + (int)blockIdx.x, d, n, ent, cnt, ovf, pool, pool_cap, ctl, at_char);
+        else scan_tile<true>(sm, tile0 + (int)blockIdx.x, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
+    }
     if (blockIdx.x == 0) {
         if (ragged_tile >= 0) {
             if (WHOLE) __syncthreads();
             scan_tile<false>(sm, ragged_tile, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
         }
         // the device copy of the index descriptor (out-of-line device functions take it by pointer)
-        if (threadIdx.x == 0 && d_L) *d_L = Lval;
-    }
-}
-
-// The same index by PERSISTENT workgroups: workgroup b takes whole tiles b, b + G, b + 2 G, ... (G = the
-// workgroups the chip holds at once), and the loads of its NEXT tile are issued as soon as the current
-// tile's bytes are parked in LDS -- into the registers that just became free.  A workgroup slot of the
-// one-tile kernel spends the ~0.4 us of its scans, compaction and stores (and the start of the next
-// workgroup in it) with no load in flight; here the next 16 KiB are on their way during that time.  The
-// grid-stride order keeps the chip's reads one contiguous window moving through the buffer, as the one-tile
-// launch does.  One more barrier per tile (LDS is reused), taken while the loads are awaited anyway.
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void k_scan_lines_p(const uint8_t *__restrict__ d, int64_t n,
-                                                            uint16_t *__restrict__ ent,
-                                                            uint32_t *__restrict__ cnt,
-                                                            unsigned long long *__restrict__ ovf,
-                                                            uint16_t *__restrict__ pool,
-                                                            unsigned long long pool_cap, Ctl *ctl, int nfull,
-                                                            LineIndex Lval, LineIndex *__restrict__ d_L,
-                                                            uint32_t at_char, int ragged_tile, int exp_)
-{
-    __shared__ ScanLds sm;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int G = (int)gridDim.x;
-    uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) o[i] = (uint32_t)(w * 4096 + i * 1024 + l * 16);
-    // two register sets: the loads of tile k + 1 go out the moment tile k's bytes have arrived, before
-    // anything is computed on them and before any barrier (the last tile's prefetch re-reads that tile)
-    u32x4 va[4], vb[4];
-    uint32_t na = 0, nb = 0;
-    const int nall = nfull + (ragged_tile >= 0 ? 1 : 0);       // tiles of the buffer, the ragged one included
-    auto issue = [&](u32x4 (&v)[4], uint32_t &nx, int t) {
-        t = min(t, nfull - 1);
-        // (scalar tile address + 32-bit lane offset; opaque, or the compiler keeps d + lane offset as a
-        // 64-bit vector across the loop)
-        const uint8_t *tb = d + ((int64_t)t << TILE_SHIFT);
-        asm volatile("" : "+s"(tb));
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4 *)(tb + o[i]));
-        nx = (uint32_t)((const __attribute__((address_space(1))) uint8_t *)tb)[t + 1 < nall ? TILE : 0];
-    };
-    auto process = [&](const u32x4 (&v)[4], uint32_t nx, int t, bool first) {
-        uint32_t m[4], c[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            m[i] = nl_mask16(make_uint4(v[i].x, v[i].y, v[i].z, v[i].w));
-            c[i] = __popc(m[i]);
-        }
-        if (!first && exp_ != 32 && exp_ != 33) __syncthreads();            // every wave is through with the previous tile's bytes and list
-#pragma unroll
-        for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4 *>(sm.data + o[i]) = v[i];
-        const uint32_t nxt = (t + 1 < nall) ? nx : 0u;
-        scan_tile_rest(sm, t, m, c, o, nxt, ent, cnt, ovf, pool, pool_cap, ctl, exp_, at_char);
-    };
-    int tile = (int)blockIdx.x;
-    issue(va, na, tile);
-    for (bool first = true;; first = false) {
-        // (an explicit wait: behind the store loops of the previous tile the compiler would wait for ALL
-        // loads at the first use of the current tile's bytes, the prefetch included)
-        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this tile's bytes are here
-        issue(vb, nb, tile + G);
-        process(va, na, tile, first);
-        tile += G;
-        if (tile >= nfull) break;
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        issue(va, na, tile + G);
-        process(vb, nb, tile, false);
-        tile += G;
-        if (tile >= nfull) break;
-    }
-    if (blockIdx.x == 0) {
-        if (ragged_tile >= 0) {
-            __syncthreads();
-            scan_tile<false>(sm, ragged_tile, d, n, ent, cnt, ovf, pool, pool_cap, ctl, 0, at_char);
-        }
         if (threadIdx.x == 0 && d_L) *d_L = Lval;
     }
 }
