@@ -516,17 +516,7 @@ static void launch_scan_lines(ffq_ctx *c, hipStream_t st, const uint8_t *d_buf, 
 {
     const int64_t nfull = n_bytes >> TILE_SHIFT;
     const int ragged = ntiles > nfull ? (int)nfull : -1;
-    static const bool lm = getenv("FFQ_SCAN_LM") != nullptr;
-    if (nfull > 0 && lm && ablate == 0) {
-        if (any_order)
-            hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8, true>), dim3((unsigned)nfull), dim3(256), 0, st, nullptr, nullptr,
-                                  hipExtAnyOrderLaunch, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0,
-                                  ablate, L, c->d_L, at_char, ragged);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8, true>), dim3((unsigned)nfull), dim3(256), 0, st, d_buf,
-                               n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, ablate, L, c->d_L,
-                               at_char, ragged);
-    } else if (nfull > 0 && any_order)
+    if (nfull > 0 && any_order)
         // No barrier in front of this dispatch: it may start while the kernel queued before it (the previous
         // scan's last, one-workgroup kernel -- another context's, on the same stream) is still running.  The
         // index kernel reads the caller's bytes and writes this context's own scratch, nothing the previous

@@ -56,7 +56,12 @@ __device__ __forceinline__ uint32_t entry_flags(const uint8_t *s_data, uint32_t 
 // the loads).  One tile per workgroup and as many resident waves as possible.  Measured on
 // MI355X: 2 / 4 / 8 consecutive tiles per workgroup with the next tile's loads issued ahead of
 // the scans, the barrier and the store tail run at 190 / 213 / 224 us per GiB against 190 us
-// (fewer, longer workgroups fill the last round of the grid worse than the prefetch gains).
+// (fewer, longer workgroups fill the last round of the grid worse than the prefetch gains).  Round 3, measured
+// again with the kernel at 163 us: persistent workgroups (the chip's 2048, grid-stride, the next tile's loads issued
+// into a second register set the moment the current tile's bytes arrive, 64 VGPRs, no spills) 185-190 us, with or
+// without the entry stores or the extra barrier and for any number of workgroups; a lane-major variant (every lane
+// reads its own 64 consecutive bytes back from the parked tile: one mask, one count, one prefix sum, two compaction
+// loops instead of four) 160-173 us, wrapped input +6 % -- profiles/r03_probes/*_index_kernel_ab.txt.
 struct ScanLds {
     __attribute__((aligned(16))) uint8_t data[TILE];
     __attribute__((aligned(16))) uint16_t list[SLOT];
@@ -308,95 +313,12 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
     scan_tile_rest(sm, tile, m, c, o, nxt, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
 }
 
-// The same tile LANE-MAJOR: the wave's 4 KiB are loaded as before (four coalesced 1 KiB rows) and parked in LDS, then
-// every lane reads back its own 64 CONSECUTIVE bytes (four ds_read_b128; the order of the four pieces rotates
-// with the lane's quad so that the 16 lanes the LDS serves per cycle hit 64 different banks).  Position order is
-// lane order then: ONE 64-bit mask, ONE count and ONE wave prefix sum per lane instead of four of each per row, and
-// the compaction walks two 32-bit halves instead of four 16-bit rows (FASTQ has a "\n+\n" in almost every
-// kilobyte: every row loop ran twice).  Same entries, same slots; ~25 % fewer VALU instructions, the resource
-// the kernel shares its time with (k_scan_lines holds the VALU busy 70 % of its run).
-__device__ __forceinline__ void scan_tile_lm(ScanLds &sm, const int tile, const uint8_t *__restrict__ d, int64_t n,
-                                             uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
-                                             unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
-                                             unsigned long long pool_cap, Ctl *ctl, uint32_t at_char)
-{
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    uint8_t *const s_data = sm.data;
-    uint16_t *const s_list = sm.list;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int64_t base = (int64_t)tile << TILE_SHIFT;
-    const uint32_t ro = (uint32_t)(w * 4096 + l * 16);
-    {
-        u32x4 v[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(d + base + ro + i * 1024));
-#pragma unroll
-        for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4 *>(s_data + ro + i * 1024) = v[i];
-    }
-    const uint32_t nxt = (base + TILE < n) ? (uint32_t)d[base + TILE] : 0u;
-    // this lane's 64 bytes: tile offsets [lo, lo + 64); piece k of the read is piece (k + q) & 3 of them
-    const uint32_t lo = (uint32_t)(w * 4096 + l * 64);
-    const uint32_t q = ((uint32_t)l >> 2) & 3u;
-    uint32_t mk[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const u32x4 r = *reinterpret_cast<const u32x4 *>(s_data + lo + (((uint32_t)k + q) & 3u) * 16u);
-        mk[k] = nl_mask16(make_uint4(r.x, r.y, r.z, r.w));
-    }
-    // rotate the four 16-bit masks back into position: a 64-bit rotate left by 16 q
-    uint32_t m0 = mk[0] | (mk[1] << 16), m1 = mk[2] | (mk[3] << 16);
-    {
-        const uint32_t a0 = __builtin_amdgcn_alignbit(m0, m1, 16), a1 = __builtin_amdgcn_alignbit(m1, m0, 16);
-        const uint32_t b0 = (q & 1u) ? a0 : m0, b1 = (q & 1u) ? a1 : m1;
-        m0 = (q & 2u) ? b1 : b0;
-        m1 = (q & 2u) ? b0 : b1;
-    }
-    const uint32_t c = (uint32_t)__popc(m0) + (uint32_t)__popc(m1);
-    const uint32_t incl = wave_incl_scan(c);
-    const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (l == 0) sm.wtot[w] = wtot;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t t = sm.wtot[k];
-        if (k < w) wbase += t;
-        total += t;
-    }
-    const bool dense = total > (uint32_t)SLOT;
-    if (dense) {   // rare: avg line shorter than 16 bytes over the whole tile
-        if (tid == 0) {
-            const unsigned long long at = atomicAdd(&ctl->pool_head, (unsigned long long)total);
-            sm.ovf = at;
-            if (at + total > pool_cap) atomicOr(&ctl->err, ERR_POOL);
-        }
-        __syncthreads();
-    }
-    const unsigned long long pbase = dense ? sm.ovf : 0ull;
-    const bool pool_ok = dense && (pbase + total <= pool_cap);
-    // newline offsets in position order; this lane's entries are ranks wbase + (incl - c) ... of the tile
-    uint32_t idx = wbase + incl - c;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        uint32_t mm = h ? m1 : m0;
-        const uint32_t ob = lo + 32u * (uint32_t)h;
-        while (mm) {
-            const uint32_t p = (uint32_t)__ffs((int)mm) - 1u;
-            mm &= mm - 1u;
-            if (!dense) s_list[idx] = (uint16_t)(ob + p);
-            else if (pool_ok) pool[pbase + idx] = (uint16_t)(ob + p);
-            idx++;
-        }
-    }
-    scan_tile_store(sm, tile, wbase, wtot, total, dense, pbase, pool_ok, nxt, ent, cnt, ovf, pool, 0, at_char);
-}
-
 // The launch: workgroup b takes whole tile tile0 + b.  Only the last tile of a buffer can be
 // ragged; it is workgroup 0's second tile (ragged_tile >= 0), with bounds-checked loads: a
 // variant of the whole kernel with a ragged test in front of the loads ran 3-8 us per GiB slower
 // on every tile, and workgroup 0 is long done when the last round of the grid starts.
 // WHOLE = false: no whole tile at all (a buffer shorter than a tile), one workgroup.
-template <bool WHOLE, int MINW, bool LM = false>
+template <bool WHOLE, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restrict__ d, int64_t n,
                                                     uint16_t *__restrict__ ent,
                                                     uint32_t *__restrict__ cnt,
@@ -407,10 +329,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
                                                     uint32_t at_char, int ragged_tile)
 {
     __shared__ ScanLds sm;
-    if (WHOLE) {
-        if (LM) scan_tile_lm(sm, tile0 + (int)blockIdx.x, d, n, ent, cnt, ovf, pool, pool_cap, ctl, at_char);
-        else scan_tile<true>(sm, tile0 + (int)blockIdx.x, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
-    }
+    if (WHOLE) scan_tile<true>(sm, tile0 + (int)blockIdx.x, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
     if (blockIdx.x == 0) {
         if (ragged_tile >= 0) {
             if (WHOLE) __syncthreads();
