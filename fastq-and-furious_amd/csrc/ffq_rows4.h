@@ -227,7 +227,10 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
     }
 }
 
-// One wave per tile, four tiles per workgroup (no workgroup barrier).
+// One wave per tile, four tiles per workgroup (no workgroup barrier).  (Round 3: a wave taking the PAIR of tiles 2w, 2w + 1 with
+// both tiles' loads issued up front -- shared ordinal base, tile 2w's look-ahead = tile 2w + 1's own entries -- measured
+// slower: 39.1 against 37.6 us per GiB, 460 against 397 us per 10 GiB in the fused variant;
+// profiles/r03_probes/rows4_two_tiles_per_wave_ab.txt.)
 // FUSED: the variant behind the single-pass index + decode kernel (ffq_fused.h); a template parameter so that the
 // usual instantiation carries none of it (as a run-time test it cost the kernel 3 VGPRs and 4 us per GiB).
 template <bool FUSED>
