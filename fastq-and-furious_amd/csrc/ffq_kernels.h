@@ -120,7 +120,6 @@ __device__ __forceinline__ void scan_tile_rest(ScanLds &sm, const int tile, cons
                                                unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
                                                unsigned long long pool_cap, Ctl *ctl, int ablate, uint32_t at_char)
 {
-    uint8_t *const s_data = sm.data;
     uint16_t *const s_list = sm.list;
     uint32_t *const s_wtot = sm.wtot;
     unsigned long long &s_ovf = sm.ovf;
