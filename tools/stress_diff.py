@@ -28,7 +28,8 @@ ctx = hip.default_context(0)
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bad = 0
 paths = {}
-for seed in range(nseeds):
+SEED0 = int(os.environ.get("FFQ_STRESS_SEED0", "0"))      # first seed (new inputs: a run with another offset)
+for seed in range(SEED0, SEED0 + nseeds):
     rng = np.random.default_rng(5000 + seed)
     kind = seed % 5
     if kind == 0:
