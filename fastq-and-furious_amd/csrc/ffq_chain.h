@@ -61,6 +61,7 @@ constexpr int64_t Y_NOCAND = -1, X_END_TERM = -2, Y_UNRES = -3, X_END_FINAL = -4
 constexpr int64_t FORCE_NONE = -1;
 
 constexpr int RES_BLOCK = 1024;            // groups per k_resolve_a workgroup
+constexpr int DCHUNK = 8192;               // records per chunk of the walked groups' stage (64 KiB of 8-byte records)
 
 struct StageRec { uint32_t p0, p1, p3, p4; };     // relative to the group's window origin
 
@@ -79,6 +80,12 @@ struct ChainBufs {
     int64_t *qb;         // [ng] quality bytes of those records
     GroupTerm *term;     // [ng] scanner status/posbuffer where the chain stops (only if it does)
     StageRec *stage;     // [ng][nmax]
+    // groups that are WALKED (k_dense_walk: dense tiles, ffq_dense.h) hold up to DCHUNK records: each takes a chunk of a
+    // second stage the first time it is walked (sbase[g] = its chunk, -1: the group's records are in `stage`)
+    int32_t *sbase;      // [ng]
+    StageRec *dstage;    // [dchunks][DCHUNK]
+    uint32_t *dhead;     // chunks handed out (and asked for: may exceed dchunks -> ERR_DSTAGE, the host grows the stage)
+    int32_t dchunks;
     int64_t *rloc;       // [ng] exclusive prefix of cnt inside the resolve block
     int64_t *qloc;       // [ng] same for qb
     int64_t *part;       // [nblk][4] block totals (cnt, qb, lines, -) -> exclusive prefixes
@@ -100,6 +107,8 @@ struct DevRes {
     int64_t approx_records;   // records the groups counted, confirmed or not (how long the records are, roughly)
     int32_t fast4_hint;  // written by k_finalize4 only: 1 = the four-line fast path stood on this buffer (probe scans)
     int32_t fused_bad;   // written by k_finalize4 only: FZ_BAD_* of the single-pass decode (ffq_fused.h), 0 = it stood
+    int32_t fast4_dense; // written by k_finalize4 only: the row kernel refused a DENSE tile (its DENSE instantiation takes those)
+    int32_t pad_;
 };
 
 // Result hand-over.  The last result-writing kernel of a scan copies the result block and the
@@ -1123,7 +1132,8 @@ __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__rest
     int64_t q0 = B.part[(g / RES_BLOCK) * 4 + 1] + B.qloc[g];
     const int own0 = g * OWN_T;
     const int64_t base = ((int64_t)((own0 > 0) ? own0 - 1 : 0) << TILE_SHIFT) + add;
-    const StageRec *st = B.stage + (int64_t)g * B.nmax;
+    const int32_t sb = B.sbase[g];
+    const StageRec *st = sb < 0 ? B.stage + (int64_t)g * B.nmax : B.dstage + (int64_t)sb * DCHUNK;
     for (uint32_t d0 = 0; d0 < cnt; d0 += 64) {
         const uint32_t dd = d0 + lane;
         const bool ok = dd < cnt;

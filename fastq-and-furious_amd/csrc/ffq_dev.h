@@ -41,6 +41,12 @@ constexpr int ST_FINAL = 21;   // internal: status 5 at eof, accepted by the fin
 // control-block error bits
 constexpr uint32_t ERR_POOL = 1u;       // overflow pool exhausted -> host grows it and re-runs
 constexpr uint32_t ERR_INTERNAL = 2u;   // an invariant of the chain kernels failed
+constexpr uint32_t ERR_DSTAGE = 4u;     // the walked groups' stage ran out of chunks -> host grows it and re-runs the chain
+
+// ovf[t] of a dense tile: where its entries start in the pool, and in the two top bits whether ANY of them carries
+// FL_AT / FL_PLUS -- a search for a flagged entry steps over a dense tile without one (a block of blank lines)
+// on that word alone
+constexpr unsigned long long OVF_MASK = (1ull << 62) - 1ull;
 
 struct Ctl {
     uint32_t err;
@@ -57,7 +63,7 @@ struct LineIndex {
     int32_t pad_;
     const uint16_t *ent;       // [ntiles][SLOT]
     const uint32_t *cnt;       // [ntiles]
-    const unsigned long long *ovf;   // [ntiles] pool offset of dense tiles
+    const unsigned long long *ovf;   // [ntiles] dense tiles: pool offset | (OR of the tile's entry flags) << 62
     const uint16_t *pool;
     unsigned long long pool_cap;     // entries the pool holds
     __device__ __forceinline__ int64_t len() const { return n + s; }
@@ -65,7 +71,7 @@ struct LineIndex {
     // larger one, but the kernels queued behind the index kernel of the failed attempt still
     // run: what such a tile did not get to store reads as 0 instead of past the allocation.
     __device__ __forceinline__ uint32_t pooled(int t, uint32_t j) const {
-        const unsigned long long at = ovf[t] + j;
+        const unsigned long long at = (ovf[t] & OVF_MASK) + j;
         return at < pool_cap ? (uint32_t)pool[at] : 0u;
     }
 };
@@ -146,9 +152,12 @@ __device__ __forceinline__ bool wv_find_t(const LineIndex &L, H from, int mask, 
         const uint32_t c = L.cnt[t];
         // (dense tile searched for a flag, after a step without a hit: see below)
         const bool wide = WIDE && mask != 0 && c > (uint32_t)SLOT;
-        const unsigned long long at0 = wide ? L.ovf[t] : 0ull;
+        const unsigned long long ov = wide ? L.ovf[t] : 0ull;
+        const unsigned long long at0 = ov & OVF_MASK;
         const uint32_t fm = ((uint32_t)mask << 14) * 0x00010001u;           // the flag bits of both halves of a dword
-        for (uint32_t j0 = (uint32_t)i; j0 < c; j0 += 64) {
+        // a dense tile none of whose entries carries the flag (ovf[t]'s top bits): not looked at at all
+        const uint32_t cend = (wide && !((int)(ov >> 62) & mask)) ? 0u : c;
+        for (uint32_t j0 = (uint32_t)i; j0 < cend; j0 += 64) {
             const uint32_t j = j0 + lane;
             bool ok = false;
             int64_t P = 0;
@@ -180,11 +189,14 @@ __device__ __forceinline__ bool wv_find_t(const LineIndex &L, H from, int mask, 
                 }
             }
         }
-        // next non-empty tile, 64 counts at a time
+        // next non-empty tile, 64 counts at a time (WIDE, searching for a flag: next tile that can hold one -- 2 MB of
+        // blank lines are 128 dense tiles without any flag: two steps instead of 4096 of 512 entries each)
         t++; i = 0;
         while (t < L.ready) {
             const uint32_t cl = (t + lane < L.ready) ? L.cnt[t + lane] : 1u;
-            const unsigned long long m = __ballot(cl != 0u);
+            bool may = cl != 0u;
+            if (WIDE && mask != 0 && cl > (uint32_t)SLOT && t + lane < L.ready) may = ((int)(L.ovf[t + lane] >> 62) & mask) != 0;
+            const unsigned long long m = __ballot(may);
             if (m) { t += __ffsll((long long)m) - 1; break; }
             t += 64;
         }

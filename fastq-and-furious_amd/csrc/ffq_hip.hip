@@ -58,6 +58,7 @@ struct ScanState {
     bool probe4 = false;      // the front carries the fast path's kernels as a probe (see ffq_ctx::fast4_skip)
     bool untimed = false;     // FFQ_F_NO_TIMING: no marks around the index kernel, which may start beside the previous front's last kernel
 
+    bool dense4 = false;      // the fast path's row kernel is the DENSE instantiation (it met a dense tile on this buffer, or the context remembers one)
     bool fused = false;       // the front is the single-pass index + decode kernel (ffq_fused.h)
     bool no_fused = false;    // ... which did not stand on this buffer: the two-pass kernels take it
     unsigned long long poll_seq = 0;   // FFQ_F_POLL_RESULT: the front ends in a publisher that writes this number; no end event
@@ -83,6 +84,7 @@ struct ffq_ctx {
     RankBufs rk = {};                    // its scratch (ffq_ranked.h), grow-only
     int64_t rk_cap_tiles = 0, rk_cap_c = 0;
     int dense_skip = 0;                  // scans left that start with the dense configuration of them
+    bool dense4_remember = false;        // four-line input with dense tiles (reads of a dozen bases): the fast path starts with k_rows4<., true>
     // single-pass index + decode (ffq_fused.h): per-tile phases, verdict; grow-only
     uint8_t *fz_qphase = nullptr;
     int64_t fz_tiles_cap = 0;
@@ -99,6 +101,7 @@ struct ffq_ctx {
     int64_t cap_groups = 0;
     ChainBufs cb = {};
     int64_t stage_cap = 0;        // StageRec entries allocated
+    int64_t dstage_chunks = 0;    // chunks of the walked groups' stage (cb.dstage, DCHUNK records each), grow-only
     unsigned long long *prof_d = nullptr;
     long long *sbbase = nullptr;
     TileQ *tileq = nullptr;              // fast path + decode: records / quality bytes per tile
@@ -114,7 +117,6 @@ struct ffq_ctx {
     int64_t qdir_cap = 0;
     int64_t *p4s = nullptr;            // pos4 of every record, compact: what the decode reads instead of the 48-byte rows
     int64_t p4s_cap = 0;
-    int dense_stride = 0;              // stage stride of the dense tier in use (WALK_STRIDE_DENSE if memory allows)
     uint32_t *qrel = nullptr;          // tile-relative quality offsets of the fast path (p4s_cap entries)
     // pinned mirrors
     Ctl *h_ctl = nullptr;               // host-mapped pinned: written by the publishing kernel (Pub)
@@ -241,12 +243,17 @@ static void free_chain(ffq_ctx *c)
     (void)hipFree(c->cb.y); (void)hipFree(c->cb.exit); (void)hipFree(c->cb.cnt); (void)hipFree(c->cb.flags);
     (void)hipFree(c->cb.lines); (void)hipFree(c->cb.qb); (void)hipFree(c->cb.term); (void)hipFree(c->cb.stage);
     (void)hipFree(c->cb.rloc); (void)hipFree(c->cb.qloc); (void)hipFree(c->cb.part); (void)hipFree(c->cb.mins);
-    (void)hipFree(c->cb.force);
+    (void)hipFree(c->cb.force); (void)hipFree(c->cb.sbase);
     (void)hipFree(c->sbbase); (void)hipFree(c->tinfo4);
     (void)hipFree(c->tileq); (void)hipFree(c->sbq); (void)hipFree(c->sbqbase);
     c->sbbase = nullptr; c->tinfo4 = nullptr;
     c->tileq = nullptr; c->sbq = nullptr; c->sbqbase = nullptr;
-    c->cb = ChainBufs{};
+    {
+        // (the walked groups' stage does not depend on the tile count: it stays)
+        StageRec *ds = c->cb.dstage; uint32_t *dh = c->cb.dhead; const int32_t dc = c->cb.dchunks;
+        c->cb = ChainBufs{};
+        c->cb.dstage = ds; c->cb.dhead = dh; c->cb.dchunks = dc;
+    }
     c->stage_cap = 0;
     c->cap_groups = 0;
 }
@@ -271,6 +278,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->rk.S[0]); (void)hipFree(c->rk.S[1]); (void)hipFree(c->rk.C[0]); (void)hipFree(c->rk.C[1]);
     (void)hipFree(c->rk.D); (void)hipFree(c->rk.root);
     free_chain(c);
+    (void)hipFree(c->cb.dstage); (void)hipFree(c->cb.dhead);
     (void)hipFree(c->fz_qphase); (void)hipFree(c->fz_bad);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
@@ -309,9 +317,6 @@ static int64_t groups_for(int64_t ntiles) { return (ntiles + OWN_T - 1) / OWN_T;
 constexpr int PER_FAST = 6, EMAX_FAST = 2048, WPB_FAST = 2;   // k_chain_wave, usual line/record density
 constexpr int PER_DENSE = 15, EMAX_DENSE = NTW * SLOT + 8, WPB_DENSE = 1;   // short records / short lines
 constexpr int NMAX_FAST = PER_FAST * 64, NMAX_DENSE = PER_DENSE * 64;
-// records a group's stage holds in the dense tier: k_group_walk stages the groups of dense tiles
-// there (very short reads: 64 KiB of 16-byte records), k_chain_wave needs NMAX_DENSE of them
-constexpr int WALK_STRIDE_DENSE = 4096;
 
 static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
 {
@@ -338,6 +343,7 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
     HIPCHK(hipMalloc((void **)&c->cb.part, (size_t)nblk * 4 * 8));
     HIPCHK(hipMalloc((void **)&c->cb.mins, 16));
     HIPCHK(hipMalloc((void **)&c->cb.force, (size_t)ng * 8));
+    HIPCHK(hipMalloc((void **)&c->cb.sbase, (size_t)ng * 4));
     {
         const int64_t nsb = (ntiles + SB_TILES - 1) / SB_TILES;
         HIPCHK(hipMalloc((void **)&c->sbbase, (size_t)nsb * sizeof(long long)));
@@ -349,6 +355,21 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
     }
     c->cap_tiles = ntiles;
     c->cap_groups = ng;
+    return FFQ_OK;
+}
+
+// the walked groups' stage (k_dense_walk): `chunks` chunks of DCHUNK records
+static int reserve_dstage(ffq_ctx *c, int64_t chunks)
+{
+    if (!c->cb.dhead) HIPCHK(hipMalloc((void **)&c->cb.dhead, 16));
+    if (chunks <= c->dstage_chunks) return FFQ_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->cb.dstage);
+    c->cb.dstage = nullptr; c->dstage_chunks = 0; c->cb.dchunks = 0;
+    hipError_t e = hipMalloc((void **)&c->cb.dstage, (size_t)chunks * DCHUNK * sizeof(StageRec));
+    if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(walked groups' stage, %lld chunks) failed: %s", (long long)chunks, hipGetErrorString(e));
+    c->dstage_chunks = chunks;
+    c->cb.dchunks = (int32_t)chunks;
     return FFQ_OK;
 }
 
@@ -413,7 +434,7 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 
 extern "C" void ffq_ctx_forget(ffq_ctx *c)
 {
-    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->ranked_skip = 0; c->fused_skip = 0; c->fused_backoff = 15; }
+    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->dense4_remember = false; c->ranked_skip = 0; c->fused_skip = 0; c->fused_backoff = 15; }
 }
 
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
@@ -625,7 +646,7 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
 {
     ChainBufs cb = c->cb;
     cb.ng = ngroups;
-    cb.nmax = dense_cfg ? (c->dense_stride ? c->dense_stride : NMAX_DENSE) : NMAX_FAST;
+    cb.nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
     cb.prof = nullptr;
     hipStream_t sA = c->stream;
     hipLaunchKernelGGL(k_repair_mark, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, sA, cb);
@@ -638,7 +659,7 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
                            dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 2, 0);
     // the groups that do not fit the kernel above (dense tiles) and whose entry is known: walked
-    hipLaunchKernelGGL(k_group_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 0, dense_cfg ? 1 : 0);
+    hipLaunchKernelGGL(k_dense_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 0, dense_cfg ? 1 : 0, c->ctl);
     return enqueue_resolve(c, a, cb, false);
 }
 
@@ -646,18 +667,10 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
 static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups,
                            bool timed = false)
 {
-    int nmax = NMAX_FAST;
-    int rc;
-    if (dense_cfg) {
-        // room for k_group_walk's records if the memory is there (one input size), else the kernel's own
-        nmax = WALK_STRIDE_DENSE;
-        size_t fr = 0, tot = 0;
-        if ((int64_t)ngroups * nmax > c->stage_cap &&
-            (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < (size_t)ngroups * nmax * sizeof(StageRec) + ((size_t)2 << 30)))
-            nmax = NMAX_DENSE;
-        c->dense_stride = nmax;
-    }
-    rc = reserve_stage(c, ngroups, nmax);
+    const int nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
+    int rc = reserve_stage(c, ngroups, nmax);
+    if (rc) return rc;
+    rc = reserve_dstage(c, 64);             // (8 MiB to start with; a scan that walks more groups asks for more: ERR_DSTAGE)
     if (rc) return rc;
     ChainBufs cb = c->cb;
     cb.ng = ngroups;
@@ -672,6 +685,8 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
         cb.prof = c->prof_d;
     }
     HIPCHK(hipMemsetAsync(cb.flags, 0, (size_t)ngroups * 4, sA));
+    HIPCHK(hipMemsetAsync(cb.sbase, 0xFF, (size_t)ngroups * 4, sA));      // no group has a chunk of the walked groups' stage yet
+    HIPCHK(hipMemsetAsync(cb.dhead, 0, 4, sA));
     if (!dense_cfg)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
                            dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
@@ -682,7 +697,7 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
     // the groups the kernel above declined (dense tiles), each from a guessed entry
     if (ablate == 0)
-        hipLaunchKernelGGL(k_group_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 1, dense_cfg ? 1 : 0);
+        hipLaunchKernelGGL(k_dense_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 1, dense_cfg ? 1 : 0, c->ctl);
     return enqueue_resolve(c, a, cb, timed);
 }
 
@@ -716,7 +731,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     }
     if (c->dense_skip > 0 && !st.dense_cfg && !st.index_done) { c->dense_skip--; st.dense_cfg = true; }
     const bool try_fast4 = !serial && !st.go_ranked && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
-                           getenv("FFQ_NO_FAST4") == nullptr;
+                           !(a.flags & FFQ_F_FORCE_GENERAL) && getenv("FFQ_NO_FAST4") == nullptr;
     const LineIndex L = make_index(c, a, ntiles);
     c->decode_timed = false;
     // without the decode every front ends in a publisher: it can say "done" itself
@@ -745,7 +760,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
             presum = c->sbq;
         }
         hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<true, false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, a.table_cap,
                            (int64_t)SG_STRIDE, (const uint8_t *)c->fz_qphase, a.d_qoff);
@@ -781,7 +796,9 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         }
         hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
         if (decode) HIPCHK(hipMemsetAsync(c->tileq, 0, (size_t)ntiles * sizeof(TileQ), sA));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
+        if (c->dense4_remember) st.dense4 = true;
+        auto rows4 = st.dense4 ? k_rows4<false, true> : k_rows4<false, false>;
+        hipLaunchKernelGGL(rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            decode ? c->qrel : (uint32_t *)nullptr, c->tileq, decode ? c->p4s : (int64_t *)nullptr,
                            decode ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0,
@@ -818,7 +835,8 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
                 presum = c->sbq;
             }
             hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
+            auto rows4 = c->dense4_remember ? k_rows4<false, true> : k_rows4<false, false>;
+            hipLaunchKernelGGL(rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                                (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                                (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, (int64_t)0,
                                (int64_t)0, (const uint8_t *)nullptr, (int64_t *)nullptr);
@@ -957,6 +975,19 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             continue;
         }
         if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
+        // more groups were walked (dense regions, ffq_dense.h) than their stage has chunks for: size it for what was
+        // asked and run the chain kernels again, from the index that is there
+        auto dstage_short = [&]() -> int {
+            if (!(c->h_ctl->err & ERR_DSTAGE)) return 0;
+            if (st.retries >= 4) return fail(FFQ_E_INTERNAL, "the walked groups' stage stays too small");
+            uint32_t asked = 0;
+            HIPCHK(hipMemcpy(&asked, c->cb.dhead, sizeof asked, hipMemcpyDeviceToHost));
+            int rc = reserve_dstage(c, std::max<int64_t>((int64_t)asked + (asked >> 3) + 8, 2 * c->dstage_chunks));
+            if (rc) return rc;
+            st.retries++;
+            st.index_done = true;
+            return 1;
+        };
         float ms = 0;
         if (!st.untimed) HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         if (!st.index_done) res->ms_index = ms;
@@ -1001,6 +1032,21 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 c->fused_skip = c->fused_backoff;
                 c->fused_backoff = std::min(4 * c->fused_backoff + 3, 1023);
                 st.index_done = !(c->h_res->fused_bad & (int32_t)FZ_BAD_INDEX);
+                st.retries++;
+                continue;
+            }
+            if (PROBES && getenv("FFQ_DEBUG") && !st.fused) {
+                Fast4Hdr hh;
+                HIPCHK(hipMemcpy(&hh, c->hdr4, sizeof hh, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[ffq debug] fast path refused: dense4 %d attempt %d dense_seen %d j0 %lld irr_min %llu term_min %llu (k %llu tile %llu)\n",
+                        (int)st.dense4, hh.attempt, hh.dense_seen, hh.j0, hh.irr_min, hh.term_min, hh.term_min >> 24, hh.term_min & 0xFFFFFF);
+            }
+            if (c->h_res->fast4_dense && !st.dense4 && !st.fused && !st.no_fused) {
+                // the row kernel met a DENSE tile (lines under 16 bytes on average: reads of a dozen bases): its DENSE
+                // instantiation takes those -- the same front again from the index that is there, and the context's next
+                // scans start with it
+                st.dense4 = true;
+                c->dense4_remember = true;
                 st.retries++;
                 continue;
             }
@@ -1068,7 +1114,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             // (groups that do not FIT -- dense tiles -- are walked one repair pass after their
             // predecessor: those passes go on as before)
             for (int round = 0; round < 16 && c->h_res->fallback && c->h_res->bad_group > prev_bad &&
-                                c->h_res->bad_group < st.ngroups; round++) {
+                                c->h_res->bad_group < st.ngroups && !(c->h_ctl->err & ERR_DSTAGE); round++) {
                 if (!no_ranked && round >= 2 && !c->h_res->bad_irregular) break;
                 // a guess in eight did not stand and the records are long (2.5 KB and more on average:
                 // wrapped reads from ~1.2 kb): repair passes would mend them a pass at a time; list ranking
@@ -1090,6 +1136,11 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 st.repairs++;
                 if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
             }
+        }
+        if (tiers) {
+            const int ds = dstage_short();
+            if (ds < 0) return ds;
+            if (ds > 0) { st.fast4_failed = true; continue; }
         }
         if (tiers && c->h_res->fallback && !st.dense_cfg && c->h_res->bad_irregular) {
             // second tier: the same kernels with the LDS budget for short lines / short records

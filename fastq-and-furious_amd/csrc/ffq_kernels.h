@@ -67,6 +67,7 @@ struct ScanLds {
     __attribute__((aligned(16))) uint16_t list[SLOT];
     uint32_t wtot[4];
     unsigned long long ovf;
+    uint32_t dfl;                  // dense tile: OR of its entries' flags
 };
 
 // The last phase of a tile: the count, then each wave stores its own entries (ranks [wbase, wbase + wtot) of the
@@ -85,7 +86,6 @@ __device__ __forceinline__ void scan_tile_store(ScanLds &sm, const int tile, con
         // no atomics here: an agent-scope atomic of 64 tiles on one address costs more than the
         // whole scan (measured: +45 us per GiB); the per-superblock sums are a kernel of their own
         cnt[tile] = total;
-        if (dense) ovf[tile] = pbase;                       // read only for tiles with cnt > SLOT
     }
     if (PROBES && (ablate == 6 || ablate == 7)) return;
     // Each wave stores its own entries, flags looked up on the way, and is done: no second
@@ -103,12 +103,24 @@ __device__ __forceinline__ void scan_tile_store(ScanLds &sm, const int tile, con
             if (PROBES && ablate == 9) const_cast<uint16_t *>(gdst)[wbase + j] = (uint16_t)e;
             else asm volatile("global_store_short %0, %1, %2 nt" : : "v"((wbase + j) * 2u), "v"(e), "s"(gdst) : "memory");
         }
-    } else if (pool_ok) {
-        uint16_t *gdst = pool + pbase;
-        for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
-            const uint32_t off = (uint32_t)gdst[wbase + j];
-            gdst[wbase + j] = (uint16_t)(off | (entry_flags(s_data, off & OFF_MASK, nxt, at_char) << 14));
+    } else {
+        uint32_t any = 0;
+        if (pool_ok) {
+            uint16_t *gdst = pool + pbase;
+            for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
+                const uint32_t off = (uint32_t)gdst[wbase + j];
+                const uint32_t fl = entry_flags(s_data, off & OFF_MASK, nxt, at_char);
+                any |= fl;
+                gdst[wbase + j] = (uint16_t)(off | (fl << 14));
+            }
         }
+        // ovf[tile] (read only for tiles with cnt > SLOT): the pool offset, and whether any entry of the tile is
+        // flagged at all (sm.dfl was zeroed in front of the barrier of the pool allocation)
+        const uint32_t wany = (__ballot(any & (uint32_t)FL_AT) ? (uint32_t)FL_AT : 0u) |
+                              (__ballot(any & (uint32_t)FL_PLUS) ? (uint32_t)FL_PLUS : 0u);
+        if (l == 0 && wany) atomicOr(&sm.dfl, wany);
+        __syncthreads();
+        if (tid == 0) ovf[tile] = pbase | ((unsigned long long)sm.dfl << 62);
     }
 }
 
@@ -246,6 +258,7 @@ __device__ __forceinline__ void scan_tile_rest(ScanLds &sm, const int tile, cons
         if (tid == 0) {
             const unsigned long long at = atomicAdd(&ctl->pool_head, (unsigned long long)total);
             s_ovf = at;
+            sm.dfl = 0u;
             if (at + total > pool_cap) atomicOr(&ctl->err, ERR_POOL);
         }
         __syncthreads();
@@ -342,6 +355,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
 }  // namespace ffq
 
 #include "ffq_rows4.h"
+#include "ffq_dense.h"
 
 namespace ffq {
 
@@ -413,84 +427,7 @@ __global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset
     res->n_lines = nl;
 }
 
-// =========================================================================
-// k_group_walk: repair pass for the groups that do not fit k_chain_wave (a DENSE region: more
-// than SLOT newlines in a tile -- a block of blank lines, very short lines).  One wave per such
-// group whose predecessor's exit is known (B.force, k_repair_mark; group 0 starts at the search
-// offset): the walker's searches, from that entry to the first candidate past the group's own
-// tiles, records staged like k_chain_wave's.  What does not fit here either (more records than
-// a group's stage holds, fields 4 GiB away) stays flagged and goes to the later tiers.
-// Without it one such region sent the WHOLE buffer to the serial walker (7.5 s per GiB of
-// short reads).
-// =========================================================================
-__global__ __launch_bounds__(256) void k_group_walk(LineIndex L, ChainBufs B, int64_t offset, int eof, int speculate,
-                                                    int walk_all)
-{
-    // (four groups per workgroup, one wave each, no barrier: nearly all of them return at once)
-    const int g = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (g >= B.ng || !(B.flags[g] & 1u)) return;
-    const int64_t fpos = speculate ? FORCE_NONE : B.force[g];
-    if (g > 0 && fpos == FORCE_NONE && !speculate) return;
-    const int own0 = g * OWN_T, own1 = min(own0 + OWN_T, L.ntiles);
-    if (!walk_all) {
-        // usual configuration: only a group with a DENSE tile in its window is walked here; one
-        // that merely exceeds this configuration's LDS budget (lines of ~32 bytes) is far better
-        // off with the dense configuration of k_chain_wave (1.3 TB/s against 0.17 walked)
-        const int wt0 = own0 > 0 ? own0 - 1 : 0, wt1 = min(own1 + 1, L.ntiles);
-        const bool dense_here = wt0 + lane < wt1 && L.cnt[wt0 + lane] > (uint32_t)SLOT;
-        if (__ballot(dense_here) == 0ull) return;
-    }
-    const int64_t own_beg = ((int64_t)own0 << TILE_SHIFT) + L.s;        // coordinate of the own tiles' first byte
-    const int64_t own_end = ((int64_t)own1 << TILE_SHIFT) + L.s;        // first coordinate past the own tiles
-    const int64_t wpos0 = (int64_t)(own0 > 0 ? own0 - 1 : 0) << TILE_SHIFT;
-    const int64_t len = L.len();
-    StageRec *stg = B.stage + (int64_t)g * B.nmax;
-    H k, hm1;
-    int64_t Pk;
-    int flk;
-    Rec r;
-    r.p0 = r.p1 = r.p3 = r.p4 = r.p5 = -1; r.status = ST_HEAD_BEG; r.final_ = false;
-    uint32_t n = 0;
-    int64_t qsum = 0, Y = Y_UNRES, EX = Y_UNRES;
-    bool have_term = false;
-    // entry: exact for group 0 (the scan's search offset) and in a repair pass (the predecessor's
-    // exit); a GUESS in the first pass -- the first candidate of the run-in, as k_chain_wave does:
-    // a chain started at a false candidate has the run-in to fall in with the true one, and the
-    // verification (y[g] == exit[g-1]) decides.  Records of the run-in are walked, not staged.
-    const bool guess = g > 0 && fpos == FORCE_NONE;
-    const int64_t X = (g == 0) ? offset : guess ? max(own_beg - RUNIN_BYTES, offset) : fpos;
-    bool have = wv_find_t<true>(L, H{-2, 0}, FL_AT, X, k, Pk, flk);
-    if (g > 0 && !guess && (!have || Pk != fpos)) return;               // not a candidate: leave it to the later tiers
-    for (;;) {
-        if (!have) { EX = Y_NOCAND; have_term = true; r.p0 = r.p1 = r.p3 = r.p4 = r.p5 = -1; r.status = ST_HEAD_BEG; break; }
-        if (Pk >= own_end) { EX = Pk; break; }
-        const bool own = !guess || Pk >= own_beg;
-        if (own && Y == Y_UNRES) Y = Pk;                                // first member in the own tiles
-        wv_record_t<true>(L, k, Pk, len, eof, r, hm1);
-        if (!own) {
-            if (r.status != ST_COMPLETE) return;                        // the guessed chain ends in the run-in: no guess
-        } else if (r.status == ST_COMPLETE || r.final_) {
-            if (n >= (uint32_t)B.nmax || r.p4 - wpos0 > 0xFFFFFFF0ll) return;
-            if (lane == 0)
-                stg[n] = StageRec{(uint32_t)(r.p0 - wpos0), (uint32_t)(r.p1 - wpos0), (uint32_t)(r.p3 - wpos0),
-                                  (uint32_t)(r.p4 - wpos0)};
-            n++;
-            qsum += r.p5 - r.p4;
-        }
-        if (r.final_) { EX = X_END_FINAL; have_term = true; break; }
-        if (r.status != ST_COMPLETE) { EX = X_END_TERM; have_term = true; break; }
-        have = wv_find_t<true>(L, hm1, FL_AT, r.p5 - 1, k, Pk, flk);
-    }
-    if (Y == Y_UNRES) Y = EX;                                           // no member in the own tiles: the chain passes over
-    if (lane != 0) return;
-    B.y[g] = Y; B.exit[g] = EX; B.cnt[g] = n; B.qb[g] = qsum; B.flags[g] = 0;
-    if (have_term) {
-        GroupTerm &t = B.term[g];
-        t.status = r.status;
-        t.pos[0] = r.p0; t.pos[1] = r.p1; t.pos[2] = (r.p1 >= 0) ? r.p1 + 1 : -1;
-        t.pos[3] = r.p3; t.pos[4] = r.p4; t.pos[5] = r.p5;
-    }
-}
+// (the walk through dense regions -- k_group_walk until round 3 -- is k_dense_walk, ffq_dense.h)
 
 // k_finalize: the iterator's `offset` at exit = pos5 - 1 of the last COMPLETE
 // record (fastqandfurious.py:254), read back from the table; qoff[n].

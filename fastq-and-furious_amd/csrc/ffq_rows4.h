@@ -35,7 +35,7 @@ constexpr int R4_LIST = SLOT + 8;             // tile entries + look-ahead entri
 struct Fast4Hdr {
     long long j0;                  // ordinal of the chain's first "\n@" match; -1: there is none
     int32_t attempt;               // 0: fast path not applicable (decided before k_rows4)
-    int32_t pad;
+    int32_t dense_seen;            // k_rows4<., false> met a dense tile (more than SLOT newlines): the DENSE instantiation can take it
     unsigned long long irr_min;    // smallest irregular record index (~0: none)
     unsigned long long term_min;   // smallest (k << 24 | tile & 0xFFFFFF) where the chain ends (~0: none)
     long long n_lines;
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
         hdr->irr_min = ~0ull;
         hdr->term_min = ~0ull;
         hdr->attempt = 1;
+        hdr->dense_seen = 0;
         hdr->j0 = -1;
         // the chain's first "\n@" match at buffer coordinate >= offset, as an ordinal
         const GAcc a(L);
@@ -233,8 +234,12 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
 // profiles/r03_probes/rows4_two_tiles_per_wave_ab.txt.)
 // FUSED: the variant behind the single-pass index + decode kernel (ffq_fused.h); a template parameter so that the
 // usual instantiation carries none of it (as a run-time test it cost the kernel 3 VGPRs and 4 us per GiB).
-template <bool FUSED>
-__global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
+// DENSE: the instantiation that also takes DENSE tiles (more than SLOT newlines in 16 KiB: reads of a dozen bases with short
+// headers, the shape of /root/reference/tests.py:8-35), their entries read from the overflow pool a chunk of SLOT list elements
+// at a time -- the closed form over newline ordinals does not care how close the newlines are.  The usual instantiation refuses
+// such a tile (Fast4Hdr::dense_seen) and is the same code as before; the host runs this one for a context that has met one.
+template <bool FUSED, bool DENSE>
+__global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap,
                                                uint32_t *__restrict__ qrel, TileQ *__restrict__ tileq,
@@ -296,8 +301,8 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
     // global ordinal of entry 0 of this tile (the sentinel, if any, is ordinal 0)
     const long long ob = sbb + (long long)wave_sum_u32((t0 + lane < t) ? cb_raw : 0u) + L.s;
     if (!attempt) return;
-    if (c > SLOT) {                    // dense tile: leave it to the general path
-        if (lane == 0) atomicMin(&hdr->irr_min, 0ull);
+    if (c > SLOT && (!DENSE || fused)) {     // dense tile: not this instantiation's (the DENSE one, or the general path)
+        if (lane == 0) { atomicMin(&hdr->irr_min, 0ull); hdr->dense_seen = 1; }
         return;
     }
     if (fused) {
@@ -311,7 +316,6 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
     // the sentinel is entry -1 of tile 0 (ordinal 0): give tile 0 a list that starts with it
     const int pre = (t == 0 && L.s) ? 1 : 0;
     if (c + pre == 0 && t != 0) return;   // no newline in the tile (long reads): no record starts here
-    const long long obl = ob - pre;                                    // ordinal of list element 0
     const int64_t tbase = ((int64_t)t << TILE_SHIFT) + L.s;            // buffer coordinate of tile offset 0
     const int64_t tb_add = tbase + add;                                // (wave-uniform: scalar registers)
     const int32_t lim = (int32_t)min(len - tbase, (int64_t)0x7FFFFFF0);   // len relative to the tile
@@ -325,78 +329,153 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
         }
         return;
     }
-    if (pre) {
+    // A tile's list = [sentinel] + its entries; it is taken in CHUNKS of SLOT elements -- one chunk for every tile but a
+    // dense one (DENSE instantiation only: the loop below is a single turn otherwise, decided at compile time).
+    const int ntot = pre + c;                                          // list elements this tile owns
+    const int nch = DENSE ? (ntot + SLOT - 1) / SLOT : 1;
+    const uint16_t *dsrc = nullptr;                                    // a dense tile's entries in the pool
+    if (DENSE && c > SLOT) {
+        const unsigned long long at = L.ovf[t] & OVF_MASK;
+        if (at + (unsigned long long)c > L.pool_cap) {                 // (the pool ran out: ERR_POOL, this scan is run again)
+            if (lane == 0) atomicMin(&hdr->irr_min, 0ull);
+            return;
+        }
+        dsrc = L.pool + at;
+    }
+    long long kfirst = -1;                           // per tile: first record, records, their quality bytes
+    int nrec_tile = 0;
+    bool tile_term_done = false;
+    uint32_t qrun = 0;
+    for (int ch = 0; ch < nch; ch++) {
+    const int e_lo = DENSE ? ch * SLOT : 0;                            // first list element of the chunk
+    const int nown = DENSE ? min(SLOT, ntot - e_lo) : ntot;            // list elements this chunk owns
+    const bool sent0 = pre && e_lo == 0;                               // chunk element 0 is the sentinel
+    const long long obl = ob - pre + e_lo;                             // ordinal of chunk element 0
+    if (DENSE && ch > 0) wave_sync();                                  // (the lists are rewritten)
+    if (DENSE && dsrc) {
+        // chunk elements x = 0 .. nown - 1 are physical entries e_lo + x - pre of the tile: eight per lane and step
+        for (int x0 = 8 * lane; x0 < nown; x0 += 512) {
+            const int ph = e_lo + x0 - pre;
+            if (ph >= 0 && ph + 8 <= c) {
+                typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(2)));
+                const u32x4u v = *reinterpret_cast<const u32x4u *>(dsrc + ph);
+                *reinterpret_cast<uint4 *>(s_ent + x0) = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (ph + q >= 0 && ph + q < c) s_ent[x0 + q] = dsrc[ph + q];
+            }
+        }
+    }
+    if (sent0) {
         if (lane == 0) {
             const uint8_t b0 = L.n > 0 ? L.d[0] : 0;
             const uint32_t fl = (b0 == '@') ? FL_AT : (b0 == '+') ? FL_PLUS : 0;
             s_ent[0] = (uint16_t)(fl << 14);             // the sentinel: coordinate 0, special-cased below
         }
-        const uint32_t x[4] = {v0.x & 0xFFFFu, v0.x >> 16, v0.y & 0xFFFFu, v0.y >> 16};
+        if (!(DENSE && dsrc)) {
+            const uint32_t x[4] = {v0.x & 0xFFFFu, v0.x >> 16, v0.y & 0xFFFFu, v0.y >> 16};
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (4 * lane + i < c) s_ent[1 + 4 * lane + i] = (uint16_t)x[i];
-    } else {
+            for (int i = 0; i < 4; i++)
+                if (4 * lane + i < c) s_ent[1 + 4 * lane + i] = (uint16_t)x[i];
+        }
+    } else if (!(DENSE && dsrc)) {
         // four entries per lane as loaded, one 8-byte LDS store; what lies past the tile's count is
         // never read as an entry of the tile
         *reinterpret_cast<uint2 *>(s_ent + 4 * lane) = v0;
     }
-    for (int i = 256 + lane; i < c; i += 64) {              // more than 256 lines in the tile
-        s_ent[pre + i] = src[i];
-    }
-    // look-ahead: the first entries of the following tiles (a record needs 4 more newlines)
-    int nl = pre + c;
-    bool idx_end = false;           // the look-ahead ran into the end of the index
-    // la_next: the look-ahead is the first five entries of tile t + 1; they are then ALSO list
-    // elements nown .. nown + 4 of s_ent as stored (position = TILE + offset), which is what the
-    // usual-record test below reads
-    const bool la_next = have_next && c1 >= 5 && c1 <= SLOT;
-    if (la_next) {
-        if (lane < 2) {
-            const uint32_t x[4] = {vla.x & 0xFFFFu, vla.x >> 16, vla.y & 0xFFFFu, vla.y >> 16};
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (4 * lane + i < 5) {
-                    s_la[4 * lane + i] = ((1u << TILE_SHIFT) + (x[i] & OFF_MASK)) | ((x[i] >> 14) << 30);
-                    s_ent[nl + 4 * lane + i] = (uint16_t)x[i];
-                }
+    if (!(DENSE && dsrc))
+        for (int i = 256 + lane; i < c; i += 64) {              // more than 256 lines in the tile
+            s_ent[pre + i] = src[i];
         }
-        nl += 5;
+    // look-ahead: the list elements that follow the chunk (a record needs 4 more newlines)
+    int nl = nown;
+    bool idx_end = false;           // the look-ahead ran into the end of the index
+    // la_simple: the look-ahead is five consecutive entries of ONE tile -- the first five of tile t + 1 (la_add = TILE) or, behind
+    // a chunk that does not end its dense tile, the tile's own next five (la_add = 0); they are then ALSO list
+    // elements nown .. nown + 4 of s_ent as stored (position = la_add + offset), which is what the
+    // usual-record test below reads
+    const bool last_ch = !DENSE || ch == nch - 1;
+    bool la_simple;
+    int32_t la_add = TILE;
+    if (last_ch) {
+        la_simple = have_next && c1 >= 5 && (c1 <= SLOT || DENSE);
+        if (la_simple && (!DENSE || c1 <= SLOT)) {
+            if (lane < 2) {
+                const uint32_t x[4] = {vla.x & 0xFFFFu, vla.x >> 16, vla.y & 0xFFFFu, vla.y >> 16};
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (4 * lane + i < 5) {
+                        s_la[4 * lane + i] = ((1u << TILE_SHIFT) + (x[i] & OFF_MASK)) | ((x[i] >> 14) << 30);
+                        s_ent[nl + 4 * lane + i] = (uint16_t)x[i];
+                    }
+            }
+            nl += 5;
+        } else if (la_simple) {
+            // (DENSE: the next tile is dense, its first five entries are in the pool)
+            const unsigned long long at1 = L.ovf[t + 1] & OVF_MASK;
+            if (at1 + 5ull <= L.pool_cap) {
+                if (lane < 5) {
+                    const uint32_t e = L.pool[at1 + lane];
+                    s_la[lane] = ((1u << TILE_SHIFT) + (e & OFF_MASK)) | ((e >> 14) << 30);
+                    s_ent[nl + lane] = (uint16_t)e;
+                }
+                nl += 5;
+            } else la_simple = false;       // (ERR_POOL: the records at the chunk's end come out irregular, the scan is run again)
+        }
     } else {
-        int tt = t + 1, got = 0;
+        la_simple = ntot - (e_lo + nown) >= 5;
+        la_add = 0;
+        if (la_simple) {
+            if (lane < 5) {
+                const uint32_t e = dsrc[e_lo + nown - pre + lane];
+                s_la[lane] = (e & OFF_MASK) | ((e >> 14) << 30);
+                s_ent[nl + lane] = (uint16_t)e;
+            }
+            nl += 5;
+        }
+    }
+    if (!la_simple) {
+        // element by element: what is left of this tile behind the chunk (DENSE), then the following tiles
+        int tt = last_ch ? t + 1 : t, pp = last_ch ? 0 : e_lo + nown - pre, got = 0;
         while (got < 5) {
             if (tt >= L.ntiles) { idx_end = true; break; }
-            const int cc = (int)L.cnt[tt];
-            if (cc > SLOT) break;
-            const int take = min(cc, 5 - got);
+            const int cc = (tt == t) ? c : (int)L.cnt[tt];
+            if (cc > SLOT && !DENSE) break;
+            if (pp >= cc) { tt++; pp = 0; if (tt - t > 60000) break; continue; }       // positions must stay below 2^30
+            const uint16_t *es = L.ent + (int64_t)tt * SLOT;
+            if (cc > SLOT) {
+                const unsigned long long at1 = L.ovf[tt] & OVF_MASK;
+                if (at1 + (unsigned long long)cc > L.pool_cap) break;
+                es = L.pool + at1;
+            }
+            const int take = min(cc - pp, 5 - got);
             if (lane < take) {
-                const uint32_t e = L.ent[(int64_t)tt * SLOT + lane];
+                const uint32_t e = es[pp + lane];
                 s_la[got + lane] = (((uint32_t)(tt - t) << TILE_SHIFT) + (e & OFF_MASK)) | ((e >> 14) << 30);
             }
             got += take;
-            tt++;
-            if (tt - t > 60000) break;              // positions must stay below 2^30
+            pp += take;
         }
         nl += got;
     }
     wave_sync();
-    const int nown = pre + c;                        // list elements this tile owns
 
     // records whose "\n@" is list element i: ordinal obl + i = j0 + 4k
-    long long kfirst = -1;
-    int nrec_tile = 0;
-    bool tile_term_done = false;
-    uint32_t qrun = 0;
+    long long kfirst_ch = -1;
+    int nrec_ch = 0;
     {
         // first owned element with ordinal >= j0 and (ordinal - j0) % 4 == 0
         long long i0 = (obl >= j0) ? ((4 - ((obl - j0) & 3)) & 3) : (j0 - obl);
         if (i0 < nown) {
-            kfirst = (obl + i0 - j0) >> 2;
-            nrec_tile = (int)((nown - i0 + 3) >> 2);
+            kfirst_ch = (obl + i0 - j0) >> 2;
+            nrec_ch = (int)((nown - i0 + 3) >> 2);
+            if (kfirst < 0) kfirst = kfirst_ch;
         }
         // positions of list elements: (s_pos & 0x0FFFFFFF) + tbase, the sentinel is coordinate 0
-        for (int r0 = 0; r0 < nrec_tile; r0 += 64) {
+        for (int r0 = 0; r0 < nrec_ch; r0 += 64) {
             const int r = r0 + lane;
-            const bool act = r < nrec_tile;
+            const bool act = r < nrec_ch;
             const int i = (int)i0 + 4 * r;
             int cls = 0;          // 0 regular COMPLETE, 1 irregular, 2 chain ends here (status below), 3 complete and last
             bool fin = false;
@@ -410,13 +489,13 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                 const int ic = min(i, R4_LIST - 5);
                 const uint32_t e0 = s_ent[ic], e1 = s_ent[ic + 1], e2 = s_ent[ic + 2], e3 = s_ent[ic + 3],
                                e4 = s_ent[ic + 4];
-                const int32_t x0 = (pre && ic == 0) ? -1 : (int32_t)(e0 & OFF_MASK) + ((ic >= nown) ? TILE : 0);
-                const int32_t x1 = (int32_t)(e1 & OFF_MASK) + ((ic + 1 >= nown) ? TILE : 0);
-                const int32_t x2 = (int32_t)(e2 & OFF_MASK) + ((ic + 2 >= nown) ? TILE : 0);
-                const int32_t x3 = (int32_t)(e3 & OFF_MASK) + ((ic + 3 >= nown) ? TILE : 0);
-                const int32_t x4 = (int32_t)(e4 & OFF_MASK) + ((ic + 4 >= nown) ? TILE : 0);
+                const int32_t x0 = (sent0 && ic == 0) ? -1 : (int32_t)(e0 & OFF_MASK) + ((ic >= nown) ? la_add : 0);
+                const int32_t x1 = (int32_t)(e1 & OFF_MASK) + ((ic + 1 >= nown) ? la_add : 0);
+                const int32_t x2 = (int32_t)(e2 & OFF_MASK) + ((ic + 2 >= nown) ? la_add : 0);
+                const int32_t x3 = (int32_t)(e3 & OFF_MASK) + ((ic + 3 >= nown) ? la_add : 0);
+                const int32_t x4 = (int32_t)(e4 & OFF_MASK) + ((ic + 4 >= nown) ? la_add : 0);
                 const int32_t qe = x3 + x2 - x1;                 // pos4 + (pos3 - pos2) = x3 + 1 + x2 - x1 - 1
-                usual = act & (i + 4 < nl) & (la_next | (i + 4 < nown))
+                usual = act & (i + 4 < nl) & (la_simple | (i + 4 < nown))
                       & (x1 <= lim - 2)                                              // header line ends inside
                       & (((e2 >> 14) & FL_PLUS) != 0) & (x2 >= x1 + 2)               // '+' line right after ONE sequence line
                       & (x2 + 2 < lim) & (x3 <= lim - 2)
@@ -425,18 +504,18 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                       & (((e4 >> 14) & FL_AT) != 0) & (x4 >= qe - 1);                // the next call finds e4
                 f0 = x0 + 1; f1 = x1; f3 = x2; f4 = x3 + 1; f5 = qe;
                 // the single pass decoded the whole quality LINE: it must end where pos5 says
-                if (fused && usual && x4 != qe) atomicMin(&hdr->irr_min, (unsigned long long)(kfirst + r));
+                if (fused && usual && x4 != qe) atomicMin(&hdr->irr_min, (unsigned long long)(kfirst_ch + r));
             }
             if (act && !usual) {
                 int64_t p0 = 0, p1 = 0, p3 = 0, p4 = 0, p5 = 0;
                 int status = ST_COMPLETE;
-                const long long k = kfirst + r;
+                const long long k = kfirst_ch + r;
                 const int have = nl - i;           // list elements from e0 on (e0 included)
                 // list element i+q: an own entry (the sentinel is element 0 of tile 0) or look-ahead
                 auto POS = [&](int q) -> int64_t {
                     const int e = i + q;
                     if (e >= nown) return tbase + (int64_t)(s_la[e - nown] & 0x3FFFFFFFu);
-                    if (pre && e == 0) return (int64_t)0;
+                    if (sent0 && e == 0) return (int64_t)0;
                     return tbase + (int64_t)(s_ent[e] & OFF_MASK);
                 };
                 auto FLG = [&](int q) -> uint32_t {
@@ -516,7 +595,7 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                 // start of the record's bytes in the decoded stream = quality bytes in front of pos4
                 const uint32_t ql = emit ? (uint32_t)(f5 - f4) : 0u;
                 const uint32_t incl = wave_incl_scan(ql);
-                if (emit && kfirst + r < p4_cap) {
+                if (emit && kfirst_ch + r < p4_cap) {
                     // the newline in front of pos4 (the '+' line's end) lies at tile-relative f4 - 1: in this tile, or
                     // in a later one -- whose earlier bytes then all belong to this record: its segment's first line
                     const int32_t x3 = f4 - 1;
@@ -527,11 +606,11 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                         // records in front of this one
                         int32_t head = 0;
                         const int e0 = (int)i0 - pre;            // physical entry of the tile's first record start
-                        if (kfirst > 0 && e0 >= 1)
+                        if (kfirst_ch > 0 && e0 >= 1)
                             head = (int32_t)(s_ent[e0 + pre] & OFF_MASK) - (int32_t)(s_ent[e0 - 1 + pre] & OFF_MASK) - 1;
                         q += head + (long long)(qrun + incl - ql);
                     }
-                    fz_qoff[kfirst + r] = q;
+                    fz_qoff[kfirst_ch + r] = q;
                 }
                 qrun += (uint32_t)__shfl((int)incl, 63);
             } else if (qrel) {
@@ -539,9 +618,9 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
                 // tile's base and writes the caller's 64-bit offsets
                 const uint32_t ql = emit ? (uint32_t)(f5 - f4) : 0u;
                 const uint32_t incl = wave_incl_scan(ql);
-                if (act && kfirst + r < p4_cap) qrel[kfirst + r] = qrun + incl - ql;
+                if (act && kfirst_ch + r < p4_cap) qrel[kfirst_ch + r] = qrun + incl - ql;
                 // pos4 once more, compact: the decode reads 8 bytes per record instead of the row's line
-                if (emit && kfirst + r < p4_cap) p4s[kfirst + r] = tb_add + f4;
+                if (emit && kfirst_ch + r < p4_cap) p4s[kfirst_ch + r] = tb_add + f4;
                 qrun += (uint32_t)__shfl((int)incl, 63);
             }
             int2 *mine = reinterpret_cast<int2 *>(s_rows + lane * 6);
@@ -550,7 +629,7 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
             // rows of one chunk are consecutive in the table: 16-byte pieces, consecutive lanes ->
             // consecutive pieces; a row is written iff its record emits
             const unsigned long long em = __ballot(emit);
-            const int64_t rowbase = kfirst + r0;
+            const int64_t rowbase = kfirst_ch + r0;
             const int2 *srcr = reinterpret_cast<const int2 *>(s_rows);
             longlong2 *dst = reinterpret_cast<longlong2 *>(table + rowbase * 6);
 #pragma unroll
@@ -568,6 +647,8 @@ __global__ __launch_bounds__(256, 8) void k_rows4(LineIndex L, const long long *
             wave_sync();
         }
     }
+    nrec_tile += nrec_ch;
+    }   // chunks
     if (qrel && lane == 0 && nrec_tile > 0) tileq[t] = TileQ{kfirst, nrec_tile, qrun};
 }
 
@@ -681,6 +762,7 @@ __global__ void k_finalize4(LineIndex L, Fast4Hdr *hdr, const TermInfo4 *__restr
     const unsigned long long tm = hdr->term_min, im = hdr->irr_min;
     const unsigned long long tk = tm >> 24;
     res->fused_bad = fz_bad ? (int32_t)*fz_bad : 0;
+    res->fast4_dense = hdr->dense_seen;
     if (!hdr->attempt || tm == ~0ull || (im != ~0ull && im <= tk) || (fz_bad && *fz_bad)) { res->fallback = 1; res->fast4_hint = 0; publish(pb, res); return; }
     res->fallback = 0;
     res->fast4_hint = 1;

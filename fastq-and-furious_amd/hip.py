@@ -38,6 +38,7 @@ F_POLL_RESULT = 8
 F_SINGLE_PASS = 16
 SEG_STRIDE = 8704            # FFQ_F_SINGLE_PASS: bytes of the quality buffer every 16 KiB tile of the input owns (include/ffq.h)
 F_NO_TIMING = 32
+F_FORCE_GENERAL = 64        # tests: skip the four-line fast path
 
 # every symbol include/ffq.h declares (tests check the library exports them all)
 SYMBOLS = (

@@ -66,6 +66,8 @@ extern "C" {
 #define FFQ_F_DECODE_QUAL   1u     /* also emit Phred-decoded qualities (value added = qual_add) */
 #define FFQ_F_FORCE_SERIAL  2u     /* debugging/tests: use the single-wave chain walker */
 #define FFQ_F_FORCE_RANKED  4u     /* debugging/tests: use the list-ranking tier */
+#define FFQ_F_FORCE_GENERAL 64u    /* debugging/tests: skip the four-line fast path (the general chain kernels and, through
+                                      dense regions, the window walker take plain four-line input too)             */
 #define FFQ_F_POLL_RESULT   8u     /* completion is signalled through the result block the last kernel
                                       writes into host-mapped memory (ffq_scan_wait polls a word of it)
                                       instead of through an event recorded behind that kernel: one stream
