@@ -12,6 +12,7 @@ Workloads (BASELINE.json configs):
     decode-10g   10 GiB S-single + quality -> int8 decode     (configs[2]; single pass, segmented output)
     decode-10g-packed  the same with the packed CSR stream of rounds 1-2 (two passes over the input)
     wrapped-10g  10 GiB S-wrapped, 50-300 bp, 80-col wrap     (configs[3])
+    dense-1g     1 GiB of the reference's test template (27-byte records: every index tile dense)
     single-100g  ONE 100 GiB S-single stream cut into N byte ranges (configs[4]; strong scaling:
                  12.5 GiB per GPU at N = 8, all of it on one GPU at N = 1)
 For N > 1 the same per-GPU workload is one byte range of a single logical
@@ -41,6 +42,10 @@ WORKLOADS = {
     # ... and as rounds 1-2 measured it: packed CSR stream, two passes over the input
     "decode-10g-packed": dict(kind="single", bytes=10 * GIB, decode=True),
     "wrapped-10g": dict(kind="wrapped", bytes=10 * GIB, decode=False),
+    # the reference's own test template repeated (/root/reference/tests.py:8-35: 27-byte records, 6.75 bytes per line):
+    # every index tile is DENSE (over its slot); 75 B of SURVEY 8(d) traffic per record, 48 of them the row
+    "dense-1g": dict(kind="dense", bytes=1 * GIB, decode=False),
+    "dense-64m": dict(kind="dense", bytes=64 << 20, decode=False),
     # small variants for quick checks
     "single-64m": dict(kind="single", bytes=64 << 20, decode=False),
     "wrapped-64m": dict(kind="wrapped", bytes=64 << 20, decode=False),
@@ -603,7 +608,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
             "config": {
                 "workload": name,
                 "description": "%s synthetic FASTQ, %d bytes/GPU, %d records/GPU%s"
-                               % ("S-single 150 bp" if wl["kind"] == "single" else "S-wrapped 50-300 bp",
+                               % ("S-single 150 bp" if wl["kind"] == "single" else
+                                  "tests.py template x n (27-byte records, every tile dense)" if wl["kind"] == "dense" else "S-wrapped 50-300 bp",
                                   n_own, n_rec, "" if not decode else
                                   (", quality->int8 decode, segmented output (record i = qual[qoff[i] : qoff[i] + pos5 - pos4]), one pass"
                                    if out.res.path == 6 else ", quality->int8 decode, packed CSR stream, two passes")),
@@ -743,7 +749,7 @@ def main():
         del shard
         torch.cuda.empty_cache()
         others = {}
-        names = ("decode-10g", "decode-10g-packed", "wrapped-10g", "single-100g") if world == 1 else ("single-100g",)
+        names = ("decode-10g", "decode-10g-packed", "wrapped-10g", "dense-1g", "single-100g") if world == 1 else ("single-100g",)
         if os.environ.get("FFQ_BENCH_DRY_MULTI") == "1":
             names = ("single-4g-split",)             # (the dry run shares ONE GPU between the ranks)
         for other in names:

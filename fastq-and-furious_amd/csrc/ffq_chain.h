@@ -81,7 +81,7 @@ struct ChainBufs {
     GroupTerm *term;     // [ng] scanner status/posbuffer where the chain stops (only if it does)
     StageRec *stage;     // [ng][nmax]
     // groups that are WALKED (k_dense_walk: dense tiles, ffq_dense.h) hold up to DCHUNK records: each takes a chunk of a
-    // second stage the first time it is walked (sbase[g] = its chunk, -1: the group's records are in `stage`)
+    // second stage the first time it is walked (sbase[g] = its chunk + 1, 0: the group's records are in `stage`)
     int32_t *sbase;      // [ng]
     StageRec *dstage;    // [dchunks][DCHUNK]
     uint32_t *dhead;     // chunks handed out (and asked for: may exceed dchunks -> ERR_DSTAGE, the host grows the stage)
@@ -125,10 +125,21 @@ __device__ __forceinline__ void publish(const Pub &pb, const DevRes *res)
 {
     if (!pb.h_res) return;
     *pb.h_res = *res;
+    unsigned long long need = 0;
+    if (pb.ctl->pool_any) {
+        // (dense tiles only: 16 loads in flight at a time)
+        for (int b0 = 0; b0 < POOL_NB; b0 += 16) {
+            unsigned long long v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = pb.ctl->pool_heads[b0 + i];
+#pragma unroll
+            for (int i = 0; i < 16; i++) { need = max(need, v[i]); pb.ctl->pool_heads[b0 + i] = 0; }
+        }
+        pb.ctl->pool_any = 0;
+    }
     pb.h_ctl->err = pb.ctl->err;
-    pb.h_ctl->pool_head = pb.ctl->pool_head;
+    pb.h_ctl->pool_head = need * POOL_NB;
     pb.ctl->err = 0;
-    pb.ctl->pool_head = 0;
     // last, and after everything above has left for host memory
     if (pb.h_seq) __hip_atomic_store(pb.h_seq, pb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1133,7 +1144,7 @@ __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__rest
     const int own0 = g * OWN_T;
     const int64_t base = ((int64_t)((own0 > 0) ? own0 - 1 : 0) << TILE_SHIFT) + add;
     const int32_t sb = B.sbase[g];
-    const StageRec *st = sb < 0 ? B.stage + (int64_t)g * B.nmax : B.dstage + (int64_t)sb * DCHUNK;
+    const StageRec *st = sb <= 0 ? B.stage + (int64_t)g * B.nmax : B.dstage + (int64_t)(sb - 1) * DCHUNK;
     for (uint32_t d0 = 0; d0 < cnt; d0 += 64) {
         const uint32_t dd = d0 + lane;
         const bool ok = dd < cnt;

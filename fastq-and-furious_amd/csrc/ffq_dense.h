@@ -102,13 +102,13 @@ __global__ __launch_bounds__(256) void k_dense_walk(LineIndex L, ChainBufs B, in
     const int64_t wpos0 = (int64_t)(own0 > 0 ? own0 - 1 : 0) << TILE_SHIFT;
     const int64_t len = L.len();
     // the group's chunk of the walked groups' stage
-    int sb = B.sbase[g];
+    int sb = B.sbase[g] - 1;
     if (sb < 0) {
         uint32_t got = 0;
         if (lane == 0) got = atomicAdd(B.dhead, 1u);
         sb = (int)__shfl((int)got, 0);
         if (sb >= B.dchunks) { if (lane == 0) atomicOr(&ctl->err, ERR_DSTAGE); return; }
-        if (lane == 0) B.sbase[g] = sb;
+        if (lane == 0) B.sbase[g] = sb + 1;
     }
     StageRec *stg = B.dstage + (int64_t)sb * DCHUNK;
 

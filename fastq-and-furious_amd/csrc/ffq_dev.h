@@ -48,10 +48,15 @@ constexpr uint32_t ERR_DSTAGE = 4u;     // the walked groups' stage ran out of c
 // on that word alone
 constexpr unsigned long long OVF_MASK = (1ull << 62) - 1ull;
 
+// The overflow pool is cut into POOL_NB equal regions, tile t allocates in region t % POOL_NB: one bump counter
+// for all dense tiles was 65536 agent-scope atomics per GiB of dense input on ONE address, served one after the other.
+constexpr int POOL_NB = 64;
+
 struct Ctl {
     uint32_t err;
-    uint32_t pad;
-    unsigned long long pool_head;
+    uint32_t pool_any;             // a dense tile allocated in this scan: the publisher gathers and zeroes pool_heads
+    unsigned long long pool_head;  // host mirror only: entries the pool must hold for this scan (POOL_NB x the fullest region)
+    unsigned long long pool_heads[POOL_NB];
 };
 
 struct LineIndex {

@@ -243,16 +243,16 @@ static void free_chain(ffq_ctx *c)
     (void)hipFree(c->cb.y); (void)hipFree(c->cb.exit); (void)hipFree(c->cb.cnt); (void)hipFree(c->cb.flags);
     (void)hipFree(c->cb.lines); (void)hipFree(c->cb.qb); (void)hipFree(c->cb.term); (void)hipFree(c->cb.stage);
     (void)hipFree(c->cb.rloc); (void)hipFree(c->cb.qloc); (void)hipFree(c->cb.part); (void)hipFree(c->cb.mins);
-    (void)hipFree(c->cb.force); (void)hipFree(c->cb.sbase);
+    (void)hipFree(c->cb.force);
     (void)hipFree(c->sbbase); (void)hipFree(c->tinfo4);
     (void)hipFree(c->tileq); (void)hipFree(c->sbq); (void)hipFree(c->sbqbase);
     c->sbbase = nullptr; c->tinfo4 = nullptr;
     c->tileq = nullptr; c->sbq = nullptr; c->sbqbase = nullptr;
     {
         // (the walked groups' stage does not depend on the tile count: it stays)
-        StageRec *ds = c->cb.dstage; uint32_t *dh = c->cb.dhead; const int32_t dc = c->cb.dchunks;
+        StageRec *ds = c->cb.dstage; const int32_t dc = c->cb.dchunks;
         c->cb = ChainBufs{};
-        c->cb.dstage = ds; c->cb.dhead = dh; c->cb.dchunks = dc;
+        c->cb.dstage = ds; c->cb.dchunks = dc;
     }
     c->stage_cap = 0;
     c->cap_groups = 0;
@@ -278,7 +278,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->rk.S[0]); (void)hipFree(c->rk.S[1]); (void)hipFree(c->rk.C[0]); (void)hipFree(c->rk.C[1]);
     (void)hipFree(c->rk.D); (void)hipFree(c->rk.root);
     free_chain(c);
-    (void)hipFree(c->cb.dstage); (void)hipFree(c->cb.dhead);
+    (void)hipFree(c->cb.dstage);
     (void)hipFree(c->fz_qphase); (void)hipFree(c->fz_bad);
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
@@ -334,7 +334,7 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
     HIPCHK(hipMalloc((void **)&c->cb.y, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.exit, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.cnt, (size_t)ng * 4));
-    HIPCHK(hipMalloc((void **)&c->cb.flags, (size_t)ng * 4));
+    HIPCHK(hipMalloc((void **)&c->cb.flags, (size_t)(2 * ng + 4) * 4));      // (flags | sbase | dhead: one fill per scan, chain_bufs)
     HIPCHK(hipMalloc((void **)&c->cb.lines, (size_t)ng * 4));
     HIPCHK(hipMalloc((void **)&c->cb.qb, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.term, (size_t)ng * sizeof(GroupTerm)));
@@ -343,7 +343,6 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
     HIPCHK(hipMalloc((void **)&c->cb.part, (size_t)nblk * 4 * 8));
     HIPCHK(hipMalloc((void **)&c->cb.mins, 16));
     HIPCHK(hipMalloc((void **)&c->cb.force, (size_t)ng * 8));
-    HIPCHK(hipMalloc((void **)&c->cb.sbase, (size_t)ng * 4));
     {
         const int64_t nsb = (ntiles + SB_TILES - 1) / SB_TILES;
         HIPCHK(hipMalloc((void **)&c->sbbase, (size_t)nsb * sizeof(long long)));
@@ -361,7 +360,6 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
 // the walked groups' stage (k_dense_walk): `chunks` chunks of DCHUNK records
 static int reserve_dstage(ffq_ctx *c, int64_t chunks)
 {
-    if (!c->cb.dhead) HIPCHK(hipMalloc((void **)&c->cb.dhead, 16));
     if (chunks <= c->dstage_chunks) return FFQ_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(c->cb.dstage);
@@ -421,6 +419,9 @@ static int reserve_p4s(ffq_ctx *c, int64_t entries)
     return FFQ_OK;
 }
 
+// the smallest pool: every region holds one full tile of newlines
+constexpr unsigned long long POOL_MIN = (unsigned long long)POOL_NB * TILE;
+
 static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 {
     if (entries <= c->pool_cap) return FFQ_OK;
@@ -446,7 +447,7 @@ extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
     if (rc) return rc;
     rc = reserve_stage(c, groups_for(nt), NMAX_FAST);
     if (rc) return rc;
-    return reserve_pool(c, 1ull << 20);
+    return reserve_pool(c, POOL_MIN);
 }
 
 // ---- memory plumbing -----------------------------------------------------
@@ -640,14 +641,24 @@ static int enqueue_resolve(ffq_ctx *c, const ScanArgs &a, const ChainBufs &cb, b
     return FFQ_OK;
 }
 
+// the chain scratch of a scan of `ngroups` groups: the walked groups' chunk numbers and the chunk counter lie right behind the
+// group flags (one fill zeroes all three at the start of the chain stage; sbase: chunk + 1, 0 = none)
+static ChainBufs chain_bufs(ffq_ctx *c, int ngroups, int nmax)
+{
+    ChainBufs cb = c->cb;
+    cb.ng = ngroups;
+    cb.nmax = nmax;
+    cb.prof = nullptr;
+    cb.sbase = reinterpret_cast<int32_t *>(cb.flags + ngroups);
+    cb.dhead = cb.flags + 2 * (size_t)ngroups;
+    return cb;
+}
+
 // repair pass: the groups whose entry guess the verification rejected are re-run from their
 // predecessor's exit (k_repair_mark), then everything is verified again
 static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bool dense_cfg, int ngroups)
 {
-    ChainBufs cb = c->cb;
-    cb.ng = ngroups;
-    cb.nmax = dense_cfg ? NMAX_DENSE : NMAX_FAST;
-    cb.prof = nullptr;
+    ChainBufs cb = chain_bufs(c, ngroups, dense_cfg ? NMAX_DENSE : NMAX_FAST);
     hipStream_t sA = c->stream;
     hipLaunchKernelGGL(k_repair_mark, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, sA, cb);
     if (!dense_cfg)
@@ -672,10 +683,7 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     if (rc) return rc;
     rc = reserve_dstage(c, 64);             // (8 MiB to start with; a scan that walks more groups asks for more: ERR_DSTAGE)
     if (rc) return rc;
-    ChainBufs cb = c->cb;
-    cb.ng = ngroups;
-    cb.nmax = nmax;
-    cb.prof = nullptr;
+    ChainBufs cb = chain_bufs(c, ngroups, nmax);
     hipStream_t sA = c->stream;
     const char *abl = PROBES ? getenv("FFQ_ABLATE") : nullptr;
     const int ablate = abl ? atoi(abl) : 0;
@@ -684,9 +692,7 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
         HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sA));
         cb.prof = c->prof_d;
     }
-    HIPCHK(hipMemsetAsync(cb.flags, 0, (size_t)ngroups * 4, sA));
-    HIPCHK(hipMemsetAsync(cb.sbase, 0xFF, (size_t)ngroups * 4, sA));      // no group has a chunk of the walked groups' stage yet
-    HIPCHK(hipMemsetAsync(cb.dhead, 0, 4, sA));
+    HIPCHK(hipMemsetAsync(cb.flags, 0, (2 * (size_t)ngroups + 1) * 4, sA));      // flags, and: no group has a chunk of the walked groups' stage yet
     if (!dense_cfg)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
                            dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
@@ -968,7 +974,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         if (c->h_ctl->err & ERR_POOL) {
             // dense tiles did not fit the overflow pool: size it for what was asked and re-run
             if (st.retries >= 2) return fail(FFQ_E_INTERNAL, "line-index pool overflow persists");
-            int rc = reserve_pool(c, std::max<unsigned long long>(c->h_ctl->pool_head, 1ull << 20));
+            int rc = reserve_pool(c, std::max<unsigned long long>(c->h_ctl->pool_head + (c->h_ctl->pool_head >> 4), POOL_MIN));
             if (rc) return rc;
             st.retries++;
             st.index_done = false;
@@ -981,7 +987,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             if (!(c->h_ctl->err & ERR_DSTAGE)) return 0;
             if (st.retries >= 4) return fail(FFQ_E_INTERNAL, "the walked groups' stage stays too small");
             uint32_t asked = 0;
-            HIPCHK(hipMemcpy(&asked, c->cb.dhead, sizeof asked, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&asked, c->cb.flags + 2 * (size_t)st.ngroups, sizeof asked, hipMemcpyDeviceToHost));
             int rc = reserve_dstage(c, std::max<int64_t>((int64_t)asked + (asked >> 3) + 8, 2 * c->dstage_chunks));
             if (rc) return rc;
             st.retries++;
@@ -1232,7 +1238,7 @@ extern "C" int ffq_scan_submit(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
     if (st.ntiles == 0) return FFQ_OK;                   // nothing to enqueue: ffq_scan_wait fills the result
     if (st.ntiles > 0x7FFFFFF0) { st.active = false; return fail(FFQ_E_ARG, "buffer too large"); }
     int rc = reserve_tiles(c, st.ntiles);
-    if (!rc) rc = reserve_pool(c, 1ull << 20);
+    if (!rc) rc = reserve_pool(c, POOL_MIN);
     if (!rc && (flags & FFQ_F_DECODE_QUAL)) rc = reserve_qdir(c, qdir_blocks(n_bytes, qual_cap));
     if (!rc && (flags & FFQ_F_DECODE_QUAL)) rc = reserve_p4s(c, p4s_need(n_bytes, table_cap));
     if (!rc) {
@@ -1468,7 +1474,7 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
     }
     if (ntiles > 0x7FFFFFF0) return fail(FFQ_E_ARG, "buffer too large");
     int rc = reserve_tiles(c, ntiles);
-    if (!rc) rc = reserve_pool(c, 1ull << 20);
+    if (!rc) rc = reserve_pool(c, POOL_MIN);
     if (!rc) rc = grow_dev(c, &c->sel_cnt, &c->sel_cnt_cap, ntiles);
     if (!rc) rc = grow_dev(c, &c->sel_base, &c->sel_base_cap, ntiles);
     if (rc) return rc;
@@ -1498,7 +1504,7 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
         HIPCHK(hipEventSynchronize(c->ev[3]));
         if (c->h_ctl->err & ERR_POOL) {
             if (attempt >= 2) return fail(FFQ_E_INTERNAL, "line-index pool overflow persists");
-            rc = reserve_pool(c, std::max<unsigned long long>(c->h_ctl->pool_head, 1ull << 20));
+            rc = reserve_pool(c, std::max<unsigned long long>(c->h_ctl->pool_head + (c->h_ctl->pool_head >> 4), POOL_MIN));
             if (rc) return rc;
             continue;
         }
@@ -1726,7 +1732,7 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         // the index kernel alone, back to back: its steady-state time without the rest of a step
         int rc = reserve_tiles(c, ntiles);
         if (rc) return rc;
-        rc = reserve_pool(c, 1ull << 20);
+        rc = reserve_pool(c, POOL_MIN);
         if (rc) return rc;
     }
     const LineIndex L = make_index(c, a, ntiles);
@@ -1734,7 +1740,7 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         // the persistent streaming loop with a lagged two-level prefix (k_pipe_probe): lag = mode - 200
         int rc = reserve_tiles(c, ntiles);
         if (rc) return rc;
-        rc = reserve_pool(c, 1ull << 20);
+        rc = reserve_pool(c, POOL_MIN);
         if (rc) return rc;
         const bool big = mode >= 210;                  // 72 KiB of LDS per workgroup, two per CU
         const int G = big ? 512 : 1024, lag = big ? mode - 210 : mode - 200;
@@ -1785,7 +1791,7 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         // what a single-pass design would pay for its prefix sums on this part)
         int rc = reserve_tiles(c, ntiles);
         if (rc) return rc;
-        rc = reserve_pool(c, 1ull << 20);
+        rc = reserve_pool(c, POOL_MIN);
         if (rc) return rc;
         float sum = 0;
         for (int r = 0; r < reps + 2; r++) {
@@ -1830,7 +1836,7 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
         // mode 2's kernel, every launch between its own pair of events (as a scan times it)
         int rc = reserve_tiles(c, ntiles);
         if (rc) return rc;
-        rc = reserve_pool(c, 1ull << 20);
+        rc = reserve_pool(c, POOL_MIN);
         if (rc) return rc;
         float sum = 0;
         for (int r = 0; r < reps + 2; r++) {

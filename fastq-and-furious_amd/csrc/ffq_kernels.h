@@ -74,7 +74,7 @@ struct ScanLds {
 // tile, offsets in sm.list or -- dense tile -- in the pool), the AT / PLUS flags looked up on the way.
 __device__ __forceinline__ void scan_tile_store(ScanLds &sm, const int tile, const uint32_t wbase, const uint32_t wtot,
                                                 const uint32_t total, const bool dense, const unsigned long long pbase,
-                                                const bool pool_ok, const uint32_t nxt,
+                                                const bool pool_ok, const uint32_t dense_any, const uint32_t nxt,
                                                 uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
                                                 unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
                                                 int ablate, uint32_t at_char)
@@ -104,20 +104,11 @@ __device__ __forceinline__ void scan_tile_store(ScanLds &sm, const int tile, con
             else asm volatile("global_store_short %0, %1, %2 nt" : : "v"((wbase + j) * 2u), "v"(e), "s"(gdst) : "memory");
         }
     } else {
-        uint32_t any = 0;
-        if (pool_ok) {
-            uint16_t *gdst = pool + pbase;
-            for (uint32_t j = (uint32_t)l; j < wtot; j += 64) {
-                const uint32_t off = (uint32_t)gdst[wbase + j];
-                const uint32_t fl = entry_flags(s_data, off & OFF_MASK, nxt, at_char);
-                any |= fl;
-                gdst[wbase + j] = (uint16_t)(off | (fl << 14));
-            }
-        }
+        // (a dense tile's entries went to the pool with their flags, straight from the compaction loop: dense_any)
         // ovf[tile] (read only for tiles with cnt > SLOT): the pool offset, and whether any entry of the tile is
         // flagged at all (sm.dfl was zeroed in front of the barrier of the pool allocation)
-        const uint32_t wany = (__ballot(any & (uint32_t)FL_AT) ? (uint32_t)FL_AT : 0u) |
-                              (__ballot(any & (uint32_t)FL_PLUS) ? (uint32_t)FL_PLUS : 0u);
+        const uint32_t wany = (__ballot(dense_any & (uint32_t)FL_AT) ? (uint32_t)FL_AT : 0u) |
+                              (__ballot(dense_any & (uint32_t)FL_PLUS) ? (uint32_t)FL_PLUS : 0u);
         if (l == 0 && wany) atomicOr(&sm.dfl, wany);
         __syncthreads();
         if (tid == 0) ovf[tile] = pbase | ((unsigned long long)sm.dfl << 62);
@@ -256,10 +247,16 @@ __device__ __forceinline__ void scan_tile_rest(ScanLds &sm, const int tile, cons
     const bool dense = total > (uint32_t)SLOT;
     if (dense) {   // rare: avg line shorter than 16 bytes over the whole tile
         if (tid == 0) {
-            const unsigned long long at = atomicAdd(&ctl->pool_head, (unsigned long long)total);
-            s_ovf = at;
+            // region tile % POOL_NB of the pool, a bump counter per region (ffq_dev.h, Ctl)
+            const unsigned long long region = pool_cap / POOL_NB;
+            const int b = tile & (POOL_NB - 1);
+            const unsigned long long at = atomicAdd(&ctl->pool_heads[b], (unsigned long long)total);
+            const bool fits = at + total <= region;
+            // (what does not fit gets an offset past the pool: nothing of it is stored or read)
+            s_ovf = fits ? (unsigned long long)b * region + at : pool_cap;
             sm.dfl = 0u;
-            if (at + total > pool_cap) atomicOr(&ctl->err, ERR_POOL);
+            ctl->pool_any = 1u;
+            if (!fits) atomicOr(&ctl->err, ERR_POOL);
         }
         __syncthreads();
     }
@@ -269,6 +266,7 @@ __device__ __forceinline__ void scan_tile_rest(ScanLds &sm, const int tile, cons
     // newline offsets in position order (no flags yet); this wave's entries are ranks
     // [wbase, wbase + wtot) of the tile
     uint32_t rb = wbase;
+    uint32_t dense_any = 0;         // dense tile: OR of the flags of this lane's entries
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         uint32_t mm = m[i];
@@ -277,12 +275,18 @@ __device__ __forceinline__ void scan_tile_rest(ScanLds &sm, const int tile, cons
             const uint32_t p = (uint32_t)__ffs((int)mm) - 1u;
             mm &= mm - 1u;
             if (!dense) s_list[idx] = (uint16_t)(o[i] + p);
-            else if (pool_ok) pool[pbase + idx] = (uint16_t)(o[i] + p);
+            else if (pool_ok) {
+                // (every wave's bytes are parked: the barrier behind the wave totals.  The entry goes out whole, one
+                // store -- until round 3 the flags were added by a second pass that read every pooled entry back)
+                const uint32_t fl = entry_flags(sm.data, o[i] + p, nxt, at_char);
+                dense_any |= fl;
+                pool[pbase + idx] = (uint16_t)((o[i] + p) | (fl << 14));
+            }
             idx++;
         }
         rb += rowtot[i];
     }
-    scan_tile_store(sm, tile, wbase, wtot, total, dense, pbase, pool_ok, nxt, ent, cnt, ovf, pool, ablate, at_char);
+    scan_tile_store(sm, tile, wbase, wtot, total, dense, pbase, pool_ok, dense_any, nxt, ent, cnt, ovf, pool, ablate, at_char);
 }
 
 template <bool FULL>

@@ -496,6 +496,9 @@ class ShardScanner:
         return out
 
 
+DENSE_TEMPLATE = b"@foo#2\nAATTGCCG\n+\n3425@!#!\n"      # /root/reference/tests.py:8-35, single-line variant: 27 bytes
+
+
 class SyntheticShard:
     """bench.py's input: this rank's byte range of a synthetic stream, built in
     HBM.  The logical stream is world * n_per records of S-single / S-wrapped
@@ -517,7 +520,16 @@ class SyntheticShard:
                 transport = SoloTransport()
         self.transport = transport
         first_rec = None
-        if kind == "single":
+        self.rec_bytes, self.rec_cols = synth.RECORD_BYTES, (0, 17, 18, 168, 171, 321)
+        if kind == "dense":
+            # the reference's own test template repeated (/root/reference/tests.py:8-35: '@foo#2', 8 bases, '+', 8
+            # qualities): 27 bytes per record, 6.75 per line -- every index tile over its slot.  One range only.
+            assert world == 1, "the dense workload is a single range"
+            self.rec_bytes, self.rec_cols = len(DENSE_TEMPLATE), (0, 6, 7, 15, 18, 26)
+            per = [bytes_per_gpu // self.rec_bytes]
+            n_per, first_rec, starts = per[0], 0, None
+            blk_bytes = [per[0] * self.rec_bytes]
+        elif kind == "single":
             if total_records is not None:
                 per = [total_records // world + (1 if r < total_records % world else 0) for r in range(world)]
             else:
@@ -552,14 +564,18 @@ class SyntheticShard:
         n_gen = n_per + (1 if rank < world - 1 else 0)
         a = self.own_lo - self.block_start              # the range starts `a` bytes into its first generated record
         assert 0 <= a <= self.tail or (a == 0 and self.tail == 0)
-        if kind == "single":
-            gen_bytes = n_gen * synth.RECORD_BYTES
+        if kind in ("single", "dense"):
+            gen_bytes = n_gen * self.rec_bytes
         else:
             gen_bytes = int(starts[n_gen])
         room = max(self.tail + self.n_own_bytes + self.head, self.tail - a + gen_bytes) + 64
         self.ext = torch.empty(room, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        if kind == "single":
+        if kind == "dense":
+            tpl = torch.tensor(list(DENSE_TEMPLATE), dtype=torch.uint8, device=dev)
+            self.ext[:gen_bytes] = tpl.repeat(n_gen)
+            del tpl
+        elif kind == "single":
             ctx.synth_single(self.ext.data_ptr() + self.tail - a, first_rec, n_gen, seed=42)
         else:
             dstart = torch.from_numpy(starts[:n_gen + 1].copy()).to(dev)
@@ -570,7 +586,7 @@ class SyntheticShard:
         self.ext[self.tail + self.n_own_bytes:].zero_()
         torch.cuda.synchronize()
         self.ext_scanned_bytes = self.tail + self.n_own_bytes + self.head
-        min_rec = 322 if kind == "single" else 120
+        min_rec = self.rec_bytes if kind in ("single", "dense") else 120
         self.max_records = n_per + (self.tail + self.head) // min_rec + 64
         self.scanner = ShardScanner(HipBackend(ctx), transport, S)
         self._lanes = None
@@ -617,8 +633,8 @@ class SyntheticShard:
         if self.rank > 0:
             skip = 322 - (self.own_lo - self.block_start)   # only used on rank 0 in practice
         n = min(nbytes, self.n_own_bytes - skip)
-        if self.kind == "single":
-            n = n // 322 * 322
+        if self.kind in ("single", "dense"):
+            n = n // self.rec_bytes * self.rec_bytes
         else:
             k = int(np.searchsorted(self.starts, n, side="right")) - 1
             n = int(self.starts[k])
@@ -632,13 +648,14 @@ class SyntheticShard:
         rows = table[out.row_lo:out.row_hi]
         n = rows.shape[0]
         # ownership is by '@' position: the first owned record is the first whose start >= own_lo
-        if self.kind == "single":
-            k0 = -(-self.own_lo // 322)
-            assert n == -(-self.own_hi // 322) - k0, "record count differs from the closed form"
-            col = torch.tensor([0, 17, 18, 168, 171, 321], dtype=torch.int64, device=rows.device)
+        if self.kind in ("single", "dense"):
+            rb = self.rec_bytes
+            k0 = -(-self.own_lo // rb)
+            assert n == -(-self.own_hi // rb) - k0, "record count differs from the closed form"
+            col = torch.tensor(list(self.rec_cols), dtype=torch.int64, device=rows.device)
             for c0 in range(0, n, 1 << 24):            # (in pieces: at 100 GiB the table is 16 GB)
                 c1 = min(n, c0 + (1 << 24))
-                k = torch.arange(k0 + c0, k0 + c1, dtype=torch.int64, device=rows.device) * 322
+                k = torch.arange(k0 + c0, k0 + c1, dtype=torch.int64, device=rows.device) * rb
                 assert bool((rows[c0:c1] == k[:, None] + col[None, :]).all()), "offset table differs from the closed form"
         else:
             st = torch.from_numpy(self.starts).to(rows.device) + self.block_start
@@ -683,9 +700,10 @@ class SyntheticShard:
         p4 = table[idx, 4] - shift
         ln = lens[idx]
         q0 = qoff[idx]
-        if self.kind == "single":
-            assert bool((ln == 150).all())
-            ar = torch.arange(150, device=table.device)
+        if self.kind in ("single", "dense"):
+            ql = self.rec_cols[5] - self.rec_cols[4]
+            assert bool((ln == ql).all())
+            ar = torch.arange(ql, device=table.device)
             src = self.ext[(p4[:, None] + ar[None, :]).reshape(-1)].to(torch.int16) - 33
             got = qual[(q0[:, None] + ar[None, :]).reshape(-1)].to(torch.int16)
             assert bool((src == got).all()), "decoded qualities differ from the buffer's bytes - 33"

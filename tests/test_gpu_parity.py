@@ -845,6 +845,68 @@ def test_reference_template_shape_dense(hipmod, oracle, general):
         assert res.path != 1, (kw, res.path)
 
 
+def dense_mess(rng, target=400000, hostile=True):
+    """~target bytes: blocks of tiny records (1-12 bases, headers of 0-5 characters), blank lines, tiny wrapped
+    records, regular records; optionally random single-byte edits."""
+    qh = np.frombuffer(b"@+@+II5#\n" if hostile else b"IIII5#?", dtype=np.uint8)
+    parts, size, i = [], 0, 0
+    while size < target:
+        u = rng.random()
+        if u < 0.55:                                        # a block of tiny four-line records
+            blk = []
+            for _ in range(int(rng.integers(50, 4000))):
+                L = int(rng.integers(1, 13))
+                h = (b"%d" % i)[:int(rng.integers(0, 6))]
+                q = rng.choice(qh[qh != 10], size=L).tobytes()
+                blk.append(b"@" + h + b"\n" + b"ACGTN"[i % 5:i % 5 + 1] * L + b"\n+\n" + q + b"\n")
+                i += 1
+            p = b"".join(blk)
+        elif u < 0.70:                                      # blank lines
+            p = b"\n" * int(rng.integers(1, 40000))
+        elif u < 0.80:                                      # tiny records wrapped at 2-4 columns
+            blk = []
+            for _ in range(int(rng.integers(20, 800))):
+                L = int(rng.integers(3, 20)); w = int(rng.integers(2, 5))
+                s = b"A" * L; q = rng.choice(qh[qh != 10], size=L).tobytes()
+                f = lambda a: b"\n".join(a[k:k + w] for k in range(0, L, w))
+                blk.append(b"@w%d\n" % i + f(s) + b"\n+\n" + f(q) + b"\n")
+                i += 1
+            p = b"".join(blk)
+        else:                                               # regular records
+            blk = []
+            for _ in range(int(rng.integers(20, 600))):
+                L = int(rng.integers(100, 300))
+                q = rng.choice(np.frombuffer(bytes(range(35, 74)), dtype=np.uint8), size=L).tobytes()
+                blk.append(b"@reg%d\n" % i + b"C" * L + b"\n+\n" + q + b"\n")
+                i += 1
+            p = b"".join(blk)
+        parts.append(p); size += len(p)
+    a = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+    if hostile:
+        for _ in range(int(rng.integers(0, 12))):
+            a[int(rng.integers(0, a.size))] = int(rng.choice(np.frombuffer(b"\n@+A", dtype=np.uint8)))
+    return a.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_differential_dense_mess(hipmod, oracle, seed):
+    """Seeded differential test of the dense tiers against the oracle (tools/stress_dense.py is the long run of the
+    same): fast path where it stands, general path forced, not at eof, from an offset."""
+    rng = np.random.default_rng(77000 + seed)
+    data = dense_mess(rng, int(rng.integers(100000, 900000)), hostile=(seed % 3 != 0))
+    if seed % 2:
+        data = data[:-int(rng.integers(1, 40))]
+    ctx = hipmod.Context(0)
+    for kw, fl in ((dict(), 0), (dict(), hipmod.F_FORCE_GENERAL), (dict(eof=False), 0),
+                   (dict(offset=len(data) // 3), hipmod.F_FORCE_GENERAL)):
+        want, end, status, off = oracle.scan(data, **kw)
+        table, res, qual, qoff = ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL | fl, table_cap=len(want) + 8, **kw)
+        assert int(res.end_state) == end and int(res.last_status) == status and int(res.end_offset) == off, (kw, fl)
+        assert table.shape == want.shape and (table == want).all(), (kw, fl)
+        wq, wqoff = oracle.decode_quals(data, want)
+        assert (qoff == wqoff).all() and (qual == wq).all(), (kw, fl)
+
+
 def test_dense_patch_in_regular_input(hipmod, oracle):
     """100 KB of 10-base reads + blank lines inside regular 150-base records, and blank lines at the very end
     (tools/cliffs.py at test size): the usual configuration of the general path with the dense groups walked."""
