@@ -429,7 +429,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
         def submit(i):
             k = i & 1
             ctxs[k].scan_submit(shard.ext.data_ptr(), shard.n_own_bytes, tables[k].data_ptr(), tables[k].shape[0],
-                                sentinel=True, eof=True, flags=flags | (hip.F_NO_TIMING if (i % te) else 0),
+                                sentinel=True, eof=True, flags=flags | (hip.F_NO_TIMING if (i % te) else 0),      # (te: read at call time)
                                 d_qual=quals[k].data_ptr() if decode else None,
                                 qual_cap=quals[k].numel() if decode else 0,
                                 d_qoff=qoffs[k].data_ptr() if decode else None)
@@ -526,6 +526,20 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     # this step's last kernel with no idle gap, and host-side waits are hidden.)
     span_ms = []
     if world == 1 and not args.sharded_step and not args.lanes_step:
+        # ... and the figures `roofline` is computed from: MARKED more steps after the timed region, pipelined as the
+        # timed ones but with the two HIP-event marks around the dominant kernel on EVERY step (the timed region itself
+        # carries them on every --time-every-th step only: a mark is a few microseconds of idle GPU)
+        if te > 1:
+            ms_index.clear()
+            te_keep, te = te, 1
+            n_marked = max(20, args.steps)
+            submit(0)
+            for i in range(1, n_marked):
+                submit(i)
+                o2 = wait(i - 1)
+                ms_index.append(o2.res.ms_index)
+            ms_index.append(wait(n_marked - 1).res.ms_index)
+            te = te_keep
         for _ in range(5):
             ctxs[0].scan_submit(shard.ext.data_ptr(), shard.n_own_bytes, tables[0].data_ptr(), tables[0].shape[0],
                                 sentinel=True, eof=True, flags=flags & ~hip.F_POLL_RESULT,
@@ -617,7 +631,9 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 "records_per_gpu": n_rec,
                 "total_bytes": total_bytes,
                 "total_records": total_records,
-                "sharding": "byte ranges, RCCL halo hand-off" if world > 1 else "single range",
+                "sharding": ("byte ranges, halo hand-off over %s" % ("RCCL (torch.distributed backend nccl)" if dist.get_backend() == "nccl"
+                                                                     else "%s: a functional dry run, every rank on ONE GPU" % dist.get_backend())
+                             if world > 1 else "single range"),
             },
             "roofline": {
                 "bound": "hbm",

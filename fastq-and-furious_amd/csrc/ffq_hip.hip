@@ -69,8 +69,23 @@ struct ScanState {
     int ngroups = 0;
 };
 
+// What the library knows about the tail of a scan stream (kept in the context that owns the stream; contexts that share it
+// point there).  FFQ_F_NO_TIMING lets a front start its index kernel without a barrier in front -- beside the previous scan's
+// last, one-workgroup kernel -- and the library does that only when IT can vouch for the order not mattering: the last thing
+// enqueued on the stream is the front of another scan (nothing else -- no copy, no wait for an event, no other kernel -- has gone
+// onto the stream since, and the stream's handle was never given out), and none of that scan's outputs overlaps the bytes this
+// one reads.
+struct StreamTail {
+    bool is_scan = false;                // the last operation enqueued on the stream is the end of a scan front
+    bool exposed = false;                // ffq_ctx_stream() handed the stream out: others may enqueue on it unseen
+    const void *out_p[3] = {nullptr, nullptr, nullptr};      // that scan's outputs (table, qualities, quality offsets)
+    size_t out_n[3] = {0, 0, 0};
+};
+
 struct ffq_ctx {
     ScanState pend;                      // the scan enqueued by ffq_scan_submit, if any
+    ffq_ctx *owner = nullptr;            // the context whose stream this one uses (itself unless created shared)
+    StreamTail tail;                     // (in the owner)
     bool owns_streams = true;            // false: streams borrowed from another context
     int device = 0;
     hipStream_t stream = nullptr;
@@ -204,6 +219,7 @@ static int ctx_create_impl(int device, ffq_ctx *share, ffq_ctx **out)
     if (!c) return fail(FFQ_E_NOMEM, "out of host memory");
     c->device = device;
     hipError_t e = hipSuccess;
+    c->owner = share ? share->owner : c;
     if (share) {
         // same streams as `share`: scans of the two contexts execute in submission order
         c->stream = share->stream; c->owns_streams = false;
@@ -298,7 +314,16 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     delete c;
 }
 
-extern "C" void *ffq_ctx_stream(ffq_ctx *c) { return c ? (void *)c->stream : nullptr; }
+// something other than a scan front goes onto the context's stream (every entry point that enqueues there says so)
+static inline void mark_other(ffq_ctx *c) { if (c && c->owner) c->owner->tail.is_scan = false; }
+
+extern "C" void *ffq_ctx_stream(ffq_ctx *c)
+{
+    if (!c) return nullptr;
+    c->owner->tail.exposed = true;       // (whoever holds the handle may enqueue on the stream without the library seeing it)
+    c->owner->tail.is_scan = false;
+    return (void *)c->stream;
+}
 
 static ReadPool *ctx_pool(ffq_ctx *c)
 {
@@ -483,6 +508,7 @@ extern "C" int ffq_pinned_free(void *hptr)
 }
 extern "C" int ffq_copy_h2d(ffq_ctx *c, void *dptr, const void *hptr, int64_t bytes, int async)
 {
+    mark_other(c);
     if (!c || bytes < 0) return fail(FFQ_E_ARG, "ffq_copy_h2d: bad argument");
     HIPCHK(hipSetDevice(c->device));
     if (bytes) HIPCHK(hipMemcpyAsync(dptr, hptr, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
@@ -491,6 +517,7 @@ extern "C" int ffq_copy_h2d(ffq_ctx *c, void *dptr, const void *hptr, int64_t by
 }
 extern "C" int ffq_copy_d2h(ffq_ctx *c, void *hptr, const void *dptr, int64_t bytes, int async)
 {
+    mark_other(c);
     if (!c || bytes < 0) return fail(FFQ_E_ARG, "ffq_copy_d2h: bad argument");
     HIPCHK(hipSetDevice(c->device));
     if (bytes) HIPCHK(hipMemcpyAsync(hptr, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
@@ -714,6 +741,17 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
 // second tile).  The last result-writing kernel publishes the result block into host-mapped
 // memory and zeroes the control block for the next scan; ev[3] follows the last kernel.  A
 // second context on the same stream queues its front right behind: the GPU never idles.
+// the stream now ends in a scan front of `c` (StreamTail)
+static void note_scan_tail(ffq_ctx *c, const ScanArgs &a)
+{
+    StreamTail &tl = c->owner->tail;
+    tl.is_scan = true;
+    const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
+    tl.out_p[0] = a.d_table; tl.out_n[0] = (size_t)a.table_cap * 48;
+    tl.out_p[1] = decode ? a.d_qual : nullptr; tl.out_n[1] = decode ? (size_t)a.qual_cap : 0;
+    tl.out_p[2] = decode ? a.d_qoff : nullptr; tl.out_n[2] = decode ? ((size_t)a.table_cap + 1) * 8 : 0;
+}
+
 static int enqueue_front(ffq_ctx *c, ScanState &st)
 {
     const ScanArgs &a = st.a;
@@ -779,16 +817,28 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         c->pub_seq = 0;
         if (!st.poll_seq) HIPCHK(hipEventRecord(c->ev[3], sA));
         HIPCHK(hipGetLastError());
+        note_scan_tail(c, a);
         return FFQ_OK;
     }
 
     // ---- line index --------------------------------------------------------------------
     // (FFQ_F_NO_TIMING with the polled completion: no stream marker anywhere in the front -- each is a barrier
     // packet with a few microseconds of idle GPU around it)
-    st.untimed = (a.flags & FFQ_F_NO_TIMING) && st.poll_seq && !st.index_done && c->ctl_was_clean;
+    st.untimed = (a.flags & FFQ_F_NO_TIMING) && st.poll_seq && !st.index_done;
+    // ... and the index kernel without a barrier in front of it only where the library itself can vouch for it (StreamTail)
+    bool any_order = st.untimed && c->ctl_was_clean;
+    {
+        const StreamTail &tl = c->owner->tail;
+        if (!tl.is_scan || tl.exposed) any_order = false;
+        const uintptr_t b0 = reinterpret_cast<uintptr_t>(a.d_buf), b1 = b0 + (size_t)a.n_bytes;
+        for (int i = 0; i < 3 && any_order; i++) {
+            const uintptr_t o0 = reinterpret_cast<uintptr_t>(tl.out_p[i]), o1 = o0 + tl.out_n[i];
+            if (tl.out_p[i] && o0 < b1 && b0 < o1) any_order = false;
+        }
+    }
     if (!st.untimed) HIPCHK(hipEventRecord(c->ev[0], sA));
     if (!st.index_done)          // (a later tier of the same scan: the index is there already)
-        launch_scan_lines(c, sA, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', k1abl, st.untimed);
+        launch_scan_lines(c, sA, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', k1abl, any_order);
     if (!st.untimed) HIPCHK(hipEventRecord(c->ev[1], sA));
 
     if (try_fast4) {
@@ -862,6 +912,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
     c->pub_seq = 0;                       // (publishers of later tiers, enqueued at the wait, signal with events)
     if (!st.poll_seq) HIPCHK(hipEventRecord(c->ev[3], sA));
     HIPCHK(hipGetLastError());
+    note_scan_tail(c, a);
     return FFQ_OK;
 }
 
@@ -1357,6 +1408,7 @@ extern "C" int ffq_scan_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, 
                              int64_t *h_table, int64_t table_cap, int8_t *h_qual, int64_t qual_cap,
                              int64_t *h_qoff, ffq_scan_result *res)
 {
+    mark_other(c);
     if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_host: ctx/res is NULL");
     if (n_bytes < 0 || table_cap < 0 || qual_cap < 0) return fail(FFQ_E_ARG, "ffq_scan_host: negative size");
     if (n_bytes > 0 && !h_buf) return fail(FFQ_E_ARG, "ffq_scan_host: h_buf is NULL");
@@ -1418,6 +1470,7 @@ extern "C" int ffq_scan_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, 
 extern "C" int ffq_entrypos(ffq_ctx *c, const uint8_t *h_buf, int64_t len, int64_t offset, int64_t *pos,
                             int *status)
 {
+    mark_other(c);
     if (!c || !pos || !status) return fail(FFQ_E_ARG, "ffq_entrypos: NULL argument");
     int64_t row[6];
     ffq_scan_result r;
@@ -1437,6 +1490,7 @@ extern "C" int ffq_entrypos(ffq_ctx *c, const uint8_t *h_buf, int64_t len, int64
 extern "C" int ffq_table_lower_bound(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int col,
                                      int64_t value, int64_t *idx)
 {
+    mark_other(c);
     if (!c || !idx || n_rows < 0 || col < 0 || col > 5 || (n_rows > 0 && !d_table))
         return fail(FFQ_E_ARG, "ffq_table_lower_bound: bad argument");
     HIPCHK(hipSetDevice(c->device));
@@ -1454,6 +1508,7 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
                                      int64_t offset, int64_t add, int64_t *d_table, int64_t table_cap,
                                      ffq_scan_result *res)
 {
+    mark_other(c);
     if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_fasta: ctx/res is NULL");
     if (n_bytes < 0 || offset < 0 || table_cap < 0) return fail(FFQ_E_ARG, "ffq_scan_fasta: negative size");
     if (n_bytes > 0 && !d_buf) return fail(FFQ_E_ARG, "ffq_scan_fasta: d_buf is NULL");
@@ -1524,6 +1579,7 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
 extern "C" int ffq_scan_fasta_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, int sentinel, int64_t offset,
                                    int64_t add, int64_t *h_table, int64_t table_cap, ffq_scan_result *res)
 {
+    mark_other(c);
     if (!c || !res) return fail(FFQ_E_ARG, "ffq_scan_fasta_host: ctx/res is NULL");
     if (n_bytes < 0 || table_cap < 0) return fail(FFQ_E_ARG, "ffq_scan_fasta_host: negative size");
     if (n_bytes > 0 && !h_buf) return fail(FFQ_E_ARG, "ffq_scan_fasta_host: h_buf is NULL");
@@ -1542,6 +1598,7 @@ extern "C" int ffq_scan_fasta_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_b
 extern "C" int ffq_table_cut(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t lo, int64_t hi,
                              int64_t out[6])
 {
+    mark_other(c);
     if (!c || !out || n_rows < 0 || (n_rows > 0 && !d_table)) return fail(FFQ_E_ARG, "ffq_table_cut: bad argument");
     HIPCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(k_table_cut, dim3(1), dim3(64), 0, c->stream, d_table, n_rows, lo, hi, c->d_cut);
@@ -1555,6 +1612,7 @@ extern "C" int ffq_table_cut(ffq_ctx *c, const int64_t *d_table, int64_t n_rows,
 extern "C" int ffq_table_select_seqlen(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t min_len,
                                        int64_t max_len, int64_t *d_out, int64_t *n_out)
 {
+    mark_other(c);
     if (!c || !n_out || n_rows < 0 || (n_rows > 0 && (!d_table || !d_out)))
         return fail(FFQ_E_ARG, "ffq_table_select_seqlen: bad argument");
     if (d_table == d_out && n_rows > 0) return fail(FFQ_E_ARG, "ffq_table_select_seqlen: d_out must not be d_table");
@@ -1587,6 +1645,7 @@ extern "C" int ffq_table_gather_column(ffq_ctx *c, const uint8_t *d_buf, int64_t
                                        int col_end, int value_add, int8_t *d_out, int64_t out_cap, int64_t *d_off,
                                        int64_t *n_out_bytes)
 {
+    mark_other(c);
     if (!c || !n_out_bytes || n_rows < 0 || n_bytes < 0 || out_cap < 0 || !d_off || (n_rows > 0 && !d_table))
         return fail(FFQ_E_ARG, "ffq_table_gather_column: bad argument");
     if (col_begin < 0 || col_begin > 5 || col_end < 0 || col_end > 5)
@@ -1634,6 +1693,7 @@ extern "C" int ffq_table_gather_column(ffq_ctx *c, const uint8_t *d_buf, int64_t
 // ---- arrayadd ----------------------------------------------------------------
 extern "C" int ffq_arrayadd_b_device(ffq_ctx *c, int8_t *d_a, int64_t n, int value)
 {
+    mark_other(c);
     if (!c || n < 0 || (n > 0 && !d_a)) return fail(FFQ_E_ARG, "ffq_arrayadd_b_device: bad argument");
     HIPCHK(hipSetDevice(c->device));
     if (n == 0) return FFQ_OK;
@@ -1648,6 +1708,7 @@ extern "C" int ffq_arrayadd_b_device(ffq_ctx *c, int8_t *d_a, int64_t n, int val
 
 extern "C" int ffq_arrayadd_q_device(ffq_ctx *c, int64_t *d_a, int64_t n, int64_t value)
 {
+    mark_other(c);
     if (!c || n < 0 || (n > 0 && !d_a)) return fail(FFQ_E_ARG, "ffq_arrayadd_q_device: bad argument");
     if ((reinterpret_cast<uintptr_t>(d_a) & 7) != 0) return fail(FFQ_E_ARG, "ffq_arrayadd_q_device: unaligned");
     HIPCHK(hipSetDevice(c->device));
@@ -1662,6 +1723,7 @@ extern "C" int ffq_arrayadd_q_device(ffq_ctx *c, int64_t *d_a, int64_t n, int64_
 
 extern "C" int ffq_arrayadd_b(ffq_ctx *c, int8_t *h_a, int64_t n, int value)
 {
+    mark_other(c);
     if (!c || n < 0 || (n > 0 && !h_a)) return fail(FFQ_E_ARG, "ffq_arrayadd_b: bad argument");
     HIPCHK(hipSetDevice(c->device));
     if (n == 0) return FFQ_OK;
@@ -1677,6 +1739,7 @@ extern "C" int ffq_arrayadd_b(ffq_ctx *c, int8_t *h_a, int64_t n, int value)
 
 extern "C" int ffq_arrayadd_q(ffq_ctx *c, int64_t *h_a, int64_t n, int64_t value)
 {
+    mark_other(c);
     if (!c || n < 0 || (n > 0 && !h_a)) return fail(FFQ_E_ARG, "ffq_arrayadd_q: bad argument");
     HIPCHK(hipSetDevice(c->device));
     if (n == 0) return FFQ_OK;
@@ -1693,6 +1756,7 @@ extern "C" int ffq_arrayadd_q(ffq_ctx *c, int64_t *h_a, int64_t n, int64_t value
 // ---- synthetic inputs ------------------------------------------------------------
 extern "C" int ffq_synth_single(ffq_ctx *c, uint8_t *d_out, int64_t first, int64_t count, uint64_t seed)
 {
+    mark_other(c);
     if (!c || count < 0 || (count > 0 && !d_out)) return fail(FFQ_E_ARG, "ffq_synth_single: bad argument");
     HIPCHK(hipSetDevice(c->device));
     if (count == 0) return FFQ_OK;
@@ -1708,6 +1772,7 @@ extern "C" int64_t ffq_synth_wrapped_size(int64_t i, uint64_t seed) { return syn
 extern "C" int ffq_synth_wrapped(ffq_ctx *c, uint8_t *d_out, const int64_t *d_start, int64_t first,
                                  int64_t count, uint64_t seed)
 {
+    mark_other(c);
     if (!c || count < 0 || (count > 0 && (!d_out || !d_start))) return fail(FFQ_E_ARG, "ffq_synth_wrapped: bad argument");
     HIPCHK(hipSetDevice(c->device));
     if (count == 0) return FFQ_OK;
@@ -1722,6 +1787,7 @@ extern "C" int ffq_synth_wrapped(ffq_ctx *c, uint8_t *d_out, const int64_t *d_st
 // ---- probes: only in the instrumented build, libffq_probe.so (include/ffq_probe.h; tools/) ----------
 extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int mode, int reps, float *ms_avg)
 {
+    mark_other(c);
     if (!c || !d_buf || !ms_avg || n_bytes < TILE || reps < 1) return fail(FFQ_E_ARG, "ffq_read_probe: bad argument");
     HIPCHK(hipSetDevice(c->device));
     const int64_t ntiles = n_bytes >> TILE_SHIFT;
@@ -1878,6 +1944,7 @@ extern "C" int ffq_read_probe(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes,
 // ---- diagnostics ---------------------------------------------------------------------
 extern "C" int ffq_selftest(ffq_ctx *c)
 {
+    mark_other(c);
     if (!c) return fail(FFQ_E_ARG, "ffq_selftest: ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
     const int NB = 256 * 16;

@@ -865,6 +865,7 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
     }
     const int64_t start = room - carry, len = carry + sl.got;
     const bool fill_eof = sl.eof;
+    mark_other(c);          // (a copy and two event waits go onto the scan stream in front of the scan)
     HIPCHK(hipMemcpyAsync(sl.d + start, sl.h + start, (size_t)carry, hipMemcpyHostToDevice, c->stream));
     if (s->prof) {          // (profiling only: the wait for the chunk's copy on its own)
         const double t = stream_now();

@@ -87,13 +87,15 @@ extern "C" {
                                       the same contract).                                                                      */
 #define FFQ_SEG_STRIDE     8704
 #define FFQ_F_NO_TIMING    32u     /* with FFQ_F_POLL_RESULT: no timing marks around the line-index kernel either (ms_index is
-                                      0 for this scan).  The front then holds no stream marker at all, and its index kernel is
-                                      dispatched without a barrier: queued behind another context's scan on the same stream it
-                                      starts while that scan's last, one-workgroup kernel is still running.  THE CALLER VOUCHES
-                                      that nothing queued on the stream in front of this scan writes the scanned bytes (a copy
-                                      or a hand-off into the buffer must be waited for first: the index kernel no longer is
-                                      ordered behind it).  A host that times every n-th scan loses nothing but the marks' idle
-                                      microseconds on the others.                                                           */
+                                      0 for this scan): the front then holds no stream marker at all.  Where the library itself
+                                      can prove that the order does not matter it also dispatches the index kernel without a
+                                      barrier, so that it starts while the previous scan's last, one-workgroup kernel is still
+                                      running: only when the last thing enqueued on the context's stream is the front of another
+                                      scan (a context sharing the stream; anything else the library enqueues there -- copies, the
+                                      stream front end's event waits, table utilities -- ends that, and so does handing the stream
+                                      out through ffq_ctx_stream), and none of that scan's outputs overlaps the bytes this one
+                                      reads.  The caller vouches for nothing.  A host that times every n-th scan loses nothing but
+                                      the marks' idle microseconds on the others.                                            */
 
 typedef struct ffq_ctx ffq_ctx;
 
