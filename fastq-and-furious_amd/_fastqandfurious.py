@@ -124,7 +124,8 @@ class _GpuEntrypos:
             return _hip.FileStream(self._context(), g[0], chunk, decode=decode, start=g[1], gzip=True)
         if getattr(fh, "readinto", None) is None and getattr(fh, "read", None) is None:
             return None
-        return _hip.PushStream(self._context(), fh, chunk, decode=decode)
+        # (reads are coalesced up to `chunk`, but a live source that comes back short is not waited on beyond fbufsize)
+        return _hip.PushStream(self._context(), fh, chunk, decode=decode, min_fill=max(int(fbufsize), 1))
 
     # -- batched protocol used by this package's readfastq_iter ------------
     def scan_buffer(self, buf, offset, eof):

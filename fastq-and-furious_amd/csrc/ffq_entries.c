@@ -85,8 +85,9 @@ done:
  * What the reference's documented decode builds per record in an entryfunc of the user's own,
  *     quality = array('b'); quality.frombytes(buf[pos[4]:pos[5]]); arrayadd_b(quality, -33)
  * (/root/reference/doc/user-guide.rst:126-141, :206-214), for a whole table at once: the decoded
- * bytes come from the stream's bulk decode on the device -- qual (int8) with CSR offsets qoff
- * (int64, one more than rows) -- and are only wrapped here.  array_type: array.array.            */
+ * bytes come from the stream's bulk decode on the device -- qual (int8) with the offsets qoff (int64,
+ * one more than rows: where each record's bytes start, and where the last one's end) -- and are only
+ * wrapped here.  array_type: array.array.                                                         */
 static PyObject *entries_phred(PyObject *self, PyObject *args)
 {
     Py_buffer buf, rows, qual, qoff;
@@ -118,14 +119,17 @@ static PyObject *entries_phred(PyObject *self, PyObject *args)
         list = PyList_New(n);
         if (!list) goto done;
         for (Py_ssize_t i = 0; i < n; i++, p += 6) {
-            if (o[i] < q0 || o[i + 1] < o[i] || o[i + 1] > o[n]) {
+            /* record i's bytes start at o[i] and are pos5 - pos4 of them (include/ffq.h: the packed stream and the
+             * segmented layout of FFQ_F_SINGLE_PASS alike; o[i + 1] - o[i] is a length only in the packed one) */
+            const int64_t ln = p[5] - p[4];
+            if (o[i] < q0 || ln < 0 || o[i] + ln > o[n]) {
                 PyErr_SetString(PyExc_ValueError, "quality offsets do not fit the decoded stream");
                 Py_CLEAR(list);
                 goto done;
             }
             PyObject *h = cut(base, buf.len, p[0] - shift + 1, p[1] - shift);
             PyObject *s = cut(base, buf.len, p[2] - shift, p[3] - shift);
-            PyObject *q = PySequence_GetSlice(big, (Py_ssize_t)(o[i] - q0), (Py_ssize_t)(o[i + 1] - q0));
+            PyObject *q = PySequence_GetSlice(big, (Py_ssize_t)(o[i] - q0), (Py_ssize_t)(o[i] + ln - q0));
             PyObject *t = !(h && s && q) ? NULL : PyTuple_New(3);
             if (!t) {
                 Py_XDECREF(h); Py_XDECREF(s); Py_XDECREF(q);

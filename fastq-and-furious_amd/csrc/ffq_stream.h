@@ -271,6 +271,7 @@ struct ffq_stream {
     bool done = false, failed = false;
     int64_t globaloffset = -1;          // readfastq_iter :242
     int64_t last_nq = 0;
+    int last_path = -1;                 // ffq_scan_result.path of the last fill's scan
     // FFQ_STREAM_PROF=1: where the time of a stream goes (printed when it closes)
     bool prof = false;
     double t_read = 0, t_slot = 0, t_feed = 0, t_scan = 0, t_rows = 0, t_copy = 0;
@@ -656,7 +657,8 @@ static int stream_open_impl(ffq_ctx *c, int src, int fd, int64_t fbufsize, uint3
     ffq_stream *s = new (std::nothrow) ffq_stream();
     if (!s) return fail(FFQ_E_NOMEM, "out of host memory");
     s->c = c; s->fd = fd; s->src = src;
-    s->flags = flags & FFQ_F_DECODE_QUAL; s->qual_add = qual_add;
+    // (FFQ_F_SINGLE_PASS: the fill's qualities come SEGMENTED -- ffq_stream_quals -- from the pass that builds the index)
+    s->flags = flags & (FFQ_F_DECODE_QUAL | ((flags & FFQ_F_DECODE_QUAL) ? FFQ_F_SINGLE_PASS : 0u)); s->qual_add = qual_add;
     s->prof = getenv("FFQ_STREAM_PROF") != nullptr;
     if (src == SRC_PUSH) s->feeder_done = true;          // there is no reader thread: chunks are pushed
     else {
@@ -802,8 +804,14 @@ extern "C" int64_t ffq_stream_tell(ffq_stream *s)
     return s->handed_pos;
 }
 
+// ffq_scan_result.path of the last fill's scan (6: index and decoded qualities in one pass)
+extern "C" int ffq_stream_path(ffq_stream *s) { return s ? s->last_path : -1; }
+
 // decoded qualities of the fill ffq_stream_next has just returned (streams opened with
-// FFQ_F_DECODE_QUAL): int8 stream + CSR offsets (n_rows + 1), pinned, valid until the next call
+// FFQ_F_DECODE_QUAL): int8 bytes + offsets (n_rows + 1), pinned, valid until the next call.  Record i's bytes are
+// h_qual[h_qoff[i] : h_qoff[i] + pos5(i) - pos4(i)] -- packed back to back (then h_qoff[i + 1] is where they end), or,
+// for a stream opened with FFQ_F_SINGLE_PASS whose fill the single pass took, with gaps between the index tiles'
+// segments (include/ffq.h, FFQ_F_SINGLE_PASS); h_qoff[n_rows] = *n_qual_bytes = where the last record's bytes end.
 extern "C" int ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int64_t **h_qoff, int64_t *n_qual_bytes)
 {
     if (!s || !h_qual || !h_qoff || !n_qual_bytes) return fail(FFQ_E_ARG, "ffq_stream_quals: NULL argument");
@@ -880,7 +888,10 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
     const int64_t mis = start & 15;
     const bool decode = (s->flags & FFQ_F_DECODE_QUAL) != 0;
     if (decode) {
-        int rc2 = stream_alloc_qual(s, len / 2 + 64);      // qualities are at most half of the bytes
+        // qualities are at most half of the bytes; the segmented layout of the single pass owns FFQ_SEG_STRIDE bytes per tile
+        int64_t need = len / 2 + 64;
+        if (s->flags & FFQ_F_SINGLE_PASS) need = std::max<int64_t>(need, ((len + mis + 16383) >> 14) * (int64_t)FFQ_SEG_STRIDE);
+        int rc2 = stream_alloc_qual(s, need);
         if (rc2) return rc2;
     }
     ffq_scan_result res;
@@ -899,6 +910,7 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
     if (res.n_records > 0)
         HIPCHK(hipMemcpyAsync(b->htab, b->dtab, (size_t)res.n_records * 48, hipMemcpyDeviceToHost, c->stream));
     s->last_nq = 0;
+    s->last_path = res.path;
     if (decode) {
         s->last_nq = res.n_qual_bytes;
         if (res.n_qual_bytes > 0)

@@ -212,8 +212,9 @@ def _phred_entries(st, fill, rows, shift):
     buf = fill.tobytes()
     qb = qual.tobytes()
     offs = qoff.tolist()
-    for i, (p0, p1, p2, p3, _p4, _p5) in enumerate((rows - shift).tolist()):
-        yield (buf[p0 + 1:p1], buf[p2:p3], array('b', qb[offs[i]:offs[i + 1]]))
+    # (record i's bytes: qual[qoff[i] : qoff[i] + pos5 - pos4] -- packed stream and single-pass segments alike)
+    for i, (p0, p1, p2, p3, p4, p5) in enumerate((rows - shift).tolist()):
+        yield (buf[p0 + 1:p1], buf[p2:p3], array('b', qb[offs[i]:offs[i] + p5 - p4]))
 
 
 def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):

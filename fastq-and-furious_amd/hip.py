@@ -27,7 +27,7 @@ MISSING_QUALHEADER_END = 7
 
 END_OK, END_REFILL, END_ERR_FINAL_QUAL, END_ERR_INCOMPLETE, END_ERR_INVALID = range(5)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK = 0
 E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_TABLE_FULL, E_INTERNAL = -1, -2, -3, -4, -5, -6
 
@@ -48,7 +48,7 @@ SYMBOLS = (
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
     "ffq_table_select_seqlen", "ffq_table_cut", "ffq_table_gather_column", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
-    "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_stream_open_push",
+    "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_stream_path", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_stream_open_push",
     "ffq_stream_push_buffer", "ffq_stream_push", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
@@ -203,6 +203,8 @@ def lib():
         L.ffq_stream_push.argtypes = [vp, i64, i32]
         L.ffq_stream_tell.argtypes = [vp]
         L.ffq_stream_tell.restype = i64
+        L.ffq_stream_path.argtypes = [vp]
+        L.ffq_stream_path.restype = i32
         L.ffq_stream_quals.argtypes = [vp, P(vp), P(vp), P(i64)]
         L.ffq_stream_close.restype = None
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
@@ -486,9 +488,16 @@ class _Stream:
         """File position behind the last chunk handed out (-1: the source has none)."""
         return int(lib().ffq_stream_tell(self._h)) if self._h else -1
 
+    def path(self):
+        """ScanResult.path of the fill the iteration has just yielded (6: index and decoded qualities in one pass)."""
+        return int(lib().ffq_stream_path(self._h)) if self._h else -1
+
     def quals(self):
         """(qual int8[], qoff int64[n + 1]) of the fill the iteration has just yielded (streams
-        opened with decode=True); views, valid until the next iteration step."""
+        opened with decode=True); views, valid until the next iteration step.  Record i's decoded
+        bytes are qual[qoff[i] : qoff[i] + pos5 - pos4] (row i's columns): packed back to back, or --
+        single_pass streams, where the input allows it -- with gaps between the index tiles' segments
+        (include/ffq.h, FFQ_F_SINGLE_PASS); qoff[n] is where the last record's bytes end."""
         qp, op, nq = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
         check(lib().ffq_stream_quals(self._h, ctypes.byref(qp), ctypes.byref(op), ctypes.byref(nq)))
         n = self._last_rows
@@ -526,20 +535,26 @@ class _Stream:
         return rows, fill, off.value, end.value, err.value
 
 
+def _decode_flags(decode, single_pass):
+    return (F_DECODE_QUAL | (F_SINGLE_PASS if single_pass else 0)) if decode else 0
+
+
 class FileStream(_Stream):
     """The stream front end over a file descriptor: buffer fills read ahead into pinned memory (reader
     threads; a gzip file is inflated by them) while the previous fill is scanned."""
 
-    def __init__(self, ctx, fd, fbufsize=1 << 24, decode=False, qual_add=-33, start=None, gzip=False):
+    def __init__(self, ctx, fd, fbufsize=1 << 24, decode=False, qual_add=-33, start=None, gzip=False, single_pass=True):
         """start: byte of the file the stream begins at (None: the descriptor's current position).
         A descriptor that can seek is read with pread: its own position does not move.
         gzip: the descriptor is a gzip file; the stream's reader thread inflates it into the pinned
-        chunk buffers (fbufsize and every offset count DECOMPRESSED bytes)."""
+        chunk buffers (fbufsize and every offset count DECOMPRESSED bytes).
+        single_pass (with decode): the qualities of a fill of four-line records are decoded by the pass
+        that builds the line index (one read of the bytes) and come segmented: see quals()."""
         self._ctx = ctx
         self._h = ctypes.c_void_p()
         self.decode = bool(decode)
         opener = lib().ffq_stream_open_gzip if gzip else lib().ffq_stream_open2
-        check(opener(ctx.handle, int(fd), int(fbufsize), F_DECODE_QUAL if decode else 0,
+        check(opener(ctx.handle, int(fd), int(fbufsize), _decode_flags(decode, single_pass),
                      int(qual_add), -1 if start is None else int(start), ctypes.byref(self._h)))
 
     def __iter__(self):
@@ -556,13 +571,18 @@ class PushStream(_Stream):
     stream's pinned chunk buffer (ffq_stream_push_buffer / ffq_stream_push; no bytes object, no
     copy), then scanned.  Iterates like FileStream."""
 
-    def __init__(self, ctx, fh, fbufsize=1 << 23, decode=False, qual_add=-33):
+    def __init__(self, ctx, fh, fbufsize=1 << 23, decode=False, qual_add=-33, single_pass=True, min_fill=None):
+        """min_fill: a chunk is handed over SHORT (which is not the end of the stream) as soon as it holds this many
+        bytes and a read comes back with less than was asked for -- a live source (a socket, stdin, a decompressor
+        over a pipe) has nothing more for now, and the reference's loop yields after every read of fbufsize bytes
+        (fastqandfurious.py:222-232 advises small buffers for latency).  None: fbufsize (a chunk is always filled)."""
         self._ctx = ctx
         self._h = ctypes.c_void_p()
         self.decode = bool(decode)
         self._fh = fh
+        self._min_fill = int(fbufsize if min_fill is None else max(1, min(int(min_fill), int(fbufsize))))
         self._readinto = getattr(fh, "readinto", None)
-        check(lib().ffq_stream_open_push(ctx.handle, int(fbufsize), F_DECODE_QUAL if decode else 0, int(qual_add),
+        check(lib().ffq_stream_open_push(ctx.handle, int(fbufsize), _decode_flags(decode, single_pass), int(qual_add),
                                          ctypes.byref(self._h)))
 
     def _pump(self):
@@ -572,18 +592,22 @@ class PushStream(_Stream):
         dst, cap = ctypes.c_void_p(), ctypes.c_int64()
         check(lib().ffq_stream_push_buffer(self._h, ctypes.byref(dst), ctypes.byref(cap)))
         mv = memoryview((ctypes.c_uint8 * cap.value).from_address(dst.value)).cast("B")
-        got = 0
+        got, eof = 0, False
         while got < cap.value:
+            want = cap.value - got
             if self._readinto is not None:
                 n = self._readinto(mv[got:]) or 0
             else:
-                data = self._fh.read(cap.value - got)
+                data = self._fh.read(want)
                 n = len(data)
                 mv[got:got + n] = data
             if n <= 0:
+                eof = True
                 break
             got += n
-        check(lib().ffq_stream_push(self._h, got, 1 if got < cap.value else 0))
+            if n < want and got >= self._min_fill:
+                break                       # a short read with enough in hand: hand the chunk over, the rest comes with the next
+        check(lib().ffq_stream_push(self._h, got, 1 if eof else 0))
 
     def __iter__(self):
         self._pump()

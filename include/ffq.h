@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FFQ_ABI_VERSION 3
+#define FFQ_ABI_VERSION 4
 
 /* scanner status codes -- identical to the reference's module constants
  * (_fastqandfurious.c:7-15,254-262; fastqandfurious.py:19-27)             */
@@ -292,8 +292,12 @@ int  ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n_rows, int
 void ffq_stream_close(ffq_stream *s);
 /* The same with options.  flags = FFQ_F_DECODE_QUAL: every fill's qualities are decoded on the
  * device (array('b').frombytes(buf[pos4:pos5]); arrayadd_b(q, qual_add), doc/user-guide.rst:130-141)
- * and ffq_stream_quals hands back the int8 stream and its CSR offsets (n_rows + 1 entries) of
- * the fill ffq_stream_next has just returned; pinned memory, valid until the next call.
+ * and ffq_stream_quals hands back the int8 bytes and their offsets (n_rows + 1 entries) of
+ * the fill ffq_stream_next has just returned; pinned memory, valid until the next call: record i's
+ * bytes are h_qual[h_qoff[i] : h_qoff[i] + pos5(i) - pos4(i)], h_qoff[n_rows] = *n_qual_bytes = where
+ * the last record's end.  Packed back to back -- or, flags = FFQ_F_DECODE_QUAL | FFQ_F_SINGLE_PASS,
+ * segmented (see FFQ_F_SINGLE_PASS above) whenever the single pass takes the fill (plain four-line
+ * records: the fill is read once); ffq_stream_path = ffq_scan_result.path of the last fill (6 then).
  * start: byte of the file the stream begins at (< 0: the descriptor's current position); stream
  * offsets count from there.  ffq_stream_tell: the file position behind the last chunk HANDED OUT by
  * ffq_stream_next (the reader itself runs ahead of that): where a caller that shares the file object
@@ -305,6 +309,7 @@ int  ffq_stream_open2(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags, in
                       ffq_stream **out);
 int  ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int64_t **h_qoff, int64_t *n_qual_bytes);
 int64_t ffq_stream_tell(ffq_stream *s);
+int  ffq_stream_path(ffq_stream *s);
 /* The same over a gzip-compressed file (what FORMAT_OPENERS['gz'] / automagic_open hand to
  * readfastq_iter, fastqandfurious.py:282-334): the stream's reader thread inflates (zlib; concatenated
  * members, zero padding behind the last one) straight into the pinned chunk buffers -- decompression

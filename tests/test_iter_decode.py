@@ -126,6 +126,57 @@ def test_phred_synthetic_streams(gpu_ctx, phred, tmp_path, name, maker):
 
 
 @pytest.mark.gpu
+def test_live_source_is_not_held_back_by_coalescing(gpu_ctx):
+    """A source that trickles (a socket, stdin: every read comes back short) with the default coalescing (8 MiB per
+    device call): the first entries must come out once fbufsize bytes are in, not after 8 MiB have arrived -- the
+    reference's loop yields after every read of fbufsize bytes (fastqandfurious.py:222-232)."""
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C, synth
+    data = synth.single(0, 4000, seed=42).tobytes()          # 1.29 MB
+
+    class Trickle:
+        def __init__(self, blob, piece):
+            self.blob, self.piece, self.at = blob, piece, 0
+
+        def readinto(self, mv):
+            n = min(len(mv), self.piece, len(self.blob) - self.at)
+            mv[:n] = self.blob[self.at:self.at + n]
+            self.at += n
+            return n
+
+    C.entrypos.coalesce_bytes = 8 << 20
+    src = Trickle(data, 997)
+    it = F.readfastq_iter(src, 20000, F.entryfunc, C.entrypos)
+    first = next(it)
+    assert src.at <= 3 * 20000, src.at                 # (a fill or two of the caller's size, not the whole megabyte)
+    got = [first] + list(it)
+    want = list(F.readfastq_iter(__import__("io").BytesIO(data), 20000, F.entryfunc, F.entrypos))
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_phred_iterator_takes_the_single_pass(gpu_ctx, phred, tmp_path):
+    """What the decoding iterator runs on: the stream readfastq_iter opens for entryfunc_phred asks for the single pass
+    (index + decoded qualities from one read of the fill, res.path 6) and gets it on four-line input; wrapped records
+    come through the two passes, packed -- the entries are the reference's either way (phred.json)."""
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C, synth
+    C.entrypos.coalesce_bytes = 8 << 20
+    for name, want_path in (("single_3000", (6,)), ("wrapped_3000", (0, 2))):
+        data = (synth.single(0, 3000, seed=42) if name.startswith("single") else synth.wrapped(0, 3000, seed=43)[0]).tobytes()
+        p = tmp_path / (name + ".fq")
+        p.write_bytes(data)
+        g = phred["synth"][name]
+        with open(p, "rb") as fh:
+            st = C.entrypos.open_stream(fh, 50000, True)
+            paths, got = set(), []
+            for rows, fill, fill_offset, end_state, err in st:
+                paths.add(st.path())
+                got.extend(F._phred_entries(st, fill, rows, fill_offset))
+            st.close()
+        assert paths <= set(want_path) and paths, (name, paths)
+        assert len(got) == g["n"] and _digest(got) == g["sha256"], name
+
+
+@pytest.mark.gpu
 def test_default_entryfunc_every_source_and_coalescing(gpu_ctx, golden, tmp_path):
     """The default entryfunc through every kind of source, coalesced and not: the golden tuples of the
     reference's fixtures (captured from the reference, golden.json)."""

@@ -183,10 +183,12 @@ def test_iterator_errors_over_real_files(mods, gpu_ctx, golden, tmp_path):
     assert n >= 5
 
 
+@pytest.mark.parametrize("single_pass", (False, True))
 @pytest.mark.parametrize("bufsize", (4096, 1 << 20))
-def test_stream_with_decode(mods, gpu_ctx, oracle, tmp_path, pkg, bufsize):
-    """fills with FFQ_F_DECODE_QUAL: the concatenated int8 streams and the per-fill CSR offsets
-    against arrayadd_b(-33) over every record's quality slice"""
+def test_stream_with_decode(mods, gpu_ctx, oracle, tmp_path, pkg, bufsize, single_pass):
+    """fills with FFQ_F_DECODE_QUAL: every record's bytes qual[qoff[i] : qoff[i] + pos5 - pos4] against arrayadd_b(-33)
+    over its quality slice; packed streams (and fills the single pass declines: wrapped records) also as the
+    concatenated int8 streams with CSR offsets.  single_pass: the stream's default, segmented where the input allows"""
     F, hip, _ = mods
     from fastqandfurious_amd import synth
     for blob in (synth.single(0, 3000, seed=42).tobytes(), synth.wrapped(0, 3000, seed=43)[0].tobytes(),
@@ -197,14 +199,21 @@ def test_stream_with_decode(mods, gpu_ctx, oracle, tmp_path, pkg, bufsize):
         open(path, "wb").write(blob)
         fd = os.open(path, os.O_RDONLY)
         try:
-            st = hip.FileStream(gpu_ctx, fd, bufsize, decode=True)
-            quals, lens, nrows = [], [], 0
+            st = hip.FileStream(gpu_ctx, fd, bufsize, decode=True, single_pass=single_pass)
+            quals, lens, nrows, packed = [], [], 0, True
             for rows, fill, off, end_state, err in st:
                 q, qo = st.quals()
-                assert qo.shape[0] == rows.shape[0] + 1 and qo[0] == 0 and qo[-1] == q.shape[0]
-                quals.append(q.copy())
-                lens.append(np.diff(qo))
-                nrows += rows.shape[0]
+                n = rows.shape[0]
+                ln = rows[:, 5] - rows[:, 4]
+                assert qo.shape[0] == n + 1 and qo[-1] == q.shape[0]
+                assert n == 0 or (qo[1:n] >= qo[:n - 1] + ln[:n - 1]).all() and qo[n] == qo[n - 1] + ln[n - 1]
+                if n and not (qo[0] == 0 and (np.diff(qo) == ln).all()):
+                    packed = False
+                    assert single_pass                 # (gaps only where the caller accepted them)
+                idx = np.repeat(qo[:n], ln) + (np.arange(int(ln.sum())) - np.repeat(np.cumsum(ln) - ln, ln))
+                quals.append(q[idx].copy())
+                lens.append(ln.copy())
+                nrows += n
                 assert end_state in (hip.END_OK, hip.END_REFILL)
             st.close()
         finally:
@@ -212,6 +221,8 @@ def test_stream_with_decode(mods, gpu_ctx, oracle, tmp_path, pkg, bufsize):
         assert nrows == len(want)
         assert np.array_equal(np.concatenate(quals), wq)
         assert np.array_equal(np.concatenate(lens), np.diff(wqoff))
+        if not single_pass:
+            assert packed
 
 
 def test_stream_long_record_after_short_ones(mods, gpu_ctx, oracle, tmp_path):
