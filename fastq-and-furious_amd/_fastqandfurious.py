@@ -121,7 +121,9 @@ class _GpuEntrypos:
             return st
         g = _gzip_fileno(fh)
         if g is not None:
-            return _hip.FileStream(self._context(), g[0], chunk, decode=decode, start=g[1], gzip=True)
+            st = _hip.FileStream(self._context(), g[0], chunk, decode=decode, start=g[1], gzip=True)
+            st.on_close = lambda: _gzip_leave_exhausted(fh)
+            return st
         if getattr(fh, "readinto", None) is None and getattr(fh, "read", None) is None:
             return None
         # (reads are coalesced up to `chunk`, but a live source that comes back short is not waited on beyond fbufsize)
@@ -152,6 +154,17 @@ def _gzip_fileno(fh):
         return raw.fileno(), raw.tell()
     except (OSError, ValueError, AttributeError):
         return None
+
+
+def _gzip_leave_exhausted(fh):
+    """The library inflated the compressed file itself (pread: the GzipFile object was never read from).  The
+    reference's loop leaves `fh` exhausted; so that a later fh.read() -- or a second iterator over the same object --
+    does not replay the whole file, the raw file is left at its end: the GzipFile then reads as empty."""
+    try:
+        raw = fh.fileobj
+        raw.seek(0, 2)
+    except (OSError, ValueError, AttributeError):
+        pass
 
 
 entrypos = _GpuEntrypos()

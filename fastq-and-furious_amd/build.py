@@ -6,7 +6,7 @@ The library is the product's only compute path: hand-written HIP kernels for
 CDNA4 behind the C ABI of include/ffq.h.  hipcc cross-compiles without a GPU.
 
 Every build bakes in a BUILD ID: the hash of the sources it was compiled from
-(csrc/*.h, *.hip, *.c and include/*.h).  `ffq_build_id()` returns it, hip.lib()
+(csrc/*.h, *.hip and include/ffq.h; the instrumented build also include/ffq_probe.h).  `ffq_build_id()` returns it, hip.lib()
 recomputes it from the tree when the library is loaded and rebuilds (or refuses
 to run) on a mismatch -- an in-tree .so that is older or newer than the sources
 cannot stand in for them (the .so files are git-ignored but travel with the
@@ -38,16 +38,18 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libffq_hip.so cannot be built")
 
 
-def source_files():
-    fs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".c"))]
-    fs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+def source_files(probe=False):
+    """What libffq_hip.so is compiled from: csrc/*.h, *.hip and include/ffq.h (ffq_entries.c is the CPython glue, a
+    library of its own; include/ffq_probe.h belongs to the instrumented build only)."""
+    fs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+    fs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h") and (probe or f != "ffq_probe.h")]
     return sorted(fs)
 
 
-def source_id():
+def source_id(probe=False):
     """16 hex digits over names and contents of every source the library is compiled from."""
     h = hashlib.sha256()
-    for f in source_files():
+    for f in source_files(probe):
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             h.update(fh.read())
@@ -67,7 +69,7 @@ def built_id(path=LIB):
 
 
 def needs_build(path=LIB):
-    return built_id(path) != source_id()
+    return built_id(path) != source_id(probe=(path == PROBE_LIB))
 
 
 ENTRIES_SRC = os.path.join(CSRC, "ffq_entries.c")
@@ -98,8 +100,34 @@ def build_entries(force=False, verbose=False):
     return out
 
 
+def _have_zlib():
+    for d in ("/usr/include", "/usr/local/include", "/opt/rocm/include"):
+        if os.path.exists(os.path.join(d, "zlib.h")):
+            return True
+    return False
+
+
+class _BuildLock:
+    """One builder at a time (ranks of one torchrun that all find the library stale: one compiles, the others wait
+    and then find it fresh)."""
+
+    def __enter__(self):
+        import fcntl
+        self.fh = open(os.path.join(CSRC, ".build.lock"), "w")
+        fcntl.flock(self.fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.fh, fcntl.LOCK_UN)
+        self.fh.close()
+
+
 def _compile(out, extra, verbose):
-    sid = source_id()
+    if not _have_zlib():
+        raise RuntimeError("zlib.h not found: csrc/ffq_stream.h (the gzip feeder of the stream front end) needs the zlib "
+                           "development headers; libffq_hip.so links -lz")
+    sid = source_id(probe=(out == PROBE_LIB))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wall", "-Wno-unused-function", '-DFFQ_BUILD_ID="%s"' % sid] + extra + \
           ["-o", out + ".tmp.%d" % os.getpid()] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz"]      # zlib: the gzip feeder (ffq_stream.h)
@@ -118,14 +146,18 @@ def build(force=False, verbose=False):
     except Exception as e:      # noqa: BLE001
         warnings.warn("csrc/ffq_entries.c not built (%s): the iterator cuts its slices in Python" % (e,))
     if force or needs_build(LIB):
-        _compile(LIB, [], verbose)
+        with _BuildLock():
+            if force or needs_build(LIB):          # (another process may have built it while this one waited)
+                _compile(LIB, [], verbose)
     return LIB
 
 
 def build_probe(force=False, verbose=False):
     """The instrumented build (tools only)."""
     if force or needs_build(PROBE_LIB):
-        _compile(PROBE_LIB, ["-DFFQ_PROBES=1"], verbose)
+        with _BuildLock():
+            if force or needs_build(PROBE_LIB):
+                _compile(PROBE_LIB, ["-DFFQ_PROBES=1"], verbose)
     return PROBE_LIB
 
 

@@ -223,13 +223,16 @@ struct GzPool {
     }
 };
 
-// threads that inflate (FFQ_GZ_THREADS; default: the host's cores, at most 16): 1 = no pool
+// threads that inflate (FFQ_GZ_THREADS; default: this process's share of the host's cores -- cores / LOCAL_WORLD_SIZE
+// when a launcher runs one rank per GPU --, at most 16): 1 = no pool
 static int gz_threads_default()
 {
     const char *e = getenv("FFQ_GZ_THREADS");
     if (e && atoi(e) > 0) return std::min(atoi(e), 256);
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::min<unsigned>(std::max<unsigned>(hw, 1u), 16u);
+    unsigned hw = std::max<unsigned>(std::thread::hardware_concurrency(), 1u);
+    const char *lw = getenv("LOCAL_WORLD_SIZE");
+    if (lw && atoi(lw) > 1) hw = std::max<unsigned>(hw / (unsigned)atoi(lw), 1u);
+    return (int)std::min<unsigned>(hw, 16u);
 }
 
 struct ffq_stream {

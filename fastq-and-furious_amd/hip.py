@@ -79,6 +79,14 @@ class FFQError(RuntimeError):
         self.code = code
 
 
+class FFQGzipError(FFQError, OSError):
+    """Corrupt gzip input met by the stream front end's reader: also an OSError, as gzip.BadGzipFile is."""
+
+
+class FFQGzipTruncated(FFQError, EOFError):
+    """A gzip file that ends before its end-of-stream marker: also an EOFError, as Python's gzip raises."""
+
+
 _lib = None
 _probe = False      # use_probe_build(): tools load the instrumented build instead of the product library
 
@@ -120,6 +128,12 @@ def _checked_build():
     from . import build as _build
     want = _build.source_id()
     if os.path.exists(LIB_PATH) and _build.built_id(LIB_PATH) == want:
+        return
+    if os.environ.get("FFQ_TRUST_BUILD") == "1" and os.path.exists(LIB_PATH):
+        # a read-only install / a box without hipcc: the caller takes responsibility (the ABI version is still checked)
+        import warnings
+        warnings.warn("%s carries build id %s, the sources in this tree hash to %s: loaded as it is (FFQ_TRUST_BUILD=1)"
+                      % (LIB_PATH, _build.built_id(LIB_PATH), want))
         return
     try:
         _build.build()
@@ -220,7 +234,11 @@ def lib():
 
 def check(rc, allow=()):
     if rc != OK and rc not in allow:
-        raise FFQError(rc, lib().ffq_last_error().decode("utf-8", "replace"))
+        msg = lib().ffq_last_error().decode("utf-8", "replace")
+        if "gzip: " in msg:
+            # what a drop-in caller of gzip.open() catches: EOFError for a file cut short, BadGzipFile (an OSError) otherwise
+            raise (FFQGzipTruncated if "ended before the end-of-stream marker" in msg else FFQGzipError)(rc, msg)
+        raise FFQError(rc, msg)
     return rc
 
 

@@ -40,7 +40,7 @@ def gpu_ctx(pkg):
     from fastqandfurious_amd import build, hip
     build.build()                                    # (rebuilds iff the in-tree library's build id is not the sources')
     # (FFQ_USE_PROBE_BUILD=1: a debugging session runs the suite on the instrumented build of the same sources)
-    assert hip.build_id() in (build.source_id(), build.source_id() + ("+probes" if os.environ.get("FFQ_USE_PROBE_BUILD") == "1" else "")), \
+    assert hip.build_id() == (build.source_id(probe=True) + "+probes" if os.environ.get("FFQ_USE_PROBE_BUILD") == "1" else build.source_id()), \
         "libffq_hip.so was not built from the sources in this tree"
     ctx = hip.default_context(0)
     return ctx

@@ -42,7 +42,7 @@ def test_probe_library_exports_its_header(hip):
     for name in names + declared_symbols():
         assert hasattr(L, name), name
     L.ffq_build_id.restype = ctypes.c_char_p
-    assert L.ffq_build_id().decode() == build.source_id() + "+probes"
+    assert L.ffq_build_id().decode() == build.source_id(probe=True) + "+probes"
 
 
 def test_build_id_is_the_hash_of_the_sources(hip, tmp_path):

@@ -208,11 +208,26 @@ def test_gzip_errors_and_pipe_stop(gpu_ctx, tmp_path):
     with pytest.raises(hip.FFQError, match="gzip"):
         with gzip.open(bad, "rb") as fh:
             list(F.readfastq_iter(fh, 50000, F.entryfunc, C.entrypos))
+    # ... as the exceptions a caller of gzip.open() catches: EOFError for a file cut short, an OSError (BadGzipFile is one)
+    # for corrupt data
+    with pytest.raises(EOFError):
+        with gzip.open(bad, "rb") as fh:
+            list(F.readfastq_iter(fh, 50000, F.entryfunc, C.entrypos))
     notgz = tmp_path / "not.fq.gz"
     notgz.write_bytes(data)
     with pytest.raises(hip.FFQError, match="gzip"):
         st = hip.FileStream(gpu_ctx, os.open(notgz, os.O_RDONLY), 1 << 20, gzip=True)
         list(st)
+    with pytest.raises(OSError):
+        st = hip.FileStream(gpu_ctx, os.open(notgz, os.O_RDONLY), 1 << 20, gzip=True)
+        list(st)
+    # a gzip file object the library inflated itself is left exhausted, as the reference's loop leaves it
+    good = tmp_path / "good.fq.gz"
+    good.write_bytes(blob)
+    with gzip.open(good, "rb") as fh:
+        assert len(list(F.readfastq_iter(fh, 50000, F.entryfunc, C.entrypos))) == 2000
+        assert fh.read() == b""
+        assert list(F.readfastq_iter(fh, 50000, F.entryfunc, C.entrypos)) == []
     # an idle pipe: some records arrive, the writer keeps the pipe open; the first fill is handed over
     # short (not the end of the stream) and close() returns at once
     r, w = os.pipe()
