@@ -372,7 +372,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     # ---- this rank's byte range of the logical stream, generated in HBM ----------
     split = bool(wl.get("split"))                   # the workload's bytes are the whole job's, not one GPU's
     shard = sharded.SyntheticShard(ctx, wl["kind"], wl["bytes"] // world if split else wl["bytes"], rank, world, dev,
-                                   total_records=wl["bytes"] // 322 if split else None)
+                                   total_records=wl["bytes"] // 322 if split else None,
+                                   native=True if getattr(args, "native_step", False) else None)
     n_own = shard.n_own_bytes
     ctx.reserve(shard.ext.numel())
     table = torch.empty((shard.max_records + 64, 6), dtype=torch.int64, device=dev)
@@ -397,7 +398,11 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     settle_steps = int(args.settle_ms * 1e-3 / ((wl["bytes"] // world if split else wl["bytes"]) / 4.0e12)) if args.settle_ms > 0 else 0
     n_untimed = settle_steps + args.warmup
 
+    comm_steps = []
+
     def note(out):
+        if getattr(out, "comm", None):
+            comm_steps.append(out.comm)
         if out.res.ms_index > 0:                       # (steps submitted with FFQ_F_NO_TIMING carry no marks)
             ms_index.append(out.res.ms_index)
         ms_chain.append(out.res.ms_chain)
@@ -631,9 +636,24 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 "records_per_gpu": n_rec,
                 "total_bytes": total_bytes,
                 "total_records": total_records,
-                "sharding": ("byte ranges, halo hand-off over %s" % ("RCCL (torch.distributed backend nccl)" if dist.get_backend() == "nccl"
-                                                                     else "%s: a functional dry run, every rank on ONE GPU" % dist.get_backend())
+                "sharding": ("byte ranges, halo hand-off over %s" % (
+                                 ("RCCL, the step behind the C ABI (ffq_shard_step_submit / _wait)" if getattr(shard, "native", False)
+                                  else "RCCL through torch.distributed") if dist.get_backend() == "nccl"
+                                 else "%s: a functional dry run, every rank on ONE GPU" % dist.get_backend())
                              if world > 1 else "single range"),
+            },
+            # what a step costs beside its scan (N > 1, the library's own step: ffq_shard_step_*): device time of the halo
+            # hand-off (ncclSend / ncclRecv in one group, on the hand-off stream beside the previous step's scan) and of the
+            # gather of the eight hand-off words (ncclAllGather behind the scan), bytes handed off per rank and step, and how
+            # often a rank had to scan again (a look-ahead grown, a guessed entry contradicted) -- rank 0's figures
+            "comm": None if not comm_steps else {
+                "transport": "RCCL (ffq_shard_*, include/ffq.h)" if shard.scanner.sh.transport() == "rccl" else shard.scanner.sh.transport(),
+                "steps": len(comm_steps),
+                "handoff_ms": round(float(np.mean([c["handoff_ms"] for c in comm_steps])), 4),
+                "handoff_bytes": int(np.mean([c["handoff_bytes"] for c in comm_steps])),
+                "allgather_ms": round(float(np.mean([c["allgather_ms"] for c in comm_steps])), 4),
+                "rescan_rounds": int(sum(c["rescan_rounds"] for c in comm_steps)),
+                "regathers": int(sum(c["regathers"] for c in comm_steps)),
             },
             "roofline": {
                 "bound": "hbm",
@@ -698,10 +718,16 @@ def main():
                          "writes them itself: the input is read once")
     ap.add_argument("--sharded-step", action="store_true",
                     help="N=1 through the synchronous step the N>1 ranks run (diagnostics)")
+    ap.add_argument("--native-step", action="store_true",
+                    help="N=1 through the step the N>1 ranks run behind the C ABI (ffq_shard_step_submit / _wait on the library's "
+                         "RCCL transport, world 1, two lanes): its queueing, the gather of the hand-off words and the comm "
+                         "figures, with no peers (diagnostics)")
     ap.add_argument("--lanes-step", action="store_true",
                     help="N=1 through the pipelined step of the N>1 ranks (two lanes, hand-off with no peers): "
                          "what the host side of a sharded step costs (diagnostics)")
     args = ap.parse_args()
+    if args.native_step:
+        args.lanes_step = True
 
     import torch
     import fastqandfurious_amd  # noqa: F401
@@ -776,7 +802,7 @@ def main():
             torch.cuda.empty_cache()
             if rank == 0:
                 others[other] = {k: ol[k] for k in ("value", "unit", "m_reads_per_s", "n_gpus", "scaling", "ms_per_step",
-                                                     "ms_per_step_spread", "settle_steps", "config", "roofline",
+                                                     "ms_per_step_spread", "settle_steps", "config", "comm", "roofline",
                                                      "hbm_read_probe", "path_roofline")}
         if rank == 0:
             line["other_workloads"] = others

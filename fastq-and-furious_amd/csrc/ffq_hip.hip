@@ -1972,3 +1972,4 @@ extern "C" int ffq_selftest(ffq_ctx *c)
 }
 
 #include "ffq_stream.h"
+#include "ffq_shard.h"

@@ -1,0 +1,759 @@
+// ffq_shard.h -- byte-range sharding of ONE FASTQ stream over the GPUs of a node, behind the C ABI (ffq_shard_*,
+// include/ffq.h).  Included at the end of ffq_hip.hip.
+//
+// The reference has nothing like it (a single-threaded generator); what is sharded is the record chain of
+// readfastq_iter (/root/reference/src/fastqandfurious.py:251-279): rank r owns the stream bytes [S_r, S_r+1) and every
+// record whose '@' lies in them.  What the reference does with a record that does not fit its buffer -- keep buf[offset:]
+// and read more (:274-279) -- happens here per range edge.  One step of a rank:
+//   1. halo hand-off: ncclSend / ncclRecv inside ONE group, on a stream of its own beside the previous step's scan -- the
+//      tail_bytes in front of the range (run-in) and the head_bytes behind it (look-ahead), from whichever ranks own them;
+//   2. one ordinary scan of [tail | own | head] (ffq_scan_submit), the scan stream waiting for the hand-off's end event;
+//   3. k_shard_words, queued behind the scan: the rows with S_r <= pos0 < S_r+1 (two lower bounds over the table, as
+//      ffq_table_cut) and the EIGHT WORDS the ranks compare -- exit (first record start at / behind my right edge as my
+//      chain sees it), first (first record start in my range), own count, look-ahead wanted, look-ahead had, error,
+//      error byte, where the search that found the exit started;
+//   4. ONE ncclAllGather of those words (a communicator of its own, on the scan stream) and one copy to pinned memory:
+//      the host reads them when it waits for the step -- nothing else comes back before that.
+// exit[r] must equal first[r + 1]; rank 0's start is exact, so that proves every range by induction, and the counts give
+// global record ordinals.  A rank whose look-ahead ends inside the record that straddles its edge asks for more (served by
+// whoever owns the bytes) and scans again; a rank whose guessed entry its left neighbour's chain contradicts scans again
+// from that neighbour's exit; each round settles the first unsettled rank.  Stream errors (the iterator's three
+// ValueErrors) are reported by every rank alike, once the failing rank's entry is proven.
+//
+// This is the C++ restatement of the protocol fastq-and-furious_amd/sharded.py runs over torch.distributed (kept there for
+// the CPU tests over gloo); the transports here are RCCL (librccl, resolved at run time: the library loads without it) and
+// an in-process one (k logical ranks as threads of one process on one GPU: tests, single-GPU dry runs).
+#pragma once
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+
+namespace ffq {
+
+constexpr int64_t SH_NONE = -1;            // no record starts at / behind the bound: the view reaches the end of the stream
+constexpr int64_t SH_UNKNOWN = -2;         // not known yet (more look-ahead needed, or the guessed entry led nowhere)
+constexpr int64_t SH_ERR_TABLE_FULL = 100; // (beside the FFQ_END_ERR_* codes) the caller's table cannot hold the view's rows
+constexpr int64_t SH_NOT_READY = 101;      // this rank's scan needs a later tier (host round trip): gather again when it is through
+constexpr int SH_WORDS = 8;
+
+struct ShView {                            // a rank's [tail | own | head] buffer and its coordinates
+    int64_t lo, hi, total, origin;         // my range, the stream's end, the offset of the stream's first byte
+    int64_t tail, head;
+    int64_t start, add, n_bytes;           // stream offset of ext[0]; what turns buffer coordinates into stream offsets
+    int32_t sentinel, eof;
+};
+
+// ---- step 3 on the device: rows of my range + the hand-off words ----------------------------------------------------
+// out[0..7] the words, out[8] row_lo, out[9] row_hi, out[10] rows in the table
+__global__ __launch_bounds__(64) void k_shard_words(const DevRes *__restrict__ res, const int64_t *__restrict__ table,
+                                                    int64_t table_cap, ShView v, int64_t offset, int64_t head_bytes,
+                                                    int64_t *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int64_t n = res->n_records;
+    int64_t w[SH_WORDS] = {SH_UNKNOWN, SH_UNKNOWN, 0, 0, v.head, 0, 0, 0};
+    int64_t i0 = 0, i1 = 0, nrows = 0;
+    if (res->fallback) w[5] = SH_NOT_READY;
+    else if (n > table_cap) { w[5] = SH_ERR_TABLE_FULL; w[6] = n; }
+    else {
+        nrows = n;
+        const int64_t lo_b = (v.lo == v.origin) ? -(1ll << 62) : v.lo, hi_b = (v.hi == v.total) ? (1ll << 62) : v.hi;
+        int64_t cut[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {       // (the two lower bounds of k_table_cut: 64 probes per round trip)
+            const int64_t value = q ? hi_b : lo_b;
+            int64_t a = 0, b = n;
+            while (b - a > 0) {
+                const int64_t stride = (b - a + 63) / 64;
+                const int64_t i = a + (int64_t)lane * stride;
+                const bool below = (i < b) && (table[i * 6] < value);
+                const int k = __popcll(__ballot(below));
+                if (k == 0) { b = a; break; }
+                const int64_t last = a + (int64_t)(k - 1) * stride;
+                a = last + 1;
+                b = min(b, last + stride);
+            }
+            cut[q] = a;
+        }
+        i0 = cut[0]; i1 = cut[1];
+        const int64_t p_i0 = (i0 < n) ? table[i0 * 6] : -1, p_i1 = (i1 < n) ? table[i1 * 6] : -1;
+        const int64_t q1 = (i1 > 0) ? table[(i1 - 1) * 6 + 5] : -1;
+        const int end = res->end_state;
+        const int good = v.eof ? FFQ_END_OK : FFQ_END_REFILL;
+        // the entry the chain stops at (incomplete / invalid): a record start like the rows'
+        const bool have_inc = end != FFQ_END_OK && res->last_status != ST_HEAD_BEG && res->last_pos[0] >= 0;
+        const int64_t p_inc = have_inc ? res->last_pos[0] : 0;
+        const int64_t unknown = (v.eof && end == FFQ_END_OK) ? SH_NONE : SH_UNKNOWN;
+        auto edge = [&](int64_t idx, int64_t p_row, int64_t bound) -> int64_t {
+            if (idx < n) return p_row;
+            if (have_inc && p_inc >= bound) return p_inc;
+            return unknown;
+        };
+        w[1] = edge(i0, p_i0, v.lo);
+        w[0] = (v.hi < v.total) ? edge(i1, p_i1, v.hi) : SH_NONE;
+        w[2] = i1 - i0;
+        // where the search that found the exit started (the iterator's `offset`, :254): the right neighbour re-enters
+        // there if its own guess does not hold
+        w[7] = (i1 < n) ? ((i1 > 0) ? q1 - 1 : offset + v.add) : res->end_offset + v.add;
+        if (end == FFQ_END_ERR_FINAL_QUAL || end == FFQ_END_ERR_INCOMPLETE || end == FFQ_END_ERR_INVALID) {
+            // a stream error: mine if the failing entry starts in my range (or nowhere: no entry at all)
+            if (!have_inc || (v.lo <= p_inc && p_inc < v.hi) || (v.hi == v.total && p_inc >= v.lo)) {
+                w[5] = end; w[6] = res->end_offset + v.add;
+            } else if (p_inc < v.lo) w[0] = w[1] = SH_UNKNOWN;           // the guessed entry led nowhere
+        } else if (end != good) { w[5] = FFQ_E_INTERNAL; }
+        if (!v.eof && !w[5] && w[0] == SH_UNKNOWN && !(have_inc && p_inc < v.lo) && end == FFQ_END_REFILL)
+            // the record that straddles my right edge does not end inside the look-ahead
+            w[3] = min(max(max(2 * v.head, head_bytes), (int64_t)4096), v.total - v.hi);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < SH_WORDS; i++) out[i] = w[i];
+        out[8] = i0; out[9] = i1; out[10] = nrows;
+    }
+}
+
+struct ShPiece { int src, dst; int64_t a, b; };          // stream bytes [a, b) go from rank src to rank dst
+
+static void sh_range_plan(const std::vector<int64_t> &B, int dst, int64_t lo, int64_t hi, std::vector<ShPiece> &plan)
+{
+    for (int p = 0; p + 1 < (int)B.size(); p++) {
+        const int64_t a = std::max(lo, B[p]), b = std::min(hi, B[p + 1]);
+        if (a < b && p != dst) plan.push_back(ShPiece{p, dst, a, b});
+    }
+}
+
+static void sh_halo_sizes(const std::vector<int64_t> &B, int rank, int64_t tail_bytes, int64_t head_bytes, int64_t *tail, int64_t *head)
+{
+    *tail = std::min(tail_bytes, B[rank] - B[0]);
+    *head = std::min(head_bytes, B.back() - B[rank + 1]);
+}
+
+// ---- transports ---------------------------------------------------------------------------------------------------
+typedef std::function<uint8_t *(int64_t, int64_t)> ShPtrFn;
+
+struct ShTransport {
+    int rank = 0, world = 1;
+    virtual ~ShTransport() {}
+    // every piece of the plan this rank sends or receives, enqueued on `st`
+    virtual int exchange(const std::vector<ShPiece> &plan, const ShPtrFn &provide, const ShPtrFn &accept, hipStream_t st) = 0;
+    // the words of every rank: d_mine (device, SH_WORDS int64) -> h_all (pinned, world * SH_WORDS); enqueue on `st`, then finish
+    virtual int gather_enqueue(const int64_t *d_mine, int64_t *d_all, int64_t *h_all, hipStream_t st) = 0;
+    virtual int gather_finish(int64_t *h_all, hipEvent_t done) = 0;      // `done`: recorded behind gather_enqueue's work
+    virtual const char *name() const = 0;
+};
+
+// librccl, resolved at run time (a process that has PyTorch's copy loaded gets that one)
+struct RcclApi {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+};
+
+static RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {getenv("FFQ_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (int pass = 0; pass < 2 && !api.h; pass++)
+            for (const char *nm : names) {
+                if (!nm || !*nm) continue;
+                api.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));      // first: a copy the process already holds
+                if (api.h) break;
+            }
+        if (!api.h) return;
+#define FFQ_RCCL_SYM(f) api.f = reinterpret_cast<decltype(api.f)>(dlsym(api.h, "nccl" #f))
+        FFQ_RCCL_SYM(GetUniqueId); FFQ_RCCL_SYM(CommInitRank); FFQ_RCCL_SYM(CommDestroy); FFQ_RCCL_SYM(GetErrorString);
+        FFQ_RCCL_SYM(AllGather); FFQ_RCCL_SYM(Broadcast); FFQ_RCCL_SYM(Send); FFQ_RCCL_SYM(Recv); FFQ_RCCL_SYM(GroupStart); FFQ_RCCL_SYM(GroupEnd);
+#undef FFQ_RCCL_SYM
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.Broadcast || !api.Send || !api.Recv ||
+            !api.GroupStart || !api.GroupEnd)
+            api.h = nullptr;
+    });
+    return api.h ? &api : nullptr;
+}
+
+#define RCCLCHK(expr)                                                                                           \
+    do {                                                                                                        \
+        ncclResult_t r__ = (expr);                                                                              \
+        if (r__ != ncclSuccess)                                                                                 \
+            return fail(FFQ_E_HIP, "%s failed: %s", #expr, A->GetErrorString ? A->GetErrorString(r__) : "rccl error"); \
+    } while (0)
+
+// RCCL over xGMI: the hand-offs and the gather on communicators of their own (one per stream: the hand-off of step i + 1
+// runs beside the scan of step i, the gather of step i behind that scan)
+struct ShRccl : ShTransport {
+    RcclApi *A = nullptr;
+    ncclComm_t cx = nullptr, cg = nullptr;
+    bool owner = true;                     // (a shard created beside another one borrows its communicators)
+    ~ShRccl() override
+    {
+        if (owner && A) { if (cx) A->CommDestroy(cx); if (cg) A->CommDestroy(cg); }
+    }
+    int init(const uint8_t *id128, int rank_, int world_, hipStream_t st)
+    {
+        A = rccl_api();
+        if (!A) return fail(FFQ_E_NODEVICE, "ffq_shard: librccl could not be loaded (FFQ_RCCL_LIB names another copy)");
+        rank = rank_; world = world_;
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof id);
+        RCCLCHK(A->CommInitRank(&cx, world, id, rank));
+        // the second communicator: rank 0 draws its id and sends it round over the first
+        ncclUniqueId id2;
+        if (rank == 0) RCCLCHK(A->GetUniqueId(&id2));
+        uint8_t *d_id = nullptr;
+        HIPCHK(hipMalloc((void **)&d_id, sizeof id2));
+        if (rank == 0) HIPCHK(hipMemcpyAsync(d_id, &id2, sizeof id2, hipMemcpyHostToDevice, st));
+        RCCLCHK(A->Broadcast(d_id, d_id, sizeof id2, ncclUint8, 0, cx, st));
+        HIPCHK(hipMemcpyAsync(&id2, d_id, sizeof id2, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        (void)hipFree(d_id);
+        RCCLCHK(A->CommInitRank(&cg, world, id2, rank));
+        return FFQ_OK;
+    }
+    int exchange(const std::vector<ShPiece> &plan, const ShPtrFn &provide, const ShPtrFn &accept, hipStream_t st) override
+    {
+        bool any = false;
+        for (const ShPiece &p : plan) any = any || p.src == rank || p.dst == rank;
+        if (!any) return FFQ_OK;
+        RCCLCHK(A->GroupStart());
+        for (const ShPiece &p : plan) {
+            if (p.src == rank) RCCLCHK(A->Send(provide(p.a, p.b), (size_t)(p.b - p.a), ncclUint8, p.dst, cx, st));
+            if (p.dst == rank) RCCLCHK(A->Recv(accept(p.a, p.b), (size_t)(p.b - p.a), ncclUint8, p.src, cx, st));
+        }
+        RCCLCHK(A->GroupEnd());
+        return FFQ_OK;
+    }
+    int gather_enqueue(const int64_t *d_mine, int64_t *d_all, int64_t *h_all, hipStream_t st) override
+    {
+        RCCLCHK(A->AllGather(d_mine, d_all, SH_WORDS, ncclInt64, cg, st));
+        HIPCHK(hipMemcpyAsync(h_all, d_all, (size_t)world * SH_WORDS * 8, hipMemcpyDeviceToHost, st));
+        return FFQ_OK;
+    }
+    // (the event, not the stream: the next step's front may already be queued behind this one's gather)
+    int gather_finish(int64_t *, hipEvent_t done) override { HIPCHK(hipEventSynchronize(done)); return FFQ_OK; }
+    const char *name() const override { return "rccl"; }
+};
+
+}  // namespace ffq
+
+// k logical ranks as threads of ONE process (ranges of one resident buffer on one GPU)
+struct ffq_shard_world {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t gen = 0;
+    bool broken = false;
+    // a barrier that can be broken (a rank that fails must not leave the others waiting)
+    bool wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
+        const uint64_t g = gen;
+        if (++waiting == world) { waiting = 0; gen++; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return gen != g || broken; });
+        return !broken;
+    }
+    void abort() { std::lock_guard<std::mutex> lk(m); broken = true; cv.notify_all(); }
+    std::vector<const ffq::ShPtrFn *> providers;
+    std::vector<int64_t> slots;
+};
+
+namespace ffq {
+
+struct ShLocal : ShTransport {
+    ffq_shard_world *W = nullptr;
+    int exchange(const std::vector<ShPiece> &plan, const ShPtrFn &provide, const ShPtrFn &accept, hipStream_t st) override
+    {
+        W->providers[rank] = &provide;
+        if (!W->wait()) return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
+        hipError_t e = hipSuccess;
+        for (const ShPiece &p : plan)
+            if (p.dst == rank && e == hipSuccess)
+                e = hipMemcpyAsync(accept(p.a, p.b), (*W->providers[p.src])(p.a, p.b), (size_t)(p.b - p.a), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);            // the sources must stay as they are until read
+        if (!W->wait()) return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
+        if (e != hipSuccess) return fail(FFQ_E_HIP, "ffq_shard: hand-off copy failed: %s", hipGetErrorString(e));
+        return FFQ_OK;
+    }
+    int gather_enqueue(const int64_t *d_mine, int64_t *, int64_t *h_all, hipStream_t st) override
+    {
+        HIPCHK(hipMemcpyAsync(h_all + (size_t)rank * SH_WORDS, d_mine, SH_WORDS * 8, hipMemcpyDeviceToHost, st));
+        return FFQ_OK;
+    }
+    int gather_finish(int64_t *h_all, hipEvent_t done) override
+    {
+        HIPCHK(hipEventSynchronize(done));
+        memcpy(&W->slots[(size_t)rank * SH_WORDS], h_all + (size_t)rank * SH_WORDS, SH_WORDS * 8);
+        if (!W->wait()) return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
+        memcpy(h_all, W->slots.data(), (size_t)world * SH_WORDS * 8);
+        if (!W->wait()) return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
+        return FFQ_OK;
+    }
+    const char *name() const override { return "in-process"; }
+};
+
+}  // namespace ffq
+
+using namespace ffq;
+
+struct ffq_shard {
+    ffq_ctx *c = nullptr;
+    ShTransport *tr = nullptr;
+    bool owns_tr = true;
+    int rank = 0, world = 1;
+    std::vector<int64_t> B;                // S_0 .. S_world
+    int64_t tail_bytes = 0, head_bytes = 0;
+    int64_t lo = 0, hi = 0, total = 0, origin = 0;
+    hipStream_t comm = nullptr;            // the hand-off stream
+    hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_g[2] = {nullptr, nullptr};
+    int64_t *d_words = nullptr;            // [16]: the words, row_lo, row_hi, rows
+    int64_t *d_all = nullptr;              // [world * SH_WORDS]
+    int64_t *h_all = nullptr, *h_own = nullptr;      // pinned
+    uint8_t *grown = nullptr;              // a view with more look-ahead than the caller's buffer has room for
+    int64_t grown_cap = 0;
+    // the pending step
+    bool pending = false, handoff_timed = false;
+    ShView v{};
+    uint8_t *ext = nullptr;
+    int64_t start = -1;                    // stream offset the first search of the last local scan started at (-1: the view's start)
+    uint32_t flags = 0;
+    int qual_add = 0;
+    int64_t *d_table = nullptr, table_cap = 0, *d_qoff = nullptr, qual_cap = 0;
+    int8_t *d_qual = nullptr;
+    int64_t handoff_bytes = 0;
+};
+
+static ShView sh_view(const ffq_shard *s, int64_t tail, int64_t head)
+{
+    ShView v;
+    v.lo = s->lo; v.hi = s->hi; v.total = s->total; v.origin = s->origin;
+    v.tail = tail; v.head = head;
+    v.start = s->lo - tail;
+    v.sentinel = v.start == s->origin ? 1 : 0;
+    v.eof = (s->hi + head == s->total) ? 1 : 0;
+    v.add = v.start - (v.sentinel ? 1 : 0);
+    v.n_bytes = tail + (s->hi - s->lo) + head;
+    return v;
+}
+
+static int shard_alloc(ffq_shard *s)
+{
+    HIPCHK(hipSetDevice(s->c->device));
+    HIPCHK(hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking));
+    for (auto &e : s->ev_x) HIPCHK(hipEventCreate(&e));
+    for (auto &e : s->ev_g) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipMalloc((void **)&s->d_words, 16 * 8));
+    HIPCHK(hipMalloc((void **)&s->d_all, (size_t)s->world * SH_WORDS * 8));
+    HIPCHK(hipHostMalloc((void **)&s->h_all, (size_t)s->world * SH_WORDS * 8, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&s->h_own, 16 * 8, hipHostMallocDefault));
+    return FFQ_OK;
+}
+
+static int shard_common(ffq_ctx *c, int rank, int world, const int64_t *bounds, int64_t tail_bytes, int64_t head_bytes, ffq_shard **out)
+{
+    if (!c || !bounds || !out) return fail(FFQ_E_ARG, "ffq_shard_create: NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(FFQ_E_ARG, "ffq_shard_create: rank %d of %d", rank, world);
+    // (the byte in front of the range must be in view: a record that starts at the range's first byte is found through
+    // the "\n" before it)
+    if (tail_bytes < 1 || head_bytes < 1) return fail(FFQ_E_ARG, "ffq_shard_create: tail_bytes and head_bytes must be at least 1");
+    for (int r = 0; r < world; r++)
+        if (bounds[r] > bounds[r + 1]) return fail(FFQ_E_ARG, "ffq_shard_create: bounds must not decrease");
+    ffq_shard *s = new (std::nothrow) ffq_shard();
+    if (!s) return fail(FFQ_E_NOMEM, "out of host memory");
+    s->c = c; s->rank = rank; s->world = world;
+    s->B.assign(bounds, bounds + world + 1);
+    s->tail_bytes = tail_bytes; s->head_bytes = head_bytes;
+    s->lo = bounds[rank]; s->hi = bounds[rank + 1]; s->total = bounds[world]; s->origin = bounds[0];
+    *out = s;
+    return FFQ_OK;
+}
+
+extern "C" void ffq_shard_destroy(ffq_shard *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->c->device);
+    if (s->comm) { (void)hipStreamSynchronize(s->comm); }
+    (void)hipStreamSynchronize(s->c->stream);
+    if (s->owns_tr) delete s->tr;
+    if (s->comm) (void)hipStreamDestroy(s->comm);
+    for (auto e : s->ev_x) if (e) (void)hipEventDestroy(e);
+    for (auto e : s->ev_g) if (e) (void)hipEventDestroy(e);
+    (void)hipFree(s->d_words); (void)hipFree(s->d_all); (void)hipFree(s->grown);
+    if (s->h_all) (void)hipHostFree(s->h_all);
+    if (s->h_own) (void)hipHostFree(s->h_own);
+    delete s;
+}
+
+extern "C" int ffq_shard_unique_id(uint8_t *id128)
+{
+    if (!id128) return fail(FFQ_E_ARG, "ffq_shard_unique_id: NULL argument");
+    RcclApi *A = rccl_api();
+    if (!A) return fail(FFQ_E_NODEVICE, "ffq_shard: librccl could not be loaded (FFQ_RCCL_LIB names another copy)");
+    ncclUniqueId id;
+    RCCLCHK(A->GetUniqueId(&id));
+    static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof id);
+    return FFQ_OK;
+}
+
+extern "C" int ffq_shard_create(ffq_ctx *c, const uint8_t *id128, int rank, int world, const int64_t *bounds,
+                                int64_t tail_bytes, int64_t head_bytes, ffq_shard **out)
+{
+    if (!id128) return fail(FFQ_E_ARG, "ffq_shard_create: NULL unique id");
+    int rc = shard_common(c, rank, world, bounds, tail_bytes, head_bytes, out);
+    if (rc) return rc;
+    ffq_shard *s = *out;
+    *out = nullptr;
+    rc = shard_alloc(s);
+    if (!rc) {
+        ShRccl *t = new (std::nothrow) ShRccl();
+        s->tr = t;
+        rc = t ? t->init(id128, rank, world, s->comm) : fail(FFQ_E_NOMEM, "out of host memory");
+    }
+    if (rc) { ffq_shard_destroy(s); return rc; }
+    *out = s;
+    return FFQ_OK;
+}
+
+// a second shard object of the same rank on another context (own scratch, own buffers: steps queued one ahead), on the
+// first one's communicators
+extern "C" int ffq_shard_create_lane(ffq_shard *parent, ffq_ctx *c, ffq_shard **out)
+{
+    if (!parent || !c || !out) return fail(FFQ_E_ARG, "ffq_shard_create_lane: NULL argument");
+    int rc = shard_common(c, parent->rank, parent->world, parent->B.data(), parent->tail_bytes, parent->head_bytes, out);
+    if (rc) return rc;
+    ffq_shard *s = *out;
+    *out = nullptr;
+    rc = shard_alloc(s);
+    if (rc) { ffq_shard_destroy(s); return rc; }
+    s->tr = parent->tr; s->owns_tr = false;
+    *out = s;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_shard_world_create(int world, ffq_shard_world **out)
+{
+    if (!out || world < 1) return fail(FFQ_E_ARG, "ffq_shard_world_create: bad argument");
+    ffq_shard_world *w = new (std::nothrow) ffq_shard_world();
+    if (!w) return fail(FFQ_E_NOMEM, "out of host memory");
+    w->world = world;
+    w->providers.assign(world, nullptr);
+    w->slots.assign((size_t)world * SH_WORDS, 0);
+    *out = w;
+    return FFQ_OK;
+}
+extern "C" void ffq_shard_world_abort(ffq_shard_world *w) { if (w) w->abort(); }
+extern "C" void ffq_shard_world_destroy(ffq_shard_world *w) { delete w; }
+
+extern "C" int ffq_shard_create_local(ffq_ctx *c, ffq_shard_world *w, int rank, const int64_t *bounds, int64_t tail_bytes,
+                                      int64_t head_bytes, ffq_shard **out)
+{
+    if (!w) return fail(FFQ_E_ARG, "ffq_shard_create_local: NULL world");
+    int rc = shard_common(c, rank, w->world, bounds, tail_bytes, head_bytes, out);
+    if (rc) return rc;
+    ffq_shard *s = *out;
+    *out = nullptr;
+    rc = shard_alloc(s);
+    if (!rc) {
+        ShLocal *t = new (std::nothrow) ShLocal();
+        if (t) { t->W = w; t->rank = rank; t->world = w->world; }
+        s->tr = t;
+        if (!t) rc = fail(FFQ_E_NOMEM, "out of host memory");
+    }
+    if (rc) { ffq_shard_destroy(s); return rc; }
+    *out = s;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_shard_halo(ffq_shard *s, int64_t *tail, int64_t *head)
+{
+    if (!s || !tail || !head) return fail(FFQ_E_ARG, "ffq_shard_halo: NULL argument");
+    sh_halo_sizes(s->B, s->rank, s->tail_bytes, s->head_bytes, tail, head);
+    return FFQ_OK;
+}
+
+// one exchange: this rank provides its own bytes out of `ext` and receives what the plan sends it into dst_ext (stream
+// offset dst_start at index 0)
+static int shard_serve(ffq_shard *s, const std::vector<ShPiece> &plan, uint8_t *ext, int64_t tail, uint8_t *dst_ext,
+                       int64_t dst_start, hipStream_t st)
+{
+    const int64_t own_lo = s->lo;
+    ShPtrFn provide = [=](int64_t a, int64_t) { return ext + tail + (a - own_lo); };
+    ShPtrFn accept = [=](int64_t a, int64_t) { return dst_ext + (a - dst_start); };
+    for (const ShPiece &p : plan) {
+        if (p.src == s->rank) s->handoff_bytes += p.b - p.a;
+        if (p.dst == s->rank) s->handoff_bytes += p.b - p.a;
+    }
+    return s->tr->exchange(plan, provide, accept, st);
+}
+
+// step 1 alone (a caller that scans by other means): fills ext[:tail] and ext[tail + own : tail + own + head]
+static int shard_handoff(ffq_shard *s, uint8_t *ext, int64_t tail, bool overlap)
+{
+    if (s->world < 2) return FFQ_OK;
+    std::vector<ShPiece> plan;
+    for (int q = 0; q < s->world; q++) {
+        int64_t t, h;
+        sh_halo_sizes(s->B, q, s->tail_bytes, s->head_bytes, &t, &h);
+        sh_range_plan(s->B, q, s->B[q] - t, s->B[q], plan);
+        sh_range_plan(s->B, q, s->B[q + 1], s->B[q + 1] + h, plan);
+    }
+    mark_other(s->c);
+    hipStream_t st = overlap ? s->comm : s->c->stream;
+    HIPCHK(hipEventRecord(s->ev_x[0], st));
+    int rc = shard_serve(s, plan, ext, tail, ext, s->lo - tail, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(s->ev_x[1], st));
+    if (overlap) HIPCHK(hipStreamWaitEvent(s->c->stream, s->ev_x[1], 0));
+    s->handoff_timed = true;
+    return FFQ_OK;
+}
+
+// steps 3-4 behind a scan of view v that searched from buffer offset `offset`
+static int shard_words_and_gather(ffq_shard *s, int64_t offset)
+{
+    ffq_ctx *c = s->c;
+    hipStream_t st = c->stream;
+    mark_other(c);
+    hipLaunchKernelGGL(k_shard_words, dim3(1), dim3(64), 0, st, (const DevRes *)c->dres, (const int64_t *)s->d_table, s->table_cap,
+                       s->v, offset, s->head_bytes, s->d_words);
+    HIPCHK(hipMemcpyAsync(s->h_own, s->d_words, 16 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(s->ev_g[0], st));
+    int rc = s->tr->gather_enqueue(s->d_words, s->d_all, s->h_all, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(s->ev_g[1], st));
+    HIPCHK(hipGetLastError());
+    return FFQ_OK;
+}
+
+// words set on the host (a rank that learns that the chain passes over its whole range): the next gather carries them
+static int shard_gather_host_words(ffq_shard *s)
+{
+    hipStream_t st = s->c->stream;
+    mark_other(s->c);
+    HIPCHK(hipMemcpyAsync(s->d_words, s->h_own, 16 * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(s->ev_g[0], st));
+    int rc = s->tr->gather_enqueue(s->d_words, s->d_all, s->h_all, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(s->ev_g[1], st));
+    return FFQ_OK;
+}
+
+extern "C" int ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_handoff, uint32_t flags, int qual_add,
+                                     int64_t *d_table, int64_t table_cap, int8_t *d_qual, int64_t qual_cap, int64_t *d_qoff)
+{
+    if (!s || !d_ext) return fail(FFQ_E_ARG, "ffq_shard_step_submit: NULL argument");
+    if (s->pending) return fail(FFQ_E_ARG, "ffq_shard_step_submit: a step is already pending on this shard");
+    ffq_ctx *c = s->c;
+    HIPCHK(hipSetDevice(c->device));
+    int64_t tail, head;
+    sh_halo_sizes(s->B, s->rank, s->tail_bytes, s->head_bytes, &tail, &head);
+    s->v = sh_view(s, tail, head);
+    s->ext = d_ext; s->start = -1;
+    s->flags = flags & ~(uint32_t)FFQ_F_NO_TIMING; s->qual_add = qual_add;
+    s->d_table = d_table; s->table_cap = table_cap; s->d_qual = d_qual; s->qual_cap = qual_cap; s->d_qoff = d_qoff;
+    s->handoff_bytes = 0; s->handoff_timed = false;
+    int rc = shard_handoff(s, d_ext, tail, overlap_handoff != 0);
+    if (rc) return rc;
+    rc = ffq_scan_submit(c, d_ext, s->v.n_bytes, s->v.sentinel, 0, s->v.eof, s->v.add, s->flags, qual_add, d_table, table_cap,
+                         d_qual, qual_cap, d_qoff);
+    if (rc) return rc;
+    if (s->v.n_bytes == 0) {
+        // an empty view (nothing is enqueued for it, the device holds no result block of this scan): its words on the host --
+        // no rows, the search "ended" at the view's start, more look-ahead wanted unless the view ends the stream
+        const ShView &v = s->v;
+        int64_t *h = s->h_own;
+        const int64_t unknown = v.eof ? SH_NONE : SH_UNKNOWN;
+        h[1] = unknown; h[0] = (v.hi < v.total) ? unknown : SH_NONE; h[2] = 0;
+        h[3] = (!v.eof && h[0] == SH_UNKNOWN) ? std::min(std::max<int64_t>(std::max(2 * v.head, s->head_bytes), 4096), v.total - v.hi) : 0;
+        h[4] = v.head; h[5] = 0; h[6] = 0; h[7] = v.add; h[8] = h[9] = h[10] = 0;
+        rc = shard_gather_host_words(s);
+    } else rc = shard_words_and_gather(s, 0);
+    if (rc) return rc;
+    s->pending = true;
+    return FFQ_OK;
+}
+
+// a synchronous scan of the current view from stream offset `start` (< 0: the view's beginning), its words gathered
+static int shard_local(ffq_shard *s, ffq_scan_result *res, int64_t start)
+{
+    const int64_t offset = start < 0 ? 0 : std::max(start, s->v.start) - s->v.add;
+    s->start = start;
+    int rc = ffq_scan_device(s->c, s->ext, s->v.n_bytes, s->v.sentinel, offset, s->v.eof, s->v.add, s->flags, s->qual_add,
+                             s->d_table, s->table_cap, s->d_qual, s->qual_cap, s->d_qoff, res);
+    if (rc && rc != FFQ_E_TABLE_FULL) return rc;
+    return shard_words_and_gather(s, offset);
+}
+
+extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
+{
+    if (!s || !out) return fail(FFQ_E_ARG, "ffq_shard_step_wait: NULL argument");
+    if (!s->pending) return fail(FFQ_E_ARG, "ffq_shard_step_wait: no step is pending on this shard");
+    s->pending = false;
+    memset(out, 0, sizeof *out);
+    ffq_ctx *c = s->c;
+    HIPCHK(hipSetDevice(c->device));
+    const int W = s->world, rank = s->rank;
+    const std::vector<int64_t> &B = s->B;
+    int rc = ffq_scan_wait(c, &out->scan);
+    if (rc && rc != FFQ_E_TABLE_FULL) return rc;
+    int rounds = 0, regathers = 0;
+    float ms = 0;
+    for (;;) {
+        rc = s->tr->gather_finish(s->h_all, s->ev_g[1]);
+        if (rc) return rc;
+        if (hipEventElapsedTime(&ms, s->ev_g[0], s->ev_g[1]) == hipSuccess) out->allgather_ms += ms;
+        const int64_t *A = s->h_all;
+        auto word = [&](int r, int k) { return A[(size_t)r * SH_WORDS + k]; };
+        bool not_ready = false;
+        for (int r = 0; r < W; r++) {
+            if (word(r, 5) == SH_ERR_TABLE_FULL) {
+                out->scan.n_records = word(r, 6);
+                return fail(FFQ_E_TABLE_FULL, "rank %d: offset table too small (%lld records in its view)", r, (long long)word(r, 6));
+            }
+            if (word(r, 5) == FFQ_E_INTERNAL) return fail(FFQ_E_INTERNAL, "rank %d: unexpected end state of its scan", r);
+            not_ready = not_ready || word(r, 5) == SH_NOT_READY;
+        }
+        if (not_ready) {
+            // some rank's scan needed a later tier (a host round trip inside its ffq_scan_wait): every rank's scan is through
+            // by now -- the words once more
+            if (++regathers > 4) return fail(FFQ_E_INTERNAL, "sharded scan: a rank's result does not become ready");
+            int64_t off = s->start < 0 ? 0 : std::max(s->start, s->v.start) - s->v.add;
+            rc = shard_words_and_gather(s, off);
+            if (rc) return rc;
+            continue;
+        }
+        std::vector<int> grow, force;
+        for (int r = 0; r < W; r++) if (word(r, 3) > 0) grow.push_back(r);
+        for (int r = 1; r < W; r++)
+            if (B[r] > B[0] && word(r - 1, 0) != SH_UNKNOWN && word(r, 1) != word(r - 1, 0)) force.push_back(r);
+        if (grow.empty() && force.empty()) {
+            for (int r = 0; r < W; r++) {
+                if (word(r, 5)) {
+                    // The byte the iterator names is its `offset` when the failing search started: pos5 - 1 of the last
+                    // COMPLETE record in front of the failing entry (:254, :275).  A rank that owns no row in front of that
+                    // entry does not know it: the nearest rank to the left that owns a row (or rank 0, whose start is exact)
+                    // has it as the start of the search that found its exit.
+                    int64_t byte = word(r, 6);
+                    if (r > 0 && word(r, 2) == 0) {
+                        int q = r - 1;
+                        while (q > 0 && word(q, 2) == 0) q--;
+                        byte = word(q, 7);
+                    }
+                    out->err_state = (int32_t)word(r, 5);
+                    out->err_byte = byte;
+                    break;                          // (every rank reports the same error)
+                }
+                if (word(r, 0) == SH_UNKNOWN) return fail(FFQ_E_INTERNAL, "sharded scan: rank %d has no exit and nobody can move", r);
+            }
+            break;
+        }
+        if (++rounds > 2 * W + 48) return fail(FFQ_E_INTERNAL, "sharded scan does not settle (%d rounds)", rounds);
+        const bool i_grow = std::find(grow.begin(), grow.end(), rank) != grow.end();
+        const bool i_force = std::find(force.begin(), force.end(), rank) != force.end();
+        int64_t start = s->start;
+        if (!grow.empty()) {
+            std::vector<ShPiece> plan;
+            for (int r : grow) sh_range_plan(B, r, B[r + 1] + word(r, 4), B[r + 1] + word(r, 3), plan);
+            uint8_t *src_ext = s->ext;
+            uint8_t *dst_ext = s->ext;
+            int64_t dst_start = s->v.start;
+            ShView nv = s->v;
+            if (i_grow) {
+                // a view with more look-ahead (the caller's buffer has room for its own halo only)
+                nv = sh_view(s, s->v.tail, word(rank, 3));
+                uint8_t *old_grown = nullptr;
+                if (nv.n_bytes + 64 > s->grown_cap || s->ext == s->grown) {
+                    uint8_t *g = nullptr;
+                    const int64_t cap = nv.n_bytes + 64;
+                    if (hipMalloc((void **)&g, (size_t)cap) != hipSuccess) return fail(FFQ_E_NOMEM, "ffq_shard: no memory for a view of %lld bytes", (long long)cap);
+                    old_grown = s->grown;
+                    s->grown = g; s->grown_cap = cap;
+                }
+                mark_other(c);
+                HIPCHK(hipMemcpyAsync(s->grown, s->ext, (size_t)s->v.n_bytes, hipMemcpyDeviceToDevice, c->stream));
+                dst_ext = s->grown; dst_start = nv.start;
+                if (old_grown) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(old_grown); }
+            }
+            mark_other(c);
+            rc = shard_serve(s, plan, src_ext, s->v.tail, dst_ext, dst_start, c->stream);
+            if (rc) return rc;
+            if (i_grow) { s->ext = s->grown; s->v = nv; }
+        }
+        bool rescan = i_grow || i_force;
+        if (i_force) {
+            const int64_t prev = word(rank - 1, 0);
+            if (prev == SH_NONE || (prev >= s->v.hi && s->v.hi < s->v.total)) {
+                // the chain passes over my whole range (or ends before it): I own nothing
+                int64_t *h = s->h_own;
+                h[0] = prev; h[1] = prev; h[2] = 0; h[3] = 0; h[4] = s->v.head; h[5] = 0; h[6] = 0; h[7] = word(rank - 1, 7);
+                h[8] = 0; h[9] = 0; h[10] = 0;
+                s->start = word(rank - 1, 7);
+                rc = shard_gather_host_words(s);
+                if (rc) return rc;
+                continue;
+            }
+            start = word(rank - 1, 7);
+        }
+        if (rescan) rc = shard_local(s, &out->scan, start);
+        else rc = shard_gather_host_words(s);      // (my words stand: the others' rounds need them again)
+        if (rc) return rc;
+    }
+    // the hand-off's own time (events on the stream it ran on)
+    if (s->handoff_timed && hipEventElapsedTime(&ms, s->ev_x[0], s->ev_x[1]) == hipSuccess) out->handoff_ms = ms;
+    const int64_t *h = s->h_own;
+    out->n_rows = h[10]; out->row_lo = h[8]; out->row_hi = h[9];
+    out->exit_pos = h[0]; out->first_pos = h[1];
+    out->n_own_records = h[9] - h[8];
+    int64_t base = 0, tot = 0;
+    for (int r = 0; r < W; r++) {
+        const int64_t cnt = s->h_all[(size_t)r * SH_WORDS + 2];
+        if (r < rank) base += cnt;
+        tot += cnt;
+    }
+    out->record_base = base; out->total_records = tot;
+    out->rounds = rounds; out->regathers = regathers;
+    out->handoff_bytes = s->handoff_bytes;
+    out->d_ext = s->ext; out->tail = s->v.tail; out->head = s->v.head;
+    return FFQ_OK;
+}
+
+// step 1 alone, for a caller that runs the scan itself: the halos of d_ext from the ranks that own them (on the scan
+// stream, or -- overlap -- on the hand-off stream with the scan stream waiting for its end)
+extern "C" int ffq_shard_exchange_halo(ffq_shard *s, uint8_t *d_ext, int overlap)
+{
+    if (!s || !d_ext) return fail(FFQ_E_ARG, "ffq_shard_exchange_halo: NULL argument");
+    HIPCHK(hipSetDevice(s->c->device));
+    int64_t tail, head;
+    sh_halo_sizes(s->B, s->rank, s->tail_bytes, s->head_bytes, &tail, &head);
+    return shard_handoff(s, d_ext, tail, overlap != 0);
+}
+
+// n bytes from d_src to d_dst through the shard's transport, this rank being both ends (ncclSend + ncclRecv to itself in
+// one group on the hand-off stream): what a world of one rank can exercise of the hand-off path
+extern "C" int ffq_shard_self_exchange(ffq_shard *s, const uint8_t *d_src, uint8_t *d_dst, int64_t n)
+{
+    if (!s || !d_src || !d_dst || n < 0) return fail(FFQ_E_ARG, "ffq_shard_self_exchange: bad argument");
+    HIPCHK(hipSetDevice(s->c->device));
+    std::vector<ShPiece> plan{ShPiece{s->rank, s->rank, 0, n}};
+    ShPtrFn provide = [=](int64_t a, int64_t) { return const_cast<uint8_t *>(d_src) + a; };
+    ShPtrFn accept = [=](int64_t a, int64_t) { return d_dst + a; };
+    int rc = s->tr->exchange(plan, provide, accept, s->comm);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(s->comm));
+    return FFQ_OK;
+}
+
+extern "C" const char *ffq_shard_transport(ffq_shard *s) { return s && s->tr ? s->tr->name() : ""; }

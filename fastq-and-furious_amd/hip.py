@@ -48,7 +48,10 @@ SYMBOLS = (
     "ffq_scan_device", "ffq_scan_submit", "ffq_scan_wait", "ffq_scan_host", "ffq_entrypos", "ffq_arrayadd_b_device",
     "ffq_arrayadd_b", "ffq_arrayadd_q_device", "ffq_arrayadd_q", "ffq_table_lower_bound",
     "ffq_table_select_seqlen", "ffq_table_cut", "ffq_table_gather_column", "ffq_stream_open", "ffq_stream_next", "ffq_stream_close",
-    "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_stream_path", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_stream_open_push",
+    "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_stream_path",
+    "ffq_shard_unique_id", "ffq_shard_create", "ffq_shard_create_lane", "ffq_shard_world_create", "ffq_shard_world_abort",
+    "ffq_shard_world_destroy", "ffq_shard_create_local", "ffq_shard_destroy", "ffq_shard_halo", "ffq_shard_exchange_halo",
+    "ffq_shard_step_submit", "ffq_shard_step_wait", "ffq_shard_transport", "ffq_shard_self_exchange", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_stream_open_push",
     "ffq_stream_push_buffer", "ffq_stream_push", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
@@ -70,6 +73,21 @@ class ScanResult(ctypes.Structure):
         ("ms_chain", ctypes.c_float),
         ("ms_decode", ctypes.c_float),
         ("ms_total", ctypes.c_float),
+    ]
+
+
+class ShardResult(ctypes.Structure):
+    """ffq_shard_result (include/ffq.h)."""
+    _fields_ = [
+        ("scan", ScanResult),
+        ("n_rows", ctypes.c_int64), ("row_lo", ctypes.c_int64), ("row_hi", ctypes.c_int64),
+        ("exit_pos", ctypes.c_int64), ("first_pos", ctypes.c_int64),
+        ("n_own_records", ctypes.c_int64), ("record_base", ctypes.c_int64), ("total_records", ctypes.c_int64),
+        ("err_byte", ctypes.c_int64),
+        ("err_state", ctypes.c_int32), ("rounds", ctypes.c_int32), ("regathers", ctypes.c_int32), ("pad_", ctypes.c_int32),
+        ("handoff_bytes", ctypes.c_int64),
+        ("handoff_ms", ctypes.c_float), ("allgather_ms", ctypes.c_float),
+        ("d_ext", ctypes.c_void_p), ("tail", ctypes.c_int64), ("head", ctypes.c_int64),
     ]
 
 
@@ -219,6 +237,24 @@ def lib():
         L.ffq_stream_tell.restype = i64
         L.ffq_stream_path.argtypes = [vp]
         L.ffq_stream_path.restype = i32
+        L.ffq_shard_unique_id.argtypes = [vp]
+        L.ffq_shard_create.argtypes = [vp, vp, i32, i32, P(i64), i64, i64, P(vp)]
+        L.ffq_shard_create_lane.argtypes = [vp, vp, P(vp)]
+        L.ffq_shard_world_create.argtypes = [i32, P(vp)]
+        L.ffq_shard_world_abort.argtypes = [vp]
+        L.ffq_shard_world_abort.restype = None
+        L.ffq_shard_world_destroy.argtypes = [vp]
+        L.ffq_shard_world_destroy.restype = None
+        L.ffq_shard_create_local.argtypes = [vp, vp, i32, P(i64), i64, i64, P(vp)]
+        L.ffq_shard_destroy.argtypes = [vp]
+        L.ffq_shard_destroy.restype = None
+        L.ffq_shard_halo.argtypes = [vp, P(i64), P(i64)]
+        L.ffq_shard_exchange_halo.argtypes = [vp, vp, i32]
+        L.ffq_shard_step_submit.argtypes = [vp, vp, i32, u32, i32, vp, i64, vp, i64, vp]
+        L.ffq_shard_step_wait.argtypes = [vp, P(ShardResult)]
+        L.ffq_shard_self_exchange.argtypes = [vp, vp, vp, i64]
+        L.ffq_shard_transport.argtypes = [vp]
+        L.ffq_shard_transport.restype = ctypes.c_char_p
         L.ffq_stream_quals.argtypes = [vp, P(vp), P(vp), P(i64)]
         L.ffq_stream_close.restype = None
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
@@ -491,6 +527,93 @@ class Context:
     def synth_wrapped(self, dptr, d_start, first, count, seed=43):
         check(lib().ffq_synth_wrapped(self.handle, ctypes.c_void_p(dptr), ctypes.c_void_p(d_start),
                                       int(first), int(count), int(seed)))
+
+
+def shard_unique_id():
+    """128 bytes of communicator id (ncclGetUniqueId): rank 0 draws it, every rank gets it from rank 0."""
+    buf = (ctypes.c_uint8 * 128)()
+    check(lib().ffq_shard_unique_id(buf))
+    return bytes(buf)
+
+
+class ShardWorld:
+    """k logical ranks as threads of one process (ffq_shard_world_*): the in-process transport of the native step."""
+
+    def __init__(self, world):
+        self.world = int(world)
+        self._h = ctypes.c_void_p()
+        check(lib().ffq_shard_world_create(self.world, ctypes.byref(self._h)))
+
+    def abort(self):
+        if self._h:
+            lib().ffq_shard_world_abort(self._h)
+
+    def close(self):
+        if self._h:
+            lib().ffq_shard_world_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+class Shard:
+    """One rank's byte-range shard of a stream, the whole step behind the C ABI (ffq_shard_*, include/ffq.h): halo
+    hand-off over RCCL (or the in-process transport), scan, cut, one gather of the hand-off words."""
+
+    def __init__(self, ctx, bounds, rank, world, tail_bytes, head_bytes, unique_id=None, local_world=None, parent=None):
+        self._ctx = ctx
+        self._h = ctypes.c_void_p()
+        self._keep = (local_world, parent)
+        b = (ctypes.c_int64 * (world + 1))(*[int(x) for x in bounds])
+        if parent is not None:
+            check(lib().ffq_shard_create_lane(parent._h, ctx.handle, ctypes.byref(self._h)))
+        elif local_world is not None:
+            check(lib().ffq_shard_create_local(ctx.handle, local_world._h, int(rank), b, int(tail_bytes), int(head_bytes),
+                                               ctypes.byref(self._h)))
+        else:
+            idb = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+            check(lib().ffq_shard_create(ctx.handle, idb, int(rank), int(world), b, int(tail_bytes), int(head_bytes),
+                                         ctypes.byref(self._h)))
+        import weakref
+        ctx._children.append(weakref.ref(self))      # (a shard lives on its context: closed with it, before it)
+
+    def lane(self, ctx):
+        """A second shard of the same rank on another context (same scan stream): steps queued one ahead."""
+        return Shard(ctx, [], 0, 0, 0, 0, parent=self)
+
+    def halo(self):
+        t, h = ctypes.c_int64(), ctypes.c_int64()
+        check(lib().ffq_shard_halo(self._h, ctypes.byref(t), ctypes.byref(h)))
+        return t.value, h.value
+
+    def transport(self):
+        return lib().ffq_shard_transport(self._h).decode()
+
+    def self_exchange(self, d_src, d_dst, n):
+        check(lib().ffq_shard_self_exchange(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_dst), int(n)))
+
+    def exchange_halo(self, d_ext, overlap=False):
+        check(lib().ffq_shard_exchange_halo(self._h, ctypes.c_void_p(d_ext), 1 if overlap else 0))
+
+    def step_submit(self, d_ext, d_table, table_cap, flags=0, qual_add=-33, d_qual=None, qual_cap=0, d_qoff=None, overlap=False):
+        check(lib().ffq_shard_step_submit(self._h, ctypes.c_void_p(d_ext), 1 if overlap else 0, int(flags), int(qual_add),
+                                          ctypes.c_void_p(d_table), int(table_cap), ctypes.c_void_p(d_qual), int(qual_cap),
+                                          ctypes.c_void_p(d_qoff)))
+
+    def step_wait(self):
+        res = ShardResult()
+        rc = lib().ffq_shard_step_wait(self._h, ctypes.byref(res))
+        check(rc, allow=(E_TABLE_FULL,))
+        return rc, res
+
+    def close(self):
+        if self._h:
+            lib().ffq_shard_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _Stream:

@@ -149,9 +149,23 @@ class LocalWorld:
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
         self.providers = [None] * world
+        self._native = None
+        self._lock = threading.Lock()
 
     def transport(self, rank):
         return LocalTransport(self, rank)
+
+    def native_world(self):
+        """The same k logical ranks for the library's own step (hip.ShardWorld: ffq_shard_world_*)."""
+        with self._lock:
+            if self._native is None:
+                self._native = _hip.ShardWorld(self.world)
+            return self._native
+
+    def abort(self):
+        self.barrier.abort()
+        if self._native is not None:
+            self._native.abort()
 
 
 class LocalTransport:
@@ -261,6 +275,7 @@ class ScanOutput:
         self.rounds = 0               # repair rounds of the step (0: the first scan of every rank stood)
         self.ext = None               # the [tail | own | head] buffer the rows refer to (grown: a new one)
         self.tail = self.head = 0
+        self.comm = None              # native step: {handoff_ms, handoff_bytes, allgather_ms, rescan_rounds, regathers}
 
 
 class _View:
@@ -496,6 +511,84 @@ class ShardScanner:
         return out
 
 
+class _DevView:
+    """A device buffer the library owns (a shard's grown view), for torch.as_tensor."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def native_unique_id(dist, device):
+    """The communicator id of the library's own RCCL transport, drawn by rank 0 and sent round with the process group
+    that is there (any backend)."""
+    import torch
+    cpu = dist.get_backend() == "gloo"
+    t = torch.zeros(128, dtype=torch.uint8, device="cpu" if cpu else device)
+    if dist.get_rank() == 0:
+        t.copy_(torch.frombuffer(bytearray(_hip.shard_unique_id()), dtype=torch.uint8))
+    dist.broadcast(t, 0)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+def native_output(shard, ext, rc, res):
+    """ScanOutput of a step of the library's own (ffq_shard_step_wait): same fields as ShardScanner's, errors raised alike."""
+    import torch
+    if rc == _hip.E_TABLE_FULL:
+        raise RuntimeError("offset table too small (%d records in a rank's view)" % int(res.scan.n_records))
+    if res.err_state:
+        raise_stream_error(int(res.err_state), int(res.err_byte))
+    out = ScanOutput(res.scan, int(res.n_rows), int(res.row_lo), int(res.row_hi), int(res.exit_pos), int(res.first_pos))
+    out.record_base, out.total_records, out.rounds = int(res.record_base), int(res.total_records), int(res.rounds)
+    out.tail, out.head = int(res.tail), int(res.head)
+    out.ext = ext if int(res.d_ext or 0) == ext.data_ptr() else torch.as_tensor(
+        _DevView(res.d_ext, res.tail + (shard.bounds[shard.rank + 1] - shard.bounds[shard.rank]) + res.head), device=ext.device)
+    out.comm = {"handoff_ms": float(res.handoff_ms), "handoff_bytes": int(res.handoff_bytes),
+                "allgather_ms": float(res.allgather_ms), "rescan_rounds": int(res.rounds), "regathers": int(res.regathers)}
+    return out
+
+
+class NativeShardScanner:
+    """ShardScanner's interface over the library's own step (ffq_shard_*: hand-off over RCCL -- or the in-process
+    transport --, scan, cut and the gather of the hand-off words queued by ONE call, one read-back per step)."""
+
+    def __init__(self, ctx, bounds, rank, world, tail_bytes=TAIL_BYTES, head_bytes=HEAD_BYTES, unique_id=None,
+                 local_world=None, parent=None):
+        self.ctx, self.bounds, self.rank, self.world = ctx, list(bounds), rank, world
+        self.tail_bytes, self.head_bytes = tail_bytes, head_bytes
+        if parent is not None:
+            self.sh = parent.sh.lane(ctx)
+        else:
+            self.sh = _hip.Shard(ctx, bounds, rank, world, tail_bytes, head_bytes, unique_id=unique_id, local_world=local_world)
+        self._pending = None
+
+    def lane(self, ctx):
+        return NativeShardScanner(ctx, self.bounds, self.rank, self.world, self.tail_bytes, self.head_bytes, parent=self)
+
+    def halo(self):
+        return self.sh.halo()
+
+    def submit(self, ext, tail, head, table, flags=0, qual=None, qoff=None, overlap=False):
+        assert (tail, head) == self.halo()
+        self.sh.step_submit(ext.data_ptr(), table.data_ptr(), table.shape[0], flags=flags,
+                            d_qual=qual.data_ptr() if qual is not None else None,
+                            qual_cap=qual.numel() if qual is not None else 0,
+                            d_qoff=qoff.data_ptr() if qoff is not None else None, overlap=overlap)
+        self._pending = ext
+
+    def finish(self):
+        ext, self._pending = self._pending, None
+        rc, res = self.sh.step_wait()
+        return native_output(self, ext, rc, res)
+
+    def scan(self, ext, tail, head, table, flags=0, qual=None, qoff=None):
+        """The whole step (the halos are handed off by it: no exchange_halo in front)."""
+        self.submit(ext, tail, head, table, flags, qual, qoff)
+        return self.finish()
+
+    def close(self):
+        self.sh.close()
+
+
 DENSE_TEMPLATE = b"@foo#2\nAATTGCCG\n+\n3425@!#!\n"      # /root/reference/tests.py:8-35, single-line variant: 27 bytes
 
 
@@ -505,10 +598,14 @@ class SyntheticShard:
     (SURVEY.md 8d); cut points are moved off the record boundaries so that a
     record straddles every edge."""
 
-    def __init__(self, ctx, kind, bytes_per_gpu, rank, world, dev, edge_shift=144, transport=None, total_records=None):
+    def __init__(self, ctx, kind, bytes_per_gpu, rank, world, dev, edge_shift=144, transport=None, total_records=None,
+                 native=None):
         """total_records (S-single only): the whole stream has exactly this many records, dealt out as
         evenly as they go (BASELINE configs[4]: 333 460 193 records = 107 374 182 146 B over 8 ranges);
-        bytes_per_gpu is ignored then."""
+        bytes_per_gpu is ignored then.
+        native: the steps run behind the C ABI (ffq_shard_*: RCCL hand-offs, or the in-process transport for logical
+        ranks) instead of through this module's protocol over torch.distributed.  None: yes where that is the product
+        path -- world > 1 over the nccl backend."""
         import torch
         from . import synth
         self.ctx, self.kind, self.rank, self.world, self.dev = ctx, kind, rank, world, dev
@@ -588,13 +685,24 @@ class SyntheticShard:
         self.ext_scanned_bytes = self.tail + self.n_own_bytes + self.head
         min_rec = self.rec_bytes if kind in ("single", "dense") else 120
         self.max_records = n_per + (self.tail + self.head) // min_rec + 64
-        self.scanner = ShardScanner(HipBackend(ctx), transport, S)
+        if native is None:
+            native = isinstance(transport, DistTransport) and not transport.gloo and world > 1 and os.environ.get("FFQ_SHARD_NATIVE", "1") != "0"
+        self.native = bool(native)
+        if self.native:
+            if isinstance(transport, LocalTransport):
+                self.scanner = NativeShardScanner(ctx, S, rank, world, local_world=transport.lw.native_world())
+            else:
+                uid = native_unique_id(transport.dist, dev) if isinstance(transport, DistTransport) else _hip.shard_unique_id()
+                self.scanner = NativeShardScanner(ctx, S, rank, world, unique_id=uid)
+        else:
+            self.scanner = ShardScanner(HipBackend(ctx), transport, S)
         self._lanes = None
 
     def scan(self, table, flags=0, qual=None, qoff=None):
         # the hand-off runs on the scan's own stream: the scan that follows needs no host
         # synchronisation in between
-        self.scanner.exchange_halo(self.ext, self.tail, self.head)
+        if not self.native:
+            self.scanner.exchange_halo(self.ext, self.tail, self.head)
         return self.scanner.scan(self.ext, self.tail, self.head, table, flags, qual, qoff)
 
     # ---- pipelined steps: submit(i + 1) before finish(i) -------------------------------------
@@ -603,14 +711,23 @@ class SyntheticShard:
         with its own stream for the small queries of finish(), so that they do not queue
         behind the next step's kernels."""
         from . import hip
-        post = hip.Context(self.ctx.device)
-        lanes = [ShardScanner(HipBackend(self.ctx, post), self.transport, self.bounds)]
-        for _ in range(n - 1):
-            c = hip.Context(share=self.ctx)
-            c.reserve(self.ext.numel())
-            lanes.append(ShardScanner(HipBackend(c, post), self.transport, self.bounds))
+        if self.native:
+            lanes = [self.scanner]
+            for _ in range(n - 1):
+                c = hip.Context(share=self.ctx)
+                c.reserve(self.ext.numel())
+                lanes.append(self.scanner.lane(c))
+            self._lane_ctx = [ln.ctx for ln in lanes]
+            self._post = None
+        else:
+            post = hip.Context(self.ctx.device)
+            lanes = [ShardScanner(HipBackend(self.ctx, post), self.transport, self.bounds)]
+            for _ in range(n - 1):
+                c = hip.Context(share=self.ctx)
+                c.reserve(self.ext.numel())
+                lanes.append(ShardScanner(HipBackend(c, post), self.transport, self.bounds))
+            self._post = post
         self._lanes = lanes
-        self._post = post
         # With peers every lane gets a [tail | own | head] buffer of its own, as consecutive steps of
         # a real stream have: the hand-off of step i + 1 then writes no byte the scan of step i reads
         # and runs beside it, on the hand-off stream (FFQ_SHARD_OVERLAP=0: behind it, on the scan stream).
@@ -620,6 +737,9 @@ class SyntheticShard:
 
     def submit(self, lane, table, flags=0, qual=None, qoff=None):
         ext = self._exts[lane]
+        if self.native:
+            self._lanes[lane].submit(ext, self.tail, self.head, table, flags, qual, qoff, overlap=self._overlap)
+            return
         self._lanes[lane].exchange_halo(ext, self.tail, self.head, overlap=self._overlap)
         self._lanes[lane].submit(ext, self.tail, self.head, table, flags, qual, qoff)
 

@@ -357,6 +357,77 @@ int ffq_synth_wrapped(ffq_ctx *ctx, uint8_t *d_out, const int64_t *d_start,
  * Runs the device self-checks (wave scan, newline mask) and returns FFQ_OK.  */
 int ffq_selftest(ffq_ctx *ctx);
 
+/* ---- one stream over the GPUs of a node: byte-range shards ------------------------------------
+ * Rank r of `world` owns the stream bytes [bounds[r], bounds[r + 1]) and every record whose '@' lies in
+ * them; offsets count from bounds[0] (readfastq_iter's globaloffset, /root/reference/src/fastqandfurious.py
+ * :198-242).  What the reference does with a record that does not fit its buffer -- keep buf[offset:] and
+ * read more (:274-279) -- happens per range edge.  One process per GPU, one ffq_shard per process; the
+ * hand-offs are RCCL over xGMI (librccl, loaded at run time):
+ *   ffq_shard_unique_id   rank 0 draws the communicator id (ncclGetUniqueId); the host hands the 128 bytes
+ *                         to every rank (MPI, torch.distributed, a file ...)
+ *   ffq_shard_create      every rank, collectively (ncclCommInitRank, twice: hand-offs and the gather have
+ *                         a communicator each)
+ *   ffq_shard_halo        how many bytes in front of / behind its range this rank's buffer holds:
+ *                         d_ext = [tail | own bytes | head], tail = min(tail_bytes, lo - bounds[0]),
+ *                         head = min(head_bytes, bounds[world] - hi); the caller fills the middle
+ *   ffq_shard_step_submit one step, queued, no host wait: the halos from the ranks that own them
+ *                         (ncclSend / ncclRecv in one group; overlap_handoff != 0: on the shard's hand-off
+ *                         stream, beside whatever the scan stream is doing -- the caller vouches that no
+ *                         scan in flight reads d_ext, e.g. every lane has a buffer of its own), the scan of
+ *                         the whole view, the rows of the range cut out (as ffq_table_cut) and ONE
+ *                         ncclAllGather of eight words per rank
+ *   ffq_shard_step_wait   the step's result: rows [row_lo, row_hi) of d_table are this rank's records
+ *                         (absolute stream offsets), record_base their global ordinal; exit_pos (first
+ *                         record start at / behind my right edge) equals the right neighbour's first_pos
+ *                         on return -- that, with rank 0's exact start, proves every range.  A look-ahead
+ *                         that ends inside the straddling record is grown (d_ext in the result then points
+ *                         at the shard's own, larger view), a contradicted entry guess re-entered from the
+ *                         left neighbour's exit: `rounds` counts those.  err_state != 0: the stream's error
+ *                         (FFQ_END_ERR_*, the byte the reference's ValueError names in err_byte), the same
+ *                         on every rank.  FFQ_E_TABLE_FULL (on every rank) if some rank's table is too small.
+ *   ffq_shard_create_lane a second shard of the same rank on another context (ffq_ctx_create_shared: same
+ *                         scan stream), on the first one's communicators: steps queued one ahead.
+ *   ffq_shard_world_* / ffq_shard_create_local   k logical ranks as THREADS of one process on one GPU, hand-offs
+ *                         by device copies (tests, dry runs): every rank's thread makes the same calls.
+ * Every rank must make the same sequence of calls (they are collective).                              */
+typedef struct ffq_shard ffq_shard;
+typedef struct ffq_shard_world ffq_shard_world;
+typedef struct ffq_shard_result {
+    ffq_scan_result scan;      /* the local scan of [tail | own | head]                                    */
+    int64_t n_rows;            /* rows it wrote to d_table                                                  */
+    int64_t row_lo, row_hi;    /* this rank's records                                                       */
+    int64_t exit_pos, first_pos;   /* stream offsets; -1: none (the view reaches the end of the stream)     */
+    int64_t n_own_records, record_base, total_records;
+    int64_t err_byte;
+    int32_t err_state;         /* 0, or FFQ_END_ERR_*                                                       */
+    int32_t rounds;            /* repair rounds (0: the first scan of every rank stood)                     */
+    int32_t regathers;         /* gathers repeated because some rank's scan needed a later tier             */
+    int32_t pad_;
+    int64_t handoff_bytes;     /* bytes this rank sent + received in hand-offs                              */
+    float   handoff_ms;        /* device time of the halo hand-off (events on the stream it ran on)         */
+    float   allgather_ms;      /* device time of the gather(s) of the eight words                           */
+    uint8_t *d_ext;            /* the view the rows refer to (the caller's, or a grown one owned by the shard) */
+    int64_t tail, head;
+} ffq_shard_result;
+int  ffq_shard_unique_id(uint8_t *id128);
+int  ffq_shard_create(ffq_ctx *ctx, const uint8_t *id128, int rank, int world, const int64_t *bounds,
+                      int64_t tail_bytes, int64_t head_bytes, ffq_shard **out);
+int  ffq_shard_create_lane(ffq_shard *parent, ffq_ctx *ctx, ffq_shard **out);
+int  ffq_shard_world_create(int world, ffq_shard_world **out);
+void ffq_shard_world_abort(ffq_shard_world *w);
+void ffq_shard_world_destroy(ffq_shard_world *w);
+int  ffq_shard_create_local(ffq_ctx *ctx, ffq_shard_world *w, int rank, const int64_t *bounds, int64_t tail_bytes,
+                            int64_t head_bytes, ffq_shard **out);
+void ffq_shard_destroy(ffq_shard *s);
+int  ffq_shard_halo(ffq_shard *s, int64_t *tail, int64_t *head);
+int  ffq_shard_exchange_halo(ffq_shard *s, uint8_t *d_ext, int overlap);
+int  ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_handoff, uint32_t flags, int qual_add,
+                           int64_t *d_table, int64_t table_cap, int8_t *d_qual, int64_t qual_cap, int64_t *d_qoff);
+int  ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out);
+const char *ffq_shard_transport(ffq_shard *s);    /* "rccl" / "in-process" */
+/* diagnostics: n bytes from d_src to d_dst through the shard's transport with this rank at both ends */
+int  ffq_shard_self_exchange(ffq_shard *s, const uint8_t *d_src, uint8_t *d_dst, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif
