@@ -807,6 +807,10 @@ def main():
         if rank == 0:
             line["other_workloads"] = others
     if rank == 0:
+        # (RCCL prints its version banner through C stdio: out with it first, the JSON line is the last line of stdout)
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

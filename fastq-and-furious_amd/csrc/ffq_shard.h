@@ -12,7 +12,7 @@
 //      ffq_table_cut) and the EIGHT WORDS the ranks compare -- exit (first record start at / behind my right edge as my
 //      chain sees it), first (first record start in my range), own count, look-ahead wanted, look-ahead had, error,
 //      error byte, where the search that found the exit started;
-//   4. ONE ncclAllGather of those words (a communicator of its own, on the scan stream) and one copy to pinned memory:
+//   4. ONE ncclAllGather of those words (a communicator of its own, on a stream of its own that waits for them) and one copy to pinned memory:
 //      the host reads them when it waits for the step -- nothing else comes back before that.
 // exit[r] must equal first[r + 1]; rank 0's start is exact, so that proves every range by induction, and the counts give
 // global record ordinals.  A rank whose look-ahead ends inside the record that straddles its edge asks for more (served by
@@ -49,7 +49,7 @@ struct ShView {                            // a rank's [tail | own | head] buffe
 // out[0..7] the words, out[8] row_lo, out[9] row_hi, out[10] rows in the table
 __global__ __launch_bounds__(64) void k_shard_words(const DevRes *__restrict__ res, const int64_t *__restrict__ table,
                                                     int64_t table_cap, ShView v, int64_t offset, int64_t head_bytes,
-                                                    int64_t *__restrict__ out)
+                                                    int64_t *__restrict__ out, int64_t *__restrict__ host_out)
 {
     const int lane = threadIdx.x;
     const int64_t n = res->n_records;
@@ -111,6 +111,12 @@ __global__ __launch_bounds__(64) void k_shard_words(const DevRes *__restrict__ r
 #pragma unroll
         for (int i = 0; i < SH_WORDS; i++) out[i] = w[i];
         out[8] = i0; out[9] = i1; out[10] = nrows;
+        // (the same into host-mapped memory: this rank's own copy, no copy packet on the scan stream; visible to the host
+        // once the gather behind this kernel is through)
+#pragma unroll
+        for (int i = 0; i < SH_WORDS; i++) host_out[i] = w[i];
+        host_out[8] = i0; host_out[9] = i1; host_out[10] = nrows;
+        __threadfence_system();
     }
 }
 
@@ -311,16 +317,18 @@ using namespace ffq;
 struct ffq_shard {
     ffq_ctx *c = nullptr;
     ShTransport *tr = nullptr;
-    bool owns_tr = true;
+    bool owns_tr = true, owns_streams = true;
     int rank = 0, world = 1;
     std::vector<int64_t> B;                // S_0 .. S_world
     int64_t tail_bytes = 0, head_bytes = 0;
     int64_t lo = 0, hi = 0, total = 0, origin = 0;
     hipStream_t comm = nullptr;            // the hand-off stream
-    hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_g[2] = {nullptr, nullptr};
+    hipStream_t gstream = nullptr;         // the gather stream
+    hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_g[2] = {nullptr, nullptr}, ev_w = nullptr;
     int64_t *d_words = nullptr;            // [16]: the words, row_lo, row_hi, rows
     int64_t *d_all = nullptr;              // [world * SH_WORDS]
     int64_t *h_all = nullptr, *h_own = nullptr;      // pinned
+    int64_t *hm_own = nullptr;             // h_own as the device sees it (host-mapped)
     uint8_t *grown = nullptr;              // a view with more look-ahead than the caller's buffer has room for
     int64_t grown_cap = 0;
     // the pending step
@@ -348,16 +356,24 @@ static ShView sh_view(const ffq_shard *s, int64_t tail, int64_t head)
     return v;
 }
 
-static int shard_alloc(ffq_shard *s)
+static int shard_alloc(ffq_shard *s, ffq_shard *parent = nullptr)
 {
     HIPCHK(hipSetDevice(s->c->device));
-    HIPCHK(hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking));
+    if (parent) {
+        // (a lane: one communicator is driven from ONE stream -- the hand-off and gather streams are the parent's)
+        s->comm = parent->comm; s->gstream = parent->gstream; s->owns_streams = false;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&s->gstream, hipStreamNonBlocking));
+    }
     for (auto &e : s->ev_x) HIPCHK(hipEventCreate(&e));
     for (auto &e : s->ev_g) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_w, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&s->d_words, 16 * 8));
     HIPCHK(hipMalloc((void **)&s->d_all, (size_t)s->world * SH_WORDS * 8));
     HIPCHK(hipHostMalloc((void **)&s->h_all, (size_t)s->world * SH_WORDS * 8, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&s->h_own, 16 * 8, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&s->h_own, 16 * 8, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&s->hm_own, s->h_own, 0));
     return FFQ_OK;
 }
 
@@ -385,9 +401,12 @@ extern "C" void ffq_shard_destroy(ffq_shard *s)
     if (!s) return;
     (void)hipSetDevice(s->c->device);
     if (s->comm) { (void)hipStreamSynchronize(s->comm); }
+    if (s->gstream) { (void)hipStreamSynchronize(s->gstream); }
     (void)hipStreamSynchronize(s->c->stream);
     if (s->owns_tr) delete s->tr;
-    if (s->comm) (void)hipStreamDestroy(s->comm);
+    if (s->comm && s->owns_streams) (void)hipStreamDestroy(s->comm);
+    if (s->gstream && s->owns_streams) (void)hipStreamDestroy(s->gstream);
+    if (s->ev_w) (void)hipEventDestroy(s->ev_w);
     for (auto e : s->ev_x) if (e) (void)hipEventDestroy(e);
     for (auto e : s->ev_g) if (e) (void)hipEventDestroy(e);
     (void)hipFree(s->d_words); (void)hipFree(s->d_all); (void)hipFree(s->grown);
@@ -436,7 +455,7 @@ extern "C" int ffq_shard_create_lane(ffq_shard *parent, ffq_ctx *c, ffq_shard **
     if (rc) return rc;
     ffq_shard *s = *out;
     *out = nullptr;
-    rc = shard_alloc(s);
+    rc = shard_alloc(s, parent);
     if (rc) { ffq_shard_destroy(s); return rc; }
     s->tr = parent->tr; s->owns_tr = false;
     *out = s;
@@ -521,21 +540,35 @@ static int shard_handoff(ffq_shard *s, uint8_t *ext, int64_t tail, bool overlap)
     return FFQ_OK;
 }
 
+// step 4: the gather of the words the scan stream has just been given to produce -- on the GATHER stream, which waits for
+// them: the collective (tens of microseconds with peers) does not sit between this step's scan and the next one's, already
+// queued behind it on the scan stream
+static int shard_gather(ffq_shard *s, bool waited = false)
+{
+    if (!waited) {
+        HIPCHK(hipEventRecord(s->ev_w, s->c->stream));
+        HIPCHK(hipStreamWaitEvent(s->gstream, s->ev_w, 0));
+    }
+    HIPCHK(hipEventRecord(s->ev_g[0], s->gstream));
+    int rc = s->tr->gather_enqueue(s->d_words, s->d_all, s->h_all, s->gstream);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(s->ev_g[1], s->gstream));
+    return FFQ_OK;
+}
+
 // steps 3-4 behind a scan of view v that searched from buffer offset `offset`
 static int shard_words_and_gather(ffq_shard *s, int64_t offset)
 {
+    // (on the gather stream too, behind ONE marker on the scan stream: the two lower bounds are a handful of dependent
+    // memory round trips -- 17 us per step when they sat between this step's scan and the next one's)
     ffq_ctx *c = s->c;
-    hipStream_t st = c->stream;
     mark_other(c);
-    hipLaunchKernelGGL(k_shard_words, dim3(1), dim3(64), 0, st, (const DevRes *)c->dres, (const int64_t *)s->d_table, s->table_cap,
-                       s->v, offset, s->head_bytes, s->d_words);
-    HIPCHK(hipMemcpyAsync(s->h_own, s->d_words, 16 * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(s->ev_g[0], st));
-    int rc = s->tr->gather_enqueue(s->d_words, s->d_all, s->h_all, st);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(s->ev_g[1], st));
+    HIPCHK(hipEventRecord(s->ev_w, c->stream));
+    HIPCHK(hipStreamWaitEvent(s->gstream, s->ev_w, 0));
+    hipLaunchKernelGGL(k_shard_words, dim3(1), dim3(64), 0, s->gstream, (const DevRes *)c->dres, (const int64_t *)s->d_table,
+                       s->table_cap, s->v, offset, s->head_bytes, s->d_words, s->hm_own);
     HIPCHK(hipGetLastError());
-    return FFQ_OK;
+    return shard_gather(s, true);
 }
 
 // words set on the host (a rank that learns that the chain passes over its whole range): the next gather carries them
@@ -544,11 +577,7 @@ static int shard_gather_host_words(ffq_shard *s)
     hipStream_t st = s->c->stream;
     mark_other(s->c);
     HIPCHK(hipMemcpyAsync(s->d_words, s->h_own, 16 * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipEventRecord(s->ev_g[0], st));
-    int rc = s->tr->gather_enqueue(s->d_words, s->d_all, s->h_all, st);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(s->ev_g[1], st));
-    return FFQ_OK;
+    return shard_gather(s);
 }
 
 extern "C" int ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_handoff, uint32_t flags, int qual_add,
