@@ -287,6 +287,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     const int g = g0 + blockIdx.x * WPB + wid;
     if (g >= g1) return;                 // no workgroup barrier is used below
     if (only_deferred == 1 && !(B.flags[g] & 4u)) return;   // second pass: only what the first one deferred
+    if (only_deferred == 3 && !(B.flags[g] & 8u)) return;   // behind k_chain_lite (ffq_lite.h): only the groups that kernel declined
     // repair pass (only_deferred == 2): only the groups whose guess the verification rejected,
     // entered where the predecessor's chain says (no run-in speculation)
     const int64_t fpos = (only_deferred == 2) ? B.force[g] : FORCE_NONE;

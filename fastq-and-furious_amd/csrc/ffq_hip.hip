@@ -342,6 +342,7 @@ static int64_t groups_for(int64_t ntiles) { return (ntiles + OWN_T - 1) / OWN_T;
 constexpr int PER_FAST = 6, EMAX_FAST = 2048, WPB_FAST = 2;   // k_chain_wave, usual line/record density
 constexpr int PER_DENSE = 15, EMAX_DENSE = NTW * SLOT + 8, WPB_DENSE = 1;   // short records / short lines
 constexpr int NMAX_FAST = PER_FAST * 64, NMAX_DENSE = PER_DENSE * 64;
+constexpr int WPB_LITE = 2;                                    // k_chain_lite (ffq_lite.h): groups per workgroup
 
 static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
 {
@@ -720,10 +721,16 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
         cb.prof = c->prof_d;
     }
     HIPCHK(hipMemsetAsync(cb.flags, 0, (2 * (size_t)ngroups + 1) * 4, sA));      // flags, and: no group has a chunk of the walked groups' stage yet
+    static const bool no_lite = getenv("FFQ_NO_LITE") != nullptr;
+    const bool lite = !dense_cfg && ablate == 0 && !cb.prof && !no_lite;
+    if (lite)
+        // ordinary groups by the lean kernel; what it declines (flag bit 3) goes to k_chain_wave right behind
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lite<WPB_LITE>), dim3((ngroups + WPB_LITE - 1) / WPB_LITE), dim3(WPB_LITE * 64), 0, sA,
+                           L, a.offset, cb, ngroups);
     if (!dense_cfg)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
                            dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
-                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
+                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, lite ? 3 : 0, ablate);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
                            dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
 
 #include "ffq_rows4.h"
 #include "ffq_dense.h"
+#include "ffq_lite.h"
 
 namespace ffq {
 

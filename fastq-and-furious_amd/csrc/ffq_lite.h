@@ -1,0 +1,229 @@
+// ffq_lite.h -- the record chain of an ORDINARY group of tiles, with a fraction of k_chain_wave's instructions.
+//
+// k_chain_wave (ffq_chain.h) is bound by instruction issue: 2390 VALU instructions per wave and group on S-wrapped,
+// half of them spent on being general (window words that carry a node id merged per entry, passes for tiles of any
+// density, search offsets, the sentinel, buffer ends, forced entries, restarts, pointer doubling, records of any
+// length).  Nearly every group needs none of that.  k_chain_lite takes a group ONLY IF it is ordinary -- not the first
+// one (sentinel, search offset), its whole window [run-in tile | OWN_T own tiles | look-ahead tile] inside the buffer
+// with room to spare (so that no buffer-end rule of the scanner can apply), every tile of it one pass of six entries
+// per lane -- computes exactly what k_chain_wave computes for it (same nodes, same scanner rules in the same order:
+// /root/reference/src/_fastqandfurious.c:25-153, same summary), and DECLINES (flag bit 3) the moment anything else
+// turns up on the chain: a node whose call does not resolve within the LT_B entries behind it (a record of many lines,
+// an INVALID '+' line, a successor far away), a chain that stops, too many nodes.  Declined groups are run by
+// k_chain_wave right behind (only_deferred == 3); repair passes are k_chain_wave's as before.
+//   window:  one word per entry (position | flags | node id) from six entries per lane and tile, one pass each
+//   nodes:   the "\n@" matches of the run-in tail and the own tiles, numbered in entry order
+//   calls:   a thread per node, the LT_B words behind its entry
+//   chain:   run by run from the window's first node (a run = nodes whose successor is the very next node: one
+//            ballot per 64), records of the own tiles staged by all lanes of a run at once
+#pragma once
+#include "ffq_chain.h"
+
+namespace ffq {
+
+constexpr int LT_E = 384;                  // entries of a tile the kernel takes: one pass of six per lane
+constexpr int LT_LA = 64;                  // entries of the look-ahead tile it looks at
+constexpr int LT_WIN = (OWN_T + 1) * LT_E + LT_LA;
+constexpr int LT_NODES = 320;
+constexpr int LT_B = 14;                   // words a node's call looks at, its own included
+constexpr uint32_t LK_OK = 0, LK_GEN = 1;  // node word: successor node (10 bits, NO_NODE: past the own tiles) | kind << 10 | mi << 12
+constexpr uint32_t FLAG_LITE_DECLINED = 8u;
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t offset, ChainBufs B, int ng)
+{
+    __shared__ uint32_t went_all[WPB][LT_WIN + 16];
+    __shared__ uint16_t nidx_all[WPB][LT_NODES];
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int g = blockIdx.x * WPB + wid;
+    if (g >= ng) return;
+    uint32_t *went = went_all[wid];
+    uint16_t *nidx = nidx_all[wid];
+    const int own0 = g * OWN_T, own1 = own0 + OWN_T, wt0 = own0 - 1;
+    const int64_t wpos0 = (int64_t)wt0 << TILE_SHIFT;
+    // not the first group (sentinel, search offset), not the last ones (every position of the window lies at least four
+    // bytes in front of the buffer's end: none of the scanner's buffer-end rules can apply), the search offset in front
+    // of the run-in tail (every "\n@" there is a candidate)
+    bool ok = g > 0 && own1 + 1 <= L.ntiles && (((int64_t)(wt0 + OWN_T + 2) << TILE_SHIFT) + L.s + 4 < L.len()) &&
+              offset <= wpos0 + L.s + (TILE - RUNIN_BYTES);
+    if (!ok) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }
+    // ---- the window's entries, one memory round trip --------------------------------------------------------------
+    const uint32_t cl = (lane < OWN_T + 2) ? L.cnt[wt0 + lane] : 0u;
+    uint32_t ev[OWN_T + 1][3];
+#pragma unroll
+    for (int k = 0; k <= OWN_T; k++) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+        const u32x3 t = *reinterpret_cast<const u32x3 *>(L.ent + (int64_t)(wt0 + k) * SLOT + 6 * lane);
+        ev[k][0] = t.x; ev[k][1] = t.y; ev[k][2] = t.z;
+    }
+    const uint32_t la_raw = (uint32_t)L.ent[(int64_t)(wt0 + OWN_T + 1) * SLOT + lane];
+    int tc[OWN_T + 2], tb[OWN_T + 2];
+    uint32_t lines = 0;
+    tb[0] = 0;
+#pragma unroll
+    for (int k = 0; k <= OWN_T + 1; k++) {
+        tc[k] = (int)__builtin_amdgcn_readlane((int)cl, k);
+        if (k <= OWN_T) { tb[k + 1] = tb[k] + tc[k]; if (tc[k] > LT_E) ok = false; }
+        if (k >= 1 && k <= OWN_T) lines += (uint32_t)tc[k];
+    }
+    if (tc[OWN_T + 1] > SLOT) ok = false;                            // (a dense look-ahead tile keeps its entries elsewhere)
+    if (!ok) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }
+    const int lac = min(tc[OWN_T + 1], LT_LA);
+    const int own_hi = tb[OWN_T + 1], nwin = own_hi + lac;
+    // ---- words + nodes, tile by tile --------------------------------------------------------------------------------
+    int ncomp = 0, n_runin = 0;
+#pragma unroll
+    for (int k = 0; k <= OWN_T; k++) {
+        const int c = tc[k];
+        const uint32_t relb = (uint32_t)(k << TILE_SHIFT) + (uint32_t)L.s;
+        uint32_t x[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = (i & 1) ? (ev[k][i >> 1] >> 16) : (ev[k][i >> 1] & 0xFFFFu);
+        const int nv = min(max(c - 6 * lane, 0), 6);
+        uint32_t at = 0;
+#pragma unroll
+        for (int h = 0; h < 3; h++) at |= (((ev[k][h] >> 14) & 1u) | ((ev[k][h] >> 29) & 2u)) << (2 * h);
+        at &= (1u << nv) - 1u;
+        if (k == 0) {
+            // the run-in tile: only its tail makes candidates
+            uint32_t tailm = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) if ((x[i] & OFF_MASK) >= (uint32_t)(TILE - RUNIN_BYTES)) tailm |= 1u << i;
+            at &= tailm;
+        }
+        const uint32_t nc = __popc(at);
+        const uint32_t incl = wave_incl_scan(nc);
+        uint32_t id = (uint32_t)ncomp + incl - nc;
+        ncomp += (int)__shfl((int)incl, 63);
+        if (6 * lane < c) {
+            uint32_t *wdst = went + tb[k] + 6 * lane;
+            const uint32_t wconst = relb + (NO_NODE << WN_SHIFT);
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                wdst[i] = __umul24(x[i] >> 14, (1u << WF_SHIFT) - (1u << 14)) + (x[i] + wconst);      // (offset | flags << 18 | no node)
+            uint32_t mrem = at;
+            while (mrem) {
+                const int i = __ffs((int)mrem) - 1;
+                mrem &= mrem - 1u;
+                uint32_t half = ev[k][0];
+                if ((i >> 1) == 1) half = ev[k][1];
+                if ((i >> 1) == 2) half = ev[k][2];
+                const uint32_t off = ((i & 1) ? (half >> 16) : half) & OFF_MASK;
+                const uint32_t idw = min(id, (uint32_t)(LT_NODES - 1));
+                nidx[idw] = (uint16_t)(tb[k] + 6 * lane + i);
+                wdst[i] = (relb + off) | ((uint32_t)FL_AT << WF_SHIFT) | (idw << WN_SHIFT);
+                id++;
+            }
+        }
+        if (k == 0) n_runin = ncomp;
+    }
+    if (lane < lac)
+        went[own_hi + lane] = (((uint32_t)(OWN_T + 1) << TILE_SHIFT) + (uint32_t)L.s + (la_raw & OFF_MASK)) |
+                              ((la_raw >> 14) << WF_SHIFT) | (NO_NODE << WN_SHIFT);
+    if (ncomp == 0 || ncomp > LT_NODES) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }     // (no candidate: the chain passes over -- a search of its own)
+    wave_sync();
+    // ---- one scanner call per node ------------------------------------------------------------------------------------
+    // A record of this kernel's kind: header line, mi - 1 sequence lines, the '+' line, as many quality lines -- entry k + mi
+    // is the "\n+" match, k + mi + 1 the '+' line's end, and the next call's "\n@" (the first one at >= pos5 - 1 behind the
+    // '+' line's end, :62 / fastqandfurious.py:254) is entry k + 2 mi: that is what is TESTED (the entry in front of it must
+    // lie in front of pos5 - 1: positions grow with the index, so no earlier entry can be the match); a node whose call
+    // looks different (another wrapping of the qualities, an INVALID '+' line, more than six sequence lines) is not taken
+    constexpr int NB = LT_NODES / 64;
+    uint32_t infr[NB], kreg[NB];           // node u * 64 + lane: its word (successor | kind | mi) and its entry
+    unsigned long long NS[NB];             // (a run = nodes whose successor is the very next node; NS = the nodes that end one)
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        const int c = u * 64 + lane;
+        uint32_t inf = LK_GEN << 10;
+        int k = 0;
+        if (u * 64 < ncomp && c < ncomp) {                     // (the first test is wave-uniform)
+            k = nidx[c];
+            if (k + LT_B < nwin) {
+                uint32_t w[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) w[i] = went[k + i];
+                const uint32_t P0 = w[0] & WP_MASK, P1 = w[1] & WP_MASK;
+                uint32_t pm = 0;                              // "\n+" at >= seq_beg + 1 (:87-88)
+#pragma unroll
+                for (int i = 2; i <= 7; i++)
+                    if (((w[i] >> WF_SHIFT) & (uint32_t)FL_PLUS) && (w[i] & WP_MASK) >= P1 + 2u) pm |= 1u << i;
+                if (pm) {
+                    const int mi = __ffs((int)pm) - 1;        // 2 .. 7: 2 mi <= LT_B
+                    const uint32_t P3 = went[k + mi] & WP_MASK, Pq = went[k + mi + 1] & WP_MASK;
+                    const uint32_t ws = went[k + 2 * mi], wp = went[k + 2 * mi - 1];
+                    const bool invalid = (Pq - P3 - 1u > 1u) && (Pq - P3 != P1 - P0);      // :109-117
+                    const uint32_t qe = Pq + P3 - P1;                                       // :129
+                    const bool succ_ok = ((ws >> WF_SHIFT) & (uint32_t)FL_AT) && (ws & WP_MASK) + 1u >= qe &&
+                                         (mi == 2 || (wp & WP_MASK) + 1u < qe);
+                    if (!invalid && succ_ok)
+                        inf = ((ws >> WN_SHIFT) & WN_MASK) | (LK_OK << 10) | ((uint32_t)mi << 12);
+                }
+            }
+        }
+        infr[u] = inf; kreg[u] = (uint32_t)k;
+        NS[u] = __ballot(!(((inf >> 10) & 3u) == LK_OK && (inf & WN_MASK) == (uint32_t)(c + 1)));
+    }
+    // ---- chain membership: run by run, on the scalar side (the chain only moves forward: batch after batch) -------------
+    unsigned long long MB[NB];
+    int cur = 0, lastn = -1;
+    uint32_t last_inf = 0, last_k = 0;
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        MB[u] = 0ull;
+        for (int guard = 0; guard < 66 && (cur >> 6) == u && lastn < 0 && !bad; guard++) {
+            const int b = cur & 63;
+            const unsigned long long ns = NS[u] >> b;
+            if (!ns) { MB[u] |= ~0ull << b; cur = (u + 1) * 64; if (cur >= ncomp) bad = true; break; }
+            const int r = b + __ffsll((long long)ns) - 1;
+            MB[u] |= (~0ull << b) & (r == 63 ? ~0ull : ((2ull << r) - 1ull));
+            const uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)infr[u], r);
+            if (((ir >> 10) & 3u) != LK_OK) bad = true;        // a node this kernel does not take lies on the chain
+            else if ((ir & WN_MASK) == NO_NODE) {               // the chain leaves the own tiles
+                lastn = u * 64 + r; last_inf = ir; last_k = (uint32_t)__builtin_amdgcn_readlane((int)kreg[u], r);
+            } else cur = (int)(ir & WN_MASK);
+        }
+    }
+    if (bad || lastn < 0) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }
+    // ---- records of the own tiles, staged in chain order -----------------------------------------------------------------
+    uint32_t ntot = 0;
+    unsigned long long OWN[NB];
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        // members at or behind node n_runin
+        const int lo = n_runin - u * 64;
+        OWN[u] = MB[u] & (lo <= 0 ? ~0ull : lo >= 64 ? 0ull : (~0ull << lo));
+        ntot += (uint32_t)__popcll(OWN[u]);
+    }
+    if (ntot > (uint32_t)B.nmax) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }
+    StageRec *stg = B.stage + (int64_t)g * B.nmax;
+    uint32_t nbase = 0, qsum = 0;
+    int64_t Y = Y_UNRES;
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        if (!OWN[u]) continue;                                  // (wave-uniform)
+        if (bit_of_lane(OWN[u], lane)) {
+            const int k = (int)kreg[u];
+            const int mi = (int)((infr[u] >> 12) & 15u);
+            StageRec o;
+            o.p0 = (went[k] & WP_MASK) + 1u;
+            o.p1 = went[k + 1] & WP_MASK;
+            o.p3 = went[k + mi] & WP_MASK;
+            o.p4 = (went[k + mi + 1] & WP_MASK) + 1u;
+            stg[nbase + (uint32_t)bits_below_lane(OWN[u])] = o;
+            qsum += o.p3 - o.p1 - 1u;
+        }
+        if (Y == Y_UNRES)
+            Y = wpos0 + (int64_t)(went[__builtin_amdgcn_readlane((int)kreg[u], __ffsll((long long)OWN[u]) - 1)] & WP_MASK);
+        nbase += (uint32_t)__popcll(OWN[u]);
+    }
+    // the candidate the chain goes on with: entry k + 2 mi of its last node
+    const int64_t EX = wpos0 + (int64_t)(went[(int)last_k + 2 * (int)((last_inf >> 12) & 15u)] & WP_MASK);
+    if (Y == Y_UNRES) Y = EX;
+    const uint32_t qtot = wave_sum_u32(qsum);                 // (a group's qualities are < 2^17 bytes)
+    if (lane == 0) {
+        B.y[g] = Y; B.exit[g] = EX; B.cnt[g] = ntot; B.qb[g] = (int64_t)qtot; B.lines[g] = lines;
+    }
+}
+
+}  // namespace ffq
