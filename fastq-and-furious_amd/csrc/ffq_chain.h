@@ -86,6 +86,8 @@ struct ChainBufs {
     StageRec *dstage;    // [dchunks][DCHUNK]
     uint32_t *dhead;     // chunks handed out (and asked for: may exceed dchunks -> ERR_DSTAGE, the host grows the stage)
     int32_t dchunks;
+    uint32_t *dlist;     // [ng] groups k_chain_lite (ffq_lite.h) declined, in no particular order
+    uint32_t *dcnt;      //      how many
     int64_t *rloc;       // [ng] exclusive prefix of cnt inside the resolve block
     int64_t *qloc;       // [ng] same for qb
     int64_t *part;       // [nblk][4] block totals (cnt, qb, lines, -) -> exclusive prefixes
@@ -267,10 +269,11 @@ __device__ __noinline__ int64_t cand_after_wave(const LineIndex *Lg, int t1, int
 // WPB: waves (= groups) per workgroup; DOUBLING: keep the pointer-doubling fallback for
 // chains with more than SEG_LIMIT jumps (otherwise such a group is reported irregular
 // and the host re-runs the stage with the DOUBLING configuration).
+// (the body for ONE group g, by one wave; the kernel below calls it once per wave, or -- behind k_chain_lite -- for every
+// group of the list that kernel declined)
 template <int PER, int EMAX, int WPB, bool DOUBLING>
-__global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const LineIndex *__restrict__ Lg,
-                                                         int64_t offset, int eof, ChainBufs B, int g0, int g1,
-                                                         int only_deferred, int ablate)
+__device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineIndex *__restrict__ Lg, int64_t offset, int eof,
+                                                 const ChainBufs &B, const int g, int only_deferred, int ablate)
 {
     constexpr int NMAX = PER * 64;
     constexpr int ND = DOUBLING ? NMAX : 1;
@@ -284,10 +287,8 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     __shared__ uint16_t dD_all[WPB][ND];       //                    rank (UNMARKED: not on the chain)
 
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = g0 + blockIdx.x * WPB + wid;
-    if (g >= g1) return;                 // no workgroup barrier is used below
     if (only_deferred == 1 && !(B.flags[g] & 4u)) return;   // second pass: only what the first one deferred
-    if (only_deferred == 3 && !(B.flags[g] & 8u)) return;   // behind k_chain_lite (ffq_lite.h): only the groups that kernel declined
+    if (only_deferred == 3) wave_sync();                    // (one group after another in the same LDS)
     // repair pass (only_deferred == 2): only the groups whose guess the verification rejected,
     // entered where the predecessor's chain says (no run-in speculation)
     const int64_t fpos = (only_deferred == 2) ? B.force[g] : FORCE_NONE;
@@ -991,6 +992,30 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
             atomicAdd(&B.prof[6], 1ull);
         }
     }
+}
+
+template <int PER, int EMAX, int WPB, bool DOUBLING>
+__global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const LineIndex *__restrict__ Lg,
+                                                         int64_t offset, int eof, ChainBufs B, int g0, int g1,
+                                                         int only_deferred, int ablate)
+{
+    const int wid = threadIdx.x >> 6;
+    const int g = g0 + blockIdx.x * WPB + wid;
+    if (g >= g1) return;                 // no workgroup barrier is used below
+    chain_wave_group<PER, EMAX, WPB, DOUBLING>(L, Lg, offset, eof, B, g, only_deferred, ablate);
+}
+
+// behind k_chain_lite (ffq_lite.h): the groups that kernel declined, from its list -- a grid of a few thousand waves takes
+// them one after another (a launch over ALL groups, most of which return at once, cost 75 us per 10 GiB).  A kernel of its
+// own: with both call sites in one kernel the register allocation of the direct one suffered (119 -> 201 VGPRs).
+template <int PER, int EMAX, int WPB, bool DOUBLING>
+__global__ __launch_bounds__(WPB * 64) void k_chain_wave_list(LineIndex L, const LineIndex *__restrict__ Lg,
+                                                              int64_t offset, int eof, ChainBufs B)
+{
+    const int wid = threadIdx.x >> 6;
+    const uint32_t nl = *B.dcnt;
+    for (uint32_t i = blockIdx.x * WPB + wid; i < nl; i += gridDim.x * WPB)
+        chain_wave_group<PER, EMAX, WPB, DOUBLING>(L, Lg, offset, eof, B, (int)B.dlist[i], 3, 0);
 }
 
 // =========================================================================

@@ -259,7 +259,7 @@ static void free_chain(ffq_ctx *c)
     (void)hipFree(c->cb.y); (void)hipFree(c->cb.exit); (void)hipFree(c->cb.cnt); (void)hipFree(c->cb.flags);
     (void)hipFree(c->cb.lines); (void)hipFree(c->cb.qb); (void)hipFree(c->cb.term); (void)hipFree(c->cb.stage);
     (void)hipFree(c->cb.rloc); (void)hipFree(c->cb.qloc); (void)hipFree(c->cb.part); (void)hipFree(c->cb.mins);
-    (void)hipFree(c->cb.force);
+    (void)hipFree(c->cb.force); (void)hipFree(c->cb.dlist);
     (void)hipFree(c->sbbase); (void)hipFree(c->tinfo4);
     (void)hipFree(c->tileq); (void)hipFree(c->sbq); (void)hipFree(c->sbqbase);
     c->sbbase = nullptr; c->tinfo4 = nullptr;
@@ -360,7 +360,8 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
     HIPCHK(hipMalloc((void **)&c->cb.y, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.exit, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.cnt, (size_t)ng * 4));
-    HIPCHK(hipMalloc((void **)&c->cb.flags, (size_t)(2 * ng + 4) * 4));      // (flags | sbase | dhead: one fill per scan, chain_bufs)
+    HIPCHK(hipMalloc((void **)&c->cb.flags, (size_t)(2 * ng + 4) * 4));      // (flags | sbase | dhead | dcnt: one fill per scan, chain_bufs)
+    HIPCHK(hipMalloc((void **)&c->cb.dlist, (size_t)ng * 4));
     HIPCHK(hipMalloc((void **)&c->cb.lines, (size_t)ng * 4));
     HIPCHK(hipMalloc((void **)&c->cb.qb, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.term, (size_t)ng * sizeof(GroupTerm)));
@@ -679,6 +680,7 @@ static ChainBufs chain_bufs(ffq_ctx *c, int ngroups, int nmax)
     cb.prof = nullptr;
     cb.sbase = reinterpret_cast<int32_t *>(cb.flags + ngroups);
     cb.dhead = cb.flags + 2 * (size_t)ngroups;
+    cb.dcnt = cb.dhead + 1;
     return cb;
 }
 
@@ -717,20 +719,24 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     const int ablate = abl ? atoi(abl) : 0;
     if (PROBES && getenv("FFQ_PROF")) {
         if (!c->prof_d) HIPCHK(hipMalloc((void **)&c->prof_d, 128));
-        HIPCHK(hipMemsetAsync(c->prof_d, 0, 64, sA));
+        HIPCHK(hipMemsetAsync(c->prof_d, 0, 128, sA));
         cb.prof = c->prof_d;
     }
-    HIPCHK(hipMemsetAsync(cb.flags, 0, (2 * (size_t)ngroups + 1) * 4, sA));      // flags, and: no group has a chunk of the walked groups' stage yet
+    HIPCHK(hipMemsetAsync(cb.flags, 0, (2 * (size_t)ngroups + 2) * 4, sA));      // flags, and: no group has a chunk of the walked groups' stage yet
     static const bool no_lite = getenv("FFQ_NO_LITE") != nullptr;
-    const bool lite = !dense_cfg && ablate == 0 && !cb.prof && !no_lite;
+    const bool lite = !dense_cfg && ablate == 0 && (!cb.prof || (PROBES && getenv("FFQ_PROF_LITE"))) && !no_lite;
     if (lite)
         // ordinary groups by the lean kernel; what it declines (flag bit 3) goes to k_chain_wave right behind
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lite<WPB_LITE>), dim3((ngroups + WPB_LITE - 1) / WPB_LITE), dim3(WPB_LITE * 64), 0, sA,
                            L, a.offset, cb, ngroups);
-    if (!dense_cfg)
+    if (lite)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave_list<PER_FAST, EMAX_FAST, WPB_FAST, false>),
+                           dim3(std::min((ngroups + WPB_FAST - 1) / WPB_FAST, 4096)), dim3(WPB_FAST * 64), 0, sA, L,
+                           (const LineIndex *)c->d_L, a.offset, a.eof, cb);
+    else if (!dense_cfg)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
                            dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
-                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, lite ? 3 : 0, ablate);
+                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_DENSE, EMAX_DENSE, WPB_DENSE, true>),
                            dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
@@ -1130,8 +1136,11 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
         }
         if (PROBES && tiers && getenv("FFQ_PROF") && c->prof_d) {
-            unsigned long long hp[8];
-            HIPCHK(hipMemcpy(hp, c->prof_d, 64, hipMemcpyDeviceToHost));
+            unsigned long long hp[16];
+            HIPCHK(hipMemcpy(hp, c->prof_d, 128, hipMemcpyDeviceToHost));
+            if (getenv("FFQ_PROF_LITE"))
+                fprintf(stderr, "[ffq prof] k_chain_lite declined of %d groups: first/last/offset %llu, tile over %d entries / dense look-ahead %llu, no node / too many %llu, "
+                        "a node it does not take on the chain %llu, stage full %llu\n", st.ngroups, hp[8], LT_E, hp[9], hp[10], hp[11], hp[12]);
             if (hp[6])
                 fprintf(stderr, "[ffq prof] k_chain_wave per-wave cycles: load %.0f lds %.0f nodes %.0f scan %.0f member %.0f summary %.0f (waves %llu)\n",
                         (double)hp[0] / hp[6], (double)hp[1] / hp[6], (double)hp[2] / hp[6], (double)hp[3] / hp[6],

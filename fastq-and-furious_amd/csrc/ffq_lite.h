@@ -29,6 +29,13 @@ constexpr int LT_B = 14;                   // words a node's call looks at, its 
 constexpr uint32_t LK_OK = 0, LK_GEN = 1;  // node word: successor node (10 bits, NO_NODE: past the own tiles) | kind << 10 | mi << 12
 constexpr uint32_t FLAG_LITE_DECLINED = 8u;
 
+__device__ __forceinline__ void lite_decline(const ChainBufs &B, int g, int why = 0)
+{
+    if (PROBES && B.prof) atomicAdd(&B.prof[8 + why], 1ull);      // (instrumented build: why groups are declined)
+    B.flags[g] = FLAG_LITE_DECLINED;
+    B.dlist[atomicAdd(B.dcnt, 1u)] = (uint32_t)g;
+}
+
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t offset, ChainBufs B, int ng)
 {
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     // of the run-in tail (every "\n@" there is a candidate)
     bool ok = g > 0 && own1 + 1 <= L.ntiles && (((int64_t)(wt0 + OWN_T + 2) << TILE_SHIFT) + L.s + 4 < L.len()) &&
               offset <= wpos0 + L.s + (TILE - RUNIN_BYTES);
-    if (!ok) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }
+    if (!ok) { if (lane == 0) lite_decline(B, g, 0); return; }
     // ---- the window's entries, one memory round trip --------------------------------------------------------------
     const uint32_t cl = (lane < OWN_T + 2) ? L.cnt[wt0 + lane] : 0u;
     uint32_t ev[OWN_T + 1][3];
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
         if (k >= 1 && k <= OWN_T) lines += (uint32_t)tc[k];
     }
     if (tc[OWN_T + 1] > SLOT) ok = false;                            // (a dense look-ahead tile keeps its entries elsewhere)
-    if (!ok) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }
+    if (!ok) { if (lane == 0) lite_decline(B, g, 1); return; }
     const int lac = min(tc[OWN_T + 1], LT_LA);
     const int own_hi = tb[OWN_T + 1], nwin = own_hi + lac;
     // ---- words + nodes, tile by tile --------------------------------------------------------------------------------
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     if (lane < lac)
         went[own_hi + lane] = (((uint32_t)(OWN_T + 1) << TILE_SHIFT) + (uint32_t)L.s + (la_raw & OFF_MASK)) |
                               ((la_raw >> 14) << WF_SHIFT) | (NO_NODE << WN_SHIFT);
-    if (ncomp == 0 || ncomp > LT_NODES) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }     // (no candidate: the chain passes over -- a search of its own)
+    if (ncomp == 0 || ncomp > LT_NODES) { if (lane == 0) lite_decline(B, g, 2); return; }     // (no candidate: the chain passes over -- a search of its own)
     wave_sync();
     // ---- one scanner call per node ------------------------------------------------------------------------------------
     // A record of this kernel's kind: header line, mi - 1 sequence lines, the '+' line, as many quality lines -- entry k + mi
@@ -178,13 +185,20 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
             const int r = b + __ffsll((long long)ns) - 1;
             MB[u] |= (~0ull << b) & (r == 63 ? ~0ull : ((2ull << r) - 1ull));
             const uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)infr[u], r);
-            if (((ir >> 10) & 3u) != LK_OK) bad = true;        // a node this kernel does not take lies on the chain
+            if (((ir >> 10) & 3u) != LK_OK) {
+                // a node this kernel does not take lies on the chain.  In the run-in that is a chain started at a false
+                // candidate (a quality line that begins with '@': one group in twenty starts so) which led nowhere: start
+                // again at the next candidate of the run-in -- the entry stays a guess, the verification decides (what was
+                // walked so far lies in front of the own tiles: nothing of it is staged)
+                if (u * 64 + r + 1 < n_runin) cur = u * 64 + r + 1;
+                else bad = true;
+            }
             else if ((ir & WN_MASK) == NO_NODE) {               // the chain leaves the own tiles
                 lastn = u * 64 + r; last_inf = ir; last_k = (uint32_t)__builtin_amdgcn_readlane((int)kreg[u], r);
             } else cur = (int)(ir & WN_MASK);
         }
     }
-    if (bad || lastn < 0) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }
+    if (bad || lastn < 0) { if (lane == 0) lite_decline(B, g, 3); return; }
     // ---- records of the own tiles, staged in chain order -----------------------------------------------------------------
     uint32_t ntot = 0;
     unsigned long long OWN[NB];
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
         OWN[u] = MB[u] & (lo <= 0 ? ~0ull : lo >= 64 ? 0ull : (~0ull << lo));
         ntot += (uint32_t)__popcll(OWN[u]);
     }
-    if (ntot > (uint32_t)B.nmax) { if (lane == 0) B.flags[g] = FLAG_LITE_DECLINED; return; }
+    if (ntot > (uint32_t)B.nmax) { if (lane == 0) lite_decline(B, g, 4); return; }
     StageRec *stg = B.stage + (int64_t)g * B.nmax;
     uint32_t nbase = 0, qsum = 0;
     int64_t Y = Y_UNRES;
