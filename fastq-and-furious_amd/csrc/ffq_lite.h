@@ -11,9 +11,9 @@
 // turns up on the chain: a node whose call does not resolve within the LT_B entries behind it (a record of many lines,
 // an INVALID '+' line, a successor far away), a chain that stops, too many nodes.  Declined groups are run by
 // k_chain_wave right behind (only_deferred == 3); repair passes are k_chain_wave's as before.
-//   window:  one word per entry (position | flags | node id) from six entries per lane and tile, one pass each
+//   window:  the entries as they are stored, 2 bytes each, six per lane and tile, one pass each
 //   nodes:   the "\n@" matches of the run-in tail and the own tiles, numbered in entry order
-//   calls:   a thread per node, the LT_B words behind its entry
+//   calls:   a thread per node, from the LT_B entries behind its own (distances modulo the tile size)
 //   chain:   run by run from the window's first node (a run = nodes whose successor is the very next node: one
 //            ballot per 64), records of the own tiles staged by all lanes of a run at once
 #pragma once
@@ -36,15 +36,21 @@ __device__ __forceinline__ void lite_decline(const ChainBufs &B, int g, int why 
     B.dlist[atomicAdd(B.dcnt, 1u)] = (uint32_t)g;
 }
 
+// LDS per wave: the window's entries as they are stored (16 bits each: offset in the tile | flags << 14), tile after tile
+// with no gap, + the node list (entry index | tile of the window << 11 | "the tile ends within LT_B entries" << 14).
+// Positions inside ONE scanner call are taken relative to the call's "\n@" entry, modulo the tile size: the LT_B entries a
+// call looks at span less than a tile (checked per node), so (off_j - off_0) & (TILE - 1) is the exact distance whether or
+// not a tile boundary lies in between -- no per-entry word has to be built, the window is 2 bytes per entry, and eight
+// waves per SIMD fit where the word window allowed four.
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t offset, ChainBufs B, int ng)
 {
-    __shared__ uint32_t went_all[WPB][LT_WIN + 16];
-    __shared__ uint16_t nidx_all[WPB][LT_NODES];
+    __shared__ __attribute__((aligned(4))) uint16_t raw_all[WPB][LT_WIN + 16];
+    __shared__ uint16_t nidx_all[WPB][LT_NODES + 4];
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int g = blockIdx.x * WPB + wid;
     if (g >= ng) return;
-    uint32_t *went = went_all[wid];
+    uint16_t *raw = raw_all[wid];
     uint16_t *nidx = nidx_all[wid];
     const int own0 = g * OWN_T, own1 = own0 + OWN_T, wt0 = own0 - 1;
     const int64_t wpos0 = (int64_t)wt0 << TILE_SHIFT;
@@ -71,31 +77,29 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     for (int k = 0; k <= OWN_T + 1; k++) {
         tc[k] = (int)__builtin_amdgcn_readlane((int)cl, k);
         if (k <= OWN_T) { tb[k + 1] = tb[k] + tc[k]; if (tc[k] > LT_E) ok = false; }
+        if (k >= 1 && tc[k] < LT_B) ok = false;                      // (a call's entries cross one tile boundary at most)
         if (k >= 1 && k <= OWN_T) lines += (uint32_t)tc[k];
     }
     if (tc[OWN_T + 1] > SLOT) ok = false;                            // (a dense look-ahead tile keeps its entries elsewhere)
     if (!ok) { if (lane == 0) lite_decline(B, g, 1); return; }
     const int lac = min(tc[OWN_T + 1], LT_LA);
     const int own_hi = tb[OWN_T + 1], nwin = own_hi + lac;
-    // ---- words + nodes, tile by tile --------------------------------------------------------------------------------
+    // ---- entries -> LDS as they are; nodes (the "\n@" matches of the run-in tail and the own tiles) numbered ------------
     int ncomp = 0, n_runin = 0;
 #pragma unroll
     for (int k = 0; k <= OWN_T; k++) {
         const int c = tc[k];
-        const uint32_t relb = (uint32_t)(k << TILE_SHIFT) + (uint32_t)L.s;
-        uint32_t x[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) x[i] = (i & 1) ? (ev[k][i >> 1] >> 16) : (ev[k][i >> 1] & 0xFFFFu);
         const int nv = min(max(c - 6 * lane, 0), 6);
         uint32_t at = 0;
 #pragma unroll
         for (int h = 0; h < 3; h++) at |= (((ev[k][h] >> 14) & 1u) | ((ev[k][h] >> 29) & 2u)) << (2 * h);
         at &= (1u << nv) - 1u;
         if (k == 0) {
-            // the run-in tile: only its tail makes candidates
+            // the run-in tile: only its tail makes candidates (offset >= TILE - RUNIN_BYTES: bit 13 of the offset)
+            static_assert(RUNIN_BYTES * 2 == TILE, "the tail test reads one bit of the offset");
             uint32_t tailm = 0;
 #pragma unroll
-            for (int i = 0; i < 6; i++) if ((x[i] & OFF_MASK) >= (uint32_t)(TILE - RUNIN_BYTES)) tailm |= 1u << i;
+            for (int h = 0; h < 3; h++) tailm |= (((ev[k][h] >> 13) & 1u) | ((ev[k][h] >> 28) & 2u)) << (2 * h);
             at &= tailm;
         }
         const uint32_t nc = __popc(at);
@@ -103,31 +107,24 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
         uint32_t id = (uint32_t)ncomp + incl - nc;
         ncomp += (int)__shfl((int)incl, 63);
         if (6 * lane < c) {
-            uint32_t *wdst = went + tb[k] + 6 * lane;
-            const uint32_t wconst = relb + (NO_NODE << WN_SHIFT);
+            // (what lies past the tile's count is overwritten by the next tile's entries, written later, or lies past nwin)
+            uint16_t *dst = raw + tb[k] + 6 * lane;
 #pragma unroll
-            for (int i = 0; i < 6; i++)
-                wdst[i] = __umul24(x[i] >> 14, (1u << WF_SHIFT) - (1u << 14)) + (x[i] + wconst);      // (offset | flags << 18 | no node)
+            for (int h = 0; h < 3; h++) { dst[2 * h] = (uint16_t)ev[k][h]; dst[2 * h + 1] = (uint16_t)(ev[k][h] >> 16); }
             uint32_t mrem = at;
             while (mrem) {
                 const int i = __ffs((int)mrem) - 1;
                 mrem &= mrem - 1u;
-                uint32_t half = ev[k][0];
-                if ((i >> 1) == 1) half = ev[k][1];
-                if ((i >> 1) == 2) half = ev[k][2];
-                const uint32_t off = ((i & 1) ? (half >> 16) : half) & OFF_MASK;
-                const uint32_t idw = min(id, (uint32_t)(LT_NODES - 1));
-                nidx[idw] = (uint16_t)(tb[k] + 6 * lane + i);
-                wdst[i] = (relb + off) | ((uint32_t)FL_AT << WF_SHIFT) | (idw << WN_SHIFT);
+                const int at_i = 6 * lane + i;
+                nidx[min(id, (uint32_t)LT_NODES)] = (uint16_t)((tb[k] + at_i) | (k << 11) | ((c - at_i < LT_B) ? 0x4000 : 0));
                 id++;
             }
         }
         if (k == 0) n_runin = ncomp;
     }
-    if (lane < lac)
-        went[own_hi + lane] = (((uint32_t)(OWN_T + 1) << TILE_SHIFT) + (uint32_t)L.s + (la_raw & OFF_MASK)) |
-                              ((la_raw >> 14) << WF_SHIFT) | (NO_NODE << WN_SHIFT);
+    if (lane < lac) raw[own_hi + lane] = (uint16_t)la_raw;
     if (ncomp == 0 || ncomp > LT_NODES) { if (lane == 0) lite_decline(B, g, 2); return; }     // (no candidate: the chain passes over -- a search of its own)
+    if (lane < 3) nidx[ncomp + lane] = 0x7FF;                 // behind the last node: no entry index any successor could have
     wave_sync();
     // ---- one scanner call per node ------------------------------------------------------------------------------------
     // A record of this kernel's kind: header line, mi - 1 sequence lines, the '+' line, as many quality lines -- entry k + mi
@@ -136,38 +133,52 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     // lie in front of pos5 - 1: positions grow with the index, so no earlier entry can be the match); a node whose call
     // looks different (another wrapping of the qualities, an INVALID '+' line, more than six sequence lines) is not taken
     constexpr int NB = LT_NODES / 64;
-    uint32_t infr[NB], kreg[NB];           // node u * 64 + lane: its word (successor | kind | mi) and its entry
+    constexpr uint32_t TM = (uint32_t)TILE - 1u;
+    uint32_t infr[NB], kreg[NB];           // node u * 64 + lane: its word (successor | kind | mi) and its list entry
     unsigned long long NS[NB];             // (a run = nodes whose successor is the very next node; NS = the nodes that end one)
 #pragma unroll
     for (int u = 0; u < NB; u++) {
         const int c = u * 64 + lane;
-        uint32_t inf = LK_GEN << 10;
-        int k = 0;
+        uint32_t inf = LK_GEN << 10, kw = 0;
         if (u * 64 < ncomp && c < ncomp) {                     // (the first test is wave-uniform)
-            k = nidx[c];
+            kw = nidx[c];
+            const int k = (int)(kw & 0x7FFu);
             if (k + LT_B < nwin) {
-                uint32_t w[8];
+                uint32_t r[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) w[i] = went[k + i];
-                const uint32_t P0 = w[0] & WP_MASK, P1 = w[1] & WP_MASK;
+                for (int i = 0; i < 8; i++) r[i] = raw[k + i];
+                const uint32_t r13 = raw[k + LT_B - 1];
+                // distances from the call's own entry, modulo the tile: exact if the LT_B entries span less than a tile --
+                // no tile boundary among them, or the last one's offset already below the first one's
+                const bool span_ok = !(kw & 0x4000u) || (r13 & TM) < (r[0] & TM);
+                const uint32_t P1 = (r[1] - r[0]) & TM;
                 uint32_t pm = 0;                              // "\n+" at >= seq_beg + 1 (:87-88)
 #pragma unroll
                 for (int i = 2; i <= 7; i++)
-                    if (((w[i] >> WF_SHIFT) & (uint32_t)FL_PLUS) && (w[i] & WP_MASK) >= P1 + 2u) pm |= 1u << i;
-                if (pm) {
+                    if (((r[i] >> 14) & (uint32_t)FL_PLUS) && ((r[i] - r[0]) & TM) >= P1 + 2u) pm |= 1u << i;
+                if (pm && span_ok) {
                     const int mi = __ffs((int)pm) - 1;        // 2 .. 7: 2 mi <= LT_B
-                    const uint32_t P3 = went[k + mi] & WP_MASK, Pq = went[k + mi + 1] & WP_MASK;
-                    const uint32_t ws = went[k + 2 * mi], wp = went[k + 2 * mi - 1];
-                    const bool invalid = (Pq - P3 - 1u > 1u) && (Pq - P3 != P1 - P0);      // :109-117
+                    const uint32_t P3 = (raw[k + mi] - r[0]) & TM, Pq = (raw[k + mi + 1] - r[0]) & TM;
+                    const uint32_t rs = raw[k + 2 * mi], rp = raw[k + 2 * mi - 1];
+                    const bool invalid = (Pq - P3 - 1u > 1u) && (Pq - P3 != P1);           // :109-117 (head_end - pos0 + 1 = P1)
                     const uint32_t qe = Pq + P3 - P1;                                       // :129
-                    const bool succ_ok = ((ws >> WF_SHIFT) & (uint32_t)FL_AT) && (ws & WP_MASK) + 1u >= qe &&
-                                         (mi == 2 || (wp & WP_MASK) + 1u < qe);
-                    if (!invalid && succ_ok)
-                        inf = ((ws >> WN_SHIFT) & WN_MASK) | (LK_OK << 10) | ((uint32_t)mi << 12);
+                    const bool succ_ok = ((rs >> 14) & (uint32_t)FL_AT) && ((rs - r[0]) & TM) + 1u >= qe &&
+                                         (mi == 2 || ((rp - r[0]) & TM) + 1u < qe);
+                    if (!invalid && succ_ok) {
+                        // the successor as a node: one of the next three (every "\n@" of the own tiles is one), or an entry
+                        // of the look-ahead tile
+                        const uint32_t t = (uint32_t)(k + 2 * mi);
+                        uint32_t nx = 0xFFFFu;
+                        if ((nidx[c + 3] & 0x7FFu) == t) nx = (uint32_t)(c + 3);
+                        if ((nidx[c + 2] & 0x7FFu) == t) nx = (uint32_t)(c + 2);
+                        if ((nidx[c + 1] & 0x7FFu) == t) nx = (uint32_t)(c + 1);
+                        if (t >= (uint32_t)own_hi) nx = NO_NODE;
+                        if (nx != 0xFFFFu) inf = nx | (LK_OK << 10) | ((uint32_t)mi << 12);
+                    }
                 }
             }
         }
-        infr[u] = inf; kreg[u] = (uint32_t)k;
+        infr[u] = inf; kreg[u] = kw;
         NS[u] = __ballot(!(((inf >> 10) & 3u) == LK_OK && (inf & WN_MASK) == (uint32_t)(c + 1)));
     }
     // ---- chain membership: run by run, on the scalar side (the chain only moves forward: batch after batch) -------------
@@ -213,26 +224,33 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     StageRec *stg = B.stage + (int64_t)g * B.nmax;
     uint32_t nbase = 0, qsum = 0;
     int64_t Y = Y_UNRES;
+    // window position of a node's own entry: its tile of the window, its offset there (+ the sentinel's shift)
+    auto node_pos = [&](uint32_t kw_) -> uint32_t {
+        return (((kw_ >> 11) & 7u) << TILE_SHIFT) + (uint32_t)L.s + ((uint32_t)raw[kw_ & 0x7FFu] & TM);
+    };
 #pragma unroll
     for (int u = 0; u < NB; u++) {
         if (!OWN[u]) continue;                                  // (wave-uniform)
         if (bit_of_lane(OWN[u], lane)) {
-            const int k = (int)kreg[u];
+            const int k = (int)(kreg[u] & 0x7FFu);
             const int mi = (int)((infr[u] >> 12) & 15u);
+            const uint32_t r0 = raw[k];
+            const uint32_t base = (((kreg[u] >> 11) & 7u) << TILE_SHIFT) + (uint32_t)L.s + (r0 & TM);
             StageRec o;
-            o.p0 = (went[k] & WP_MASK) + 1u;
-            o.p1 = went[k + 1] & WP_MASK;
-            o.p3 = went[k + mi] & WP_MASK;
-            o.p4 = (went[k + mi + 1] & WP_MASK) + 1u;
+            o.p0 = base + 1u;
+            o.p1 = base + ((raw[k + 1] - r0) & TM);
+            o.p3 = base + ((raw[k + mi] - r0) & TM);
+            o.p4 = base + ((raw[k + mi + 1] - r0) & TM) + 1u;
             stg[nbase + (uint32_t)bits_below_lane(OWN[u])] = o;
             qsum += o.p3 - o.p1 - 1u;
         }
         if (Y == Y_UNRES)
-            Y = wpos0 + (int64_t)(went[__builtin_amdgcn_readlane((int)kreg[u], __ffsll((long long)OWN[u]) - 1)] & WP_MASK);
+            Y = wpos0 + (int64_t)node_pos((uint32_t)__builtin_amdgcn_readlane((int)kreg[u], __ffsll((long long)OWN[u]) - 1));
         nbase += (uint32_t)__popcll(OWN[u]);
     }
     // the candidate the chain goes on with: entry k + 2 mi of its last node
-    const int64_t EX = wpos0 + (int64_t)(went[(int)last_k + 2 * (int)((last_inf >> 12) & 15u)] & WP_MASK);
+    const int kl = (int)(last_k & 0x7FFu);
+    const int64_t EX = wpos0 + (int64_t)(node_pos(last_k) + (((uint32_t)raw[kl + 2 * (int)((last_inf >> 12) & 15u)] - (uint32_t)raw[kl]) & TM));
     if (Y == Y_UNRES) Y = EX;
     const uint32_t qtot = wave_sum_u32(qsum);                 // (a group's qualities are < 2^17 bytes)
     if (lane == 0) {
