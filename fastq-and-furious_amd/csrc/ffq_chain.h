@@ -88,6 +88,8 @@ struct ChainBufs {
     int32_t dchunks;
     uint32_t *dlist;     // [ng] groups k_chain_lite (ffq_lite.h) declined, in no particular order
     uint32_t *dcnt;      //      how many
+    uint32_t *ilist;     // [ng] groups that do not fit k_chain_wave (flag bit 0), as the first pass meets them: what
+    uint32_t *icnt;      //      k_dense_walk looks at, instead of at every group's flags
     int64_t *rloc;       // [ng] exclusive prefix of cnt inside the resolve block
     int64_t *qloc;       // [ng] same for qb
     int64_t *part;       // [nblk][4] block totals (cnt, qb, lines, -) -> exclusive prefixes
@@ -347,6 +349,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
         if (lane == 0) {
             B.y[g] = Y_UNRES; B.exit[g] = Y_UNRES; B.cnt[g] = 0; B.qb[g] = 0;
             B.flags[g] = 1; B.lines[g] = lines;      // (bit 2 cannot be pending: nothing was looked up)
+            if (only_deferred != 2) B.ilist[atomicAdd(B.icnt, 1u)] = (uint32_t)g;      // (the first pass's walker works from this list)
         }
         return;
     }
@@ -498,6 +501,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
         if (lane == 0) {
             B.y[g] = Y_UNRES; B.exit[g] = Y_UNRES; B.cnt[g] = 0; B.qb[g] = 0;
             B.flags[g] = 1; B.lines[g] = lines;      // (bit 2 cannot be pending: nothing was looked up)
+            if (only_deferred != 2) B.ilist[atomicAdd(B.icnt, 1u)] = (uint32_t)g;      // (the first pass's walker works from this list)
         }
         return;
     }

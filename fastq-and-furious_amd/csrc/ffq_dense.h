@@ -75,13 +75,11 @@ __device__ __forceinline__ const uint16_t *dw_tile_entries(const LineIndex &L, i
     return (at + c <= L.pool_cap) ? L.pool + at : nullptr;
 }
 
-__global__ __launch_bounds__(256) void k_dense_walk(LineIndex L, ChainBufs B, int64_t offset, int eof, int speculate,
-                                                    int walk_all, Ctl *ctl)
+// (the walk of ONE group by one wave; k_dense_walk below calls it per wave, or for every group of the first pass's list)
+__device__ __forceinline__ void dense_walk_group(const LineIndex &L, const ChainBufs &B, int64_t offset, int eof, int speculate,
+                                                 int walk_all, Ctl *ctl, const int g, DwLds &sm)
 {
-    __shared__ DwLds lds_all[4];
-    // (four groups per workgroup, one wave each, no barrier: nearly all of them return at once)
-    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + wid;
+    const int lane = threadIdx.x & 63;
     if (g >= B.ng || !(B.flags[g] & 1u)) return;
     const int64_t fpos = speculate ? FORCE_NONE : B.force[g];
     if (g > 0 && fpos == FORCE_NONE && !speculate) return;
@@ -94,7 +92,6 @@ __global__ __launch_bounds__(256) void k_dense_walk(LineIndex L, ChainBufs B, in
         const bool dense_here = wt0 + lane < wt1 && L.cnt[wt0 + lane] > (uint32_t)SLOT;
         if (__ballot(dense_here) == 0ull) return;
     }
-    DwLds &sm = lds_all[wid];
     uint32_t *went = sm.went, *info = sm.info;
     uint16_t *nidx = sm.nidx;
     const int64_t own_beg = ((int64_t)own0 << TILE_SHIFT) + L.s;        // coordinate of the own tiles' first byte
@@ -370,6 +367,24 @@ __global__ __launch_bounds__(256) void k_dense_walk(LineIndex L, ChainBufs B, in
         t.pos[0] = r.p0; t.pos[1] = r.p1; t.pos[2] = (r.p1 >= 0) ? r.p1 + 1 : -1;
         t.pos[3] = r.p3; t.pos[4] = r.p4; t.pos[5] = r.p5;
     }
+}
+
+// use_list: the first pass -- the groups k_chain_wave flagged are on B.ilist, a small grid takes them one after another (a
+// launch over ALL groups, nearly all of which return at once, cost 26 us per 10 GiB); else (repair passes) every group's
+// flags and forced entry are looked at.
+__global__ __launch_bounds__(256) void k_dense_walk(LineIndex L, ChainBufs B, int64_t offset, int eof, int speculate,
+                                                    int walk_all, Ctl *ctl, int use_list)
+{
+    __shared__ DwLds lds_all[4];
+    // (four groups per workgroup, one wave each, no barrier)
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (use_list) {
+        const uint32_t nl = *B.icnt;
+        for (uint32_t i = blockIdx.x * 4 + wid; i < nl; i += gridDim.x * 4)
+            dense_walk_group(L, B, offset, eof, speculate, walk_all, ctl, (int)B.ilist[i], lds_all[wid]);
+        return;
+    }
+    dense_walk_group(L, B, offset, eof, speculate, walk_all, ctl, blockIdx.x * 4 + wid, lds_all[wid]);
 }
 
 }  // namespace ffq

@@ -259,7 +259,7 @@ static void free_chain(ffq_ctx *c)
     (void)hipFree(c->cb.y); (void)hipFree(c->cb.exit); (void)hipFree(c->cb.cnt); (void)hipFree(c->cb.flags);
     (void)hipFree(c->cb.lines); (void)hipFree(c->cb.qb); (void)hipFree(c->cb.term); (void)hipFree(c->cb.stage);
     (void)hipFree(c->cb.rloc); (void)hipFree(c->cb.qloc); (void)hipFree(c->cb.part); (void)hipFree(c->cb.mins);
-    (void)hipFree(c->cb.force); (void)hipFree(c->cb.dlist);
+    (void)hipFree(c->cb.force); (void)hipFree(c->cb.dlist); (void)hipFree(c->cb.ilist);
     (void)hipFree(c->sbbase); (void)hipFree(c->tinfo4);
     (void)hipFree(c->tileq); (void)hipFree(c->sbq); (void)hipFree(c->sbqbase);
     c->sbbase = nullptr; c->tinfo4 = nullptr;
@@ -360,8 +360,9 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
     HIPCHK(hipMalloc((void **)&c->cb.y, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.exit, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.cnt, (size_t)ng * 4));
-    HIPCHK(hipMalloc((void **)&c->cb.flags, (size_t)(2 * ng + 4) * 4));      // (flags | sbase | dhead | dcnt: one fill per scan, chain_bufs)
+    HIPCHK(hipMalloc((void **)&c->cb.flags, (size_t)(2 * ng + 8) * 4));      // (flags | sbase | dhead | dcnt: one fill per scan, chain_bufs)
     HIPCHK(hipMalloc((void **)&c->cb.dlist, (size_t)ng * 4));
+    HIPCHK(hipMalloc((void **)&c->cb.ilist, (size_t)ng * 4));
     HIPCHK(hipMalloc((void **)&c->cb.lines, (size_t)ng * 4));
     HIPCHK(hipMalloc((void **)&c->cb.qb, (size_t)ng * 8));
     HIPCHK(hipMalloc((void **)&c->cb.term, (size_t)ng * sizeof(GroupTerm)));
@@ -681,6 +682,7 @@ static ChainBufs chain_bufs(ffq_ctx *c, int ngroups, int nmax)
     cb.sbase = reinterpret_cast<int32_t *>(cb.flags + ngroups);
     cb.dhead = cb.flags + 2 * (size_t)ngroups;
     cb.dcnt = cb.dhead + 1;
+    cb.icnt = cb.dhead + 2;
     return cb;
 }
 
@@ -700,7 +702,7 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
                            dim3((ngroups + WPB_DENSE - 1) / WPB_DENSE), dim3(WPB_DENSE * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 2, 0);
     // the groups that do not fit the kernel above (dense tiles) and whose entry is known: walked
-    hipLaunchKernelGGL(k_dense_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 0, dense_cfg ? 1 : 0, c->ctl);
+    hipLaunchKernelGGL(k_dense_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 0, dense_cfg ? 1 : 0, c->ctl, 0);
     return enqueue_resolve(c, a, cb, false);
 }
 
@@ -722,13 +724,28 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
         HIPCHK(hipMemsetAsync(c->prof_d, 0, 128, sA));
         cb.prof = c->prof_d;
     }
-    HIPCHK(hipMemsetAsync(cb.flags, 0, (2 * (size_t)ngroups + 2) * 4, sA));      // flags, and: no group has a chunk of the walked groups' stage yet
+    HIPCHK(hipMemsetAsync(cb.flags, 0, (2 * (size_t)ngroups + 3) * 4, sA));      // flags, and: no group has a chunk of the walked groups' stage yet
     static const bool no_lite = getenv("FFQ_NO_LITE") != nullptr;
     const bool lite = !dense_cfg && ablate == 0 && (!cb.prof || (PROBES && getenv("FFQ_PROF_LITE"))) && !no_lite;
-    if (lite)
-        // ordinary groups by the lean kernel; what it declines (flag bit 3) goes to k_chain_wave right behind
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lite<WPB_LITE>), dim3((ngroups + WPB_LITE - 1) / WPB_LITE), dim3(WPB_LITE * 64), 0, sA,
-                           L, a.offset, cb, ngroups);
+    if (lite) {
+        // ordinary groups by the lean kernel; what it declines (flag bit 3) goes to k_chain_wave right behind.  The groups it
+        // cannot take by their place -- the first one (sentinel, search offset), the last ones (the buffer's end) -- are
+        // k_chain_wave's from the start: two small launches IN FRONT of the lean kernel's, which is dispatched without a barrier
+        // so that their one-wave latency (30 us) runs under it (all three read the same finished line index and write different
+        // groups' summaries)
+        const int gl = lite_first_end_group(a.n_bytes, L.ntiles, ngroups);
+        // (order: the first small launch is an ordinary one -- the command processor waits for the index kernel there --, the
+        // second one and the lean kernel follow without a barrier: a barrier-free packet BEHIND the lean kernel's would only
+        // be looked at once that kernel's last workgroup has been dispatched, i.e. at its end)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>), dim3(1), dim3(WPB_FAST * 64), 0, sA,
+                           L, (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, 1, 0, 0);
+        if (gl < ngroups)
+            hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
+                                  dim3((ngroups - gl + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, nullptr, nullptr,
+                                  hipExtAnyOrderLaunch, L, (const LineIndex *)c->d_L, a.offset, a.eof, cb, gl, ngroups, 0, 0);
+        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lite<WPB_LITE>), dim3((ngroups + WPB_LITE - 1) / WPB_LITE), dim3(WPB_LITE * 64), 0, sA,
+                              nullptr, nullptr, hipExtAnyOrderLaunch, L, a.offset, cb, ngroups, gl);
+    }
     if (lite)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave_list<PER_FAST, EMAX_FAST, WPB_FAST, false>),
                            dim3(std::min((ngroups + WPB_FAST - 1) / WPB_FAST, 4096)), dim3(WPB_FAST * 64), 0, sA, L,
@@ -743,7 +760,8 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
     // the groups the kernel above declined (dense tiles), each from a guessed entry
     if (ablate == 0)
-        hipLaunchKernelGGL(k_dense_walk, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 1, dense_cfg ? 1 : 0, c->ctl);
+        hipLaunchKernelGGL(k_dense_walk, dim3((unsigned)std::min((ngroups + 3) / 4, 1024)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 1,
+                           dense_cfg ? 1 : 0, c->ctl, 1);
     return enqueue_resolve(c, a, cb, timed);
 }
 

@@ -26,7 +26,7 @@ constexpr int LT_LA = 64;                  // entries of the look-ahead tile it 
 constexpr int LT_WIN = (OWN_T + 1) * LT_E + LT_LA;
 constexpr int LT_NODES = 320;
 constexpr int LT_B = 14;                   // words a node's call looks at, its own included
-constexpr uint32_t LK_OK = 0, LK_GEN = 1;  // node word: successor node (10 bits, NO_NODE: past the own tiles) | kind << 10 | mi << 12
+constexpr uint32_t LK_OK = 0, LK_GEN = 1;  // node word: successor node (10 bits, NO_NODE: past the own tiles) | kind << 10 | mi << 12 | sj << 16
 constexpr uint32_t FLAG_LITE_DECLINED = 8u;
 
 __device__ __forceinline__ void lite_decline(const ChainBufs &B, int g, int why = 0)
@@ -42,8 +42,22 @@ __device__ __forceinline__ void lite_decline(const ChainBufs &B, int g, int why 
 // call looks at span less than a tile (checked per node), so (off_j - off_0) & (TILE - 1) is the exact distance whether or
 // not a tile boundary lies in between -- no per-entry word has to be built, the window is 2 bytes per entry, and eight
 // waves per SIMD fit where the word window allowed four.
+// the first group whose window does not lie at least four bytes in front of the buffer's end (host side: those groups, and
+// group 0, are launched as k_chain_wave's from the start)
+static inline int lite_first_end_group(int64_t n_bytes, int64_t ntiles, int ngroups)
+{
+    int gl = ngroups;
+    while (gl > 1) {
+        const int g = gl - 1;
+        const bool fits = (int64_t)g * OWN_T + OWN_T + 1 <= ntiles && (((int64_t)g * OWN_T + OWN_T + 1) << TILE_SHIFT) + 4 < n_bytes;
+        if (fits) break;
+        gl--;
+    }
+    return gl;
+}
+
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t offset, ChainBufs B, int ng)
+__global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t offset, ChainBufs B, int ng, int gl)
 {
     __shared__ __attribute__((aligned(4))) uint16_t raw_all[WPB][LT_WIN + 16];
     __shared__ uint16_t nidx_all[WPB][LT_NODES + 4];
@@ -57,7 +71,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     // not the first group (sentinel, search offset), not the last ones (every position of the window lies at least four
     // bytes in front of the buffer's end: none of the scanner's buffer-end rules can apply), the search offset in front
     // of the run-in tail (every "\n@" there is a candidate)
-    bool ok = g > 0 && own1 + 1 <= L.ntiles && (((int64_t)(wt0 + OWN_T + 2) << TILE_SHIFT) + L.s + 4 < L.len()) &&
+    // (the first group and those from gl on -- lite_first_end_group -- are k_chain_wave's by a launch of their own, beside this one)
+    if (g == 0 || g >= gl) return;
+    bool ok = own1 + 1 <= L.ntiles && (((int64_t)(wt0 + OWN_T + 2) << TILE_SHIFT) + L.s + 4 < L.len()) &&
               offset <= wpos0 + L.s + (TILE - RUNIN_BYTES);
     if (!ok) { if (lane == 0) lite_decline(B, g, 0); return; }
     // ---- the window's entries, one memory round trip --------------------------------------------------------------
@@ -80,7 +96,18 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
         if (k >= 1 && tc[k] < LT_B) ok = false;                      // (a call's entries cross one tile boundary at most)
         if (k >= 1 && k <= OWN_T) lines += (uint32_t)tc[k];
     }
-    if (tc[OWN_T + 1] > SLOT) ok = false;                            // (a dense look-ahead tile keeps its entries elsewhere)
+    bool dense = false;
+#pragma unroll
+    for (int k = 0; k <= OWN_T + 1; k++) dense = dense || tc[k] > SLOT;
+    if (dense) {
+        // a DENSE tile in the window: k_chain_wave would only find that the group does not fit it -- say so at once (flag
+        // bit 0, on the walker's list: ffq_dense.h), as that kernel does
+        if (lane == 0) {
+            B.y[g] = Y_UNRES; B.exit[g] = Y_UNRES; B.cnt[g] = 0; B.qb[g] = 0; B.flags[g] = 1; B.lines[g] = lines;
+            B.ilist[atomicAdd(B.icnt, 1u)] = (uint32_t)g;
+        }
+        return;
+    }
     if (!ok) { if (lane == 0) lite_decline(B, g, 1); return; }
     const int lac = min(tc[OWN_T + 1], LT_LA);
     const int own_hi = tb[OWN_T + 1], nwin = own_hi + lac;
@@ -162,18 +189,27 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
                     const uint32_t rs = raw[k + 2 * mi], rp = raw[k + 2 * mi - 1];
                     const bool invalid = (Pq - P3 - 1u > 1u) && (Pq - P3 != P1);           // :109-117 (head_end - pos0 + 1 = P1)
                     const uint32_t qe = Pq + P3 - P1;                                       // :129
-                    const bool succ_ok = ((rs >> 14) & (uint32_t)FL_AT) && ((rs - r[0]) & TM) + 1u >= qe &&
-                                         (mi == 2 || ((rp - r[0]) & TM) + 1u < qe);
+                    bool succ_ok = ((rs >> 14) & (uint32_t)FL_AT) && ((rs - r[0]) & TM) + 1u >= qe &&
+                                   (mi == 2 || ((rp - r[0]) & TM) + 1u < qe);
+                    int sj = 2 * mi;
+                    if (!succ_ok && !invalid) {
+                        // not the usual shape (qualities wrapped otherwise than the read, a line too many or too few): the
+                        // rule itself, entry by entry -- the first "\n@" behind the '+' line's end at >= pos5 - 1
+                        for (int j = mi + 2; j < LT_B && !succ_ok; j++) {
+                            const uint32_t rj = raw[k + j];
+                            if (((rj >> 14) & (uint32_t)FL_AT) && ((rj - r[0]) & TM) + 1u >= qe) { succ_ok = true; sj = j; }
+                        }
+                    }
                     if (!invalid && succ_ok) {
                         // the successor as a node: one of the next three (every "\n@" of the own tiles is one), or an entry
                         // of the look-ahead tile
-                        const uint32_t t = (uint32_t)(k + 2 * mi);
+                        const uint32_t t = (uint32_t)(k + sj);
                         uint32_t nx = 0xFFFFu;
                         if ((nidx[c + 3] & 0x7FFu) == t) nx = (uint32_t)(c + 3);
                         if ((nidx[c + 2] & 0x7FFu) == t) nx = (uint32_t)(c + 2);
                         if ((nidx[c + 1] & 0x7FFu) == t) nx = (uint32_t)(c + 1);
                         if (t >= (uint32_t)own_hi) nx = NO_NODE;
-                        if (nx != 0xFFFFu) inf = nx | (LK_OK << 10) | ((uint32_t)mi << 12);
+                        if (nx != 0xFFFFu) inf = nx | (LK_OK << 10) | ((uint32_t)mi << 12) | ((uint32_t)sj << 16);
                     }
                 }
             }
@@ -248,9 +284,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
             Y = wpos0 + (int64_t)node_pos((uint32_t)__builtin_amdgcn_readlane((int)kreg[u], __ffsll((long long)OWN[u]) - 1));
         nbase += (uint32_t)__popcll(OWN[u]);
     }
-    // the candidate the chain goes on with: entry k + 2 mi of its last node
+    // the candidate the chain goes on with: entry k + sj of its last node
     const int kl = (int)(last_k & 0x7FFu);
-    const int64_t EX = wpos0 + (int64_t)(node_pos(last_k) + (((uint32_t)raw[kl + 2 * (int)((last_inf >> 12) & 15u)] - (uint32_t)raw[kl]) & TM));
+    const int64_t EX = wpos0 + (int64_t)(node_pos(last_k) + (((uint32_t)raw[kl + (int)((last_inf >> 16) & 15u)] - (uint32_t)raw[kl]) & TM));
     if (Y == Y_UNRES) Y = EX;
     const uint32_t qtot = wave_sum_u32(qsum);                 // (a group's qualities are < 2^17 bytes)
     if (lane == 0) {
