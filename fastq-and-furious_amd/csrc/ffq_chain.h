@@ -165,13 +165,6 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return (uint32_t)__shfl((int)wave_incl_scan(v), 63);
 }
 
-// wave-local ordering of LDS traffic (several independent waves share a workgroup)
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // successor codes of a node (values below are node ids)
 constexpr uint32_t SN_OUT = 0xFFFFu;      // successor candidate lies beyond the window

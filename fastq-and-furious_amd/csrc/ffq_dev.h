@@ -275,6 +275,14 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
     return x;
 }
 
+// wave-local ordering of LDS traffic (several independent waves share a workgroup)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // 16-bit mask of the bytes of v equal to '\n' (bit p = byte p in memory order)
 __device__ __forceinline__ uint32_t nl_mask16(const uint4 v)
 {

@@ -255,7 +255,7 @@ __device__ __forceinline__ void scan_tile_rest(ScanLds &sm, const int tile, cons
             // (what does not fit gets an offset past the pool: nothing of it is stored or read)
             s_ovf = fits ? (unsigned long long)b * region + at : pool_cap;
             sm.dfl = 0u;
-            ctl->pool_any = 1u;
+            if (at == 0ull) ctl->pool_any = 1u;               // (the first allocation of a region says so: one store per region, not one per tile on ONE address)
             if (!fits) atomicOr(&ctl->err, ERR_POOL);
         }
         __syncthreads();
