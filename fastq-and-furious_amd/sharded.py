@@ -685,16 +685,34 @@ class SyntheticShard:
         self.ext_scanned_bytes = self.tail + self.n_own_bytes + self.head
         min_rec = self.rec_bytes if kind in ("single", "dense") else 120
         self.max_records = n_per + (self.tail + self.head) // min_rec + 64
-        if native is None:
+        auto = native is None
+        if auto:
             native = isinstance(transport, DistTransport) and not transport.gloo and world > 1 and os.environ.get("FFQ_SHARD_NATIVE", "1") != "0"
         self.native = bool(native)
         if self.native:
-            if isinstance(transport, LocalTransport):
-                self.scanner = NativeShardScanner(ctx, S, rank, world, local_world=transport.lw.native_world())
-            else:
-                uid = native_unique_id(transport.dist, dev) if isinstance(transport, DistTransport) else _hip.shard_unique_id()
-                self.scanner = NativeShardScanner(ctx, S, rank, world, unique_id=uid)
-        else:
+            try:
+                if isinstance(transport, LocalTransport):
+                    self.scanner = NativeShardScanner(ctx, S, rank, world, local_world=transport.lw.native_world())
+                else:
+                    uid = native_unique_id(transport.dist, dev) if isinstance(transport, DistTransport) else _hip.shard_unique_id()
+                    self.scanner = NativeShardScanner(ctx, S, rank, world, unique_id=uid)
+                made = 1
+            except Exception as e:      # noqa: BLE001
+                if not auto:
+                    raise
+                made = 0
+                import warnings
+                warnings.warn("rank %d: the library's own sharded step is not available (%s): this package's protocol over "
+                              "torch.distributed instead" % (rank, e))
+            if auto:
+                # every rank takes the same path: the C step only if every rank has it
+                flag = torch.tensor([made], dtype=torch.int32, device=dev)
+                transport.dist.all_reduce(flag, op=transport.dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if made:
+                        self.scanner.close()
+                    self.native = False
+        if not self.native:
             self.scanner = ShardScanner(HipBackend(ctx), transport, S)
         self._lanes = None
 
