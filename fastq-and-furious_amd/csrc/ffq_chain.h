@@ -112,7 +112,7 @@ struct DevRes {
     int32_t fast4_hint;  // written by k_finalize4 only: 1 = the four-line fast path stood on this buffer (probe scans)
     int32_t fused_bad;   // written by k_finalize4 only: FZ_BAD_* of the single-pass decode (ffq_fused.h), 0 = it stood
     int32_t fast4_dense; // written by k_finalize4 only: the row kernel refused a DENSE tile (its DENSE instantiation takes those)
-    int32_t pad_;
+    int32_t n_declined;  // general path: groups k_chain_lite (ffq_lite.h) left to k_chain_wave (many: the host skips the lean kernel next time)
 };
 
 // Result hand-over.  The last result-writing kernel of a scan copies the result block and the
@@ -1117,6 +1117,7 @@ __global__ __launch_bounds__(1024) void k_resolve_b(ChainBufs B, int nblk, int e
         res->bad_group = tbad;
         res->n_bad = (int32_t)((unsigned int)B.mins[2] - 0x7F7F7F7Fu);
         res->approx_records = carry_c;
+        res->n_declined = (int32_t)min(*B.dcnt, 0x7FFFFFFFu);
         res->bad_irregular = (tbad >= 0 && tbad < B.ng && (B.flags[tbad] & 5u)) ? 1 : 0;
         res->term_group = fallback ? -1 : tterm;
         res->end_offset = offset;

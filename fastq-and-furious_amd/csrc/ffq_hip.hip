@@ -99,6 +99,8 @@ struct ffq_ctx {
     RankBufs rk = {};                    // its scratch (ffq_ranked.h), grow-only
     int64_t rk_cap_tiles = 0, rk_cap_c = 0;
     int dense_skip = 0;                  // scans left that start with the dense configuration of them
+    bool lite_ran = false;               // the last general front used the lean kernel
+    int lite_skip = 0;                   // scans left whose general path runs k_chain_wave over all groups (the lean kernel declined too many)
     bool dense4_remember = false;        // four-line input with dense tiles (reads of a dozen bases): the fast path starts with k_rows4<., true>
     // single-pass index + decode (ffq_fused.h): per-tile phases, verdict; grow-only
     uint8_t *fz_qphase = nullptr;
@@ -463,7 +465,7 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 
 extern "C" void ffq_ctx_forget(ffq_ctx *c)
 {
-    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->dense4_remember = false; c->ranked_skip = 0; c->fused_skip = 0; c->fused_backoff = 15; }
+    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->lite_skip = 0; c->dense4_remember = false; c->ranked_skip = 0; c->fused_skip = 0; c->fused_backoff = 15; }
 }
 
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
@@ -726,7 +728,11 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     }
     HIPCHK(hipMemsetAsync(cb.flags, 0, (2 * (size_t)ngroups + 3) * 4, sA));      // flags, and: no group has a chunk of the walked groups' stage yet
     static const bool no_lite = getenv("FFQ_NO_LITE") != nullptr;
-    const bool lite = !dense_cfg && ablate == 0 && (!cb.prof || (PROBES && getenv("FFQ_PROF_LITE"))) && !no_lite;
+    bool lite = !dense_cfg && ablate == 0 && (!cb.prof || (PROBES && getenv("FFQ_PROF_LITE"))) && !no_lite;
+    // (a context whose recent input the lean kernel mostly declined -- tiles of more than LT_E lines that still fit the usual
+    // window: lines of 43-48 bytes -- runs k_chain_wave directly for a while: the list kernel is the slower way to run many groups)
+    if (lite && c->lite_skip > 0) { c->lite_skip--; lite = false; }
+    c->lite_ran = lite;
     if (lite) {
         // ordinary groups by the lean kernel; what it declines (flag bit 3) goes to k_chain_wave right behind.  The groups it
         // cannot take by their place -- the first one (sentinel, search offset), the last ones (the buffer's end) -- are
@@ -1288,6 +1294,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             res->ms_chain += ms;
             res->ms_total += ms;
         }
+        if (tiers && c->lite_ran && (int64_t)c->h_res->n_declined * 4 > (int64_t)st.ngroups) c->lite_skip = 15;
         fill_result(res, *c->h_res, path, st.retries + st.repairs);
         break;
     }

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const
     const long long ob = sbb + (long long)wave_sum_u32((t0 + lane < t) ? cb_raw : 0u) + L.s;
     if (!attempt) return;
     if (c > SLOT && (!DENSE || fused)) {     // dense tile: not this instantiation's (the DENSE one, or the general path)
-        if (lane == 0) { atomicMin(&hdr->irr_min, 0ull); hdr->dense_seen = 1; }
+        // (every dense tile says the same: look before storing -- 65536 atomics / stores onto one address took 2.9 ms)
+        if (lane == 0 && (hdr->irr_min != 0ull || !hdr->dense_seen)) { atomicMin(&hdr->irr_min, 0ull); hdr->dense_seen = 1; }
         return;
     }
     if (fused) {

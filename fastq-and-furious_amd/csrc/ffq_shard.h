@@ -591,7 +591,7 @@ extern "C" int ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_h
     sh_halo_sizes(s->B, s->rank, s->tail_bytes, s->head_bytes, &tail, &head);
     s->v = sh_view(s, tail, head);
     s->ext = d_ext; s->start = -1;
-    s->flags = flags & ~(uint32_t)FFQ_F_NO_TIMING; s->qual_add = qual_add;
+    s->flags = flags; s->qual_add = qual_add;        // (FFQ_F_NO_TIMING: no marks; the hand-off's wait in front of the scan rules the barrier-free dispatch out)
     s->d_table = d_table; s->table_cap = table_cap; s->d_qual = d_qual; s->qual_cap = qual_cap; s->d_qoff = d_qoff;
     s->handoff_bytes = 0; s->handoff_timed = false;
     int rc = shard_handoff(s, d_ext, tail, overlap_handoff != 0);
