@@ -750,7 +750,8 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
                                   dim3((ngroups - gl + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, nullptr, nullptr,
                                   hipExtAnyOrderLaunch, L, (const LineIndex *)c->d_L, a.offset, a.eof, cb, gl, ngroups, 0, 0);
         hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lite<WPB_LITE>), dim3((ngroups + WPB_LITE - 1) / WPB_LITE), dim3(WPB_LITE * 64), 0, sA,
-                              nullptr, nullptr, hipExtAnyOrderLaunch, L, a.offset, cb, ngroups, gl);
+                              nullptr, nullptr, hipExtAnyOrderLaunch, L, a.offset, cb, ngroups, gl,
+                              (PROBES && getenv("FFQ_LITE_ABLATE")) ? atoi(getenv("FFQ_LITE_ABLATE")) : 0);
     }
     if (lite)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave_list<PER_FAST, EMAX_FAST, WPB_FAST, false>),

@@ -26,7 +26,7 @@ constexpr int LT_LA = 64;                  // entries of the look-ahead tile it 
 constexpr int LT_WIN = (OWN_T + 1) * LT_E + LT_LA;
 constexpr int LT_NODES = 320;
 constexpr int LT_B = 14;                   // words a node's call looks at, its own included
-constexpr uint32_t LK_OK = 0, LK_GEN = 1;  // node word: successor node (10 bits, NO_NODE: past the own tiles) | kind << 10 | mi << 12 | sj << 16
+constexpr uint32_t LK_OK = 0, LK_GEN = 1, LK_SLOW = 2;  // node word: successor node (10 bits, NO_NODE: past the own tiles) | kind << 10 | mi << 12 | sj << 16
 constexpr uint32_t FLAG_LITE_DECLINED = 8u;
 
 __device__ __forceinline__ void lite_decline(const ChainBufs &B, int g, int why = 0)
@@ -57,7 +57,7 @@ static inline int lite_first_end_group(int64_t n_bytes, int64_t ntiles, int ngro
 }
 
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t offset, ChainBufs B, int ng, int gl)
+__global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t offset, ChainBufs B, int ng, int gl, int ablate)
 {
     __shared__ __attribute__((aligned(4))) uint16_t raw_all[WPB][LT_WIN + 16];
     __shared__ uint16_t nidx_all[WPB][LT_NODES + 4];
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     if (ncomp == 0 || ncomp > LT_NODES) { if (lane == 0) lite_decline(B, g, 2); return; }     // (no candidate: the chain passes over -- a search of its own)
     if (lane < 3) nidx[ncomp + lane] = 0x7FF;                 // behind the last node: no entry index any successor could have
     wave_sync();
+    if (PROBES && ablate == 1) { if (lane == 0) B.lines[g] = lines + (uint32_t)ncomp; return; }      // (instruction counts per phase: tools/pmc_insts.sh)
     // ---- one scanner call per node ------------------------------------------------------------------------------------
     // A record of this kernel's kind: header line, mi - 1 sequence lines, the '+' line, as many quality lines -- entry k + mi
     // is the "\n+" match, k + mi + 1 the '+' line's end, and the next call's "\n@" (the first one at >= pos5 - 1 behind the
@@ -189,17 +190,13 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
                     const uint32_t rs = raw[k + 2 * mi], rp = raw[k + 2 * mi - 1];
                     const bool invalid = (Pq - P3 - 1u > 1u) && (Pq - P3 != P1);           // :109-117 (head_end - pos0 + 1 = P1)
                     const uint32_t qe = Pq + P3 - P1;                                       // :129
-                    bool succ_ok = ((rs >> 14) & (uint32_t)FL_AT) && ((rs - r[0]) & TM) + 1u >= qe &&
-                                   (mi == 2 || ((rp - r[0]) & TM) + 1u < qe);
-                    int sj = 2 * mi;
-                    if (!succ_ok && !invalid) {
-                        // not the usual shape (qualities wrapped otherwise than the read, a line too many or too few): the
-                        // rule itself, entry by entry -- the first "\n@" behind the '+' line's end at >= pos5 - 1
-                        for (int j = mi + 2; j < LT_B && !succ_ok; j++) {
-                            const uint32_t rj = raw[k + j];
-                            if (((rj >> 14) & (uint32_t)FL_AT) && ((rj - r[0]) & TM) + 1u >= qe) { succ_ok = true; sj = j; }
-                        }
-                    }
+                    const bool succ_ok = ((rs >> 14) & (uint32_t)FL_AT) && ((rs - r[0]) & TM) + 1u >= qe &&
+                                         (mi == 2 || ((rp - r[0]) & TM) + 1u < qe);
+                    const int sj = 2 * mi;
+                    // not the usual shape (qualities wrapped otherwise than the read, a line too many or too few -- and nearly
+                    // every FALSE candidate, which no chain visits): the rule itself, entry by entry, is applied by the whole
+                    // wave IF the chain gets there (LK_SLOW, below) -- as a loop in here every wave paid for it in every batch
+                    if (!invalid && !succ_ok) inf = (LK_SLOW << 10) | ((uint32_t)mi << 12);
                     if (!invalid && succ_ok) {
                         // the successor as a node: one of the next three (every "\n@" of the own tiles is one), or an entry
                         // of the look-ahead tile
@@ -217,6 +214,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
         infr[u] = inf; kreg[u] = kw;
         NS[u] = __ballot(!(((inf >> 10) & 3u) == LK_OK && (inf & WN_MASK) == (uint32_t)(c + 1)));
     }
+    if (PROBES && ablate == 2) { uint32_t x = 0; for (int u = 0; u < NB; u++) x += infr[u] + kreg[u]; if (x == 0x12345u) B.lines[g] = x; return; }
     // ---- chain membership: run by run, on the scalar side (the chain only moves forward: batch after batch) -------------
     unsigned long long MB[NB];
     int cur = 0, lastn = -1;
@@ -231,7 +229,31 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
             if (!ns) { MB[u] |= ~0ull << b; cur = (u + 1) * 64; if (cur >= ncomp) bad = true; break; }
             const int r = b + __ffsll((long long)ns) - 1;
             MB[u] |= (~0ull << b) & (r == 63 ? ~0ull : ((2ull << r) - 1ull));
-            const uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)infr[u], r);
+            uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)infr[u], r);
+            if (((ir >> 10) & 3u) == LK_SLOW) {
+                // the successor rule entry by entry, by the whole wave: the first "\n@" behind the '+' line's end at >= pos5 - 1
+                const uint32_t kw_ = (uint32_t)__builtin_amdgcn_readlane((int)kreg[u], r);
+                const int k = (int)(kw_ & 0x7FFu), mi = (int)((ir >> 12) & 15u), c = u * 64 + r;
+                const uint32_t r0 = raw[k];
+                const uint32_t P1 = ((uint32_t)raw[k + 1] - r0) & TM, P3 = ((uint32_t)raw[k + mi] - r0) & TM,
+                               Pq = ((uint32_t)raw[k + mi + 1] - r0) & TM;
+                const uint32_t qe = Pq + P3 - P1;
+                const int j = mi + 2 + lane;
+                const uint32_t rj = (j < LT_B) ? (uint32_t)raw[k + j] : 0u;
+                const unsigned long long hit = __ballot(j < LT_B && ((rj >> 14) & (uint32_t)FL_AT) && ((rj - r0) & TM) + 1u >= qe);
+                ir = LK_GEN << 10;
+                if (hit) {
+                    const int sj = mi + 2 + (__ffsll((long long)hit) - 1);
+                    const uint32_t t = (uint32_t)(k + sj);
+                    uint32_t nx = 0xFFFFu;
+                    if (t >= (uint32_t)own_hi) nx = NO_NODE;
+                    else {
+                        const unsigned long long nm = __ballot(lane < 8 && c + 1 + lane < ncomp && (uint32_t)(nidx[c + 1 + lane] & 0x7FFu) == t);
+                        if (nm) nx = (uint32_t)(c + 1 + (__ffsll((long long)nm) - 1));
+                    }
+                    if (nx != 0xFFFFu) ir = nx | (LK_OK << 10) | ((uint32_t)mi << 12) | ((uint32_t)sj << 16);
+                }
+            }
             if (((ir >> 10) & 3u) != LK_OK) {
                 // a node this kernel does not take lies on the chain.  In the run-in that is a chain started at a false
                 // candidate (a quality line that begins with '@': one group in twenty starts so) which led nowhere: start
@@ -245,6 +267,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
             } else cur = (int)(ir & WN_MASK);
         }
     }
+    if (PROBES && ablate == 3) { if (lane == 0) B.lines[g] = lines + (uint32_t)lastn + (uint32_t)MB[0]; return; }
     if (bad || lastn < 0) { if (lane == 0) lite_decline(B, g, 3); return; }
     // ---- records of the own tiles, staged in chain order -----------------------------------------------------------------
     uint32_t ntot = 0;
