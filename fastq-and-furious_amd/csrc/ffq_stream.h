@@ -35,6 +35,9 @@
 #include <poll.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <sys/stat.h>
+
+#include "ffq_pgz.h"
 
 #include <atomic>
 #include <chrono>
@@ -224,7 +227,7 @@ struct GzPool {
 };
 
 // threads that inflate (FFQ_GZ_THREADS; default: this process's share of the host's cores -- cores / LOCAL_WORLD_SIZE
-// when a launcher runs one rank per GPU --, at most 16): 1 = no pool
+// when a launcher runs one rank per GPU --, at most 32): 1 = no pool
 static int gz_threads_default()
 {
     const char *e = getenv("FFQ_GZ_THREADS");
@@ -232,7 +235,7 @@ static int gz_threads_default()
     unsigned hw = std::max<unsigned>(std::thread::hardware_concurrency(), 1u);
     const char *lw = getenv("LOCAL_WORLD_SIZE");
     if (lw && atoi(lw) > 1) hw = std::max<unsigned>(hw / (unsigned)atoi(lw), 1u);
-    return (int)std::min<unsigned>(hw, 16u);
+    return (int)std::min<unsigned>(hw, 32u);
 }
 
 struct ffq_stream {
@@ -254,6 +257,15 @@ struct ffq_stream {
     bool zraw_init = false;
     std::vector<GzJob> gz_jobs;
     int64_t bgzf_members = 0;           // members inflated by the pool (statistics)
+    // one member inflated by several threads (ffq_pgz.h: a regular file that is not BGZF), and zlib going on from
+    // the block boundary the engine gave up at
+    pgz::Engine *pgz = nullptr;
+    bool pgz_ok = true, pgz_active = false;
+    int pgz_small = 0;
+    int64_t pgz_member_off = 0, gz_file_size = -1;
+    bool z_raw = false;                 // zs is a raw deflate stream: the member's trailer is checked here
+    uint32_t z_crc = 0;
+    uint64_t z_isize = 0;
     int64_t handed_pos = 0;             // position of the source behind the last chunk handed out
     uint32_t flags = 0;                 // FFQ_F_DECODE_QUAL: qualities decoded per fill
     int qual_add = -33;
@@ -403,12 +415,95 @@ static int64_t gz_bgzf_batch(ffq_stream *s, uint8_t *dst, int64_t room)
     return out;
 }
 
+// The compressed input goes on at file offset `off` (what zin held is dropped).
+static void gz_reposition(ffq_stream *s, int64_t off)
+{
+    s->z_filepos = off;
+    s->zin_len = s->zin_pos = 0;
+    s->z_in_eof = s->gz_file_size >= 0 && off >= s->gz_file_size;
+}
+
+// At a member boundary of a regular file: the member is handed to the several-thread engine if enough of the file
+// lies behind it to be worth a batch (FFQ_PGZ_MIN compressed bytes, default 4 MiB).  false: zlib takes the member.
+static bool gz_pgz_begin(ffq_stream *s)
+{
+    if (s->gz_file_size < 0) {
+        struct stat st;
+        if (fstat(s->fd, &st) != 0 || !S_ISREG(st.st_mode)) { s->pgz_ok = false; return false; }
+        s->gz_file_size = (int64_t)st.st_size;
+    }
+    const int64_t member_off = s->z_filepos - (s->zin_len - s->zin_pos);
+    if (s->gz_file_size - member_off < pgz::env_i64("FFQ_PGZ_MIN", 4 << 20)) return false;
+    if (!s->pgz) {
+        s->pgz = new (std::nothrow) pgz::Engine();
+        if (!s->pgz || !s->pgz->init(s->fd, s->gz_threads, s->gz_file_size)) { delete s->pgz; s->pgz = nullptr; s->pgz_ok = false; return false; }
+    }
+    if (!s->pgz->begin(member_off)) return false;
+    s->pgz_member_off = member_off;
+    s->pgz_active = true;
+    return true;
+}
+
+// The engine gave up at a block boundary: zlib goes on from that bit with the window the engine holds, as a raw
+// deflate stream; the CRC-32 and the length run on here and are compared with the trailer (gz_raw_trailer).
+static bool gz_handoff(ffq_stream *s)
+{
+    pgz::Engine &e = *s->pgz;
+    if (inflateReset2(&s->zs, -15) != Z_OK) { s->z_msg = "inflateReset failed"; return false; }
+    if (e.win_valid > 0 && inflateSetDictionary(&s->zs, e.window + pgz::WSIZE - e.win_valid, (uInt)e.win_valid) != Z_OK) {
+        s->z_msg = "inflateSetDictionary failed";
+        return false;
+    }
+    int64_t byte = e.pos_bit >> 3;
+    const int r = (int)(e.pos_bit & 7);
+    if (r) {
+        uint8_t b = 0;
+        if (e.pread_full(&b, 1, byte) != 1) { s->z_msg = "compressed file ended before the end-of-stream marker was reached"; return false; }
+        if (inflatePrime(&s->zs, 8 - r, b >> r) != Z_OK) { s->z_msg = "inflatePrime failed"; return false; }
+        byte++;
+    }
+    gz_reposition(s, byte);
+    s->z_raw = true; s->z_crc = e.crc; s->z_isize = e.isize;
+    s->z_member = true;
+    return true;
+}
+
+static bool gz_raw_trailer(ffq_stream *s)
+{
+    while (s->zin_len - s->zin_pos < 8) {
+        if (s->z_in_eof) { s->z_msg = "compressed file ended before the end-of-stream marker was reached"; return false; }
+        if (gz_more_input(s) < 0) return false;
+    }
+    const uint8_t *t = s->zin + s->zin_pos;
+    const uint32_t fcrc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    const uint32_t flen = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    s->zin_pos += 8;
+    s->z_raw = false;
+    if (fcrc != s->z_crc) { s->z_msg = "incorrect data check"; return false; }
+    if (flen != (uint32_t)s->z_isize) { s->z_msg = "incorrect length check"; return false; }
+    return true;
+}
+
 static int64_t stream_gz_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
 {
     int64_t got = 0;
     *eof = false;
     while (got < n) {
         { std::lock_guard<std::mutex> lk(s->m); if (s->stop) break; }
+        if (s->pgz_active) {
+            got += s->pgz->read(dst + got, n - got);
+            if (s->pgz->pending()) continue;                           // (the chunk is full)
+            if (s->pgz->failed) { s->z_msg = s->pgz->msg; return -1; }
+            if (s->pgz->member_done) {
+                s->pgz_active = false;
+                if (s->pgz->end_off - s->pgz_member_off < (2 << 20) && ++s->pgz_small >= 4) s->pgz_ok = false;   // (a file of small members)
+                gz_reposition(s, s->pgz->end_off);
+            } else if (s->pgz->gave_up) {
+                s->pgz_active = false;
+                if (!gz_handoff(s)) return -1;
+            }
+            continue;
+        }
         if (s->zin_pos == s->zin_len && !s->z_in_eof) {
             const int r = gz_more_input(s);
             if (r == -2) break;                                  // asked to stop / park with nothing read
@@ -427,7 +522,8 @@ static int64_t stream_gz_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
                 if (r < 0) return -1;
                 if (r > 0) { got += r; continue; }
             }
-            if (inflateReset(&s->zs) != Z_OK) { s->z_msg = "inflateReset failed"; return -1; }
+            if (s->gz_threads > 1 && s->seekable && s->pgz_ok && gz_pgz_begin(s)) continue;
+            if (inflateReset2(&s->zs, 15 + 16) != Z_OK) { s->z_msg = "inflateReset failed"; return -1; }
             s->z_member = true;
         } else if (s->zin_pos == s->zin_len && s->z_in_eof) {
             s->z_msg = "compressed file ended before the end-of-stream marker was reached";
@@ -440,8 +536,16 @@ static int64_t stream_gz_read(ffq_stream *s, uint8_t *dst, int64_t n, bool *eof)
         const uInt out0 = s->zs.avail_out;
         const int zr = inflate(&s->zs, Z_NO_FLUSH);
         s->zin_pos = s->zin_len - (int64_t)s->zs.avail_in;
+        if (s->z_raw) {
+            const int64_t made = (int64_t)(out0 - s->zs.avail_out);
+            s->z_crc = (uint32_t)crc32(s->z_crc, dst + got, (uInt)made);
+            s->z_isize += (uint64_t)made;
+        }
         got += (int64_t)(out0 - s->zs.avail_out);
-        if (zr == Z_STREAM_END) s->z_member = false;
+        if (zr == Z_STREAM_END) {
+            if (s->z_raw && !gz_raw_trailer(s)) return -1;
+            s->z_member = false;
+        }
         else if (zr != Z_OK && zr != Z_BUF_ERROR) {
             s->z_msg = s->zs.msg ? s->zs.msg : (zr == Z_DATA_ERROR ? "not a gzip file / corrupt data" : "inflate failed");
             return -1;
@@ -554,6 +658,7 @@ static void stream_free(ffq_stream *s)
                 s->t_rows * 1e3);
     if (s->z_init) (void)inflateEnd(&s->zs);
     delete s->gz_pool;
+    delete s->pgz;
     if (s->zraw_init) (void)inflateEnd(&s->zraw);
     free(s->zin);
     if (s->b) {
@@ -757,10 +862,17 @@ extern "C" int64_t ffq_gunzip_fd(int fd, uint8_t *h_dst, int64_t cap, int64_t ch
     if (n_parallel_members) *n_parallel_members = s->bgzf_members;
     if (s->z_init) (void)inflateEnd(&s->zs);
     delete s->gz_pool;
+    delete s->pgz;
     if (s->zraw_init) (void)inflateEnd(&s->zraw);
     free(s->zin);
     delete s;
     return rc ? rc : got;
+}
+
+extern "C" void ffq_gunzip_stats(int64_t out[5])
+{
+    pgz::Stats &st = pgz::stats();
+    out[0] = st.batches.load(); out[1] = st.chunks.load(); out[2] = st.rejected.load(); out[3] = st.giveups.load(); out[4] = st.members.load();
 }
 
 extern "C" int ffq_stream_open_push(ffq_ctx *c, int64_t fbufsize, uint32_t flags, int qual_add, ffq_stream **out)

@@ -51,7 +51,7 @@ SYMBOLS = (
     "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_stream_path",
     "ffq_shard_unique_id", "ffq_shard_create", "ffq_shard_create_lane", "ffq_shard_world_create", "ffq_shard_world_abort",
     "ffq_shard_world_destroy", "ffq_shard_create_local", "ffq_shard_destroy", "ffq_shard_halo", "ffq_shard_exchange_halo",
-    "ffq_shard_step_submit", "ffq_shard_step_wait", "ffq_shard_transport", "ffq_shard_self_exchange", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_stream_open_push",
+    "ffq_shard_step_submit", "ffq_shard_step_wait", "ffq_shard_transport", "ffq_shard_self_exchange", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_gunzip_stats", "ffq_stream_open_push",
     "ffq_stream_push_buffer", "ffq_stream_push", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
@@ -230,6 +230,8 @@ def lib():
         L.ffq_stream_open_gzip.argtypes = [vp, i32, i64, u32, i32, i64, P(vp)]
         L.ffq_gunzip_fd.argtypes = [i32, vp, i64, i64, i32, P(i64)]
         L.ffq_gunzip_fd.restype = i64
+        L.ffq_gunzip_stats.argtypes = [P(i64)]
+        L.ffq_gunzip_stats.restype = None
         L.ffq_stream_open_push.argtypes = [vp, i64, u32, i32, P(vp)]
         L.ffq_stream_push_buffer.argtypes = [vp, P(vp), P(i64)]
         L.ffq_stream_push.argtypes = [vp, i64, i32]
@@ -774,6 +776,13 @@ def gunzip_fd(fd, cap, chunk=16 << 20, threads=0):
     if n < 0:
         check(int(n))
     return out[:n], int(npar.value)
+
+
+def gunzip_stats():
+    """Counters of the several-thread inflate of plain gzip members (ffq_gunzip_stats; csrc/ffq_pgz.h)."""
+    a = (ctypes.c_int64 * 5)()
+    lib().ffq_gunzip_stats(a)
+    return dict(zip(("batches", "chunks", "rejected", "giveups", "members"), (int(x) for x in a)))
 
 
 def default_context(device=None):

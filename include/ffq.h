@@ -319,7 +319,7 @@ int  ffq_stream_open_gzip(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags
                           ffq_stream **out);
 /* Members that say how long they are -- the BGZF blocks bgzip writes ("BC" extra field, SAM specification
  * section 4.1) -- are located without inflating anything and inflated side by side by FFQ_GZ_THREADS threads
- * (default: the host's cores, at most 16; 1 = one member at a time), each straight into its place in the
+ * (default: the host's cores, at most 32; 1 = one member at a time), each straight into its place in the
  * chunk; every member is checked against the length and CRC-32 of its trailer, and a file that is not what
  * its headers promise goes through the one-at-a-time inflate from that member on (same bytes or same error).
  *
@@ -329,6 +329,20 @@ int  ffq_stream_open_gzip(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags
  * more than cap, FFQ_E_ARG for corrupt input (ffq_last_error says what); *n_parallel_members (optional):
  * how many members were inflated side by side.                                                         */
 int64_t ffq_gunzip_fd(int fd, uint8_t *h_dst, int64_t cap, int64_t chunk, int threads, int64_t *n_parallel_members);
+/* A member that does NOT say how long it is -- what plain `gzip` writes: one deflate stream -- is inflated by
+ * the same threads when the file is a regular one (csrc/ffq_pgz.h): the compressed bytes are cut into chunks
+ * (FFQ_PGZ_CHUNK, default 1 MiB; two per thread and batch), every chunk but the first of a batch enters the
+ * stream at the first bit that parses as a dynamic-Huffman block header and inflates into 16-bit symbols
+ * (a literal, or a reference into the 32 KiB it was not given), a chunk ends at the first accepted block
+ * boundary behind its range, the stitch step takes a chunk if it starts at the bit its predecessor ended at,
+ * and the symbols become bytes -- and a CRC-32, checked against the member's trailer -- side by side.  zlib
+ * keeps the last word: whatever the engine does not take (a decode error, a block longer than a batch, the
+ * end of the file inside a block) makes it stop at the last block boundary it committed, and the serial
+ * inflate goes on from that bit (same bytes or the same error).  Members of less than FFQ_PGZ_MIN (4 MiB)
+ * compressed bytes, pipes and FFQ_GZ_THREADS=1 go through zlib alone.
+ * ffq_gunzip_stats: process-wide counters of that engine since the library was loaded --
+ * out[0] batches, [1] chunks taken, [2] chunks not taken, [3] times it gave up, [4] members finished.    */
+void ffq_gunzip_stats(int64_t out[5]);
 /* The same without a reader thread, for sources only the host can read (any object with a read() /
  * readinto(): BytesIO, bz2, lzma, sockets ...): the host asks where the next chunk goes
  * (ffq_stream_push_buffer: pinned memory, *cap = fbufsize bytes of room), writes up to *cap bytes

@@ -170,3 +170,121 @@ def test_random_layouts(hip, tmp_path):
         assert gzip.decompress(blob) == want
         out, _ = _gunzip(hip, tmp_path, blob, len(want), int(rng.integers(1, 300000)), int(rng.integers(1, 7)))
         assert out == want, it
+
+
+# ---- one plain member inflated by several threads (csrc/ffq_pgz.h) -------------------------------------------------------
+def _fastq(n, seed=3):
+    rng = np.random.default_rng(seed)
+    out = bytearray()
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(n, 100))
+    q = (np.clip(rng.normal(36, 4, size=(n, 100)).astype(np.int64), 2, 41) + 33).astype(np.uint8)
+    for i in range(n):
+        out += b"@SRR0000001.%d %d/1\n" % (i + 1, i + 1) + seq[i].tobytes() + b"\n+\n" + q[i].tobytes() + b"\n"
+    return bytes(out)
+
+
+def _gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, name=b""):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    hdr = struct.pack("<BBBBIBB", 0x1F, 0x8B, 8, 8 if name else 0, 0, 0, 3) + (name + b"\0" if name else b"")
+    return hdr + c.compress(data) + c.flush() + struct.pack("<II", zlib.crc32(data), len(data) & 0xFFFFFFFF)
+
+
+@pytest.fixture
+def pgz_env(monkeypatch):
+    def set_(chunk=65536, minimum=1, **kw):
+        monkeypatch.setenv("FFQ_PGZ_CHUNK", str(chunk))
+        monkeypatch.setenv("FFQ_PGZ_MIN", str(minimum))
+        for k, v in kw.items():
+            monkeypatch.setenv("FFQ_PGZ_" + k.upper(), str(v))
+    return set_
+
+
+@pytest.mark.parametrize("level", (1, 6, 9))
+@pytest.mark.parametrize("pchunk", (16384, 100000, 1 << 20))
+def test_plain_member_by_several_threads(hip, tmp_path, pgz_env, level, pchunk):
+    data = _fastq(12000)
+    blob = _gz(data, level, name=b"reads.fq")
+    assert gzip.decompress(blob) == data
+    pgz_env(chunk=pchunk)
+    for threads, chunk in ((2, 1 << 24), (4, 65280), (5, 777777)):
+        s0 = hip.gunzip_stats()
+        out, _ = _gunzip(hip, tmp_path, blob, len(data), chunk, threads)
+        s1 = hip.gunzip_stats()
+        assert out == data
+        assert s1["giveups"] == s0["giveups"] and s1["members"] == s0["members"] + 1
+        if pchunk < (1 << 20):
+            assert s1["chunks"] - s0["chunks"] > (s1["batches"] - s0["batches"])      # chunks entered mid-stream were taken
+    # one thread: zlib alone
+    s0 = hip.gunzip_stats()
+    out, _ = _gunzip(hip, tmp_path, blob, len(data), 1 << 20, 1)
+    assert out == data and hip.gunzip_stats() == s0
+
+
+def test_plain_member_block_kinds(hip, tmp_path, pgz_env):
+    """Stored and fixed-Huffman blocks are never entered mid-stream (only chunk 0 of a batch meets them); data that
+    mixes all three kinds; a member that inflates to a thousand times its size."""
+    rng = np.random.default_rng(11)
+    fq = _fastq(4000, 5)
+    noise = rng.integers(0, 256, size=300000, dtype=np.uint8).tobytes()
+    mixed = fq[:200000] + noise + fq[200000:] + noise[:70000] + b"A" * 500000 + fq[:100000]
+    pgz_env(chunk=32768)
+    for data, level, strategy in ((fq, 0, zlib.Z_DEFAULT_STRATEGY), (fq, 6, zlib.Z_FIXED), (mixed, 6, zlib.Z_DEFAULT_STRATEGY),
+                                  (mixed, 1, zlib.Z_DEFAULT_STRATEGY), (mixed, 9, zlib.Z_HUFFMAN_ONLY), (fq, 6, zlib.Z_RLE),
+                                  (b"\0" * 40_000_000, 9, zlib.Z_DEFAULT_STRATEGY), (b"", 6, zlib.Z_DEFAULT_STRATEGY), (b"x", 6, zlib.Z_DEFAULT_STRATEGY)):
+        blob = _gz(data, level, strategy)
+        assert gzip.decompress(blob) == data
+        for threads in (2, 4):
+            out, _ = _gunzip(hip, tmp_path, blob, len(data), 1 << 22, threads)
+            assert out == data
+
+
+def test_plain_members_in_a_row(hip, tmp_path, pgz_env):
+    a, b = _fastq(5000, 1), _fastq(3000, 2)
+    pgz_env(chunk=50000)
+    blob = _gz(a, 6) + _gz(b, 1) + b"\0" * 77 + bgzf.compress(a[:300000]) + _gz(b, 9) + b"\0" * 3
+    want = a + b + a[:300000] + b
+    assert gzip.decompress(blob) == want
+    for chunk in (4099, 1 << 20, 1 << 26):
+        out, _ = _gunzip(hip, tmp_path, blob, len(want), chunk, 4)
+        assert out == want
+
+
+def test_plain_member_handed_over_to_zlib(hip, tmp_path, pgz_env):
+    """The engine gives up (here: told to, after k batches; or a chunk that may not grow) and zlib goes on from the
+    block boundary it stopped at -- a bit position inside a byte, with the 32 KiB in front as its dictionary."""
+    data = _fastq(15000, 8)
+    blob = _gz(data, 6)
+    for k in (1, 2, 5):
+        pgz_env(chunk=40000, giveup_after=k)
+        s0 = hip.gunzip_stats()
+        out, _ = _gunzip(hip, tmp_path, blob, len(data), 1 << 20, 3)
+        assert out == data
+        assert hip.gunzip_stats()["giveups"] == s0["giveups"] + 1
+    pgz_env(chunk=40000, max_out=65536 + 300, giveup_after=1000000)
+    out, _ = _gunzip(hip, tmp_path, blob, len(data), 1 << 20, 3)
+    assert out == data
+    zeros = b"\0" * 30_000_000                         # blocks of megabytes: nothing fits a chunk that may not grow
+    out, _ = _gunzip(hip, tmp_path, _gz(zeros, 9), len(zeros), 1 << 22, 3)
+    assert out == zeros
+
+
+def test_plain_member_errors(hip, tmp_path, pgz_env):
+    data = _fastq(9000, 4)
+    good = _gz(data, 6)
+    pgz_env(chunk=30000)
+    n = len(good)
+    for at, what in ((n // 2, "data"), (n // 7, "data"), (n - 8, "crc"), (n - 4, "isize"), (n - 3000, "data")):
+        bad = bytearray(good)
+        bad[at] ^= 0x04
+        with pytest.raises((OSError, EOFError, zlib.error)):
+            gzip.decompress(bytes(bad))
+        with pytest.raises(hip.FFQError, match="gzip"):
+            _gunzip(hip, tmp_path, bytes(bad), len(data) + 100, 1 << 20, 4)
+    for cut in (n - 1, n - 5, n - 9, n // 2, n // 3, 100, 12):
+        with pytest.raises(hip.FFQError, match="ended before the end-of-stream marker"):
+            _gunzip(hip, tmp_path, good[:cut], len(data), 1 << 20, 4)
+    with pytest.raises(hip.FFQError, match="gzip"):
+        _gunzip(hip, tmp_path, good + b"garbage, not a member", len(data) + 100, 1 << 20, 4)
+    # what comes out in front of the error is what zlib gives: the good bytes of a file cut short
+    out, _ = _gunzip(hip, tmp_path, good + b"\0" * 9, len(data), 1 << 20, 4)
+    assert out == data
