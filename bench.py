@@ -282,13 +282,13 @@ def iterator_rates(ctx, sample_u8, n_gz, budget_s=3.0):
 
     out = {"unit": "M reads/s", "cores": 1,
            "what": "readfastq_iter(fh, fbufsize, entryfunc, GPU scanner): Python tuples per second, one host core; "
-                   "plain = %d-byte file in %s, gzip = its first %d bytes at level 1, bgzf = the same bytes in BGZF members "
-                   "(inflated side by side); *_stream_gb_s = decompressed GB/s of the stream front end alone (tables, no "
+                   "plain = %d-byte file in %s, gzip = its first %d bytes at level 1 (ONE member: inflated by gz_threads threads, "
+                   "csrc/ffq_pgz.h), bgzf = the same bytes in BGZF members (inflated side by side); *_stream_gb_s = decompressed GB/s of the stream front end alone (tables, no "
                    "tuples)" % (sample_u8.size, d, n_gz)}
     def table_rate(path):
         # decompressed GB/s through the stream front end alone: offset tables out, no Python object per record
         best = None
-        for _ in range(2):
+        for _ in range(3):
             fd = os.open(path, os.O_RDONLY)
             t0 = time.perf_counter()
             st = hip.FileStream(ctx, fd, 1 << 24, gzip=True)
@@ -303,7 +303,8 @@ def iterator_rates(ctx, sample_u8, n_gz, budget_s=3.0):
     try:
         out["gzip_stream_gb_s"] = table_rate(gz)
         out["bgzf_stream_gb_s"] = table_rate(bg)
-        out["bgzf_threads"] = int(os.environ.get("FFQ_GZ_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+        out["gz_threads"] = int(os.environ.get("FFQ_GZ_THREADS", "0")) or min(os.cpu_count() or 1, 32)
+        out["gzip_engine"] = hip.gunzip_stats()
         for tag, opener in (("plain", lambda: open(plain, "rb")), ("gzip", lambda: gzip.open(gz, "rb")),
                             ("bgzf", lambda: gzip.open(bg, "rb"))):
             for fb in (50000, 1 << 24):
@@ -795,7 +796,7 @@ def main():
             line["cpu_baseline"]["reference_c_iterator"] = cpu_reference_iter(sample.tobytes(), 3.0)
             line["host_inclusive"] = host_inclusive(ctx, sample, flags)
             line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, shard.host_sample(1 << 30))
-            line["host_inclusive"]["iterator"] = iterator_rates(ctx, sample, int(shard.host_sample(96 << 20).size))
+            line["host_inclusive"]["iterator"] = iterator_rates(ctx, sample, int(sample.size))
             del sample
         else:
             line["cpu_baseline"] = None

@@ -515,9 +515,10 @@ struct Engine {
     int64_t win_valid = 0;
     uint32_t crc = 0;
     uint64_t isize = 0;
-    // ---- output not yet taken ----
-    std::vector<uint8_t> hold;
-    int64_t hold_pos = 0, hold_len = 0;
+    // ---- the batch whose bytes are being handed out ----
+    int b_na = 0;                       // chunks taken
+    int64_t b_total = 0, emit_pos = 0;  // bytes they hold, bytes handed out
+    bool b_fin = false;                 // the last one ends with the member's final block
     bool member_done = false, gave_up = false, failed = false;
     int64_t end_off = 0;                // file offset behind the member's trailer
     std::string msg;
@@ -557,7 +558,7 @@ struct Engine {
     bool begin(int64_t member_off)
     {
         member_done = gave_up = failed = false;
-        hold_pos = hold_len = 0;
+        b_na = 0; b_total = emit_pos = 0; b_fin = false;
         nbatches = 0;
         uint8_t h[4096];
         const int64_t n = pread_full(h, sizeof h, member_off);
@@ -660,9 +661,8 @@ struct Engine {
         return (uint8_t)((v & ~m) | (w[v & 0x7FFFu] & m));
     }
 
-    // One batch: inflate, stitch, turn into bytes.  Up to `room` bytes go to dst, what is more into `hold`.
-    // Returns the bytes put into dst; -1: nothing could be committed (give up here).
-    int64_t batch(uint8_t *dst, int64_t room)
+    // One batch: inflate, stitch.  0: committed (emit hands out its bytes); -1: nothing could be committed (give up here).
+    int64_t batch()
     {
         if (giveup_after > 0 && nbatches >= giveup_after) return -1;
         nbatches++;
@@ -672,7 +672,19 @@ struct Engine {
         const int64_t want = std::min<int64_t>((int64_t)nslots * chunk_bytes + slack, file_size - byte0);
         if (want <= 0) return -1;
         if ((int64_t)in.size() < want + 16) in.resize((size_t)want + 16);
-        const int64_t in_len = pread_full(in.data(), want, byte0);
+        // (read side by side: from the page cache one thread copies 5-10 GB/s, a batch inflates at several)
+        const int64_t rp = 4 << 20;
+        const int nrp = (int)((want + rp - 1) / rp);
+        std::vector<int64_t> rgot((size_t)nrp, 0);
+        const std::function<void(int)> rd = [&](int q) { rgot[(size_t)q] = pread_full(in.data() + q * rp, std::min(rp, want - q * rp), byte0 + q * rp); };
+        if (nrp > 1) pool->run(nrp, rd);
+        else rd(0);
+        int64_t in_len = 0;
+        for (int q = 0; q < nrp; q++) {
+            if (rgot[(size_t)q] < 0) return -1;
+            in_len += rgot[(size_t)q];
+            if (rgot[(size_t)q] < std::min(rp, want - q * rp)) break;          // (the file is shorter than fstat said)
+        }
         if (in_len <= 0) return -1;
         memset(in.data() + in_len, 0, 16);
         const int nck = (int)std::min<int64_t>(nslots, (in_len + chunk_bytes - 1) / chunk_bytes);
@@ -727,52 +739,74 @@ struct Engine {
         stats().chunks += na;
         stats().rejected += nck - na;
         if (na == 0 || (total == 0 && !fin && pos == rel0)) return -1;
-        // ---- bytes and checksums, side by side --------------------------------------------------------------------------
-        const int64_t to_dst = std::min(total, room), to_hold = total - to_dst;
-        if ((int64_t)hold.size() < to_hold) hold.resize((size_t)to_hold);
-        const std::function<void(int)> stage2 = [&](int k) {
-            Chunk *c = ck[k];
-            const uint8_t *w = k ? ck[k - 1]->win : window;
-            uint32_t crc_k = (uint32_t)crc32(0L, Z_NULL, 0);
-            // the chunk's bytes [a, b) of the batch, in up to two pieces (dst, hold)
-            for (int piece = 0; piece < 2; piece++) {
-                const int64_t a = std::max(c->out_at, piece ? to_dst : 0), b = std::min(c->out_at + c->nout, piece ? total : to_dst);
-                if (b <= a) continue;
-                uint8_t *o = piece ? hold.data() + (a - to_dst) : dst + a;
-                if (k == 0) memcpy(o, c->b8 + WSIZE + (a - c->out_at), (size_t)(b - a));
-                else {
-                    const uint16_t *s = c->b16 + WSIZE + (a - c->out_at);
-                    const int64_t n = b - a;
-                    for (int64_t i = 0; i < n; i++) o[i] = resolve1(s[i], w);
-                }
-                for (int64_t q = 0; q < b - a; q += 1 << 30) crc_k = (uint32_t)crc32(crc_k, o + q, (uInt)std::min<int64_t>(b - a - q, 1 << 30));
-            }
-            c->crc = crc_k;
-        };
-        const int64_t t3 = now_ns();
-        stats().ns_stitch += t3 - t2;
-        pool->run(na, stage2);
-        stats().ns_stage2 += now_ns() - t3;
-        for (int k = 0; k < na; k++) if (ck[k]->nout) crc = (uint32_t)crc32_combine(crc, ck[k]->crc, (z_off_t)ck[k]->nout);
-        isize += (uint64_t)total;
+        // ---- committed: the bytes are made when they are asked for (emit) --------------------------------------------------
+        stats().ns_stitch += now_ns() - t2;
         memcpy(window, ck[na - 1]->win, WSIZE);
         win_valid = prev_valid;
         pos_bit = byte0 * 8 + pos;
-        hold_pos = 0; hold_len = to_hold;
-        if (fin) {
-            // the member's trailer: CRC-32 and length (modulo 2^32) of what it inflates to (RFC 1952 section 2.3.1)
-            const int64_t t = (pos_bit + 7) >> 3;
-            uint8_t tr[8];
-            if (pread_full(tr, 8, t) != 8) { failed = true; msg = "compressed file ended before the end-of-stream marker was reached"; return to_dst; }
-            const uint32_t fcrc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
-            const uint32_t flen = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
-            if (fcrc != crc) { failed = true; msg = "incorrect data check"; }
-            else if (flen != (uint32_t)isize) { failed = true; msg = "incorrect length check"; }
-            member_done = true;
-            end_off = t + 8;
-            stats().members++;
+        b_na = na; b_total = total; b_fin = fin; emit_pos = 0;
+        if (total == 0) finish_batch();
+        return 0;
+    }
+
+    // The next min(n, what the batch still holds) bytes of the batch, straight into dst: cut into pieces, each piece
+    // resolved (symbols -> bytes through the window in front of its chunk) and summed (CRC-32) by one thread, the sums
+    // put together in order.
+    int64_t emit(uint8_t *dst, int64_t n)
+    {
+        const int64_t t0 = now_ns();
+        const int64_t m = std::min(n, b_total - emit_pos);
+        const int P = (int)std::min<int64_t>(threads, std::max<int64_t>(1, m >> 18));
+        std::vector<uint32_t> sums((size_t)P);
+        const std::function<void(int)> fn = [&](int p) {
+            const int64_t a = emit_pos + m * p / P, b = emit_pos + m * (p + 1) / P;
+            uint32_t c32 = (uint32_t)crc32(0L, Z_NULL, 0);
+            int k = 0;
+            while (k + 1 < b_na && ck[k + 1]->out_at <= a) k++;
+            for (; k < b_na && ck[k]->out_at < b; k++) {
+                const Chunk *c = ck[k];
+                const int64_t lo = std::max(a, c->out_at), hi = std::min(b, c->out_at + c->nout);
+                if (hi <= lo) continue;
+                uint8_t *o = dst + (lo - emit_pos);
+                if (k == 0) memcpy(o, c->b8 + WSIZE + (lo - c->out_at), (size_t)(hi - lo));
+                else {
+                    const uint16_t *sy = c->b16 + WSIZE + (lo - c->out_at);
+                    const uint8_t *w = ck[k - 1]->win;
+                    for (int64_t i = 0; i < hi - lo; i++) o[i] = resolve1(sy[i], w);
+                }
+                for (int64_t q = 0; q < hi - lo; q += 1 << 30) c32 = (uint32_t)crc32(c32, o + q, (uInt)std::min<int64_t>(hi - lo - q, 1 << 30));
+            }
+            sums[(size_t)p] = c32;
+        };
+        if (P == 1) fn(0);
+        else pool->run(P, fn);
+        for (int p = 0; p < P; p++) {
+            const int64_t len = (emit_pos + m * (p + 1) / P) - (emit_pos + m * p / P);
+            if (len) crc = (uint32_t)crc32_combine(crc, sums[(size_t)p], (z_off_t)len);
         }
-        return to_dst;
+        isize += (uint64_t)m;
+        emit_pos += m;
+        if (emit_pos == b_total) finish_batch();
+        stats().ns_stage2 += now_ns() - t0;
+        return m;
+    }
+
+    // All of the batch is out: behind a final block comes the member's trailer -- CRC-32 and length (modulo 2^32) of
+    // what the member inflates to (RFC 1952 section 2.3.1)
+    void finish_batch()
+    {
+        if (!b_fin) return;
+        b_fin = false;
+        const int64_t t = (pos_bit + 7) >> 3;
+        uint8_t tr[8];
+        if (pread_full(tr, 8, t) != 8) { failed = true; msg = "compressed file ended before the end-of-stream marker was reached"; return; }
+        const uint32_t fcrc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        const uint32_t flen = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (fcrc != crc) { failed = true; msg = "incorrect data check"; }
+        else if (flen != (uint32_t)isize) { failed = true; msg = "incorrect length check"; }
+        member_done = true;
+        end_off = t + 8;
+        stats().members++;
     }
 
     // Up to n bytes of the member.  Returns what was written; then look at member_done / gave_up / failed
@@ -781,21 +815,15 @@ struct Engine {
     {
         int64_t got = 0;
         while (got < n) {
-            if (hold_pos < hold_len) {
-                const int64_t m = std::min(n - got, hold_len - hold_pos);
-                memcpy(dst + got, hold.data() + hold_pos, (size_t)m);
-                hold_pos += m; got += m;
-                continue;
-            }
+            if (emit_pos < b_total) { got += emit(dst + got, n - got); continue; }
             if (member_done || gave_up || failed) break;
             int64_t r;
-            try { r = batch(dst + got, n - got); } catch (const std::bad_alloc &) { r = -1; }
+            try { r = batch(); } catch (const std::bad_alloc &) { r = -1; }
             if (r < 0) { gave_up = true; stats().giveups++; break; }
-            got += r;
         }
         return got;
     }
-    int64_t pending() const { return hold_len - hold_pos; }
+    int64_t pending() const { return b_total - emit_pos; }
 };
 
 }  // namespace pgz

@@ -402,7 +402,7 @@ static int64_t gz_bgzf_batch(ffq_stream *s, uint8_t *dst, int64_t room)
     if (jobs.size() < 2) return 0;            // (one member: the serial inflate is as good)
     if (!s->gz_pool) {
         s->gz_pool = new (std::nothrow) GzPool();
-        if (!s->gz_pool || !s->gz_pool->start(s->gz_threads - 1)) { delete s->gz_pool; s->gz_pool = nullptr; s->bgzf_ok = false; return 0; }
+        if (!s->gz_pool || !s->gz_pool->start(std::min(s->gz_threads, 16) - 1)) { delete s->gz_pool; s->gz_pool = nullptr; s->bgzf_ok = false; return 0; }
     }
     if (!s->zraw_init) {
         memset(&s->zraw, 0, sizeof s->zraw);
@@ -432,6 +432,8 @@ static bool gz_pgz_begin(ffq_stream *s)
         if (fstat(s->fd, &st) != 0 || !S_ISREG(st.st_mode)) { s->pgz_ok = false; return false; }
         s->gz_file_size = (int64_t)st.st_size;
     }
+    int xl = 0;
+    if (bgzf_member_len(s->zin + s->zin_pos, s->zin_len - s->zin_pos, &xl) != 0) return false;      // (a BGZF member: 64 KiB at most)
     const int64_t member_off = s->z_filepos - (s->zin_len - s->zin_pos);
     if (s->gz_file_size - member_off < pgz::env_i64("FFQ_PGZ_MIN", 4 << 20)) return false;
     if (!s->pgz) {
