@@ -502,7 +502,7 @@ struct Engine {
     int fd = -1;
     int threads = 1, nslots = 1;     // chunks of a batch: threads x FFQ_PGZ_CPT (two: a thread that drew a slow chunk is waited for less)
     int64_t chunk_bytes = 1 << 20;      // compressed bytes per chunk (FFQ_PGZ_CHUNK)
-    int64_t max_out = 1ll << 27;        // elements a chunk may grow to before it stops at its last boundary
+    int64_t max_out = 1ll << 24;        // elements a chunk may grow to before it stops at its last boundary
     int64_t giveup_after = 0;           // FFQ_PGZ_GIVEUP_AFTER = k: hand over to zlib after k batches (tests of the hand-over)
     int64_t nbatches = 0;
     int64_t file_size = 0;
