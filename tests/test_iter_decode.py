@@ -110,10 +110,17 @@ def test_phred_goldens_every_source(gpu_ctx, phred, tmp_path, coalesce):
 @pytest.mark.parametrize("name,maker", (("single_3000", lambda s: s.single(0, 3000, seed=42)),
                                         ("wrapped_3000", lambda s: s.wrapped(0, 3000, seed=43)[0]),
                                         ("single_3000_at_7", lambda s: s.single(7, 3000, seed=42))))
-def test_phred_synthetic_streams(gpu_ctx, phred, tmp_path, name, maker):
-    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C, synth
+@pytest.mark.parametrize("pgz", (False, True))
+def test_phred_synthetic_streams(gpu_ctx, phred, tmp_path, name, maker, pgz, monkeypatch):
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C, synth, hip
     data = maker(synth).tobytes()
     g = phred["synth"][name]
+    if pgz:
+        # plain gzip members through the several-thread inflate (csrc/ffq_pgz.h) although they are small: chunks of 20 KB
+        monkeypatch.setenv("FFQ_PGZ_MIN", "1")
+        monkeypatch.setenv("FFQ_PGZ_CHUNK", "20000")
+        monkeypatch.setenv("FFQ_GZ_THREADS", "4")
+    stats0 = hip.gunzip_stats()
     for coalesce in (0, 8 << 20):
         C.entrypos.coalesce_bytes = coalesce
         for src, opener in _sources(tmp_path, data, name):
@@ -123,6 +130,11 @@ def test_phred_synthetic_streams(gpu_ctx, phred, tmp_path, name, maker):
                 assert len(got) == g["n"] and _digest(got) == g["sha256"], (name, src, bs, coalesce)
                 assert [x.hex() for x in (got[0][0], got[0][1], got[0][2].tobytes())] == g["first"]
                 assert [x.hex() for x in (got[-1][0], got[-1][1], got[-1][2].tobytes())] == g["last"]
+    stats1 = hip.gunzip_stats()
+    if pgz:
+        assert stats1["chunks"] > stats0["chunks"] + 100 and stats1["giveups"] == stats0["giveups"]
+    else:
+        assert stats1 == stats0
 
 
 @pytest.mark.gpu
