@@ -41,6 +41,7 @@
 #include <thread>
 #include <vector>
 
+#include <emmintrin.h>
 #include <unistd.h>
 
 namespace ffq {
@@ -661,6 +662,25 @@ struct Engine {
         return (uint8_t)((v & ~m) | (w[v & 0x7FFFu] & m));
     }
 
+    // n symbols -> bytes.  Literals sixteen at a time (SSE2 pack); a group that holds references -- they come in runs: the
+    // part of a header every record copies from the one before -- is then patched element by element.
+    static void resolve_run(const uint16_t *sy, uint8_t *o, int64_t n, const uint8_t *w)
+    {
+        int64_t i = 0;
+        for (; i + 16 <= n; i += 16) {
+            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(sy + i));
+            const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(sy + i + 8));
+            _mm_storeu_si128(reinterpret_cast<__m128i *>(o + i), _mm_packus_epi16(a, b));      // (a reference is negative: packed to 0)
+            uint32_t m = ((uint32_t)_mm_movemask_epi8(a) | ((uint32_t)_mm_movemask_epi8(b) << 16)) & 0xAAAAAAAAu;
+            while (m) {
+                const int j = __builtin_ctz(m) >> 1;
+                m &= m - 1;
+                o[i + j] = w[sy[i + j] & 0x7FFFu];
+            }
+        }
+        for (; i < n; i++) o[i] = resolve1(sy[i], w);
+    }
+
     // One batch: inflate, stitch.  0: committed (emit hands out its bytes); -1: nothing could be committed (give up here).
     int64_t batch()
     {
@@ -722,11 +742,10 @@ struct Engine {
             if (k > 0 && prev_valid < WSIZE) break;              // (references into a window shorter than 32 KiB are not checked)
             // the window behind this chunk
             if (k == 0) memcpy(c->win, c->b8 + c->nout, WSIZE);
-            else if (c->nout >= WSIZE) { const uint16_t *s = c->b16 + c->nout; for (int i = 0; i < WSIZE; i++) c->win[i] = resolve1(s[i], prev); }
+            else if (c->nout >= WSIZE) resolve_run(c->b16 + c->nout, c->win, WSIZE, prev);
             else {
                 memmove(c->win, prev + c->nout, (size_t)(WSIZE - c->nout));
-                const uint16_t *s = c->b16 + WSIZE;
-                for (int64_t i = 0; i < c->nout; i++) c->win[WSIZE - c->nout + i] = resolve1(s[i], prev);
+                resolve_run(c->b16 + WSIZE, c->win + (WSIZE - c->nout), c->nout, prev);
             }
             c->out_at = total;
             total += c->nout;
@@ -772,7 +791,7 @@ struct Engine {
                 else {
                     const uint16_t *sy = c->b16 + WSIZE + (lo - c->out_at);
                     const uint8_t *w = ck[k - 1]->win;
-                    for (int64_t i = 0; i < hi - lo; i++) o[i] = resolve1(sy[i], w);
+                    resolve_run(sy, o, hi - lo, w);
                 }
                 for (int64_t q = 0; q < hi - lo; q += 1 << 30) c32 = (uint32_t)crc32(c32, o + q, (uInt)std::min<int64_t>(hi - lo - q, 1 << 30));
             }
