@@ -132,7 +132,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
         const uint32_t nc = __popc(at);
         const uint32_t incl = wave_incl_scan(nc);
         uint32_t id = (uint32_t)ncomp + incl - nc;
-        ncomp += (int)__shfl((int)incl, 63);
+        ncomp += __builtin_amdgcn_readlane((int)incl, 63);            // (a scalar: what is decided on it below is decided once per wave)
         if (6 * lane < c) {
             // (what lies past the tile's count is overwritten by the next tile's entries, written later, or lies past nwin)
             uint16_t *dst = raw + tb[k] + 6 * lane;
