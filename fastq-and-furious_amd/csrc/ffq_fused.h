@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 8) void k_scan_seg(SegArgs a)
     }
     const uint32_t s01 = wave_incl_scan(c[0] | (c[1] << 16));
     const uint32_t s23 = wave_incl_scan(c[2] | (c[3] << 16));
-    const uint32_t t01 = (uint32_t)__shfl((int)s01, 63), t23 = (uint32_t)__shfl((int)s23, 63);
+    const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)s01, 63), t23 = (uint32_t)__builtin_amdgcn_readlane((int)s23, 63);   // (scalars: the row totals)
     uint32_t ex[4], rowtot[4];
     ex[0] = (s01 & 0xFFFFu) - c[0];  rowtot[0] = t01 & 0xFFFFu;
     ex[1] = (s01 >> 16) - c[1];      rowtot[1] = t01 >> 16;

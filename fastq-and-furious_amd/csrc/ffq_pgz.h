@@ -688,8 +688,12 @@ struct Engine {
         nbatches++;
         const int64_t t00 = now_ns();
         const int64_t byte0 = pos_bit >> 3;
-        const int64_t slack = std::max<int64_t>(chunk_bytes, 1 << 20);
-        const int64_t want = std::min<int64_t>((int64_t)nslots * chunk_bytes + slack, file_size - byte0);
+        // (a member's first batch is a small one -- a quarter of a chunk per thread: the first bytes are out sooner)
+        const bool first = nbatches == 1 && chunk_bytes >= (1 << 18);
+        const int64_t cb = first ? chunk_bytes / 4 : chunk_bytes;
+        const int ns = first ? threads : nslots;
+        const int64_t slack = std::max<int64_t>(cb, 1 << 20);
+        const int64_t want = std::min<int64_t>((int64_t)ns * cb + slack, file_size - byte0);
         if (want <= 0) return -1;
         if ((int64_t)in.size() < want + 16) in.resize((size_t)want + 16);
         // (read side by side: from the page cache one thread copies 5-10 GB/s, a batch inflates at several)
@@ -707,10 +711,10 @@ struct Engine {
         }
         if (in_len <= 0) return -1;
         memset(in.data() + in_len, 0, 16);
-        const int nck = (int)std::min<int64_t>(nslots, (in_len + chunk_bytes - 1) / chunk_bytes);
+        const int nck = (int)std::min<int64_t>(ns, (in_len + cb - 1) / cb);
         for (int k = 0; k < nck; k++) {
-            ck[k]->lo_bit = (int64_t)k * chunk_bytes * 8;
-            ck[k]->limit_bit = (int64_t)(k + 1) * chunk_bytes * 8;
+            ck[k]->lo_bit = (int64_t)k * cb * 8;
+            ck[k]->limit_bit = (int64_t)(k + 1) * cb * 8;
             ck[k]->ok = false;
         }
         const int64_t rel0 = pos_bit - byte0 * 8;
