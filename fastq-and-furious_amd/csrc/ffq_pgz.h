@@ -838,11 +838,16 @@ struct Engine {
     {
         int64_t got = 0;
         while (got < n) {
-            if (emit_pos < b_total) { got += emit(dst + got, n - got); continue; }
-            if (member_done || gave_up || failed) break;
-            int64_t r;
-            try { r = batch(); } catch (const std::bad_alloc &) { r = -1; }
-            if (r < 0) { gave_up = true; stats().giveups++; break; }
+            try {
+                if (emit_pos < b_total) { got += emit(dst + got, n - got); continue; }
+                if (member_done || gave_up || failed) break;
+                if (batch() < 0) { gave_up = true; stats().giveups++; break; }
+            } catch (const std::bad_alloc &) {
+                // (out of memory in front of a batch: zlib goes on; while its bytes are handed out: nothing to go back to)
+                if (emit_pos < b_total) { failed = true; msg = "out of host memory"; }
+                else { gave_up = true; stats().giveups++; }
+                break;
+            }
         }
         return got;
     }
