@@ -288,3 +288,48 @@ def test_plain_member_errors(hip, tmp_path, pgz_env):
     # what comes out in front of the error is what zlib gives: the good bytes of a file cut short
     out, _ = _gunzip(hip, tmp_path, good + b"\0" * 9, len(data), 1 << 20, 4)
     assert out == data
+
+
+def test_engine_under_sanitizers_with_corrupt_files(tmp_path):
+    """The engine reads files it was not promised anything about: its harness (tools/pgz_main.cpp = ffq_pgz.h alone)
+    built with ASan + UBSan and run over flipped bits, cut and overwritten stretches -- any exit but 'done', 'failed'
+    (trailer mismatch) or 'gave up' (zlib's turn) is a memory error or undefined behaviour."""
+    import random
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = tmp_path / "pgz_asan"
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-pthread",
+                        "-o", str(exe), os.path.join(root, "tools", "pgz_main.cpp"), "-lz"], capture_output=True)
+    if r.returncode != 0:
+        pytest.skip("no sanitizer runtime: " + r.stderr.decode()[-200:])
+    blob = _gz(_fastq(9000, 13), 6)
+    random.seed(7)
+    env = dict(os.environ, FFQ_PGZ_MIN="1", ASAN_OPTIONS="detect_leaks=0")
+    f = tmp_path / "fz.gz"
+    seen = set()
+    for it in range(40):
+        b = bytearray(blob)
+        kind = it % 4
+        if kind == 0:
+            for _ in range(random.randint(1, 4)):
+                b[random.randrange(10, len(b))] ^= 1 << random.randrange(8)
+        elif kind == 1:
+            b = b[:random.randrange(10, len(b))]
+        elif kind == 2:
+            at, n = random.randrange(10, len(b)), random.randrange(1, 3000)
+            b[at:at + n] = bytes(random.randrange(256) for _ in range(n))
+        else:
+            at = random.randrange(10, len(b))
+            del b[at:at + random.randrange(1, 500)]
+        f.write_bytes(bytes(b))
+        env["FFQ_PGZ_CHUNK"] = random.choice(["4096", "16384", "100000"])
+        r = subprocess.run([str(exe), str(f), str(random.randint(2, 5))], env=env, capture_output=True, timeout=300)
+        assert r.returncode in (0, 1, 3), r.stderr.decode()[-2000:]
+        seen.add(r.returncode)
+    f.write_bytes(blob)
+    r = subprocess.run([str(exe), str(f), "3", "check"], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0 and b"EQUAL" in r.stdout, r.stderr.decode()[-2000:]
+    assert seen - {0}                 # (the corruptions were noticed)
