@@ -180,10 +180,12 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
                 // no tile boundary among them, or the last one's offset already below the first one's
                 const bool span_ok = !(kw & 0x4000u) || (r13 & TM) < (r[0] & TM);
                 const uint32_t P1 = (r[1] - r[0]) & TM;
-                uint32_t pm = 0;                              // "\n+" at >= seq_beg + 1 (:87-88)
+                // "\n+" at >= seq_beg + 1 (:87-88): entry 2 must lie two bytes behind the header's end; entries 3 .. 7 do
+                // anyway (positions grow by at least one per entry) -- for them the flag alone
+                static_assert(FL_PLUS == 2, "the '+' flag is bit 15 of an entry");
+                uint32_t pm = (((r[2] >> 15) & 1u) && ((r[2] - r[0]) & TM) >= P1 + 2u) ? 4u : 0u;
 #pragma unroll
-                for (int i = 2; i <= 7; i++)
-                    if (((r[i] >> 14) & (uint32_t)FL_PLUS) && ((r[i] - r[0]) & TM) >= P1 + 2u) pm |= 1u << i;
+                for (int i = 3; i <= 7; i++) pm |= ((r[i] >> 15) & 1u) << i;
                 if (pm && span_ok) {
                     const int mi = __ffs((int)pm) - 1;        // 2 .. 7: 2 mi <= LT_B
                     const uint32_t P3 = (raw[k + mi] - r[0]) & TM, Pq = (raw[k + mi + 1] - r[0]) & TM;
@@ -216,19 +218,22 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     }
     if (PROBES && ablate == 2) { uint32_t x = 0; for (int u = 0; u < NB; u++) x += infr[u] + kreg[u]; if (x == 0x12345u) B.lines[g] = x; return; }
     // ---- chain membership: run by run, on the scalar side (the chain only moves forward: batch after batch) -------------
-    unsigned long long MB[NB];
+    // (the walk only marks where a run of members starts and where it ends; runs are disjoint and in order, so the
+    // members of a batch are (ends << 1) - starts, modulo 2^64 for a run that ends with the batch)
+    unsigned long long MB[NB], ST[NB], EN[NB];
     int cur = 0, lastn = -1;
     uint32_t last_inf = 0, last_k = 0;
     bool bad = false;
 #pragma unroll
     for (int u = 0; u < NB; u++) {
-        MB[u] = 0ull;
+        ST[u] = 0ull; EN[u] = 0ull;
         for (int guard = 0; guard < 66 && (cur >> 6) == u && lastn < 0 && !bad; guard++) {
             const int b = cur & 63;
+            ST[u] |= 1ull << b;
             const unsigned long long ns = NS[u] >> b;
-            if (!ns) { MB[u] |= ~0ull << b; cur = (u + 1) * 64; if (cur >= ncomp) bad = true; break; }
+            if (!ns) { EN[u] |= 1ull << 63; cur = (u + 1) * 64; if (cur >= ncomp) bad = true; break; }
             const int r = b + __ffsll((long long)ns) - 1;
-            MB[u] |= (~0ull << b) & (r == 63 ? ~0ull : ((2ull << r) - 1ull));
+            EN[u] |= 1ull << r;
             uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)infr[u], r);
             if (((ir >> 10) & 3u) == LK_SLOW) {
                 // the successor rule entry by entry, by the whole wave: the first "\n@" behind the '+' line's end at >= pos5 - 1
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
                 lastn = u * 64 + r; last_inf = ir; last_k = (uint32_t)__builtin_amdgcn_readlane((int)kreg[u], r);
             } else cur = (int)(ir & WN_MASK);
         }
+        MB[u] = (EN[u] << 1) - ST[u];
     }
     if (PROBES && ablate == 3) { if (lane == 0) B.lines[g] = lines + (uint32_t)lastn + (uint32_t)MB[0]; return; }
     if (bad || lastn < 0) { if (lane == 0) lite_decline(B, g, 3); return; }
