@@ -1165,7 +1165,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             HIPCHK(hipMemcpy(hp, c->prof_d, 128, hipMemcpyDeviceToHost));
             if (getenv("FFQ_PROF_LITE"))
                 fprintf(stderr, "[ffq prof] k_chain_lite declined of %d groups: first/last/offset %llu, tile over %d entries / dense look-ahead %llu, no node / too many %llu, "
-                        "a node it does not take on the chain %llu, stage full %llu\n", st.ngroups, hp[8], LT_E, hp[9], hp[10], hp[11], hp[12]);
+                        "a node it does not take on the chain %llu, stage full %llu; runs walked %llu, successors found entry by entry %llu\n", st.ngroups, hp[8], LT_E, hp[9], hp[10], hp[11], hp[12], hp[14], hp[13]);
             if (hp[6])
                 fprintf(stderr, "[ffq prof] k_chain_wave per-wave cycles: load %.0f lds %.0f nodes %.0f scan %.0f member %.0f summary %.0f (waves %llu)\n",
                         (double)hp[0] / hp[6], (double)hp[1] / hp[6], (double)hp[2] / hp[6], (double)hp[3] / hp[6],

@@ -235,7 +235,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
             const int r = b + __ffsll((long long)ns) - 1;
             EN[u] |= 1ull << r;
             uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)infr[u], r);
+            if (PROBES && B.prof && lane == 0) atomicAdd(&B.prof[14], 1ull);
             if (((ir >> 10) & 3u) == LK_SLOW) {
+                if (PROBES && B.prof && lane == 0) atomicAdd(&B.prof[13], 1ull);
                 // the successor rule entry by entry, by the whole wave: the first "\n@" behind the '+' line's end at >= pos5 - 1
                 const uint32_t kw_ = (uint32_t)__builtin_amdgcn_readlane((int)kreg[u], r);
                 const int k = (int)(kw_ & 0x7FFu), mi = (int)((ir >> 12) & 15u), c = u * 64 + r;
