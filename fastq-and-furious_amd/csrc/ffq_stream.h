@@ -35,6 +35,7 @@
 #include <poll.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <memory>
 #include <sys/stat.h>
 
 #include "ffq_pgz.h"
@@ -168,12 +169,34 @@ struct GzPool {
         if (r != Z_STREAM_END || z->avail_in != 0 || z->total_out != j.isize) return false;
         return (uint32_t)crc32(crc32(0L, Z_NULL, 0), j.dst, j.isize) == j.crc;
     }
+    // The same member through this build's own decoder (ffq_pgz.h; about twice zlib's rate on FASTQ), into a scratch
+    // buffer of the thread (a match is copied a word at a time: the bytes behind a member's end belong to the next
+    // member, which another thread is writing); whatever it does not like is zlib's (inflate_one).
+    struct Scratch { pgz::Inflater<uint8_t> inf; std::vector<uint8_t> buf; };
+    static bool inflate_fast(const GzJob &j)
+    {
+        thread_local std::unique_ptr<Scratch> sc;
+        try {
+            if (!sc) sc.reset(new Scratch());
+            const int64_t cap = (int64_t)j.isize + pgz::OUT_SLACK + 8;
+            if ((int64_t)sc->buf.size() < cap) sc->buf.resize((size_t)cap);
+        } catch (const std::bad_alloc &) { return false; }
+        pgz::Inflater<uint8_t> &f = sc->inf;
+        f.win_valid = 0;
+        f.limit_bit = INT64_MAX;
+        f.set_out(sc->buf.data(), 0, (int64_t)j.isize + pgz::OUT_SLACK + 8);
+        f.start(j.src, j.clen, 0);
+        if (f.run() != pgz::R_FINAL || f.b_out != (int64_t)j.isize || ((f.b_bit + 7) >> 3) != (int64_t)j.clen) return false;
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), sc->buf.data(), j.isize) != j.crc) return false;
+        memcpy(j.dst, sc->buf.data(), j.isize);
+        return true;
+    }
     void work(z_stream *z)
     {
         for (;;) {
             const int j = next.fetch_add(1);
             if (j >= njobs) break;
-            if (!inflate_one(z, jobs[j])) failed.store(1);
+            if (!inflate_fast(jobs[j]) && !inflate_one(z, jobs[j])) failed.store(1);
         }
     }
     void worker()
@@ -402,7 +425,7 @@ static int64_t gz_bgzf_batch(ffq_stream *s, uint8_t *dst, int64_t room)
     if (jobs.size() < 2) return 0;            // (one member: the serial inflate is as good)
     if (!s->gz_pool) {
         s->gz_pool = new (std::nothrow) GzPool();
-        if (!s->gz_pool || !s->gz_pool->start(std::min(s->gz_threads, 16) - 1)) { delete s->gz_pool; s->gz_pool = nullptr; s->bgzf_ok = false; return 0; }
+        if (!s->gz_pool || !s->gz_pool->start(s->gz_threads - 1)) { delete s->gz_pool; s->gz_pool = nullptr; s->bgzf_ok = false; return 0; }
     }
     if (!s->zraw_init) {
         memset(&s->zraw, 0, sizeof s->zraw);
@@ -781,7 +804,7 @@ static int stream_open_impl(ffq_ctx *c, int src, int fd, int64_t fbufsize, uint3
     }
     if (src == SRC_GZIP) {
         memset(&s->zs, 0, sizeof s->zs);
-        s->zin = static_cast<uint8_t *>(malloc((size_t)GZ_IN));
+        s->zin = static_cast<uint8_t *>(malloc((size_t)GZ_IN + 16));      // (+16: the decoders read whole words)
         if (!s->zin || inflateInit2(&s->zs, 15 + 16) != Z_OK) {      // 16: gzip wrapper (header, CRC-32, length)
             free(s->zin); delete s;
             return fail(FFQ_E_NOMEM, "ffq_stream_open: zlib could not be initialised");
@@ -845,7 +868,7 @@ extern "C" int64_t ffq_gunzip_fd(int fd, uint8_t *h_dst, int64_t cap, int64_t ch
     s->seekable = at != (off_t)-1;
     s->z_filepos = s->seekable ? (int64_t)at : 0;
     memset(&s->zs, 0, sizeof s->zs);
-    s->zin = static_cast<uint8_t *>(malloc((size_t)GZ_IN));
+    s->zin = static_cast<uint8_t *>(malloc((size_t)GZ_IN + 16));      // (+16: the decoders read whole words)
     int64_t rc = FFQ_OK, got = 0;
     if (!s->zin || inflateInit2(&s->zs, 15 + 16) != Z_OK) rc = fail(FFQ_E_NOMEM, "ffq_gunzip_fd: zlib could not be initialised");
     else {

@@ -320,7 +320,8 @@ int  ffq_stream_open_gzip(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags
 /* Members that say how long they are -- the BGZF blocks bgzip writes ("BC" extra field, SAM specification
  * section 4.1) -- are located without inflating anything and inflated side by side by FFQ_GZ_THREADS threads
  * (default: the host's cores, at most 32; 1 = one member at a time), each straight into its place in the
- * chunk; every member is checked against the length and CRC-32 of its trailer, and a file that is not what
+ * chunk, by this build's own decoder (csrc/ffq_pgz.h; zlib for a member it does not take); every member is checked
+ * against the length and CRC-32 of its trailer, and a file that is not what
  * its headers promise goes through the one-at-a-time inflate from that member on (same bytes or same error).
  *
  * ffq_gunzip_fd: that reader on its own, no device involved -- the file behind fd (from its current
