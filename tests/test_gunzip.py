@@ -333,3 +333,21 @@ def test_engine_under_sanitizers_with_corrupt_files(tmp_path):
     r = subprocess.run([str(exe), str(f), "3", "check"], env=env, capture_output=True, timeout=300)
     assert r.returncode == 0 and b"EQUAL" in r.stdout, r.stderr.decode()[-2000:]
     assert seen - {0}                 # (the corruptions were noticed)
+
+
+def test_plain_member_default_settings(hip, tmp_path, monkeypatch):
+    """No switches: a member of more than 4 MiB goes to the engine with its 1 MiB chunks and the small first batch;
+    one of less than that is zlib's."""
+    for k in ("FFQ_PGZ_CHUNK", "FFQ_PGZ_MIN", "FFQ_PGZ_CPT", "FFQ_PGZ_MAX_OUT", "FFQ_PGZ_GIVEUP_AFTER", "FFQ_GZ_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+    big = _fastq(12000, 21) * 8                      # ~22 MB, ~9 MB compressed
+    blob = _gz(big, 6)
+    assert len(blob) > (5 << 20)
+    s0 = hip.gunzip_stats()
+    out, _ = _gunzip(hip, tmp_path, blob, len(big), 16 << 20, 4)
+    s1 = hip.gunzip_stats()
+    assert out == big
+    assert s1["members"] == s0["members"] + 1 and s1["giveups"] == s0["giveups"] and s1["chunks"] >= s0["chunks"] + 6
+    small = _gz(big[:3_000_000], 6)
+    out, _ = _gunzip(hip, tmp_path, small, 3_000_000, 16 << 20, 4)
+    assert out == big[:3_000_000] and hip.gunzip_stats() == s1
