@@ -157,6 +157,14 @@ struct FixedTables {
 };
 static const FixedTables &fixed_tables() { static const FixedTables t; return t; }
 
+// Kraft sums (in 128ths) of four 3-bit code lengths at a time
+static const uint16_t *kraft4()
+{
+    struct T { uint16_t k[4096]; T() { for (int x = 0; x < 4096; x++) { int s = 0; for (int q = 0; q < 4; q++) { const int l = (x >> (3 * q)) & 7; if (l) s += 128 >> l; } k[x] = (uint16_t)s; } } };
+    static const T t;
+    return t.k;
+}
+
 // Does the header of a non-final dynamic-Huffman block (RFC 1951 section 3.2.7) start at this bit?  All of it is
 // checked: counts, a complete code-length code, the run-length coded lengths, an end-of-block code, complete
 // literal/length and distance codes.  (`in` is readable 16 bytes past in_len.)
@@ -171,14 +179,13 @@ static bool is_candidate(const uint8_t *in, int64_t in_len, int64_t bit)
     int64_t p = bit + 17;
     if (p + 3 * hclen > nbits) return false;
     v = ld64(in + (p >> 3)) >> (p & 7);                          // >= 57 bits = 19 x 3
+    // the code-length code must be complete: Kraft sum of the 3-bit lengths, four of them per table look-up (nearly
+    // every position that got this far is turned away here)
+    const uint64_t fields = v & ((1ull << (3 * hclen)) - 1ull);
+    const uint16_t *K = kraft4();
+    if (K[fields & 4095u] + K[(fields >> 12) & 4095u] + K[(fields >> 24) & 4095u] + K[(fields >> 36) & 4095u] + K[(fields >> 48) & 4095u] != 128) return false;
     uint8_t cl[19] = {0};
-    int kraft = 0;
-    for (int i = 0; i < hclen; i++) {
-        const int l = (int)((v >> (3 * i)) & 7u);
-        cl[CL_ORDER[i]] = (uint8_t)l;
-        if (l) kraft += 128 >> l;
-    }
-    if (kraft != 128) return false;
+    for (int i = 0; i < hclen; i++) cl[CL_ORDER[i]] = (uint8_t)((v >> (3 * i)) & 7u);
     p += 3 * hclen;
     uint32_t pt[1 << PBITS];
     if (build_table(cl, 19, PBITS, pt, 1 << PBITS, T_CODELEN) != 0) return false;
