@@ -364,8 +364,13 @@ struct Inflater {
             const T *src = op - dist;
             T *dst = op;
             op += len;
-            constexpr int W = 8 / (int)sizeof(T);
-            if (dist >= W) {
+            constexpr int W = 8 / (int)sizeof(T), W2 = 16 / (int)sizeof(T);
+            if (dist >= W2) {
+                do {
+                    _mm_storeu_si128(reinterpret_cast<__m128i *>(dst), _mm_loadu_si128(reinterpret_cast<const __m128i *>(src)));
+                    dst += W2; src += W2; len -= W2;
+                } while (len > 0);
+            } else if (dist >= W) {
                 do { memcpy(dst, src, 8); dst += W; src += W; len -= W; } while (len > 0);
             } else if (dist == 1) {
                 const T c = *src;
