@@ -653,7 +653,8 @@ static void stream_feeder(ffq_stream *s)
             std::lock_guard<std::mutex> lk(s->m);
             if (rc) { s->feeder_rc = rc; s->feeder_msg = msg; s->feeder_done = true; }
             else {
-                s->file_pos = s->src == SRC_GZIP ? s->z_filepos - (s->zin_len - s->zin_pos) : s->file_pos + got;
+                s->file_pos = s->src != SRC_GZIP ? s->file_pos + got :
+                              s->pgz_active ? (s->pgz->pos_bit >> 3) : s->z_filepos - (s->zin_len - s->zin_pos);      // (inside a member the engine inflates: the block boundary it has committed)
                 sl.end_pos = s->file_pos;
                 s->produced = p + 1;
                 if (sl.eof) s->feeder_done = true;
