@@ -220,20 +220,23 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     // ---- chain membership: run by run, on the scalar side (the chain only moves forward: batch after batch) -------------
     // (the walk only marks where a run of members starts and where it ends; runs are disjoint and in order, so the
     // members of a batch are (ends << 1) - starts, modulo 2^64 for a run that ends with the batch)
-    unsigned long long MB[NB], ST[NB], EN[NB];
+    // (cur only grows -- a successor lies behind its node, a restart behind the run -- so the walk ends by itself; a walk
+    // that is over, well or badly, parks cur behind the last batch: one test per turn)
+    constexpr int CUR_DONE = NB * 64;
+    unsigned long long MB[NB];
     int cur = 0, lastn = -1;
     uint32_t last_inf = 0, last_k = 0;
     bool bad = false;
 #pragma unroll
     for (int u = 0; u < NB; u++) {
-        ST[u] = 0ull; EN[u] = 0ull;
-        for (int guard = 0; guard < 66 && (cur >> 6) == u && lastn < 0 && !bad; guard++) {
+        unsigned long long st = 0ull, en = 0ull;
+        while ((cur >> 6) == u) {
             const int b = cur & 63;
-            ST[u] |= 1ull << b;
+            st |= 1ull << b;
             const unsigned long long ns = NS[u] >> b;
-            if (!ns) { EN[u] |= 1ull << 63; cur = (u + 1) * 64; if (cur >= ncomp) bad = true; break; }
+            if (!ns) { en |= 1ull << 63; cur = (u + 1) * 64; if (cur >= ncomp) { bad = true; cur = CUR_DONE; } break; }
             const int r = b + __ffsll((long long)ns) - 1;
-            EN[u] |= 1ull << r;
+            en |= 1ull << r;
             uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)infr[u], r);
             if (PROBES && B.prof && lane == 0) atomicAdd(&B.prof[14], 1ull);
             if (((ir >> 10) & 3u) == LK_SLOW) {
@@ -267,13 +270,14 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
                 // again at the next candidate of the run-in -- the entry stays a guess, the verification decides (what was
                 // walked so far lies in front of the own tiles: nothing of it is staged)
                 if (u * 64 + r + 1 < n_runin) cur = u * 64 + r + 1;
-                else bad = true;
+                else { bad = true; cur = CUR_DONE; }
             }
             else if ((ir & WN_MASK) == NO_NODE) {               // the chain leaves the own tiles
                 lastn = u * 64 + r; last_inf = ir; last_k = (uint32_t)__builtin_amdgcn_readlane((int)kreg[u], r);
+                cur = CUR_DONE;
             } else cur = (int)(ir & WN_MASK);
         }
-        MB[u] = (EN[u] << 1) - ST[u];
+        MB[u] = (en << 1) - st;
     }
     if (PROBES && ablate == 3) { if (lane == 0) B.lines[g] = lines + (uint32_t)lastn + (uint32_t)MB[0]; return; }
     if (bad || lastn < 0) { if (lane == 0) lite_decline(B, g, 3); return; }
