@@ -1,6 +1,7 @@
-"""A gzip file of 1 GiB of synthetic FASTQ through the stream front end (ffq_stream_open_gzip: the several-thread inflate\nfeeding the pinned chunks) against the same bytes as a plain file: record count, SHA-256 of all rows, seconds."""
+"""A gzip file of 1 GiB of synthetic FASTQ through the stream front end (ffq_stream_open_gzip: the several-thread inflate
+feeding the pinned chunks) against the same bytes as a plain file: record count, SHA-256 of all rows, seconds."""
 import os, sys, time, zlib, hashlib
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from fastqandfurious_amd import hip, sharded
 ctx = hip.Context(0)
