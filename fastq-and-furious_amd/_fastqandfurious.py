@@ -122,7 +122,7 @@ class _GpuEntrypos:
         g = _gzip_fileno(fh)
         if g is not None:
             st = _hip.FileStream(self._context(), g[0], chunk, decode=decode, start=g[1], gzip=True)
-            st.on_close = lambda: _gzip_leave_exhausted(fh)
+            st.on_close = lambda: _gzip_leave(fh, st)
             return st
         if getattr(fh, "readinto", None) is None and getattr(fh, "read", None) is None:
             return None
@@ -156,14 +156,19 @@ def _gzip_fileno(fh):
         return None
 
 
-def _gzip_leave_exhausted(fh):
+def _gzip_leave(fh, st):
     """The library inflated the compressed file itself (pread: the GzipFile object was never read from).  The
-    reference's loop leaves `fh` exhausted; so that a later fh.read() -- or a second iterator over the same object --
-    does not replay the whole file, the raw file is left at its end: the GzipFile then reads as empty."""
+    reference's loop leaves `fh` where its last read(fbufsize) ended: exhausted once the stream is through -- the raw
+    file is then left at its end, so that a later fh.read() (or a second iterator over the same object) reads as empty
+    instead of replaying the whole file --, and behind the fills handed out when the iterator is abandoned early (a
+    break out of the loop, an exception in the caller): the GzipFile is moved there (it inflates up to that point
+    itself: only an abandoned stream pays for it), and a later fh.read() gives the data that follows."""
     try:
-        raw = fh.fileobj
-        raw.seek(0, 2)
-    except (OSError, ValueError, AttributeError):
+        if st.at_end:
+            fh.fileobj.seek(0, 2)
+        elif st.consumed > 0:
+            fh.seek(st.consumed)
+    except (OSError, ValueError, AttributeError, EOFError):
         pass
 
 

@@ -220,9 +220,11 @@ static bool is_candidate(const uint8_t *in, int64_t in_len, int64_t bit)
     return check_lengths(cnt, T_DIST) >= 0;
 }
 
-// First candidate at or behind `from`, in front of `to`; -1: none.
+// First candidate at or behind `from`, in front of `to`; -1: none.  (`to` may lie behind the input -- the last chunk of a
+// batch the end of the file cut short: the scan itself stops where the input does, it reads a word per byte position.)
 static int64_t find_candidate(const uint8_t *in, int64_t in_len, int64_t from, int64_t to)
 {
+    to = std::min(to, in_len * 8);
     for (int64_t byte = from >> 3; byte * 8 < to; byte++) {
         // eight bit positions from one load: BFINAL/BTYPE = 0b100 at bit r means bits r..r+2 of the word
         const uint64_t w = ld64(in + byte);
@@ -287,8 +289,12 @@ struct Inflater {
         consume(14);
         if (nl > 286 || nd > 30) return error();
         uint8_t cl[19] = {0};
+        const uint8_t *const in_lim = in + in_len;
         for (int i = 0; i < ncl; i++) {
-            if (bc < 3) refill();
+            if (bc < 3) {
+                refill();
+                if (__builtin_expect(ip >= in_lim, 0) && bitpos() > in_len * 8) return input_end();
+            }
             cl[CL_ORDER[i]] = (uint8_t)(bb & 7u);
             consume(3);
         }
@@ -299,6 +305,9 @@ struct Inflater {
         int i = 0;
         while (i < total) {
             refill();
+            // (every symbol: a header cut short by the end of the input decodes its zero padding as short lengths, and
+            // only 16 bytes behind in_len are readable)
+            if (__builtin_expect(ip >= in_lim, 0) && bitpos() > in_len * 8) return input_end();
             const uint32_t e = pt[bb & ((1u << PBITS) - 1u)];
             if (!(e & F_LIT)) return error();
             consume((int)(e & 15u));
@@ -310,8 +319,8 @@ struct Inflater {
             else { rep = 11 + (int)(bb & 127u); consume(7); }
             if (i + rep > total) return error();
             while (rep--) lens[i++] = (uint8_t)val;
-            if (bitpos() > in_len * 8) return input_end();
         }
+        if (bitpos() > in_len * 8) return input_end();
         if (!lens[256]) return error();
         if (build_table(lens, nl, LBITS, ltab, LT_CAP, T_LITLEN) != 0) return error();
         if (build_table(lens + nl, nd, DBITS, dtab, DT_CAP, T_DIST) != 0) return error();
@@ -517,6 +526,12 @@ struct Engine {
     int64_t chunk_bytes = 1 << 20;      // compressed bytes per chunk (FFQ_PGZ_CHUNK)
     int64_t max_out = 1ll << 24;        // elements a chunk may grow to before it stops at its last boundary
     int64_t giveup_after = 0;           // FFQ_PGZ_GIVEUP_AFTER = k: hand over to zlib after k batches (tests of the hand-over)
+    // Host memory of the symbol buffers (two bytes per output byte of a chunk, up to max_out each): FFQ_PGZ_MEM bounds
+    // their sum (default 1 GiB per open stream) -- fewer chunks per batch when the initial buffers alone would not fit, a
+    // chunk that would grow past it stops at its last block boundary instead (as at max_out), and what grew is given
+    // back when its member is through.
+    int64_t mem_budget = 1ll << 30;
+    std::atomic<int64_t> mem16{0};
     int64_t nbatches = 0;
     int64_t file_size = 0;
     Pool *pool = nullptr;
@@ -547,6 +562,9 @@ struct Engine {
         pool = new (std::nothrow) Pool();
         if (!pool || !pool->start(threads - 1)) return false;
         nslots = threads * (int)std::min<int64_t>(env_i64("FFQ_PGZ_CPT", threads > 1 ? 2 : 1), 8);
+        mem_budget = env_i64("FFQ_PGZ_MEM", mem_budget);
+        const int64_t per_chunk = (int64_t)(WSIZE + cap0()) * (int64_t)sizeof(uint16_t);
+        nslots = (int)std::max<int64_t>(std::min<int64_t>(nslots, (mem_budget * 3 / 4) / per_chunk), std::min(threads, 2));
         for (int i = 0; i < nslots; i++) {
             Chunk *c = new (std::nothrow) Chunk();
             if (!c) return false;
@@ -588,14 +606,28 @@ struct Engine {
         return true;
     }
 
-    static void grow16(Chunk *c, int64_t cap)
+    int64_t cap0() const { return std::max<int64_t>(chunk_bytes * 6, 1 << 16) + OUT_SLACK; }      // elements a chunk's buffer starts with
+    void grow16(Chunk *c, int64_t cap)
     {
         uint16_t *nb = static_cast<uint16_t *>(malloc((size_t)(WSIZE + cap) * sizeof(uint16_t)));
         if (!nb) throw std::bad_alloc();
         if (c->b16 && c->i16 && c->i16->op) memcpy(nb + WSIZE, c->b16 + WSIZE, (size_t)(c->i16->op - c->i16->out_base) * sizeof(uint16_t));
         for (int i = 0; i < WSIZE; i++) nb[i] = (uint16_t)(0x8000 + i);
+        mem16 += (cap - (c->b16 ? c->cap16 : 0)) * (int64_t)sizeof(uint16_t);
         free(c->b16);
         c->b16 = nb; c->cap16 = cap;
+    }
+    // (a member is through: buffers that grew go back to the allocator -- the next member's chunks start small again)
+    void shrink16()
+    {
+        for (Chunk *c : ck)
+            if (c->b16 && c->cap16 > cap0()) {
+                mem16 -= c->cap16 * (int64_t)sizeof(uint16_t);
+                free(c->b16);
+                c->b16 = nullptr; c->cap16 = 0;
+                if (c->i16) c->i16->op = nullptr;
+            }
+        if ((int64_t)in.capacity() > (int64_t)nslots * chunk_bytes * 2 + (8 << 20)) std::vector<uint8_t>().swap(in);
     }
     static void grow8(Chunk *c, int64_t cap, int64_t keep)
     {
@@ -611,7 +643,7 @@ struct Engine {
         c->ok = false;
         if (!c->i8) c->i8 = new Inflater<uint8_t>();
         Inflater<uint8_t> &f = *c->i8;
-        const int64_t cap0 = std::max<int64_t>(chunk_bytes * 6, 1 << 16) + OUT_SLACK;
+        const int64_t cap0 = this->cap0();
         if (c->cap8 < cap0) { free(c->b8); c->b8 = nullptr; grow8(c, cap0, 0); }
         memcpy(c->b8, window, WSIZE);
         f.win_valid = win_valid;
@@ -637,7 +669,7 @@ struct Engine {
         c->ok = false;
         if (!c->i16) c->i16 = new Inflater<uint16_t>();
         Inflater<uint16_t> &f = *c->i16;
-        const int64_t cap0 = std::max<int64_t>(chunk_bytes * 6, 1 << 16) + OUT_SLACK;
+        const int64_t cap0 = this->cap0();
         f.op = nullptr;
         if (c->cap16 < cap0) grow16(c, cap0);
         int64_t from = c->lo_bit;
@@ -655,8 +687,11 @@ struct Engine {
                 r = f.run();
                 if (r != R_FULL) break;
                 const int64_t have = f.op - f.out_base;
-                if (c->cap16 >= max_out) { f.op = f.out_base + f.b_out; r = R_INPUT_END; break; }
-                grow16(c, std::min(c->cap16 * 2, max_out));
+                const int64_t ncap = std::min(c->cap16 * 2, max_out);
+                if (c->cap16 >= max_out || mem16.load() + (ncap - c->cap16) * (int64_t)sizeof(uint16_t) > mem_budget) {
+                    f.op = f.out_base + f.b_out; r = R_INPUT_END; break;            // (stops at its last boundary)
+                }
+                grow16(c, ncap);
                 f.set_out(c->b16 + WSIZE, have, c->cap16);
             }
             if (r == R_ERROR) { from = s + 1; continue; }           // not a block after all: the next candidate
@@ -842,6 +877,7 @@ struct Engine {
         member_done = true;
         end_off = t + 8;
         stats().members++;
+        shrink16();
     }
 
     // Up to n bytes of the member.  Returns what was written; then look at member_done / gave_up / failed

@@ -333,6 +333,20 @@ def test_engine_under_sanitizers_with_corrupt_files(tmp_path):
     r = subprocess.run([str(exe), str(f), "3", "check"], env=env, capture_output=True, timeout=300)
     assert r.returncode == 0 and b"EQUAL" in r.stdout, r.stderr.decode()[-2000:]
     assert seen - {0}                 # (the corruptions were noticed)
+    # a batch the end of the file cuts short, its last chunk a short tail without a block header in it (zero padding
+    # behind the member): the candidate scan of that chunk must stop where the input does
+    env["FFQ_PGZ_CHUNK"] = "16384"
+    for tail in (1, 100, 1500):
+        f.write_bytes(blob + b"\0" * ((tail - len(blob)) % 16384))
+        r = subprocess.run([str(exe), str(f), "32", "check"], env=env, capture_output=True, timeout=300)
+        assert r.returncode == 0 and b"EQUAL" in r.stdout, r.stderr.decode()[-2000:]
+    # the file ends inside the header of a dynamic-Huffman block (the first one starts right behind the gzip header;
+    # further ones at the boundaries a chunked run reports): every cut over the first header, and cuts a few bytes
+    # behind random later positions
+    for cut in list(range(11, 140)) + [random.randrange(200, len(blob)) for _ in range(40)]:
+        f.write_bytes(blob[:cut])
+        r = subprocess.run([str(exe), str(f), "2"], env=env, capture_output=True, timeout=300)
+        assert r.returncode in (1, 3), r.stderr.decode()[-2000:]
 
 
 def test_plain_member_default_settings(hip, tmp_path, monkeypatch):

@@ -240,6 +240,16 @@ def test_gzip_errors_and_pipe_stop(gpu_ctx, tmp_path):
         assert len(list(F.readfastq_iter(fh, 50000, F.entryfunc, C.entrypos))) == 2000
         assert fh.read() == b""
         assert list(F.readfastq_iter(fh, 50000, F.entryfunc, C.entrypos)) == []
+    # ... and one the caller ABANDONS after a few records behind the fills that were handed out, as the reference's
+    # generator leaves it behind its last read(): what follows is still there for fh.read()
+    big = synth.single(0, 40000, seed=42).tobytes()                 # 12.9 MB: two fills of the coalesced 8 MiB
+    good.write_bytes(gzip.compress(big, 1))
+    with gzip.open(good, "rb") as fh:
+        it = F.readfastq_iter(fh, 1 << 23, F.entryfunc, C.entrypos)
+        first = [next(it) for _ in range(3)]
+        it.close()
+        assert [h for h, s, q in first] == [b"SYN.%010d/1" % i for i in range(3)]
+        assert fh.tell() == 1 << 23 and fh.read() == big[1 << 23:]
     # an idle pipe: some records arrive, the writer keeps the pipe open; the first fill is handed over
     # short (not the end of the stream) and close() returns at once
     r, w = os.pipe()
