@@ -1394,14 +1394,14 @@ static int grow_dev(ffq_ctx *c, T **p, int64_t *cap, int64_t need)
 // ---- staging of the host-buffer entry points --------------------------------------------------
 constexpr int64_t STAGE_CH = 8 << 20;
 
-static int stage_setup(ffq_ctx *c)
+static int stage_setup(ffq_ctx *c, int64_t ch = STAGE_CH)
 {
-    if (c->stage_h_cap < 3 * STAGE_CH) {
+    if (c->stage_h_cap < 3 * ch) {
         if (c->stage_h) (void)hipHostFree(c->stage_h);
         c->stage_h = nullptr; c->stage_h_cap = 0;
-        hipError_t e = hipHostMalloc((void **)&c->stage_h, (size_t)(3 * STAGE_CH), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void **)&c->stage_h, (size_t)(3 * ch), hipHostMallocDefault);
         if (e != hipSuccess) return fail(FFQ_E_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
-        c->stage_h_cap = 3 * STAGE_CH;
+        c->stage_h_cap = 3 * ch;
     }
     for (auto &st : c->stage_cs)
         if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1443,6 +1443,74 @@ static int stage_d2h(ffq_ctx *c, void *h_dst, const void *d_src, int64_t bytes)
     for (int b = 0; b < 3; b++)
         if (busy[b]) c->helpers->wait(&c->stage_cr[b]);
     return FFQ_OK;
+}
+
+// ---- a byte range of a file into device memory ----------------------------------------------------------------------
+// (/root/reference/src/fastqandfurious.py:30-36 `read(fh, fbufsize)`, for a range that stays resident: a shard of a
+// file, ffq_shard.h)  pread in slices by the helper threads into three pinned slots of 32 MiB, each slot over the link
+// in two halves on the two copy streams while the next one is read; the context's stream waits for the last copies.
+constexpr int64_t FSTAGE_CH = 32 << 20;
+
+static int stage_fd2d(ffq_ctx *c, uint8_t *d_dst, int fd, int64_t pos, int64_t n, int64_t *got)
+{
+    *got = 0;
+    if (n <= 0) return FFQ_OK;
+    int rc = stage_setup(c, FSTAGE_CH);
+    if (rc) return rc;
+    mark_other(c);
+    // the copies start behind whatever the scan stream holds (a scan in flight may still read d_dst)
+    hipEvent_t front = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&front, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(front, c->stream);
+    for (auto &st : c->stage_cs) if (e == hipSuccess) e = hipStreamWaitEvent(st, front, 0);
+    (void)hipEventDestroy(front);
+    if (e != hipSuccess) return fail(FFQ_E_HIP, "ffq_load_fd: %s", hipGetErrorString(e));
+    bool used[3] = {false, false, false};
+    const int64_t nch = (n + FSTAGE_CH - 1) / FSTAGE_CH;
+    int64_t k_enq = 0, k = 0;
+    bool ended = false;
+    for (; k < nch && !ended && !rc; k++) {
+        for (; k_enq < nch && k_enq - k < 3; k_enq++) {
+            const int b = (int)(k_enq % 3);
+            if (used[b]) { (void)hipEventSynchronize(c->stage_ev[b][0]); (void)hipEventSynchronize(c->stage_ev[b][1]); }
+            const int64_t at = k_enq * FSTAGE_CH;
+            c->helpers->enqueue(fd, c->stage_h + b * FSTAGE_CH, std::min<int64_t>(FSTAGE_CH, n - at), pos + at, &c->stage_cr[b]);
+        }
+        const int b = (int)(k % 3);
+        const int64_t at = k * FSTAGE_CH, want = std::min<int64_t>(FSTAGE_CH, n - at);
+        c->helpers->wait(&c->stage_cr[b]);
+        const int64_t m = c->stage_cr[b].total();
+        if (m < 0) { rc = fail(FFQ_E_ARG, "ffq_load_fd: read failed at byte %lld: %s", (long long)(pos + at), strerror(errno)); break; }
+        if (m < want) ended = true;                       // the file ends here
+        const int64_t half = ((m / 2) + 4095) & ~(int64_t)4095;
+        for (int h = 0; h < 2 && !rc; h++) {
+            const int64_t a = h ? std::min(half, m) : 0, z = h ? m : std::min(half, m);
+            if (z > a) e = hipMemcpyAsync(d_dst + at + a, c->stage_h + b * FSTAGE_CH + a, (size_t)(z - a), hipMemcpyHostToDevice, c->stage_cs[h]);
+            if (e == hipSuccess) e = hipEventRecord(c->stage_ev[b][h], c->stage_cs[h]);
+            if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_load_fd: chunk copy failed: %s", hipGetErrorString(e));
+        }
+        used[b] = true;
+        *got += m;
+    }
+    // reads queued past the end of the file (or past an error) still write into the slots
+    for (int64_t j = k; j < k_enq; j++) c->helpers->wait(&c->stage_cr[j % 3]);
+    // the slots belong to the next caller when this returns: the copies out of them are waited for here (the bytes
+    // are then in d_dst for whatever is enqueued next, on any stream)
+    for (int b = 0; b < 3; b++)
+        if (used[b])
+            for (int h = 0; h < 2; h++)
+                if ((e = hipEventSynchronize(c->stage_ev[b][h])) != hipSuccess && !rc) rc = fail(FFQ_E_HIP, "ffq_load_fd: %s", hipGetErrorString(e));
+    return rc;
+}
+
+extern "C" int ffq_load_fd(ffq_ctx *c, int fd, int64_t pos, int64_t n_bytes, void *d_dst, int64_t *n_loaded)
+{
+    if (!c || fd < 0 || pos < 0 || n_bytes < 0 || (n_bytes > 0 && !d_dst)) return fail(FFQ_E_ARG, "ffq_load_fd: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    int64_t got = 0;
+    const int rc = stage_fd2d(c, static_cast<uint8_t *>(d_dst), fd, pos, n_bytes, &got);
+    if (n_loaded) *n_loaded = got;
+    return rc;
 }
 
 extern "C" int ffq_scan_host(ffq_ctx *c, const uint8_t *h_buf, int64_t n_bytes, int sentinel,

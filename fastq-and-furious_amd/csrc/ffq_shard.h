@@ -341,6 +341,11 @@ struct ffq_shard {
     int64_t *d_table = nullptr, table_cap = 0, *d_qoff = nullptr, qual_cap = 0;
     int8_t *d_qual = nullptr;
     int64_t handoff_bytes = 0;
+    // a range of a FILE (ffq_shard_load_fd): the view's bytes -- halos included -- were read from fd into file_ext; a
+    // step over that buffer hands off nothing, and a look-ahead that must grow is read from the file too
+    int fd = -1;
+    uint8_t *file_ext = nullptr;
+    bool from_file = false;                // the pending step runs over file_ext
 };
 
 static ShView sh_view(const ffq_shard *s, int64_t tail, int64_t head)
@@ -594,7 +599,8 @@ extern "C" int ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_h
     s->flags = flags; s->qual_add = qual_add;        // (FFQ_F_NO_TIMING: no marks; the hand-off's wait in front of the scan rules the barrier-free dispatch out)
     s->d_table = d_table; s->table_cap = table_cap; s->d_qual = d_qual; s->qual_cap = qual_cap; s->d_qoff = d_qoff;
     s->handoff_bytes = 0; s->handoff_timed = false;
-    int rc = shard_handoff(s, d_ext, tail, overlap_handoff != 0);
+    s->from_file = s->fd >= 0 && d_ext == s->file_ext;
+    int rc = s->from_file ? FFQ_OK : shard_handoff(s, d_ext, tail, overlap_handoff != 0);
     if (rc) return rc;
     rc = ffq_scan_submit(c, d_ext, s->v.n_bytes, s->v.sentinel, 0, s->v.eof, s->v.add, s->flags, qual_add, d_table, table_cap,
                          d_qual, qual_cap, d_qoff);
@@ -693,17 +699,37 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
         const bool i_grow = std::find(grow.begin(), grow.end(), rank) != grow.end();
         const bool i_force = std::find(force.begin(), force.end(), rank) != force.end();
         int64_t start = s->start;
-        if (!grow.empty()) {
+        if (!grow.empty() && s->from_file) {
+            // every rank's bytes are the file's: a rank that needs more look-ahead reads it itself, nobody serves anybody
+            if (i_grow) {
+                ShView nv = sh_view(s, s->v.tail, word(rank, 3));
+                uint8_t *g = nullptr;
+                const int64_t cap = nv.n_bytes + 64;
+                if (hipMalloc((void **)&g, (size_t)cap) != hipSuccess) return fail(FFQ_E_NOMEM, "ffq_shard: no memory for a view of %lld bytes", (long long)cap);
+                mark_other(c);
+                hipError_t e = hipMemcpyAsync(g, s->ext, (size_t)s->v.n_bytes, hipMemcpyDeviceToDevice, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                int64_t got = 0;
+                const int64_t more = nv.head - s->v.head;
+                rc = e != hipSuccess ? fail(FFQ_E_HIP, "ffq_shard: %s", hipGetErrorString(e))
+                                     : stage_fd2d(c, g + s->v.n_bytes, s->fd, s->hi + s->v.head, more, &got);
+                if (!rc && got != more) rc = fail(FFQ_E_ARG, "ffq_shard: the file ends at byte %lld, its bounds say %lld", (long long)(s->hi + s->v.head + got), (long long)s->total);
+                if (rc) { (void)hipFree(g); return rc; }
+                if (s->grown) (void)hipFree(s->grown);           // (nothing in flight reads it: the stream was waited for above)
+                s->grown = g; s->grown_cap = cap;
+                s->ext = g; s->v = nv;
+            }
+        } else if (!grow.empty()) {
             std::vector<ShPiece> plan;
             for (int r : grow) sh_range_plan(B, r, B[r + 1] + word(r, 4), B[r + 1] + word(r, 3), plan);
             uint8_t *src_ext = s->ext;
             uint8_t *dst_ext = s->ext;
             int64_t dst_start = s->v.start;
             ShView nv = s->v;
+            uint8_t *old_grown = nullptr;
             if (i_grow) {
                 // a view with more look-ahead (the caller's buffer has room for its own halo only)
                 nv = sh_view(s, s->v.tail, word(rank, 3));
-                uint8_t *old_grown = nullptr;
                 if (nv.n_bytes + 64 > s->grown_cap || s->ext == s->grown) {
                     uint8_t *g = nullptr;
                     const int64_t cap = nv.n_bytes + 64;
@@ -714,10 +740,12 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
                 mark_other(c);
                 HIPCHK(hipMemcpyAsync(s->grown, s->ext, (size_t)s->v.n_bytes, hipMemcpyDeviceToDevice, c->stream));
                 dst_ext = s->grown; dst_start = nv.start;
-                if (old_grown) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(old_grown); }
             }
             mark_other(c);
+            // (src_ext may BE the old grown view -- a rank growing a second time that a neighbour's look-ahead reaches into in
+            // the same round: it is freed only once the exchange that reads it is through)
             rc = shard_serve(s, plan, src_ext, s->v.tail, dst_ext, dst_start, c->stream);
+            if (old_grown) { if (!rc) (void)hipStreamSynchronize(c->stream); (void)hipFree(old_grown); }
             if (rc) return rc;
             if (i_grow) { s->ext = s->grown; s->v = nv; }
         }
@@ -754,6 +782,7 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
     }
     out->record_base = base; out->total_records = tot;
     out->rounds = rounds; out->regathers = regathers;
+    out->halo_source = s->from_file ? 1 : 0;
     out->handoff_bytes = s->handoff_bytes;
     out->d_ext = s->ext; out->tail = s->v.tail; out->head = s->v.head;
     return FFQ_OK;
@@ -782,6 +811,29 @@ extern "C" int ffq_shard_self_exchange(ffq_shard *s, const uint8_t *d_src, uint8
     int rc = s->tr->exchange(plan, provide, accept, s->comm);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(s->comm));
+    return FFQ_OK;
+}
+
+// This rank's range of a FILE: bytes [lo - tail, hi + head) of fd (bounds are file offsets) into d_ext -- pread by the
+// context's helper threads into pinned slots, over the link on two copy streams (stage_fd2d).  What the reference's
+// single reader does for the whole stream (/root/reference/src/fastqandfurious.py:30-36 read(), :241-245 the first fill)
+// happens here once per rank, for its range; the carry of :274-279 is the look-ahead, which comes from the file as well.
+extern "C" int ffq_shard_load_fd(ffq_shard *s, int fd, uint8_t *d_ext, int64_t *n_bytes)
+{
+    if (!s) return fail(FFQ_E_ARG, "ffq_shard_load_fd: NULL shard");
+    if (s->pending) return fail(FFQ_E_ARG, "ffq_shard_load_fd: a step is pending on this shard");
+    if (fd < 0) { s->fd = -1; s->file_ext = nullptr; if (n_bytes) *n_bytes = 0; return FFQ_OK; }      // back to hand-offs between ranks
+    if (!d_ext) return fail(FFQ_E_ARG, "ffq_shard_load_fd: NULL buffer");
+    HIPCHK(hipSetDevice(s->c->device));
+    int64_t tail, head;
+    sh_halo_sizes(s->B, s->rank, s->tail_bytes, s->head_bytes, &tail, &head);
+    const int64_t n = tail + (s->hi - s->lo) + head;
+    int64_t got = 0;
+    const int rc = stage_fd2d(s->c, d_ext, fd, s->lo - tail, n, &got);
+    if (rc) return rc;
+    if (got != n) return fail(FFQ_E_ARG, "ffq_shard_load_fd: the file ends at byte %lld, the bounds say %lld", (long long)(s->lo - tail + got), (long long)s->total);
+    s->fd = fd; s->file_ext = d_ext;
+    if (n_bytes) *n_bytes = n;
     return FFQ_OK;
 }
 

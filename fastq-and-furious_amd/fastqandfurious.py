@@ -354,6 +354,101 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
         offset = 0
 
 
+class RangeEntries:
+    """What readfastq_iter_range returns: an iterator over ONE rank's entries of a file that `world` ranks read
+    together, with what the ranks agreed on -- `record_base` (global ordinal of this rank's first record: entry i of
+    this iterator is record record_base + i of the file), `n_records` (this rank's), `total_records` (the file's),
+    `bounds` (the byte ranges), `comm` (the step's figures: transport, halo source, repair rounds)."""
+
+    def __init__(self, shard, entryfunc, batch_rows):
+        self._sh, self._entryfunc, self._batch = shard, entryfunc, int(batch_rows)
+        res = shard.out
+        self.record_base, self.total_records = int(res.record_base), int(res.total_records)
+        self.n_records = int(res.row_hi - res.row_lo)
+        self.bounds = list(shard.bounds)
+        self.comm = {"transport": shard.sh.transport(), "halo_source": "file" if res.halo_source else "ranks",
+                     "rescan_rounds": int(res.rounds), "regathers": int(res.regathers), "allgather_ms": float(res.allgather_ms)}
+        self._gen = self._entries()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._gen)
+
+    def close(self):
+        self._gen.close()
+
+    def _entries(self):
+        import mmap
+        sh, entryfunc = self._sh, self._entryfunc
+        mm = None
+        try:
+            if self.n_records:
+                mm = mmap.mmap(sh.fd, 0, access=mmap.ACCESS_READ)       # (the page cache holds the range: it was just read)
+                view = memoryview(mm)
+            for i0 in range(0, self.n_records, self._batch):
+                i1 = min(i0 + self._batch, self.n_records)
+                rows = sh.rows(i0, i1)
+                a, b = int(rows[0, 0]), int(rows[-1, 5]) + 1
+                if entryfunc is entryfunc_phred and sh.decoded and _entries.native() is not None and hasattr(_entries.native(), "entries_phred"):
+                    qual, qoff = sh.quals(i0, i1, rows)
+                    yield from _entries.native().entries_phred(view[a:b], memoryview(rows).cast('B'), a, qual, memoryview(qoff).cast('B'), array)
+                elif (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
+                    yield from _default_entries(view[a:b], rows, a, None if entryfunc is _ENTRYFUNC else Entry)
+                else:
+                    # any entryfunc: `buf` holds the batch's bytes, `pos` is relative to it and pos + globaloffset the
+                    # absolute file offsets (entryfunc_abspos, :186-195) -- the contract of the reference's loop (:252-255)
+                    buf = mm[a:b]
+                    rel = array('q')
+                    rel.frombytes((rows - a).tobytes())
+                    for i in range(0, len(rel), 6):
+                        yield entryfunc(buf, rel[i:i + 6], a)
+        finally:
+            if mm is not None:
+                try:
+                    view.release()
+                    mm.close()
+                except BufferError:
+                    pass                  # (an entry handed out still views the map: it goes with the last reference)
+            sh.close()
+
+
+def readfastq_iter_range(path, rank: int, world: int, entryfunc: typing.Callable = entryfunc, comm=None, ctx=None,
+                         start: int = 0, end: typing.Optional[int] = None, batch_rows: int = 1 << 15,
+                         tail_bytes: typing.Optional[int] = None, head_bytes: typing.Optional[int] = None,
+                         bounds: typing.Optional[typing.Sequence[int]] = None) -> RangeEntries:
+    """readfastq_iter for ONE FILE read by `world` ranks (one process per GPU): rank `rank` gets the entries whose '@'
+    lies in its byte range [S_rank, S_rank+1) of the file, the same objects in the same order the reference's
+    iterator (:198-279) yields for them -- the ranks' iterators concatenated ARE readfastq_iter over the whole file.
+
+    Collective: every rank calls it (and reaches its first entry only when all have: the ranges are proven against
+    each other in one step, ffq_shard_step_*).  Each rank reads its own range of the file (plus 1 MiB either side)
+    into its GPU's memory -- nothing is handed from rank to rank but eight words each --, so the range must fit
+    there (a 100 GiB file over 8 GPUs: 12.5 GiB each).  Errors of the stream (the iterator's three ValueErrors,
+    :262, :269, :272) are raised on every rank alike, before any entry is yielded.
+
+    comm: None (world 1; or torch.distributed's default group hands the communicator id round), 128 bytes of
+    ffq_shard_unique_id, or a hip.ShardWorld (logical ranks as threads).  entryfunc_phred: the qualities are decoded
+    on the device with the scan.  Returns a RangeEntries (iterate it; .record_base is the global ordinal)."""
+    from . import hip as _hip, sharded as _sharded
+    if ctx is None:
+        ctx = _hip.default_context()
+    kw = {}
+    if tail_bytes is not None:
+        kw["tail_bytes"] = tail_bytes
+    if head_bytes is not None:
+        kw["head_bytes"] = head_bytes
+    sh = _sharded.FileShard(ctx, path, rank, world, comm=comm, start=start, end=end, bounds=bounds, **kw)
+    try:
+        sh.load()
+        sh.scan(decode=entryfunc is entryfunc_phred)
+    except BaseException:
+        sh.close()
+        raise
+    return RangeEntries(sh, entryfunc, batch_rows)
+
+
 # extension -> (module name or namespace, opener name, positional arguments after the file name)
 FORMAT_OPENERS: typing.Dict[str, typing.Tuple[typing.Union[str, object], str, list]] = {
     'gz': ('gzip', 'open', list()),

@@ -27,7 +27,7 @@ MISSING_QUALHEADER_END = 7
 
 END_OK, END_REFILL, END_ERR_FINAL_QUAL, END_ERR_INCOMPLETE, END_ERR_INVALID = range(5)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK = 0
 E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_TABLE_FULL, E_INTERNAL = -1, -2, -3, -4, -5, -6
 
@@ -54,7 +54,7 @@ SYMBOLS = (
     "ffq_shard_step_submit", "ffq_shard_step_wait", "ffq_shard_transport", "ffq_shard_self_exchange", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_gunzip_stats", "ffq_stream_open_push",
     "ffq_stream_push_buffer", "ffq_stream_push", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
-    "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest",
+    "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest", "ffq_shard_load_fd", "ffq_load_fd",
 )
 
 
@@ -84,7 +84,7 @@ class ShardResult(ctypes.Structure):
         ("exit_pos", ctypes.c_int64), ("first_pos", ctypes.c_int64),
         ("n_own_records", ctypes.c_int64), ("record_base", ctypes.c_int64), ("total_records", ctypes.c_int64),
         ("err_byte", ctypes.c_int64),
-        ("err_state", ctypes.c_int32), ("rounds", ctypes.c_int32), ("regathers", ctypes.c_int32), ("pad_", ctypes.c_int32),
+        ("err_state", ctypes.c_int32), ("rounds", ctypes.c_int32), ("regathers", ctypes.c_int32), ("halo_source", ctypes.c_int32),
         ("handoff_bytes", ctypes.c_int64),
         ("handoff_ms", ctypes.c_float), ("allgather_ms", ctypes.c_float),
         ("d_ext", ctypes.c_void_p), ("tail", ctypes.c_int64), ("head", ctypes.c_int64),
@@ -257,6 +257,8 @@ def lib():
         L.ffq_shard_self_exchange.argtypes = [vp, vp, vp, i64]
         L.ffq_shard_transport.argtypes = [vp]
         L.ffq_shard_transport.restype = ctypes.c_char_p
+        L.ffq_shard_load_fd.argtypes = [vp, i32, vp, P(i64)]
+        L.ffq_load_fd.argtypes = [vp, i32, i64, i64, vp, P(i64)]
         L.ffq_stream_quals.argtypes = [vp, P(vp), P(vp), P(i64)]
         L.ffq_stream_close.restype = None
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
@@ -350,6 +352,13 @@ class Context:
     def d2h(self, arr, dptr):
         assert arr.flags.c_contiguous
         check(lib().ffq_copy_d2h(self.handle, arr.ctypes.data, ctypes.c_void_p(dptr), arr.nbytes, 0))
+
+    def load_fd(self, fd, pos, n_bytes, d_dst):
+        """Bytes [pos, pos + n_bytes) of the file behind fd into device memory (ffq_load_fd); returns the bytes loaded
+        (less than n_bytes: the file ended)."""
+        n = ctypes.c_int64()
+        check(lib().ffq_load_fd(self.handle, int(fd), int(pos), int(n_bytes), ctypes.c_void_p(d_dst), ctypes.byref(n)))
+        return n.value
 
     def sync(self):
         check(lib().ffq_sync(self.handle))
@@ -595,6 +604,13 @@ class Shard:
     def exchange_halo(self, d_ext, overlap=False):
         check(lib().ffq_shard_exchange_halo(self._h, ctypes.c_void_p(d_ext), 1 if overlap else 0))
 
+    def load_fd(self, fd, d_ext):
+        """This rank's bytes [lo - tail, hi + head) of the file behind fd (bounds are file offsets) into d_ext; steps over
+        that buffer then hand off nothing (ffq_shard_load_fd).  Returns the bytes loaded.  fd < 0: detach."""
+        n = ctypes.c_int64()
+        check(lib().ffq_shard_load_fd(self._h, int(fd), ctypes.c_void_p(d_ext), ctypes.byref(n)))
+        return n.value
+
     def step_submit(self, d_ext, d_table, table_cap, flags=0, qual_add=-33, d_qual=None, qual_cap=0, d_qoff=None, overlap=False):
         check(lib().ffq_shard_step_submit(self._h, ctypes.c_void_p(d_ext), 1 if overlap else 0, int(flags), int(qual_add),
                                           ctypes.c_void_p(d_table), int(table_cap), ctypes.c_void_p(d_qual), int(qual_cap),
@@ -626,6 +642,8 @@ class _Stream:
     _h = None
     decode = False
     on_close = None        # called once, before the native stream goes away
+    consumed = 0
+    at_end = False
 
     def tell(self):
         """File position behind the last chunk handed out (-1: the source has none)."""
@@ -671,6 +689,8 @@ class _Stream:
         check(lib().ffq_stream_next(self._h, ctypes.byref(rows_p), ctypes.byref(n), ctypes.byref(end),
                                     ctypes.byref(err), ctypes.byref(fill_p), ctypes.byref(nb), ctypes.byref(off)))
         self._last_rows = n.value
+        self.consumed = off.value + nb.value     # stream bytes handed out so far (byte i of the fill is stream offset off + i)
+        self.at_end = end.value != END_REFILL    # the stream is through (cleanly or with its error): nothing follows
         rows = (np.ctypeslib.as_array((ctypes.c_int64 * (n.value * 6)).from_address(rows_p.value)).reshape(-1, 6)
                 if n.value else np.zeros((0, 6), dtype=np.int64))
         fill = (np.ctypeslib.as_array((ctypes.c_uint8 * nb.value).from_address(fill_p.value))

@@ -850,3 +850,161 @@ class SyntheticShard:
                 src = (self.ext[a:a + l].to(torch.int16) - 33).to(torch.int8)
                 assert bool((src == qual[q:q + l]).all()), "decoded qualities differ from the buffer's bytes - 33"
 
+
+
+# ---- a rank's byte range of a FILE -------------------------------------------------------------------------------
+class FileShard:
+    """Rank `rank` of `world`'s byte range of a FASTQ file, resident in HBM: what the reference's single reader does
+    for the whole stream (/root/reference/src/fastqandfurious.py:30-36 read(), :241-245 the first fill and its
+    sentinel, :274-279 the carry of an unfinished entry) happens once per rank for [S_r - tail, S_r+1 + head) --
+    pread by the library's helper threads into pinned slots, over the link on two copy streams
+    (ffq_shard_load_fd) -- and ONE native step (ffq_shard_step_*) scans it, cuts this rank's rows out and proves
+    them against the neighbours' (one gather of eight words; no hand-off: the halos are the file's own bytes, a
+    look-ahead that must grow is read from the file).  No torch: device memory comes from the context.
+
+    comm: how the ranks find each other -- a hip.ShardWorld (k logical ranks as threads of one process), 128 bytes of
+    communicator id (ffq_shard_unique_id, handed round by the caller), or None: a world of one needs nothing, a larger
+    one takes torch.distributed's default process group (any backend) to hand the id round; the steps themselves
+    are RCCL.  start / end: the part of the file that is the stream (offsets in every row are FILE offsets; the
+    default cut points are shard_bounds' -- 16-byte aligned, even shares --, bounds= names others)."""
+
+    def __init__(self, ctx, path, rank=0, world=1, comm=None, start=0, end=None, tail_bytes=TAIL_BYTES,
+                 head_bytes=HEAD_BYTES, device=None, bounds=None):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self._own_fd = not isinstance(path, int)
+        self.fd = os.open(path, os.O_RDONLY) if self._own_fd else path
+        self.path = path
+        size = os.fstat(self.fd).st_size
+        end = size if end is None else min(int(end), size)
+        start = min(int(start), end)
+        self.bounds = [start + b for b in shard_bounds(end - start, world)]
+        if bounds is not None:               # (the caller's cut points: file offsets, world + 1 of them, not decreasing)
+            self.bounds = [int(b) for b in bounds]
+            assert len(self.bounds) == world + 1 and self.bounds[-1] <= size
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self._world_obj = None
+        if isinstance(comm, _hip.ShardWorld):
+            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, local_world=comm)
+        elif isinstance(comm, (bytes, bytearray)):
+            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, unique_id=bytes(comm))
+        elif world == 1:
+            self._world_obj = _hip.ShardWorld(1)
+            self.sh = _hip.Shard(ctx, self.bounds, 0, 1, tail_bytes, head_bytes, local_world=self._world_obj)
+        else:
+            import torch.distributed as dist
+            if not dist.is_initialized() or dist.get_world_size() != world:
+                raise ValueError("FileShard: world %d needs comm= (a hip.ShardWorld, a communicator id) or an initialised "
+                                 "torch.distributed group of that size" % world)
+            import torch
+            dev = device if device is not None else torch.device("cuda", ctx.device)
+            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, unique_id=native_unique_id(dist, dev))
+        self.tail, self.head = self.sh.halo()
+        self.n_view = self.tail + (self.hi - self.lo) + self.head
+        self.d_ext = ctx.dev_alloc(self.n_view + 64)
+        self.view_start = self.lo - self.tail                     # file offset of d_ext[0]
+        self.d_table = self.d_qual = self.d_qoff = None
+        self.table_cap = self.qual_cap = 0
+        self.loaded = False
+        self.out = None
+
+    def load(self):
+        """This rank's bytes from the file into HBM; returns the bytes loaded."""
+        n = self.sh.load_fd(self.fd, self.d_ext)
+        self.loaded = True
+        return n
+
+    def _alloc(self, rows, decode):
+        c = self.ctx
+        if rows > self.table_cap:
+            for p in (self.d_table, self.d_qoff):
+                if p:
+                    c.dev_free(p)
+            self.d_table = c.dev_alloc(rows * 48)
+            self.d_qoff = c.dev_alloc((rows + 1) * 8) if decode else None
+            self.table_cap = rows
+        elif decode and not self.d_qoff:
+            self.d_qoff = c.dev_alloc((self.table_cap + 1) * 8)
+        if decode:
+            need = max(self.n_view // 2 + 64, -(-(self.n_view + 16) // 16384) * _hip.SEG_STRIDE)
+            if need > self.qual_cap:
+                if self.d_qual:
+                    c.dev_free(self.d_qual)
+                self.d_qual = c.dev_alloc(need)
+                self.qual_cap = need
+
+    def scan(self, decode=False, flags=0, rows_hint=None):
+        """The step (collective: every rank calls it).  Returns the step's ShardResult; this rank's records are rows
+        [row_lo, row_hi) of the device table, `record_base` their global ordinal.  A table that turns out too small
+        on ANY rank is grown on every rank and the step repeated.  Stream errors are raised on every rank alike."""
+        if not self.loaded:
+            self.load()
+        if decode:
+            flags |= _hip.F_DECODE_QUAL | _hip.F_SINGLE_PASS
+        rows = int(rows_hint) if rows_hint else self.n_view // 160 + 1024
+        while True:
+            self._alloc(rows, decode)
+            self.ctx.reserve(self.n_view + 64)
+            self.sh.step_submit(self.d_ext, self.d_table, self.table_cap, flags=flags, d_qual=self.d_qual if decode else None,
+                                qual_cap=self.qual_cap if decode else 0, d_qoff=self.d_qoff if decode else None)
+            rc, res = self.sh.step_wait()
+            if rc == _hip.E_TABLE_FULL:
+                rows = max(2 * self.table_cap, int(res.scan.n_records) + 1024)
+                continue
+            break
+        if res.err_state:
+            raise_stream_error(int(res.err_state), int(res.err_byte))
+        self.out = res
+        self.decoded = bool(decode)
+        return res
+
+    # ---- this rank's rows (and decoded qualities) back on the host, a batch at a time -------------------------------
+    def rows(self, i0=None, i1=None):
+        """Rows [i0, i1) of THIS RANK's records (0 = its first) as int64[n][6], absolute file offsets."""
+        res = self.out
+        n_own = int(res.row_hi - res.row_lo)
+        i0 = 0 if i0 is None else i0
+        i1 = n_own if i1 is None else min(i1, n_own)
+        out = np.empty((max(i1 - i0, 0), 6), dtype=np.int64)
+        if out.size:
+            self.ctx.d2h(out, self.d_table + (int(res.row_lo) + i0) * 48)
+        return out
+
+    def quals(self, i0, i1, rows):
+        """(qual int8[], qoff int64[n + 1]) of this rank's records [i0, i1) (scan(decode=True)): record j's decoded
+        bytes are qual[qoff[j] : qoff[j] + pos5 - pos4] (packed or segmented alike, include/ffq.h FFQ_F_SINGLE_PASS)."""
+        res = self.out
+        base = int(res.row_lo) + i0
+        n = i1 - i0
+        qoff = np.empty(n + 1, dtype=np.int64)
+        self.ctx.d2h(qoff, self.d_qoff + base * 8)
+        q0 = int(qoff[0])
+        q1 = int(qoff[n - 1] + rows[n - 1, 5] - rows[n - 1, 4]) if n else q0
+        qual = np.empty(max(q1 - q0, 0), dtype=np.int8)
+        if qual.size:
+            self.ctx.d2h(qual, self.d_qual + q0)
+        qoff -= q0
+        qoff[n] = q1 - q0
+        return qual, qoff
+
+    def close(self):
+        if getattr(self, "sh", None) is not None:
+            self.sh.close()
+            self.sh = None
+        c = self.ctx
+        for name in ("d_ext", "d_table", "d_qual", "d_qoff"):
+            p = getattr(self, name, None)
+            if p:
+                c.dev_free(p)
+                setattr(self, name, None)
+        if self._world_obj is not None:
+            self._world_obj.close()
+            self._world_obj = None
+        if self._own_fd and self.fd is not None:
+            os.close(self.fd)
+            self.fd = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FFQ_ABI_VERSION 4
+#define FFQ_ABI_VERSION 5
 
 /* scanner status codes -- identical to the reference's module constants
  * (_fastqandfurious.c:7-15,254-262; fastqandfurious.py:19-27)             */
@@ -354,6 +354,12 @@ int  ffq_stream_open_push(ffq_ctx *ctx, int64_t fbufsize, uint32_t flags, int qu
 int  ffq_stream_push_buffer(ffq_stream *s, uint8_t **dst, int64_t *cap);
 int  ffq_stream_push(ffq_stream *s, int64_t n, int eof);
 
+/* Bytes [pos, pos + n_bytes) of the file behind fd into device memory (read(), fastqandfurious.py:30-36, for a range
+ * that stays resident): pread in slices by the context's helper threads into pinned slots, each slot over the link in
+ * two halves on two copy streams while the next is read.  Returns when the bytes are in d_dst; *n_loaded < n_bytes:
+ * the file ended there.  The descriptor's position is not moved.                                                  */
+int  ffq_load_fd(ffq_ctx *ctx, int fd, int64_t pos, int64_t n_bytes, void *d_dst, int64_t *n_loaded);
+
 /* ---- synthetic FASTQ generators (bench / test inputs) -----
  * Counter-based (splitmix64), so the numpy generator in
  * fastq-and-furious_amd/synth.py produces the same bytes.
@@ -417,7 +423,7 @@ typedef struct ffq_shard_result {
     int32_t err_state;         /* 0, or FFQ_END_ERR_*                                                       */
     int32_t rounds;            /* repair rounds (0: the first scan of every rank stood)                     */
     int32_t regathers;         /* gathers repeated because some rank's scan needed a later tier             */
-    int32_t pad_;
+    int32_t halo_source;       /* 0: the halos were handed off between ranks; 1: read from the file (ffq_shard_load_fd) */
     int64_t handoff_bytes;     /* bytes this rank sent + received in hand-offs                              */
     float   handoff_ms;        /* device time of the halo hand-off (events on the stream it ran on)         */
     float   allgather_ms;      /* device time of the gather(s) of the eight words                           */
@@ -440,6 +446,16 @@ int  ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_handoff, ui
                            int64_t *d_table, int64_t table_cap, int8_t *d_qual, int64_t qual_cap, int64_t *d_qoff);
 int  ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out);
 const char *ffq_shard_transport(ffq_shard *s);    /* "rccl" / "in-process" */
+/* A shard of a FILE: bounds[] are file offsets.  ffq_shard_load_fd reads this rank's bytes [lo - tail, hi + head) of fd
+ * (pread: the descriptor's position is not moved) into d_ext -- helper threads -> pinned slots -> hipMemcpyAsync on two
+ * copy streams -- and returns when they are there; a step submitted over that d_ext then hands off NOTHING between
+ * ranks (the halos are the file's own bytes: ffq_shard_result.halo_source = 1), and a look-ahead that has to grow is
+ * read from the file by the rank that needs it.  The gather of the eight words, and with it the proof of every range
+ * and the global ordinals, is unchanged.  Every rank of the world or none (the ranks must agree on whether a grown
+ * look-ahead is an exchange).  fd < 0: detach (steps hand off between ranks again).  This is what replaces the
+ * reference's single reader per rank: read() (fastqandfurious.py:30-36), the first fill and its sentinel (:241-245,
+ * rank 0's view starts the stream), the carry of an unfinished entry (:274-279, here the look-ahead).           */
+int  ffq_shard_load_fd(ffq_shard *s, int fd, uint8_t *d_ext, int64_t *n_bytes);
 /* diagnostics: n bytes from d_src to d_dst through the shard's transport with this rank at both ends */
 int  ffq_shard_self_exchange(ffq_shard *s, const uint8_t *d_src, uint8_t *d_dst, int64_t n);
 
