@@ -245,6 +245,90 @@ def stream_inclusive(ctx, sample_u8, fbufsize=1 << 24):
                                "scanner) over the same file, %.1f s" % (n_it, el_it)}
 
 
+def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, budget_s=3.0):
+    """File in, this rank's rows out through the file-backed byte-range shards (sharded.FileShard: ffq_shard_load_fd +
+    one ffq_shard_step): every rank writes the first bytes of its range of the synthetic stream into ONE file in
+    /dev/shm, then every rank loads ITS range of that file (pread -> pinned slots -> two copy streams) and the ranks
+    prove their rows against each other with one gather of eight words -- no byte passes between GPUs.  Load-bound
+    (page cache -> PCIe); like the other host-inclusive figures never `value`.  Collective."""
+    import tempfile
+    import torch
+    from fastqandfurious_amd import fastqandfurious as F, sharded
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    tag = os.environ.get("MASTER_PORT", str(os.getpid())) if world > 1 else str(os.getpid())
+    path = os.path.join(d, "ffq_bench_shards_%s.fq" % tag)
+    # rank r's piece: the first whole records of its range of the logical stream, up to per_rank_bytes; the pieces go
+    # into the file back to back (a well-formed FASTQ file whose even cut points fall inside records, as a real file's do)
+    blk = shard.own_lo - shard.block_start
+    if shard.kind in ("single", "dense"):
+        skip = (-blk) % shard.rec_bytes
+        n = (min(per_rank_bytes, shard.n_own_bytes) - skip) // shard.rec_bytes * shard.rec_bytes
+    else:
+        k0 = int(np.searchsorted(shard.starts, blk, side="left"))
+        k1 = int(np.searchsorted(shard.starts, blk + min(per_rank_bytes, shard.n_own_bytes), side="right")) - 1
+        skip, n = int(shard.starts[k0]) - blk, int(shard.starts[k1] - shard.starts[k0])
+    piece = shard.ext[shard.tail + skip:shard.tail + skip + n].cpu().numpy()
+    at, whole = 0, n
+    if world > 1:
+        lens = [torch.zeros(1, dtype=torch.int64, device=dev if not dry_gloo(dist) else "cpu") for _ in range(world)]
+        dist.all_gather(lens, torch.tensor([n], dtype=torch.int64, device=lens[0].device))
+        lens = [int(x.item()) for x in lens]
+        at, whole = sum(lens[:rank]), sum(lens)
+    fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
+    try:
+        os.pwrite(fd, piece.tobytes(), at)
+        os.close(fd)
+        del piece
+        if world > 1:
+            dist.barrier()
+        comm = sharded.native_unique_id(dist, dev) if world > 1 else None
+        best = None
+        for _ in range(3):
+            sh = sharded.FileShard(ctx, path, rank, world, comm=comm)
+            t0 = time.perf_counter()
+            nb = sh.load()
+            t1 = time.perf_counter()
+            res = sh.scan()
+            t2 = time.perf_counter()
+            recs, total = int(res.row_hi - res.row_lo), int(res.total_records)
+            src, tr = int(res.halo_source), sh.sh.transport()
+            sh.close()
+            el = [t1 - t0, t2 - t1]
+            if world > 1:                                   # (the slowest rank's load and step)
+                tt = torch.tensor(el, dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = [float(x) for x in tt.tolist()]
+            if best is None or sum(el) < sum(best):
+                best = el
+        best_load, best_step = best
+        # the per-rank iterator on top: Python tuples of THIS rank's records (readfastq_iter_range), bounded
+        it = F.readfastq_iter_range(path, rank, world, F.entryfunc, comm=comm, ctx=ctx)
+        t0 = time.perf_counter()
+        n_it = 0
+        for _e in it:
+            n_it += 1
+            if (n_it & 0xFFFF) == 0 and time.perf_counter() - t0 > budget_s:
+                break
+        el_it = time.perf_counter() - t0
+        it.close()
+        if world > 1:
+            dist.barrier()
+    finally:
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+    return {"value": round(whole / (best_load + best_step) / 1e9, 3), "unit": "GB/s",
+            "m_reads_per_s": round(total / (best_load + best_step) / 1e6, 3),
+            "load_gb_s_per_rank": round(nb / best_load / 1e9, 3), "load_ms": round(best_load * 1e3, 3), "step_ms": round(best_step * 1e3, 3),
+            "transport": tr, "halo_source": "file" if src else "ranks", "records_rank0": recs, "total_records": total,
+            "iterator_m_reads_per_s_per_rank": round(n_it / el_it / 1e6, 3),
+            "sample": "one %d-byte file in %s read by %d rank(s), an even share each (+ 1 MiB either side): ffq_shard_load_fd + one "
+                      "ffq_shard_step per rank, max over ranks, best of 3; iterator: readfastq_iter_range(entryfunc) tuples of "
+                      "rank 0's records, %.1f s" % (whole, d, world, el_it)}
+
+
 def iterator_rates(ctx, sample_u8, n_gz, budget_s=3.0):
     """The drop-in iterator as a user of the reference calls it -- readfastq_iter(fh, fbufsize, entryfunc,
     entrypos) with this package's GPU scanner -- at the reference's own buffer size (50 000 bytes:
@@ -353,6 +437,10 @@ def pmc_traffic(workload, kernel="k_scan_lines<"):
     return best
 
 
+def dry_gloo(dist):
+    return dist is not None and dist.get_backend() == "gloo"
+
+
 def spread(xs):
     xs = sorted(float(x) for x in xs)
     return {"min": round(xs[0], 4), "median": round(xs[len(xs) // 2], 4), "max": round(xs[-1], 4)} if xs else None
@@ -373,9 +461,10 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
 
     # ---- this rank's byte range of the logical stream, generated in HBM ----------
     split = bool(wl.get("split"))                   # the workload's bytes are the whole job's, not one GPU's
+    # (N = 1 --native-step: the device step on the library's RCCL transport at world 1 instead of the in-process one)
     shard = sharded.SyntheticShard(ctx, wl["kind"], wl["bytes"] // world if split else wl["bytes"], rank, world, dev,
                                    total_records=wl["bytes"] // 322 if split else None,
-                                   native=True if getattr(args, "native_step", False) else None)
+                                   solo_rccl=bool(getattr(args, "native_step", False)))
     n_own = shard.n_own_bytes
     ctx.reserve(shard.ext.numel())
     table = torch.empty((shard.max_records + 64, 6), dtype=torch.int64, device=dev)
@@ -653,9 +742,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 "total_bytes": total_bytes,
                 "total_records": total_records,
                 "sharding": ("byte ranges, halo hand-off over %s" % (
-                                 ("RCCL, the step behind the C ABI (ffq_shard_step_submit / _wait)" if getattr(shard, "native", False)
-                                  else "RCCL through torch.distributed") if dist.get_backend() == "nccl"
-                                 else "%s: a functional dry run, every rank on ONE GPU" % dist.get_backend())
+                                 "RCCL, the step behind the C ABI (ffq_shard_step_submit / _wait)" if dist.get_backend() == "nccl"
+                                 else "%s: a functional dry run, every rank on ONE GPU through the host step (ffq_shard_host_step)" % dist.get_backend())
                              if world > 1 else "single range"),
             },
             # what a step costs beside its scan (N > 1, the library's own step: ffq_shard_step_*): device time of the halo
@@ -663,7 +751,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
             # gather of the eight hand-off words (ncclAllGather behind the scan), bytes handed off per rank and step, and how
             # often a rank had to scan again (a look-ahead grown, a guessed entry contradicted) -- rank 0's figures
             "comm": None if not comm_steps else {
-                "transport": "RCCL (ffq_shard_*, include/ffq.h)" if shard.scanner.sh.transport() == "rccl" else shard.scanner.sh.transport(),
+                "transport": ("RCCL (ffq_shard_*, include/ffq.h)" if shard.scanner.sh.transport() == "rccl" else shard.scanner.sh.transport())
+                             if hasattr(shard.scanner, "sh") else "host step (ffq_shard_host_step) over %s" % shard.scanner.transport_name,
                 "steps": len(comm_steps),
                 "handoff_ms": round(float(np.mean([c["handoff_ms"] for c in comm_steps])), 4),
                 "handoff_bytes": int(np.mean([c["handoff_bytes"] for c in comm_steps])),
@@ -798,8 +887,29 @@ def main():
             line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, shard.host_sample(1 << 30))
             line["host_inclusive"]["iterator"] = iterator_rates(ctx, sample, int(sample.size))
             del sample
+        elif not args.no_cpu_baseline:
+            # N > 1: the same CPU legs beside the multi-GPU line, on rank 0's host cores with a 3 s budget each (the other
+            # ranks wait at the next collective); north_star: "GB/s and reads/s at 1/2/4/8 GPUs reported next to the
+            # reference C path timed on the same box's host cores"
+            sample = shard.host_sample(64 << 20)
+            line["cpu_baseline"] = cpu_baseline(sample, min(args.cpu_seconds, 3.0))
+            line["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(sample[:16 << 20], min(args.cpu_seconds, 3.0))
+            line["cpu_baseline"]["reference_c_extension"] = cpu_reference_c(sample.tobytes(), 2.0)
+            line["cpu_baseline"]["reference_c_iterator"] = cpu_reference_iter(sample.tobytes(), 2.0)
+            line["cpu_baseline"]["what"] = ("rank 0's host, while the other ranks wait: `value` is the PORT (oracle/ffq_oracle.c) on one core, "
+                                            "all_cores the same on every core; reference_c_* = the reference's own compiled scanner")
+            del sample
         else:
             line["cpu_baseline"] = None
+    if not args.no_cpu_baseline and not dry_gloo(dist):
+        # file-backed byte-range shards (collective: every rank takes part; the line is rank 0's)
+        sf = sharded_file(ctx, shard, rank, world, dev, dist)
+        if rank == 0:
+            line.setdefault("host_inclusive", {})
+            if line["host_inclusive"] is None:
+                line["host_inclusive"] = {}
+            line["host_inclusive"]["sharded_file"] = sf
     # N = 1, default workload: BASELINE configs[2] and [3] timed the same way, under their own key
     # (`value` stays configs[1]'s)
     # (at every N also BASELINE configs[4]: the one 100 GiB stream cut into `world` ranges)

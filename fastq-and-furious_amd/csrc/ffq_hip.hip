@@ -2083,3 +2083,4 @@ extern "C" int ffq_selftest(ffq_ctx *c)
 
 #include "ffq_stream.h"
 #include "ffq_shard.h"
+#include "ffq_shard_host.h"

@@ -24,31 +24,17 @@
 // the CPU tests over gloo); the transports here are RCCL (librccl, resolved at run time: the library loads without it) and
 // an in-process one (k logical ranks as threads of one process on one GPU: tests, single-GPU dry runs).
 #pragma once
+#include "ffq_shard_proto.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
-#include <condition_variable>
 #include <functional>
-#include <mutex>
 
 namespace ffq {
 
-constexpr int64_t SH_NONE = -1;            // no record starts at / behind the bound: the view reaches the end of the stream
-constexpr int64_t SH_UNKNOWN = -2;         // not known yet (more look-ahead needed, or the guessed entry led nowhere)
-constexpr int64_t SH_ERR_TABLE_FULL = 100; // (beside the FFQ_END_ERR_* codes) the caller's table cannot hold the view's rows
-constexpr int64_t SH_NOT_READY = 101;      // this rank's scan needs a later tier (host round trip): gather again when it is through
-constexpr int SH_WORDS = 8;
-
-struct ShView {                            // a rank's [tail | own | head] buffer and its coordinates
-    int64_t lo, hi, total, origin;         // my range, the stream's end, the offset of the stream's first byte
-    int64_t tail, head;
-    int64_t start, add, n_bytes;           // stream offset of ext[0]; what turns buffer coordinates into stream offsets
-    int32_t sentinel, eof;
-};
-
 // ---- step 3 on the device: rows of my range + the hand-off words ----------------------------------------------------
-// out[0..7] the words, out[8] row_lo, out[9] row_hi, out[10] rows in the table
+// out[0..7] the words (ffq_shard_proto.h: sh_words_from), out[8] row_lo, out[9] row_hi, out[10] rows in the table
 __global__ __launch_bounds__(64) void k_shard_words(const DevRes *__restrict__ res, const int64_t *__restrict__ table,
-                                                    int64_t table_cap, ShView v, int64_t offset, int64_t head_bytes,
+                                                    int64_t table_cap, int64_t qual_cap, ShView v, int64_t offset, int64_t head_bytes,
                                                     int64_t *__restrict__ out, int64_t *__restrict__ host_out)
 {
     const int lane = threadIdx.x;
@@ -57,13 +43,13 @@ __global__ __launch_bounds__(64) void k_shard_words(const DevRes *__restrict__ r
     int64_t i0 = 0, i1 = 0, nrows = 0;
     if (res->fallback) w[5] = SH_NOT_READY;
     else if (n > table_cap) { w[5] = SH_ERR_TABLE_FULL; w[6] = n; }
+    else if (qual_cap >= 0 && res->n_qual_bytes > qual_cap) { w[5] = SH_ERR_QUAL_FULL; w[6] = res->n_qual_bytes; }      // (decoding: qual_cap >= 0)
     else {
         nrows = n;
-        const int64_t lo_b = (v.lo == v.origin) ? -(1ll << 62) : v.lo, hi_b = (v.hi == v.total) ? (1ll << 62) : v.hi;
         int64_t cut[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {       // (the two lower bounds of k_table_cut: 64 probes per round trip)
-            const int64_t value = q ? hi_b : lo_b;
+            const int64_t value = q ? sh_hi_bound(v) : sh_lo_bound(v);
             int64_t a = 0, b = n;
             while (b - a > 0) {
                 const int64_t stride = (b - a + 63) / 64;
@@ -78,34 +64,14 @@ __global__ __launch_bounds__(64) void k_shard_words(const DevRes *__restrict__ r
             cut[q] = a;
         }
         i0 = cut[0]; i1 = cut[1];
-        const int64_t p_i0 = (i0 < n) ? table[i0 * 6] : -1, p_i1 = (i1 < n) ? table[i1 * 6] : -1;
-        const int64_t q1 = (i1 > 0) ? table[(i1 - 1) * 6 + 5] : -1;
-        const int end = res->end_state;
-        const int good = v.eof ? FFQ_END_OK : FFQ_END_REFILL;
-        // the entry the chain stops at (incomplete / invalid): a record start like the rows'
-        const bool have_inc = end != FFQ_END_OK && res->last_status != ST_HEAD_BEG && res->last_pos[0] >= 0;
-        const int64_t p_inc = have_inc ? res->last_pos[0] : 0;
-        const int64_t unknown = (v.eof && end == FFQ_END_OK) ? SH_NONE : SH_UNKNOWN;
-        auto edge = [&](int64_t idx, int64_t p_row, int64_t bound) -> int64_t {
-            if (idx < n) return p_row;
-            if (have_inc && p_inc >= bound) return p_inc;
-            return unknown;
-        };
-        w[1] = edge(i0, p_i0, v.lo);
-        w[0] = (v.hi < v.total) ? edge(i1, p_i1, v.hi) : SH_NONE;
-        w[2] = i1 - i0;
-        // where the search that found the exit started (the iterator's `offset`, :254): the right neighbour re-enters
-        // there if its own guess does not hold
-        w[7] = (i1 < n) ? ((i1 > 0) ? q1 - 1 : offset + v.add) : res->end_offset + v.add;
-        if (end == FFQ_END_ERR_FINAL_QUAL || end == FFQ_END_ERR_INCOMPLETE || end == FFQ_END_ERR_INVALID) {
-            // a stream error: mine if the failing entry starts in my range (or nowhere: no entry at all)
-            if (!have_inc || (v.lo <= p_inc && p_inc < v.hi) || (v.hi == v.total && p_inc >= v.lo)) {
-                w[5] = end; w[6] = res->end_offset + v.add;
-            } else if (p_inc < v.lo) w[0] = w[1] = SH_UNKNOWN;           // the guessed entry led nowhere
-        } else if (end != good) { w[5] = FFQ_E_INTERNAL; }
-        if (!v.eof && !w[5] && w[0] == SH_UNKNOWN && !(have_inc && p_inc < v.lo) && end == FFQ_END_REFILL)
-            // the record that straddles my right edge does not end inside the look-ahead
-            w[3] = min(max(max(2 * v.head, head_bytes), (int64_t)4096), v.total - v.hi);
+        ShScanFacts f;
+        f.n = n; f.i0 = i0; f.i1 = i1;
+        f.p_i0 = (i0 < n) ? table[i0 * 6] : -1;
+        f.p_i1 = (i1 < n) ? table[i1 * 6] : -1;
+        f.q1 = (i1 > 0) ? table[(i1 - 1) * 6 + 5] : -1;
+        f.end_state = res->end_state; f.last_status = res->last_status;
+        f.last_pos0 = res->last_pos[0]; f.end_offset = res->end_offset;
+        sh_words_from(v, f, offset, head_bytes, w);
     }
     if (lane == 0) {
 #pragma unroll
@@ -118,22 +84,6 @@ __global__ __launch_bounds__(64) void k_shard_words(const DevRes *__restrict__ r
         host_out[8] = i0; host_out[9] = i1; host_out[10] = nrows;
         __threadfence_system();
     }
-}
-
-struct ShPiece { int src, dst; int64_t a, b; };          // stream bytes [a, b) go from rank src to rank dst
-
-static void sh_range_plan(const std::vector<int64_t> &B, int dst, int64_t lo, int64_t hi, std::vector<ShPiece> &plan)
-{
-    for (int p = 0; p + 1 < (int)B.size(); p++) {
-        const int64_t a = std::max(lo, B[p]), b = std::min(hi, B[p + 1]);
-        if (a < b && p != dst) plan.push_back(ShPiece{p, dst, a, b});
-    }
-}
-
-static void sh_halo_sizes(const std::vector<int64_t> &B, int rank, int64_t tail_bytes, int64_t head_bytes, int64_t *tail, int64_t *head)
-{
-    *tail = std::min(tail_bytes, B[rank] - B[0]);
-    *head = std::min(head_bytes, B.back() - B[rank + 1]);
 }
 
 // ---- transports ---------------------------------------------------------------------------------------------------
@@ -251,33 +201,7 @@ struct ShRccl : ShTransport {
     const char *name() const override { return "rccl"; }
 };
 
-}  // namespace ffq
-
-// k logical ranks as threads of ONE process (ranges of one resident buffer on one GPU)
-struct ffq_shard_world {
-    int world = 0;
-    std::mutex m;
-    std::condition_variable cv;
-    int waiting = 0;
-    uint64_t gen = 0;
-    bool broken = false;
-    // a barrier that can be broken (a rank that fails must not leave the others waiting)
-    bool wait()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        if (broken) return false;
-        const uint64_t g = gen;
-        if (++waiting == world) { waiting = 0; gen++; cv.notify_all(); return true; }
-        cv.wait(lk, [&] { return gen != g || broken; });
-        return !broken;
-    }
-    void abort() { std::lock_guard<std::mutex> lk(m); broken = true; cv.notify_all(); }
-    std::vector<const ffq::ShPtrFn *> providers;
-    std::vector<int64_t> slots;
-};
-
-namespace ffq {
-
+// k logical ranks as threads of ONE process (ranges of one resident buffer on one GPU): hand-offs by device copies
 struct ShLocal : ShTransport {
     ffq_shard_world *W = nullptr;
     int exchange(const std::vector<ShPiece> &plan, const ShPtrFn &provide, const ShPtrFn &accept, hipStream_t st) override
@@ -287,7 +211,7 @@ struct ShLocal : ShTransport {
         hipError_t e = hipSuccess;
         for (const ShPiece &p : plan)
             if (p.dst == rank && e == hipSuccess)
-                e = hipMemcpyAsync(accept(p.a, p.b), (*W->providers[p.src])(p.a, p.b), (size_t)(p.b - p.a), hipMemcpyDeviceToDevice, st);
+                e = hipMemcpyAsync(accept(p.a, p.b), (*static_cast<const ShPtrFn *>(W->providers[p.src]))(p.a, p.b), (size_t)(p.b - p.a), hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);            // the sources must stay as they are until read
         if (!W->wait()) return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
         if (e != hipSuccess) return fail(FFQ_E_HIP, "ffq_shard: hand-off copy failed: %s", hipGetErrorString(e));
@@ -348,18 +272,7 @@ struct ffq_shard {
     bool from_file = false;                // the pending step runs over file_ext
 };
 
-static ShView sh_view(const ffq_shard *s, int64_t tail, int64_t head)
-{
-    ShView v;
-    v.lo = s->lo; v.hi = s->hi; v.total = s->total; v.origin = s->origin;
-    v.tail = tail; v.head = head;
-    v.start = s->lo - tail;
-    v.sentinel = v.start == s->origin ? 1 : 0;
-    v.eof = (s->hi + head == s->total) ? 1 : 0;
-    v.add = v.start - (v.sentinel ? 1 : 0);
-    v.n_bytes = tail + (s->hi - s->lo) + head;
-    return v;
-}
+static ShView sh_view(const ffq_shard *s, int64_t tail, int64_t head) { return sh_make_view(s->lo, s->hi, s->total, s->origin, tail, head); }
 
 static int shard_alloc(ffq_shard *s, ffq_shard *parent = nullptr)
 {
@@ -528,12 +441,7 @@ static int shard_handoff(ffq_shard *s, uint8_t *ext, int64_t tail, bool overlap)
 {
     if (s->world < 2) return FFQ_OK;
     std::vector<ShPiece> plan;
-    for (int q = 0; q < s->world; q++) {
-        int64_t t, h;
-        sh_halo_sizes(s->B, q, s->tail_bytes, s->head_bytes, &t, &h);
-        sh_range_plan(s->B, q, s->B[q] - t, s->B[q], plan);
-        sh_range_plan(s->B, q, s->B[q + 1], s->B[q + 1] + h, plan);
-    }
+    sh_halo_plan(s->B, s->tail_bytes, s->head_bytes, plan);
     mark_other(s->c);
     hipStream_t st = overlap ? s->comm : s->c->stream;
     HIPCHK(hipEventRecord(s->ev_x[0], st));
@@ -571,7 +479,7 @@ static int shard_words_and_gather(ffq_shard *s, int64_t offset)
     HIPCHK(hipEventRecord(s->ev_w, c->stream));
     HIPCHK(hipStreamWaitEvent(s->gstream, s->ev_w, 0));
     hipLaunchKernelGGL(k_shard_words, dim3(1), dim3(64), 0, s->gstream, (const DevRes *)c->dres, (const int64_t *)s->d_table,
-                       s->table_cap, s->v, offset, s->head_bytes, s->d_words, s->hm_own);
+                       s->table_cap, (s->flags & FFQ_F_DECODE_QUAL) ? s->qual_cap : (int64_t)-1, s->v, offset, s->head_bytes, s->d_words, s->hm_own);
     HIPCHK(hipGetLastError());
     return shard_gather(s, true);
 }
@@ -608,12 +516,9 @@ extern "C" int ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_h
     if (s->v.n_bytes == 0) {
         // an empty view (nothing is enqueued for it, the device holds no result block of this scan): its words on the host --
         // no rows, the search "ended" at the view's start, more look-ahead wanted unless the view ends the stream
-        const ShView &v = s->v;
         int64_t *h = s->h_own;
-        const int64_t unknown = v.eof ? SH_NONE : SH_UNKNOWN;
-        h[1] = unknown; h[0] = (v.hi < v.total) ? unknown : SH_NONE; h[2] = 0;
-        h[3] = (!v.eof && h[0] == SH_UNKNOWN) ? std::min(std::max<int64_t>(std::max(2 * v.head, s->head_bytes), 4096), v.total - v.hi) : 0;
-        h[4] = v.head; h[5] = 0; h[6] = 0; h[7] = v.add; h[8] = h[9] = h[10] = 0;
+        sh_words_empty(s->v, s->head_bytes, h);
+        h[8] = h[9] = h[10] = 0;
         rc = shard_gather_host_words(s);
     } else rc = shard_words_and_gather(s, 0);
     if (rc) return rc;
@@ -652,16 +557,17 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
         if (hipEventElapsedTime(&ms, s->ev_g[0], s->ev_g[1]) == hipSuccess) out->allgather_ms += ms;
         const int64_t *A = s->h_all;
         auto word = [&](int r, int k) { return A[(size_t)r * SH_WORDS + k]; };
-        bool not_ready = false;
-        for (int r = 0; r < W; r++) {
-            if (word(r, 5) == SH_ERR_TABLE_FULL) {
-                out->scan.n_records = word(r, 6);
-                return fail(FFQ_E_TABLE_FULL, "rank %d: offset table too small (%lld records in its view)", r, (long long)word(r, 6));
-            }
-            if (word(r, 5) == FFQ_E_INTERNAL) return fail(FFQ_E_INTERNAL, "rank %d: unexpected end state of its scan", r);
-            not_ready = not_ready || word(r, 5) == SH_NOT_READY;
+        const ShRound d = sh_decide(A, W, rank, B, s->v);          // (ffq_shard_proto.h: the protocol's one statement)
+        if (d.kind == ShRound::TABLE_FULL) {
+            out->scan.n_records = d.need;
+            return fail(FFQ_E_TABLE_FULL, "rank %d: offset table too small (%lld records in its view)", d.who, (long long)d.need);
         }
-        if (not_ready) {
+        if (d.kind == ShRound::QUAL_FULL) {
+            out->scan.n_records = 0; out->scan.n_qual_bytes = d.need;
+            return fail(FFQ_E_TABLE_FULL, "rank %d: quality buffer too small (%lld decoded bytes in its view)", d.who, (long long)d.need);
+        }
+        if (d.kind == ShRound::INTERNAL) return fail(FFQ_E_INTERNAL, "sharded scan: rank %d %s", d.who, d.what);
+        if (d.kind == ShRound::NOT_READY) {
             // some rank's scan needed a later tier (a host round trip inside its ffq_scan_wait): every rank's scan is through
             // by now -- the words once more
             if (++regathers > 4) return fail(FFQ_E_INTERNAL, "sharded scan: a rank's result does not become ready");
@@ -670,34 +576,11 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
             if (rc) return rc;
             continue;
         }
-        std::vector<int> grow, force;
-        for (int r = 0; r < W; r++) if (word(r, 3) > 0) grow.push_back(r);
-        for (int r = 1; r < W; r++)
-            if (B[r] > B[0] && word(r - 1, 0) != SH_UNKNOWN && word(r, 1) != word(r - 1, 0)) force.push_back(r);
-        if (grow.empty() && force.empty()) {
-            for (int r = 0; r < W; r++) {
-                if (word(r, 5)) {
-                    // The byte the iterator names is its `offset` when the failing search started: pos5 - 1 of the last
-                    // COMPLETE record in front of the failing entry (:254, :275).  A rank that owns no row in front of that
-                    // entry does not know it: the nearest rank to the left that owns a row (or rank 0, whose start is exact)
-                    // has it as the start of the search that found its exit.
-                    int64_t byte = word(r, 6);
-                    if (r > 0 && word(r, 2) == 0) {
-                        int q = r - 1;
-                        while (q > 0 && word(q, 2) == 0) q--;
-                        byte = word(q, 7);
-                    }
-                    out->err_state = (int32_t)word(r, 5);
-                    out->err_byte = byte;
-                    break;                          // (every rank reports the same error)
-                }
-                if (word(r, 0) == SH_UNKNOWN) return fail(FFQ_E_INTERNAL, "sharded scan: rank %d has no exit and nobody can move", r);
-            }
-            break;
-        }
-        if (++rounds > 2 * W + 48) return fail(FFQ_E_INTERNAL, "sharded scan does not settle (%d rounds)", rounds);
-        const bool i_grow = std::find(grow.begin(), grow.end(), rank) != grow.end();
-        const bool i_force = std::find(force.begin(), force.end(), rank) != force.end();
+        if (d.kind == ShRound::STREAM_ERROR) { out->err_state = d.err_state; out->err_byte = d.err_byte; break; }
+        if (d.kind == ShRound::SETTLED) break;
+        const std::vector<int> &grow = d.grow;
+        if (++rounds > sh_max_rounds(W)) return fail(FFQ_E_INTERNAL, "sharded scan does not settle (%d rounds)", rounds);
+        const bool i_grow = d.i_grow, i_force = d.i_force;
         int64_t start = s->start;
         if (!grow.empty() && s->from_file) {
             // every rank's bytes are the file's: a rank that needs more look-ahead reads it itself, nobody serves anybody
@@ -721,7 +604,7 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
             }
         } else if (!grow.empty()) {
             std::vector<ShPiece> plan;
-            for (int r : grow) sh_range_plan(B, r, B[r + 1] + word(r, 4), B[r + 1] + word(r, 3), plan);
+            sh_grow_plan(A, B, grow, plan);
             uint8_t *src_ext = s->ext;
             uint8_t *dst_ext = s->ext;
             int64_t dst_start = s->v.start;
@@ -751,18 +634,17 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
         }
         bool rescan = i_grow || i_force;
         if (i_force) {
-            const int64_t prev = word(rank - 1, 0);
-            if (prev == SH_NONE || (prev >= s->v.hi && s->v.hi < s->v.total)) {
+            if (d.passed_over) {
                 // the chain passes over my whole range (or ends before it): I own nothing
                 int64_t *h = s->h_own;
-                h[0] = prev; h[1] = prev; h[2] = 0; h[3] = 0; h[4] = s->v.head; h[5] = 0; h[6] = 0; h[7] = word(rank - 1, 7);
+                sh_words_passed_over(s->v, d.prev_exit, d.prev_search, h);
                 h[8] = 0; h[9] = 0; h[10] = 0;
-                s->start = word(rank - 1, 7);
+                s->start = d.prev_search;
                 rc = shard_gather_host_words(s);
                 if (rc) return rc;
                 continue;
             }
-            start = word(rank - 1, 7);
+            start = d.prev_search;
         }
         if (rescan) rc = shard_local(s, &out->scan, start);
         else rc = shard_gather_host_words(s);      // (my words stand: the others' rounds need them again)

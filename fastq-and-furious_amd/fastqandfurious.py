@@ -378,6 +378,7 @@ class RangeEntries:
 
     def close(self):
         self._gen.close()
+        self._sh.close()         # (a generator that never started has no `finally` to run)
 
     def _entries(self):
         import mmap

@@ -55,6 +55,7 @@ SYMBOLS = (
     "ffq_stream_push_buffer", "ffq_stream_push", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest", "ffq_shard_load_fd", "ffq_load_fd",
+    "ffq_shard_host_step", "ffq_shard_host_free",
 )
 
 
@@ -89,6 +90,22 @@ class ShardResult(ctypes.Structure):
         ("handoff_ms", ctypes.c_float), ("allgather_ms", ctypes.c_float),
         ("d_ext", ctypes.c_void_p), ("tail", ctypes.c_int64), ("head", ctypes.c_int64),
     ]
+
+
+class ShardPiece(ctypes.Structure):
+    """ffq_shard_piece: stream bytes [a, b) go from rank src to rank dst; ptr: where this rank reads / writes them."""
+    _fields_ = [("src", ctypes.c_int32), ("dst", ctypes.c_int32), ("a", ctypes.c_int64), ("b", ctypes.c_int64), ("ptr", ctypes.c_void_p)]
+
+
+_SCAN_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                            ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ScanResult))
+_EXCHANGE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ShardPiece), ctypes.c_int)
+_GATHER_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64))
+
+
+class ShardHostOps(ctypes.Structure):
+    """ffq_shard_host_ops (include/ffq.h)."""
+    _fields_ = [("user", ctypes.c_void_p), ("scan", _SCAN_CB), ("exchange", _EXCHANGE_CB), ("allgather", _GATHER_CB)]
 
 
 class FFQError(RuntimeError):
@@ -259,6 +276,9 @@ def lib():
         L.ffq_shard_transport.restype = ctypes.c_char_p
         L.ffq_shard_load_fd.argtypes = [vp, i32, vp, P(i64)]
         L.ffq_load_fd.argtypes = [vp, i32, i64, i64, vp, P(i64)]
+        L.ffq_shard_host_step.argtypes = [P(ShardHostOps), vp, i32, i32, P(i64), i64, i64, vp, vp, i64, P(ShardResult)]
+        L.ffq_shard_host_free.argtypes = [vp]
+        L.ffq_shard_host_free.restype = None
         L.ffq_stream_quals.argtypes = [vp, P(vp), P(vp), P(i64)]
         L.ffq_stream_close.restype = None
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
@@ -545,6 +565,50 @@ def shard_unique_id():
     buf = (ctypes.c_uint8 * 128)()
     check(lib().ffq_shard_unique_id(buf))
     return bytes(buf)
+
+
+def shard_host_step(rank, world, bounds, tail_bytes, head_bytes, ext_ptr, table_ptr, table_cap, exchange, allgather, scan=None, ctx=None):
+    """One step of the byte-range shards over HOST memory (ffq_shard_host_step): the protocol is the library's
+    (csrc/ffq_shard_proto.h), the transport the caller's --
+        exchange(pieces)   pieces = [(src, dst, a, b, ptr)]: the same list on every rank; ptr is this rank's end (or None)
+        allgather(words)   eight ints in, [world][8] out
+        scan(buf_ptr, n, sentinel, offset, eof, add, table_ptr, cap, res) -> FFQ code, res (a ScanResult) filled;
+                           None: ffq_scan_host on `ctx` (the GPU)
+    An exception raised inside a callback is re-raised here.  Returns (rc, ShardResult); rc is OK or E_TABLE_FULL."""
+    err = []
+
+    def guard(fn):
+        def run(*a):
+            try:
+                return int(fn(*a) or 0)
+            except BaseException as e:      # noqa: BLE001  (must not propagate through the C frames)
+                err.append(e)
+                return E_INTERNAL
+        return run
+
+    def c_exchange(_user, pieces, n):
+        exchange([(pieces[i].src, pieces[i].dst, pieces[i].a, pieces[i].b, pieces[i].ptr) for i in range(n)])
+
+    def c_gather(_user, mine, out):
+        allv = allgather([mine[i] for i in range(8)])
+        for r in range(world):
+            for k in range(8):
+                out[r * 8 + k] = int(allv[r][k])
+
+    def c_scan(_user, buf, n, sentinel, offset, eof, add, table, cap, res):
+        return scan(buf, n, sentinel, offset, eof, add, table, cap, res.contents)
+
+    ops = ShardHostOps(None, _SCAN_CB(guard(c_scan)) if scan is not None else _SCAN_CB(), _EXCHANGE_CB(guard(c_exchange)),
+                       _GATHER_CB(guard(c_gather)))
+    b = (ctypes.c_int64 * (world + 1))(*[int(x) for x in bounds])
+    res = ShardResult()
+    rc = lib().ffq_shard_host_step(ctypes.byref(ops), ctx.handle if ctx is not None else None, int(rank), int(world), b,
+                                   int(tail_bytes), int(head_bytes), ctypes.c_void_p(ext_ptr), ctypes.c_void_p(table_ptr),
+                                   int(table_cap), ctypes.byref(res))
+    if err:
+        raise err[0]
+    check(rc, allow=(E_TABLE_FULL,))
+    return rc, res
 
 
 class ShardWorld:

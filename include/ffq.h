@@ -405,7 +405,9 @@ int ffq_selftest(ffq_ctx *ctx);
  *                         at the shard's own, larger view), a contradicted entry guess re-entered from the
  *                         left neighbour's exit: `rounds` counts those.  err_state != 0: the stream's error
  *                         (FFQ_END_ERR_*, the byte the reference's ValueError names in err_byte), the same
- *                         on every rank.  FFQ_E_TABLE_FULL (on every rank) if some rank's table is too small.
+ *                         on every rank.  FFQ_E_TABLE_FULL (on every rank) if some rank's table is too small
+ *                         (scan.n_records = the rows that rank's view holds) or, decoding, its quality buffer
+ *                         (scan.n_records = 0, scan.n_qual_bytes = the bytes needed).
  *   ffq_shard_create_lane a second shard of the same rank on another context (ffq_ctx_create_shared: same
  *                         scan stream), on the first one's communicators: steps queued one ahead.
  *   ffq_shard_world_* / ffq_shard_create_local   k logical ranks as THREADS of one process on one GPU, hand-offs
@@ -456,6 +458,31 @@ const char *ffq_shard_transport(ffq_shard *s);    /* "rccl" / "in-process" */
  * reference's single reader per rank: read() (fastqandfurious.py:30-36), the first fill and its sentinel (:241-245,
  * rank 0's view starts the stream), the carry of an unfinished entry (:274-279, here the look-ahead).           */
 int  ffq_shard_load_fd(ffq_shard *s, int fd, uint8_t *d_ext, int64_t *n_bytes);
+/* The same step over HOST memory with the transport supplied by the caller (and, for tests, the scan): the protocol
+ * functions are the device step's (csrc/ffq_shard_proto.h), driven synchronously.  For hosts whose ranks cannot talk RCCL
+ * -- a multi-process CPU test-suite over gloo (scan = the test's own engine), a functional dry run of several ranks on
+ * one GPU (scan = NULL: ffq_scan_host on `ctx`) -- not a CPU fallback: without a scan callback it needs a context like
+ * every other compute entry point.
+ *   exchange   collective: the same list of pieces on every rank; for a piece with src == rank, ptr is where its b - a
+ *              bytes are read from, with dst == rank where they go (NULL on ranks that are neither)
+ *   allgather  collective: SH words (8 x int64) of every rank into all[world][8]
+ *   scan       ffq_scan_host's contract over h_buf (rows + add into h_table, res filled; FFQ_E_TABLE_FULL with
+ *              res->n_records = the need)
+ * h_ext = [tail | own bytes | head] with the middle filled (ffq_shard_halo's sizes from the same bounds and byte counts);
+ * on return out->d_ext is the view the rows refer to: h_ext, or a larger one the step allocated (a look-ahead had to
+ * grow) that the caller releases with ffq_shard_host_free.  Callbacks return 0 or a negative FFQ_E_* code.          */
+typedef struct ffq_shard_piece { int32_t src, dst; int64_t a, b; uint8_t *ptr; } ffq_shard_piece;
+typedef struct ffq_shard_host_ops {
+    void *user;
+    int (*scan)(void *user, const uint8_t *h_buf, int64_t n_bytes, int sentinel, int64_t offset, int eof, int64_t add,
+                int64_t *h_table, int64_t table_cap, ffq_scan_result *res);
+    int (*exchange)(void *user, const ffq_shard_piece *pieces, int n_pieces);
+    int (*allgather)(void *user, const int64_t *mine, int64_t *all);
+} ffq_shard_host_ops;
+int  ffq_shard_host_step(const ffq_shard_host_ops *ops, ffq_ctx *ctx, int rank, int world, const int64_t *bounds,
+                         int64_t tail_bytes, int64_t head_bytes, uint8_t *h_ext, int64_t *h_table, int64_t table_cap,
+                         ffq_shard_result *out);
+void ffq_shard_host_free(void *p);
 /* diagnostics: n bytes from d_src to d_dst through the shard's transport with this rank at both ends */
 int  ffq_shard_self_exchange(ffq_shard *s, const uint8_t *d_src, uint8_t *d_dst, int64_t n);
 

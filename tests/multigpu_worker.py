@@ -1,0 +1,167 @@
+"""Worker of tests/test_multigpu.py: one process per GPU under torch.distributed.run, backend nccl (= RCCL).
+
+Every rank builds the same stream (the generators are counter-based), takes its byte range, and runs the library's own
+step (ffq_shard_*: halo hand-off by ncclSend / ncclRecv between DIFFERENT ranks, scan, one ncclAllGather of the eight
+words) -- plain, pipelined over two lanes with the hand-off on its own stream, with and without the decode -- and the
+file-backed form (every rank preads its range of one file; only the gather is RCCL).  Each rank leaves its rows in the
+scratch directory; rank 0 puts them together and compares with the oracle's scan of the whole stream, and with what k
+logical ranks in ONE process (the in-process transport the single-GPU tests use) give for the same ranges: same rows,
+same repair rounds.  The invariant is the reference's own: results do not depend on how the stream is cut
+(/root/reference/tests.py:219-226)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import fastqandfurious_amd  # noqa: F401
+from fastqandfurious_amd import fastqandfurious as F, hip, sharded
+from test_sharded import bounds_for, expected, make_stream
+
+KINDS = ("single", "wrapped", "tricky", "long-wrapped", "long", "small")
+
+
+def main(scratch):
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group(backend="nccl", device_id=dev)
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+    ctx = hip.Context(local)
+    lane_ctx = hip.Context(share=ctx)
+    report = {}
+    for kind in KINDS:
+        stream = make_stream(kind)
+        t = torch.from_numpy(stream.copy()).to(dev)
+        for origin, shift in ((0, 0), (5 * (1 << 32) + 123457, 48)):
+            bounds = bounds_for(stream.size, world, origin, shift)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            sc = sharded.NativeShardScanner(ctx, bounds, rank, world, unique_id=sharded.native_unique_id(dist, dev))
+            assert sc.sh.transport() == "rccl"
+            lanes = [sc, sc.lane(lane_ctx)]
+            tail, head = sc.halo()
+            n_rows = stream.size // 40 + 64
+            exts, tabs = [], []
+            for _ in lanes:
+                e = torch.zeros(tail + (hi - lo) + head + 64, dtype=torch.uint8, device=dev)
+                e[tail:tail + hi - lo] = t[lo - origin:hi - origin]          # own bytes only: the halos must come from the peers
+                exts.append(e)
+                tabs.append(torch.empty((n_rows, 6), dtype=torch.int64, device=dev))
+            qual = torch.empty(exts[0].numel() + (8 << 20), dtype=torch.int8, device=dev)
+            qoff = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            ctx.reserve(exts[0].numel())
+            lane_ctx.reserve(exts[0].numel())
+            outs = []
+            # plain step, then the decode, then three pipelined steps over the two lanes (hand-off of step i + 1 beside
+            # the scan of step i)
+            outs.append(("plain", 0, sc.scan(exts[0], tail, head, tabs[0])))
+            for e in exts:                                                    # (wipe the halos again: each step must fetch them)
+                e[:tail].zero_()
+                e[tail + hi - lo:].zero_()
+            torch.cuda.synchronize()
+            outs.append(("decode", 0, sc.scan(exts[0], tail, head, tabs[0], hip.F_DECODE_QUAL, qual, qoff)))
+            dq = None
+            o = outs[-1][2]
+            if o.row_hi > o.row_lo:
+                qo = qoff[o.row_lo:o.row_hi + 1].cpu().numpy()
+                dq = (qual[int(qo[0]):int(qo[-1])].cpu().numpy(), qo - qo[0])
+            for e in exts:
+                e[:tail].zero_()
+                e[tail + hi - lo:].zero_()
+            torch.cuda.synchronize()
+            lanes[0].submit(exts[0], tail, head, tabs[0], overlap=True)
+            for i in range(1, 3):
+                lanes[i & 1].submit(exts[i & 1], tail, head, tabs[i & 1], overlap=True)
+                outs.append(("lane", (i - 1) & 1, lanes[(i - 1) & 1].finish()))
+            outs.append(("lane", 0, lanes[0].finish()))
+            key = "%s@%d" % (kind, origin)
+            rep = report[key] = {"steps": []}
+            for name, li, o in outs:
+                rows = (tabs[li] if name == "lane" else tabs[0])[o.row_lo:o.row_hi].cpu().numpy()
+                rep["steps"].append({"name": name, "base": o.record_base, "total": o.total_records, "rounds": o.rounds,
+                                     "handoff_bytes": o.comm["handoff_bytes"], "n": int(rows.shape[0])})
+                np.save(os.path.join(scratch, "rows_%s_%s%d_%d.npy" % (key, name, len(rep["steps"]), rank)), rows)
+                # the view the rows refer to is the stream's bytes: the hand-off delivered them
+                got = o.ext[:o.tail + hi - lo + o.head].cpu().numpy()
+                assert (got == stream[lo - o.tail - origin:hi + o.head - origin]).all(), "%s rank %d: halo bytes differ" % (key, rank)
+            if dq is not None:
+                np.save(os.path.join(scratch, "qual_%s_%d.npy" % (key, rank)), dq[0])
+            for ln in reversed(lanes):
+                ln.close()
+            dist.barrier()
+    # ---- one FILE read by all ranks: every rank preads its range, only the eight words travel ----------------------
+    fpath = os.path.join(scratch, "shared.fq")
+    fstream = make_stream("wrapped")
+    if rank == 0:
+        with open(fpath, "wb") as fh:
+            fh.write(fstream.tobytes())
+    dist.barrier()
+    for kw in ({}, dict(tail_bytes=200, head_bytes=64)):
+        it = F.readfastq_iter_range(fpath, rank, world, F.entryfunc_abspos, ctx=ctx, comm=sharded.native_unique_id(dist, dev), **kw)
+        assert it.comm["transport"] == "rccl" and it.comm["halo_source"] == "file"
+        rows = np.array([list(p) for p in it], dtype=np.int64).reshape(-1, 6)
+        np.save(os.path.join(scratch, "file_rows_%d_%d.npy" % (len(kw), rank)), rows)
+        report["file%d" % len(kw)] = {"base": it.record_base, "total": it.total_records, "n": it.n_records}
+    with open(os.path.join(scratch, "report_%d.json" % rank), "w") as fh:
+        json.dump(report, fh)
+    dist.barrier()
+    if rank == 0:
+        check(scratch, world)
+        print("multi-gpu shards ok: world %d" % world, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def check(scratch, world):
+    from oracle import ffq_oracle as oracle
+    from test_sharded import _hip_backends, run_local
+    reports = [json.load(open(os.path.join(scratch, "report_%d.json" % r))) for r in range(world)]
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    for kind in KINDS:
+        stream = make_stream(kind)
+        want0, err = expected(oracle, stream)
+        assert err is None
+        wq, wqoff = oracle.decode_quals(stream, want0)
+        for origin, shift in ((0, 0), (5 * (1 << 32) + 123457, 48)):
+            key = "%s@%d" % (kind, origin)
+            want = want0 + origin
+            bounds = bounds_for(stream.size, world, origin, shift)
+            # the same ranges as k logical ranks of ONE process (in-process transport): the rounds must agree
+            make, made = _hip_backends(None)
+            local = run_local(torch.from_numpy(stream.copy()).to(dev), bounds, make, native=True)
+            for c in made.values():
+                c.close()
+            nsteps = len(reports[0][key]["steps"])
+            for si in range(nsteps):
+                name = reports[0][key]["steps"][si]["name"]
+                parts = [np.load(os.path.join(scratch, "rows_%s_%s%d_%d.npy" % (key, name, si + 1, r))) for r in range(world)]
+                got = np.concatenate(parts)
+                assert got.shape == want.shape and (got == want).all(), "%s step %d (%s): rows over the ranks differ from the oracle's" % (key, si, name)
+                base = 0
+                for r in range(world):
+                    st = reports[r][key]["steps"][si]
+                    assert st["base"] == base and st["total"] == len(want) and st["n"] == parts[r].shape[0]
+                    assert st["rounds"] == local[r][0].rounds, "%s step %d rank %d: %d repair rounds over RCCL, %d in process" % (key, si, r, st["rounds"], local[r][0].rounds)
+                    if world > 1 and stream.size > 64 * world:
+                        assert st["handoff_bytes"] > 0, "%s rank %d: no bytes were handed off" % (key, r)
+                    base += parts[r].shape[0]
+            qs = [np.load(os.path.join(scratch, "qual_%s_%d.npy" % (key, r))) for r in range(world)
+                  if os.path.exists(os.path.join(scratch, "qual_%s_%d.npy" % (key, r)))]
+            assert (np.concatenate(qs) == wq).all(), "%s: decoded qualities over the ranks differ from the oracle's" % key
+    fwant, _ = expected(oracle, make_stream("wrapped"))
+    for k in (0, 2):
+        got = np.concatenate([np.load(os.path.join(scratch, "file_rows_%d_%d.npy" % (k, r))) for r in range(world)])
+        assert got.shape == fwant.shape and (got == fwant).all(), "file-backed ranges: rows over the ranks differ from the oracle's"
+        assert [reports[r]["file%d" % k]["base"] for r in range(world)] == \
+            [sum(reports[q]["file%d" % k]["n"] for q in range(r)) for r in range(world)]
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -4,9 +4,9 @@ configs[4]: 100 GiB synthetic 150 bp (107 374 182 146 B, 333 460 193 records) sh
 byte ranges with the chunk-edge stitch.  An 8-GPU node is not available to these tests; what one
 MI355X can show is (a) the whole protocol at full size -- 8 logical ranks as threads, each with its
 12.5 GiB range resident, its own context, halos handed off by the in-process transport, the HIP
-engine on every range, offsets past 2^36 -- and (b) the product's transport, DistTransport on the
-`nccl` backend (= RCCL), initialised at world size 1: its device-tensor all_gather, and the
-ordering of a collective on the hand-off stream against the scan stream (HipBackend.comm_context).
+engine on every range, offsets past 2^36 -- and (b) the product's transport, the library's own RCCL
+one (ffq_shard_create), initialised at world size 1: two communicators, the gather of the words,
+pipelined lanes, a re-gather, send / recv to itself (with peers: tests/test_multigpu.py).
 Semantics matched: /root/reference/src/fastqandfurious.py:251-279 (the record chain, here cut into
 ranges: every rank's rows must be exactly the rows of the one-range scan that fall into its range).
 """
@@ -26,10 +26,10 @@ RECORDS_100G = 333460193
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("native", (True, False))
+@pytest.mark.parametrize("native", (True,))
 def test_config5_eight_logical_ranges_full_size(gpu_ctx, native):
-    """native: every step behind the C ABI (ffq_shard_step_submit / _wait, in-process transport) -- the product's step with
-    device copies in place of RCCL; False: this package's protocol over the Python transport."""
+    """Every step behind the C ABI (ffq_shard_step_submit / _wait, in-process transport): the product's step with
+    device copies in place of RCCL."""
     from fastqandfurious_amd import hip, sharded
     free, _tot = torch.cuda.mem_get_info()
     if free < 190 * (1 << 30):
@@ -96,16 +96,6 @@ def _run_worker(mode, timeout):
 
 
 @pytest.mark.gpu
-def test_nccl_transport_world1(gpu_ctx):
-    """DistTransport on the nccl (RCCL) backend: the device all_gather of the hand-off words, a sharded
-    step through it, and a collective on the hand-off stream ordered in front of the scan."""
-    r = _run_worker("transport", 300)
-    assert not isinstance(r, subprocess.TimeoutExpired), "nccl worker timed out"
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "nccl transport ok" in r.stdout
-
-
-@pytest.mark.gpu
 def test_native_step_on_rccl_world1(gpu_ctx):
     """The library's own step (ffq_shard_*) on its RCCL transport at world size 1: two communicators from one unique id,
     steps plain and pipelined over two lanes, the gather of the hand-off words, comm figures in the result; and
@@ -116,16 +106,3 @@ def test_native_step_on_rccl_world1(gpu_ctx):
         pytest.skip("RCCL refuses send/recv to self: " + r.stdout.strip().splitlines()[-1])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "native step on rccl ok" in r.stdout
-
-
-@pytest.mark.gpu
-def test_nccl_self_sendrecv_world1(gpu_ctx):
-    """batch_isend_irecv on device tensors (the halo hand-off's call) with the only peer there is at
-    world size 1: this rank itself.  RCCL builds without self send/recv are skipped, not failed."""
-    r = _run_worker("p2p", 120)
-    if isinstance(r, subprocess.TimeoutExpired):
-        pytest.skip("RCCL self send/recv did not complete at world size 1")
-    if r.returncode != 0 and "self-p2p unsupported" in r.stdout:
-        pytest.skip("RCCL refuses send/recv to self: " + r.stdout.strip().splitlines()[-1])
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "nccl self p2p ok" in r.stdout

@@ -1,0 +1,65 @@
+"""Several GPUs, one process each, RCCL between them -- a test that ARMS ITSELF: world = min(8, visible GPUs), skipped
+on a one-GPU box (where the same worker still runs at world size 1, so that its code cannot rot unseen).
+
+tests/multigpu_worker.py under torch.distributed.run: every rank takes its byte range of S-single, S-wrapped, "tricky"
+(a quality block of FASTQ-looking text: wrong entry guesses), "long" / "long-wrapped" (a record longer than the halo:
+the look-ahead grows across ranks) and "small" streams, runs the library's own step (ffq_shard_*; ncclSend / ncclRecv
+between different ranks, one ncclAllGather) plain, with the decode and pipelined over two lanes, then the file-backed
+form (readfastq_iter_range over one shared file); rank 0 gathers every rank's rows and compares them with the oracle's
+scan of the whole stream and with the run of the same ranges as k logical ranks in one process (same rows, same repair
+rounds), asserts transport == "rccl" and handoff_bytes > 0.  The invariance being tested is the reference's own:
+/root/reference/tests.py:219-226 (the entries do not depend on how the stream is cut into buffers)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(world, scratch, timeout):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multigpu_worker.py"), str(scratch)]
+    try:
+        return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        return e
+
+
+def n_gpus():
+    try:
+        return min(8, torch.cuda.device_count())
+    except Exception:      # noqa: BLE001
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(n_gpus() < 2, reason="one GPU visible: RCCL between ranks needs at least two (the test arms itself on a multi-GPU box)")
+def test_native_shards_over_rccl_all_visible_gpus(gpu_ctx, tmp_path):
+    world = n_gpus()
+    r = _launch(world, tmp_path, 1500)
+    assert not isinstance(r, subprocess.TimeoutExpired), "multi-GPU worker timed out (world %d)" % world
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    assert "multi-gpu shards ok: world %d" % world in r.stdout
+
+
+@pytest.mark.gpu
+def test_multigpu_worker_at_world_one(gpu_ctx, tmp_path):
+    """The same worker under the same launcher with one rank: communicators, lanes, gathers, the file-backed ranges and
+    rank 0's check all run (no peer to hand anything to)."""
+    r = _launch(1, tmp_path, 900)
+    assert not isinstance(r, subprocess.TimeoutExpired), "worker timed out"
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    assert "multi-gpu shards ok: world 1" in r.stdout

@@ -1,17 +1,16 @@
-"""Byte-range sharding (fastq-and-furious_amd/sharded.py).
+"""Byte-range sharding (fastq-and-furious_amd/sharded.py; the protocol itself: csrc/ffq_shard_proto.h).
 
-CPU (`-m "not gpu"`): the host protocol -- halo hand-off by owner, row ownership cut, hand-off
-verification, look-ahead growth for records longer than the halo, re-entry from the left
-neighbour's exit, stream errors raised by every rank -- with the CPU oracle as the scan engine
-(test infrastructure), over gloo (world 2 and 3, separate processes) and over the in-process
-transport (k logical ranks as threads).
+CPU (`-m "not gpu"`): the HOST step of the library (ffq_shard_host_step: the same protocol functions the device step
+runs) -- halo hand-off by owner, row ownership cut, hand-off verification, look-ahead growth for records longer than the
+halo, re-entry from the left neighbour's exit, stream errors raised by every rank -- with the CPU oracle as the scan
+engine (test infrastructure, handed in as the step's scan callback), over gloo (world 2 and 3, separate processes) and
+over the in-process transport (k logical ranks as threads).
 
-GPU (`-m gpu`): the same protocol on the HIP engine -- k in {2, 3, 8} logical ranges of one
-resident buffer through ShardScanner(HipBackend) with the in-process transport, S-single and
-S-wrapped, with and without decode, stream offsets past 2^32 (so that `add` and ffq_table_cut
-see the offsets of BASELINE config 5), records longer than the halo across an edge.  The unit
-that shards is the record chain of /root/reference/src/fastqandfurious.py:251-279; the reference
-grows its buffer until a record fits (:274-279).
+GPU (`-m gpu`): the DEVICE step (ffq_shard_step_*) with k in {2, 3, 8} logical ranges of one resident buffer, S-single and
+S-wrapped, with and without decode, stream offsets past 2^32 (so that `add` and the cut see the offsets of BASELINE
+config 5), records longer than the halo across an edge -- and the host step with the GPU scanning (ffq_scan_host).  The
+unit that shards is the record chain of /root/reference/src/fastqandfurious.py:251-279; the reference grows its buffer
+until a record fits (:274-279).
 
 Concatenated shard rows must equal the oracle's single-range table, bit for bit."""
 import contextlib
@@ -30,41 +29,26 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class OracleBackend:
-    def __init__(self):
-        from oracle import ffq_oracle
-        self.o = ffq_oracle
+def oracle_scan(data, sentinel, offset, eof, add, rows, small=False):
+    """The host step's scan callback on the CPU oracle: (rc, n_records, end_state, end_offset, last_status, last_pos0)."""
+    from oracle import ffq_oracle as o
+    t, end, status, off = o.scan(data, sentinel=sentinel, offset=offset, eof=eof, add=add)
+    n = len(t)
+    if small or n > rows.shape[0]:
+        return -5, n, end, off, status, -1              # E_TABLE_FULL, as the HIP engine reports it
+    rows[:n] = t
+    pos0 = -1
+    if end != 0:
+        st, pos = o.entrypos(np.concatenate([np.array([10], dtype=np.uint8), data]) if sentinel else data, off, 0)
+        pos0 = int(pos[0]) + add if pos[0] >= 0 else -1
+    return 0, n, end, off, status, pos0
 
-    def scan(self, ext, n_bytes, sentinel, offset, eof, add, table, flags=0, qual=None, qoff=None,
-             table_cap=None):
-        data = ext[:n_bytes].numpy()
-        t, end, status, off = self.o.scan(data, sentinel=sentinel, offset=offset, eof=eof, add=add)
-        n = len(t)
-        table[:n] = torch.from_numpy(t)
-        res = types.SimpleNamespace(n_records=n, end_state=end, end_offset=off, last_status=status,
-                                    last_pos=[-1] * 6, path=0, n_qual_bytes=0)
-        if end != 0:
-            st, pos = self.o.entrypos(np.concatenate([np.array([10], dtype=np.uint8), data])
-                                      if sentinel else data, off, 0)
-            res.last_pos = [int(p) + add if p >= 0 else -1 for p in pos]
-        return 0, res
 
-    # submit / wait: the engine runs at wait time (what matters is the protocol above it)
-    def scan_submit(self, *a, **kw):
-        self._queued = (a, kw)
+class HostEngine:
+    """What run_local hands a rank: the scan of its host step (None: the GPU, through `ctx`)."""
 
-    def scan_wait(self):
-        a, kw = self._queued
-        return self.scan(*a, **kw)
-
-    def cut(self, table, n_rows, lo, hi):
-        t = table[:n_rows].numpy()
-        i0, i1 = (int(np.searchsorted(t[:, 0], x, side="left")) for x in (lo, hi))
-        return (i0, i1, int(t[i0, 0]) if i0 < n_rows else -1, int(t[i1, 0]) if i1 < n_rows else -1,
-                int(t[i0 - 1, 5]) if i0 > 0 else -1, int(t[i1 - 1, 5]) if i1 > 0 else -1)
-
-    def stream_context(self, ext):
-        return contextlib.nullcontext()
+    def __init__(self, scan=oracle_scan, ctx=None):
+        self.scan, self.ctx = scan, ctx
 
 
 # ---- streams ------------------------------------------------------------------------------------
@@ -144,8 +128,10 @@ def expected(oracle, stream, origin=0):
 # ---- k logical ranks as threads of one process ---------------------------------------------------
 def run_local(stream_t, bounds, make_backend, tail_bytes=None, head_bytes=None, flags=0, lanes=False,
               table_rows=None, decode=False, native=False):
-    """Every rank: ext = [zeros | own bytes | zeros] -> exchange_halo -> scan.  Returns the list of
-    (ScanOutput, table, qual, qoff) per rank, or raises what the ranks raised (all the same)."""
+    """Every rank: ext = [zeros | own bytes | zeros] -> one step.  native: the device step (NativeShardScanner over
+    hip.ShardWorld, `stream_t` on the GPU); else the host step (HostShardScanner over the thread transport, buffers in
+    host memory, the engine's scan).  Returns the list of (ScanOutput, table, qual, qoff) per rank, or raises what the
+    ranks raised (all the same)."""
     from fastqandfurious_amd import sharded
     world = len(bounds) - 1
     lw = sharded.LocalWorld(world)
@@ -155,42 +141,43 @@ def run_local(stream_t, bounds, make_backend, tail_bytes=None, head_bytes=None, 
     results, errors = [None] * world, [None] * world
     origin = bounds[0]
     n_rows = table_rows or (stream_t.numel() // 40 + 64)
+    host_bytes = None if native else stream_t.cpu().numpy()
 
     def work(rank):
         try:
-            if native:
-                # the library's own step (ffq_shard_*, in-process transport): hand-off, scan, cut and gather behind the C ABI
-                sc = sharded.NativeShardScanner(make_backend(rank).ctx, bounds, rank, world, local_world=lw.native_world(), **kw)
-            else:
-                sc = sharded.ShardScanner(make_backend(rank), lw.transport(rank), bounds, **kw)
-            tail, head = sc.halo()
+            eng = make_backend(rank)
             lo, hi = bounds[rank], bounds[rank + 1]
-            ext = torch.zeros(tail + (hi - lo) + head + 64, dtype=torch.uint8, device=stream_t.device)
-            ext[tail:tail + hi - lo] = stream_t[lo - origin:hi - origin]
-            if ext.is_cuda:
-                torch.cuda.synchronize()
-            table = torch.empty((n_rows, 6), dtype=torch.int64, device=stream_t.device)
             qual = qoff = None
-            if decode:
-                qual = torch.empty(ext.numel() + (8 << 20), dtype=torch.int8, device=stream_t.device)
-                qoff = torch.empty(n_rows + 1, dtype=torch.int64, device=stream_t.device)
-            if not native:
-                sc.exchange_halo(ext, tail, head)
-                if ext.is_cuda:
-                    torch.cuda.synchronize()
-                got = ext[:tail + hi - lo + head].cpu().numpy()
-                ref = stream_t[lo - tail - origin:hi + head - origin].cpu().numpy()
-                assert (got == ref).all(), "halo bytes differ"
+            if native:
+                sc = sharded.NativeShardScanner(eng.ctx, bounds, rank, world, local_world=lw.native_world(), **kw)
+                tail, head = sc.halo()
+                ext = torch.zeros(tail + (hi - lo) + head + 64, dtype=torch.uint8, device=stream_t.device)
+                ext[tail:tail + hi - lo] = stream_t[lo - origin:hi - origin]
+                torch.cuda.synchronize()
+                table = torch.empty((n_rows, 6), dtype=torch.int64, device=stream_t.device)
+                if decode:
+                    qual = torch.empty(ext.numel() + (8 << 20), dtype=torch.int8, device=stream_t.device)
+                    qoff = torch.empty(n_rows + 1, dtype=torch.int64, device=stream_t.device)
+                args = (ext, tail, head, table, flags, qual, qoff)
+            else:
+                assert not decode
+                sc = sharded.HostShardScanner(lw.transport(rank), bounds, ctx=eng.ctx, scan=eng.scan, **kw)
+                tail, head = sc.halo()
+                ext = np.zeros(tail + (hi - lo) + head + 64, dtype=np.uint8)
+                ext[tail:tail + hi - lo] = host_bytes[lo - origin:hi - origin]
+                table = np.empty((n_rows, 6), dtype=np.int64)
+                args = (ext, tail, head, table)
             if lanes:
-                sc.submit(ext, tail, head, table, flags, qual, qoff)
+                sc.submit(*args)
                 out = sc.finish()
             else:
-                out = sc.scan(ext, tail, head, table, flags, qual, qoff)
-            if native:
-                torch.cuda.synchronize()
-                got = ext[:tail + hi - lo + head].cpu().numpy()
-                ref = stream_t[lo - tail - origin:hi + head - origin].cpu().numpy()
-                assert (got == ref).all(), "halo bytes differ"
+                out = sc.scan(*args)
+            # the view the rows refer to is the stream's bytes: the hand-off delivered them
+            got = out.ext[:out.tail + hi - lo + out.head]
+            got = got.cpu().numpy() if native else np.asarray(got)
+            ref = (stream_t[lo - out.tail - origin:hi + out.head - origin].cpu().numpy() if native
+                   else host_bytes[lo - out.tail - origin:hi + out.head - origin])
+            assert (got == ref).all(), "halo bytes differ"
             results[rank] = (out, table, qual, qoff)
         except BaseException as e:   # noqa: BLE001
             errors[rank] = e
@@ -211,12 +198,16 @@ def run_local(stream_t, bounds, make_backend, tail_bytes=None, head_bytes=None, 
     return results
 
 
+def _np(x):
+    return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+
+
 def check_rows(results, bounds, want):
     world = len(bounds) - 1
     parts, base = [], 0
     for r in range(world):
         out, table = results[r][0], results[r][1]
-        rows = table[out.row_lo:out.row_hi].cpu().numpy()
+        rows = _np(table[out.row_lo:out.row_hi])
         mine = want[(want[:, 0] >= bounds[r]) & (want[:, 0] < bounds[r + 1])]
         assert rows.shape == mine.shape and (rows == mine).all(), "rank %d: shard rows differ from the single-range table" % r
         assert out.record_base == base and out.total_records == len(want)
@@ -257,7 +248,7 @@ def test_local_ranks_oracle_engine(oracle, pkg, kind, world, kw):
     t = torch.from_numpy(stream.copy())
     for origin, shift in ((0, 0), (5 * (1 << 32) + 123457, 48)):
         bounds = bounds_for(stream.size, world, origin, shift)
-        res = run_local(t, bounds, lambda r: OracleBackend(), lanes=(origin != 0), **kw)
+        res = run_local(t, bounds, lambda r: HostEngine(), lanes=(origin != 0), **kw)
         check_rows(res, bounds, want + origin)
     if kind in ("long", "long-wrapped") and not kw:
         assert any(r[0].rounds > 0 and r[0].head > (1 << 20) for r in res), "no rank grew its look-ahead"
@@ -275,7 +266,7 @@ def test_local_ranks_stream_errors(oracle, pkg, kind, world):
     assert err is not None
     t = torch.from_numpy(stream.copy())
     with pytest.raises(ValueError) as ei:
-        run_local(t, bounds_for(stream.size, world), lambda r: OracleBackend())
+        run_local(t, bounds_for(stream.size, world), lambda r: HostEngine())
     assert str(ei.value) == err
 
 
@@ -300,7 +291,7 @@ def test_local_ranks_stream_error_byte_with_tiny_halos(oracle, pkg):
         for world in (2, 3, 5):
             for tail, head in ((1, 16), (64, 48), (256, 64)):
                 with pytest.raises(ValueError) as ei:
-                    run_local(t, bounds_for(stream.size, world, 0, int(rng.integers(-40, 40))), lambda r: OracleBackend(),
+                    run_local(t, bounds_for(stream.size, world, 0, int(rng.integers(-40, 40))), lambda r: HostEngine(),
                               tail_bytes=tail, head_bytes=head)
                 assert str(ei.value) == err, (it, world, tail, head)
                 checked += 1
@@ -312,14 +303,8 @@ def test_local_ranks_table_too_small(oracle, pkg):
     stream = make_stream("single")
     t = torch.from_numpy(stream.copy())
     with pytest.raises(RuntimeError) as ei:
-        run_local(t, bounds_for(stream.size, 3), lambda r: OracleBackendSmall() if r == 1 else OracleBackend())
+        run_local(t, bounds_for(stream.size, 3), lambda r: HostEngine(lambda *a: oracle_scan(*a, small=True)) if r == 1 else HostEngine())
     assert "offset table too small" in str(ei.value)
-
-
-class OracleBackendSmall(OracleBackend):
-    def scan(self, ext, n_bytes, sentinel, offset, eof, add, table, *a, **kw):
-        rc, res = OracleBackend.scan(self, ext, n_bytes, sentinel, offset, eof, add, torch.empty((20000, 6), dtype=torch.int64))
-        return -5, res              # E_TABLE_FULL, as the HIP engine reports it
 
 
 def test_local_ranks_empty_and_tiny(oracle, pkg):
@@ -330,10 +315,10 @@ def test_local_ranks_empty_and_tiny(oracle, pkg):
         for world in (2, 4):
             bounds = bounds_for(stream.size, world)
             if err is None:
-                check_rows(run_local(t, bounds, lambda r: OracleBackend()), bounds, want)
+                check_rows(run_local(t, bounds, lambda r: HostEngine()), bounds, want)
             else:
                 with pytest.raises(ValueError) as ei:
-                    run_local(t, bounds, lambda r: OracleBackend())
+                    run_local(t, bounds, lambda r: HostEngine())
                 assert str(ei.value) == err
 
 
@@ -352,29 +337,32 @@ def _worker(rank, world, port, kind, tmpdir):
         total = stream.size
         S = sharded.shard_bounds(total, world)
         lo, hi = S[rank], S[rank + 1]
-        tr = sharded.DistTransport(dist, None, torch.device("cpu"))
-        sc = sharded.ShardScanner(OracleBackend(), tr, S)
+        # the library's host step (ffq_shard_host_step): its protocol, gloo as the transport, the oracle as the scan
+        tr = sharded.DistTransport(dist)
+        sc = sharded.HostShardScanner(tr, S, scan=oracle_scan)
         tail, head = sc.halo()
-        ext = torch.zeros(tail + (hi - lo) + head, dtype=torch.uint8)
-        ext[tail:tail + hi - lo] = torch.from_numpy(stream[lo:hi].copy())
-        sc.exchange_halo(ext, tail, head)
-        assert bytes(ext.numpy()) == bytes(stream[lo - tail:hi + head]), "halo bytes differ"
-        table = torch.empty((100000, 6), dtype=torch.int64)
+
+        def fresh():
+            e = np.zeros(tail + (hi - lo) + head + 64, dtype=np.uint8)
+            e[tail:tail + hi - lo] = stream[lo:hi]
+            return e
+        ext = fresh()
+        table = np.empty((100000, 6), dtype=np.int64)
         out = sc.scan(ext, tail, head, table)
-        # the same step through submit / finish, two lanes, two rounds (the queue bench.py keeps)
-        lanes = [sc, sharded.ShardScanner(OracleBackend(), tr, S)]
-        tabs = [table, torch.empty_like(table)]
-        lanes[0].submit(ext, tail, head, tabs[0])
-        for i in range(1, 4):
-            lanes[i & 1].submit(ext, tail, head, tabs[i & 1])
-            o2 = lanes[(i - 1) & 1].finish()
-            assert (o2.row_lo, o2.row_hi, o2.exit_pos, o2.first_pos, o2.record_base) == \
-                   (out.row_lo, out.row_hi, out.exit_pos, out.first_pos, out.record_base)
-            assert (tabs[(i - 1) & 1][:o2.n_rows] == table[:out.n_rows]).all()
-        lanes[3 & 1].finish()
+        assert bytes(out.ext[:out.tail + hi - lo + out.head]) == bytes(stream[lo - out.tail:hi + out.head]), "halo bytes differ"
+        if world > 1:
+            assert out.comm["handoff_bytes"] > 0
+        # the same step again through submit / finish, twice (the queue bench.py keeps): same rows, same words
+        tabs = [table, np.empty_like(table)]
+        for i in range(1, 3):
+            sc.submit(fresh(), tail, head, tabs[i & 1])
+            o2 = sc.finish()
+            assert (o2.row_lo, o2.row_hi, o2.exit_pos, o2.first_pos, o2.record_base, o2.rounds) == \
+                   (out.row_lo, out.row_hi, out.exit_pos, out.first_pos, out.record_base, out.rounds)
+            assert (tabs[i & 1][:o2.n_rows] == table[:out.n_rows]).all()
         want, end, st, off = ffq_oracle.scan(stream)
         mine = want[(want[:, 0] >= lo) & (want[:, 0] < hi)]
-        got = table[out.row_lo:out.row_hi].numpy()
+        got = table[out.row_lo:out.row_hi]
         assert got.shape == mine.shape and (got == mine).all(), "shard rows differ from the single-range table"
         first = int(np.searchsorted(want[:, 0], lo))
         assert out.record_base == first
@@ -415,14 +403,13 @@ def _error_worker(rank, world, port, kind, tmpdir):
         stream = make_stream(kind)
         S = sharded.shard_bounds(stream.size, world)
         lo, hi = S[rank], S[rank + 1]
-        sc = sharded.ShardScanner(OracleBackend(), sharded.DistTransport(dist, None, torch.device("cpu")), S)
+        sc = sharded.HostShardScanner(sharded.DistTransport(dist), S, scan=oracle_scan)
         tail, head = sc.halo()
-        ext = torch.zeros(tail + (hi - lo) + head, dtype=torch.uint8)
-        ext[tail:tail + hi - lo] = torch.from_numpy(stream[lo:hi].copy())
-        sc.exchange_halo(ext, tail, head)
+        ext = np.zeros(tail + (hi - lo) + head + 64, dtype=np.uint8)
+        ext[tail:tail + hi - lo] = stream[lo:hi]
         msg = "none"
         try:
-            sc.scan(ext, tail, head, torch.empty((100000, 6), dtype=torch.int64))
+            sc.scan(ext, tail, head, np.empty((100000, 6), dtype=np.int64))
         except ValueError as e:
             msg = str(e)
         with open(os.path.join(tmpdir, "err_%d.txt" % rank), "w") as fh:
@@ -442,15 +429,27 @@ def test_shard_bounds(pkg):
     from fastqandfurious_amd import sharded
     b = sharded.shard_bounds(1000003, 4)
     assert b[0] == 0 and b[-1] == 1000003 and all(x % 16 == 0 for x in b[:-1]) and b == sorted(b)
-    # every byte of every halo has exactly one provider
-    plan = sharded.halo_plan([0, 1600, 3200, 4800, 5000], 1000, 2000)
+    # every byte of every halo has exactly one provider: the pieces the host step asks its transport for
+    B = [0, 1600, 3200, 4800, 5000]
+    seen = []
+
+    class Recorder(sharded.SoloTransport):
+        world = 4
+
+        def exchange(self, pieces):
+            seen.append([(s_, d, a, c) for s_, d, a, c, _p in pieces])
+            raise StopIteration                     # (the plan is all this test wants)
+    sc = sharded.HostShardScanner(Recorder(), B, tail_bytes=1000, head_bytes=2000, scan=oracle_scan)
+    with pytest.raises(StopIteration):
+        sc.scan(np.zeros(1600 + 2000 + 64, dtype=np.uint8), 0, 2000, np.empty((10, 6), dtype=np.int64))
+    plan = seen[0]
     for q in range(4):
-        got = sorted((a, c) for s, d, a, c in plan if d == q)
-        lo, hi = [0, 1600, 3200, 4800, 5000][q:q + 2]
+        got = sorted((a, c) for s_, d, a, c in plan if d == q)
+        lo, hi = B[q:q + 2]
         need = [(max(lo - 1000, 0), lo), (hi, min(hi + 2000, 5000))]
-        covered = sum(c - a for a, c in got)
-        assert covered == sum(c - a for a, c in need)
-        assert all(s != q for s, d, a, c in plan if d == q)
+        assert sum(c - a for a, c in got) == sum(c - a for a, c in need)
+        assert all(s_ != q for s_, d, a, c in plan if d == q)
+    assert all(B[s_] <= a and c <= B[s_ + 1] for s_, d, a, c in plan)          # ... and the provider owns what it provides
 
 
 # ---- the HIP engine ---------------------------------------------------------------------------------
@@ -461,7 +460,7 @@ def _hip_backends(gpu_ctx):
 
     def make(rank):
         made[rank] = hip.Context(0)
-        return sharded.HipBackend(made[rank])
+        return HostEngine(scan=None, ctx=made[rank])          # (the host step's scan: ffq_scan_host on this context)
     return make, made
 
 
@@ -481,9 +480,12 @@ GPU_CASES = [
 @pytest.mark.parametrize("decode", (False, True))
 @pytest.mark.parametrize("native", (False, True))
 def test_local_ranks_hip_engine(gpu_ctx, oracle, kind, world, kw, decode, native):
-    """native: the step behind the C ABI (ffq_shard_step_submit / _wait with the in-process transport) instead of this
-    package's protocol over the Python transport -- same ranges, same rows, same rounds."""
+    """native: the DEVICE step (ffq_shard_step_submit / _wait with the in-process transport); else the HOST step
+    (ffq_shard_host_step over the thread transport, the GPU scanning through ffq_scan_host) -- same protocol functions,
+    same ranges, same rows, same rounds."""
     from fastqandfurious_amd import hip
+    if decode and not native:
+        pytest.skip("the host step has no decode")
     stream = make_stream(kind)
     want, err = expected(oracle, stream)
     assert err is None
@@ -552,14 +554,15 @@ def test_synthetic_shards_local_ranks(gpu_ctx, kind, native):
             table = torch.empty((sh.max_records + 64, 6), dtype=torch.int64, device=dev)
             qual = torch.empty(sh.ext.numel(), dtype=torch.int8, device=dev)
             qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
-            out = sh.scan(table, flags=hip.F_DECODE_QUAL, qual=qual, qoff=qoff)
+            out = sh.scan(table, flags=hip.F_DECODE_QUAL if native else 0, qual=qual, qoff=qoff)
             sh.verify(table, out)
-            sh.verify_decode(table, out, qual, qoff)
+            if native:
+                sh.verify_decode(table, out, qual, qoff)
             sh.make_lanes(2)
             # with peers every lane has a buffer of its own and its hand-off runs on the hand-off stream,
             # beside the other lane's scan: wipe the halos, so that rows can only come out right if
             # each lane's hand-off has landed before its scan reads them
-            assert sh._overlap and sh._exts[0].data_ptr() != sh._exts[1].data_ptr()
+            assert not native or (sh._overlap and sh._exts[0].data_ptr() != sh._exts[1].data_ptr())
             for e in sh._exts:
                 e[:sh.tail].zero_()
                 e[sh.tail + sh.n_own_bytes:].zero_()
