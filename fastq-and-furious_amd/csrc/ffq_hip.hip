@@ -941,7 +941,7 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
             int rc = enqueue_general(c, a, L, st.dense_cfg, st.ngroups, true);
             if (rc) return rc;
         } else {
-            hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, sA, c->dres, make_pub(c));
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, sA, c->dres, make_pub(c), 1);
             c->ctl_clean = true;
         }
         st.stage = 2;
@@ -1031,7 +1031,7 @@ static int enqueue_offsets_and_decode(ffq_ctx *c, const ScanArgs &a, int64_t n_r
     hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, sA, c->col_sum, nblk, n_rows, c->dres);
     hipLaunchKernelGGL(k_col_offsets, dim3((unsigned)nblk), dim3(256), 0, sA, (const int64_t *)a.d_table, n_rows, 4, 0, 5,
                        (const long long *)c->col_sum, (const DevRes *)c->dres, a.d_qoff, c->p4s, c->qdir, c->qdir_cap);
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, sA, c->dres, make_pub(c));
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, sA, c->dres, make_pub(c), 0);
     enqueue_decode(c, a, sA);
     return FFQ_OK;
 }

@@ -455,10 +455,14 @@ __global__ void k_finalize_serial(DevRes *res, int64_t table_cap, int64_t *__res
     publish(pb, res);
 }
 
-// publisher of a front that ends without a result kernel (forced serial walker)
-__global__ void k_publish(DevRes *res, Pub pb)
+// publisher of a front that ends without a result kernel (the list-ranking tier and the one-wave walker are driven from
+// the host's wait): the result block on the DEVICE says so -- fallback = 1, "a later tier follows" -- for whoever reads it
+// behind this front without a host round trip (k_shard_words: the words of such a rank are "not ready", gathered again
+// once its wait is through; before this mark they were the PREVIOUS scan's)
+__global__ void k_publish(DevRes *res, Pub pb, int later_tier_follows)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (later_tier_follows) res->fallback = 1;
     publish(pb, res);
 }
 

@@ -272,6 +272,8 @@ struct ffq_shard {
     bool from_file = false;                // the pending step runs over file_ext
 };
 
+static bool sh_debug() { static const bool on = getenv("FFQ_SHARD_DEBUG") != nullptr; return on; }
+
 static ShView sh_view(const ffq_shard *s, int64_t tail, int64_t head) { return sh_make_view(s->lo, s->hi, s->total, s->origin, tail, head); }
 
 static int shard_alloc(ffq_shard *s, ffq_shard *parent = nullptr)
@@ -558,6 +560,18 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
         const int64_t *A = s->h_all;
         auto word = [&](int r, int k) { return A[(size_t)r * SH_WORDS + k]; };
         const ShRound d = sh_decide(A, W, rank, B, s->v);          // (ffq_shard_proto.h: the protocol's one statement)
+        if (sh_debug()) {
+            // FFQ_SHARD_DEBUG=1: what this rank sees in every round (a run on several GPUs that nobody can attach to)
+            std::string line;
+            char buf[256];
+            for (int r = 0; r < W; r++) {
+                snprintf(buf, sizeof buf, " [%d: exit %lld first %lld n %lld want %lld had %lld err %lld/%lld search %lld]", r, (long long)word(r, 0), (long long)word(r, 1),
+                         (long long)word(r, 2), (long long)word(r, 3), (long long)word(r, 4), (long long)word(r, 5), (long long)word(r, 6), (long long)word(r, 7));
+                line += buf;
+            }
+            fprintf(stderr, "[ffq shard %d/%d] round %d regather %d kind %d view [%lld | %lld, %lld | %lld] rows %lld..%lld of %lld:%s\n", rank, W, rounds, regathers, (int)d.kind,
+                    (long long)s->v.tail, (long long)s->v.lo, (long long)s->v.hi, (long long)s->v.head, (long long)s->h_own[8], (long long)s->h_own[9], (long long)s->h_own[10], line.c_str());
+        }
         if (d.kind == ShRound::TABLE_FULL) {
             out->scan.n_records = d.need;
             return fail(FFQ_E_TABLE_FULL, "rank %d: offset table too small (%lld records in its view)", d.who, (long long)d.need);

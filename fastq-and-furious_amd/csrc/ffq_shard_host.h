@@ -6,30 +6,13 @@
 //   * a functional dry run of bench.py's N > 1 path on ONE GPU (FFQ_BENCH_DRY_MULTI: RCCL refuses two ranks per device):
 //     scan == NULL means ffq_scan_host on the caller's context, the transport is gloo.
 // It is NOT a CPU fallback of anything: without a scan callback it needs a context (a gfx950 device) like every other
-// compute entry point.  Included at the end of ffq_hip.hip; tools/shard_proto_tsan.cpp includes it without HIP
-// (FFQ_SHARD_HOST_STANDALONE: the caller must bring the scan).
+// compute entry point.  Included at the end of ffq_hip.hip; tests/test_tsan.py runs it under ThreadSanitizer (k ranks as
+// threads, a -fsanitize=thread build of the library's host code).
 #pragma once
 #include "ffq_shard_proto.h"
 
 #include <cstdlib>
 #include <cstring>
-
-#ifdef FFQ_SHARD_HOST_STANDALONE
-#include <cstdarg>
-#include <cstdio>
-#include <string>
-static thread_local std::string g_sh_err;
-static int fail(int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_sh_err = buf;
-    return code;
-}
-#endif
 
 extern "C" void ffq_shard_host_free(void *p) { free(p); }
 
@@ -43,12 +26,7 @@ extern "C" int ffq_shard_host_step(const ffq_shard_host_ops *ops, ffq_ctx *ctx, 
     if (tail_bytes < 1 || head_bytes < 1) return fail(FFQ_E_ARG, "ffq_shard_host_step: tail_bytes and head_bytes must be at least 1");
     for (int r = 0; r < world; r++)
         if (bounds[r] > bounds[r + 1]) return fail(FFQ_E_ARG, "ffq_shard_host_step: bounds must not decrease");
-#ifdef FFQ_SHARD_HOST_STANDALONE
-    if (!ops->scan) return fail(FFQ_E_ARG, "ffq_shard_host_step: no scan");
-    (void)ctx;
-#else
     if (!ops->scan && !ctx) return fail(FFQ_E_ARG, "ffq_shard_host_step: neither a scan callback nor a context");
-#endif
     memset(out, 0, sizeof *out);
     const std::vector<int64_t> B(bounds, bounds + world + 1);
     const int64_t lo = B[rank], hi = B[rank + 1], total = B[world], origin = B[0];
@@ -89,11 +67,8 @@ extern "C" int ffq_shard_host_step(const ffq_shard_host_ops *ops, ffq_ctx *ctx, 
         ffq_scan_result &res = out->scan;
         memset(&res, 0, sizeof res);
         int r;
-#ifndef FFQ_SHARD_HOST_STANDALONE
         if (!ops->scan) r = ffq_scan_host(ctx, ext, v.n_bytes, v.sentinel, offset, v.eof, v.add, 0, 0, h_table, table_cap, nullptr, 0, nullptr, &res);
-        else
-#endif
-            r = ops->scan(ops->user, ext, v.n_bytes, v.sentinel, offset, v.eof, v.add, h_table, table_cap, &res);
+        else r = ops->scan(ops->user, ext, v.n_bytes, v.sentinel, offset, v.eof, v.add, h_table, table_cap, &res);
         if (r && r != FFQ_E_TABLE_FULL) return r < 0 ? r : fail(FFQ_E_INTERNAL, "ffq_shard_host_step: the scan callback failed (%d)", r);
         const int64_t n = res.n_records;
         if (r == FFQ_E_TABLE_FULL || n > table_cap) {

@@ -3,8 +3,8 @@
 // look-ahead to grow / an entry to re-enter from the left neighbour's exit), who hands which bytes to whom, the barrier of
 // the in-process world.  ONE statement of it: the device step (ffq_shard.h: HIP streams, RCCL) and the host step
 // (ffq_shard_host.h: caller-supplied scan / exchange / gather, what the CPU tests drive over gloo) both run on these
-// functions, so a change of the protocol lands once.  Compiles without HIP (g++ -fsanitize=thread:
-// tools/shard_proto_tsan.cpp); under hipcc sh_words_from is also device code (k_shard_words calls it).
+// functions, so a change of the protocol lands once.  No HIP in here (tests/tsan_host_threads.cpp includes it for the
+// barrier it runs its ranks over); under hipcc sh_words_from is also device code (k_shard_words calls it).
 //
 // What is sharded is the record chain of readfastq_iter (/root/reference/src/fastqandfurious.py:251-279): rank r owns the
 // stream bytes [S_r, S_r+1) and every record whose '@' lies in them; what the reference does with a record that does not

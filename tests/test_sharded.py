@@ -591,3 +591,61 @@ def test_synthetic_shards_local_ranks(gpu_ctx, kind, native):
         raise real[0]
     assert sum(t[2] for t in totals) == totals[0][0]
     assert [t[1] for t in totals] == [sum(x[2] for x in totals[:r]) for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world,flag", (("long-wrapped", 3, 0), ("long-wrapped", 2, "ranked"), ("small", 3, "serial"), ("wrapped", 3, "ranked")))
+def test_device_step_when_the_scan_ends_in_a_host_driven_tier(gpu_ctx, oracle, kind, world, flag):
+    """A scan whose result only exists after the host's wait -- the list-ranking tier and the one-wave walker are driven
+    from ffq_scan_wait; a context that has met long records goes straight there on its NEXT scans -- must not hand the
+    step the previous scan's result block: its words are "not ready" and gathered again (k_publish marks the block).
+    Three consecutive steps on the same shard objects; the second and third start in the ranking tier."""
+    from fastqandfurious_amd import hip, sharded
+    stream = make_stream(kind)
+    want, err = expected(oracle, stream)
+    assert err is None
+    t = torch.from_numpy(stream.copy()).cuda()
+    bounds = bounds_for(stream.size, world)
+    lw = sharded.LocalWorld(world)
+    flags = {0: 0, "ranked": hip.F_FORCE_RANKED, "serial": hip.F_FORCE_SERIAL}[flag]
+    results, errors = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            ctx = hip.Context(0)
+            sc = sharded.NativeShardScanner(ctx, bounds, rank, world, local_world=lw.native_world())
+            tail, head = sc.halo()
+            lo, hi = bounds[rank], bounds[rank + 1]
+            ext = torch.zeros(tail + (hi - lo) + head + 64, dtype=torch.uint8, device="cuda")
+            ext[tail:tail + hi - lo] = t[lo:hi]
+            table = torch.empty((stream.size // 40 + 64, 6), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            outs = []
+            for step in range(3):
+                table.fill_(-7)
+                torch.cuda.synchronize()
+                out = sc.scan(ext, tail, head, table, flags)
+                outs.append((out.res.path, out.rounds, out.record_base, table[out.row_lo:out.row_hi].cpu().numpy()))
+            results[rank] = outs
+            sc.close()
+            ctx.close()
+        except BaseException as e:   # noqa: BLE001
+            errors[rank] = e
+            lw.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    real = [e for e in errors if e is not None and "another logical rank failed" not in str(e)]
+    if real:
+        raise real[0]
+    for step in range(3):
+        got = np.concatenate([results[r][step][3] for r in range(world)])
+        assert got.shape == want.shape and (got == want).all(), "step %d: rows over the ranks differ from the oracle's" % step
+        assert [results[r][step][2] for r in range(world)] == [sum(results[q][step][3].shape[0] for q in range(r)) for r in range(world)]
+    if flag == "serial":
+        assert all(results[r][0][0] == 1 for r in range(world))
+    elif kind == "long-wrapped" or flag == "ranked":
+        assert any(results[r][2][0] == 5 for r in range(world)), "no rank's third scan took the ranking tier"
