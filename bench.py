@@ -411,6 +411,52 @@ def iterator_rates(ctx, sample_u8, n_gz, budget_s=3.0):
     return out
 
 
+def pushdown_rates(local_rank, dev, budget_s=3.0, nbytes=256 << 20, threshold=76):
+    """The user guide's length filter (/root/reference/doc/user-guide.rst:153-180) over S-wrapped reads (50-300 bases: a
+    threshold of 76 keeps ~10 %): M INPUT reads/s of the drop-in iterator with (a) the default entryfunc, nothing dropped,
+    (b) the guide's function as a plain Python entryfunc behind the GPU scanner (a call per record), (c)
+    entryfunc_lengthfilter(threshold): rows filtered and the kept sequences gathered on the device (ffq_stream_set_filter),
+    a dropped record = one None in a list.  One host core; never `value`."""
+    import tempfile
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C, hip, sharded
+    ctx = hip.Context(local_rank)
+    sh = sharded.SyntheticShard(ctx, "wrapped", nbytes, 0, 1, dev)
+    sample = sh.host_sample(nbytes)
+    del sh
+    ctx.close()
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(d, "ffq_pushdown_%d.fq" % os.getpid())
+    with open(path, "wb") as fh:
+        fh.write(sample.tobytes())
+
+    def guide(buf, posarray, globaloffset=None):
+        if posarray[3] - posarray[2] < threshold:
+            return buf[posarray[2]:posarray[3]]
+        return None
+
+    def rate(entryfunc):
+        n = kept = 0
+        t0 = time.perf_counter()
+        with open(path, "rb") as fh:
+            for e in F.readfastq_iter(fh, 1 << 24, entryfunc, C.entrypos):
+                n += 1
+                kept += e is not None
+                if (n & 0xFFFF) == 0 and time.perf_counter() - t0 > budget_s:
+                    break
+        return round(n / (time.perf_counter() - t0) / 1e6, 3), n, kept
+    try:
+        rate(F.entryfunc_lengthfilter(threshold))                  # (warm: pinned buffers, page cache)
+        a, b, c = rate(F.entryfunc), rate(guide), rate(F.entryfunc_lengthfilter(threshold))
+    finally:
+        os.unlink(path)
+    return {"unit": "M input reads/s", "cores": 1, "threshold": threshold, "kept_fraction": round(c[2] / max(c[1], 1), 4),
+            "unfiltered_entryfunc": a[0], "guide_function_per_record": b[0], "pushed_down": c[0],
+            "speedup_vs_unfiltered": round(c[0] / a[0], 2), "records_seen": c[1],
+            "what": "readfastq_iter over a %d-byte S-wrapped file in %s, GPU scanner: default entryfunc / the guide's "
+                    "lengthfilter_entryfunc called per record / entryfunc_lengthfilter(%d) with the filter and the sequence gather "
+                    "on the device" % (sample.size, d, threshold)}
+
+
 def pmc_traffic(workload, kernel="k_scan_lines<"):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this
     workload (profiles/*/pmc_fetch_write.json): FETCH_SIZE and WRITE_SIZE are KiB; on gfx950
@@ -887,6 +933,7 @@ def main():
             line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, shard.host_sample(1 << 30))
             line["host_inclusive"]["iterator"] = iterator_rates(ctx, sample, int(sample.size))
             del sample
+            line["host_inclusive"]["pushdown"] = pushdown_rates(local_rank, dev)
         elif not args.no_cpu_baseline:
             # N > 1: the same CPU legs beside the multi-GPU line, on rank 0's host cores with a 3 s budget each (the other
             # ranks wait at the next collective); north_star: "GB/s and reads/s at 1/2/4/8 GPUs reported next to the

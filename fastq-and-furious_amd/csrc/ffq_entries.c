@@ -152,7 +152,110 @@ done:
     return list;
 }
 
+/* sparse(n_total, index, col, coloff) -> list of n_total items: bytes(col[coloff[i] : coloff[i + 1]]) at position
+ * index[i], None everywhere else.  What an entryfunc that filters -- the reference's user guide,
+ * /root/reference/doc/user-guide.rst:153-180: `buf[posarray[2]:posarray[3]] if posarray[3] - posarray[2] < THRESHOLD else
+ * None` -- makes readfastq_iter yield for a whole buffer fill, from the stream's device-side selection (kept rows' ordinals)
+ * and gathered column: a dropped record costs one pointer in a list.
+ * sparse_entries(n_total, index, buf, rows, shift, cls=None): the same with the (header, sequence, quality) tuple of every
+ * kept row (rows: the KEPT rows, six int64 each).                                                                      */
+static PyObject *sparse(PyObject *self, PyObject *args)
+{
+    Py_buffer idx, col, off;
+    Py_ssize_t n_total = 0;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "ny*y*y*", &n_total, &idx, &col, &off)) return NULL;
+    PyObject *list = NULL;
+    const Py_ssize_t k = idx.len / 8;
+    if (n_total < 0 || idx.len % 8 != 0 || off.len < (k + 1) * 8) {
+        PyErr_SetString(PyExc_ValueError, "index must hold int64 ordinals and coloff one offset more");
+        goto done;
+    }
+    list = PyList_New(n_total);
+    if (!list) goto done;
+    for (Py_ssize_t i = 0; i < n_total; i++) { Py_INCREF(Py_None); PyList_SET_ITEM(list, i, Py_None); }
+    {
+        const int64_t *ix = (const int64_t *)idx.buf, *o = (const int64_t *)off.buf;
+        for (Py_ssize_t i = 0; i < k; i++) {
+            if (ix[i] < 0 || ix[i] >= n_total || o[i] < 0 || o[i + 1] < o[i] || o[i + 1] > (int64_t)col.len) {
+                PyErr_SetString(PyExc_ValueError, "selection does not fit the fill");
+                Py_CLEAR(list);
+                goto done;
+            }
+            PyObject *b = PyBytes_FromStringAndSize((const char *)col.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]));
+            if (!b) { Py_CLEAR(list); goto done; }
+            PyObject *old = PyList_GET_ITEM(list, (Py_ssize_t)ix[i]);
+            PyList_SET_ITEM(list, (Py_ssize_t)ix[i], b);
+            Py_DECREF(old);
+        }
+    }
+done:
+    PyBuffer_Release(&idx); PyBuffer_Release(&col); PyBuffer_Release(&off);
+    return list;
+}
+
+static PyObject *sparse_entries(PyObject *self, PyObject *args)
+{
+    Py_buffer idx, buf, rows;
+    Py_ssize_t n_total = 0;
+    long long shift = 0;
+    PyObject *cls = Py_None;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "ny*y*y*L|O", &n_total, &idx, &buf, &rows, &shift, &cls)) return NULL;
+    PyObject *list = NULL;
+    PyTypeObject *tp = &PyTuple_Type;
+    const Py_ssize_t k = idx.len / 8;
+    if (cls != Py_None) {
+        if (!PyType_Check(cls) || !PyType_IsSubtype((PyTypeObject *)cls, &PyTuple_Type) ||
+            ((PyTypeObject *)cls)->tp_basicsize != PyTuple_Type.tp_basicsize || ((PyTypeObject *)cls)->tp_itemsize != PyTuple_Type.tp_itemsize) {
+            PyErr_SetString(PyExc_TypeError, "cls must be a tuple subclass without fields of its own (a namedtuple)");
+            goto done;
+        }
+        tp = (PyTypeObject *)cls;
+    }
+    if (n_total < 0 || idx.len % 8 != 0 || rows.len != k * 48) {
+        PyErr_SetString(PyExc_ValueError, "index must hold one int64 ordinal per kept row, rows six int64 positions");
+        goto done;
+    }
+    list = PyList_New(n_total);
+    if (!list) goto done;
+    for (Py_ssize_t i = 0; i < n_total; i++) { Py_INCREF(Py_None); PyList_SET_ITEM(list, i, Py_None); }
+    {
+        const int64_t *ix = (const int64_t *)idx.buf, *p = (const int64_t *)rows.buf;
+        const char *base = (const char *)buf.buf;
+        for (Py_ssize_t i = 0; i < k; i++, p += 6) {
+            if (ix[i] < 0 || ix[i] >= n_total) {
+                PyErr_SetString(PyExc_ValueError, "selection does not fit the fill");
+                Py_CLEAR(list);
+                goto done;
+            }
+            PyObject *h = cut(base, buf.len, p[0] - shift + 1, p[1] - shift);
+            PyObject *q2 = cut(base, buf.len, p[2] - shift, p[3] - shift);
+            PyObject *q = cut(base, buf.len, p[4] - shift, p[5] - shift);
+            PyObject *t = !(h && q2 && q) ? NULL : (tp == &PyTuple_Type) ? PyTuple_New(3) : tp->tp_alloc(tp, 3);
+            if (!t) {
+                Py_XDECREF(h); Py_XDECREF(q2); Py_XDECREF(q);
+                Py_CLEAR(list);
+                goto done;
+            }
+            PyTuple_SET_ITEM(t, 0, h);
+            PyTuple_SET_ITEM(t, 1, q2);
+            PyTuple_SET_ITEM(t, 2, q);
+            PyObject *old = PyList_GET_ITEM(list, (Py_ssize_t)ix[i]);
+            PyList_SET_ITEM(list, (Py_ssize_t)ix[i], t);
+            Py_DECREF(old);
+        }
+    }
+done:
+    PyBuffer_Release(&idx); PyBuffer_Release(&buf); PyBuffer_Release(&rows);
+    return list;
+}
+
 static PyMethodDef methods[] = {
+    {"sparse", sparse, METH_VARARGS,
+     "sparse(n_total, index, col, coloff) -> list of n_total items: bytes of the gathered column at the kept rows' ordinals, None elsewhere"},
+    {"sparse_entries", sparse_entries, METH_VARARGS,
+     "sparse_entries(n_total, index, buf, rows, shift, cls=None) -> list of n_total items: (header, sequence, quality) at the kept rows' ordinals, None elsewhere"},
     {"entries_phred", entries_phred, METH_VARARGS,
      "entries_phred(buf, rows, shift, qual, qoff, array_type) -> list of (header, sequence, array('b') of decoded qualities)"},
     {"entries", entries, METH_VARARGS,

@@ -1719,8 +1719,18 @@ extern "C" int ffq_table_cut(ffq_ctx *c, const int64_t *d_table, int64_t n_rows,
     return FFQ_OK;
 }
 
+static int table_select(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t min_len, int64_t max_len, int64_t *d_out,
+                        int64_t *d_idx, int64_t *n_out);
+
 extern "C" int ffq_table_select_seqlen(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t min_len,
                                        int64_t max_len, int64_t *d_out, int64_t *n_out)
+{
+    return table_select(c, d_table, n_rows, min_len, max_len, d_out, nullptr, n_out);
+}
+
+// (d_idx, optional: the ordinal of every kept row -- the stream front end's push-down, ffq_stream_set_filter)
+static int table_select(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t min_len, int64_t max_len, int64_t *d_out,
+                        int64_t *d_idx, int64_t *n_out)
 {
     mark_other(c);
     if (!c || !n_out || n_rows < 0 || (n_rows > 0 && (!d_table || !d_out)))
@@ -1741,7 +1751,7 @@ extern "C" int ffq_table_select_seqlen(ffq_ctx *c, const int64_t *d_table, int64
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, st, (const unsigned int *)c->sel_cnt, nblk, c->sel_base,
                        (long long *)c->d_word);
     hipLaunchKernelGGL(k_sel_scatter, dim3((unsigned)nblk), dim3(256), 0, st, d_table, n_rows, min_len, max_len,
-                       (const long long *)c->sel_base, d_out);
+                       (const long long *)c->sel_base, d_out, d_idx);
     HIPCHK(hipMemcpyAsync(c->h_word, c->d_word, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));

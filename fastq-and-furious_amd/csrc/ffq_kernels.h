@@ -771,8 +771,10 @@ __global__ __launch_bounds__(1024) void k_scan_i64(const unsigned int *__restric
 
 __global__ __launch_bounds__(256) void k_sel_scatter(const int64_t *__restrict__ table, int64_t n, int64_t lo,
                                                      int64_t hi, const long long *__restrict__ bbase,
-                                                     int64_t *__restrict__ out)
+                                                     int64_t *__restrict__ out, int64_t *__restrict__ idx_out)
 {
+    // idx_out (optional): the ordinal in `table` of every kept row -- what a host that must hand back one item per
+    // ORIGINAL row (None for a dropped one, /root/reference/doc/user-guide.rst:166-170) puts the kept ones back by
     __shared__ uint32_t s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t i = (int64_t)blockIdx.x * 256 + tid;
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(256) void k_sel_scatter(const int64_t *__restrict__
     longlong2 *dst = reinterpret_cast<longlong2 *>(out + r * 6);
     const longlong2 a = src[0], b = src[1], c = src[2];
     dst[0] = a; dst[1] = b; dst[2] = c;
+    if (idx_out) idx_out[r] = i;
 }
 
 // =========================================================================

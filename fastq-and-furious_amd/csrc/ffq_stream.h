@@ -73,6 +73,13 @@ struct StreamBufs {
     int64_t qual_cap = 0;
     int64_t *dqoff = nullptr, *hqoff = nullptr;
     int64_t qoff_cap = 0;
+    // push-down (ffq_stream_set_filter): the kept rows and their ordinals, the gathered column
+    int64_t *dsel = nullptr, *didx = nullptr, *hidx = nullptr;
+    int64_t sel_cap = 0;
+    int8_t *dcol = nullptr, *hcol = nullptr;
+    int64_t col_cap = 0;
+    int64_t *dcoff = nullptr, *hcoff = nullptr;
+    int64_t coff_cap = 0;
     ReadPool *pool = nullptr;    // the context's helper threads (not owned)
 };
 
@@ -93,6 +100,10 @@ static void streambufs_free(StreamBufs *b)
     if (b->htab) (void)hipHostFree(b->htab);
     if (b->hqual) (void)hipHostFree(b->hqual);
     if (b->hqoff) (void)hipHostFree(b->hqoff);
+    if (b->hidx) (void)hipHostFree(b->hidx);
+    if (b->hcol) (void)hipHostFree(b->hcol);
+    if (b->hcoff) (void)hipHostFree(b->hcoff);
+    (void)hipFree(b->dsel); (void)hipFree(b->didx); (void)hipFree(b->dcol); (void)hipFree(b->dcoff);
     (void)hipFree(b->dtab); (void)hipFree(b->dqual); (void)hipFree(b->dqoff);
     for (auto &st : b->cs) if (st) (void)hipStreamDestroy(st);
     delete b;
@@ -310,6 +321,11 @@ struct ffq_stream {
     int64_t globaloffset = -1;          // readfastq_iter :242
     int64_t last_nq = 0;
     int last_path = -1;                 // ffq_scan_result.path of the last fill's scan
+    // push-down: rows by sequence length, one component of the kept rows (ffq_stream_set_filter)
+    bool filter_on = false;
+    int64_t f_min = 0, f_max = 0;
+    int f_col = 0, f_add = 0;
+    int64_t last_scanned = 0, last_kept = 0, last_col_bytes = 0;
     // FFQ_STREAM_PROF=1: where the time of a stream goes (printed when it closes)
     bool prof = false;
     double t_read = 0, t_slot = 0, t_feed = 0, t_scan = 0, t_rows = 0, t_copy = 0;
@@ -721,6 +737,39 @@ static int stream_alloc_tab(ffq_stream *s, int64_t rows)
     return FFQ_OK;
 }
 
+// device / pinned buffers of the push-down for a fill of up to `rows` rows (and `bytes` of column)
+static int stream_alloc_sel(ffq_stream *s, int64_t rows, int64_t bytes)
+{
+    StreamBufs *b = s->b;
+    if (rows > b->sel_cap) {
+        if (b->hidx) (void)hipHostFree(b->hidx);
+        (void)hipFree(b->dsel); (void)hipFree(b->didx);
+        b->hidx = nullptr; b->dsel = nullptr; b->didx = nullptr; b->sel_cap = 0;
+        if (hipMalloc((void **)&b->dsel, (size_t)rows * 48) != hipSuccess || hipMalloc((void **)&b->didx, (size_t)rows * 8) != hipSuccess ||
+            hipHostMalloc((void **)&b->hidx, (size_t)rows * 8, hipHostMallocDefault) != hipSuccess)
+            return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld selected rows", (long long)rows);
+        b->sel_cap = rows;
+    }
+    if (s->f_col && rows + 1 > b->coff_cap) {
+        if (b->hcoff) (void)hipHostFree(b->hcoff);
+        (void)hipFree(b->dcoff);
+        b->hcoff = nullptr; b->dcoff = nullptr; b->coff_cap = 0;
+        if (hipMalloc((void **)&b->dcoff, (size_t)(rows + 1) * 8) != hipSuccess ||
+            hipHostMalloc((void **)&b->hcoff, (size_t)(rows + 1) * 8, hipHostMallocDefault) != hipSuccess)
+            return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld column offsets", (long long)rows);
+        b->coff_cap = rows + 1;
+    }
+    if (s->f_col && bytes > b->col_cap) {
+        if (b->hcol) (void)hipHostFree(b->hcol);
+        (void)hipFree(b->dcol);
+        b->hcol = nullptr; b->dcol = nullptr; b->col_cap = 0;
+        if (hipMalloc((void **)&b->dcol, (size_t)bytes) != hipSuccess || hipHostMalloc((void **)&b->hcol, (size_t)bytes, hipHostMallocDefault) != hipSuccess)
+            return fail(FFQ_E_NOMEM, "ffq_stream: no memory for %lld column bytes", (long long)bytes);
+        b->col_cap = bytes;
+    }
+    return FFQ_OK;
+}
+
 static int stream_alloc_qual(ffq_stream *s, int64_t bytes)
 {
     StreamBufs *b = s->b;
@@ -961,6 +1010,36 @@ extern "C" int ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int6
     return FFQ_OK;
 }
 
+// Push-down into the stream (the reference's user guide, doc/user-guide.rst:153-180: an entryfunc that looks at the read's
+// length and builds one component of the entries it keeps): from the next fill on, ffq_stream_next hands back only the rows
+// with min_seq_len <= pos3 - pos2 <= max_seq_len, in order, and -- column != 0 -- that component of every kept row as a
+// packed stream (+ value_add: -33 on the quality is the Phred decode of the kept records only).
+extern "C" int ffq_stream_set_filter(ffq_stream *s, int64_t min_seq_len, int64_t max_seq_len, int column, int value_add)
+{
+    if (!s) return fail(FFQ_E_ARG, "ffq_stream_set_filter: NULL stream");
+    if (column < 0 || column > 3) return fail(FFQ_E_ARG, "ffq_stream_set_filter: column is FFQ_COL_NONE / _HEADER / _SEQUENCE / _QUALITY");
+    if (s->flags & FFQ_F_DECODE_QUAL) return fail(FFQ_E_ARG, "ffq_stream_set_filter: the stream decodes every record's qualities (FFQ_F_DECODE_QUAL); "
+                                                              "a filtered stream gathers the kept records' (column = FFQ_COL_QUALITY, value_add)");
+    s->filter_on = true;
+    s->f_min = min_seq_len; s->f_max = max_seq_len; s->f_col = column; s->f_add = value_add;
+    return FFQ_OK;
+}
+
+// What the filter did with the fill ffq_stream_next has just returned: h_index[i] = ordinal, among the n_scanned records of
+// the fill, of kept row i (the caller that owes its own caller one item per record puts the kept ones back by it); the
+// gathered column: bytes of kept row i = h_col[h_coloff[i] : h_coloff[i + 1]].  Pinned memory, valid until the next call.
+extern "C" int ffq_stream_selected(ffq_stream *s, const int64_t **h_index, int64_t *n_scanned, const int8_t **h_col,
+                                   const int64_t **h_coloff, int64_t *n_col_bytes)
+{
+    if (!s || !h_index || !n_scanned) return fail(FFQ_E_ARG, "ffq_stream_selected: NULL argument");
+    if (!s->filter_on) return fail(FFQ_E_ARG, "ffq_stream_selected: the stream has no filter (ffq_stream_set_filter)");
+    *h_index = s->b->hidx; *n_scanned = s->last_scanned;
+    if (h_col) *h_col = s->f_col ? s->b->hcol : nullptr;
+    if (h_coloff) *h_coloff = s->f_col ? s->b->hcoff : nullptr;
+    if (n_col_bytes) *n_col_bytes = s->last_col_bytes;
+    return FFQ_OK;
+}
+
 extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n_rows, int *end_state,
                                int64_t *err_offset, const uint8_t **h_bytes, int64_t *n_bytes,
                                int64_t *bytes_offset)
@@ -1048,7 +1127,35 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
     }
     if (rc != FFQ_OK) return rc;
     const double tp2 = s->prof ? stream_now() : 0;
-    if (res.n_records > 0)
+    int64_t n_out = res.n_records;
+    s->last_scanned = res.n_records; s->last_kept = res.n_records; s->last_col_bytes = 0;
+    if (s->filter_on) {
+        // ---- push-down: the fill's table is filtered (and one component of the kept rows gathered) on the DEVICE, before
+        // anything is copied back: a dropped record costs the host nothing (doc/user-guide.rst:153-180) -----------------
+        n_out = 0;
+        if (res.n_records > 0) {
+            int rc2 = stream_alloc_sel(s, res.n_records, len + 64);
+            if (rc2) return rc2;
+            rc2 = table_select(c, b->dtab, res.n_records, s->f_min, s->f_max, b->dsel, b->didx, &n_out);
+            if (rc2) return rc2;
+        }
+        s->last_kept = n_out;
+        if (n_out > 0) {
+            HIPCHK(hipMemcpyAsync(b->htab, b->dsel, (size_t)n_out * 48, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(b->hidx, b->didx, (size_t)n_out * 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (s->f_col && res.n_records > 0) {
+            static const int COLS[4][3] = {{0, 0, 0}, {0, 1, 1}, {2, 0, 3}, {4, 0, 5}};       // header: buf[pos0 + 1 : pos1] (:161-171)
+            int64_t nb = 0;
+            // rows are stream offsets: buffer coordinate = row - add, with add = globaloffset - mis as the scan was given
+            int rc2 = ffq_table_gather_column(c, sl.d + start - mis, len + mis, 0, s->globaloffset - mis, b->dsel, n_out, COLS[s->f_col][0],
+                                              COLS[s->f_col][1], COLS[s->f_col][2], s->f_add, b->dcol, b->col_cap, b->dcoff, &nb);
+            if (rc2) return rc2;
+            s->last_col_bytes = nb;
+            if (nb > 0) HIPCHK(hipMemcpyAsync(b->hcol, b->dcol, (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(b->hcoff, b->dcoff, (size_t)(n_out + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        }
+    } else if (res.n_records > 0)
         HIPCHK(hipMemcpyAsync(b->htab, b->dtab, (size_t)res.n_records * 48, hipMemcpyDeviceToHost, c->stream));
     s->last_nq = 0;
     s->last_path = res.path;
@@ -1065,7 +1172,7 @@ extern "C" int ffq_stream_next(ffq_stream *s, const int64_t **h_rows, int64_t *n
     s->handed_pos = sl.end_pos;
     s->fill_start = start; s->fill_len = len;
     *h_rows = b->htab;
-    *n_rows = res.n_records;
+    *n_rows = n_out;
     if (h_bytes) *h_bytes = sl.h + start;
     if (n_bytes) *n_bytes = len;
     // byte i of this fill is stream offset globaloffset + i (the sentinel of the first fill is -1)

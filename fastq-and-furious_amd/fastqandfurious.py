@@ -166,6 +166,55 @@ def entryfunc_phred(buf: bytes, pos, globaloffset: int):
     return (buf[(pos[0] + 1):pos[1]], buf[pos[2]:pos[3]], quality)
 
 
+class entryfunc_lengthfilter:
+    """The length filter of the reference's user guide (doc/user-guide.rst:153-180) as an entryfunc OBJECT:
+
+        LENGTH_THRESHOLD = 25
+        def lengthfilter_entryfunc(buf, posarray):
+            if posarray[3] - posarray[2] < LENGTH_THRESHOLD:
+                return buf[posarray[2]:posarray[3]]
+            else:
+                return None
+
+    is entryfunc_lengthfilter(25): called per record (any scanner; with or without the third argument the iterator
+    passes, :255) it does exactly that -- the sequence of a read SHORTER than the threshold, None for the others; the
+    iterator yields one item per record either way.  More generally min_len <= pos[3] - pos[2] <= max_len is kept
+    (the length is the byte length of the slice, as in the guide: a wrapped read counts its newlines), and `column`
+    says what is built for a kept record: "sequence" (the guide's), "header", "quality", or "entry" -- the (header,
+    sequence, quality) tuple of entryfunc.
+
+    readfastq_iter RECOGNISES the object when the scanner is the GPU one: the stream front end filters every buffer
+    fill's offset table on the device, gathers the one component of the kept rows there (ffq_stream_set_filter), and
+    copies back nothing of a dropped record -- for which the iterator then spends one None in a list instead of a
+    scanner call, an entryfunc call and three slices.  Same items, same order."""
+
+    def __init__(self, threshold=None, min_len=None, max_len=None, column="sequence"):
+        if column not in ("sequence", "header", "quality", "entry"):
+            raise ValueError("column must be 'sequence', 'header', 'quality' or 'entry'")
+        if threshold is not None:
+            if max_len is not None:
+                raise ValueError("threshold and max_len say the same thing")
+            max_len = int(threshold) - 1
+        self.min_len = None if min_len is None else int(min_len)
+        self.max_len = None if max_len is None else int(max_len)
+        self.column = column
+
+    def keeps(self, length):
+        return (self.min_len is None or length >= self.min_len) and (self.max_len is None or length <= self.max_len)
+
+    def __call__(self, buf, pos, globaloffset=None):
+        if not self.keeps(pos[3] - pos[2]):
+            return None
+        c = self.column
+        if c == "sequence":
+            return buf[pos[2]:pos[3]]
+        if c == "header":
+            return buf[(pos[0] + 1):pos[1]]
+        if c == "quality":
+            return buf[pos[4]:pos[5]]
+        return (buf[(pos[0] + 1):pos[1]], buf[pos[2]:pos[3]], buf[pos[4]:pos[5]])
+
+
 def entryfunc_abspos(buf: bytes, pos, globaloffset: int):
     """Absolute stream positions: pos[i] += globaloffset, in place; returns
     the same `pos` object (reference :186-195)."""
@@ -217,6 +266,30 @@ def _phred_entries(st, fill, rows, shift):
         yield (buf[p0 + 1:p1], buf[p2:p3], array('b', qb[offs[i]:offs[i] + p5 - p4]))
 
 
+def _filtered_items(st, flt, rows, fill, fill_offset):
+    """What readfastq_iter yields for one fill of a filtered stream: n_scanned items, None for the dropped records, the
+    filter's component for the kept ones (from the device's gathered column, or cut out of the fill for "entry")."""
+    idx, n_scanned, col, off = st.selected()
+    nat = _entries.native()
+    if n_scanned == 0:
+        return []
+    if flt.column == "entry":
+        if nat is not None and hasattr(nat, "sparse_entries"):
+            return nat.sparse_entries(n_scanned, memoryview(idx).cast('B'), fill, memoryview(rows).cast('B'), fill_offset)
+        out = [None] * n_scanned
+        buf = fill.tobytes()
+        for k, (p0, p1, p2, p3, p4, p5) in zip(idx.tolist(), (rows - fill_offset).tolist()):
+            out[k] = (buf[p0 + 1:p1], buf[p2:p3], buf[p4:p5])
+        return out
+    if nat is not None and hasattr(nat, "sparse"):
+        return nat.sparse(n_scanned, memoryview(idx).cast('B'), col, memoryview(off).cast('B'))
+    out = [None] * n_scanned
+    cb, o = col.tobytes(), off.tolist()
+    for j, k in enumerate(idx.tolist()):
+        out[k] = cb[o[j]:o[j + 1]]
+    return out
+
+
 def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
     """readfastq_iter with a batched scanner: one scan per buffer fill.
 
@@ -264,7 +337,10 @@ def _iter_stream(st, entryfunc):
     exactly what the reference's loop passes to entryfunc (:252-255), globaloffset included."""
     try:
         for rows, fill, fill_offset, end_state, err_offset in st:
-            if rows.shape[0] and entryfunc is entryfunc_phred and st.decode:
+            if st.filtered:
+                # the stream dropped rows on the device (entryfunc_lengthfilter): one item per scanned record all the same
+                yield from _filtered_items(st, entryfunc, rows, fill, fill_offset)
+            elif rows.shape[0] and entryfunc is entryfunc_phred and st.decode:
                 yield from _phred_entries(st, fill, rows, fill_offset)
             elif rows.shape[0] and (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
                 # the default entryfunc over the whole table, natively (csrc/ffq_entries.c): the slices
@@ -312,6 +388,9 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
         # the native stream front end: a real file, a gzip file, or anything with readinto() / read();
         # with entryfunc_phred the qualities of every fill are decoded on the device
         st = open_stream(fh, fbufsize, entryfunc is entryfunc_phred) if entryfunc is entryfunc_phred else open_stream(fh, fbufsize)
+        if st is not None and isinstance(entryfunc, entryfunc_lengthfilter):
+            # push-down: the filter runs on the device, on every fill's table, before anything is copied back
+            st.set_filter(entryfunc.min_len, entryfunc.max_len, None if entryfunc.column == "entry" else entryfunc.column)
         if st is not None:
             yield from _iter_stream(st, entryfunc)
             return

@@ -55,7 +55,7 @@ SYMBOLS = (
     "ffq_stream_push_buffer", "ffq_stream_push", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest", "ffq_shard_load_fd", "ffq_load_fd",
-    "ffq_shard_host_step", "ffq_shard_host_free",
+    "ffq_shard_host_step", "ffq_shard_host_free", "ffq_stream_set_filter", "ffq_stream_selected",
 )
 
 
@@ -279,6 +279,8 @@ def lib():
         L.ffq_shard_host_step.argtypes = [P(ShardHostOps), vp, i32, i32, P(i64), i64, i64, vp, vp, i64, P(ShardResult)]
         L.ffq_shard_host_free.argtypes = [vp]
         L.ffq_shard_host_free.restype = None
+        L.ffq_stream_set_filter.argtypes = [vp, i64, i64, i32, i32]
+        L.ffq_stream_selected.argtypes = [vp, P(vp), P(i64), P(vp), P(vp), P(i64)]
         L.ffq_stream_quals.argtypes = [vp, P(vp), P(vp), P(i64)]
         L.ffq_stream_close.restype = None
         L.ffq_synth_single.argtypes = [vp, vp, i64, i64, u64]
@@ -708,6 +710,7 @@ class _Stream:
     on_close = None        # called once, before the native stream goes away
     consumed = 0
     at_end = False
+    filtered = False
 
     def tell(self):
         """File position behind the last chunk handed out (-1: the source has none)."""
@@ -730,6 +733,32 @@ class _Stream:
                 else np.zeros(0, dtype=np.int8))
         qoff = np.ctypeslib.as_array((ctypes.c_int64 * (n + 1)).from_address(op.value))
         return qual, qoff
+
+    COLUMNS = {None: 0, "entry": 0, "header": 1, "sequence": 2, "quality": 3}
+
+    def set_filter(self, min_seq_len=None, max_seq_len=None, column=None, value_add=0):
+        """Push-down (ffq_stream_set_filter; doc/user-guide.rst:153-180): from the next fill on the iteration yields only the
+        rows with min_seq_len <= pos3 - pos2 <= max_seq_len; column = "header" | "sequence" | "quality": that component
+        of the kept rows is gathered on the device (selected())."""
+        lo = -(1 << 62) if min_seq_len is None else int(min_seq_len)
+        hi = (1 << 62) if max_seq_len is None else int(max_seq_len)
+        check(lib().ffq_stream_set_filter(self._h, lo, hi, self.COLUMNS[column], int(value_add)))
+        self.filtered = True
+
+    def selected(self):
+        """(index int64[kept], n_scanned, col int8[] or None, coloff int64[kept + 1] or None) of the fill the iteration has
+        just yielded: index[i] = ordinal of kept row i among the fill's n_scanned records; bytes of kept row i =
+        col[coloff[i] : coloff[i + 1]].  Views, valid until the next iteration step."""
+        ip, cp, op = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        ns, nb = ctypes.c_int64(), ctypes.c_int64()
+        check(lib().ffq_stream_selected(self._h, ctypes.byref(ip), ctypes.byref(ns), ctypes.byref(cp), ctypes.byref(op), ctypes.byref(nb)))
+        k = self._last_rows
+        idx = np.ctypeslib.as_array((ctypes.c_int64 * k).from_address(ip.value)) if k else np.zeros(0, dtype=np.int64)
+        col = off = None
+        if op.value:
+            off = np.ctypeslib.as_array((ctypes.c_int64 * (k + 1)).from_address(op.value))
+            col = np.ctypeslib.as_array((ctypes.c_int8 * nb.value).from_address(cp.value)) if nb.value else np.zeros(0, dtype=np.int8)
+        return idx, int(ns.value), col, off
 
     def close(self):
         if self._h:

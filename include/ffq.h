@@ -310,6 +310,24 @@ int  ffq_stream_open2(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags, in
 int  ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int64_t **h_qoff, int64_t *n_qual_bytes);
 int64_t ffq_stream_tell(ffq_stream *s);
 int  ffq_stream_path(ffq_stream *s);
+/* Push-down into the stream -- the reference's user guide (doc/user-guide.rst:153-180): an entryfunc that looks at the
+ * read's length and builds ONE component of the entries it keeps, `buf[posarray[2]:posarray[3]] if posarray[3] -
+ * posarray[2] < LENGTH_THRESHOLD else None`, so that a dropped record costs (nearly) nothing.  ffq_stream_set_filter
+ * (any kind of stream, before the first ffq_stream_next; not with FFQ_F_DECODE_QUAL): every fill's table is filtered on
+ * the DEVICE before anything is copied back -- ffq_stream_next then returns the rows with min_seq_len <= pos3 - pos2 <=
+ * max_seq_len only, in order -- and, column != FFQ_COL_NONE, that component of every kept row is gathered there into a
+ * packed stream (header as entryfunc cuts it, fastqandfurious.py:161-171: buf[pos0 + 1 : pos1]; + value_add per byte:
+ * -33 on the quality is the Phred decode of the kept records only).  ffq_stream_selected, for the fill just returned:
+ * h_index[i] = the ordinal of kept row i among the n_scanned records of the fill (a caller that owes one item per
+ * record -- the guide's loop sees None for a dropped one -- puts the kept ones back by it); bytes of kept row i =
+ * h_col[h_coloff[i] : h_coloff[i + 1]].  Pinned memory of the stream, valid until the next call.                     */
+#define FFQ_COL_NONE     0
+#define FFQ_COL_HEADER   1
+#define FFQ_COL_SEQUENCE 2
+#define FFQ_COL_QUALITY  3
+int  ffq_stream_set_filter(ffq_stream *s, int64_t min_seq_len, int64_t max_seq_len, int column, int value_add);
+int  ffq_stream_selected(ffq_stream *s, const int64_t **h_index, int64_t *n_scanned, const int8_t **h_col,
+                         const int64_t **h_coloff, int64_t *n_col_bytes);
 /* The same over a gzip-compressed file (what FORMAT_OPENERS['gz'] / automagic_open hand to
  * readfastq_iter, fastqandfurious.py:282-334): the stream's reader thread inflates (zlib; concatenated
  * members, zero padding behind the last one) straight into the pinned chunk buffers -- decompression

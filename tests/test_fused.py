@@ -174,7 +174,7 @@ def test_fused_in_byte_range_shards(gpu_ctx, hipmod, oracle, world):
     t = torch.from_numpy(stream.copy()).cuda()
     bounds = bounds_for(stream.size, world, 0, 48)
     make, made = _hip_backends(gpu_ctx)
-    res = run_local(t, bounds, make, decode=True, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS)
+    res = run_local(t, bounds, make, decode=True, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS, native=True)
     check_rows(res, bounds, want)
     base = 0
     for r in range(world):
