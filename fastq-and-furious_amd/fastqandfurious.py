@@ -186,9 +186,12 @@ class entryfunc_lengthfilter:
     readfastq_iter RECOGNISES the object when the scanner is the GPU one: the stream front end filters every buffer
     fill's offset table on the device, gathers the one component of the kept rows there (ffq_stream_set_filter), and
     copies back nothing of a dropped record -- for which the iterator then spends one None in a list instead of a
-    scanner call, an entryfunc call and three slices.  Same items, same order."""
+    scanner call, an entryfunc call and three slices.  Same items, same order.
 
-    def __init__(self, threshold=None, min_len=None, max_len=None, column="sequence"):
+    yield_dropped=False (an extension: the guide's loop skips the Nones itself, `if sequence is None: # do nothing`):
+    the iterator yields the kept records' items only -- a dropped record then never reaches the interpreter at all."""
+
+    def __init__(self, threshold=None, min_len=None, max_len=None, column="sequence", yield_dropped=True):
         if column not in ("sequence", "header", "quality", "entry"):
             raise ValueError("column must be 'sequence', 'header', 'quality' or 'entry'")
         if threshold is not None:
@@ -198,6 +201,7 @@ class entryfunc_lengthfilter:
         self.min_len = None if min_len is None else int(min_len)
         self.max_len = None if max_len is None else int(max_len)
         self.column = column
+        self.yield_dropped = bool(yield_dropped)
 
     def keeps(self, length):
         return (self.min_len is None or length >= self.min_len) and (self.max_len is None or length <= self.max_len)
@@ -266,13 +270,23 @@ def _phred_entries(st, fill, rows, shift):
         yield (buf[p0 + 1:p1], buf[p2:p3], array('b', qb[offs[i]:offs[i] + p5 - p4]))
 
 
+def _np_arange(k):
+    import numpy as np
+    return np.arange(k, dtype=np.int64)
+
+
 def _filtered_items(st, flt, rows, fill, fill_offset):
     """What readfastq_iter yields for one fill of a filtered stream: n_scanned items, None for the dropped records, the
     filter's component for the kept ones (from the device's gathered column, or cut out of the fill for "entry")."""
     idx, n_scanned, col, off = st.selected()
     nat = _entries.native()
+    k = int(idx.shape[0])
+    if not flt.yield_dropped:                   # the kept records' items only: as if every record had been kept
+        n_scanned, idx = k, _np_arange(k)
     if n_scanned == 0:
         return []
+    if k == 0:
+        return [None] * n_scanned
     if flt.column == "entry":
         if nat is not None and hasattr(nat, "sparse_entries"):
             return nat.sparse_entries(n_scanned, memoryview(idx).cast('B'), fill, memoryview(rows).cast('B'), fill_offset)
@@ -315,6 +329,11 @@ def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
             it = iter(rows)                      # the default entryfunc inlined (see _iter_stream)
             for p0, p1, p2, p3, p4, p5 in zip(it, it, it, it, it, it):
                 yield (buf[p0 + 1:p1], buf[p2:p3], buf[p4:p5])
+        elif isinstance(entryfunc, entryfunc_lengthfilter) and not entryfunc.yield_dropped:
+            for i in range(0, len(rows), 6):
+                e = entryfunc(buf, rows[i:i + 6], globaloffset)
+                if e is not None:
+                    yield e
         else:
             for i in range(0, len(rows), 6):
                 yield entryfunc(buf, rows[i:i + 6], globaloffset)
@@ -399,6 +418,11 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
         yield from _iter_batched(fh, fbufsize, entryfunc, scan_buffer)
         return
 
+    if isinstance(entryfunc, entryfunc_lengthfilter) and not entryfunc.yield_dropped:
+        # (the kept records only: the reference's loop below with the guide's `if sequence is None: # do nothing` folded in)
+        keep_all = entryfunc_lengthfilter(min_len=entryfunc.min_len, max_len=entryfunc.max_len, column=entryfunc.column)
+        yield from (e for e in readfastq_iter(fh, fbufsize, keep_all, entrypos) if e is not None)
+        return
     posbuffer = array('q', [-1, ] * 6)
     globaloffset = -1
     offset = 0

@@ -79,6 +79,9 @@ def check_all(F, lf, scanner, openers_for, bufsizes):
                 for c in ("header", "quality", "entry"):
                     got, err = run(F, opener, bufsizes[0], F.entryfunc_lengthfilter(int(th), column=c), scanner)
                     assert [enc(x) for x in got] == v["columns"][c], (fn, th, name, c)
+                    # yield_dropped=False: the kept records' items alone, in order
+                    got, err = run(F, opener, bufsizes[0], F.entryfunc_lengthfilter(int(th), column=c, yield_dropped=False), scanner)
+                    assert [enc(x) for x in got] == [x for x in v["columns"][c] if x is not None], (fn, th, name, c)
     for case, d in lf["edge"].items():
         data = bytes.fromhex(d["data"])
         for th, v in d["thresholds"].items():
@@ -96,6 +99,7 @@ def check_all(F, lf, scanner, openers_for, bufsizes):
                 got, err = run(F, opener, bufsizes[-1], F.entryfunc_lengthfilter(int(th)), scanner)
                 kept = [x for x in got if x is not None]
                 assert err is None and (len(got), len(kept), digest(got)) == (v["n"], v["kept"], v["sha256"]), (sname, th, name)
+                assert run(F, opener, bufsizes[-1], F.entryfunc_lengthfilter(int(th), yield_dropped=False), scanner) == (kept, None)
                 assert (enc(kept[0]) if kept else None, enc(kept[-1]) if kept else None) == (v["first_kept"], v["last_kept"])
             opener = openers_for(data, sname)[0][1]
             for c in ("header", "quality", "entry"):
