@@ -281,7 +281,9 @@ def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, b
         del piece
         if world > 1:
             dist.barrier()
-        comm = sharded.native_unique_id(dist, dev) if world > 1 else None
+        comm = None
+        if world > 1:       # RCCL between the ranks' GPUs; a dry run of several ranks on ONE GPU: the device step over gloo
+            comm = sharded.DistTransport(dist) if dry_gloo(dist) else sharded.native_unique_id(dist, dev)
         best = None
         for _ in range(3):
             sh = sharded.FileShard(ctx, path, rank, world, comm=comm)
@@ -295,7 +297,7 @@ def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, b
             sh.close()
             el = [t1 - t0, t2 - t1]
             if world > 1:                                   # (the slowest rank's load and step)
-                tt = torch.tensor(el, dtype=torch.float64, device=dev)
+                tt = torch.tensor(el, dtype=torch.float64, device="cpu" if dry_gloo(dist) else dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = [float(x) for x in tt.tolist()]
             if best is None or sum(el) < sum(best):
@@ -958,8 +960,10 @@ def main():
             del sample
         else:
             line["cpu_baseline"] = None
-    if not args.no_cpu_baseline and not dry_gloo(dist):
-        # file-backed byte-range shards (collective: every rank takes part; the line is rank 0's)
+    if not args.no_cpu_baseline and (world == 1 or dry_gloo(dist) or os.environ.get("FFQ_BENCH_SHARDED_FILE") == "1"):
+        # file-backed byte-range shards (collective: every rank takes part; the line is rank 0's).  On a real multi-GPU run
+        # only on request (FFQ_BENCH_SHARDED_FILE=1): it is a host-inclusive extra, and nothing that is not the metric
+        # should be able to hold up the ranks of the measured line
         sf = sharded_file(ctx, shard, rank, world, dev, dist)
         if rank == 0:
             line.setdefault("host_inclusive", {})

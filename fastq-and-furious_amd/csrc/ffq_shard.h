@@ -234,6 +234,52 @@ struct ShLocal : ShTransport {
     const char *name() const override { return "in-process"; }
 };
 
+// The caller's own transport under the DEVICE step (ffq_shard_create_hosted): ranks that cannot talk RCCL -- several
+// processes on ONE GPU (a dry run; RCCL refuses two ranks per device), a group over gloo or MPI.  Hand-offs are staged
+// through host memory (device -> host, the caller's exchange, host -> device), the words gathered by the caller's
+// allgather once this rank's are on the host.  Functional, not fast: file-backed shards hand off nothing and gather 64 bytes.
+struct ShHosted : ShTransport {
+    ffq_shard_host_ops ops{};
+    int exchange(const std::vector<ShPiece> &plan, const ShPtrFn &provide, const ShPtrFn &accept, hipStream_t st) override
+    {
+        std::vector<ffq_shard_piece> ps(plan.size());
+        std::vector<std::vector<uint8_t>> stage(plan.size());
+        hipError_t e = hipSuccess;
+        for (size_t i = 0; i < plan.size(); i++) {
+            const ShPiece &p = plan[i];
+            ps[i].src = p.src; ps[i].dst = p.dst; ps[i].a = p.a; ps[i].b = p.b; ps[i].ptr = nullptr;
+            if (p.src != rank && p.dst != rank) continue;
+            stage[i].resize((size_t)(p.b - p.a));
+            ps[i].ptr = stage[i].data();
+            if (p.src == rank && e == hipSuccess) e = hipMemcpyAsync(stage[i].data(), provide(p.a, p.b), (size_t)(p.b - p.a), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(FFQ_E_HIP, "ffq_shard: hand-off staging failed: %s", hipGetErrorString(e));
+        const int r = ops.exchange(ops.user, ps.data(), (int)ps.size());
+        if (r) return fail(r < 0 ? r : FFQ_E_INTERNAL, "ffq_shard: the exchange callback failed (%d)", r);
+        for (size_t i = 0; i < plan.size(); i++)
+            if (plan[i].dst == rank && e == hipSuccess)
+                e = hipMemcpyAsync(accept(plan[i].a, plan[i].b), stage[i].data(), stage[i].size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);            // (the staging buffers go away with this call)
+        if (e != hipSuccess) return fail(FFQ_E_HIP, "ffq_shard: hand-off staging failed: %s", hipGetErrorString(e));
+        return FFQ_OK;
+    }
+    int gather_enqueue(const int64_t *d_mine, int64_t *, int64_t *h_all, hipStream_t st) override
+    {
+        HIPCHK(hipMemcpyAsync(h_all + (size_t)rank * SH_WORDS, d_mine, SH_WORDS * 8, hipMemcpyDeviceToHost, st));
+        return FFQ_OK;
+    }
+    int gather_finish(int64_t *h_all, hipEvent_t done) override
+    {
+        HIPCHK(hipEventSynchronize(done));
+        int64_t mine[SH_WORDS];
+        memcpy(mine, h_all + (size_t)rank * SH_WORDS, sizeof mine);
+        const int r = ops.allgather(ops.user, mine, h_all);
+        return r ? fail(r < 0 ? r : FFQ_E_INTERNAL, "ffq_shard: the gather callback failed (%d)", r) : FFQ_OK;
+    }
+    const char *name() const override { return "hosted"; }
+};
+
 }  // namespace ffq
 
 using namespace ffq;
@@ -408,6 +454,26 @@ extern "C" int ffq_shard_create_local(ffq_ctx *c, ffq_shard_world *w, int rank, 
     if (!rc) {
         ShLocal *t = new (std::nothrow) ShLocal();
         if (t) { t->W = w; t->rank = rank; t->world = w->world; }
+        s->tr = t;
+        if (!t) rc = fail(FFQ_E_NOMEM, "out of host memory");
+    }
+    if (rc) { ffq_shard_destroy(s); return rc; }
+    *out = s;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_shard_create_hosted(ffq_ctx *c, const ffq_shard_host_ops *ops, int rank, int world, const int64_t *bounds,
+                                       int64_t tail_bytes, int64_t head_bytes, ffq_shard **out)
+{
+    if (!ops || !ops->allgather || (world > 1 && !ops->exchange)) return fail(FFQ_E_ARG, "ffq_shard_create_hosted: NULL callback");
+    int rc = shard_common(c, rank, world, bounds, tail_bytes, head_bytes, out);
+    if (rc) return rc;
+    ffq_shard *s = *out;
+    *out = nullptr;
+    rc = shard_alloc(s);
+    if (!rc) {
+        ShHosted *t = new (std::nothrow) ShHosted();
+        if (t) { t->ops = *ops; t->rank = rank; t->world = world; }
         s->tr = t;
         if (!t) rc = fail(FFQ_E_NOMEM, "out of host memory");
     }

@@ -56,6 +56,7 @@ SYMBOLS = (
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest", "ffq_shard_load_fd", "ffq_load_fd",
     "ffq_shard_host_step", "ffq_shard_host_free", "ffq_stream_set_filter", "ffq_stream_selected",
+    "ffq_shard_create_hosted",
 )
 
 
@@ -277,6 +278,7 @@ def lib():
         L.ffq_shard_load_fd.argtypes = [vp, i32, vp, P(i64)]
         L.ffq_load_fd.argtypes = [vp, i32, i64, i64, vp, P(i64)]
         L.ffq_shard_host_step.argtypes = [P(ShardHostOps), vp, i32, i32, P(i64), i64, i64, vp, vp, i64, P(ShardResult)]
+        L.ffq_shard_create_hosted.argtypes = [vp, P(ShardHostOps), i32, i32, P(i64), i64, i64, P(vp)]
         L.ffq_shard_host_free.argtypes = [vp]
         L.ffq_shard_host_free.restype = None
         L.ffq_stream_set_filter.argtypes = [vp, i64, i64, i32, i32]
@@ -635,12 +637,41 @@ class Shard:
     """One rank's byte-range shard of a stream, the whole step behind the C ABI (ffq_shard_*, include/ffq.h): halo
     hand-off over RCCL (or the in-process transport), scan, cut, one gather of the hand-off words."""
 
-    def __init__(self, ctx, bounds, rank, world, tail_bytes, head_bytes, unique_id=None, local_world=None, parent=None):
+    def __init__(self, ctx, bounds, rank, world, tail_bytes, head_bytes, unique_id=None, local_world=None, parent=None, hosted=None):
+        """unique_id: RCCL between processes; local_world: a ShardWorld (threads of this process); hosted: a transport object
+        with exchange(pieces) / allgather(words) as shard_host_step takes them -- the device step over the caller's own
+        transport (ffq_shard_create_hosted: several processes on one GPU, a group over gloo)."""
         self._ctx = ctx
         self._h = ctypes.c_void_p()
         self._keep = (local_world, parent)
+        self._err = []
         b = (ctypes.c_int64 * (world + 1))(*[int(x) for x in bounds])
-        if parent is not None:
+        if hosted is not None:
+            err = self._err
+
+            def c_exchange(_user, pieces, n):
+                try:
+                    hosted.exchange([(pieces[i].src, pieces[i].dst, pieces[i].a, pieces[i].b, pieces[i].ptr) for i in range(n)])
+                    return 0
+                except BaseException as e:      # noqa: BLE001
+                    err.append(e)
+                    return E_INTERNAL
+
+            def c_gather(_user, mine, out):
+                try:
+                    allv = hosted.allgather([mine[i] for i in range(8)])
+                    for r in range(world):
+                        for k in range(8):
+                            out[r * 8 + k] = int(allv[r][k])
+                    return 0
+                except BaseException as e:      # noqa: BLE001
+                    err.append(e)
+                    return E_INTERNAL
+            ops = ShardHostOps(None, _SCAN_CB(), _EXCHANGE_CB(c_exchange), _GATHER_CB(c_gather))
+            self._keep = (ops, hosted)                     # (the callbacks live as long as the shard)
+            check(lib().ffq_shard_create_hosted(ctx.handle, ctypes.byref(ops), int(rank), int(world), b, int(tail_bytes), int(head_bytes),
+                                                ctypes.byref(self._h)))
+        elif parent is not None:
             check(lib().ffq_shard_create_lane(parent._h, ctx.handle, ctypes.byref(self._h)))
         elif local_world is not None:
             check(lib().ffq_shard_create_local(ctx.handle, local_world._h, int(rank), b, int(tail_bytes), int(head_bytes),
@@ -685,6 +716,8 @@ class Shard:
     def step_wait(self):
         res = ShardResult()
         rc = lib().ffq_shard_step_wait(self._h, ctypes.byref(res))
+        if self._err:                                   # (an exception inside a hosted transport's callback)
+            raise self._err.pop(0)
         check(rc, allow=(E_TABLE_FULL,))
         return rc, res
 

@@ -287,13 +287,14 @@ class NativeShardScanner:
     transport --, scan, cut and the gather of the hand-off words queued by ONE call, one read-back per step)."""
 
     def __init__(self, ctx, bounds, rank, world, tail_bytes=TAIL_BYTES, head_bytes=HEAD_BYTES, unique_id=None,
-                 local_world=None, parent=None):
+                 local_world=None, parent=None, hosted=None):
         self.ctx, self.bounds, self.rank, self.world = ctx, list(bounds), rank, world
         self.tail_bytes, self.head_bytes = tail_bytes, head_bytes
         if parent is not None:
             self.sh = parent.sh.lane(ctx)
         else:
-            self.sh = _hip.Shard(ctx, bounds, rank, world, tail_bytes, head_bytes, unique_id=unique_id, local_world=local_world)
+            self.sh = _hip.Shard(ctx, bounds, rank, world, tail_bytes, head_bytes, unique_id=unique_id, local_world=local_world,
+                                 hosted=hosted)
         self._pending = None
 
     def lane(self, ctx):
@@ -335,7 +336,8 @@ class FileShard:
     look-ahead that must grow is read from the file).  No torch: device memory comes from the context.
 
     comm: how the ranks find each other -- a hip.ShardWorld (k logical ranks as threads of one process), 128 bytes of
-    communicator id (ffq_shard_unique_id, handed round by the caller), or None: a world of one needs nothing, a larger
+    communicator id (ffq_shard_unique_id, handed round by the caller), a transport object with exchange / allgather
+    (DistTransport over gloo: several processes that cannot talk RCCL, e.g. sharing one GPU), or None: a world of one needs nothing, a larger
     one takes torch.distributed's default process group (any backend) to hand the id round; the steps themselves
     are RCCL.  start / end: the part of the file that is the stream (offsets in every row are FILE offsets; the
     default cut points are shard_bounds' -- 16-byte aligned, even shares --, bounds= names others)."""
@@ -359,6 +361,10 @@ class FileShard:
             self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, local_world=comm)
         elif isinstance(comm, (bytes, bytearray)):
             self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, unique_id=bytes(comm))
+        elif comm is not None and hasattr(comm, "allgather") and hasattr(comm, "exchange"):
+            # a transport of the host step's kind (DistTransport over gloo, ...): the device step over it (file-backed
+            # shards hand off nothing: 64 bytes of words per rank and step go through it)
+            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, hosted=comm)
         elif world == 1:
             self._world_obj = _hip.ShardWorld(1)
             self.sh = _hip.Shard(ctx, self.bounds, 0, 1, tail_bytes, head_bytes, local_world=self._world_obj)

@@ -497,6 +497,13 @@ typedef struct ffq_shard_host_ops {
     int (*exchange)(void *user, const ffq_shard_piece *pieces, int n_pieces);
     int (*allgather)(void *user, const int64_t *mine, int64_t *all);
 } ffq_shard_host_ops;
+/* ... and the DEVICE step (ffq_shard_step_*: buffers in HBM, the scan and the words on the device) over the caller's
+ * transport: hand-offs staged through host memory around ops->exchange, the words gathered by ops->allgather (ops->scan is
+ * not used; the callbacks and `user` must stay valid while the shard lives).  ffq_shard_transport says "hosted".  For ranks
+ * that cannot talk RCCL -- several processes sharing ONE GPU, a group over gloo / MPI; with file-backed shards
+ * (ffq_shard_load_fd) the only traffic is the 64 bytes of words per rank.                                            */
+int  ffq_shard_create_hosted(ffq_ctx *ctx, const ffq_shard_host_ops *ops, int rank, int world, const int64_t *bounds,
+                             int64_t tail_bytes, int64_t head_bytes, ffq_shard **out);
 int  ffq_shard_host_step(const ffq_shard_host_ops *ops, ffq_ctx *ctx, int rank, int world, const int64_t *bounds,
                          int64_t tail_bytes, int64_t head_bytes, uint8_t *h_ext, int64_t *h_table, int64_t table_cap,
                          ffq_shard_result *out);

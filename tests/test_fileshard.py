@@ -304,3 +304,64 @@ def test_load_fd_and_short_file(gpu_ctx, shm_file):
             sh.load()
     finally:
         sh.close()
+
+
+@pytest.mark.parametrize("kind,world", (("wrapped", 3), ("long", 2), ("tricky", 8), ("small", 5)))
+def test_device_step_over_a_hosted_transport(gpu_ctx, oracle, shm_file, kind, world):
+    """ffq_shard_create_hosted: the device step (buffers in HBM, scan and words on the device) over the caller's own
+    transport -- here the thread transport of the host step, as DistTransport over gloo would be for several processes
+    sharing one GPU: hand-offs staged through host memory, the words gathered by the callback.  With halos handed off
+    (a resident buffer) and with a file behind every rank (nothing handed off)."""
+    import torch
+    from fastqandfurious_amd import hip, sharded
+    from test_sharded import bounds_for
+    stream = make_stream(kind)
+    want, err = expected(oracle, stream)
+    assert err is None
+    bounds = bounds_for(stream.size, world)
+    lw = sharded.LocalWorld(world)
+    path = shm_file(stream)
+    t = torch.from_numpy(stream.copy()).cuda()
+    results, errors = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            ctx = hip.Context(0)
+            sc = sharded.NativeShardScanner(ctx, bounds, rank, world, hosted=lw.transport(rank))
+            assert sc.sh.transport() == "hosted"
+            tail, head = sc.halo()
+            lo, hi = bounds[rank], bounds[rank + 1]
+            ext = torch.zeros(tail + (hi - lo) + head + 64, dtype=torch.uint8, device="cuda")
+            ext[tail:tail + hi - lo] = t[lo:hi]
+            table = torch.empty((stream.size // 40 + 64, 6), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            out = sc.scan(ext, tail, head, table)
+            rows = table[out.row_lo:out.row_hi].cpu().numpy()
+            assert world == 1 or stream.size < 64 * world or out.comm["handoff_bytes"] > 0
+            sc.close()
+            fs = sharded.FileShard(ctx, path, rank, world, comm=lw.transport(rank), bounds=bounds)
+            fs.load()
+            res = fs.scan()
+            assert fs.sh.transport() == "hosted" and res.halo_source == 1 and res.handoff_bytes == 0
+            frows = fs.rows()
+            fs.close()
+            ctx.close()
+            results[rank] = (rows, frows, out.record_base, int(res.record_base), out.rounds, int(res.rounds))
+        except BaseException as e:   # noqa: BLE001
+            errors[rank] = e
+            lw.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    real = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if real:
+        raise real[0]
+    for k in (0, 1):
+        got = np.concatenate([r[k] for r in results])
+        assert got.shape == want.shape and (got == want).all()
+        assert [r[2 + k] for r in results] == [sum(q[k].shape[0] for q in results[:i]) for i in range(world)]
+    if kind in ("long", "tricky"):
+        assert any(r[4] > 0 for r in results) and any(r[5] > 0 for r in results)
