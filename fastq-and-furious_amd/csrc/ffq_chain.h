@@ -64,6 +64,12 @@ constexpr int RES_BLOCK = 1024;            // groups per k_resolve_a workgroup
 constexpr int DCHUNK = 8192;               // records per chunk of the walked groups' stage (64 KiB of 8-byte records)
 
 struct StageRec { uint32_t p0, p1, p3, p4; };     // relative to the group's window origin
+// The lean kernel's groups (ffq_lite.h) stage HALF of that: every record it takes starts in the four own tiles (64 KiB) and
+// its call spans less than a tile, so pos0 fits 16 bits counted from the own tiles' first byte and pos1 / pos3 / pos4 fit 16
+// bits counted from pos0 -- 8 bytes per record written by k_chain_lite and read back by k_expand instead of 16 (flag bit 4
+// of the group says which layout its stage holds; a repair pass or the general kernel rewrites both)
+struct StageRec8 { uint16_t d0, d1, d3, d4; };     // pos0 - (window origin + TILE + sentinel shift + 1); pos1 / pos3 / pos4 - pos0
+constexpr uint32_t FLAG_STAGE8 = 16u;
 
 struct GroupTerm {
     int64_t pos[6];
@@ -1011,6 +1017,9 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave_list(LineIndex L, const
 {
     const int wid = threadIdx.x >> 6;
     const uint32_t nl = *B.dcnt;
+    // (the verification's minima start at their fill value: set here, behind the lean kernel and in front of k_resolve_a,
+    // instead of by a 16-byte fill of its own between two kernels)
+    if (blockIdx.x == 0 && threadIdx.x < 4) B.mins[threadIdx.x] = 0x7F7F7F7F;
     for (uint32_t i = blockIdx.x * WPB + wid; i < nl; i += gridDim.x * WPB)
         chain_wave_group<PER, EMAX, WPB, DOUBLING>(L, Lg, offset, eof, B, (int)B.dlist[i], 3, 0);
 }
@@ -1156,7 +1165,7 @@ __global__ __launch_bounds__(1024) void k_resolve_b(ChainBufs B, int nblk, int e
 __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__restrict__ res, int64_t add,
                                                int64_t *__restrict__ table, int64_t table_cap,
                                                int64_t *__restrict__ qoff, int64_t *__restrict__ qdir,
-                                               int64_t qdir_cap, int64_t *__restrict__ p4s, int64_t p4_cap)
+                                               int64_t qdir_cap, int64_t *__restrict__ p4s, int64_t p4_cap, int sshift)
 {
     __shared__ __attribute__((aligned(16))) int64_t s_rows[64 * 6];
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -1169,12 +1178,21 @@ __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__rest
     const int64_t base = ((int64_t)((own0 > 0) ? own0 - 1 : 0) << TILE_SHIFT) + add;
     const int32_t sb = B.sbase[g];
     const StageRec *st = sb <= 0 ? B.stage + (int64_t)g * B.nmax : B.dstage + (int64_t)(sb - 1) * DCHUNK;
+    const bool stage8 = (B.flags[g] & FLAG_STAGE8) != 0;              // (the lean kernel's 8-byte records: wave-uniform)
+    const int64_t base8 = base + TILE + sshift + 1;
     for (uint32_t d0 = 0; d0 < cnt; d0 += 64) {
         const uint32_t dd = d0 + lane;
         const bool ok = dd < cnt;
-        StageRec r = {0, 0, 0, 0};
-        if (ok) r = st[dd];
-        const int64_t p0 = base + r.p0, p1 = base + r.p1, p3 = base + r.p3, p4 = base + r.p4;
+        int64_t p0, p1, p3, p4;
+        if (stage8) {
+            uint2 w = make_uint2(0u, 0u);
+            if (ok) w = reinterpret_cast<const uint2 *>(st)[dd];
+            p0 = base8 + (w.x & 0xFFFFu); p1 = p0 + (w.x >> 16); p3 = p0 + (w.y & 0xFFFFu); p4 = p0 + (w.y >> 16);
+        } else {
+            StageRec r = {0, 0, 0, 0};
+            if (ok) r = st[dd];
+            p0 = base + r.p0; p1 = base + r.p1; p3 = base + r.p3; p4 = base + r.p4;
+        }
         const int64_t p5 = p4 + p3 - p1 - 1;
         if (qoff) {
             const uint32_t ql = ok ? (uint32_t)(p5 - p4) : 0u;

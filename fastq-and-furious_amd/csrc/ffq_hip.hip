@@ -653,19 +653,19 @@ static int poll_seq(ffq_ctx *c, unsigned long long want)
 }
 
 // verification + scan of the group counts, rows, result block (publishes) [-> decode]
-static int enqueue_resolve(ffq_ctx *c, const ScanArgs &a, const ChainBufs &cb, bool timed)
+static int enqueue_resolve(ffq_ctx *c, const ScanArgs &a, const ChainBufs &cb, bool timed, bool mins_set = false)
 {
     const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
     int64_t *qoff = decode ? a.d_qoff : nullptr;
     hipStream_t sA = c->stream;
     const int ngroups = cb.ng;
     const int nblk = (ngroups + RES_BLOCK - 1) / RES_BLOCK;
-    HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sA));
+    if (!mins_set) HIPCHK(hipMemsetAsync(cb.mins, 0x7F, 16, sA));       // (the list kernel of the lean path sets them itself)
     hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sA, cb);
     hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sA, cb, nblk, a.eof, a.offset, a.add, c->dres);
     hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sA, cb, (const DevRes *)c->dres, a.add, a.d_table,
                        a.table_cap, qoff, c->qdir, c->qdir_cap, qoff ? c->p4s : (int64_t *)nullptr,
-                       qoff ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0);
+                       qoff ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0, a.s);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sA, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff,
                        make_pub(c));
     c->ctl_clean = true;
@@ -740,18 +740,11 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
         // so that their one-wave latency (30 us) runs under it (all three read the same finished line index and write different
         // groups' summaries)
         const int gl = lite_first_end_group(a.n_bytes, L.ntiles, ngroups);
-        // (order: the first small launch is an ordinary one -- the command processor waits for the index kernel there --, the
-        // second one and the lean kernel follow without a barrier: a barrier-free packet BEHIND the lean kernel's would only
-        // be looked at once that kernel's last workgroup has been dispatched, i.e. at its end)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>), dim3(1), dim3(WPB_FAST * 64), 0, sA,
-                           L, (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, 1, 0, 0);
-        if (gl < ngroups)
-            hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
-                                  dim3((ngroups - gl + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, nullptr, nullptr,
-                                  hipExtAnyOrderLaunch, L, (const LineIndex *)c->d_L, a.offset, a.eof, cb, gl, ngroups, 0, 0);
-        hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lite<WPB_LITE>), dim3((ngroups + WPB_LITE - 1) / WPB_LITE), dim3(WPB_LITE * 64), 0, sA,
-                              nullptr, nullptr, hipExtAnyOrderLaunch, L, a.offset, cb, ngroups, gl,
-                              (PROBES && getenv("FFQ_LITE_ABLATE")) ? atoi(getenv("FFQ_LITE_ABLATE")) : 0);
+        // (round 5: those groups go onto the lean kernel's list of declined groups and are run by the list kernel behind
+        // it with whatever else was declined -- one launch of one-wave latency instead of three, and none in FRONT of the lean
+        // kernel, where round 4's ordinary launch of the first group held the whole GPU for 29 us)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_lite<WPB_LITE>), dim3((ngroups + WPB_LITE - 1) / WPB_LITE), dim3(WPB_LITE * 64), 0, sA,
+                           L, a.offset, cb, ngroups, gl, (PROBES && getenv("FFQ_LITE_ABLATE")) ? atoi(getenv("FFQ_LITE_ABLATE")) : 0);
     }
     if (lite)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave_list<PER_FAST, EMAX_FAST, WPB_FAST, false>),
@@ -769,7 +762,7 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     if (ablate == 0)
         hipLaunchKernelGGL(k_dense_walk, dim3((unsigned)std::min((ngroups + 3) / 4, 1024)), dim3(256), 0, sA, L, cb, a.offset, a.eof, 1,
                            dense_cfg ? 1 : 0, c->ctl, 1);
-    return enqueue_resolve(c, a, cb, timed);
+    return enqueue_resolve(c, a, cb, timed, lite);
 }
 
 // front of a scan: everything on ONE in-order stream (the context's), no host synchronisation

@@ -71,8 +71,10 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     // not the first group (sentinel, search offset), not the last ones (every position of the window lies at least four
     // bytes in front of the buffer's end: none of the scanner's buffer-end rules can apply), the search offset in front
     // of the run-in tail (every "\n@" there is a candidate)
-    // (the first group and those from gl on -- lite_first_end_group -- are k_chain_wave's by a launch of their own, beside this one)
-    if (g == 0 || g >= gl) return;
+    // (the first group and those from gl on -- lite_first_end_group -- are k_chain_wave's: on the list of declined groups
+    // with the rest; round 4 gave them two launches of their own in front of this kernel, the first of which -- an ordinary
+    // launch, one workgroup, 29 us -- ran with the GPU otherwise idle)
+    if (g == 0 || g >= gl) { if (lane == 0) lite_decline(B, g, 0); return; }
     bool ok = own1 + 1 <= L.ntiles && (((int64_t)(wt0 + OWN_T + 2) << TILE_SHIFT) + L.s + 4 < L.len()) &&
               offset <= wpos0 + L.s + (TILE - RUNIN_BYTES);
     if (!ok) { if (lane == 0) lite_decline(B, g, 0); return; }
@@ -306,14 +308,12 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
             const int k = (int)(kreg[u] & 0x7FFu);
             const int mi = (int)((infr[u] >> 12) & 15u);
             const uint32_t r0 = raw[k];
-            const uint32_t base = (((kreg[u] >> 11) & 7u) << TILE_SHIFT) + (uint32_t)L.s + (r0 & TM);
-            StageRec o;
-            o.p0 = base + 1u;
-            o.p1 = base + ((raw[k + 1] - r0) & TM);
-            o.p3 = base + ((raw[k + mi] - r0) & TM);
-            o.p4 = base + ((raw[k + mi + 1] - r0) & TM) + 1u;
-            stg[nbase + (uint32_t)bits_below_lane(OWN[u])] = o;
-            qsum += o.p3 - o.p1 - 1u;
+            // 8 bytes per record (StageRec8): pos0 counted from the own tiles' first byte -- the node lies in one of them,
+            // window tile 1 .. OWN_T --, pos1 / pos3 / pos4 from pos0 (a call spans less than a tile)
+            const uint32_t d0 = ((((kreg[u] >> 11) & 7u) - 1u) << TILE_SHIFT) + (r0 & TM);
+            const uint32_t d1 = ((raw[k + 1] - r0) & TM) - 1u, d3 = ((raw[k + mi] - r0) & TM) - 1u, d4 = (raw[k + mi + 1] - r0) & TM;
+            reinterpret_cast<uint2 *>(stg)[nbase + (uint32_t)bits_below_lane(OWN[u])] = make_uint2(d0 | (d1 << 16), d3 | (d4 << 16));
+            qsum += d3 - d1 - 1u;
         }
         if (Y == Y_UNRES)
             Y = wpos0 + (int64_t)node_pos((uint32_t)__builtin_amdgcn_readlane((int)kreg[u], __ffsll((long long)OWN[u]) - 1));
@@ -326,6 +326,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_lite(LineIndex L, int64_t of
     const uint32_t qtot = wave_sum_u32(qsum);                 // (a group's qualities are < 2^17 bytes)
     if (lane == 0) {
         B.y[g] = Y; B.exit[g] = EX; B.cnt[g] = ntot; B.qb[g] = (int64_t)qtot; B.lines[g] = lines;
+        B.flags[g] = FLAG_STAGE8;
     }
 }
 
