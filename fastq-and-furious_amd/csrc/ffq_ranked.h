@@ -59,12 +59,30 @@ __device__ __forceinline__ uint32_t rk_entry(const LineIndex &L, int t, uint32_t
     return (c <= (uint32_t)SLOT) ? (uint32_t)L.ent[(int64_t)t * SLOT + j] : L.pooled(t, j);
 }
 
+// the FL_AT bits of entries j .. j + 3 of a tile that fits its slot (j a multiple of 4: one 8-byte load), as bits 0 .. 3
+__device__ __forceinline__ uint32_t rk_at4(const LineIndex &L, int t, uint32_t j)
+{
+    static_assert(FL_AT == 1, "the '@' flag is bit 14 of an entry");
+    const uint2 w = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)t * SLOT + j);
+    return ((w.x >> 14) & 1u) | ((w.x >> 29) & 2u) | (((w.y >> 14) & 1u) << 2) | (((w.y >> 30) & 1u) << 3);
+}
+
 // AT entries among entries [0, upto) of tile t (wave-uniform)
 __device__ __forceinline__ uint32_t rk_count_at(const LineIndex &L, int t, uint32_t upto)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t c = L.cnt[t];
     uint32_t n = 0;
+    if (c <= (uint32_t)SLOT) {
+        // four entries per lane: a tile of 80-column lines (~200 entries) is ONE memory round trip instead of four
+        for (uint32_t j0 = 0; j0 < upto; j0 += 256) {
+            const uint32_t j = j0 + 4u * (uint32_t)lane;
+            uint32_t m = (j < upto) ? rk_at4(L, t, j) : 0u;
+            if (j + 4u > upto) m &= (1u << (upto > j ? upto - j : 0u)) - 1u;
+            n += (uint32_t)__popc(m);
+        }
+        return wave_sum_u32(n);
+    }
     for (uint32_t j0 = 0; j0 < upto; j0 += 64) {
         const uint32_t j = j0 + lane;
         const bool at = j < upto && ((rk_entry(L, t, c, j) >> 14) & FL_AT);
@@ -92,6 +110,24 @@ __global__ __launch_bounds__(256) void k_rk_list(LineIndex L, RankBufs R)
         base = 1;
     }
     const uint32_t c = L.cnt[t];
+    if (c <= (uint32_t)SLOT) {
+        for (uint32_t j0 = 0; j0 < c; j0 += 256) {
+            const uint32_t j = j0 + 4u * (uint32_t)lane;
+            uint32_t m = (j < c) ? rk_at4(L, t, j) : 0u;
+            if (j + 4u > c) m &= (1u << (c > j ? c - j : 0u)) - 1u;
+            const uint32_t k = (uint32_t)__popc(m);
+            const uint32_t incl = wave_incl_scan(k);
+            long long o = base + (long long)(incl - k);
+            while (m) {
+                const int q = __ffs((int)m) - 1;
+                m &= m - 1u;
+                if (o < R.nc) R.cand[o] = H{t, (int32_t)(j + (uint32_t)q)};
+                o++;
+            }
+            base += (long long)(uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        return;
+    }
     for (uint32_t j0 = 0; j0 < c; j0 += 64) {
         const uint32_t j = j0 + lane;
         const bool at = j < c && ((rk_entry(L, t, c, j) >> 14) & FL_AT);
@@ -102,6 +138,49 @@ __global__ __launch_bounds__(256) void k_rk_list(LineIndex L, RankBufs R)
         }
         base += __popcll(m);
     }
+}
+
+// the first "\n@" entry at buffer coordinate >= minP behind entry `from` (what wv_find(L, from, FL_AT, minP, ...) returns),
+// with four entries per lane in the tile the position falls into when that tile fits its slot: the successor search of a
+// candidate is one memory round trip there instead of up to four
+__device__ __forceinline__ bool rk_find_at(const LineIndex &L, H from, int64_t minP, H &out, int64_t &Pout, int &flout)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tmin = (minP - L.s) >> TILE_SHIFT;
+    if (from.tile >= 0 && tmin >= (int64_t)from.tile && tmin < (int64_t)L.ready) {
+        const int t = (int)tmin;
+        const uint32_t c = L.cnt[t];
+        if (c <= (uint32_t)SLOT && c > 0) {
+            const uint32_t i0 = (t == from.tile) ? (uint32_t)from.i + 1u : 0u;
+            for (uint32_t j0 = i0 & ~3u; j0 < c; j0 += 256) {
+                const uint32_t j = j0 + 4u * (uint32_t)lane;
+                int hit = -1;
+                uint32_t e_hit = 0;
+                if (j < c) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)t * SLOT + j);
+                    const uint32_t e[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+#pragma unroll
+                    for (int q = 3; q >= 0; q--) {
+                        const int64_t P = ((int64_t)t << TILE_SHIFT) + (e[q] & OFF_MASK) + L.s;
+                        if (j + (uint32_t)q < c && j + (uint32_t)q >= i0 && ((e[q] >> 14) & FL_AT) && P >= minP) { hit = q; e_hit = e[q]; }
+                    }
+                }
+                const unsigned long long m = __ballot(hit >= 0);
+                if (m) {
+                    const int w = __ffsll((long long)m) - 1;
+                    const int q = __shfl(hit, w);
+                    const uint32_t e = (uint32_t)__shfl((int)e_hit, w);
+                    out = H{t, (int32_t)(j0 + 4u * (uint32_t)w + (uint32_t)q)};
+                    Pout = ((int64_t)t << TILE_SHIFT) + (e & OFF_MASK) + L.s;
+                    flout = (int)(e >> 14);
+                    return true;
+                }
+            }
+            // nothing in that tile: the general search goes on behind its last entry
+            return wv_find(L, H{t, (int32_t)c - 1}, FL_AT, minP, out, Pout, flout);
+        }
+    }
+    return wv_find(L, from, FL_AT, minP, out, Pout, flout);
 }
 
 // ordinal of the candidate at line-index entry h
@@ -125,7 +204,7 @@ __global__ __launch_bounds__(256) void k_rk_succ(LineIndex L, RankBufs R, int eo
     uint32_t nx = RK_NONE;
     if (r.status == ST_COMPLETE) {
         H kn; int64_t Pn; int fln;
-        if (wv_find(L, hm1, FL_AT, r.p5 - 1, kn, Pn, fln)) {
+        if (rk_find_at(L, hm1, r.p5 - 1, kn, Pn, fln)) {
             const long long o = rk_ordinal(L, R, kn);
             nx = (o < R.nc) ? (uint32_t)o : RK_NONE;
         }
@@ -146,7 +225,16 @@ __global__ __launch_bounds__(1024) void k_rk_root(LineIndex L, RankBufs R, int64
     __shared__ unsigned long long s_nl[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     unsigned long long nlp = 0;
-    for (int t = tid; t < L.ntiles; t += 1024) nlp += L.cnt[t];
+    {
+        // (sixteen counts per thread and step, four 16-byte loads in flight: one count per step took 62 us for 4 GiB)
+        const int64_t nt = L.ntiles, n16 = nt & ~(int64_t)15;
+        for (int64_t t0 = (int64_t)tid * 16; t0 < n16; t0 += 1024 * 16) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(L.cnt + t0);
+            const uint4 a = p[0], b = p[1], c4 = p[2], d = p[3];
+            nlp += (unsigned long long)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c4.x + c4.y + c4.z + c4.w + d.x + d.y + d.z + d.w;
+        }
+        for (int64_t t = n16 + tid; t < nt; t += 1024) nlp += L.cnt[t];
+    }
     const uint32_t lo = wave_sum_u32((uint32_t)(nlp & 0xFFFFFu)), hi = wave_sum_u32((uint32_t)(nlp >> 20));
     if (lane == 0) s_nl[wid] = ((unsigned long long)hi << 20) + lo;
     __syncthreads();
