@@ -1,7 +1,8 @@
-"""The library's host threads under ThreadSanitizer (the reference is single-threaded and needs no
-race detector; this build's reader pool, gzip pools, chunked inflate and in-process shard world do).
+"""The library's host threads under ThreadSanitizer -- and the same runs under AddressSanitizer + UBSan -- (SURVEY.md
+section 5: the reference is single-threaded and needs no race detector; this build's reader pool, gzip pools, chunked
+inflate and in-process shard world do).
 
-A -fsanitize=thread build of libffq_hip.so (hipcc instruments the HOST code; no device is touched by what runs here) +
+A -fsanitize=thread (then: address,undefined) build of libffq_hip.so (hipcc instruments the HOST code; no device is touched by what runs here) +
 tests/tsan_host_threads.cpp + the oracle (the scan of the shard mode), all in one TSan runtime:
   * ffq_gunzip_fd = the stream front end's gzip reader: BGZF members side by side (GzPool), ONE plain member by several
     threads (csrc/ffq_pgz.h: chunks entered at block headers, hand-overs at odd bits, stitch, CRC pieces combined),
@@ -25,13 +26,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
-@pytest.fixture(scope="module")
-def tsan(tmp_path_factory):
+@pytest.fixture(scope="module", params=("thread", "address,undefined"))
+def tsan(request, tmp_path_factory):
     import fastqandfurious_amd  # noqa: F401
+    san = request.param
+    rtname = "libclang_rt.tsan-x86_64.so" if san == "thread" else "libclang_rt.asan-x86_64.so"
     from fastqandfurious_amd import build
-    d = tmp_path_factory.mktemp("tsan")
-    if not (os.path.exists(CLANG) and shutil.which("gcc")):
-        pytest.skip("no clang++ / gcc")
+    d = tmp_path_factory.mktemp("san")
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++")
     try:
         hipcc = build._hipcc()
     except RuntimeError:
@@ -40,33 +43,35 @@ def tsan(tmp_path_factory):
     for cand in subprocess.run([CLANG, "--print-runtime-dir"], capture_output=True, text=True).stdout.split() + \
             [os.path.join(os.path.dirname(os.path.dirname(CLANG)), "lib", "clang", v, "lib", "linux")
              for v in (os.listdir(os.path.join(os.path.dirname(os.path.dirname(CLANG)), "lib", "clang")) if os.path.isdir(os.path.join(os.path.dirname(os.path.dirname(CLANG)), "lib", "clang")) else [])]:
-        if os.path.exists(os.path.join(cand, "libclang_rt.tsan-x86_64.so")):
+        if os.path.exists(os.path.join(cand, rtname)):
             rt = cand
             break
     if rt is None:
-        pytest.skip("no shared ThreadSanitizer runtime (libclang_rt.tsan-x86_64.so)")
+        pytest.skip("no shared sanitizer runtime (%s)" % rtname)
     lib = d / "libffq_tsan.so"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=thread", "-shared-libsan",
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=" + san, "-shared-libsan",
                         "-Wno-unused-function", "-Wno-option-ignored", '-DFFQ_BUILD_ID="tsan"', "-o", str(lib),
                         os.path.join(build.CSRC, "ffq_hip.hip"), "-lz"], capture_output=True, text=True)
     if r.returncode != 0:
-        pytest.skip("the library does not build with -fsanitize=thread here: " + r.stderr[-300:])
-    obj = d / "oracle_tsan.o"
-    subprocess.run(["gcc", "-O1", "-g", "-std=c99", "-fPIC", "-fsanitize=thread", "-c", os.path.join(ROOT, "oracle", "ffq_oracle.c"), "-o", str(obj)], check=True)
-    exe = d / "tsan_drv"
-    r = subprocess.run([CLANG, "-fsanitize=thread", "-shared-libsan", "-O1", "-g", "-std=c++17", "-pthread",
+        pytest.skip("the library does not build with -fsanitize=%s here: %s" % (san, r.stderr[-300:]))
+    obj = d / "oracle_san.o"
+    subprocess.run([CLANG.replace("clang++", "clang"), "-O1", "-g", "-std=c99", "-D_GNU_SOURCE", "-fPIC", "-fsanitize=" + san, "-c",
+                    os.path.join(ROOT, "oracle", "ffq_oracle.c"), "-o", str(obj)], check=True)
+    exe = d / "san_drv"
+    r = subprocess.run([CLANG, "-fsanitize=" + san, "-shared-libsan", "-O1", "-g", "-std=c++17", "-pthread",
                         os.path.join(ROOT, "tests", "tsan_host_threads.cpp"), str(obj), "-L" + str(d), "-lffq_tsan", "-lz",
                         "-Wl,-rpath," + str(d), "-Wl,-rpath," + rt, "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
 
     def run(*args, env=None, ok=(0,)):
-        e = dict(os.environ, TSAN_OPTIONS="exitcode=66 halt_on_error=0", LD_LIBRARY_PATH=rt + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        e = dict(os.environ, TSAN_OPTIONS="exitcode=66 halt_on_error=0", ASAN_OPTIONS="detect_leaks=0 exitcode=66", UBSAN_OPTIONS="halt_on_error=1 exitcode=66",
+                 LD_LIBRARY_PATH=rt + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
         e.update(env or {})
         p = subprocess.run([str(exe)] + [str(a) for a in args], env=e, capture_output=True, text=True, timeout=900)
-        assert "ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
+        assert "Sanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
         assert p.returncode in ok, (p.returncode, p.stdout[-500:], p.stderr[-2000:])
         return p
-    run.exe, run.rt = str(exe), rt
+    run.exe, run.rt, run.san = str(exe), rt, san
     return run
 
 
@@ -77,6 +82,8 @@ def _fastq(n, seed):
 
 
 def test_detector_is_awake(tsan):
+    if tsan.san != "thread":
+        pytest.skip("the deliberate race is ThreadSanitizer's to find")
     e = dict(os.environ, TSAN_OPTIONS="exitcode=66", LD_LIBRARY_PATH=tsan.rt)
     p = subprocess.run([tsan.exe, "race", "x"], env=e, capture_output=True, text=True, timeout=120)
     assert p.returncode == 66 and "ThreadSanitizer: data race" in p.stderr
