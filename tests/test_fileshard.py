@@ -365,3 +365,55 @@ def test_device_step_over_a_hosted_transport(gpu_ctx, oracle, shm_file, kind, wo
         assert [r[2 + k] for r in results] == [sum(q[k].shape[0] for q in results[:i]) for i in range(world)]
     if kind in ("long", "tricky"):
         assert any(r[4] > 0 for r in results) and any(r[5] > 0 for r in results)
+
+
+def test_file_shards_at_size_closed_form(gpu_ctx, shm_file):
+    """A 3 GiB S-single file in /dev/shm read by 8 logical ranks (0.38 GiB each, resident): every rank's rows against the
+    generator's closed form (row k = 322 k + the six column offsets), ordinals and counts adding up -- the file-backed
+    counterpart of the config-5 property test, at a size the pool's boxes hold in host memory."""
+    import torch
+    from fastqandfurious_amd import sharded
+    n = (3 << 30) // 322
+    total = n * 322
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    if os.statvfs(d).f_bavail * os.statvfs(d).f_frsize < total + (1 << 30):
+        pytest.skip("no room for a 3 GiB file in %s" % d)
+    path = os.path.join(d, "ffq_fileshard_big.%d.fq" % os.getpid())
+    dev = torch.device("cuda", 0)
+    try:
+        # the file, written piece by piece from the device generator (counter-based: any piece on its own)
+        with open(path, "wb") as fh:
+            piece = 1 << 20                                # records per piece (322 MB)
+            buf = torch.empty(piece * 322, dtype=torch.uint8, device=dev)
+            for first in range(0, n, piece):
+                cnt = min(piece, n - first)
+                gpu_ctx.synth_single(buf.data_ptr(), first, cnt, seed=42)
+                gpu_ctx.sync()
+                fh.write(buf[:cnt * 322].cpu().numpy().tobytes())
+            del buf
+        world = 8
+        col = torch.tensor([0, 17, 18, 168, 171, 321], dtype=torch.int64, device=dev)
+
+        def work(rank, ctx, sw):
+            sh = sharded.FileShard(ctx, path, rank, world, comm=sw)
+            try:
+                assert sh.load() == sh.n_view
+                res = sh.scan()
+                assert res.scan.path == 3 and res.rounds == 0 and res.halo_source == 1
+                n_own = int(res.row_hi - res.row_lo)
+                k0 = -(-sh.lo // 322)
+                assert n_own == -(-sh.hi // 322) - k0 and int(res.record_base) == k0 and int(res.total_records) == n
+                rows = torch.as_tensor(sharded._DevView(sh.d_table + int(res.row_lo) * 48, n_own * 48), device=dev).view(torch.int64).view(-1, 6)
+                k = torch.arange(k0, k0 + n_own, dtype=torch.int64, device=dev) * 322
+                assert bool((rows == k[:, None] + col[None, :]).all()), "rank %d: rows differ from the closed form" % rank
+                return n_own
+            finally:
+                sh.close()
+        counts = run_ranks(world, work)
+        assert sum(counts) == n
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        torch.cuda.empty_cache()
