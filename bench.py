@@ -800,7 +800,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 "total_records": total_records,
                 "sharding": ("byte ranges, halo hand-off over %s" % (
                                  "RCCL, the step behind the C ABI (ffq_shard_step_submit / _wait)" if dist.get_backend() == "nccl"
-                                 else "%s: a functional dry run, every rank on ONE GPU through the host step (ffq_shard_host_step)" % dist.get_backend())
+                                 else "%s: a functional dry run, every rank on ONE GPU -- the device step over a hosted transport (ffq_shard_create_hosted)" % dist.get_backend())
                              if world > 1 else "single range"),
             },
             # what a step costs beside its scan (N > 1, the library's own step: ffq_shard_step_*): device time of the halo

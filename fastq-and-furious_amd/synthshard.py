@@ -24,10 +24,10 @@ class SyntheticShard:
         evenly as they go (BASELINE configs[4]: 333 460 193 records = 107 374 182 146 B over 8 ranges);
         bytes_per_gpu is ignored then.
         native: the DEVICE step (ffq_shard_step_*: RCCL hand-offs between processes, the in-process transport for
-        logical ranks and for a world of one) -- the product path; False: the HOST step (ffq_shard_host_step) over
-        host copies of the range with this transport, the GPU scanning through ffq_scan_host -- what a dry run of
-        several processes on ONE GPU uses (gloo; RCCL refuses two ranks per device).  None: the device step wherever it
-        can run.  solo_rccl: a world of one on the library's RCCL transport (communicators of one rank) instead of the
+        logical ranks and for a world of one, the hosted transport over gloo for a dry run of several processes on ONE
+        GPU -- RCCL refuses two ranks per device) -- the product path, and the default; False: the HOST step
+        (ffq_shard_host_step) over host copies of the range with this transport, the GPU scanning through ffq_scan_host
+        (tests).  solo_rccl: a world of one on the library's RCCL transport (communicators of one rank) instead of the
         in-process one -- what the product's step costs with no peers."""
         import torch
         from . import synth
@@ -110,7 +110,7 @@ class SyntheticShard:
         self.max_records = n_per + (self.tail + self.head) // min_rec + 64
         gloo = isinstance(transport, DistTransport)
         if native is None:
-            native = not gloo
+            native = True
         self.native = bool(native)
         self._own_world = None
         if self.native:
@@ -122,7 +122,9 @@ class SyntheticShard:
                 self._own_world = _hip.ShardWorld(1)
                 self.scanner = NativeShardScanner(ctx, S, 0, 1, local_world=self._own_world)
             elif gloo:
-                raise ValueError("the device step needs RCCL between processes: several ranks over gloo take the host step (native=False)")
+                # several processes that cannot talk RCCL (a dry run on ONE GPU): the device step all the same, its hand-offs
+                # staged through host memory around gloo, its words gathered by gloo (ffq_shard_create_hosted)
+                self.scanner = NativeShardScanner(ctx, S, rank, world, hosted=transport)
             else:
                 self.scanner = NativeShardScanner(ctx, S, rank, world, unique_id=native_unique_id(transport, dev))
         else:
