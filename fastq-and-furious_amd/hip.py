@@ -709,9 +709,12 @@ class Shard:
         return n.value
 
     def step_submit(self, d_ext, d_table, table_cap, flags=0, qual_add=-33, d_qual=None, qual_cap=0, d_qoff=None, overlap=False):
-        check(lib().ffq_shard_step_submit(self._h, ctypes.c_void_p(d_ext), 1 if overlap else 0, int(flags), int(qual_add),
-                                          ctypes.c_void_p(d_table), int(table_cap), ctypes.c_void_p(d_qual), int(qual_cap),
-                                          ctypes.c_void_p(d_qoff)))
+        rc = lib().ffq_shard_step_submit(self._h, ctypes.c_void_p(d_ext), 1 if overlap else 0, int(flags), int(qual_add),
+                                         ctypes.c_void_p(d_table), int(table_cap), ctypes.c_void_p(d_qual), int(qual_cap),
+                                         ctypes.c_void_p(d_qoff))
+        if self._err:                                   # (an exception inside a hosted transport's callback: the hand-off)
+            raise self._err.pop(0)
+        check(rc)
 
     def step_wait(self):
         res = ShardResult()

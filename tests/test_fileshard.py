@@ -417,3 +417,22 @@ def test_file_shards_at_size_closed_form(gpu_ctx, shm_file):
         except OSError:
             pass
         torch.cuda.empty_cache()
+
+
+def test_tiny_and_empty_files(gpu_ctx, oracle, shm_file):
+    """An empty file, one record, a file smaller than the number of ranks: ranges of zero bytes, ranks that own nothing."""
+    from fastqandfurious_amd import fastqandfurious as F, synth
+    for nrec, worlds in ((0, (1, 3)), (1, (1, 2, 8)), (3, (8,))):
+        data = synth.single(0, nrec, seed=42) if nrec else np.zeros(0, dtype=np.uint8)
+        path = shm_file(data, "ffq_tiny_%d.fq" % nrec)
+        want, err = expected(oracle, data)
+        assert err is None and len(want) == nrec
+        for world in worlds:
+            res = run_ranks(world, lambda rank, ctx, sw: (lambda it: (it.record_base, it.total_records, [list(p) for p in it]))(
+                F.readfastq_iter_range(path, rank, world, F.entryfunc_abspos, comm=sw, ctx=ctx)))
+            assert [r for _, _, o in res for r in o] == [list(map(int, r)) for r in want]
+            assert all(t == nrec for _, t, _ in res)
+    # a file of a few bytes that is no FASTQ at all: the stream's error, on every rank
+    path = shm_file(b"@r1\nAC", "ffq_tiny_bad.fq")
+    with pytest.raises(ValueError, match="Incomplete entry at byte"):
+        run_ranks(2, lambda rank, ctx, sw: list(F.readfastq_iter_range(path, rank, 2, comm=sw, ctx=ctx)))
