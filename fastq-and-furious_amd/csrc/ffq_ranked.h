@@ -191,12 +191,94 @@ __device__ __forceinline__ long long rk_ordinal(const LineIndex &L, const RankBu
     return (h.tile == 0 ? (long long)rk_sentinel_cand(L) : R.tbase[h.tile]) + before;
 }
 
+// The usual candidate, in ONE look at the index: the call from a "\n@" whose record -- and the "\n@" the chain goes on with --
+// lie within the 256 entries behind it in the SAME tile (reads of a few kilobases wrapped at 80 columns: 40-80 lines), far
+// from the buffer's end (none of the scanner's buffer-end rules can apply).  Four entries per lane from one 8-byte load; the
+// three searches of the call (/root/reference/src/_fastqandfurious.c:70-71, :87-88, :102-103), the successor search
+// (fastqandfurious.py:254) and the successor's ordinal (this candidate's + the "\n@" entries in between) are ballots over
+// those registers -- where the general path below makes a dozen dependent look-ups.  false: not such a candidate (the
+// general path decides everything).
+__device__ __forceinline__ bool rk_succ_window(const LineIndex &L, const RankBufs &R, int64_t c, H k)
+{
+    const int lane = threadIdx.x & 63;
+    if (k.tile < 0) return false;
+    const int t = k.tile;
+    const uint32_t ct = L.cnt[t];
+    const int64_t tbase = ((int64_t)t << TILE_SHIFT) + L.s, len = L.len();
+    if (ct > (uint32_t)SLOT || tbase + TILE + 4 >= len) return false;
+    const uint32_t i = (uint32_t)k.i, j0 = i & ~3u, j = j0 + 4u * (uint32_t)lane;
+    uint32_t e[4] = {0u, 0u, 0u, 0u};
+    if (j < ct) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)t * SLOT + j);
+        e[0] = w.x & 0xFFFFu; e[1] = w.x >> 16; e[2] = w.y & 0xFFFFu; e[3] = w.y >> 16;
+    }
+    const uint32_t hi = min(ct, j0 + 256u);                    // entries [j0, hi) are in the registers
+    auto entry_at = [&](uint32_t idx) -> uint32_t {            // idx wave-uniform, in [j0, hi)
+        const uint32_t d = idx - j0;
+        const uint32_t q = d & 3u;
+        const uint32_t v = q == 0 ? e[0] : q == 1 ? e[1] : q == 2 ? e[2] : e[3];
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(d >> 2));
+    };
+    // first entry of index > after (and < hi) with the flag, at position >= minP (tile-relative); -1: none in the window
+    auto first_flag = [&](uint32_t after, uint32_t flag_bit, int64_t minP) -> int {
+        uint32_t m4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t idx = j + (uint32_t)q;
+            const bool ok = idx > after && idx < hi && ((e[q] >> flag_bit) & 1u) && tbase + (int64_t)(e[q] & OFF_MASK) >= minP;
+            m4 |= (ok ? 1u : 0u) << q;
+        }
+        const unsigned long long m = __ballot(m4 != 0u);
+        if (!m) return -1;
+        const int w = __ffsll((long long)m) - 1;
+        const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)m4, w);
+        return (int)(j0 + 4u * (uint32_t)w) + (__ffs((int)mw) - 1);
+    };
+    if (i + 1u >= hi) return false;
+    const int64_t Pk = tbase + (int64_t)(entry_at(i) & OFF_MASK);
+    const int64_t he = tbase + (int64_t)(entry_at(i + 1u) & OFF_MASK);                    // :70-71 (the next newline)
+    const int mi = first_flag(i + 1u, 15u, he + 2);                                       // :87-88 "\n+" at >= seq_beg + 1
+    if (mi < 0 || (uint32_t)mi + 1u >= hi) return false;
+    const int64_t se = tbase + (int64_t)(entry_at((uint32_t)mi) & OFF_MASK);
+    const int64_t qhe = tbase + (int64_t)(entry_at((uint32_t)mi + 1u) & OFF_MASK);        // :102-103
+    const int64_t p0 = Pk + 1;
+    if ((qhe - se - 1 > 1) && (qhe - se != he - p0 + 1)) {                               // :109-117
+        if (lane == 0) {
+            R.rec[c] = RankRec{he, se, -1, ST_INVALID, 0};
+            R.succ[c] = RK_NONE; R.S[0][c] = (uint32_t)c; R.C[0][c] = 0u; R.D[c] = RK_NONE;
+        }
+        return true;
+    }
+    const int64_t p4 = qhe + 1, qe = p4 + se - he - 1;                                    // :129
+    if (qe + 2 >= len) return false;                                                     // (:130-133: the general path's)
+    const int ni = first_flag((uint32_t)mi + 1u, 14u, qe - 1);                            // fastqandfurious.py:254: the next "\n@" at >= pos5 - 1
+    if (ni < 0) return false;
+    // its ordinal: this candidate's + 1 + the "\n@" entries strictly between the two
+    uint32_t between = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t idx = j + (uint32_t)q;
+        between += (idx > i && idx < (uint32_t)ni && ((e[q] >> 14) & 1u)) ? 1u : 0u;
+    }
+    const long long o = (long long)c + 1 + (long long)wave_sum_u32(between);
+    if (lane == 0) {
+        const uint32_t nx = (o < R.nc) ? (uint32_t)o : RK_NONE;
+        R.rec[c] = RankRec{he, se, p4, ST_COMPLETE, 0};
+        R.succ[c] = nx;
+        R.S[0][c] = (nx != RK_NONE) ? nx : (uint32_t)c;
+        R.C[0][c] = (nx != RK_NONE) ? 1u : 0u;
+        R.D[c] = RK_NONE;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_rk_succ(LineIndex L, RankBufs R, int eof)
 {
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= R.nc) return;
     const H k = R.cand[c];
+    if (rk_succ_window(L, R, c, k)) return;
     int64_t Pk; int fl;
     GAcc(L).get(k, Pk, fl);
     Rec r; H hm1;
