@@ -518,6 +518,12 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
     // fast << 29 (set: fields are re-read from the window when the record is staged)
     uint32_t info[PER];
     uint32_t pend = 0;          // slots of this lane that need the generic path
+    // slots of this lane whose call lands EXACTLY on its successor: pos5 is the very newline in front of the next '@'.  Every
+    // record of a well-formed file does; a call started at a quality line that happens to begin with '@' reads several
+    // records as one and lands in the middle of a line.  Only used to choose WHERE the guessed chain starts (below): with
+    // records of a kilobase the 8 KiB run-in holds four of them, too few for a chain started at a false candidate to fall
+    // in with the true one every time (4 % of the groups were repaired, one pass per scan, at 1 kbp).
+    uint32_t clean = 0;
     // successor beyond the entries read so far: binary search of the window for the first entry at
     // >= qe - 1 (from index `from` on), then the first "\n@" among the next 8.  ~0u: not found.
     auto far_successor = [&](int from, uint32_t qe) -> uint32_t {
@@ -582,6 +588,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
                     } else if (dn) {
                         info[u] = (uint32_t)(c + dn) | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
                                   (15u << 25) | (1u << 29);
+                        if ((dn == 1 ? np[0] : dn == 2 ? np[1] : np[2]) == qe) clean |= 1u << u;
                         done = true;
                     } else {
                         // the successor is not an own node (it lies in the look-ahead tile: the last
@@ -602,6 +609,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
                             const uint32_t nx = (k + j < own_hi && nid != NO_NODE) ? nid : SN_AHEAD;
                             info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
                                       ((uint32_t)j << 25) | (1u << 29);
+                            if ((wj & WP_MASK) == qe) clean |= 1u << u;
                             done = true;
                         } else if (qe + 2 < lenrel) {
                             // the record is COMPLETE but its successor lies beyond the batch (a
@@ -611,6 +619,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
                             if (nx != 0xFFFFFFFFu) {
                                 info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
                                           (15u << 25) | (1u << 29);
+                                if (nx < (uint32_t)NMAX && npos[nx] == qe) clean |= 1u << u;
                                 done = true;
                             }
                         }
@@ -647,6 +656,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
                                 if (nx != 0xFFFFFFFFu) {
                                     info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
                                               (1u << 29) | (1u << 31);
+                                    if (nx < (uint32_t)NMAX && npos[nx] == qe) clean |= 1u << u;
                                     done = true;
                                 }
                             }
@@ -701,7 +711,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
             }
             const uint32_t st = (uint32_t)(f.r.final_ ? ST_FINAL : f.r.status);
             const uint32_t v = nxn | ((st + 1u) << 16) | (ext ? (1u << 30) : 0u);
-            if (lane == ln) info[u] = v;
+            if (lane == ln) { info[u] = v; if (f.r.status == ST_COMPLETE && f.after == f.r.p5) clean |= 1u << u; }
         }
     }
     pend = 0;
@@ -753,6 +763,14 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
         }
     }
     int e0 = (e_forced >= 0) ? e_forced : 0, lastn = -1;
+    if (e_forced < 0 && n_runin > 0) {
+        // the guessed chain starts at the first run-in node whose call lands exactly (see `clean`); none: at the first node
+        unsigned long long CL[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) CL[u] = __ballot(((clean >> u) & 1u) != 0u);
+        const int cs = first_set_from<PER>(CL, 0);
+        if (cs < n_runin) e0 = cs;
+    }
     bool unresolved = (fpos != FORCE_NONE && e_forced < 0), too_many_jumps = false;
     for (int attempt = 0; attempt < 4 && ncomp > 0 && !unresolved; attempt++) {
         if (lane < 2 * (NMAX / 32)) bits_all[wid][lane] = 0u;
