@@ -765,10 +765,25 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
     int e0 = (e_forced >= 0) ? e_forced : 0, lastn = -1;
     if (e_forced < 0 && n_runin > 0) {
         // the guessed chain starts at the first run-in node whose call lands exactly (see `clean`); none: at the first node
-        unsigned long long CL[PER];
+        // (better: whose SUCCESSOR lands exactly too -- one exact landing from a false candidate is a 1-in-10^4 event per
+        // group, which at 65 536 groups still meant a repair pass per scan; two in a row is not seen)
+        unsigned long long CL[PER], C2[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) CL[u] = __ballot(((clean >> u) & 1u) != 0u);
-        const int cs = first_set_from<PER>(CL, 0);
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const uint32_t nx = info[u] & 0xFFFFu;
+            bool ok2 = false;
+            if (((clean >> u) & 1u) && nx < (uint32_t)NMAX) {
+                unsigned long long wsel = 0ull;
+#pragma unroll
+                for (int q = 0; q < PER; q++) if ((int)(nx >> 6) == q) wsel = CL[q];
+                ok2 = ((wsel >> (nx & 63u)) & 1ull) != 0ull;
+            }
+            C2[u] = __ballot(ok2);
+        }
+        int cs = first_set_from<PER>(C2, 0);
+        if (cs >= n_runin) cs = first_set_from<PER>(CL, 0);
         if (cs < n_runin) e0 = cs;
     }
     bool unresolved = (fpos != FORCE_NONE && e_forced < 0), too_many_jumps = false;

@@ -1182,6 +1182,17 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             for (int g = 0; g < ng; g++)
                 fprintf(stderr, "[ffq debug]  g=%d y=%lld exit=%lld cnt=%u flags=%u\n", g, (long long)y[g],
                         (long long)ex[g], cn[g], fl[g]);
+            // ... and the first group the verification rejected, with its neighbours
+            fprintf(stderr, "[ffq debug] n_bad=%d bad_irregular=%d declined=%d\n", c->h_res->n_bad, c->h_res->bad_irregular, c->h_res->n_declined);
+            if (mins[1] >= 0 && mins[1] < st.ngroups) {
+                const int g0 = std::max(mins[1] - 1, 0), g1 = std::min(mins[1] + 2, st.ngroups);
+                for (int g = g0; g < g1; g++) {
+                    int64_t yy, ee; uint32_t cc, ff;
+                    HIPCHK(hipMemcpy(&yy, c->cb.y + g, 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&ee, c->cb.exit + g, 8, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(&cc, c->cb.cnt + g, 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&ff, c->cb.flags + g, 4, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[ffq debug]  g=%d y=%lld exit=%lld cnt=%u flags=%u\n", g, (long long)yy, (long long)ee, cc, ff);
+                }
+            }
         }
         int path = 0;
         if (PROBES && tiers && getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) {
