@@ -333,7 +333,9 @@ static ReadPool *ctx_pool(ffq_ctx *c)
         c->helpers = new (std::nothrow) ReadPool();
         if (c->helpers) {
             const unsigned hw = std::thread::hardware_concurrency();
-            c->helpers->start((int)std::min<unsigned>(16, hw > 2 ? hw - 2 : 1));
+            const char *e = getenv("FFQ_POOL_THREADS");              // (measurements; default: up to 16)
+            const unsigned want = (e && atoi(e) > 0) ? (unsigned)std::min(atoi(e), 64) : 16u;
+            c->helpers->start((int)std::min<unsigned>(want, hw > 2 ? hw - 2 : 1));
         }
     }
     return c->helpers;
