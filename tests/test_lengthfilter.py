@@ -11,7 +11,6 @@ GPU: the same call with the GPU scanner -- the stream front end filters every fi
 (ffq_stream_set_filter: k_sel_count / k_scan / k_sel_scatter, then the column kernels over the kept rows) before
 anything is copied back -- through every kind of source (descriptor, gzip, BGZF, pushed chunks) and buffer size;
 and the C ABI itself (ffq_stream_selected: kept rows, their ordinals, the gathered column) against the oracle."""
-import gzip
 import hashlib
 import io
 import json

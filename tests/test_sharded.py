@@ -13,12 +13,10 @@ unit that shards is the record chain of /root/reference/src/fastqandfurious.py:2
 until a record fits (:274-279).
 
 Concatenated shard rows must equal the oracle's single-range table, bit for bit."""
-import contextlib
 import os
 import socket
 import sys
 import threading
-import types
 
 import numpy as np
 import pytest

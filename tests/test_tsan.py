@@ -15,11 +15,9 @@ ffq_stream_* and the device step's streams (they need the GPU, and the HIP runti
 import gzip
 import os
 import random
-import shutil
 import subprocess
 import zlib
 
-import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
