@@ -763,7 +763,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
         }
     }
     int e0 = (e_forced >= 0) ? e_forced : 0, lastn = -1;
-    if (e_forced < 0 && n_runin > 0) {
+    if (e_forced < 0 && has_runin) {          // (the first group starts where the caller says: it is the induction's base)
         // the guessed chain starts at the first run-in node whose call lands exactly (see `clean`); none: at the first node
         // (better: whose SUCCESSOR lands exactly too -- one exact landing from a false candidate is a 1-in-10^4 event per
         // group, which at 65 536 groups still meant a repair pass per scan; two in a row is not seen)
@@ -782,9 +782,11 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
             }
             C2[u] = __ballot(ok2);
         }
+        // (a run-in without such a node -- records of several kilobases: the 8 KiB tail holds no header at all -- takes the
+        // first one of the own tiles: the first true header there, which is where the predecessor's chain arrives)
         int cs = first_set_from<PER>(C2, 0);
-        if (cs >= n_runin) cs = first_set_from<PER>(CL, 0);
-        if (cs < n_runin) e0 = cs;
+        if (cs >= ncomp) cs = first_set_from<PER>(CL, 0);
+        if (cs < ncomp) e0 = cs;
     }
     bool unresolved = (fpos != FORCE_NONE && e_forced < 0), too_many_jumps = false;
     for (int attempt = 0; attempt < 4 && ncomp > 0 && !unresolved; attempt++) {

@@ -543,16 +543,22 @@ def test_long_wrapped_records_take_the_ranked_tier(gpu_ctx, hipmod, oracle, L):
     rng = np.random.default_rng(L)
     data = random_records(rng, (8 << 20) // (2 * L), L // 2, L, wrap=80, hdr_hi=10)
     gpu_ctx.forget()
+    # (records of 2.5-5 KB: since round 5 the group kernels may prove them -- the guessed chain starts at a node whose call lands
+    # exactly --, and the tier is then not needed: forced, so that it stays tested at this length too)
+    want = (0, 5) if L == 5000 else (5,)
     table, res = check_same(gpu_ctx, oracle, data)
-    assert res.path == 5
+    assert res.path in want
     table, res = check_same(gpu_ctx, oracle, data[:-1])          # no trailing newline: the final-record rule
-    assert res.path == 5
+    assert res.path in want
+    if L == 5000:
+        table, res = check_same(gpu_ctx, oracle, data, flags=hipmod.F_FORCE_RANKED)
+        assert res.path == 5
     check_same(gpu_ctx, oracle, data[:len(data) * 2 // 3])       # cut inside a record
     check_same(gpu_ctx, oracle, data, offset=len(data) // 2, eof=False)
     decode_same(gpu_ctx, hipmod, oracle, data)
     short = random_records(rng, 20000, 50, 150)
     table, res = check_same(gpu_ctx, oracle, short)
-    assert res.path == 3
+    assert res.path == 3 or (L == 5000 and res.path == 0)     # (a context whose last scans were the group kernels' asks the fast path again later)
     gpu_ctx.forget()
 
 
