@@ -312,4 +312,157 @@ __global__ __launch_bounds__(256, 8) void k_scan_seg(SegArgs a)
     }
 }
 
+
+// ---- the same single pass with the output IN PLACE: decoded byte of input offset p at output offset p -----------------
+// Nothing is packed: a tile writes the 16-byte pieces of its own bytes that touch a quality line, decoded, at the offsets
+// they have in the input (a superset of the quality bytes: the rest of such a piece is some other line's, decoded too,
+// and nobody's).  A record's bytes are out[pos4 : pos5] in the coordinates of d -- contiguous whatever tiles they cross,
+// so there is no limit on the length of a line -- and qoff[i] is pos4 itself.  Which lines are quality lines is the same
+// speculation as above ([none][+] among the tile's first 64 entries), verified the same way (k_rows4<2>); a tile that
+// cannot tell (no such pair: a tile inside one long line, or one with a newline or two) writes ALL of its bytes and has
+// nothing to be verified.  Output buffer: as many bytes as the input's tiles (a.out_cap >= ntiles * TILE).
+
+// four bytes, each one of A C G T N in either case
+__device__ __forceinline__ bool all_bases4(uint32_t x)
+{
+    const uint32_t y = x & 0xDFDFDFDFu;
+    uint32_t hit = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t letter = (k == 0 ? 'A' : k == 1 ? 'C' : k == 2 ? 'G' : k == 3 ? 'T' : 'N') * 0x01010101u;
+        const uint32_t v = y ^ letter;
+        hit |= ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);          // 0x80 in every byte that is the letter
+    }
+    return hit == 0x80808080u;
+}
+
+__global__ __launch_bounds__(256, 8) void k_scan_ident(SegArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[TILE + 16];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[SLOT];
+    __shared__ uint32_t s_wtot[4];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int64_t T = blockIdx.x;
+    const int64_t tbase = T << TILE_SHIFT;
+    if (T == 0 && tid == 0 && a.d_L) *a.d_L = a.Lval;
+    uint32_t o4[4];
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o4[i] = (uint32_t)(w * 4096 + i * 1024 + l * 16);
+    if (tbase + TILE <= a.n) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.d + tbase + o4[i]));
+            v[i] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = load_tail16(a.d, a.n, tbase + o4[i]);
+    }
+    const uint32_t nxt = (tbase + TILE < a.n) ? (uint32_t)a.d[tbase + TILE] : 0u;   // the flags of a newline at the tile's last offset
+    uint32_t m[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        *reinterpret_cast<uint4 *>(s_data + o4[i]) = v[i];
+        m[i] = nl_mask16(v[i]);
+        c[i] = __popc(m[i]);
+    }
+    if (tid == 0) s_data[TILE] = (uint8_t)nxt;
+    const uint32_t s01 = wave_incl_scan(c[0] | (c[1] << 16));
+    const uint32_t s23 = wave_incl_scan(c[2] | (c[3] << 16));
+    const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)s01, 63), t23 = (uint32_t)__builtin_amdgcn_readlane((int)s23, 63);
+    uint32_t ex[4], rowtot[4];
+    ex[0] = (s01 & 0xFFFFu) - c[0];  rowtot[0] = t01 & 0xFFFFu;
+    ex[1] = (s01 >> 16) - c[1];      rowtot[1] = t01 >> 16;
+    ex[2] = (s23 & 0xFFFFu) - c[2];  rowtot[2] = t23 & 0xFFFFu;
+    ex[3] = (s23 >> 16) - c[3];      rowtot[3] = t23 >> 16;
+    const uint32_t wtot = rowtot[0] + rowtot[1] + rowtot[2] + rowtot[3];
+    if (l == 0) s_wtot[w] = wtot;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t t = s_wtot[q];
+        if (q < w) wbase += t;
+        total += t;
+    }
+    const bool dense = total > (uint32_t)SLOT;
+    const bool no_room = (T + 1) * (int64_t)TILE > a.out_cap;
+    if (tid == 0) {
+        a.cnt[T] = total;
+        if (dense) atomicOr(a.bad, FZ_BAD_SHAPE | FZ_BAD_INDEX);
+        else if (no_room) atomicOr(a.bad, FZ_BAD_SHAPE);
+    }
+    if (dense) { if (tid == 0) a.qphase[T] = FZ_NOPHASE; return; }
+    uint32_t j[4];                                       // entries of the tile in front of piece i
+    {
+        uint32_t rb = wbase;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t mm = m[i];
+            uint32_t idx = rb + ex[i];
+            j[i] = idx;
+            while (mm) {
+                const uint32_t p = (uint32_t)__ffs((int)mm) - 1u;
+                mm &= mm - 1u;
+                s_list[idx] = (uint16_t)(o4[i] + p);
+                idx++;
+            }
+            rb += rowtot[i];
+        }
+        uint16_t *gdst = a.ent + T * SLOT;
+        for (uint32_t jj = (uint32_t)l; jj < wtot; jj += 64) {
+            const uint32_t off = (uint32_t)s_list[wbase + jj];
+            const uint32_t nb = (uint32_t)s_data[off + 1u];
+            const uint32_t fl = (nb == a.at_char) ? (uint32_t)FL_AT : (nb == '+') ? (uint32_t)FL_PLUS : 0u;
+            const uint16_t e = (uint16_t)(off | (fl << 14));
+            s_list[wbase + jj] = e;
+            __builtin_nontemporal_store(e, gdst + wbase + jj);
+        }
+    }
+    __syncthreads();                                   // the list, flags included, is complete
+    const int tot = (int)total;
+    uint32_t phase = FZ_ALL;
+    {
+        const uint32_t f1 = (uint32_t)s_list[min(l, max(tot - 1, 0))] >> 14;
+        const uint32_t f2 = (uint32_t)s_list[min(l + 1, max(tot - 1, 0))] >> 14;
+        const unsigned long long hit = __ballot(l + 1 < tot && f1 == 0u && f2 == (uint32_t)FL_PLUS);
+        if (hit) phase = (uint32_t)((__ffsll((long long)hit) - 1 + 2) & 3);     // the line behind entry i is S: Q lines follow entries = i + 2 (mod 4)
+    }
+    if (phase == FZ_ALL) {
+        // LONG LINES (a tile inside one line, or with a newline or two): no such pair.  Second-rate evidence, good enough
+        // for a guess that is verified like the first kind: 64 bytes of nothing but bases at the tile's beginning (its end)
+        // are a stretch of a sequence line -- the line behind entry -1 (behind the tile's last entry) is S.  A tile inside
+        // a quality line finds neither and writes everything, which is what it would have written anyway.
+        const int at = (l < 4) ? 16 * l : TILE - 64 + 16 * (l & 3);
+        const uint4 x = *reinterpret_cast<const uint4 *>(s_data + at);
+        const bool b = all_bases4(x.x) && all_bases4(x.y) && all_bases4(x.z) && all_bases4(x.w);
+        const unsigned long long ok = __ballot(b);
+        if ((ok & 0xFull) == 0xFull) phase = 1u;
+        else if ((ok & 0xF0ull) == 0xF0ull) phase = (uint32_t)(tot + 1) & 3u;
+    }
+    if (tid == 0) a.qphase[T] = (uint8_t)phase;
+    if (no_room) return;
+    const uint32_t vv = (uint32_t)(uint8_t)a.qadd * 0x01010101u;
+    int8_t *seg = a.out + tbase;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        // the piece's first byte belongs to the line behind entry j - 1, its last to the one behind entry j - 1 + c
+        const uint32_t r = (j[i] - 1u - phase) & 3u;
+        bool q = phase == FZ_ALL || r == 0u || r + c[i] >= 4u;
+        // whole 64-byte blocks (four lanes): at 150-base reads 2.84 TB/s against 1.93 with single pieces, 2.11 with 32-byte
+        // pairs and 2.72 with 128 bytes -- partly written blocks cost more than the extra bytes
+        // (profiles/r05_probes/single_pass_in_place.txt)
+        q |= __shfl_xor((int)q, 1) != 0;
+        q |= __shfl_xor((int)q, 2) != 0;
+        if (q) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(s_data + o4[i]);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 t; t.x = addb4(x.x, vv); t.y = addb4(x.y, vv); t.z = addb4(x.z, vv); t.w = addb4(x.w, vv);
+            __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(seg + o4[i]));
+        }
+    }
+}
+
 }  // namespace ffq

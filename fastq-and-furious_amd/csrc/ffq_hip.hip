@@ -61,6 +61,8 @@ struct ScanState {
     bool dense4 = false;      // the fast path's row kernel is the DENSE instantiation (it met a dense tile on this buffer, or the context remembers one)
     bool fused = false;       // the front is the single-pass index + decode kernel (ffq_fused.h)
     bool no_fused = false;    // ... which did not stand on this buffer: the two-pass kernels take it
+    bool in_place = false;    // the single pass of this front writes in place (k_scan_ident) rather than segments (k_scan_seg)
+    bool seg_refused = false; // the segmented single pass met a shape it cannot take (a long line): the in-place one is next
     unsigned long long poll_seq = 0;   // FFQ_F_POLL_RESULT: the front ends in a publisher that writes this number; no end event
     bool go_ranked = false;   // the front is the index kernel only: the list-ranking tier follows at the wait
     bool index_done = false;  // the line index of this buffer is built (a later tier re-uses it)
@@ -106,7 +108,8 @@ struct ffq_ctx {
     uint8_t *fz_qphase = nullptr;
     int64_t fz_tiles_cap = 0;
     uint32_t *fz_bad = nullptr;
-    int fused_skip = 0, fused_backoff = 15;   // scans left that do not try it (it failed: long lines, odd records), and the next count
+    int fused_skip = 0, fused_backoff = 15;   // scans left that do not try it (it failed: odd records), and the next count
+    bool fz_in_place = false;                 // the last single pass that stood wrote in place (long lines): start with that one
     bool decode_timed = false;           // ev[6] marks the start of the decode kernel of the pending front
     // scratch, grow-only
     int64_t cap_tiles = 0;
@@ -467,7 +470,7 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 
 extern "C" void ffq_ctx_forget(ffq_ctx *c)
 {
-    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->lite_skip = 0; c->dense4_remember = false; c->ranked_skip = 0; c->fused_skip = 0; c->fused_backoff = 15; }
+    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->lite_skip = 0; c->dense4_remember = false; c->ranked_skip = 0; c->fused_skip = 0; c->fused_backoff = 15; c->fz_in_place = false; }
 }
 
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
@@ -608,7 +611,7 @@ static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles);
 
 static_assert(SG_STRIDE == FFQ_SEG_STRIDE, "include/ffq.h and csrc/ffq_fused.h disagree on the segment stride");
 
-static int enqueue_fused_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
+static int enqueue_fused_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles, bool in_place)
 {
     if (ntiles > c->fz_tiles_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -627,7 +630,8 @@ static int enqueue_fused_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
     fa.out = a.d_qual; fa.out_cap = a.qual_cap; fa.qadd = a.qual_add; fa.at_char = (uint32_t)'@';
     fa.Lval = make_index(c, a, ntiles); fa.d_L = c->d_L;      // (the device copy of the index descriptor, as k_scan_lines leaves it)
     HIPCHK(hipEventRecord(c->ev[0], sA));
-    hipLaunchKernelGGL(k_scan_seg, dim3((unsigned)ntiles), dim3(256), 0, sA, fa);
+    if (in_place) hipLaunchKernelGGL(k_scan_ident, dim3((unsigned)ntiles), dim3(256), 0, sA, fa);
+    else hipLaunchKernelGGL(k_scan_seg, dim3((unsigned)ntiles), dim3(256), 0, sA, fa);
     HIPCHK(hipEventRecord(c->ev[1], sA));
     return FFQ_OK;
 }
@@ -820,15 +824,19 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
 
     // ---- four-line input with the decode: index AND decoded stream in one pass over the bytes ---------
     st.fused = false;
-    // (the segmented layout needs SG_STRIDE bytes of the caller's buffer per tile and is written in whole 16-byte pieces: an
-    // unaligned d_qual gets the packed stream)
+    // (two layouts, both "record i at d_qual + d_qoff[i]", include/ffq.h: SEGMENTED -- SG_STRIDE bytes of the caller's buffer
+    // per tile, lines up to SG_EXT bytes behind a tile's end -- and IN PLACE -- TILE bytes per tile, lines of any length, a
+    // few per cent slower on short reads (more bytes written); both write whole 16-byte pieces: an unaligned d_qual gets the
+    // packed stream.  The segmented one first; once it has refused a buffer for its shape the in-place one, which the
+    // context then remembers.)
+    st.in_place = (c->fz_in_place || st.seg_refused) && a.qual_cap >= ntiles * (int64_t)TILE;
     if (decode && (a.flags & FFQ_F_SINGLE_PASS) && try_fast4 && !st.index_done && !st.no_fused && a.offset < 16 &&
-        a.qual_cap >= ntiles * (int64_t)SG_STRIDE && (reinterpret_cast<uintptr_t>(a.d_qual) & 15) == 0) {
+        (st.in_place || (!st.seg_refused && a.qual_cap >= ntiles * (int64_t)SG_STRIDE)) && (reinterpret_cast<uintptr_t>(a.d_qual) & 15) == 0) {
         if (c->fused_skip > 0) c->fused_skip--;
         else st.fused = true;
     }
     if (st.fused) {
-        int rc = enqueue_fused_index(c, a, ntiles);
+        int rc = enqueue_fused_index(c, a, ntiles, st.in_place);
         if (rc) return rc;
         const unsigned int *presum = nullptr;
         if (nsb > 2048) {
@@ -837,10 +845,11 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
             presum = c->sbq;
         }
         hipLaunchKernelGGL(k_sbscan, dim3(1), dim3(1024), 0, sA, L, nsb, c->sbbase, a.offset, c->hdr4, presum);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows4<true, false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
+        auto rows4 = st.in_place ? k_rows4<2, false> : k_rows4<1, false>;
+        hipLaunchKernelGGL(rows4, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L,
                            (const long long *)c->sbbase, a.eof, a.add, c->hdr4, c->tinfo4, a.d_table, a.table_cap,
                            (uint32_t *)nullptr, c->tileq, (int64_t *)nullptr, a.table_cap,
-                           (int64_t)SG_STRIDE, (const uint8_t *)c->fz_qphase, a.d_qoff);
+                           (int64_t)(st.in_place ? TILE : SG_STRIDE), (const uint8_t *)c->fz_qphase, a.d_qoff);
         hipLaunchKernelGGL(k_finalize4, dim3(1), dim3(64), 0, sA, L, c->hdr4, (const TermInfo4 *)c->tinfo4, a.eof,
                            a.offset, a.add, (const int64_t *)a.d_table, a.table_cap, c->dres, no_pub(c), (const uint32_t *)c->fz_bad);
         hipLaunchKernelGGL(k_qtotal4, dim3(1), dim3(1), 0, sA, c->dres, (const int64_t *)a.d_table, a.table_cap,
@@ -1104,7 +1113,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         if (st.stage == 1) {
             if (!c->h_res->fallback) {
                 fill_result(res, *c->h_res, st.fused ? 6 : 3, st.retries);
-                if (st.fused) c->fused_backoff = 15;
+                if (st.fused) { c->fused_backoff = 15; c->fz_in_place = st.in_place; }
                 break;
             }
             if (st.fused) {
@@ -1114,9 +1123,20 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 if (PROBES && getenv("FFQ_DEBUG")) {
                     Fast4Hdr hh;
                     HIPCHK(hipMemcpy(&hh, c->hdr4, sizeof hh, hipMemcpyDeviceToHost));
-                    fprintf(stderr, "[ffq debug] single pass refused: fused_bad %d attempt %d j0 %lld irr_min %llu term_min %llu\n",
-                            c->h_res->fused_bad, hh.attempt, hh.j0, hh.irr_min, hh.term_min);
+                    fprintf(stderr, "[ffq debug] single pass (%s) refused: fused_bad %d attempt %d j0 %lld irr_min %llu term_min %llu\n",
+                            st.in_place ? "in place" : "segmented", c->h_res->fused_bad, hh.attempt, hh.j0, hh.irr_min, hh.term_min);
                 }
+                if (!st.in_place && !st.seg_refused && (c->h_res->fused_bad & (int32_t)FZ_BAD_SHAPE) &&
+                    !(c->h_res->fused_bad & (int32_t)FZ_BAD_INDEX) && a.qual_cap >= st.ntiles * (int64_t)TILE) {
+                    // a shape the segments cannot take (a line longer than SG_EXT behind a tile, no S P pair in a tile
+                    // of a few long lines) and the caller's buffer has room for the in-place layout: that pass next
+                    st.seg_refused = true;
+                    st.fused = false;
+                    st.index_done = false;          // (that pass builds the index itself)
+                    st.retries++;
+                    continue;
+                }
+                c->fz_in_place = false;
                 st.no_fused = true;
                 st.fused = false;
                 c->fused_skip = c->fused_backoff;

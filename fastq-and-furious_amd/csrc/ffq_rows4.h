@@ -238,7 +238,8 @@ __global__ __launch_bounds__(1024) void k_sbscan(LineIndex L, int nsb, long long
 // headers, the shape of /root/reference/tests.py:8-35), their entries read from the overflow pool a chunk of SLOT list elements
 // at a time -- the closed form over newline ordinals does not care how close the newlines are.  The usual instantiation refuses
 // such a tile (Fast4Hdr::dense_seen) and is the same code as before; the host runs this one for a context that has met one.
-template <bool FUSED, bool DENSE>
+constexpr uint8_t FZ_ALL = 0xFE;      // fz_phase of a tile that wrote all of its bytes (k_scan_ident, ffq_fused.h)
+template <int FUSED, bool DENSE>
 __global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const long long *__restrict__ sbbase, int eof,
                                                int64_t add, Fast4Hdr *hdr, TermInfo4 *__restrict__ tinfo,
                                                int64_t *__restrict__ table, int64_t table_cap,
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const
     const uint2 vla_raw = *reinterpret_cast<const uint2 *>(L.ent + (int64_t)tn * SLOT + 4 * (lane & 1));
     const uint32_t cb_raw = L.cnt[min(t0 + lane, L.ntiles - 1)];     // SB_TILES == 64 lanes
     const long long sbb = sbbase[sb];
-    constexpr bool fused = FUSED;
+    constexpr bool fused = FUSED != 0, in_place = FUSED == 2;
     uint32_t fzph = 0;
     if (fused) fzph = fz_phase[t];
     // pin the loads here: without a use in front of the early exits below the compiler sinks
@@ -312,7 +313,9 @@ __global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const
         // tile without a newline starts no line: nothing was decoded for it.)  The chain must start at the
         // buffer's very first newline (nothing in front of it that could pass for a quality line).
         const uint32_t want = (uint32_t)(((j0 + 3 - ob) % 4 + 4) % 4);
-        if (((c > 0 && fzph != want) || j0 != 0) && lane == 0) atomicMin(&hdr->irr_min, 0ull);
+        // (in place: a tile that wrote all of its bytes assumed nothing)
+        const bool wrong = in_place ? (fzph != (uint32_t)FZ_ALL && fzph != want) : (c > 0 && fzph != want);
+        if ((wrong || j0 != 0) && lane == 0) atomicMin(&hdr->irr_min, 0ull);
     }
     // the sentinel is entry -1 of tile 0 (ordinal 0): give tile 0 a list that starts with it
     const int pre = (t == 0 && L.s) ? 1 : 0;
@@ -592,7 +595,10 @@ __global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const
             if (__ballot(act && (cls == 2 || cls == 3)) != 0ull) tile_term_done = true;      // (wave-uniform)
             // rows: COMPLETE records (cls 0, 3) and the final record
             const bool emit = act && (cls == 0 || cls == 3 || (cls == 2 && fin));
-            if (fused) {
+            if (in_place) {
+                // the record's bytes lie where they lie in the input: pos4 in the coordinates of d
+                if (emit && kfirst_ch + r < p4_cap) fz_qoff[kfirst_ch + r] = ((long long)t << TILE_SHIFT) + f4;
+            } else if (fused) {
                 // start of the record's bytes in the decoded stream = quality bytes in front of pos4
                 const uint32_t ql = emit ? (uint32_t)(f5 - f4) : 0u;
                 const uint32_t incl = wave_incl_scan(ql);

@@ -37,6 +37,7 @@ F_FORCE_RANKED = 4
 F_POLL_RESULT = 8
 F_SINGLE_PASS = 16
 SEG_STRIDE = 8704            # FFQ_F_SINGLE_PASS: bytes of the quality buffer every 16 KiB tile of the input owns (include/ffq.h)
+INPLACE_STRIDE = 16384       # ... and what admits the in-place layout as well (lines of any length)
 F_NO_TIMING = 32
 F_FORCE_GENERAL = 64        # tests: skip the four-line fast path
 
@@ -422,9 +423,11 @@ class Context:
         return rc, res
 
     def scan_host(self, buf, sentinel=True, offset=0, eof=True, add=None, flags=0, qual_add=-33,
-                  table_cap=None):
+                  table_cap=None, qual_room=None):
         """Record chain over a host bytes-like object.
 
+        qual_room: with F_SINGLE_PASS, bytes of the quality buffer per 16 KiB tile of input (SEG_STRIDE; INPLACE_STRIDE
+        admits the in-place layout, i.e. long lines, as well).
         Returns (table int64[n,6], ScanResult[, qual int8[], qoff int64[n+1]])."""
         a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
         if add is None:
@@ -435,7 +438,7 @@ class Context:
             table = np.empty((cap, 6), dtype=np.int64)
             nq = a.size if decode else 0
             if decode and (flags & F_SINGLE_PASS):
-                nq = max(nq, ((a.size + 16383) >> 14) * SEG_STRIDE)        # the segmented layout: room for every tile's segment
+                nq = max(nq, ((a.size + 16383) >> 14) * int(qual_room or SEG_STRIDE))     # room for every tile's segment
             qual = np.empty(nq, dtype=np.int8)
             qoff = np.empty(cap + 1 if decode else 0, dtype=np.int64)
             res = ScanResult()

@@ -74,18 +74,24 @@ extern "C" {
                                       marker less per scan (~3 us of idle GPU); ms_chain / ms_total are
                                       not measured then.  Ignored with FFQ_F_DECODE_QUAL.              */
 
-#define FFQ_F_SINGLE_PASS  16u     /* with FFQ_F_DECODE_QUAL: the caller accepts the decoded qualities SEGMENTED instead of packed --
+#define FFQ_F_SINGLE_PASS  16u     /* with FFQ_F_DECODE_QUAL: the caller accepts the decoded qualities WITH GAPS instead of packed --
                                       the bytes of record i are d_qual[d_qoff[i] : d_qoff[i] + (pos5 - pos4)], contiguous and in
                                       file order, but there may be gaps between records (d_qoff[i + 1] - d_qoff[i] is NOT a
                                       length; n_qual_bytes = where the last record's bytes end).  On plain four-line input the
-                                      line-index pass itself then writes them (csrc/ffq_fused.h; res.path 6): every 16 KiB of
-                                      input owns FFQ_SEG_STRIDE bytes of d_qual, the input is read ONCE -- HBM traffic 1.0 x the
-                                      algorithmic bytes instead of 1.5 x.  qual_cap must be at least FFQ_SEG_STRIDE per 16 KiB
-                                      tile of the buffer (rounded up), else -- or when the input is not what the single pass can
-                                      vouch for: wrapped records, lines longer than 512 bytes behind a tile's end, a quality line
-                                      longer than its read -- the two passes run and the output is packed (a special case of
-                                      the same contract).                                                                      */
+                                      line-index pass itself then writes them (csrc/ffq_fused.h; res.path 6) and the input is
+                                      read ONCE -- HBM traffic 1.0 x the algorithmic bytes instead of 1.5 x -- in one of two
+                                      layouts, by the room the caller gives:
+                                        qual_cap >= FFQ_SEG_STRIDE per 16 KiB tile of the buffer (rounded up): SEGMENTED, every
+                                          tile owns that many bytes of d_qual and packs the quality lines that start in it
+                                          there; lines up to 512 bytes behind a tile's end (reads of a few hundred bases);
+                                        qual_cap >= FFQ_INPLACE_STRIDE per tile: also IN PLACE, d_qoff[i] = the offset pos4 has
+                                          in d_buf -- lines of any length (long reads); taken when the segmented pass refuses
+                                          the buffer for its shape, and first from then on (until ffq_ctx_forget).
+                                      Less room -- or input the single pass cannot vouch for: wrapped records, a quality line
+                                      longer than its read, text in front of the first record -- and the two passes run: the
+                                      output is packed (a special case of the same contract).                                */
 #define FFQ_SEG_STRIDE     8704
+#define FFQ_INPLACE_STRIDE 16384
 #define FFQ_F_NO_TIMING    32u     /* with FFQ_F_POLL_RESULT: no timing marks around the line-index kernel either (ms_index is
                                       0 for this scan): the front then holds no stream marker at all.  Where the library itself
                                       can prove that the order does not matter it also dispatches the index kernel without a

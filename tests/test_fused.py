@@ -16,11 +16,11 @@ from test_gpu_parity import decode_same as _decode_same, random_records
 pytestmark = pytest.mark.gpu
 
 
-def decode_same(ctx, hipmod, oracle, data, flags=0, **kw):
+def decode_same(ctx, hipmod, oracle, data, flags=0, qual_room=None, **kw):
     """Table, offsets of every record's bytes and the bytes themselves against the oracle; the stream may have gaps."""
     want, *_ = oracle.scan(data, **kw)
     wq, wqoff = oracle.decode_quals(data, want)
-    table, res, qual, qoff = ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS | flags, **kw)
+    table, res, qual, qoff = ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS | flags, qual_room=qual_room, **kw)
     assert table.shape == want.shape and (table == want).all()
     n = len(want)
     lens = want[:, 5] - want[:, 4] if n else np.zeros(0, np.int64)
@@ -247,3 +247,131 @@ def test_quality_add_values_wrap_like_arrayadd_b(gpu_ctx, hipmod, oracle, value)
         assert (table == want).all() and res.path == (6 if flags else 3)
         idx = np.repeat(qoff[:3000] - wqoff[:3000], lens) + np.arange(wq.size)
         assert (qual[idx] == wq).all()
+
+
+# ---- the in-place layout (k_scan_ident): room for FFQ_INPLACE_STRIDE bytes per tile admits lines of any length ----------
+
+def long_records(rng, n, lo, hi, base_quals=0.0):
+    """Four-line records with reads of lo..hi bases; qualities over the whole printable range ('@' and '+' at line starts
+    included), or -- with probability base_quals -- made of base letters only."""
+    qa = np.frombuffer(bytes(range(33, 127)), dtype=np.uint8)
+    ba = np.frombuffer(b"ACGTNacgtn", dtype=np.uint8)
+    parts = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        h = b"r%d " % i + b"x" * int(rng.integers(0, 60))
+        seq = rng.choice(ba[:5], size=L).tobytes()
+        qual = rng.choice(ba if rng.random() < base_quals else qa, size=L).tobytes()
+        parts.append(b"@" + h + b"\n" + seq + b"\n+" + (h if rng.random() < 0.2 else b"") + b"\n" + qual + b"\n")
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("n,lo,hi", ((3000, 300, 700), (600, 2000, 6000), (60, 30000, 90000), (400, 50, 40000), (3, 200000, 300000)))
+def test_in_place_takes_long_lines(gpu_ctx, hipmod, oracle, n, lo, hi):
+    rng = np.random.default_rng(n + lo)
+    data = long_records(rng, n, lo, hi)
+    room = hipmod.INPLACE_STRIDE
+    gpu_ctx.forget()
+    res = decode_same(gpu_ctx, hipmod, oracle, data, qual_room=room)
+    assert res.path == 6 and res.retries == 1            # (the segmented pass refused the shape first)
+    res = decode_same(gpu_ctx, hipmod, oracle, data, qual_room=room)
+    assert res.path == 6 and res.retries == 0            # ... and the context remembers
+    # in place means in place: record i's bytes lie at the offset pos4 has in the buffer
+    table, res, qual, qoff = gpu_ctx.scan_host(data, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS, qual_room=room)
+    assert res.path == 6 and (qoff[:-1] == table[:, 4]).all()
+    for cut in (data[:-1], data[:len(data) * 2 // 3]):
+        for eof in (True, False):
+            gpu_ctx.forget()
+            decode_same(gpu_ctx, hipmod, oracle, cut, qual_room=room, eof=eof)
+    gpu_ctx.forget()
+    assert decode_same(gpu_ctx, hipmod, oracle, data).path == 3          # room for segments only: the two passes, as before
+    gpu_ctx.forget()
+
+
+def test_in_place_guess_is_verified(gpu_ctx, hipmod, oracle):
+    """A tile inside one long line takes 64 bytes of base letters at its beginning (end) for a stretch of a sequence line;
+    quality lines made of base letters are false evidence: the pass must be refused, not wrong."""
+    rng = np.random.default_rng(80)
+    room = hipmod.INPLACE_STRIDE
+    data = long_records(rng, 60, 20000, 50000, base_quals=0.3)
+    gpu_ctx.forget()
+    res = decode_same(gpu_ctx, hipmod, oracle, data, qual_room=room)
+    assert res.path == 3
+    decode_same(gpu_ctx, hipmod, oracle, data, qual_room=room)
+    good = long_records(rng, 300, 3000, 9000)
+    cases = {
+        "long-quality-line": good[:1500000].rsplit(b"\n@", 1)[0] + b"\n@odd\nACGT\n+\nIIIIIIII\n" + good[:600000],
+        "leading-text": b"# produced by a tool\n# and a second line\n# third\n# fourth\n# fifth\n" + good,
+        "blank-line": good[:1000000].rsplit(b"\n@", 1)[0] + b"\n\n" + good[:500000],
+        "one-wrapped": good[:900000].rsplit(b"\n@", 1)[0] + b"\n@w\nACGTAC\nGTAC\n+\nIIIIII\nIIII\n" + good[:700000],
+        "short-lines-in-between": good[:900000].rsplit(b"\n@", 1)[0] + b"\n" + random_records(rng, 3000, 1, 9, hdr_hi=3) + good[:700000],
+    }
+    for name, d in cases.items():
+        gpu_ctx.forget()
+        res = decode_same(gpu_ctx, hipmod, oracle, d, qual_room=room)
+        assert res.path != 6, name
+        decode_same(gpu_ctx, hipmod, oracle, d, qual_room=room)
+    gpu_ctx.forget()
+
+
+def test_in_place_then_short_reads_again(gpu_ctx, hipmod, oracle):
+    """The context starts with the layout that stood last; forget() goes back to segments (fewer bytes written on short reads)."""
+    from fastqandfurious_amd import synth
+    rng = np.random.default_rng(81)
+    room = hipmod.INPLACE_STRIDE
+    longs = long_records(rng, 40, 30000, 60000)
+    plain = synth.single(0, 20000, seed=42)
+    gpu_ctx.forget()
+    assert decode_same(gpu_ctx, hipmod, oracle, longs, qual_room=room).path == 6
+    table, res, qual, qoff = gpu_ctx.scan_host(plain, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS, qual_room=room)
+    assert res.path == 6 and (qoff[:-1] == table[:, 4]).all()            # in place, remembered
+    decode_same(gpu_ctx, hipmod, oracle, plain, qual_room=room)
+    gpu_ctx.forget()
+    table, res, qual, qoff = gpu_ctx.scan_host(plain, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS, qual_room=room)
+    assert res.path == 6 and not (qoff[:-1] == table[:, 4]).all()        # segments
+    gpu_ctx.forget()
+
+
+def test_in_place_at_size_past_4g(gpu_ctx, hipmod, oracle):
+    """6 GiB of long reads (500 ... 40000 bases, a 32 MiB block of distinct records repeated on the device), one pass, in
+    place: EVERY row against the oracle's rows of the block (+ the repeat's offset), every record's offset = pos4, every
+    quality byte of every repeat against the block's own bytes - 33."""
+    import torch
+    rng = np.random.default_rng(90)
+    parts, tot, i = [], 0, 0
+    qa = np.frombuffer(bytes(range(33, 127)), dtype=np.uint8)
+    while tot < (32 << 20):
+        L = int(np.exp(rng.uniform(np.log(500), np.log(40000))))
+        r = (b"@read%d len=%d\n" % (i, L) + rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L).tobytes() + b"\n+\n" +
+             rng.choice(qa, size=L).tobytes() + b"\n")
+        parts.append(r); tot += len(r); i += 1
+    block = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    rows, end, status, off = oracle.scan(block)
+    assert len(rows) == i and end == 0
+    reps = (6 << 30) // block.size + 1
+    dev = torch.device("cuda:0")
+    d = torch.from_numpy(block.copy()).to(dev).repeat(reps)
+    n = i * reps
+    table = torch.empty((n + 64, 6), dtype=torch.int64, device=dev)
+    ntiles = (d.numel() + 16383) >> 14
+    qual = torch.zeros(ntiles * hipmod.INPLACE_STRIDE, dtype=torch.int8, device=dev)
+    qoff = torch.zeros(n + 65, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()          # (torch's stream; the scan runs on the context's)
+    gpu_ctx.forget()
+    rc, res = gpu_ctx.scan_device(d.data_ptr(), d.numel(), table.data_ptr(), n + 64, flags=hipmod.F_DECODE_QUAL | hipmod.F_SINGLE_PASS,
+                                  d_qual=qual.data_ptr(), qual_cap=qual.numel(), d_qoff=qoff.data_ptr())
+    assert rc == 0 and res.path == 6 and int(res.n_records) == n and res.end_state == 0
+    assert d.numel() > (1 << 32)
+    want = torch.from_numpy(rows).to(dev)
+    shift = (torch.arange(reps, device=dev, dtype=torch.int64) * block.size).view(reps, 1, 1)
+    assert bool((table[:n].view(reps, i, 6) == want.view(1, i, 6) + shift).all())
+    assert bool((qoff[:n] == table[:n, 4]).all())
+    assert int(qoff[n].item()) == int(res.n_qual_bytes) == int(table[n - 1, 5].item())
+    mask = np.zeros(block.size, dtype=bool)
+    for a, b in zip(rows[:, 4], rows[:, 5]):
+        mask[a:b] = True
+    at = torch.from_numpy(np.nonzero(mask)[0]).to(dev)
+    src = (torch.from_numpy(block.copy()).to(dev)[at].to(torch.int16) - 33).to(torch.int8)
+    for r in range(reps):
+        assert bool((qual[r * block.size:(r + 1) * block.size][at] == src).all()), r
+    gpu_ctx.forget()

@@ -14,6 +14,7 @@ for seqlen in (10000, 200):
     data = np.frombuffer(b"\n" + rec * n, dtype=np.uint8)
     d = torch.from_numpy(data.copy()).cuda()
     table = torch.empty((n + 64, 6), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()        # (the context's stream does not wait for torch's: include/ffq.h)
     ctx.reserve(d.numel())
     ms = []
     for i in range(6):

@@ -18,6 +18,7 @@ for L in (20, 36, 50, 100, 151, 250, 1000, 10000, 100000, 1000000):
     d = torch.from_numpy(data.copy()).cuda()
     cap = n + 64
     table = torch.empty((cap, 6), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()        # (the context's stream does not wait for torch's: include/ffq.h)
     ctx.reserve(d.numel())
     ms = []
     for i in range(5):

@@ -28,6 +28,7 @@ for L in Ls:
         n *= reps
     cap = n + 64
     table = torch.empty((cap, 6), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()        # (the context's stream does not wait for torch's: include/ffq.h)
     ctx.reserve(d.numel()); ctx.forget()
     ms = []
     for i in range(4):
