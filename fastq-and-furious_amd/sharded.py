@@ -343,8 +343,11 @@ class FileShard:
     default cut points are shard_bounds' -- 16-byte aligned, even shares --, bounds= names others)."""
 
     def __init__(self, ctx, path, rank=0, world=1, comm=None, start=0, end=None, tail_bytes=TAIL_BYTES,
-                 head_bytes=HEAD_BYTES, device=None, bounds=None):
+                 head_bytes=HEAD_BYTES, device=None, bounds=None, qual_room=None):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        # scan(decode=True): bytes of the quality buffer per 16 KiB tile of the view -- hip.SEG_STRIDE (reads of a few hundred
+        # bases in one pass) unless given; hip.INPLACE_STRIDE lets four-line reads of any length decode in one pass as well
+        self.qual_room = int(qual_room) if qual_room else _hip.SEG_STRIDE
         self._own_fd = not isinstance(path, int)
         self.fd = os.open(path, os.O_RDONLY) if self._own_fd else path
         self.path = path
@@ -403,7 +406,7 @@ class FileShard:
         elif decode and not self.d_qoff:
             self.d_qoff = c.dev_alloc((self.table_cap + 1) * 8)
         if decode:
-            need = max(self.n_view // 2 + 64, -(-(self.n_view + 16) // 16384) * _hip.SEG_STRIDE, qneed)
+            need = max(self.n_view // 2 + 64, -(-(self.n_view + 16) // 16384) * self.qual_room, qneed)
             if need > self.qual_cap:
                 if self.d_qual:
                     c.dev_free(self.d_qual)
