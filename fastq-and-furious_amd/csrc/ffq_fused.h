@@ -211,19 +211,39 @@ __global__ __launch_bounds__(256, 8) void k_scan_seg(SegArgs a)
         if (hit) phase = (uint8_t)((__ffsll((long long)hit) - 1 + 2) & 3);     // the line behind entry i is S: Q lines follow entries = i + 2 (mod 4)
     }
     if (phase == FZ_NOPHASE && tot > 0 && T > 0) {
-        // RARE (a short last tile; a tile of a few long lines): no S P pair among the tile's own lines -- look for
-        // one among the lines in front of it.  Every lane walks the same bytes back from the tile's first (a scalar
-        // loop in effect, a few microseconds for the one workgroup it concerns): newline -1, -2, ... with the
-        // class of the byte behind each; [none][+] at entries (e, e + 1) makes the line behind e the sequence line.
+        // RARE on short reads (a short last tile), EVERY tile on long ones (a tile of a few long lines -- which the pass
+        // then refuses anyway: it must get there cheaply): no S P pair among the tile's own lines -- look for one among the
+        // lines in front of it, in the 1024 bytes before the tile (round 5: the walk was one byte per memory round trip, up
+        // to 4096 of them, and a first scan of 4 GiB of 30 kbp reads spent 58 ms here before it was refused).  Every wave
+        // does the same: lane l of round k looks at the byte at distance 64 k + l + 1 and the one behind it; the newlines
+        // then go by in the order of the walk, closest first, on the scalar side: newline -1, -2, ... with the class of the
+        // byte behind each; [none][+] at entries (e, e + 1) makes the line behind e the sequence line.
         uint32_t fnext = (uint32_t)s_list[0] >> 14;            // flags of entry e + 1, starting with entry 0
         int e = -1;
-        for (int64_t p = tbase - 1; p >= 0 && p >= tbase - 4096 && phase == FZ_NOPHASE; p--) {
-            if (a.d[p] != '\n') continue;
-            const uint32_t nb = (uint32_t)a.d[p + 1];          // (p + 1 <= tbase < n)
-            const uint32_t fl = (nb == a.at_char) ? (uint32_t)FL_AT : (nb == '+') ? (uint32_t)FL_PLUS : 0u;
-            if (fl == 0u && fnext == (uint32_t)FL_PLUS) phase = (uint8_t)(((e + 2) % 4 + 4) % 4);
-            fnext = fl;
-            e--;
+        for (int k4 = 0; k4 < 4 && phase == FZ_NOPHASE; k4++) {
+            unsigned long long NL[4], PL[4], AT[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t pos = tbase - 1 - (64 * (4 * k4 + k) + l);
+                uint32_t b0 = 0, b1 = 0;
+                if (pos >= 0) { b0 = a.d[pos]; b1 = a.d[pos + 1]; }          // (pos + 1 <= tbase < n)
+                NL[k] = __ballot(b0 == '\n');
+                PL[k] = __ballot(b0 == '\n' && b1 == '+');
+                AT[k] = __ballot(b0 == '\n' && b1 == a.at_char);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned long long N = NL[k];
+                while (N != 0ull && phase == FZ_NOPHASE) {
+                    const int i = __ffsll((long long)N) - 1;
+                    N &= N - 1ull;
+                    const uint32_t fl = ((AT[k] >> i) & 1ull) ? (uint32_t)FL_AT : ((PL[k] >> i) & 1ull) ? (uint32_t)FL_PLUS : 0u;
+                    if (fl == 0u && fnext == (uint32_t)FL_PLUS) phase = (uint8_t)(((e + 2) % 4 + 4) % 4);
+                    fnext = fl;
+                    e--;
+                }
+            }
+            if (tbase - 1 - 256 * (k4 + 1) < 0) break;
         }
     }
     // (a tile without any newline starts no line: nothing to decode, nothing to vouch for)
@@ -275,7 +295,9 @@ __global__ __launch_bounds__(256, 8) void k_scan_seg(SegArgs a)
     if (tid == 0) {
         s_qs[NQ] = (uint16_t)min(qcount, 0xFFFF);
         a.qphase[T] = (any_bad || phase == FZ_NOPHASE) ? FZ_NOPHASE : phase;
-        if (bad_here) atomicOr(a.bad, FZ_BAD_SHAPE);
+        // (every tile of a buffer of long reads says the same: look before storing -- tens of thousands of atomics onto one
+        // address are milliseconds)
+        if (bad_here && !(__hip_atomic_load(a.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FZ_BAD_SHAPE)) atomicOr(a.bad, FZ_BAD_SHAPE);
     }
     __syncthreads();
     if (bad_here || qcount <= 0) return;

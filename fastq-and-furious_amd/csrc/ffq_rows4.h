@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const
         const uint32_t want = (uint32_t)(((j0 + 3 - ob) % 4 + 4) % 4);
         // (in place: a tile that wrote all of its bytes assumed nothing)
         const bool wrong = in_place ? (fzph != (uint32_t)FZ_ALL && fzph != want) : (c > 0 && fzph != want);
-        if ((wrong || j0 != 0) && lane == 0) atomicMin(&hdr->irr_min, 0ull);
+        // (look before storing: a refused buffer says so from every tile)
+        if ((wrong || j0 != 0) && lane == 0 && hdr->irr_min != 0ull) atomicMin(&hdr->irr_min, 0ull);
     }
     // the sentinel is entry -1 of tile 0 (ordinal 0): give tile 0 a list that starts with it
     const int pre = (t == 0 && L.s) ? 1 : 0;

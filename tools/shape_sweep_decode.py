@@ -1,5 +1,6 @@
 """Four-line records across read lengths, with and without the Phred decode (packed / single pass): where the decode's
-single pass (csrc/ffq_fused.h) stops taking the input (lines longer than its 512-byte look into the next tile)."""
+single pass (csrc/ffq_fused.h) changes layout (segments: lines up to 512 bytes behind a tile's end; in place: any).
+tools/shape_sweep_decode.py [bytes] [L,L,...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,7 +9,8 @@ from fastqandfurious_amd import hip
 ctx = hip.Context(0)
 rng = np.random.default_rng(0)
 size = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 30)
-for L in (150, 250, 400, 600, 1000, 3000, 10000, 30000):
+LS = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (150, 250, 400, 600, 1000, 3000, 10000, 30000)
+for L in LS:
     # variable lengths around L (0.5 L .. 1.5 L), a 32 MiB block of distinct records repeated on the device
     parts, tot, i = [], 0, 0
     while tot < (32 << 20):
