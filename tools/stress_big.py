@@ -13,7 +13,7 @@ nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 bad = 0
 paths = {}
 for seed in range(nseeds):
-    rng = np.random.default_rng(70000 + seed)
+    rng = np.random.default_rng(70000 + int(os.environ.get("FFQ_STRESS_SEED0", "0")) + seed)
     kind = seed % 4
     if kind == 0:
         data = T._mess(rng, 120000, fatal=False)
