@@ -268,6 +268,8 @@ __global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const
     // them up here would put a second memory round trip in front of every wave
     const int attempt = hdr->attempt;
     const long long j0 = hdr->j0;
+    const unsigned long long irr0 = hdr->irr_min;     // (as they stand when this wave starts: they only ever fall)
+    const unsigned long long term0 = hdr->term_min;
     uint16_t *s_ent = s_ent_all[wid];
     uint32_t *s_la = s_la_all[wid];
     int32_t *s_rows = s_rows_all[wid];
@@ -302,6 +304,12 @@ __global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const
     // global ordinal of entry 0 of this tile (the sentinel, if any, is ordinal 0)
     const long long ob = sbb + (long long)wave_sum_u32((t0 + lane < t) ? cb_raw : 0u) + L.s;
     if (!attempt) return;
+    // An irregular record in front of everything this tile could hold: whatever the tile finds, the attempt is refused (or the
+    // chain ended before that record and none of this tile's rows is wanted): k_finalize4 accepts only irr_min > the chain's
+    // last record.  On hostile text -- every record irregular, each through the careful path below -- the refused attempt
+    // took 4.9 ms per GiB (tools/stress_huge.py); the waves that start after the first such record is known now leave here.
+    // (the same behind the chain's end, term_min = record << 24 | tile: rows behind it are nobody's)
+    if (ob - j0 > 0 && ((unsigned long long)((ob - j0) >> 2) > irr0 || (unsigned long long)((ob - j0) >> 2) > (term0 >> 24))) return;
     if (c > SLOT && (!DENSE || fused)) {     // dense tile: not this instantiation's (the DENSE one, or the general path)
         // (every dense tile says the same: look before storing -- 65536 atomics / stores onto one address took 2.9 ms)
         if (lane == 0 && (hdr->irr_min != 0ull || !hdr->dense_seen)) { atomicMin(&hdr->irr_min, 0ull); hdr->dense_seen = 1; }
@@ -567,12 +575,22 @@ __global__ __launch_bounds__(256, DENSE ? 4 : 8) void k_rows4(LineIndex L, const
                     }
                 }
                 if (fused && (cls == 0 || cls == 3 || (cls == 2 && fin)) && !(have >= 5 && POS(4) == p5)) cls = 1;   // (see above)
-                if (cls == 1) atomicMin(&hdr->irr_min, (unsigned long long)k);
-                else if (cls == 2 || cls == 3) {
+                {
+                    // the smallest k of the wave's irregular records (lanes are in k order), and only if it can lower the
+                    // minimum: a buffer of nothing but irregular records (hostile text: 5 M of them per GiB) put every one of
+                    // them through an atomic on this one address -- 5 ms of a refused attempt
+                    const unsigned long long im = __ballot(cls == 1);
+                    if (cls == 1 && lane == __ffsll((long long)im) - 1 &&
+                        (unsigned long long)k < __hip_atomic_load(&hdr->irr_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        atomicMin(&hdr->irr_min, (unsigned long long)k);
+                }
+                if (cls == 2 || cls == 3) {
                     // where the chain ends: cls 2 -> at record k (status of its call); cls 3 -> after
                     // record k: the next call finds no "\n@" at all
+                    // (look first, as above: on hostile text every other record "ends the chain")
                     const unsigned long long kk = (unsigned long long)(cls == 3 ? k + 1 : k);
-                    atomicMin(&hdr->term_min, (kk << 24) | (unsigned long long)(t & 0xFFFFFF));
+                    const unsigned long long mine = (kk << 24) | (unsigned long long)(t & 0xFFFFFF);
+                    if (mine < __hip_atomic_load(&hdr->term_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&hdr->term_min, mine);
                 }
                 // (a row that is written has all its fields; they lie within 2^31 of the tile)
                 f0 = (int32_t)(p0 - tbase); f1 = (int32_t)(p1 - tbase); f3 = (int32_t)(p3 - tbase);
