@@ -858,6 +858,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
 
 
 def main():
+    t_main = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -997,6 +998,7 @@ def main():
         import ctypes
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
+        line["wall_s"] = round(time.perf_counter() - t_main, 1)          # this process, start to line (imports and set-up included)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
