@@ -1494,13 +1494,15 @@ static int stage_fd2d(ffq_ctx *c, uint8_t *d_dst, int fd, int64_t pos, int64_t n
     bool used[3] = {false, false, false};
     const int64_t nch = (n + FSTAGE_CH - 1) / FSTAGE_CH;
     int64_t k_enq = 0, k = 0;
+    static const int ablate = (PROBES && getenv("FFQ_LOAD_ABLATE")) ? atoi(getenv("FFQ_LOAD_ABLATE")) : 0;     // 1: no copies, 2: no reads, 4: one copy stream
     bool ended = false;
     for (; k < nch && !ended && !rc; k++) {
         for (; k_enq < nch && k_enq - k < 3; k_enq++) {
             const int b = (int)(k_enq % 3);
             if (used[b]) { (void)hipEventSynchronize(c->stage_ev[b][0]); (void)hipEventSynchronize(c->stage_ev[b][1]); }
             const int64_t at = k_enq * FSTAGE_CH;
-            c->helpers->enqueue(fd, c->stage_h + b * FSTAGE_CH, std::min<int64_t>(FSTAGE_CH, n - at), pos + at, &c->stage_cr[b]);
+            if (ablate & 2) { std::lock_guard<std::mutex> lk(c->helpers->m); ChunkRead &cr = c->stage_cr[b]; cr.nsl = 1; cr.left = 0; cr.got[0] = cr.want[0] = std::min<int64_t>(FSTAGE_CH, n - at); }
+            else c->helpers->enqueue(fd, c->stage_h + b * FSTAGE_CH, std::min<int64_t>(FSTAGE_CH, n - at), pos + at, &c->stage_cr[b]);
         }
         const int b = (int)(k % 3);
         const int64_t at = k * FSTAGE_CH, want = std::min<int64_t>(FSTAGE_CH, n - at);
@@ -1508,10 +1510,10 @@ static int stage_fd2d(ffq_ctx *c, uint8_t *d_dst, int fd, int64_t pos, int64_t n
         const int64_t m = c->stage_cr[b].total();
         if (m < 0) { rc = fail(FFQ_E_ARG, "ffq_load_fd: read failed at byte %lld: %s", (long long)(pos + at), strerror(errno)); break; }
         if (m < want) ended = true;                       // the file ends here
-        const int64_t half = ((m / 2) + 4095) & ~(int64_t)4095;
+        const int64_t half = (ablate & 4) ? m : ((m / 2) + 4095) & ~(int64_t)4095;
         for (int h = 0; h < 2 && !rc; h++) {
             const int64_t a = h ? std::min(half, m) : 0, z = h ? m : std::min(half, m);
-            if (z > a) e = hipMemcpyAsync(d_dst + at + a, c->stage_h + b * FSTAGE_CH + a, (size_t)(z - a), hipMemcpyHostToDevice, c->stage_cs[h]);
+            if (z > a && !(ablate & 1)) e = hipMemcpyAsync(d_dst + at + a, c->stage_h + b * FSTAGE_CH + a, (size_t)(z - a), hipMemcpyHostToDevice, c->stage_cs[h]);
             if (e == hipSuccess) e = hipEventRecord(c->stage_ev[b][h], c->stage_cs[h]);
             if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_load_fd: chunk copy failed: %s", hipGetErrorString(e));
         }
