@@ -48,7 +48,13 @@
 #include <thread>
 #include <vector>
 
-constexpr int STREAM_SLOTS = 3;
+#ifndef FFQ_STREAM_SLOTS
+#define FFQ_STREAM_SLOTS 3
+#endif
+#ifndef FFQ_STREAM_AHEAD
+#define FFQ_STREAM_AHEAD 2
+#endif
+constexpr int STREAM_SLOTS = FFQ_STREAM_SLOTS;
 
 struct StreamSlot {
     uint8_t *h = nullptr;        // pinned  [room | fbufsize (+16)]
@@ -630,7 +636,7 @@ static void stream_feeder(ffq_stream *s)
                     s->cv.notify_all();
                     return;
                 }
-                if (s->seekable && s->src == SRC_FD && !s->pause_req && e - s->released < STREAM_SLOTS && e - p < 2) {
+                if (s->seekable && s->src == SRC_FD && !s->pause_req && e - s->released < STREAM_SLOTS && e - p < FFQ_STREAM_AHEAD) {
                     StreamSlot &sq = b->slot[e % STREAM_SLOTS];
                     lk.unlock();
                     b->pool->enqueue(s->fd, sq.h + b->room, b->fbufsize, pos0 + e * b->fbufsize, &sq.cr);
