@@ -69,6 +69,50 @@ __device__ int fa_run_parity_before(const LineIndex &L, int64_t offset, int t)
     }
 }
 
+// Round 5: the two kernels below were chains of dependent memory round trips per wave (the tile's count, the count of the
+// tile in front, its entries, then the tile's own entries 64 at a time: seven of them for the usual tile, 80 us for the
+// row kernel of a GiB whatever it held).  Now two: the counts of tile t and t - 1, then -- together -- the last 64 entries
+// of tile t - 1 (where the parity of the run in front is usually decided at once) and the tile's first 256 entries.
+struct FaPre {
+    uint32_t c, cp;            // entries of tile t, of tile t - 1
+    uint32_t e[4];             // entries 64 q + lane of tile t (q < 4), as stored; valid where the tile is not pooled
+    uint32_t ep;               // entry cp - 1 - lane of tile t - 1
+    bool own, prev;            // e[] / ep were loaded (tiles within their slots)
+};
+
+__device__ __forceinline__ FaPre fa_preload(const LineIndex &L, int t)
+{
+    const int lane = threadIdx.x & 63;
+    FaPre p;
+    p.c = L.cnt[t];
+    p.cp = t > 0 ? L.cnt[t - 1] : 0u;
+    asm volatile("" ::"v"(p.c), "v"(p.cp));
+    p.own = p.c <= (uint32_t)SLOT;
+    p.prev = t > 0 && p.cp > 0u && p.cp <= (uint32_t)SLOT;
+    const uint16_t *src = L.ent + (int64_t)t * SLOT;
+#pragma unroll
+    for (int q = 0; q < 4; q++) p.e[q] = p.own ? (uint32_t)src[min(64 * q + lane, SLOT - 1)] : 0u;
+    p.ep = p.prev ? (uint32_t)L.ent[(int64_t)(t - 1) * SLOT + max((int)p.cp - 1 - lane, 0)] : 0u;
+    asm volatile("" ::"v"(p.e[0]), "v"(p.e[1]), "v"(p.e[2]), "v"(p.e[3]), "v"(p.ep));
+    return p;
+}
+
+// fa_run_parity_before from the preloaded entries where they decide it (a run that ends inside tile t - 1's last 64
+// entries: always, but for runs of dozens of empty headers), the walk otherwise
+__device__ __forceinline__ int fa_run_parity_pre(const LineIndex &L, int64_t offset, int t, const FaPre &p)
+{
+    if (p.prev) {
+        const int lane = threadIdx.x & 63;
+        const int nvalid = (int)min(64u, p.cp);
+        const int64_t P = ((int64_t)(t - 1) << TILE_SHIFT) + (p.ep & OFF_MASK) + L.s;
+        const bool at = lane < nvalid && ((p.ep >> 14) & FL_AT) && P >= offset;
+        const unsigned long long m = __ballot(at);
+        const int k = (~m == 0ull) ? 64 : (__ffsll((long long)~m) - 1);
+        if (k < nvalid) return k & 1;
+    }
+    return fa_run_parity_before(L, offset, t);
+}
+
 // Starts among entries [j0, j0 + 64) of tile t: a "\n>" entry starts a record iff the run of
 // eligible entries right in front of it has even length.  carry = parity of the run that ends in
 // front of j0 (updated for the next chunk).  Returns this lane's answer.
@@ -105,10 +149,20 @@ __global__ __launch_bounds__(256) void k_fa_count(LineIndex L, int64_t offset, u
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= L.ntiles) return;
-    const uint32_t c = L.cnt[t];
+    const FaPre pre = fa_preload(L, t);
+    const uint32_t c = pre.c;
     uint32_t n = 0;
-    int carry = c ? fa_run_parity_before(L, offset, t) : 0;
-    for (uint32_t j0 = 0; j0 < c; j0 += 64) {
+    int carry = c ? fa_run_parity_pre(L, offset, t, pre) : 0;
+    const int64_t tbase = ((int64_t)t << TILE_SHIFT) + L.s;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (pre.own && (uint32_t)(64 * q) < c) {
+            const uint32_t j = (uint32_t)(64 * q + lane);
+            const bool at = j < c && ((pre.e[q] >> 14) & FL_AT) && tbase + (int64_t)(pre.e[q] & OFF_MASK) >= offset;
+            n += (uint32_t)__popcll(__ballot(fa_chunk_starts_of(at, (uint32_t)(64 * q), c, carry)));
+        }
+    }
+    for (uint32_t j0 = pre.own ? 256u : 0u; j0 < c; j0 += 64) {
         const bool st = fa_chunk_starts(L, offset, t, j0, c, carry);
         n += (uint32_t)__popcll(__ballot(st));
     }
@@ -126,11 +180,12 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= L.ntiles) return;
-    const uint32_t c = L.cnt[t];
     const long long ntot = *total;
+    long long rank = base[t];
+    const FaPre pre = fa_preload(L, t);
+    const uint32_t c = pre.c;
     __shared__ __attribute__((aligned(16))) int64_t s_rows_all[4][64 * 6];       // a chunk's rows, compact
     int64_t *s_rows = s_rows_all[wid];
-    long long rank = base[t];
     long long pend = -1;                  // rank of the start whose pos3 is still open (wave-uniform)
     const int64_t len = L.len();
     if (t == 0 && lane == 0) hdr->n_starts = ntot;
@@ -152,12 +207,14 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
         pend = rank;
         rank += 1;
     }
-    int carry = c ? fa_run_parity_before(L, offset, t) : 0;
+    int carry = c ? fa_run_parity_pre(L, offset, t, pre) : 0;
     const int64_t tbase = ((int64_t)t << TILE_SHIFT) + L.s;
     for (uint32_t j0 = 0; j0 < c; j0 += 64) {
         const uint32_t j = j0 + lane;
         // this lane's entry, once: eligibility, position, and (through the neighbour lane) the header's end
-        const uint32_t e = (j < c) ? fa_entry(L, t, (int)j, c) : 0u;
+        uint32_t e;
+        if (pre.own && j0 < 256u) { const uint32_t q = j0 >> 6; e = q == 0 ? pre.e[0] : q == 1 ? pre.e[1] : q == 2 ? pre.e[2] : pre.e[3]; if (j >= c) e = 0u; }
+        else e = (j < c) ? fa_entry(L, t, (int)j, c) : 0u;
         const int64_t Pe = tbase + (e & OFF_MASK);
         const bool st = fa_chunk_starts_of(j < c && ((e >> 14) & FL_AT) && Pe >= offset, j0, c, carry);
         const int64_t P = st ? Pe : 0;
