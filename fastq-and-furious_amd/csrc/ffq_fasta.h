@@ -72,10 +72,11 @@ __device__ int fa_run_parity_before(const LineIndex &L, int64_t offset, int t)
 // Round 5: the two kernels below were chains of dependent memory round trips per wave (the tile's count, the count of the
 // tile in front, its entries, then the tile's own entries 64 at a time: seven of them for the usual tile, 80 us for the
 // row kernel of a GiB whatever it held).  Now two: the counts of tile t and t - 1, then -- together -- the last 64 entries
-// of tile t - 1 (where the parity of the run in front is usually decided at once) and the tile's first 256 entries.
+// of tile t - 1 (where the parity of the run in front is usually decided at once) and the tile's first 384 entries.
+constexpr int FA_PRE = 6;        // chunks of 64 entries loaded up front: 384 entries = 16 KiB of lines of 43 bytes or more (60-column FASTA: 268)
 struct FaPre {
     uint32_t c, cp;            // entries of tile t, of tile t - 1
-    uint32_t e[4];             // entries 64 q + lane of tile t (q < 4), as stored; valid where the tile is not pooled
+    uint32_t e[FA_PRE];        // entries 64 q + lane of tile t (q < FA_PRE), as stored; valid where the tile is not pooled
     uint32_t ep;               // entry cp - 1 - lane of tile t - 1
     bool own, prev;            // e[] / ep were loaded (tiles within their slots)
 };
@@ -91,9 +92,10 @@ __device__ __forceinline__ FaPre fa_preload(const LineIndex &L, int t)
     p.prev = t > 0 && p.cp > 0u && p.cp <= (uint32_t)SLOT;
     const uint16_t *src = L.ent + (int64_t)t * SLOT;
 #pragma unroll
-    for (int q = 0; q < 4; q++) p.e[q] = p.own ? (uint32_t)src[min(64 * q + lane, SLOT - 1)] : 0u;
+    for (int q = 0; q < FA_PRE; q++) p.e[q] = p.own ? (uint32_t)src[min(64 * q + lane, SLOT - 1)] : 0u;
     p.ep = p.prev ? (uint32_t)L.ent[(int64_t)(t - 1) * SLOT + max((int)p.cp - 1 - lane, 0)] : 0u;
-    asm volatile("" ::"v"(p.e[0]), "v"(p.e[1]), "v"(p.e[2]), "v"(p.e[3]), "v"(p.ep));
+    asm volatile("" ::"v"(p.e[0]), "v"(p.e[1]), "v"(p.e[2]), "v"(p.e[3]), "v"(p.e[4]), "v"(p.e[5]), "v"(p.ep));
+    static_assert(FA_PRE == 6, "the pin above names every element");
     return p;
 }
 
@@ -155,14 +157,14 @@ __global__ __launch_bounds__(256) void k_fa_count(LineIndex L, int64_t offset, u
     int carry = c ? fa_run_parity_pre(L, offset, t, pre) : 0;
     const int64_t tbase = ((int64_t)t << TILE_SHIFT) + L.s;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < FA_PRE; q++) {
         if (pre.own && (uint32_t)(64 * q) < c) {
             const uint32_t j = (uint32_t)(64 * q + lane);
             const bool at = j < c && ((pre.e[q] >> 14) & FL_AT) && tbase + (int64_t)(pre.e[q] & OFF_MASK) >= offset;
             n += (uint32_t)__popcll(__ballot(fa_chunk_starts_of(at, (uint32_t)(64 * q), c, carry)));
         }
     }
-    for (uint32_t j0 = pre.own ? 256u : 0u; j0 < c; j0 += 64) {
+    for (uint32_t j0 = pre.own ? (uint32_t)(64 * FA_PRE) : 0u; j0 < c; j0 += 64) {
         const bool st = fa_chunk_starts(L, offset, t, j0, c, carry);
         n += (uint32_t)__popcll(__ballot(st));
     }
@@ -213,7 +215,11 @@ __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, in
         const uint32_t j = j0 + lane;
         // this lane's entry, once: eligibility, position, and (through the neighbour lane) the header's end
         uint32_t e;
-        if (pre.own && j0 < 256u) { const uint32_t q = j0 >> 6; e = q == 0 ? pre.e[0] : q == 1 ? pre.e[1] : q == 2 ? pre.e[2] : pre.e[3]; if (j >= c) e = 0u; }
+        if (pre.own && j0 < (uint32_t)(64 * FA_PRE)) {
+            const uint32_t q = j0 >> 6;
+            e = q == 0 ? pre.e[0] : q == 1 ? pre.e[1] : q == 2 ? pre.e[2] : q == 3 ? pre.e[3] : q == 4 ? pre.e[4] : pre.e[5];
+            if (j >= c) e = 0u;
+        }
         else e = (j < c) ? fa_entry(L, t, (int)j, c) : 0u;
         const int64_t Pe = tbase + (e & OFF_MASK);
         const bool st = fa_chunk_starts_of(j < c && ((e >> 14) & FL_AT) && Pe >= offset, j0, c, carry);
