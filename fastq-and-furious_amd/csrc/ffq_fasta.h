@@ -177,20 +177,22 @@ __global__ __launch_bounds__(256) void k_fa_count(LineIndex L, int64_t offset, u
 __global__ __launch_bounds__(256) void k_fa_rows(LineIndex L, int64_t offset, int64_t add,
                                                  const long long *__restrict__ base,
                                                  const long long *__restrict__ total, int64_t *__restrict__ table,
-                                                 int64_t table_cap, FaHdr *hdr)
+                                                 int64_t table_cap, FaHdr *hdr, const unsigned int *__restrict__ cnt_start)
 {
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
     if (t >= L.ntiles) return;
     const long long ntot = *total;
     long long rank = base[t];
+    const unsigned int mine = cnt_start[t];
+    if (t == 0 && lane == 0) hdr->n_starts = ntot;
+    if (mine == 0u) return;               // (no start in this tile -- most tiles of a file of long entries: nothing to write)
     const FaPre pre = fa_preload(L, t);
     const uint32_t c = pre.c;
     __shared__ __attribute__((aligned(16))) int64_t s_rows_all[4][64 * 6];       // a chunk's rows, compact
     int64_t *s_rows = s_rows_all[wid];
     long long pend = -1;                  // rank of the start whose pos3 is still open (wave-uniform)
     const int64_t len = L.len();
-    if (t == 0 && lane == 0) hdr->n_starts = ntot;
     // the sentinel start (rank 0 of tile 0)
     const bool sent_start = (t == 0 && L.s && L.n > 0 && L.d[0] == '>' && offset <= 0);
     if (sent_start) {

@@ -1687,7 +1687,7 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
         hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, sA, (const unsigned int *)c->sel_cnt, ntiles, c->sel_base,
                            (long long *)c->d_word);
         hipLaunchKernelGGL(k_fa_rows, dim3(tb), dim3(256), 0, sA, L, offset, add, (const long long *)c->sel_base,
-                           (const long long *)c->d_word, d_table, table_cap, c->fa_hdr);
+                           (const long long *)c->d_word, d_table, table_cap, c->fa_hdr, (const unsigned int *)c->sel_cnt);
         hipLaunchKernelGGL(k_fa_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sA, L, offset, add,
                            (const FaHdr *)c->fa_hdr, (const unsigned int *)c->sel_cnt, (const long long *)c->sel_base, d_table,
                            table_cap, c->dres, make_pub(c));
