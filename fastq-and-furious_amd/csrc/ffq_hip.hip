@@ -171,6 +171,8 @@ struct ffq_ctx {
     int64_t tab_h_cap = 0;
     long long *col_sum = nullptr;  // column selection: bytes per block of rows, their scan
     int64_t col_sum_cap = 0;
+    long long *scan_bs = nullptr;  // block sums of the two-level scan (launch_scan_i64v)
+    int64_t scan_bs_cap = 0;
     DevRes *col_res = nullptr;     //   its result block (row count, total bytes)
     // ffq_scan_host: pageable memory goes through three pinned staging slots, copied in by the
     // helper threads and out over two copy streams (and back the same way)
@@ -304,7 +306,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
     (void)hipFree(c->qdir); (void)hipFree(c->p4s); (void)hipFree(c->qrel);
-    (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base); (void)hipFree(c->col_sum); (void)hipFree(c->col_res);
+    (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base); (void)hipFree(c->col_sum); (void)hipFree(c->scan_bs); (void)hipFree(c->col_res);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_word) (void)hipHostFree(c->h_word);
     if (c->h_cut) (void)hipHostFree(c->h_cut);
@@ -961,6 +963,23 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
 template <class T>
 static int grow_dev(ffq_ctx *c, T **p, int64_t *cap, int64_t need);
 
+// in-place exclusive scan of nv int64 values on stream st, total into res (k_scan_i64v's contract): one workgroup for short
+// arrays, two levels for long ones
+static int launch_scan_i64v(ffq_ctx *c, hipStream_t st, long long *v, int64_t nv, int64_t n_rows, DevRes *res)
+{
+    if (nv <= 2 * 32768) {
+        hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, st, v, nv, n_rows, res);
+        return FFQ_OK;
+    }
+    const int64_t nb = (nv + SCAN_BLK - 1) / SCAN_BLK;
+    int rc = grow_dev(c, &c->scan_bs, &c->scan_bs_cap, nb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_blksum, dim3((unsigned)nb), dim3(256), 0, st, (const long long *)v, nv, c->scan_bs);
+    hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, st, c->scan_bs, nb, n_rows, res);
+    hipLaunchKernelGGL(k_scan_blkapply, dim3((unsigned)nb), dim3(256), 0, st, v, nv, (const long long *)c->scan_bs);
+    return FFQ_OK;
+}
+
 // ---- the list-ranking tier (ffq_ranked.h): exact on any input, cost per "\n@" match ----------------
 // Returns FFQ_OK with the result published, 1 if the tier cannot run here (too many candidates for
 // 32-bit ranks, no memory: the caller then takes the one-wave walker), 2 if only_if_sparse is set
@@ -977,7 +996,7 @@ static int run_ranked(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, int64_t
     if (!R.root && hipMalloc((void **)&R.root, 16) != hipSuccess) return 1;
     if (!c->col_res && hipMalloc((void **)&c->col_res, sizeof(DevRes)) != hipSuccess) return 1;
     hipLaunchKernelGGL(k_rk_count, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, sA, L, R.tbase);
-    hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, sA, R.tbase, ntiles, (int64_t)0, c->col_res);
+    if (launch_scan_i64v(c, sA, R.tbase, ntiles, (int64_t)0, c->col_res)) return 1;
     HIPCHK(hipMemcpyAsync(c->h_word, &c->col_res->n_qual_bytes, sizeof(int64_t), hipMemcpyDeviceToHost, sA));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(sA));
@@ -1032,7 +1051,7 @@ static int enqueue_offsets_and_decode(ffq_ctx *c, const ScanArgs &a, int64_t n_r
     if (rc) return rc;
     hipLaunchKernelGGL(k_col_sum, dim3((unsigned)nblk), dim3(256), 0, sA, (const int64_t *)a.d_table, n_rows, 4, 0, 5, c->col_sum);
     // (the scan's totals go into the scan's own result block: the decode kernel and the host read them there)
-    hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, sA, c->col_sum, nblk, n_rows, c->dres);
+    if ((rc = launch_scan_i64v(c, sA, c->col_sum, nblk, n_rows, c->dres))) return rc;
     hipLaunchKernelGGL(k_col_offsets, dim3((unsigned)nblk), dim3(256), 0, sA, (const int64_t *)a.d_table, n_rows, 4, 0, 5,
                        (const long long *)c->col_sum, (const DevRes *)c->dres, a.d_qoff, c->p4s, c->qdir, c->qdir_cap);
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, sA, c->dres, make_pub(c), 0);
@@ -1820,7 +1839,7 @@ extern "C" int ffq_table_gather_column(ffq_ctx *c, const uint8_t *d_buf, int64_t
     if (rc) return rc;
     hipLaunchKernelGGL(k_col_sum, dim3((unsigned)nblk), dim3(256), 0, st, d_table, n_rows, col_begin, begin_shift, col_end,
                        c->col_sum);
-    hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, st, c->col_sum, nblk, n_rows, c->col_res);
+    if ((rc = launch_scan_i64v(c, st, c->col_sum, nblk, n_rows, c->col_res))) return rc;
     hipLaunchKernelGGL(k_col_offsets, dim3((unsigned)nblk), dim3(256), 0, st, d_table, n_rows, col_begin, begin_shift,
                        col_end, (const long long *)c->col_sum, (const DevRes *)c->col_res, d_off, c->p4s, c->qdir,
                        c->qdir_cap);

@@ -905,6 +905,78 @@ __global__ __launch_bounds__(1024) void k_scan_i64v(long long *__restrict__ v, i
     if (tid == 0) { res->n_records = n_rows; res->n_qual_bytes = carry; res->fallback = 0; }
 }
 
+// The same scan in two levels for long arrays (the per-tile counts of a 4 GiB buffer: 262 144 values took the one
+// workgroup above 132 us -- eight rounds, every lane reading its own 256 bytes): k_scan_blksum, one workgroup per 2048
+// values, their sums; k_scan_i64v over the sums (it also writes the total); k_scan_blkapply, the scan inside each block
+// on top of its base.  Three launches of a few microseconds.
+constexpr int SCAN_BLK = 2048;
+
+__device__ __forceinline__ long long scan_blk_load8(const long long *__restrict__ v, int64_t nv, int64_t b0, long long (&x)[8])
+{
+    if (b0 + 8 <= nv) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const longlong2 t = *reinterpret_cast<const longlong2 *>(v + b0 + 2 * k);      // (v: hipMalloc'ed, b0 a multiple of 8)
+            x[2 * k] = t.x; x[2 * k + 1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = (b0 + k < nv) ? v[b0 + k] : 0;
+    }
+    long long s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += x[k];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_scan_blksum(const long long *__restrict__ v, int64_t nv, long long *__restrict__ bs)
+{
+    __shared__ long long s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    long long x[8];
+    long long s = scan_blk_load8(v, nv, (int64_t)blockIdx.x * SCAN_BLK + (int64_t)tid * 8, x);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) s_w[wid] = s;
+    __syncthreads();
+    if (tid == 0) bs[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void k_scan_blkapply(long long *__restrict__ v, int64_t nv, const long long *__restrict__ bs)
+{
+    __shared__ long long s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * SCAN_BLK + (int64_t)tid * 8;
+    const long long base = bs[blockIdx.x];
+    long long x[8];
+    const long long mine = scan_blk_load8(v, nv, b0, x);
+    long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    long long wpre = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q < wid) wpre += s_w[q];
+    long long run = base + wpre + incl - mine;
+    if (b0 + 8 <= nv) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            longlong2 o;
+            o.x = run; run += x[2 * k];
+            o.y = run; run += x[2 * k + 1];
+            *reinterpret_cast<longlong2 *>(v + b0 + 2 * k) = o;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { if (b0 + k < nv) v[b0 + k] = run; run += x[k]; }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_col_offsets(const int64_t *__restrict__ table, int64_t n, int ca, int shift, int cb,
                                                      const long long *__restrict__ bbase, const DevRes *__restrict__ res,
                                                      int64_t *__restrict__ coff, int64_t *__restrict__ starts,
