@@ -173,6 +173,7 @@ struct ffq_ctx {
     int64_t col_sum_cap = 0;
     long long *scan_bs = nullptr;  // block sums of the two-level scan (launch_scan_i64v)
     int64_t scan_bs_cap = 0;
+    DevRes *scan_res = nullptr;    // (the middle level's result block: nobody reads it)
     DevRes *col_res = nullptr;     //   its result block (row count, total bytes)
     // ffq_scan_host: pageable memory goes through three pinned staging slots, copied in by the
     // helper threads and out over two copy streams (and back the same way)
@@ -306,7 +307,7 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
     (void)hipFree(c->ctl); (void)hipFree(c->dres); (void)hipFree(c->d_L); (void)hipFree(c->hdr4);
     if (c->h_L) (void)hipHostFree(c->h_L);
     (void)hipFree(c->qdir); (void)hipFree(c->p4s); (void)hipFree(c->qrel);
-    (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base); (void)hipFree(c->col_sum); (void)hipFree(c->scan_bs); (void)hipFree(c->col_res);
+    (void)hipFree(c->sel_cnt); (void)hipFree(c->sel_base); (void)hipFree(c->col_sum); (void)hipFree(c->scan_bs); (void)hipFree(c->scan_res); (void)hipFree(c->col_res);
     (void)hipFree(c->stage_d); (void)hipFree(c->tab_d); (void)hipFree(c->qual_d); (void)hipFree(c->qoff_d);
     if (c->h_word) (void)hipHostFree(c->h_word);
     if (c->h_cut) (void)hipHostFree(c->h_cut);
@@ -977,6 +978,23 @@ static int launch_scan_i64v(ffq_ctx *c, hipStream_t st, long long *v, int64_t nv
     hipLaunchKernelGGL(k_scan_blksum, dim3((unsigned)nb), dim3(256), 0, st, (const long long *)v, nv, c->scan_bs);
     hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, st, c->scan_bs, nb, n_rows, res);
     hipLaunchKernelGGL(k_scan_blkapply, dim3((unsigned)nb), dim3(256), 0, st, v, nv, (const long long *)c->scan_bs);
+    return FFQ_OK;
+}
+
+// the same for u32 counts -> int64 offsets + their total (k_scan_i64's contract)
+static int launch_scan_u32(ffq_ctx *c, hipStream_t st, const unsigned int *v, int64_t nv, long long *base, long long *total)
+{
+    if (nv <= 32768) {
+        hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, st, v, nv, base, total);
+        return FFQ_OK;
+    }
+    const int64_t nb = (nv + SCAN_BLK - 1) / SCAN_BLK;
+    int rc = grow_dev(c, &c->scan_bs, &c->scan_bs_cap, nb);
+    if (rc) return rc;
+    if (!c->scan_res && hipMalloc((void **)&c->scan_res, sizeof(DevRes)) != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc failed");
+    hipLaunchKernelGGL(k_scan_blksum_u32, dim3((unsigned)nb), dim3(256), 0, st, v, nv, c->scan_bs);
+    hipLaunchKernelGGL(k_scan_i64v, dim3(1), dim3(1024), 0, st, c->scan_bs, nb, (int64_t)0, c->scan_res);
+    hipLaunchKernelGGL(k_scan_blkapply_u32, dim3((unsigned)nb), dim3(256), 0, st, v, nv, (const long long *)c->scan_bs, base, total);
     return FFQ_OK;
 }
 
@@ -1703,8 +1721,7 @@ extern "C" int ffq_scan_fasta_device(ffq_ctx *c, const uint8_t *d_buf, int64_t n
         HIPCHK(hipEventRecord(c->ev[1], sA));
         const unsigned tb = (unsigned)((ntiles + 3) / 4);
         hipLaunchKernelGGL(k_fa_count, dim3(tb), dim3(256), 0, sA, L, offset, c->sel_cnt);
-        hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, sA, (const unsigned int *)c->sel_cnt, ntiles, c->sel_base,
-                           (long long *)c->d_word);
+        { const int rs = launch_scan_u32(c, sA, (const unsigned int *)c->sel_cnt, ntiles, c->sel_base, (long long *)c->d_word); if (rs) return rs; }
         hipLaunchKernelGGL(k_fa_rows, dim3(tb), dim3(256), 0, sA, L, offset, add, (const long long *)c->sel_base,
                            (const long long *)c->d_word, d_table, table_cap, c->fa_hdr, (const unsigned int *)c->sel_cnt);
         hipLaunchKernelGGL(k_fa_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, sA, L, offset, add,
@@ -1795,8 +1812,7 @@ static int table_select(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int6
     hipStream_t st = c->stream;
     hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nblk), dim3(256), 0, st, d_table, n_rows, min_len, max_len,
                        c->sel_cnt);
-    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, st, (const unsigned int *)c->sel_cnt, nblk, c->sel_base,
-                       (long long *)c->d_word);
+    if ((rc = launch_scan_u32(c, st, (const unsigned int *)c->sel_cnt, nblk, c->sel_base, (long long *)c->d_word))) return rc;
     hipLaunchKernelGGL(k_sel_scatter, dim3((unsigned)nblk), dim3(256), 0, st, d_table, n_rows, min_len, max_len,
                        (const long long *)c->sel_base, d_out, d_idx);
     HIPCHK(hipMemcpyAsync(c->h_word, c->d_word, sizeof(int64_t), hipMemcpyDeviceToHost, st));

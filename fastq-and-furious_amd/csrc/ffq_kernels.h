@@ -942,6 +942,62 @@ __global__ __launch_bounds__(256) void k_scan_blksum(const long long *__restrict
     if (tid == 0) bs[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
+// ... and of u32 counts into i64 offsets (k_scan_i64's contract: base[i] = values in front of i, *total = all of them)
+__device__ __forceinline__ long long scan_blk_load8u(const unsigned int *__restrict__ v, int64_t nv, int64_t b0, uint32_t (&x)[8])
+{
+    if (b0 + 8 <= nv) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(v + b0), b = *reinterpret_cast<const uint4 *>(v + b0 + 4);   // (hipMalloc'ed, b0 a multiple of 8)
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = (b0 + k < nv) ? v[b0 + k] : 0u;
+    }
+    long long s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += (long long)x[k];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_scan_blksum_u32(const unsigned int *__restrict__ v, int64_t nv, long long *__restrict__ bs)
+{
+    __shared__ long long s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t x[8];
+    long long s = scan_blk_load8u(v, nv, (int64_t)blockIdx.x * SCAN_BLK + (int64_t)tid * 8, x);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) s_w[wid] = s;
+    __syncthreads();
+    if (tid == 0) bs[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void k_scan_blkapply_u32(const unsigned int *__restrict__ v, int64_t nv, const long long *__restrict__ bs,
+                                                           long long *__restrict__ base, long long *__restrict__ total)
+{
+    __shared__ long long s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * SCAN_BLK + (int64_t)tid * 8;
+    const long long bb = bs[blockIdx.x];
+    uint32_t x[8];
+    const long long mine = scan_blk_load8u(v, nv, b0, x);
+    long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    long long wpre = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (q < wid) wpre += s_w[q];
+    long long run = bb + wpre + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { if (b0 + k < nv) base[b0 + k] = run; run += (long long)x[k]; }
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) *total = run;        // (values past nv count as zero)
+}
+
 __global__ __launch_bounds__(256) void k_scan_blkapply(long long *__restrict__ v, int64_t nv, const long long *__restrict__ bs)
 {
     __shared__ long long s_w[4];

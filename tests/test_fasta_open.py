@@ -259,3 +259,46 @@ def test_fasta_long_header_runs(gpu_ctx, oracle, pkg):
         table, res = gpu_ctx.scan_fasta_host(hostile, table_cap=len(want) + 8)
         assert time.perf_counter() - t0 < 5.0
         assert np.array_equal(table, want) and int(res.last_status) == st and list(res.last_pos) == last
+
+
+@pytest.mark.gpu
+def test_fasta_and_select_at_size(gpu_ctx, oracle, pkg):
+    """Past 32 768 tiles / row blocks the offsets come from the two-level scan (launch_scan_u32): 640 MiB of FASTA (an
+    8 MiB block of distinct entries repeated on the device) -- EVERY row against the oracle's rows of the block + the
+    repeat's offset --, then the length filter over that table (9 M rows would do; here what the scan gave) against torch."""
+    import numpy as np
+    import torch
+    from fastqandfurious_amd import index as X
+    rng = np.random.default_rng(12)
+    parts, tot = [], 0
+    while tot < (8 << 20):
+        L = int(np.exp(rng.uniform(np.log(30), np.log(20000))))
+        seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=L).tobytes()
+        e = b">e%d some text\n" % len(parts) + b"\n".join(seq[k:k + 60] for k in range(0, L, 60)) + b"\n"
+        parts.append(e); tot += len(e)
+    block = b"".join(parts)
+    nb = len(parts)
+    want2, *_ = oracle.scan_fasta(b"\n" + block + block)
+    want = want2[:nb]                                       # (the block's entries, the last one closed by the next block's first)
+    assert len(want2) == 2 * nb - 1
+    reps = 80
+    d = torch.cat([torch.tensor([10], dtype=torch.uint8), torch.from_numpy(np.frombuffer(block, dtype=np.uint8).copy()).repeat(reps)]).cuda()
+    assert d.numel() > (32768 << 14)
+    n = nb * reps - 1
+    table = torch.empty((n + 64, 6), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rc, res = gpu_ctx.scan_fasta_device(d.data_ptr(), d.numel(), table.data_ptr(), n + 64)
+    assert rc == 0 and int(res.n_records) == n
+    wt = torch.from_numpy(want).cuda()
+    shift = (torch.arange(reps, device="cuda", dtype=torch.int64) * len(block)).view(reps, 1, 1)
+    exp = (wt.view(1, nb, 6) + shift).view(-1, 6)[:n].clone()
+    exp[:, 4:] = -1                                         # (FASTA rows: no quality)
+    assert bool((table[:n] == exp).all())
+    # the filter, a table long enough for its own two-level scan: the same rows eight times over
+    big = table[:n].repeat(8 * (1 + (9_000_000 // (8 * n))), 1)
+    assert big.shape[0] > 32768 * 256
+    lens = big[:, 3] - big[:, 2]
+    for lo, hi in ((100, 5000), (None, 60), (20001, None)):
+        got = X.select_rows_device(gpu_ctx, big, lo, hi)
+        keep = (lens >= (lo if lo is not None else -(1 << 62))) & (lens <= (hi if hi is not None else (1 << 62)))
+        assert got.shape[0] == int(keep.sum().item()) and bool((got == big[keep]).all()), (lo, hi)
