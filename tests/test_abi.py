@@ -127,3 +127,29 @@ def test_mirror_module_surface(pkg):
         C.arrayadd_b(array("b", [1]), 40000)
     with pytest.raises(TypeError):
         C.arrayadd_b(array("b", [1]), 1.5)
+
+
+def build_c_example(out_dir):
+    """examples/ffq_count.c compiled as C99 and linked against the in-tree library: the boundary is a C ABI, not a
+    Python extension.  Returns the binary's path (None without gcc)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        return None
+    libdir = os.path.join(ROOT, "fastq-and-furious_amd", "csrc")
+    exe = os.path.join(str(out_dir), "ffq_count")
+    subprocess.run([gcc, "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "ffq_count.c"), "-o", exe, "-L", libdir, "-lffq_hip", "-Wl,-rpath," + libdir],
+                   check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_plain_c_program_links_against_the_library(hip, tmp_path):
+    import subprocess
+    exe = build_c_example(tmp_path)
+    if exe is None:
+        pytest.skip("no gcc")
+    r = subprocess.run([exe, "-v"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split()[:3] == ["ffq", "abi", str(hip.ABI_VERSION)]

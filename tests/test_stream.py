@@ -284,3 +284,24 @@ def test_stream_many_fills_and_reuse(mods, gpu_ctx, oracle, tmp_path):
     for bufsize in (1 << 16, (1 << 20) + 4096, 3 << 20, 1 << 16):
         rows, _, err = with_file(tmp_path, blob, lambda fd: run_stream(mods, gpu_ctx, fd, bufsize))
         assert err is None and np.array_equal(np.array(rows, dtype=np.int64), want)
+
+
+def test_plain_c_host_counts_like_the_oracle(gpu_ctx, oracle, tmp_path):
+    """examples/ffq_count.c: a host written in C on the same ABI (ffq_stream_open / _next): records and bases of a file."""
+    import subprocess
+    from fastqandfurious_amd import synth
+    from test_abi import build_c_example
+    exe = build_c_example(tmp_path)
+    if exe is None:
+        pytest.skip("no gcc")
+    data = bytes(synth.wrapped(0, 40000, seed=5)[0])
+    p = tmp_path / "c_host.fq"
+    p.write_bytes(data)
+    want, *_ = oracle.scan(data)
+    r = subprocess.run([exe, str(p)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == [str(len(want)), "records,", str(int((want[:, 3] - want[:, 2]).sum())), "bases"]
+    bad = tmp_path / "c_host_bad.fq"
+    bad.write_bytes(data[:len(data) // 2])                       # cut inside a record: the reference raises, the C host reports
+    r = subprocess.run([exe, str(bad)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "stream error" in r.stderr
