@@ -24,6 +24,15 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <string.h>
+
+/* A tuple of three bytes / array('b') objects refers to nothing the cycle collector looks after: it cannot be part of a
+ * cycle, and the collector itself takes such tuples off its lists when it first meets them.  It meets these while the
+ * list is still being built (a collection every 700 allocations): hundreds of thousands of live young tuples are then
+ * promoted from generation to generation, which makes FULL collections due (the 25 % rule counts promoted objects) -- a
+ * dozen per 800 000 records, milliseconds each in a process with many objects (torch imported: 188 ms per 800 000 records
+ * with the collector on, 110 with it off).  Untracked at birth they are never promoted. */
+#define UNTRACK(t) PyObject_GC_UnTrack(t)
 
 static PyObject *cut(const char *base, Py_ssize_t len, int64_t a, int64_t b)
 {
@@ -72,6 +81,7 @@ static PyObject *entries(PyObject *self, PyObject *args)
             PyTuple_SET_ITEM(t, 0, h);
             PyTuple_SET_ITEM(t, 1, s);
             PyTuple_SET_ITEM(t, 2, q);
+            UNTRACK(t);
             PyList_SET_ITEM(list, i, t);
         }
     }
@@ -88,6 +98,37 @@ done:
  * bytes come from the stream's bulk decode on the device -- qual (int8) with the offsets qoff (int64,
  * one more than rows: where each record's bytes start, and where the last one's end) -- and are only
  * wrapped here.  array_type: array.array.                                                         */
+/* One array('b') that lives from call to call: a fill's decoded bytes are copied INTO it (its own buffer, through the buffer
+ * protocol) and the records' arrays are slices of it.  Until round 5 every call built a bytes object of the whole fill and an
+ * array from that -- two allocations and two copies of megabytes per fill, unmapped again at the end of the call; with a
+ * process full of threads (torch imported: 80 of them) the page faults of those fresh mappings cost more than the slices. */
+static PyObject *g_big = NULL, *g_big_type = NULL;
+static Py_ssize_t g_big_cap = 0;
+
+static PyObject *big_array(PyObject *atype, const char *src, Py_ssize_t n)
+{
+    if (!g_big || g_big_type != atype || g_big_cap < n) {
+        const Py_ssize_t cap = n + n / 4 + (1 << 16);
+        PyObject *raw = PyBytes_FromStringAndSize(NULL, cap);
+        PyObject *nb = raw ? PyObject_CallFunction(atype, "sO", "b", raw) : NULL;
+        Py_XDECREF(raw);
+        if (!nb) return NULL;
+        Py_XDECREF(g_big); Py_XDECREF(g_big_type);
+        g_big = nb; g_big_cap = cap; g_big_type = atype; Py_INCREF(atype);
+    }
+    Py_buffer v;
+    if (PyObject_GetBuffer(g_big, &v, PyBUF_WRITABLE) != 0) return NULL;
+    if (v.len < n || v.itemsize != 1) {
+        PyBuffer_Release(&v);
+        PyErr_SetString(PyExc_TypeError, "array_type('b', bytes) did not give an array of bytes");
+        return NULL;
+    }
+    memcpy(v.buf, src, (size_t)n);
+    PyBuffer_Release(&v);
+    Py_INCREF(g_big);
+    return g_big;
+}
+
 static PyObject *entries_phred(PyObject *self, PyObject *args)
 {
     Py_buffer buf, rows, qual, qoff;
@@ -112,9 +153,7 @@ static PyObject *entries_phred(PyObject *self, PyObject *args)
         }
         /* the decoded bytes of all these rows as ONE array('b'); a record's array is a slice of it (the
          * array type's own slicing: no constructor call with a typecode per record) */
-        PyObject *allb = PyBytes_FromStringAndSize((const char *)qual.buf + q0, (Py_ssize_t)(o[n] - q0));
-        big = allb ? PyObject_CallFunction(atype, "sO", "b", allb) : NULL;
-        Py_XDECREF(allb);
+        big = big_array(atype, (const char *)qual.buf + q0, (Py_ssize_t)(o[n] - q0));
         if (!big) goto done;
         list = PyList_New(n);
         if (!list) goto done;
@@ -139,6 +178,7 @@ static PyObject *entries_phred(PyObject *self, PyObject *args)
             PyTuple_SET_ITEM(t, 0, h);
             PyTuple_SET_ITEM(t, 1, s);
             PyTuple_SET_ITEM(t, 2, q);
+            UNTRACK(t);
             PyList_SET_ITEM(list, i, t);
         }
     }
@@ -241,6 +281,7 @@ static PyObject *sparse_entries(PyObject *self, PyObject *args)
             PyTuple_SET_ITEM(t, 0, h);
             PyTuple_SET_ITEM(t, 1, q2);
             PyTuple_SET_ITEM(t, 2, q);
+            UNTRACK(t);
             PyObject *old = PyList_GET_ITEM(list, (Py_ssize_t)ix[i]);
             PyList_SET_ITEM(list, (Py_ssize_t)ix[i], t);
             Py_DECREF(old);
