@@ -248,8 +248,9 @@ def _default_entries(buf, rows, shift, cls=None):
     cut = _entries.native().entries
     mv = memoryview(rows).cast('B')
     step = 48 * _ENTRY_CHUNK
+    # (one LIST per chunk: the caller yields from the list itself -- a generator level less per record)
     for at in range(0, len(mv), step):
-        yield from cut(buf, mv[at:at + step], shift, 1, cls)
+        yield cut(buf, mv[at:at + step], shift, 1, cls)
 
 
 def _phred_entries(st, fill, rows, shift):
@@ -260,14 +261,14 @@ def _phred_entries(st, fill, rows, shift):
         mv, mo = memoryview(rows).cast('B'), memoryview(qoff).cast('B')
         step = _ENTRY_CHUNK
         for at in range(0, rows.shape[0], step):
-            yield from nat.entries_phred(fill, mv[48 * at:48 * (at + step)], shift, qual, mo[8 * at:8 * (at + step + 1)], array)
+            yield nat.entries_phred(fill, mv[48 * at:48 * (at + step)], shift, qual, mo[8 * at:8 * (at + step + 1)], array)
         return
     buf = fill.tobytes()
     qb = qual.tobytes()
     offs = qoff.tolist()
     # (record i's bytes: qual[qoff[i] : qoff[i] + pos5 - pos4] -- packed stream and single-pass segments alike)
-    for i, (p0, p1, p2, p3, p4, p5) in enumerate((rows - shift).tolist()):
-        yield (buf[p0 + 1:p1], buf[p2:p3], array('b', qb[offs[i]:offs[i] + p5 - p4]))
+    yield [(buf[p0 + 1:p1], buf[p2:p3], array('b', qb[offs[i]:offs[i] + p5 - p4]))
+           for i, (p0, p1, p2, p3, p4, p5) in enumerate((rows - shift).tolist())]
 
 
 def _np_arange(k):
@@ -324,7 +325,8 @@ def _iter_batched(fh, fbufsize, entryfunc, scan_buffer):
     while True:
         rows, end_state, end_offset = scan_buffer(buf, offset, eof)
         if (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
-            yield from _default_entries(buf, rows, 0, None if entryfunc is _ENTRYFUNC else Entry)
+            for chunk in _default_entries(buf, rows, 0, None if entryfunc is _ENTRYFUNC else Entry):
+                yield from chunk
         elif entryfunc is _ENTRYFUNC:
             it = iter(rows)                      # the default entryfunc inlined (see _iter_stream)
             for p0, p1, p2, p3, p4, p5 in zip(it, it, it, it, it, it):
@@ -360,12 +362,14 @@ def _iter_stream(st, entryfunc):
                 # the stream dropped rows on the device (entryfunc_lengthfilter): one item per scanned record all the same
                 yield from _filtered_items(st, entryfunc, rows, fill, fill_offset)
             elif rows.shape[0] and entryfunc is entryfunc_phred and st.decode:
-                yield from _phred_entries(st, fill, rows, fill_offset)
+                for chunk in _phred_entries(st, fill, rows, fill_offset):
+                    yield from chunk
             elif rows.shape[0] and (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
                 # the default entryfunc over the whole table, natively (csrc/ffq_entries.c): the slices
                 # are cut straight out of the stream's own (pinned) fill -- no bytes copy of the fill,
                 # no posbuffer and no interpreter loop per record
-                yield from _default_entries(fill, rows, fill_offset, None if entryfunc is _ENTRYFUNC else Entry)
+                for chunk in _default_entries(fill, rows, fill_offset, None if entryfunc is _ENTRYFUNC else Entry):
+                    yield from chunk
             elif rows.shape[0]:
                 buf = fill.tobytes()
                 rel = array('q')
@@ -499,7 +503,8 @@ class RangeEntries:
                     qual, qoff = sh.quals(i0, i1, rows)
                     yield from _entries.native().entries_phred(view[a:b], memoryview(rows).cast('B'), a, qual, memoryview(qoff).cast('B'), array)
                 elif (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
-                    yield from _default_entries(view[a:b], rows, a, None if entryfunc is _ENTRYFUNC else Entry)
+                    for chunk in _default_entries(view[a:b], rows, a, None if entryfunc is _ENTRYFUNC else Entry):
+                        yield from chunk
                 else:
                     # any entryfunc: `buf` holds the batch's bytes, `pos` is relative to it and pos + globaloffset the
                     # absolute file offsets (entryfunc_abspos, :186-195) -- the contract of the reference's loop (:252-255)

@@ -182,7 +182,8 @@ def test_phred_iterator_takes_the_single_pass(gpu_ctx, phred, tmp_path):
             paths, got = set(), []
             for rows, fill, fill_offset, end_state, err in st:
                 paths.add(st.path())
-                got.extend(F._phred_entries(st, fill, rows, fill_offset))
+                for chunk in F._phred_entries(st, fill, rows, fill_offset):      # (one list of entries per native call)
+                    got.extend(chunk)
             st.close()
         assert paths <= set(want_path) and paths, (name, paths)
         assert len(got) == g["n"] and _digest(got) == g["sha256"], name
