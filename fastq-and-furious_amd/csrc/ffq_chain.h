@@ -524,29 +524,29 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
     // records of a kilobase the 8 KiB run-in holds four of them, too few for a chain started at a false candidate to fall
     // in with the true one every time (4 % of the groups were repaired, one pass per scan, at 1 kbp).
     uint32_t clean = 0;
-    // successor beyond the entries read so far: binary search of the window for the first entry at
-    // >= qe - 1 (from index `from` on), then the first "\n@" among the next 8.  ~0u: not found.
-    auto far_successor = [&](int from, uint32_t qe) -> uint32_t {
-        int lo = from, hi = nwin;
+    // successor of node c beyond the entries its call has read: the first "\n@" at >= qe - 1.  Every "\n@" of the own tiles
+    // (and of the run-in tail) is a node, numbered in position order: a binary search of the nodes' positions finds it
+    // wherever it lies -- until round 5 this looked at the eight entries behind qe - 1 only, and a call that "reads" several
+    // records as one (a quality line of a long record that begins with '@': its successor is dozens of lines on) went through
+    // the whole-wave call over the global index instead: 4-6 such nodes per group at 1-5 kbp, 55 000 cycles each, 70 % of the
+    // kernel's time.  Behind the last node: any "\n@" of the look-ahead tile (SN_AHEAD; the summary finds its position), or
+    // ~0u -- nothing in the window, the generic path decides.
+    auto far_successor = [&](int c, int from, uint32_t qe) -> uint32_t {
+        int lo = c + 1, hi = ncomp;
+        while (lo < hi) {
+            const int md = (lo + hi) >> 1;
+            if (npos[md] + 1 >= qe) hi = md; else lo = md + 1;
+        }
+        while (lo < ncomp && (int)nidx[lo] < from) lo++;       // (behind the entries the call itself has looked at: the callers' rule)
+        if (lo < ncomp) return (uint32_t)lo;
+        lo = max(from, own_hi); hi = nwin;
         while (lo < hi) {
             const int md = (lo + hi) >> 1;
             if ((went[md] & WP_MASK) + 1 >= qe) hi = md; else lo = md + 1;
         }
-        if (lo + 8 > nwin) return 0xFFFFFFFFu;
-        uint32_t x[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = went[lo + i];
-        uint32_t am = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            if ((x[i] >> WF_SHIFT) & FL_AT) am |= 1u << i;
-        if (!am) return 0xFFFFFFFFu;
-        const int i0 = __ffs((int)am) - 1;
-        uint32_t wj = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) if (i == i0) wj = x[i];
-        const uint32_t nid = (wj >> WN_SHIFT) & WN_MASK;
-        return (lo + i0 < own_hi && nid != NO_NODE) ? nid : SN_AHEAD;
+        for (; lo < nwin; lo++)
+            if ((went[lo] >> WF_SHIFT) & FL_AT) return SN_AHEAD;
+        return 0xFFFFFFFFu;
     };
 #pragma unroll
     for (int u = 0; u < PER; u++) {
@@ -615,7 +615,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
                             // the record is COMPLETE but its successor lies beyond the batch (a
                             // candidate inside a wrapped quality block "reads" several records as
                             // one).  sj = 15: not encoded.
-                            const uint32_t nx = far_successor(k + 13, qe);
+                            const uint32_t nx = far_successor(c, k + 13, qe);
                             if (nx != 0xFFFFFFFFu) {
                                 info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
                                           (15u << 25) | (1u << 29);
@@ -652,7 +652,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
                                 if (np[0] + 1 >= qe) nx = (uint32_t)(c + 1);
                                 else if (np[1] + 1 >= qe) nx = (uint32_t)(c + 2);
                                 else if (np[2] + 1 >= qe) nx = (uint32_t)(c + 3);
-                                else nx = far_successor(k + mi + 2, qe);
+                                else nx = far_successor(c, k + mi + 2, qe);
                                 if (nx != 0xFFFFFFFFu) {
                                     info[u] = nx | ((uint32_t)(ST_COMPLETE + 1) << 16) | ((uint32_t)mi << 21) |
                                               (1u << 29) | (1u << 31);
@@ -915,10 +915,26 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
             // stops there and the posbuffer of that call is wanted, or it is a generic node)
             const bool from_word = st == ST_COMPLETE &&
                                    (nx == SN_NOCAND || (nx == SN_AHEAD && (li >> 29 & 1u) && !(li >> 31) && ((li >> 25) & 15u) != 15u));
+            // ... or an in-window call (bit 29) whose successor far_successor found in the look-ahead tile: the first "\n@"
+            // there at >= pos5 - 1, by the whole wave over the window (the same entries, the same rule)
+            const bool from_window = st == ST_COMPLETE && !from_word && nx == SN_AHEAD && (li >> 29 & 1u);
+            int64_t after_win = Y_NOCAND;
+            if (from_window) {
+                const int kl = nidx[lastn];
+                const int mi = (li >> 31) ? (int)((li >> 21) & 255u) : (int)((li >> 21) & 15u);
+                const uint32_t r1 = went[kl + 1] & WP_MASK, r3 = went[kl + mi] & WP_MASK, rm1 = went[kl + mi + 1] & WP_MASK;
+                const uint32_t qe = rm1 + 1 + r3 - r1 - 1;
+                for (int j0 = own_hi; j0 < nwin && after_win == Y_NOCAND; j0 += 64) {
+                    const int j = j0 + lane;
+                    const uint32_t x = (j < nwin) ? went[j] : 0u;
+                    const unsigned long long hit = __ballot(j < nwin && ((x >> WF_SHIFT) & FL_AT) && (x & WP_MASK) + 1 >= qe);
+                    if (hit) after_win = wpos0 + (int64_t)(went[j0 + (__ffsll((long long)hit) - 1)] & WP_MASK);
+                }
+            }
             FollowOut fo;
             fo.after = Y_NOCAND;
             fo.r = tr;
-            if (!from_word) {
+            if (!from_word && !(from_window && after_win != Y_NOCAND)) {
                 const int kl = nidx[lastn];
                 fo = node_wave(Lg, node_handle(kl), wpos0 + (int64_t)(went[kl] & WP_MASK), eof);
             }
@@ -927,6 +943,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
                     int64_t after;
                     if (nx == SN_NOCAND) after = Y_NOCAND;
                     else if (from_word) after = wpos0 + (int64_t)(went[nidx[lastn] + ((li >> 25) & 15u)] & WP_MASK);
+                    else if (from_window && after_win != Y_NOCAND) after = after_win;
                     else after = fo.after;
                     EX = after;
                     if (after == Y_NOCAND) { have_term = true; tstatus = ST_HEAD_BEG; }
