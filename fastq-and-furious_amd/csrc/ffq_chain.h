@@ -626,16 +626,16 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
                     }
                 } else {
                     // no "\n+" among the next nine entries: a record wrapped over many lines.  Look
-                    // further, eight entries at a time (up to 250 entries, ~10 KB at 80 columns);
+                    // further, eight entries at a time (up to 255 entries, ~20 KB at 80 columns);
                     // bit 31 of the node word says that mi is the wide field (8 bits, no sj).
                     int mi = 0;
-                    const int lim = min(nwin - k - 2, 250);
-                    for (int bb = 10; bb + 8 <= lim && !mi; bb += 8) {
+                    const int lim = min(nwin - k - 2, 256);          // (mi is an 8-bit field of the node word)
+                    for (int bb = 10; bb < lim && !mi; bb += 8) {
                         uint32_t pm = 0;
 #pragma unroll
                         for (int i = 0; i < 8; i++) {
-                            const uint32_t x = went[k + bb + i];
-                            if (((x >> WF_SHIFT) & FL_PLUS) && (x & WP_MASK) >= r1 + 2) pm |= 1u << i;
+                            const uint32_t x = went[min(k + bb + i, nwin - 1)];
+                            if (bb + i < lim && ((x >> WF_SHIFT) & FL_PLUS) && (x & WP_MASK) >= r1 + 2) pm |= 1u << i;
                         }
                         if (pm) mi = bb + (__ffs((int)pm) - 1);
                     }
@@ -784,7 +784,23 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
         }
         // (a run-in without such a node -- records of several kilobases: the 8 KiB tail holds no header at all -- takes the
         // first one of the own tiles: the first true header there, which is where the predecessor's chain arrives)
-        int cs = first_set_from<PER>(C2, 0);
+        // (three in a row where the window shows that much: at 5 kbp -- six records per group, one false candidate per record --
+        // two exact landings from a false start did turn up, once in 65 452 groups, and cost every scan a repair pass)
+        unsigned long long C3[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const uint32_t nx = info[u] & 0xFFFFu;
+            bool ok3 = false;
+            if (((clean >> u) & 1u) && nx < (uint32_t)NMAX) {
+                unsigned long long wsel = 0ull;
+#pragma unroll
+                for (int q = 0; q < PER; q++) if ((int)(nx >> 6) == q) wsel = C2[q];
+                ok3 = ((wsel >> (nx & 63u)) & 1ull) != 0ull;
+            }
+            C3[u] = __ballot(ok3);
+        }
+        int cs = first_set_from<PER>(C3, 0);
+        if (cs >= ncomp) cs = first_set_from<PER>(C2, 0);
         if (cs >= ncomp) cs = first_set_from<PER>(CL, 0);
         if (cs < ncomp) e0 = cs;
     }
