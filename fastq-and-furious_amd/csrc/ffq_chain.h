@@ -803,6 +803,19 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
         if (cs >= ncomp) cs = first_set_from<PER>(C2, 0);
         if (cs >= ncomp) cs = first_set_from<PER>(CL, 0);
         if (cs < ncomp) e0 = cs;
+#ifdef FFQ_PROBES
+        if (ablate >= 1000 && g == ablate - 1000) {
+            // (FFQ_ABLATE=1000+g: the nodes of one group as the start rule sees them)
+            if (lane == 0) printf("[group %d] ncomp %d n_runin %d nwin %d own_hi %d start %d (C3 %d C2 %d CL %d) wpos0 %lld\n", g, ncomp, n_runin, nwin, own_hi, e0,
+                                  first_set_from<PER>(C3, 0), first_set_from<PER>(C2, 0), first_set_from<PER>(CL, 0), (long long)wpos0);
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int c = u * 64 + lane;
+                if (c < ncomp) printf("[group %d] node %3d entry %4d pos %lld succ %5u status %2d wide %d clean %d\n", g, c, (int)nidx[c], (long long)(wpos0 + (int64_t)(went[nidx[c]] & WP_MASK)),
+                                      info[u] & 0xFFFFu, (int)((info[u] >> 16) & 31u) - 1, (int)(info[u] >> 31), (int)((clean >> u) & 1u));
+            }
+        }
+#endif
     }
     bool unresolved = (fpos != FORCE_NONE && e_forced < 0), too_many_jumps = false;
     for (int attempt = 0; attempt < 4 && ncomp > 0 && !unresolved; attempt++) {
