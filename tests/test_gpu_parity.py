@@ -513,6 +513,24 @@ def test_wrapped_kilobase_records_are_repaired_not_serialised(gpu_ctx, oracle, L
     check_same(gpu_ctx, oracle, data, offset=len(data) // 2)
 
 
+@pytest.mark.parametrize("L,wrap", ((500, 60), (1000, 80), (3000, 80), (5000, 200)))
+def test_wrapped_reads_of_kilobases_stay_on_the_group_kernels(gpu_ctx, oracle, L, wrap):
+    """64 MiB of wrapped reads of 0.5-5 kbp whose quality lines begin with '@' and '+' now and then (false candidates: a
+    call from one "reads" several records as one and its successor lies dozens of lines on -- found in the window since
+    round 5, by a binary search of the node positions): the group kernels prove the chain without a repair pass, and the
+    second scan of the context does too."""
+    rng = np.random.default_rng(7 * L + wrap)
+    data = random_records(rng, (64 << 20) // (2 * L + 2 * (L // wrap) + 60), L * 3 // 4, L, wrap=wrap, hdr_hi=20)
+    gpu_ctx.forget()
+    table, res = check_same(gpu_ctx, oracle, data)
+    assert res.path == 0
+    table, res = check_same(gpu_ctx, oracle, data)
+    assert res.path == 0 and res.retries == 0
+    check_same(gpu_ctx, oracle, data[:-1])
+    check_same(gpu_ctx, oracle, data, offset=len(data) // 2, eof=False)
+    gpu_ctx.forget()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_differential_mess_ranked(gpu_ctx, hipmod, oracle, seed):
     """The hostile streams of test_differential_mess through the list-ranking tier (forced): the
