@@ -21,6 +21,8 @@ stream N times as long (weak scaling); ranks exchange only the bytes around
 their range edges (RCCL send/recv) and verify the hand-off.  `--gpus N` without a
 launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).  The default
 run reports single-100g (and at N = 1 decode-10g, wrapped-10g) under `other_workloads`.
+At N = 1 it also carries `shapes`: read shapes that are no BASELINE config (long four-line reads with the decode in one
+pass, wrapped reads of kilobases, FASTA), 4 GiB each, every row verified against the generator's own offsets (shape_rates).
 """
 import argparse
 import json
@@ -857,6 +859,94 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     return line, (shard, flags)
 
 
+def shape_rates(local_rank, dev, gib=4):
+    """Read shapes that are no BASELINE config (never `value`): long four-line reads with the decode in ONE pass (qualities
+    decoded in place, csrc/ffq_fused.h k_scan_ident), wrapped reads of kilobases (the group kernels / list ranking), FASTA.
+    A 32 MiB block of distinct records, generated here with their rows (the generator knows every offset: pos0 = the '@',
+    pos1 = the header's newline, pos3 = the newline in front of the '+' line, pos4 = pos3 + 3, pos5 = pos4 + pos3 - pos2), is
+    repeated on the device to `gib` GiB; EVERY row of every repeat is compared with the block's rows + the repeat's offset,
+    the decoded bytes of the first and the last repeat with the block's own bytes - 33."""
+    import torch
+    from fastqandfurious_amd import hip
+    rng = np.random.default_rng(2025)
+    out = {"what": shape_rates.__doc__.split("\n\n")[0].replace("\n    ", " "), "bytes": None}
+    ctx = hip.Context(local_rank)
+
+    def block_of(L, wrap, fasta=False):
+        parts, rows, at, i = [], [], 0, 0
+        while at < (32 << 20):
+            n = int(rng.integers(L // 2, L * 3 // 2 + 1))
+            seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n).tobytes()
+            w = wrap or n
+            st = b"\n".join(seq[k:k + w] for k in range(0, n, w))
+            if fasta:
+                h = b">entry%d len=%d" % (i, n)
+                r = h + b"\n" + st + b"\n"
+                rows.append((at, at + len(h), at + len(h) + 1, at + len(r) - 1, -1, -1))
+            else:
+                q = rng.choice(np.frombuffer(bytes(range(35, 74)), dtype=np.uint8), size=n).tobytes()
+                qt = b"\n".join(q[k:k + w] for k in range(0, n, w))
+                h = b"@read%d len=%d" % (i, n)
+                r = h + b"\n" + st + b"\n+\n" + qt + b"\n"
+                p1 = at + len(h); p3 = p1 + 1 + len(st); p4 = p3 + 3
+                rows.append((at, p1, p1 + 1, p3, p4, p4 + len(st)))
+            parts.append(r); at += len(r); i += 1
+        return np.frombuffer(b"".join(parts), dtype=np.uint8), np.array(rows, dtype=np.int64)
+
+    for name, L, wrap, flags, fasta in (("four-line ~3 kbp, decode in one pass (in place)", 3000, 0, hip.F_DECODE_QUAL | hip.F_SINGLE_PASS, False),
+                                        ("four-line ~30 kbp, decode in one pass (in place)", 30000, 0, hip.F_DECODE_QUAL | hip.F_SINGLE_PASS, False),
+                                        ("wrapped at 80 columns, ~1 kbp", 1000, 80, 0, False),
+                                        ("wrapped at 80 columns, ~3 kbp", 3000, 80, 0, False),
+                                        ("wrapped at 80 columns, ~20 kbp", 20000, 80, 0, False),
+                                        ("FASTA at 60 columns, ~10 kbp entries", 10000, 60, 0, True)):
+        block, rows = block_of(L, wrap, fasta)
+        reps = max(1, (gib << 30) // block.size)
+        hb = torch.from_numpy(block.copy()).to(dev)
+        d = hb.repeat(reps) if not fasta else torch.cat([torch.tensor([10], dtype=torch.uint8, device=dev), hb.repeat(reps)])
+        nb, n = rows.shape[0], rows.shape[0] * reps - (1 if fasta else 0)     # (FASTA: the last entry is never COMPLETE)
+        table = torch.empty((n + 64, 6), dtype=torch.int64, device=dev)
+        decode = bool(flags & hip.F_DECODE_QUAL)
+        qual = torch.zeros(((d.numel() + 16383) >> 14) * hip.INPLACE_STRIDE, dtype=torch.int8, device=dev) if decode else None
+        qoff = torch.zeros(n + 65, dtype=torch.int64, device=dev) if decode else None
+        torch.cuda.synchronize()
+        ctx.reserve(d.numel()); ctx.forget()
+        ms = []
+        for it in range(6):
+            if fasta:
+                rc, res = ctx.scan_fasta_device(d.data_ptr(), d.numel(), table.data_ptr(), n + 64)
+            else:
+                rc, res = ctx.scan_device(d.data_ptr(), d.numel(), table.data_ptr(), n + 64, flags=flags,
+                                          d_qual=qual.data_ptr() if decode else None, qual_cap=qual.numel() if decode else 0,
+                                          d_qoff=qoff.data_ptr() if decode else None)
+            assert rc == 0 and int(res.n_records) == n, (name, rc, int(res.n_records), n)
+            if it >= 2:
+                ms.append(float(res.ms_total))
+        want = torch.from_numpy(rows).to(dev)
+        shift = (torch.arange(reps, device=dev, dtype=torch.int64) * block.size).view(reps, 1, 1)
+        exp = (want.view(1, nb, 6) + shift + (1 if fasta else 0)).view(-1, 6)[:n]
+        if fasta:
+            exp = exp.clone(); exp[:, 4:] = -1
+        ok = bool((table[:n] == exp).all())
+        if decode and ok:
+            mask = np.zeros(block.size, dtype=bool)
+            for a, b in zip(rows[:, 4], rows[:, 5]):
+                mask[a:b] = True
+            at = torch.from_numpy(np.nonzero(mask)[0]).to(dev)
+            src = (hb[at].to(torch.int16) - 33).to(torch.int8)
+            ok = bool((qoff[:n] == table[:n, 4]).all())
+            for r in (0, reps - 1):
+                ok = ok and bool((qual[r * block.size:(r + 1) * block.size][at] == src).all())
+        assert ok, "shape_rates: %s does not verify" % name
+        best = min(ms)
+        out[name] = {"value": round(d.numel() / (best * 1e-3) / 1e9, 1), "unit": "GB/s", "ms": round(best, 4), "path": int(res.path),
+                     "retries": int(res.retries), "records": n, "bytes": int(d.numel()), "verified": "every row" + (", decoded bytes of two repeats" if decode else "")}
+        del d, hb, table, qual, qoff, want, exp
+        torch.cuda.empty_cache()
+    out.pop("bytes")
+    ctx.close()
+    return out
+
+
 def main():
     t_main = time.perf_counter()
     ap = argparse.ArgumentParser()
@@ -993,6 +1083,8 @@ def main():
                                                      "hbm_read_probe", "path_roofline")}
         if rank == 0:
             line["other_workloads"] = others
+        if rank == 0 and world == 1 and os.environ.get("FFQ_BENCH_DRY_MULTI") != "1":
+            line["shapes"] = shape_rates(local_rank, dev)
     if rank == 0:
         # (RCCL prints its version banner through C stdio: out with it first, the JSON line is the last line of stdout)
         import ctypes
