@@ -1084,7 +1084,10 @@ def main():
         if rank == 0:
             line["other_workloads"] = others
         if rank == 0 and world == 1 and os.environ.get("FFQ_BENCH_DRY_MULTI") != "1":
-            line["shapes"] = shape_rates(local_rank, dev)
+            try:                    # (an extra: whatever happens in it, the line goes out)
+                line["shapes"] = shape_rates(local_rank, dev)
+            except Exception as e:
+                line["shapes"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         # (RCCL prints its version banner through C stdio: out with it first, the JSON line is the last line of stdout)
         import ctypes
