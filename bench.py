@@ -947,6 +947,15 @@ def shape_rates(local_rank, dev, gib=4):
     return out
 
 
+def guarded(fn, *a, **kw):
+    """An extra leg of the line (everything that is not the timed region): its result, or what went wrong -- the line goes
+    out either way."""
+    try:
+        return fn(*a, **kw)
+    except Exception as e:      # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     t_main = time.perf_counter()
     ap = argparse.ArgumentParser()
@@ -1022,30 +1031,30 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             sample = shard.host_sample(256 << 20)
-            line["cpu_baseline"] = cpu_baseline(sample, args.cpu_seconds)
+            line["cpu_baseline"] = guarded(cpu_baseline, sample, args.cpu_seconds)
             line["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-            line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(sample[:64 << 20], args.cpu_seconds / 2)
-            line["cpu_baseline"]["python_iterator"] = cpu_iterator_rate(sample.tobytes(), 3.0)
+            line["cpu_baseline"]["all_cores"] = guarded(cpu_baseline_all_cores, sample[:64 << 20], args.cpu_seconds / 2)
+            line["cpu_baseline"]["python_iterator"] = guarded(cpu_iterator_rate, sample.tobytes(), 3.0)
             line["cpu_baseline"]["what"] = ("`value` is the PORT (oracle/ffq_oracle.c, whole-buffer chain, no interpreter); "
                                             "reference_c_extension = the reference's own compiled scanner, bare calls; "
                                             "reference_c_iterator = the same scanner inside the per-record iterator loop")
-            line["cpu_baseline"]["reference_c_extension"] = cpu_reference_c(sample.tobytes(), 3.0)
-            line["cpu_baseline"]["reference_c_iterator"] = cpu_reference_iter(sample.tobytes(), 3.0)
-            line["host_inclusive"] = host_inclusive(ctx, sample, flags)
-            line["host_inclusive"]["stream_fd"] = stream_inclusive(ctx, shard.host_sample(1 << 30))
-            line["host_inclusive"]["iterator"] = iterator_rates(ctx, sample, int(sample.size))
+            line["cpu_baseline"]["reference_c_extension"] = guarded(cpu_reference_c, sample.tobytes(), 3.0)
+            line["cpu_baseline"]["reference_c_iterator"] = guarded(cpu_reference_iter, sample.tobytes(), 3.0)
+            line["host_inclusive"] = guarded(host_inclusive, ctx, sample, flags)
+            line["host_inclusive"]["stream_fd"] = guarded(lambda: stream_inclusive(ctx, shard.host_sample(1 << 30)))
+            line["host_inclusive"]["iterator"] = guarded(iterator_rates, ctx, sample, int(sample.size))
             del sample
-            line["host_inclusive"]["pushdown"] = pushdown_rates(local_rank, dev)
+            line["host_inclusive"]["pushdown"] = guarded(pushdown_rates, local_rank, dev)
         elif not args.no_cpu_baseline:
             # N > 1: the same CPU legs beside the multi-GPU line, on rank 0's host cores with a 3 s budget each (the other
             # ranks wait at the next collective); north_star: "GB/s and reads/s at 1/2/4/8 GPUs reported next to the
             # reference C path timed on the same box's host cores"
             sample = shard.host_sample(64 << 20)
-            line["cpu_baseline"] = cpu_baseline(sample, min(args.cpu_seconds, 3.0))
+            line["cpu_baseline"] = guarded(cpu_baseline, sample, min(args.cpu_seconds, 3.0))
             line["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-            line["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(sample[:16 << 20], min(args.cpu_seconds, 3.0))
-            line["cpu_baseline"]["reference_c_extension"] = cpu_reference_c(sample.tobytes(), 2.0)
-            line["cpu_baseline"]["reference_c_iterator"] = cpu_reference_iter(sample.tobytes(), 2.0)
+            line["cpu_baseline"]["all_cores"] = guarded(cpu_baseline_all_cores, sample[:16 << 20], min(args.cpu_seconds, 3.0))
+            line["cpu_baseline"]["reference_c_extension"] = guarded(cpu_reference_c, sample.tobytes(), 2.0)
+            line["cpu_baseline"]["reference_c_iterator"] = guarded(cpu_reference_iter, sample.tobytes(), 2.0)
             line["cpu_baseline"]["what"] = ("rank 0's host, while the other ranks wait: `value` is the PORT (oracle/ffq_oracle.c) on one core, "
                                             "all_cores the same on every core; reference_c_* = the reference's own compiled scanner")
             del sample
@@ -1055,7 +1064,7 @@ def main():
         # file-backed byte-range shards (collective: every rank takes part; the line is rank 0's).  On a real multi-GPU run
         # only on request (FFQ_BENCH_SHARDED_FILE=1): it is a host-inclusive extra, and nothing that is not the metric
         # should be able to hold up the ranks of the measured line
-        sf = sharded_file(ctx, shard, rank, world, dev, dist)
+        sf = guarded(sharded_file, ctx, shard, rank, world, dev, dist) if world == 1 else sharded_file(ctx, shard, rank, world, dev, dist)
         if rank == 0:
             line.setdefault("host_inclusive", {})
             if line["host_inclusive"] is None:
@@ -1073,7 +1082,14 @@ def main():
             names = ("single-4g-split",)             # (the dry run shares ONE GPU between the ranks)
         for other in names:
             ctx_o = hip.Context(local_rank)
-            ol, keep = run_workload(other, args, ctx_o, rank, world, dev, dist)
+            if world == 1:
+                got = guarded(run_workload, other, args, ctx_o, rank, world, dev, dist)
+                if isinstance(got, dict):          # (the extra failed: say so under its name)
+                    others[other] = got
+                    continue
+                ol, keep = got
+            else:
+                ol, keep = run_workload(other, args, ctx_o, rank, world, dev, dist)
             del keep
             ctx_o.close()
             torch.cuda.empty_cache()
@@ -1084,10 +1100,7 @@ def main():
         if rank == 0:
             line["other_workloads"] = others
         if rank == 0 and world == 1 and os.environ.get("FFQ_BENCH_DRY_MULTI") != "1":
-            try:                    # (an extra: whatever happens in it, the line goes out)
-                line["shapes"] = shape_rates(local_rank, dev)
-            except Exception as e:
-                line["shapes"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            line["shapes"] = guarded(shape_rates, local_rank, dev)
     if rank == 0:
         # (RCCL prints its version banner through C stdio: out with it first, the JSON line is the last line of stdout)
         import ctypes
