@@ -184,6 +184,33 @@ def _checked_build():
         raise FFQError(E_INTERNAL, "%s does not carry the build id of its sources after a rebuild" % LIB_PATH)
 
 
+class _MissingExport:
+    """An export the library named by FFQ_HIP_LIB does not have: an error when CALLED, not when bound."""
+
+    def __init__(self, name):
+        self._name = name
+        self.argtypes = self.restype = None
+
+    def __call__(self, *a):
+        raise FFQError(E_INTERNAL, "%s: the library named by FFQ_HIP_LIB (%s) does not export it" % (self._name, LIB_PATH))
+
+
+class _OtherBuild:
+    """FFQ_HIP_LIB names another build on purpose (tools/ab_*.sh: an OLDER commit's library under this tree's Python for a
+    same-box A/B): what it lacks is bound to _MissingExport.  The in-tree library never goes through this."""
+
+    def __init__(self, cdll):
+        self.__dict__["_cdll"] = cdll
+
+    def __getattr__(self, name):
+        try:
+            f = getattr(self._cdll, name)
+        except AttributeError:
+            f = _MissingExport(name)
+        self.__dict__[name] = f
+        return f
+
+
 def build_id():
     """The source hash baked into the loaded library (== build.source_id() of this tree)."""
     return lib().ffq_build_id().decode("ascii")
@@ -202,6 +229,8 @@ def lib():
                            "%s is missing: build it with `python fastq-and-furious_amd/build.py` "
                            "(there is no CPU fallback for the scan path)" % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
+        if os.environ.get("FFQ_HIP_LIB"):
+            L = _OtherBuild(L)
         vp, i64, i32, u32, u64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32,
                                   ctypes.c_uint64)
         P = ctypes.POINTER
