@@ -283,9 +283,10 @@ def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, b
         del piece
         if world > 1:
             dist.barrier()
-        comm = None
-        if world > 1:       # RCCL between the ranks' GPUs; a dry run of several ranks on ONE GPU: the device step over gloo
-            comm = sharded.DistTransport(dist) if dry_gloo(dist) else sharded.native_unique_id(dist, dev)
+        # RCCL between the ranks' GPUs (comm=None: every FileShard / iterator draws a communicator id of its OWN over the
+        # process group -- an id is good for one ncclCommInitRank round); a dry run of several ranks on ONE GPU: the
+        # device step over gloo
+        comm = sharded.DistTransport(dist) if (world > 1 and dry_gloo(dist)) else None
         best = None
         for _ in range(3):
             sh = sharded.FileShard(ctx, path, rank, world, comm=comm)
@@ -505,9 +506,10 @@ def spread(xs):
     return {"min": round(xs[0], 4), "median": round(xs[len(xs) // 2], 4), "max": round(xs[-1], 4)} if xs else None
 
 
-def run_workload(name, args, ctx, rank, world, dev, dist):
+def run_workload(name, args, ctx, rank, world, dev, dist, ctl=None):
     """Time `args.steps` passes of the hot path over workload `name`; returns (line dict, closure
-    of what the CPU-side extras need) on rank 0, (None, None) elsewhere."""
+    of what the CPU-side extras need) on rank 0, (None, None) elsewhere.  ctl: the side group (gloo) communicator ids
+    travel over at N > 1."""
     import torch
     from fastqandfurious_amd import hip, sharded
     wl = WORKLOADS[name]
@@ -523,7 +525,14 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
     # (N = 1 --native-step: the device step on the library's RCCL transport at world 1 instead of the in-process one)
     shard = sharded.SyntheticShard(ctx, wl["kind"], wl["bytes"] // world if split else wl["bytes"], rank, world, dev,
                                    total_records=wl["bytes"] // 322 if split else None,
-                                   solo_rccl=bool(getattr(args, "native_step", False)))
+                                   solo_rccl=bool(getattr(args, "native_step", False)), ctl_group=ctl)
+    # Who is there (N > 1, the library's own RCCL transport): the communicators must count --gpus ranks and those ranks
+    # must sit on distinct GPUs -- asserted BEFORE anything is timed, printed in the line's `comm`
+    peers = None
+    if hasattr(shard.scanner, "sh"):
+        peers = shard.scanner.info()
+        if peers and shard.scanner.sh.transport() == "rccl":
+            sharded.check_peers(peers, world)
     n_own = shard.n_own_bytes
     ctx.reserve(shard.ext.numel())
     table = torch.empty((shard.max_records + 64, 6), dtype=torch.int64, device=dev)
@@ -660,20 +669,39 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
                 note(out)
             return out
 
-        if n_untimed:
-            out = run(n_untimed, False)
-        barrier()
-        t0 = time.perf_counter()
-        out = run(args.steps, True)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if te_l > 1:
-            t_keep, c_keep = list(t_done), list(comm_steps)
-            ms_index.clear()
-            run(max(20, args.steps + (args.steps & 1)), True, every=1)      # (an even count: the last step's lane stays the same)
-            t_done[:] = t_keep
-            comm_steps[:] = c_keep
-            barrier()
+        # (diagnostics, tests/test_watchdog.py: FFQ_BENCH_INJECT_STALL=hand-off|scan|gather makes the first step of this rank hang
+        # there -- a kernel that waits for a host flag --, so that the watchdog and the recovery below run without a broken peer)
+        inj = os.environ.get("FFQ_BENCH_INJECT_STALL")
+        if inj and getattr(shard, "native", False):
+            shard.scanner.sh.inject_stall(hip.STAGE_NAMES.index(inj), 60.0)
+        # A step that does not come back is an exception on every rank (the step watchdog: hip.FFQTimeout names the stage
+        # and the ranks), not a hang.  On the RCCL transport the steps are then taken ONCE more in serial mode -- a new
+        # communicator, ONE, everything on the scan stream (SyntheticShard.recover_serial) -- and `comm` says so.
+        for attempt in (0, 1):
+            try:
+                if n_untimed:
+                    out = run(n_untimed, False)
+                barrier()
+                t0 = time.perf_counter()
+                out = run(args.steps, True)
+                barrier()
+                elapsed = time.perf_counter() - t0
+                if te_l > 1:
+                    t_keep, c_keep = list(t_done), list(comm_steps)
+                    ms_index.clear()
+                    run(max(20, args.steps + (args.steps & 1)), True, every=1)      # (an even count: the last step's lane stays the same)
+                    t_done[:] = t_keep
+                    comm_steps[:] = c_keep
+                    barrier()
+                break
+            except hip.FFQTimeout as e:
+                sys.stderr.write("[bench rank %d] %s\n" % (rank, e))
+                if attempt or not (getattr(shard, "native", False) and shard.scanner.sh.transport() == "rccl"):
+                    raise
+                sys.stderr.write("[bench rank %d] -> once more with the serial step (one communicator, one stream)\n" % rank)
+                shard.recover_serial(e)
+                for lst in (comm_steps, ms_index, ms_chain, ms_decode, ms_total, t_done):
+                    lst.clear()
         table = tables[(args.steps - 1) & 1]
         qual, qoff = quals[(args.steps - 1) & 1], qoffs[(args.steps - 1) & 1]
     if dist is not None:
@@ -812,6 +840,15 @@ def run_workload(name, args, ctx, rank, world, dev, dist):
             "comm": None if not comm_steps else {
                 "transport": ("RCCL (ffq_shard_*, include/ffq.h)" if shard.scanner.sh.transport() == "rccl" else shard.scanner.sh.transport())
                              if hasattr(shard.scanner, "sh") else "host step (ffq_shard_host_step) over %s" % shard.scanner.transport_name,
+                # who was there: ranks of the communicator the words were gathered on (ncclCommCount; asserted == --gpus
+                # before the timed region), every rank's GPU by PCI bus id (gathered over RCCL at set-up; asserted distinct),
+                # which step ran (pipelined: two communicators, three streams; serial: one and one) and, if the watchdog
+                # tripped on the way, what it said
+                "nranks": comm_steps[-1].get("nranks"),
+                "mode": comm_steps[-1].get("mode"),
+                "bus_ids": (shard.scanner.info() if hasattr(shard.scanner, "sh") else {}).get("bus_ids"),
+                "watchdog_s": (peers or {}).get("timeout_s"),
+                "recovered_from": getattr(shard, "recovered", None),
                 "steps": len(comm_steps),
                 "handoff_ms": round(float(np.mean([c["handoff_ms"] for c in comm_steps])), 4),
                 "handoff_bytes": int(np.mean([c["handoff_bytes"] for c in comm_steps])),
@@ -1019,15 +1056,37 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    ctl = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         if dry:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            # (torch's own collectives -- barriers, the reduction of the timings -- give up after 5 minutes instead of the
+            # default 10; the control group is gloo: the library's communicator ids travel over it, also when a new one is
+            # needed because the GPUs' fabric has just swallowed a collective)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
+            ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
 
     ctx = hip.Context(local_rank)
-    line, (shard, flags) = run_workload(args.workload, args, ctx, rank, world, dev, dist)
+    try:
+        line, (shard, flags) = run_workload(args.workload, args, ctx, rank, world, dev, dist, ctl)
+    except Exception as e:      # noqa: BLE001
+        # the measured workload itself failed (N > 1: a step that did not come back even in serial mode, ranks that share a
+        # GPU, a communicator that counts the wrong number of ranks): a line that SAYS so instead of a silent death at the
+        # driver's timeout
+        import traceback
+        traceback.print_exc()
+        if rank == 0:
+            import ctypes
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps({"metric": "GB/s FASTQ parsed", "value": None, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+                              "config": {"workload": args.workload}, "error": "%s: %s" % (type(e).__name__, e),
+                              "wall_s": round(time.perf_counter() - t_main, 1)}), flush=True)
+        os._exit(1)              # (no collective tear-down: a peer may be gone)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             sample = shard.host_sample(256 << 20)
@@ -1064,7 +1123,9 @@ def main():
         # file-backed byte-range shards (collective: every rank takes part; the line is rank 0's).  On a real multi-GPU run
         # only on request (FFQ_BENCH_SHARDED_FILE=1): it is a host-inclusive extra, and nothing that is not the metric
         # should be able to hold up the ranks of the measured line
-        sf = guarded(sharded_file, ctx, shard, rank, world, dev, dist) if world == 1 else sharded_file(ctx, shard, rank, world, dev, dist)
+        # (guarded at every N: with the step watchdog a collective that does not come back is an exception on every rank,
+        # not a hang, and the measured line goes out either way)
+        sf = guarded(sharded_file, ctx, shard, rank, world, dev, dist)
         if rank == 0:
             line.setdefault("host_inclusive", {})
             if line["host_inclusive"] is None:
@@ -1089,7 +1150,13 @@ def main():
                     continue
                 ol, keep = got
             else:
-                ol, keep = run_workload(other, args, ctx_o, rank, world, dev, dist)
+                # (guarded at N > 1 too: a step that does not come back is an exception on every rank -- the watchdog --, and
+                # the measured line goes out either way)
+                got = guarded(run_workload, other, args, ctx_o, rank, world, dev, dist, ctl)
+                if isinstance(got, dict):
+                    others[other] = got
+                    continue
+                ol, keep = got
             del keep
             ctx_o.close()
             torch.cuda.empty_cache()

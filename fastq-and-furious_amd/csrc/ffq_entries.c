@@ -98,35 +98,98 @@ done:
  * bytes come from the stream's bulk decode on the device -- qual (int8) with the offsets qoff (int64,
  * one more than rows: where each record's bytes start, and where the last one's end) -- and are only
  * wrapped here.  array_type: array.array.                                                         */
-/* One array('b') that lives from call to call: a fill's decoded bytes are copied INTO it (its own buffer, through the buffer
- * protocol) and the records' arrays are slices of it.  Until round 5 every call built a bytes object of the whole fill and an
- * array from that -- two allocations and two copies of megabytes per fill, unmapped again at the end of the call; with a
- * process full of threads (torch imported: 80 of them) the page faults of those fresh mappings cost more than the slices. */
-static PyObject *g_big = NULL, *g_big_type = NULL;
-static Py_ssize_t g_big_cap = 0;
+/* How a record's array('b') is made.  The array module has no C API; what Python offers is the constructor (a call with a
+ * typecode string per record) or slicing ONE big array (a slice object + the subscript protocol per record: what round 5
+ * did, out of a process-global array that a second thread's call could overwrite mid-loop -- the round-5 advisor's finding).
+ * Round 6: the records' arrays are built DIRECTLY -- tp_alloc of the array type, the items from PyMem_Malloc, the
+ * descriptor taken from an array('b') the real constructor made -- which is what arraymodule.c's newarrayobject does, with
+ * no global state at all.  That relies on CPython's private `arrayobject` layout, so it is used only when a probe at first
+ * use finds every field where this file expects it (size, item pointer, allocation, export count observed through the
+ * public buffer protocol); otherwise -- another CPython -- the records are slices of a PER-CALL array.               */
+typedef struct {
+    PyObject_VAR_HEAD
+    char *ob_item;
+    Py_ssize_t allocated;
+    const void *ob_descr;
+    PyObject *weakreflist;
+    Py_ssize_t ob_exports;
+} ffq_arrayobject;
 
-static PyObject *big_array(PyObject *atype, const char *src, Py_ssize_t n)
+static int g_direct = -1;                 /* -1: not probed yet; 0: slices of a per-call array; 1: direct construction */
+static const void *g_descr_b = NULL;      /* array('b')'s type descriptor (static data of the array module) */
+static PyTypeObject *g_direct_type = NULL;
+
+/* array_type('b', bytes-of-n) through the public constructor */
+static PyObject *array_from(PyObject *atype, const char *src, Py_ssize_t n)
 {
-    if (!g_big || g_big_type != atype || g_big_cap < n) {
-        const Py_ssize_t cap = n + n / 4 + (1 << 16);
-        PyObject *raw = PyBytes_FromStringAndSize(NULL, cap);
-        PyObject *nb = raw ? PyObject_CallFunction(atype, "sO", "b", raw) : NULL;
-        Py_XDECREF(raw);
-        if (!nb) return NULL;
-        Py_XDECREF(g_big); Py_XDECREF(g_big_type);
-        g_big = nb; g_big_cap = cap; g_big_type = atype; Py_INCREF(atype);
-    }
+    PyObject *raw = PyBytes_FromStringAndSize(src, n);
+    PyObject *a = raw ? PyObject_CallFunction(atype, "sO", "b", raw) : NULL;
+    Py_XDECREF(raw);
+    return a;
+}
+
+static void probe_direct(PyObject *atype)
+{
+    g_direct = 0;
+#if PY_VERSION_HEX >= 0x03080000 && PY_VERSION_HEX < 0x030D0000 && !defined(PYPY_VERSION)
+    if (!PyType_Check(atype)) return;
+    PyTypeObject *tp = (PyTypeObject *)atype;
+    if (tp->tp_basicsize != (Py_ssize_t)sizeof(ffq_arrayobject) || tp->tp_itemsize != 0) return;
+    static const char pat[7] = {1, -2, 3, -4, 5, -6, 7};
+    PyObject *a = array_from(atype, pat, 7);
+    if (!a) { PyErr_Clear(); return; }
+    ffq_arrayobject *ao = (ffq_arrayobject *)a;
     Py_buffer v;
-    if (PyObject_GetBuffer(g_big, &v, PyBUF_WRITABLE) != 0) return NULL;
-    if (v.len < n || v.itemsize != 1) {
+    int ok = Py_TYPE(a) == tp && Py_SIZE(a) == 7 && ao->allocated >= 7 && ao->ob_item && ao->ob_exports == 0 && ao->weakreflist == NULL &&
+             memcmp(ao->ob_item, pat, 7) == 0 && ao->ob_descr != NULL;
+    if (ok && PyObject_GetBuffer(a, &v, PyBUF_SIMPLE) == 0) {
+        ok = v.buf == (void *)ao->ob_item && v.len == 7 && v.itemsize == 1 && ao->ob_exports == 1;
         PyBuffer_Release(&v);
-        PyErr_SetString(PyExc_TypeError, "array_type('b', bytes) did not give an array of bytes");
-        return NULL;
+        ok = ok && ao->ob_exports == 0;
+    } else { PyErr_Clear(); ok = 0; }
+    if (ok) {
+        /* one built by hand must BE an array: equal to the constructor's, typecode 'b', growable, freed by the type's own dealloc */
+        ffq_arrayobject *h = (ffq_arrayobject *)tp->tp_alloc(tp, 0);
+        if (h) {
+            h->ob_item = (char *)PyMem_Malloc(7);
+            if (h->ob_item) {
+                memcpy(h->ob_item, pat, 7);
+                h->allocated = 7; h->ob_descr = ao->ob_descr; h->weakreflist = NULL; h->ob_exports = 0;
+                Py_SET_SIZE(h, 7);
+                PyObject *tc = PyObject_GetAttrString((PyObject *)h, "typecode");
+                const int same = PyObject_RichCompareBool((PyObject *)h, a, Py_EQ);
+                PyObject *r = PyObject_CallMethod((PyObject *)h, "append", "i", -8);
+                ok = same == 1 && tc && PyUnicode_Check(tc) && PyUnicode_CompareWithASCIIString(tc, "b") == 0 && r && Py_SIZE(h) == 8 &&
+                     h->ob_item[7] == -8;
+                Py_XDECREF(tc); Py_XDECREF(r);
+                if (PyErr_Occurred()) { PyErr_Clear(); ok = 0; }
+            } else ok = 0;
+            Py_DECREF((PyObject *)h);
+        } else { PyErr_Clear(); ok = 0; }
     }
-    memcpy(v.buf, src, (size_t)n);
-    PyBuffer_Release(&v);
-    Py_INCREF(g_big);
-    return g_big;
+    if (ok) { g_direct = 1; g_descr_b = ao->ob_descr; g_direct_type = tp; Py_INCREF(atype); }
+    Py_DECREF(a);
+#else
+    (void)atype;
+#endif
+}
+
+static inline PyObject *array_direct(const char *src, Py_ssize_t n)
+{
+    ffq_arrayobject *h = (ffq_arrayobject *)g_direct_type->tp_alloc(g_direct_type, 0);
+    if (!h) return NULL;
+    h->ob_item = NULL;
+    if (n > 0) {
+        h->ob_item = (char *)PyMem_Malloc((size_t)n);
+        if (!h->ob_item) { Py_DECREF((PyObject *)h); return PyErr_NoMemory(); }
+        memcpy(h->ob_item, src, (size_t)n);
+    }
+    h->allocated = n; h->ob_descr = g_descr_b; h->weakreflist = NULL; h->ob_exports = 0;
+    Py_SET_SIZE(h, n);
+    /* (CPython 3.10's array is a heap type and as such a GC type: its traverse visits the type alone -- nothing a cycle
+     * could go through -- so the records' arrays need not sit on the collector's lists, like their tuples) */
+    if (PyType_IS_GC(g_direct_type)) PyObject_GC_UnTrack((PyObject *)h);
+    return (PyObject *)h;
 }
 
 static PyObject *entries_phred(PyObject *self, PyObject *args)
@@ -151,10 +214,13 @@ static PyObject *entries_phred(PyObject *self, PyObject *args)
             PyErr_SetString(PyExc_ValueError, "quality offsets do not fit the decoded stream");
             goto done;
         }
-        /* the decoded bytes of all these rows as ONE array('b'); a record's array is a slice of it (the
-         * array type's own slicing: no constructor call with a typecode per record) */
-        big = big_array(atype, (const char *)qual.buf + q0, (Py_ssize_t)(o[n] - q0));
-        if (!big) goto done;
+        if (g_direct < 0 || (g_direct == 1 && (PyObject *)g_direct_type != atype)) probe_direct(atype);
+        const int direct = g_direct == 1 && (PyObject *)g_direct_type == atype;
+        if (!direct) {
+            /* the decoded bytes of all these rows as ONE array('b') of this call's own; a record's array is a slice of it */
+            big = array_from(atype, (const char *)qual.buf + q0, (Py_ssize_t)(o[n] - q0));
+            if (!big) goto done;
+        }
         list = PyList_New(n);
         if (!list) goto done;
         for (Py_ssize_t i = 0; i < n; i++, p += 6) {
@@ -168,7 +234,8 @@ static PyObject *entries_phred(PyObject *self, PyObject *args)
             }
             PyObject *h = cut(base, buf.len, p[0] - shift + 1, p[1] - shift);
             PyObject *s = cut(base, buf.len, p[2] - shift, p[3] - shift);
-            PyObject *q = PySequence_GetSlice(big, (Py_ssize_t)(o[i] - q0), (Py_ssize_t)(o[i] + ln - q0));
+            PyObject *q = direct ? array_direct((const char *)qual.buf + o[i], (Py_ssize_t)ln)
+                                 : PySequence_GetSlice(big, (Py_ssize_t)(o[i] - q0), (Py_ssize_t)(o[i] + ln - q0));
             PyObject *t = !(h && s && q) ? NULL : PyTuple_New(3);
             if (!t) {
                 Py_XDECREF(h); Py_XDECREF(s); Py_XDECREF(q);

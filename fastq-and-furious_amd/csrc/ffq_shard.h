@@ -86,12 +86,29 @@ __global__ __launch_bounds__(64) void k_shard_words(const DevRes *__restrict__ r
     }
 }
 
+// diagnostics (ffq_shard_inject_stall): one lane waits for a host flag -- or for `budget` ticks of the 100 MHz wall clock,
+// whichever comes first: it cannot outlive its budget --, so that a step hangs at a chosen stage without a broken peer
+__global__ __launch_bounds__(64) void k_shard_stall(const int *flag, unsigned long long budget)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < budget)
+        __builtin_amdgcn_s_sleep(127);
+}
+
 // ---- transports ---------------------------------------------------------------------------------------------------
 typedef std::function<uint8_t *(int64_t, int64_t)> ShPtrFn;
 
 struct ShTransport {
     int rank = 0, world = 1;
+    bool serial = false;                   // ONE communicator on ONE stream (the fallback mode; include/ffq.h)
+    bool poisoned = false, aborted = false;
+    double timeout_s = sh_default_timeout();
+    std::vector<int64_t> bus;              // PCI bus id of every rank's GPU (-1: unknown)
     virtual ~ShTransport() {}
+    virtual int nranks(int /*which: 0 hand-off, 1 gather*/) const { return world; }
+    virtual const char *async_error() { return nullptr; }           // RCCL: ncclCommGetAsyncError of either communicator
+    virtual void abort() { aborted = true; }                        // RCCL: ncclCommAbort
     // every piece of the plan this rank sends or receives, enqueued on `st`
     virtual int exchange(const std::vector<ShPiece> &plan, const ShPtrFn &provide, const ShPtrFn &accept, hipStream_t st) = 0;
     // the words of every rank: d_mine (device, SH_WORDS int64) -> h_all (pinned, world * SH_WORDS); enqueue on `st`, then finish
@@ -113,6 +130,9 @@ struct RcclApi {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
 };
 
 static RcclApi *rccl_api()
@@ -131,9 +151,10 @@ static RcclApi *rccl_api()
 #define FFQ_RCCL_SYM(f) api.f = reinterpret_cast<decltype(api.f)>(dlsym(api.h, "nccl" #f))
         FFQ_RCCL_SYM(GetUniqueId); FFQ_RCCL_SYM(CommInitRank); FFQ_RCCL_SYM(CommDestroy); FFQ_RCCL_SYM(GetErrorString);
         FFQ_RCCL_SYM(AllGather); FFQ_RCCL_SYM(Broadcast); FFQ_RCCL_SYM(Send); FFQ_RCCL_SYM(Recv); FFQ_RCCL_SYM(GroupStart); FFQ_RCCL_SYM(GroupEnd);
+        FFQ_RCCL_SYM(CommCount); FFQ_RCCL_SYM(CommAbort); FFQ_RCCL_SYM(CommGetAsyncError);
 #undef FFQ_RCCL_SYM
         if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.Broadcast || !api.Send || !api.Recv ||
-            !api.GroupStart || !api.GroupEnd)
+            !api.GroupStart || !api.GroupEnd || !api.CommCount || !api.CommAbort)
             api.h = nullptr;
     });
     return api.h ? &api : nullptr;
@@ -146,35 +167,127 @@ static RcclApi *rccl_api()
             return fail(FFQ_E_HIP, "%s failed: %s", #expr, A->GetErrorString ? A->GetErrorString(r__) : "rccl error"); \
     } while (0)
 
-// RCCL over xGMI: the hand-offs and the gather on communicators of their own (one per stream: the hand-off of step i + 1
-// runs beside the scan of step i, the gather of step i behind that scan)
+// PCI domain << 16 | bus << 8 | device << 3 (| function 0) of a HIP device: what tells two ranks on ONE GPU from two GPUs
+static int64_t sh_bus_id(int device)
+{
+    int dom = 0, bus = 0, dev = 0;
+    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess ||
+        hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess ||
+        hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) != hipSuccess) return -1;
+    return ((int64_t)dom << 16) | ((int64_t)(bus & 0xFF) << 8) | ((int64_t)(dev & 0x1F) << 3);
+}
+
+// The watchdog's wait: polls `ev` until it is through, `seconds` have passed (1) or the transport reports an
+// asynchronous error (2); seconds <= 0: an ordinary wait.  A step is through in milliseconds, so the first two are
+// spun and the rest slept in 100 us pieces.
+static int sh_wait_event(hipEvent_t ev, double seconds, ShTransport *tr, double *waited = nullptr)
+{
+    if (seconds <= 0) { HIPCHK(hipEventSynchronize(ev)); return 0; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1;; spins++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail(FFQ_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+        if ((spins & 31) == 0) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited) *waited = dt;
+            if (tr && dt > 1e-3 && tr->async_error()) return 2;
+            if (dt > seconds) return 1;
+            if (dt > 2e-3) usleep(100);
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+// RCCL over xGMI.  Pipelined mode: the hand-offs and the gather on communicators of their own (one per stream: the
+// hand-off of step i + 1 runs beside the scan of step i, the gather of step i behind that scan).  Serial mode: cx alone,
+// everything on the scan stream.
 struct ShRccl : ShTransport {
     RcclApi *A = nullptr;
     ncclComm_t cx = nullptr, cg = nullptr;
     bool owner = true;                     // (a shard created beside another one borrows its communicators)
+    int n_cx = 0, n_cg = 0;
+    char async_text[160] = {0};
     ~ShRccl() override
     {
-        if (owner && A) { if (cx) A->CommDestroy(cx); if (cg) A->CommDestroy(cg); }
+        if (!owner || !A) return;
+        // (a communicator a collective is stuck on is aborted, not destroyed: ncclCommDestroy would wait for it)
+        if (cx) { if (poisoned) A->CommAbort(cx); else A->CommDestroy(cx); }
+        if (cg) { if (poisoned) A->CommAbort(cg); else A->CommDestroy(cg); }
     }
-    int init(const uint8_t *id128, int rank_, int world_, hipStream_t st)
+    int nranks(int which) const override { return which ? n_cg : n_cx; }
+    const char *async_error() override
+    {
+        if (!A || !A->CommGetAsyncError) return nullptr;
+        ncclComm_t cs[2] = {cx, cg};
+        for (ncclComm_t c : cs) {
+            ncclResult_t r = ncclSuccess;
+            if (c && A->CommGetAsyncError(c, &r) == ncclSuccess && r != ncclSuccess && r != ncclInProgress) {
+                snprintf(async_text, sizeof async_text, "%s", A->GetErrorString ? A->GetErrorString(r) : "rccl error");
+                return async_text;
+            }
+        }
+        return nullptr;
+    }
+    void abort() override
+    {
+        if (aborted) return;
+        aborted = true;
+        if (owner && A) {
+            if (cx) { A->CommAbort(cx); cx = nullptr; }
+            if (cg) { A->CommAbort(cg); cg = nullptr; }
+        }
+    }
+    // a collective of the set-up, waited for with the watchdog's deadline: the FIRST thing that talks to the peers must
+    // not be able to hang either
+    int settle(hipStream_t st, const char *what)
+    {
+        hipEvent_t ev = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, st);
+        int w = e == hipSuccess ? sh_wait_event(ev, timeout_s, this) : fail(FFQ_E_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+        if (w <= 0) (void)hipEventDestroy(ev);            // (left alone while something may still refer to it)
+        if (w == 0) return FFQ_OK;
+        if (w < 0) return w;
+        poisoned = true;
+        if (w == 2) return fail(FFQ_E_HIP, "ffq_shard_create: rank %d of %d: RCCL reports an asynchronous error during %s: %s", rank, world, what, async_text);
+        return fail(FFQ_E_TIMEOUT, "ffq_shard_create: rank %d of %d: %s did not complete within %.1f s (FFQ_SHARD_TIMEOUT_S): a peer is missing or the fabric does not carry the communicator",
+                    rank, world, what, timeout_s);
+    }
+    int init(const uint8_t *id128, int rank_, int world_, int device, hipStream_t st, bool serial_)
     {
         A = rccl_api();
         if (!A) return fail(FFQ_E_NODEVICE, "ffq_shard: librccl could not be loaded (FFQ_RCCL_LIB names another copy)");
-        rank = rank_; world = world_;
+        rank = rank_; world = world_; serial = serial_;
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
         RCCLCHK(A->CommInitRank(&cx, world, id, rank));
-        // the second communicator: rank 0 draws its id and sends it round over the first
-        ncclUniqueId id2;
-        if (rank == 0) RCCLCHK(A->GetUniqueId(&id2));
-        uint8_t *d_id = nullptr;
-        HIPCHK(hipMalloc((void **)&d_id, sizeof id2));
-        if (rank == 0) HIPCHK(hipMemcpyAsync(d_id, &id2, sizeof id2, hipMemcpyHostToDevice, st));
-        RCCLCHK(A->Broadcast(d_id, d_id, sizeof id2, ncclUint8, 0, cx, st));
-        HIPCHK(hipMemcpyAsync(&id2, d_id, sizeof id2, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        (void)hipFree(d_id);
-        RCCLCHK(A->CommInitRank(&cg, world, id2, rank));
+        RCCLCHK(A->CommCount(cx, &n_cx));
+        // who is there: every rank's PCI bus id, ONE all-gather on the new communicator (and its first collective)
+        bus.assign((size_t)world, -1);
+        int64_t *d_b = nullptr;
+        HIPCHK(hipMalloc((void **)&d_b, (size_t)(world + 1) * 8 + sizeof(ncclUniqueId)));
+        const int64_t mine = sh_bus_id(device);
+        HIPCHK(hipMemcpyAsync(d_b + world, &mine, 8, hipMemcpyHostToDevice, st));
+        RCCLCHK(A->AllGather(d_b + world, d_b, 1, ncclInt64, cx, st));
+        HIPCHK(hipMemcpyAsync(bus.data(), d_b, (size_t)world * 8, hipMemcpyDeviceToHost, st));
+        int rc = settle(st, "the first all-gather (the ranks' bus ids)");
+        if (rc) return rc;                  // (d_b is left to the process: something may still write it)
+        if (!serial) {
+            // the second communicator: rank 0 draws its id and sends it round over the first
+            ncclUniqueId id2;
+            if (rank == 0) RCCLCHK(A->GetUniqueId(&id2));
+            uint8_t *d_id = reinterpret_cast<uint8_t *>(d_b + world + 1);
+            if (rank == 0) HIPCHK(hipMemcpyAsync(d_id, &id2, sizeof id2, hipMemcpyHostToDevice, st));
+            RCCLCHK(A->Broadcast(d_id, d_id, sizeof id2, ncclUint8, 0, cx, st));
+            HIPCHK(hipMemcpyAsync(&id2, d_id, sizeof id2, hipMemcpyDeviceToHost, st));
+            if ((rc = settle(st, "the broadcast of the second communicator's id"))) return rc;
+            RCCLCHK(A->CommInitRank(&cg, world, id2, rank));
+            RCCLCHK(A->CommCount(cg, &n_cg));
+        }
+        (void)hipFree(d_b);
+        if (n_cx != world || (!serial && n_cg != world))
+            return fail(FFQ_E_INTERNAL, "ffq_shard_create: the communicators count %d / %d ranks, the world has %d", n_cx, n_cg, world);
         return FFQ_OK;
     }
     int exchange(const std::vector<ShPiece> &plan, const ShPtrFn &provide, const ShPtrFn &accept, hipStream_t st) override
@@ -192,28 +305,42 @@ struct ShRccl : ShTransport {
     }
     int gather_enqueue(const int64_t *d_mine, int64_t *d_all, int64_t *h_all, hipStream_t st) override
     {
-        RCCLCHK(A->AllGather(d_mine, d_all, SH_WORDS, ncclInt64, cg, st));
+        RCCLCHK(A->AllGather(d_mine, d_all, SH_WORDS, ncclInt64, serial ? cx : cg, st));
         HIPCHK(hipMemcpyAsync(h_all, d_all, (size_t)world * SH_WORDS * 8, hipMemcpyDeviceToHost, st));
         return FFQ_OK;
     }
-    // (the event, not the stream: the next step's front may already be queued behind this one's gather)
-    int gather_finish(int64_t *, hipEvent_t done) override { HIPCHK(hipEventSynchronize(done)); return FFQ_OK; }
+    // (the step waits for the gather's end event itself, with the watchdog: nothing left to do here)
+    int gather_finish(int64_t *, hipEvent_t) override { return FFQ_OK; }
     const char *name() const override { return "rccl"; }
 };
 
 // k logical ranks as threads of ONE process (ranges of one resident buffer on one GPU): hand-offs by device copies
 struct ShLocal : ShTransport {
     ffq_shard_world *W = nullptr;
+    int last_stage = FFQ_SHARD_STAGE_NONE;
+    // the in-process world's barrier with the watchdog's deadline: whoever runs out of time breaks it for everybody
+    int meet(int stage)
+    {
+        const int r = W->wait_for(rank, timeout_s);
+        if (r > 0) return FFQ_OK;
+        if (r < 0 || W->timed_out) {
+            poisoned = true; last_stage = stage;
+            return fail(FFQ_E_TIMEOUT, "ffq_shard: rank %d of %d: no progress within %.1f s at stage '%s' (transport in-process, %s step): rank(s) %s did not arrive",
+                        rank, world, timeout_s, sh_stage_name(stage), serial ? "serial" : "pipelined", W->absent_list().c_str());
+        }
+        return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
+    }
     int exchange(const std::vector<ShPiece> &plan, const ShPtrFn &provide, const ShPtrFn &accept, hipStream_t st) override
     {
         W->providers[rank] = &provide;
-        if (!W->wait()) return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
+        int rc = meet(FFQ_SHARD_STAGE_HANDOFF);
+        if (rc) return rc;
         hipError_t e = hipSuccess;
         for (const ShPiece &p : plan)
             if (p.dst == rank && e == hipSuccess)
                 e = hipMemcpyAsync(accept(p.a, p.b), (*static_cast<const ShPtrFn *>(W->providers[p.src]))(p.a, p.b), (size_t)(p.b - p.a), hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);            // the sources must stay as they are until read
-        if (!W->wait()) return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
+        if ((rc = meet(FFQ_SHARD_STAGE_HANDOFF))) return rc;
         if (e != hipSuccess) return fail(FFQ_E_HIP, "ffq_shard: hand-off copy failed: %s", hipGetErrorString(e));
         return FFQ_OK;
     }
@@ -222,14 +349,13 @@ struct ShLocal : ShTransport {
         HIPCHK(hipMemcpyAsync(h_all + (size_t)rank * SH_WORDS, d_mine, SH_WORDS * 8, hipMemcpyDeviceToHost, st));
         return FFQ_OK;
     }
-    int gather_finish(int64_t *h_all, hipEvent_t done) override
+    int gather_finish(int64_t *h_all, hipEvent_t) override            // (this rank's words are on the host: the step has waited for them)
     {
-        HIPCHK(hipEventSynchronize(done));
         memcpy(&W->slots[(size_t)rank * SH_WORDS], h_all + (size_t)rank * SH_WORDS, SH_WORDS * 8);
-        if (!W->wait()) return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
+        int rc = meet(FFQ_SHARD_STAGE_GATHER);
+        if (rc) return rc;
         memcpy(h_all, W->slots.data(), (size_t)world * SH_WORDS * 8);
-        if (!W->wait()) return fail(FFQ_E_INTERNAL, "ffq_shard: another logical rank failed");
-        return FFQ_OK;
+        return meet(FFQ_SHARD_STAGE_GATHER);
     }
     const char *name() const override { return "in-process"; }
 };
@@ -238,6 +364,8 @@ struct ShLocal : ShTransport {
 // processes on ONE GPU (a dry run; RCCL refuses two ranks per device), a group over gloo or MPI.  Hand-offs are staged
 // through host memory (device -> host, the caller's exchange, host -> device), the words gathered by the caller's
 // allgather once this rank's are on the host.  Functional, not fast: file-backed shards hand off nothing and gather 64 bytes.
+// (The watchdog covers the device side of a step; how long a callback may block is the caller's transport's business --
+// a gloo group has its own timeout.)
 struct ShHosted : ShTransport {
     ffq_shard_host_ops ops{};
     int exchange(const std::vector<ShPiece> &plan, const ShPtrFn &provide, const ShPtrFn &accept, hipStream_t st) override
@@ -269,9 +397,8 @@ struct ShHosted : ShTransport {
         HIPCHK(hipMemcpyAsync(h_all + (size_t)rank * SH_WORDS, d_mine, SH_WORDS * 8, hipMemcpyDeviceToHost, st));
         return FFQ_OK;
     }
-    int gather_finish(int64_t *h_all, hipEvent_t done) override
+    int gather_finish(int64_t *h_all, hipEvent_t) override
     {
-        HIPCHK(hipEventSynchronize(done));
         int64_t mine[SH_WORDS];
         memcpy(mine, h_all + (size_t)rank * SH_WORDS, sizeof mine);
         const int r = ops.allgather(ops.user, mine, h_all);
@@ -316,7 +443,20 @@ struct ffq_shard {
     int fd = -1;
     uint8_t *file_ext = nullptr;
     bool from_file = false;                // the pending step runs over file_ext
+    // the watchdog (include/ffq.h): where the last trip found the step; a stall to inject into the next one
+    int last_stage = FFQ_SHARD_STAGE_NONE;
+    int stall_stage = FFQ_SHARD_STAGE_NONE;
+    double stall_s = 0;
+    int *h_stall = nullptr, *hm_stall = nullptr;     // the flag an injected stall waits for (host-mapped)
+    bool leaked = false;                   // an abort could not drain the streams: destroy frees nothing on the device
+    // a failure of THIS rank's own scan inside a step: the peers are told through the words before it is returned
+    int local_fail = 0;
+    std::string local_msg;
 };
+
+// the streams of a step: the pipelined step's own three, or -- serial -- the scan stream for everything
+static hipStream_t sh_xs(const ffq_shard *s, bool overlap) { return (overlap && !s->tr->serial) ? s->comm : s->c->stream; }
+static hipStream_t sh_gs(const ffq_shard *s) { return s->tr->serial ? s->c->stream : s->gstream; }
 
 static bool sh_debug() { static const bool on = getenv("FFQ_SHARD_DEBUG") != nullptr; return on; }
 
@@ -340,7 +480,40 @@ static int shard_alloc(ffq_shard *s, ffq_shard *parent = nullptr)
     HIPCHK(hipHostMalloc((void **)&s->h_all, (size_t)s->world * SH_WORDS * 8, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&s->h_own, 16 * 8, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void **)&s->hm_own, s->h_own, 0));
+    HIPCHK(hipHostMalloc((void **)&s->h_stall, 64, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&s->hm_stall, s->h_stall, 0));
+    *s->h_stall = 0;
     return FFQ_OK;
+}
+
+static bool sh_serial_env() { const char *e = getenv("FFQ_SHARD_SERIAL"); return e && *e && *e != '0'; }
+
+// every stream of the shard idle within `seconds`?  (after an abort: kernels of a collective that waited for a peer leave)
+static bool shard_drained(ffq_shard *s, double seconds)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t sts[3] = {s->owns_streams ? s->comm : nullptr, s->owns_streams ? s->gstream : nullptr, s->c->stream};
+    for (;;) {
+        bool busy = false;
+        for (hipStream_t st : sts) if (st && hipStreamQuery(st) == hipErrorNotReady) busy = true;
+        if (!busy) return true;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+        usleep(200);
+    }
+}
+
+extern "C" int ffq_shard_abort(ffq_shard *s)
+{
+    if (!s) return fail(FFQ_E_ARG, "ffq_shard_abort: NULL shard");
+    (void)hipSetDevice(s->c->device);
+    if (s->h_stall) __atomic_store_n(s->h_stall, 1, __ATOMIC_RELEASE);
+    if (s->tr) { s->tr->poisoned = true; s->tr->abort(); }
+    s->pending = false;
+    s->c->pend.active = false;              // (the scan of the abandoned step: its result is never read)
+    mark_other(s->c);
+    if (shard_drained(s, 10.0)) return FFQ_OK;
+    s->leaked = true;
+    return fail(FFQ_E_TIMEOUT, "ffq_shard_abort: rank %d of %d: the shard's streams did not drain within 10 s of the abort", s->rank, s->world);
 }
 
 static int shard_common(ffq_ctx *c, int rank, int world, const int64_t *bounds, int64_t tail_bytes, int64_t head_bytes, ffq_shard **out)
@@ -366,6 +539,15 @@ extern "C" void ffq_shard_destroy(ffq_shard *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->c->device);
+    if (s->h_stall) __atomic_store_n(s->h_stall, 1, __ATOMIC_RELEASE);
+    if (s->tr && s->tr->poisoned && !s->leaked) (void)ffq_shard_abort(s);      // (a step that never came back: do not wait for it here)
+    if (s->leaked) {
+        // something still runs on the shard's streams and nothing will stop it: the device memory those kernels may touch,
+        // the streams and the events stay (hipFree would wait for the device); the host objects go
+        if (s->owns_tr) delete s->tr;
+        delete s;
+        return;
+    }
     if (s->comm) { (void)hipStreamSynchronize(s->comm); }
     if (s->gstream) { (void)hipStreamSynchronize(s->gstream); }
     (void)hipStreamSynchronize(s->c->stream);
@@ -378,6 +560,7 @@ extern "C" void ffq_shard_destroy(ffq_shard *s)
     (void)hipFree(s->d_words); (void)hipFree(s->d_all); (void)hipFree(s->grown);
     if (s->h_all) (void)hipHostFree(s->h_all);
     if (s->h_own) (void)hipHostFree(s->h_own);
+    if (s->h_stall) (void)hipHostFree(s->h_stall);
     delete s;
 }
 
@@ -393,8 +576,8 @@ extern "C" int ffq_shard_unique_id(uint8_t *id128)
     return FFQ_OK;
 }
 
-extern "C" int ffq_shard_create(ffq_ctx *c, const uint8_t *id128, int rank, int world, const int64_t *bounds,
-                                int64_t tail_bytes, int64_t head_bytes, ffq_shard **out)
+extern "C" int ffq_shard_create2(ffq_ctx *c, const uint8_t *id128, int rank, int world, const int64_t *bounds,
+                                 int64_t tail_bytes, int64_t head_bytes, uint32_t mode, ffq_shard **out)
 {
     if (!id128) return fail(FFQ_E_ARG, "ffq_shard_create: NULL unique id");
     int rc = shard_common(c, rank, world, bounds, tail_bytes, head_bytes, out);
@@ -405,11 +588,20 @@ extern "C" int ffq_shard_create(ffq_ctx *c, const uint8_t *id128, int rank, int 
     if (!rc) {
         ShRccl *t = new (std::nothrow) ShRccl();
         s->tr = t;
-        rc = t ? t->init(id128, rank, world, s->comm) : fail(FFQ_E_NOMEM, "out of host memory");
+        // (serial: the one-communicator step from the start -- the second communicator is never made, the set-up's own
+        // collectives run on the scan stream)
+        const bool serial = (mode & FFQ_SHARD_F_SERIAL) != 0;
+        rc = t ? t->init(id128, rank, world, c->device, serial ? c->stream : s->comm, serial) : fail(FFQ_E_NOMEM, "out of host memory");
     }
     if (rc) { ffq_shard_destroy(s); return rc; }
     *out = s;
     return FFQ_OK;
+}
+
+extern "C" int ffq_shard_create(ffq_ctx *c, const uint8_t *id128, int rank, int world, const int64_t *bounds,
+                                int64_t tail_bytes, int64_t head_bytes, ffq_shard **out)
+{
+    return ffq_shard_create2(c, id128, rank, world, bounds, tail_bytes, head_bytes, sh_serial_env() ? FFQ_SHARD_F_SERIAL : 0u, out);
 }
 
 // a second shard object of the same rank on another context (own scratch, own buffers: steps queued one ahead), on the
@@ -453,7 +645,7 @@ extern "C" int ffq_shard_create_local(ffq_ctx *c, ffq_shard_world *w, int rank, 
     rc = shard_alloc(s);
     if (!rc) {
         ShLocal *t = new (std::nothrow) ShLocal();
-        if (t) { t->W = w; t->rank = rank; t->world = w->world; }
+        if (t) { t->W = w; t->rank = rank; t->world = w->world; t->serial = sh_serial_env(); t->bus.assign((size_t)w->world, -1); t->bus[(size_t)rank] = sh_bus_id(c->device); }
         s->tr = t;
         if (!t) rc = fail(FFQ_E_NOMEM, "out of host memory");
     }
@@ -473,7 +665,7 @@ extern "C" int ffq_shard_create_hosted(ffq_ctx *c, const ffq_shard_host_ops *ops
     rc = shard_alloc(s);
     if (!rc) {
         ShHosted *t = new (std::nothrow) ShHosted();
-        if (t) { t->ops = *ops; t->rank = rank; t->world = world; }
+        if (t) { t->ops = *ops; t->rank = rank; t->world = world; t->serial = sh_serial_env(); t->bus.assign((size_t)world, -1); t->bus[(size_t)rank] = sh_bus_id(c->device); }
         s->tr = t;
         if (!t) rc = fail(FFQ_E_NOMEM, "out of host memory");
     }
@@ -504,36 +696,51 @@ static int shard_serve(ffq_shard *s, const std::vector<ShPiece> &plan, uint8_t *
     return s->tr->exchange(plan, provide, accept, st);
 }
 
+// diagnostics: the stall asked for at this stage, once (ffq_shard_inject_stall)
+static void shard_stall(ffq_shard *s, int stage, hipStream_t st)
+{
+    if (s->stall_stage != stage) return;
+    s->stall_stage = FFQ_SHARD_STAGE_NONE;
+    *s->h_stall = 0;
+    hipLaunchKernelGGL(k_shard_stall, dim3(1), dim3(64), 0, st, (const int *)s->hm_stall, (unsigned long long)(s->stall_s * 1e8));
+}
+
 // step 1 alone (a caller that scans by other means): fills ext[:tail] and ext[tail + own : tail + own + head]
 static int shard_handoff(ffq_shard *s, uint8_t *ext, int64_t tail, bool overlap)
 {
-    if (s->world < 2) return FFQ_OK;
+    const bool stall = s->stall_stage == FFQ_SHARD_STAGE_HANDOFF;
+    if (s->world < 2 && !stall) return FFQ_OK;
     std::vector<ShPiece> plan;
-    sh_halo_plan(s->B, s->tail_bytes, s->head_bytes, plan);
+    if (s->world >= 2) sh_halo_plan(s->B, s->tail_bytes, s->head_bytes, plan);
     mark_other(s->c);
-    hipStream_t st = overlap ? s->comm : s->c->stream;
+    hipStream_t st = sh_xs(s, overlap);
     HIPCHK(hipEventRecord(s->ev_x[0], st));
-    int rc = shard_serve(s, plan, ext, tail, ext, s->lo - tail, st);
+    shard_stall(s, FFQ_SHARD_STAGE_HANDOFF, st);
+    int rc = plan.empty() ? FFQ_OK : shard_serve(s, plan, ext, tail, ext, s->lo - tail, st);
     if (rc) return rc;
     HIPCHK(hipEventRecord(s->ev_x[1], st));
-    if (overlap) HIPCHK(hipStreamWaitEvent(s->c->stream, s->ev_x[1], 0));
+    if (st != s->c->stream) HIPCHK(hipStreamWaitEvent(s->c->stream, s->ev_x[1], 0));
     s->handoff_timed = true;
     return FFQ_OK;
 }
 
 // step 4: the gather of the words the scan stream has just been given to produce -- on the GATHER stream, which waits for
 // them: the collective (tens of microseconds with peers) does not sit between this step's scan and the next one's, already
-// queued behind it on the scan stream
+// queued behind it on the scan stream.  (Serial: on the scan stream itself, in order.)
 static int shard_gather(ffq_shard *s, bool waited = false)
 {
+    hipStream_t gs = sh_gs(s);
     if (!waited) {
         HIPCHK(hipEventRecord(s->ev_w, s->c->stream));
-        HIPCHK(hipStreamWaitEvent(s->gstream, s->ev_w, 0));
+        if (gs != s->c->stream) HIPCHK(hipStreamWaitEvent(gs, s->ev_w, 0));
     }
-    HIPCHK(hipEventRecord(s->ev_g[0], s->gstream));
-    int rc = s->tr->gather_enqueue(s->d_words, s->d_all, s->h_all, s->gstream);
+    // (what a watchdog trip reads to say whose words are there: "look-ahead had" is never negative)
+    if (s->world > 1 && !strcmp(s->tr->name(), "rccl")) HIPCHK(hipMemsetAsync(s->d_all, 0xFF, (size_t)s->world * SH_WORDS * 8, gs));
+    HIPCHK(hipEventRecord(s->ev_g[0], gs));
+    shard_stall(s, FFQ_SHARD_STAGE_GATHER, gs);
+    int rc = s->tr->gather_enqueue(s->d_words, s->d_all, s->h_all, gs);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(s->ev_g[1], s->gstream));
+    HIPCHK(hipEventRecord(s->ev_g[1], gs));
     return FFQ_OK;
 }
 
@@ -543,10 +750,11 @@ static int shard_words_and_gather(ffq_shard *s, int64_t offset)
     // (on the gather stream too, behind ONE marker on the scan stream: the two lower bounds are a handful of dependent
     // memory round trips -- 17 us per step when they sat between this step's scan and the next one's)
     ffq_ctx *c = s->c;
+    hipStream_t gs = sh_gs(s);
     mark_other(c);
     HIPCHK(hipEventRecord(s->ev_w, c->stream));
-    HIPCHK(hipStreamWaitEvent(s->gstream, s->ev_w, 0));
-    hipLaunchKernelGGL(k_shard_words, dim3(1), dim3(64), 0, s->gstream, (const DevRes *)c->dres, (const int64_t *)s->d_table,
+    if (gs != c->stream) HIPCHK(hipStreamWaitEvent(gs, s->ev_w, 0));
+    hipLaunchKernelGGL(k_shard_words, dim3(1), dim3(64), 0, gs, (const DevRes *)c->dres, (const int64_t *)s->d_table,
                        s->table_cap, (s->flags & FFQ_F_DECODE_QUAL) ? s->qual_cap : (int64_t)-1, s->v, offset, s->head_bytes, s->d_words, s->hm_own);
     HIPCHK(hipGetLastError());
     return shard_gather(s, true);
@@ -561,11 +769,67 @@ static int shard_gather_host_words(ffq_shard *s)
     return shard_gather(s);
 }
 
+// ---- the watchdog ------------------------------------------------------------------------------------------------------
+// where a step that does not come back is stuck: the hand-off's end mark, the mark behind the scan front, the gather's
+static int shard_stage(ffq_shard *s)
+{
+    if (s->handoff_timed && hipEventQuery(s->ev_x[1]) == hipErrorNotReady) return FFQ_SHARD_STAGE_HANDOFF;
+    if (hipEventQuery(s->ev_w) == hipErrorNotReady) return FFQ_SHARD_STAGE_SCAN;
+    return FFQ_SHARD_STAGE_GATHER;
+}
+
+// whose words the unfinished gather has delivered so far, as far as this rank can see (the buffer was filled with 0xFF in
+// front of the collective): read on a stream of its own, with a deadline of its own
+static std::string shard_words_seen(ffq_shard *s)
+{
+    std::string have, lack;
+    std::vector<int64_t> seen((size_t)s->world * SH_WORDS, -1);
+    bool ok = false;
+    hipStream_t ds = nullptr;
+    hipEvent_t de = nullptr;
+    int64_t *h = nullptr;
+    if (hipStreamCreateWithFlags(&ds, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&de, hipEventDisableTiming) == hipSuccess &&
+        hipHostMalloc((void **)&h, seen.size() * 8, hipHostMallocDefault) == hipSuccess &&
+        hipMemcpyAsync(h, s->d_all, seen.size() * 8, hipMemcpyDeviceToHost, ds) == hipSuccess && hipEventRecord(de, ds) == hipSuccess &&
+        sh_wait_event(de, 1.0, nullptr) == 0) {
+        memcpy(seen.data(), h, seen.size() * 8);
+        ok = true;
+    }
+    if (ok) { (void)hipHostFree(h); (void)hipEventDestroy(de); (void)hipStreamDestroy(ds); }      // (else: left alone, a copy may be in flight)
+    if (!ok) return "which ranks' words have arrived could not be read";
+    for (int r = 0; r < s->world; r++) {
+        std::string &dst = seen[(size_t)r * SH_WORDS + 4] >= 0 ? have : lack;
+        if (!dst.empty()) dst += ", ";
+        dst += std::to_string(r);
+    }
+    return "words present from rank(s) [" + have + "], absent from [" + lack + "]";
+}
+
+// waits for one mark of the pending step with the watchdog's deadline
+static int shard_wait_mark(ffq_shard *s, hipEvent_t ev)
+{
+    ShTransport *tr = s->tr;
+    double waited = 0;
+    const int w = sh_wait_event(ev, tr->timeout_s, tr, &waited);
+    if (w <= 0) return w;
+    const int stage = shard_stage(s);
+    s->last_stage = stage;
+    tr->poisoned = true;
+    s->pending = false;
+    if (w == 2)
+        return fail(FFQ_E_HIP, "ffq_shard_step_wait: rank %d of %d: RCCL reports an asynchronous error at stage '%s' (%s step): %s", s->rank, s->world,
+                    sh_stage_name(stage), tr->serial ? "serial" : "pipelined", tr->async_error() ? tr->async_error() : "?");
+    std::string seen = (stage == FFQ_SHARD_STAGE_GATHER && s->world > 1 && !strcmp(tr->name(), "rccl")) ? "; " + shard_words_seen(s) : std::string();
+    return fail(FFQ_E_TIMEOUT, "ffq_shard_step_wait: rank %d of %d: no progress within %.1f s at stage '%s' (transport %s, %s step; FFQ_SHARD_TIMEOUT_S)%s",
+                s->rank, s->world, waited, sh_stage_name(stage), tr->name(), tr->serial ? "serial" : "pipelined", seen.c_str());
+}
+
 extern "C" int ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_handoff, uint32_t flags, int qual_add,
                                      int64_t *d_table, int64_t table_cap, int8_t *d_qual, int64_t qual_cap, int64_t *d_qoff)
 {
     if (!s || !d_ext) return fail(FFQ_E_ARG, "ffq_shard_step_submit: NULL argument");
     if (s->pending) return fail(FFQ_E_ARG, "ffq_shard_step_submit: a step is already pending on this shard");
+    if (s->tr->poisoned) return fail(FFQ_E_ARG, "ffq_shard_step_submit: this shard's last step did not come back (watchdog): only ffq_shard_abort / _destroy are left");
     ffq_ctx *c = s->c;
     HIPCHK(hipSetDevice(c->device));
     int64_t tail, head;
@@ -575,9 +839,11 @@ extern "C" int ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_h
     s->flags = flags; s->qual_add = qual_add;        // (FFQ_F_NO_TIMING: no marks; the hand-off's wait in front of the scan rules the barrier-free dispatch out)
     s->d_table = d_table; s->table_cap = table_cap; s->d_qual = d_qual; s->qual_cap = qual_cap; s->d_qoff = d_qoff;
     s->handoff_bytes = 0; s->handoff_timed = false;
+    s->local_fail = 0; s->last_stage = FFQ_SHARD_STAGE_NONE;
     s->from_file = s->fd >= 0 && d_ext == s->file_ext;
     int rc = s->from_file ? FFQ_OK : shard_handoff(s, d_ext, tail, overlap_handoff != 0);
     if (rc) return rc;
+    if (s->stall_stage == FFQ_SHARD_STAGE_SCAN) { mark_other(c); shard_stall(s, FFQ_SHARD_STAGE_SCAN, c->stream); }
     rc = ffq_scan_submit(c, d_ext, s->v.n_bytes, s->v.sentinel, 0, s->v.eof, s->v.add, s->flags, qual_add, d_table, table_cap,
                          d_qual, qual_cap, d_qoff);
     if (rc) return rc;
@@ -601,7 +867,13 @@ static int shard_local(ffq_shard *s, ffq_scan_result *res, int64_t start)
     s->start = start;
     int rc = ffq_scan_device(s->c, s->ext, s->v.n_bytes, s->v.sentinel, offset, s->v.eof, s->v.add, s->flags, s->qual_add,
                              s->d_table, s->table_cap, s->d_qual, s->qual_cap, s->d_qoff, res);
-    if (rc && rc != FFQ_E_TABLE_FULL) return rc;
+    if (rc && rc != FFQ_E_TABLE_FULL) {
+        // (every rank gathers at the end of a repair round: mine says "failed", and the step ends with INTERNAL everywhere)
+        s->local_fail = rc; s->local_msg = ffq_last_error();
+        sh_words_failed(s->v, s->h_own);
+        s->h_own[8] = s->h_own[9] = s->h_own[10] = 0;
+        return shard_gather_host_words(s);
+    }
     return shard_words_and_gather(s, offset);
 }
 
@@ -609,19 +881,32 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
 {
     if (!s || !out) return fail(FFQ_E_ARG, "ffq_shard_step_wait: NULL argument");
     if (!s->pending) return fail(FFQ_E_ARG, "ffq_shard_step_wait: no step is pending on this shard");
-    s->pending = false;
     memset(out, 0, sizeof *out);
     ffq_ctx *c = s->c;
     HIPCHK(hipSetDevice(c->device));
     const int W = s->world, rank = s->rank;
     const std::vector<int64_t> &B = s->B;
-    int rc = ffq_scan_wait(c, &out->scan);
-    if (rc && rc != FFQ_E_TABLE_FULL) return rc;
+    out->nranks = s->tr->nranks(s->tr->serial ? 0 : 1);
+    out->serial = s->tr->serial ? 1 : 0;
+    // The watchdog's first look: the mark behind the scan front.  Once it is through, the hand-off is (the scan waited
+    // for it) and ffq_scan_wait has nothing left to wait for but its own later tiers -- local work.
+    int rc = shard_wait_mark(s, s->ev_w);
+    if (rc) return rc;
+    s->pending = false;
+    rc = ffq_scan_wait(c, &out->scan);
+    // A scan that failed HERE (not the stream's error: a kernel invariant, no memory for a later tier) must not leave the
+    // peers waiting in the next collective: such a scan's words say "not ready" (its result block is marked), every rank
+    // gathers once more, and this rank's words then say "failed" -- INTERNAL on every rank.
+    int &local_fail = s->local_fail;
+    std::string &local_msg = s->local_msg;
+    local_fail = 0;
+    if (rc && rc != FFQ_E_TABLE_FULL) { local_fail = rc; local_msg = ffq_last_error(); }
     int rounds = 0, regathers = 0;
     float ms = 0;
     for (;;) {
-        rc = s->tr->gather_finish(s->h_all, s->ev_g[1]);
-        if (rc) return rc;
+        rc = shard_wait_mark(s, s->ev_g[1]);
+        if (!rc) rc = s->tr->gather_finish(s->h_all, s->ev_g[1]);
+        if (rc) { if (rc == FFQ_E_TIMEOUT) { s->tr->poisoned = true; if (!s->last_stage) s->last_stage = FFQ_SHARD_STAGE_GATHER; } return rc; }
         if (hipEventElapsedTime(&ms, s->ev_g[0], s->ev_g[1]) == hipSuccess) out->allgather_ms += ms;
         const int64_t *A = s->h_all;
         auto word = [&](int r, int k) { return A[(size_t)r * SH_WORDS + k]; };
@@ -646,16 +931,26 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
             out->scan.n_records = 0; out->scan.n_qual_bytes = d.need;
             return fail(FFQ_E_TABLE_FULL, "rank %d: quality buffer too small (%lld decoded bytes in its view)", d.who, (long long)d.need);
         }
-        if (d.kind == ShRound::INTERNAL) return fail(FFQ_E_INTERNAL, "sharded scan: rank %d %s", d.who, d.what);
+        if (d.kind == ShRound::INTERNAL) {
+            if (local_fail) return fail(local_fail, "%s", local_msg.c_str());            // (mine: my own error, not "rank r failed")
+            return fail(FFQ_E_INTERNAL, "sharded scan: rank %d %s", d.who, d.what);
+        }
         if (d.kind == ShRound::NOT_READY) {
             // some rank's scan needed a later tier (a host round trip inside its ffq_scan_wait): every rank's scan is through
             // by now -- the words once more
             if (++regathers > 4) return fail(FFQ_E_INTERNAL, "sharded scan: a rank's result does not become ready");
-            int64_t off = s->start < 0 ? 0 : std::max(s->start, s->v.start) - s->v.add;
-            rc = shard_words_and_gather(s, off);
+            if (local_fail) {
+                sh_words_failed(s->v, s->h_own);
+                s->h_own[8] = s->h_own[9] = s->h_own[10] = 0;
+                rc = shard_gather_host_words(s);
+            } else {
+                int64_t off = s->start < 0 ? 0 : std::max(s->start, s->v.start) - s->v.add;
+                rc = shard_words_and_gather(s, off);
+            }
             if (rc) return rc;
             continue;
         }
+        if (local_fail) return fail(local_fail, "%s", local_msg.c_str());
         if (d.kind == ShRound::STREAM_ERROR) { out->err_state = d.err_state; out->err_byte = d.err_byte; break; }
         if (d.kind == ShRound::SETTLED) break;
         const std::vector<int> &grow = d.grow;
@@ -770,9 +1065,11 @@ extern "C" int ffq_shard_self_exchange(ffq_shard *s, const uint8_t *d_src, uint8
     std::vector<ShPiece> plan{ShPiece{s->rank, s->rank, 0, n}};
     ShPtrFn provide = [=](int64_t a, int64_t) { return const_cast<uint8_t *>(d_src) + a; };
     ShPtrFn accept = [=](int64_t a, int64_t) { return d_dst + a; };
-    int rc = s->tr->exchange(plan, provide, accept, s->comm);
+    hipStream_t st = sh_xs(s, true);
+    if (st == s->c->stream) mark_other(s->c);
+    int rc = s->tr->exchange(plan, provide, accept, st);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(s->comm));
+    HIPCHK(hipStreamSynchronize(st));
     return FFQ_OK;
 }
 
@@ -800,3 +1097,50 @@ extern "C" int ffq_shard_load_fd(ffq_shard *s, int fd, uint8_t *d_ext, int64_t *
 }
 
 extern "C" const char *ffq_shard_transport(ffq_shard *s) { return s && s->tr ? s->tr->name() : ""; }
+
+extern "C" int ffq_shard_get_info(ffq_shard *s, ffq_shard_info *out)
+{
+    if (!s || !out) return fail(FFQ_E_ARG, "ffq_shard_get_info: NULL argument");
+    memset(out, 0, sizeof *out);
+    ShTransport *t = s->tr;
+    out->rank = s->rank; out->world = s->world;
+    out->nranks_handoff = t->nranks(0); out->nranks_gather = t->nranks(1);
+    out->serial = t->serial ? 1 : 0;
+    out->last_stage = s->last_stage;
+    if (!out->last_stage) if (ShLocal *l = dynamic_cast<ShLocal *>(t)) out->last_stage = l->last_stage;
+    out->poisoned = t->poisoned ? 1 : 0;
+    out->timeout_s = t->timeout_s;
+    out->n_bus = std::min<int>(s->world, FFQ_SHARD_MAX_INFO_RANKS);
+    for (int r = 0; r < FFQ_SHARD_MAX_INFO_RANKS; r++) out->bus_id[r] = (r < out->n_bus && r < (int)t->bus.size()) ? t->bus[(size_t)r] : -1;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_shard_set_timeout(ffq_shard *s, double seconds)
+{
+    if (!s || !(seconds >= 0)) return fail(FFQ_E_ARG, "ffq_shard_set_timeout: bad argument");
+    s->tr->timeout_s = seconds;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_shard_set_serial(ffq_shard *s, int on)
+{
+    if (!s) return fail(FFQ_E_ARG, "ffq_shard_set_serial: NULL shard");
+    if (s->pending) return fail(FFQ_E_ARG, "ffq_shard_set_serial: a step is pending on this shard");
+    if (s->tr->poisoned) return fail(FFQ_E_ARG, "ffq_shard_set_serial: this shard's last step did not come back: build a new one (FFQ_SHARD_SERIAL=1)");
+    if (!on && s->tr->nranks(1) == 0) return fail(FFQ_E_ARG, "ffq_shard_set_serial: created serial: there is no second communicator to go back to");
+    // (what the other mode's streams still hold must be through before the first step of this one)
+    HIPCHK(hipSetDevice(s->c->device));
+    if (s->comm) HIPCHK(hipStreamSynchronize(s->comm));
+    if (s->gstream) HIPCHK(hipStreamSynchronize(s->gstream));
+    HIPCHK(hipStreamSynchronize(s->c->stream));
+    s->tr->serial = on != 0;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_shard_inject_stall(ffq_shard *s, int stage, double seconds)
+{
+    if (!s || stage < FFQ_SHARD_STAGE_NONE || stage > FFQ_SHARD_STAGE_GATHER || !(seconds >= 0) || seconds > 120)
+        return fail(FFQ_E_ARG, "ffq_shard_inject_stall: bad argument (stage 0..3, at most 120 s)");
+    s->stall_stage = stage; s->stall_s = seconds;
+    return FFQ_OK;
+}

@@ -13,6 +13,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 extern "C" void ffq_shard_host_free(void *p) { free(p); }
 
@@ -91,7 +92,13 @@ extern "C" int ffq_shard_host_step(const ffq_shard_host_ops *ops, ffq_ctx *ctx, 
         row_lo = f.i0; row_hi = f.i1; nrows = n;
         return FFQ_OK;
     };
-    if ((rc = local(-1))) return rc;
+    // A failure of THIS rank's scan (the callback's, ffq_scan_host's) must not leave the peers waiting in the next gather for a
+    // rank that has gone home: its words say "failed" -- sh_decide makes that INTERNAL on every rank -- and it returns its
+    // own error once everybody has seen them.
+    int local_fail = 0;
+    std::string local_msg;
+    auto failed = [&](int code) { local_fail = code; local_msg = ffq_last_error(); sh_words_failed(v, w); row_lo = row_hi = nrows = 0; };
+    if ((rc = local(-1))) failed(rc);
 
     std::vector<int64_t> all((size_t)world * SH_WORDS);
     int rounds = 0;
@@ -100,6 +107,7 @@ extern "C" int ffq_shard_host_step(const ffq_shard_host_ops *ops, ffq_ctx *ctx, 
         if (r) { free(grown); return fail(r < 0 ? r : FFQ_E_INTERNAL, "ffq_shard_host_step: the gather callback failed (%d)", r); }
         const int64_t *A = all.data();
         const ShRound d = sh_decide(A, world, rank, B, v);
+        if (local_fail) { free(grown); return fail(local_fail, "%s", local_msg.c_str()); }
         if (d.kind == ShRound::TABLE_FULL) {
             out->scan.n_records = d.need;
             free(grown);
@@ -140,7 +148,7 @@ extern "C" int ffq_shard_host_step(const ffq_shard_host_ops *ops, ffq_ctx *ctx, 
             }
             st = d.prev_search;
         }
-        if (d.i_grow || d.i_force) { if ((rc = local(st))) { free(grown); return rc; } }
+        if (d.i_grow || d.i_force) { if ((rc = local(st))) failed(rc); }
         // (else: my words stand; the others' rounds need them again)
     }
     out->n_rows = nrows; out->row_lo = row_lo; out->row_hi = row_hi;

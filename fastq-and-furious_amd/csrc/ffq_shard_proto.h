@@ -14,9 +14,13 @@
 
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #if defined(__HIPCC__)
@@ -219,27 +223,72 @@ static inline void sh_grow_plan(const int64_t *A, const std::vector<int64_t> &B,
 
 static inline int sh_max_rounds(int W) { return 2 * W + 48; }
 
+// the words of a rank whose own step failed (a scan error, no memory): sh_decide turns them into INTERNAL on EVERY rank, so
+// that nobody waits in the next collective for a rank that has already gone home
+static inline void sh_words_failed(const ShView &v, int64_t w[SH_WORDS])
+{
+    w[0] = SH_UNKNOWN; w[1] = SH_UNKNOWN; w[2] = 0; w[3] = 0; w[4] = v.head; w[5] = FFQ_E_INTERNAL; w[6] = 0; w[7] = 0;
+}
+
+// the step watchdog's default: FFQ_SHARD_TIMEOUT_S seconds without progress at one stage of a step (0: wait for ever)
+static inline double sh_default_timeout()
+{
+    const char *e = getenv("FFQ_SHARD_TIMEOUT_S");
+    if (e && *e) { const double t = atof(e); return t < 0 ? 0 : t; }
+    return 30.0;
+}
+
+static inline const char *sh_stage_name(int stage)
+{
+    return stage == FFQ_SHARD_STAGE_HANDOFF ? "hand-off" : stage == FFQ_SHARD_STAGE_SCAN ? "scan" : stage == FFQ_SHARD_STAGE_GATHER ? "gather" : "none";
+}
+
 }  // namespace ffq
 
 // k logical ranks as threads of ONE process: a barrier that can be broken (a rank that fails must not leave the others
-// waiting) and the slots their words meet in
+// waiting), that gives up after a deadline (a rank that never arrives must not either: the watchdog of the in-process
+// world -- whoever runs out of time breaks the barrier for everybody and says who was missing) and the slots their words
+// meet in
 struct ffq_shard_world {
     int world = 0;
     std::mutex m;
     std::condition_variable cv;
     int waiting = 0;
     uint64_t gen = 0;
-    bool broken = false;
-    bool wait()
+    bool broken = false, timed_out = false;
+    std::vector<char> here;                       // ranks that have arrived at the barrier now forming
+    std::vector<int> absent;                      // after a time-out: the ranks that had not
+    // 1: through; 0: broken (another rank failed, or ran out of time: timed_out says which); -1: THIS rank's wait ran out
+    int wait_for(int rank, double seconds)
     {
         std::unique_lock<std::mutex> lk(m);
-        if (broken) return false;
+        if (broken) return 0;
+        if ((int)here.size() != world) here.assign((size_t)world, 0);
+        if (rank >= 0 && rank < world) here[(size_t)rank] = 1;
         const uint64_t g = gen;
-        if (++waiting == world) { waiting = 0; gen++; cv.notify_all(); return true; }
-        cv.wait(lk, [&] { return gen != g || broken; });
-        return !broken;
+        if (++waiting == world) { waiting = 0; gen++; std::fill(here.begin(), here.end(), 0); cv.notify_all(); return 1; }
+        auto pred = [&] { return gen != g || broken; };
+        if (seconds > 0) {
+            if (!cv.wait_for(lk, std::chrono::duration<double>(seconds), pred)) {
+                absent.clear();
+                for (int r = 0; r < world; r++) if (!here[(size_t)r]) absent.push_back(r);
+                broken = true; timed_out = true;
+                cv.notify_all();
+                return -1;
+            }
+        } else cv.wait(lk, pred);
+        return (gen != g) ? 1 : 0;               // (a barrier that completed stays completed even if it broke right after)
     }
+    bool wait() { return wait_for(-1, 0) > 0; }
     void abort() { std::lock_guard<std::mutex> lk(m); broken = true; cv.notify_all(); }
+    // "1, 3" -- the ranks a time-out found missing
+    std::string absent_list()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        std::string s;
+        for (int r : absent) { if (!s.empty()) s += ", "; s += std::to_string(r); }
+        return s.empty() ? std::string("none") : s;
+    }
     std::vector<const void *> providers;          // (per rank: what the transport parks for the others to read)
     std::vector<int64_t> slots;
 };

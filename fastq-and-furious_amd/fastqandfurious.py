@@ -253,6 +253,17 @@ def _default_entries(buf, rows, shift, cls=None):
         yield cut(buf, mv[at:at + step], shift, 1, cls)
 
 
+def _pushes_down(entryfunc):
+    """Is this entryfunc the library's own length filter, unchanged?  Only then may the device evaluate it from min_len /
+    max_len / column alone; a subclass that overrides __call__ or keeps() is CALLED per record like any other entryfunc --
+    on every scanner alike (the same entryfunc must not yield different items depending on the scanner)."""
+    if not isinstance(entryfunc, entryfunc_lengthfilter):
+        return False
+    t = type(entryfunc)
+    return t is entryfunc_lengthfilter or (t.__call__ is entryfunc_lengthfilter.__call__ and
+                                           getattr(t, "keeps", None) is getattr(entryfunc_lengthfilter, "keeps", None))
+
+
 def _phred_entries(st, fill, rows, shift):
     """entryfunc_phred over a whole table, from the stream's bulk decode of that fill."""
     qual, qoff = st.quals()
@@ -381,6 +392,13 @@ def _iter_stream(st, entryfunc):
                     it = iter(rel)
                     for p0, p1, p2, p3, p4, p5 in zip(it, it, it, it, it, it):
                         yield (buf[p0 + 1:p1], buf[p2:p3], buf[p4:p5])
+                elif isinstance(entryfunc, entryfunc_lengthfilter) and not entryfunc.yield_dropped:
+                    # (a length filter that is not pushed down -- a subclass with a __call__ / keeps() of its own: called per
+                    # record, its dropped records left out as on every other scanner)
+                    for i in range(0, len(rel), 6):
+                        e = entryfunc(buf, rel[i:i + 6], fill_offset)
+                        if e is not None:
+                            yield e
                 else:
                     for i in range(0, len(rel), 6):
                         yield entryfunc(buf, rel[i:i + 6], fill_offset)
@@ -411,9 +429,13 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
         # the native stream front end: a real file, a gzip file, or anything with readinto() / read();
         # with entryfunc_phred the qualities of every fill are decoded on the device
         st = open_stream(fh, fbufsize, entryfunc is entryfunc_phred) if entryfunc is entryfunc_phred else open_stream(fh, fbufsize)
-        if st is not None and isinstance(entryfunc, entryfunc_lengthfilter):
+        if st is not None and _pushes_down(entryfunc):
             # push-down: the filter runs on the device, on every fill's table, before anything is copied back
-            st.set_filter(entryfunc.min_len, entryfunc.max_len, None if entryfunc.column == "entry" else entryfunc.column)
+            try:
+                st.set_filter(entryfunc.min_len, entryfunc.max_len, None if entryfunc.column == "entry" else entryfunc.column)
+            except BaseException:
+                st.close()                 # (the native stream, its pinned buffers and its feeder thread; a gzip stream's hook)
+                raise
         if st is not None:
             yield from _iter_stream(st, entryfunc)
             return
@@ -422,7 +444,7 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
         yield from _iter_batched(fh, fbufsize, entryfunc, scan_buffer)
         return
 
-    if isinstance(entryfunc, entryfunc_lengthfilter) and not entryfunc.yield_dropped:
+    if _pushes_down(entryfunc) and not entryfunc.yield_dropped:
         # (the kept records only: the reference's loop below with the guide's `if sequence is None: # do nothing` folded in)
         keep_all = entryfunc_lengthfilter(min_len=entryfunc.min_len, max_len=entryfunc.max_len, column=entryfunc.column)
         yield from (e for e in readfastq_iter(fh, fbufsize, keep_all, entrypos) if e is not None)

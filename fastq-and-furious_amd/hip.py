@@ -27,9 +27,11 @@ MISSING_QUALHEADER_END = 7
 
 END_OK, END_REFILL, END_ERR_FINAL_QUAL, END_ERR_INCOMPLETE, END_ERR_INVALID = range(5)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK = 0
-E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_TABLE_FULL, E_INTERNAL = -1, -2, -3, -4, -5, -6
+E_NODEVICE, E_HIP, E_ARG, E_NOMEM, E_TABLE_FULL, E_INTERNAL, E_TIMEOUT = -1, -2, -3, -4, -5, -6, -7
+STAGE_NONE, STAGE_HANDOFF, STAGE_SCAN, STAGE_GATHER = 0, 1, 2, 3      # FFQ_SHARD_STAGE_*
+STAGE_NAMES = ("none", "hand-off", "scan", "gather")
 
 F_DECODE_QUAL = 1
 F_FORCE_SERIAL = 2
@@ -58,6 +60,7 @@ SYMBOLS = (
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest", "ffq_shard_load_fd", "ffq_load_fd",
     "ffq_shard_host_step", "ffq_shard_host_free", "ffq_stream_set_filter", "ffq_stream_selected",
     "ffq_shard_create_hosted",
+    "ffq_shard_create2", "ffq_shard_get_info", "ffq_shard_set_timeout", "ffq_shard_set_serial", "ffq_shard_abort", "ffq_shard_inject_stall",
 )
 
 
@@ -91,6 +94,19 @@ class ShardResult(ctypes.Structure):
         ("handoff_bytes", ctypes.c_int64),
         ("handoff_ms", ctypes.c_float), ("allgather_ms", ctypes.c_float),
         ("d_ext", ctypes.c_void_p), ("tail", ctypes.c_int64), ("head", ctypes.c_int64),
+        ("nranks", ctypes.c_int32), ("serial", ctypes.c_int32),
+    ]
+
+
+class ShardInfo(ctypes.Structure):
+    """ffq_shard_info (include/ffq.h): who is there -- the communicators' rank counts, every rank's PCI bus id --, the
+    mode, the watchdog's deadline and where its last trip found the step."""
+    _fields_ = [
+        ("rank", ctypes.c_int32), ("world", ctypes.c_int32),
+        ("nranks_handoff", ctypes.c_int32), ("nranks_gather", ctypes.c_int32),
+        ("serial", ctypes.c_int32), ("last_stage", ctypes.c_int32), ("poisoned", ctypes.c_int32), ("n_bus", ctypes.c_int32),
+        ("timeout_s", ctypes.c_double),
+        ("bus_id", ctypes.c_int64 * 64),
     ]
 
 
@@ -114,6 +130,11 @@ class FFQError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libffq_hip error %d: %s" % (code, msg))
         self.code = code
+
+
+class FFQTimeout(FFQError, TimeoutError):
+    """A shard step's watchdog (E_TIMEOUT): the message names the stage (hand-off / scan / gather), the transport, the mode
+    and the ranks whose words are missing.  The shard is poisoned: abort() + close(), then build a new one."""
 
 
 class FFQGzipError(FFQError, OSError):
@@ -289,6 +310,7 @@ def lib():
         L.ffq_stream_path.restype = i32
         L.ffq_shard_unique_id.argtypes = [vp]
         L.ffq_shard_create.argtypes = [vp, vp, i32, i32, P(i64), i64, i64, P(vp)]
+        L.ffq_shard_create2.argtypes = [vp, vp, i32, i32, P(i64), i64, i64, u32, P(vp)]
         L.ffq_shard_create_lane.argtypes = [vp, vp, P(vp)]
         L.ffq_shard_world_create.argtypes = [i32, P(vp)]
         L.ffq_shard_world_abort.argtypes = [vp]
@@ -305,6 +327,11 @@ def lib():
         L.ffq_shard_self_exchange.argtypes = [vp, vp, vp, i64]
         L.ffq_shard_transport.argtypes = [vp]
         L.ffq_shard_transport.restype = ctypes.c_char_p
+        L.ffq_shard_get_info.argtypes = [vp, P(ShardInfo)]
+        L.ffq_shard_set_timeout.argtypes = [vp, ctypes.c_double]
+        L.ffq_shard_set_serial.argtypes = [vp, i32]
+        L.ffq_shard_abort.argtypes = [vp]
+        L.ffq_shard_inject_stall.argtypes = [vp, i32, ctypes.c_double]
         L.ffq_shard_load_fd.argtypes = [vp, i32, vp, P(i64)]
         L.ffq_load_fd.argtypes = [vp, i32, i64, i64, vp, P(i64)]
         L.ffq_shard_host_step.argtypes = [P(ShardHostOps), vp, i32, i32, P(i64), i64, i64, vp, vp, i64, P(ShardResult)]
@@ -332,7 +359,7 @@ def check(rc, allow=()):
         if "gzip: " in msg:
             # what a drop-in caller of gzip.open() catches: EOFError for a file cut short, BadGzipFile (an OSError) otherwise
             raise (FFQGzipTruncated if "ended before the end-of-stream marker" in msg else FFQGzipError)(rc, msg)
-        raise FFQError(rc, msg)
+        raise (FFQTimeout if rc == E_TIMEOUT else FFQError)(rc, msg)
     return rc
 
 
@@ -669,8 +696,10 @@ class Shard:
     """One rank's byte-range shard of a stream, the whole step behind the C ABI (ffq_shard_*, include/ffq.h): halo
     hand-off over RCCL (or the in-process transport), scan, cut, one gather of the hand-off words."""
 
-    def __init__(self, ctx, bounds, rank, world, tail_bytes, head_bytes, unique_id=None, local_world=None, parent=None, hosted=None):
-        """unique_id: RCCL between processes; local_world: a ShardWorld (threads of this process); hosted: a transport object
+    def __init__(self, ctx, bounds, rank, world, tail_bytes, head_bytes, unique_id=None, local_world=None, parent=None, hosted=None,
+                 serial=None):
+        """serial: True -- the serial step (ONE communicator, ONE stream) from the start; None: as FFQ_SHARD_SERIAL says.
+        unique_id: RCCL between processes; local_world: a ShardWorld (threads of this process); hosted: a transport object
         with exchange(pieces) / allgather(words) as shard_host_step takes them -- the device step over the caller's own
         transport (ffq_shard_create_hosted: several processes on one GPU, a group over gloo)."""
         self._ctx = ctx
@@ -710,8 +739,15 @@ class Shard:
                                                ctypes.byref(self._h)))
         else:
             idb = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
-            check(lib().ffq_shard_create(ctx.handle, idb, int(rank), int(world), b, int(tail_bytes), int(head_bytes),
-                                         ctypes.byref(self._h)))
+            if serial is None:
+                check(lib().ffq_shard_create(ctx.handle, idb, int(rank), int(world), b, int(tail_bytes), int(head_bytes),
+                                             ctypes.byref(self._h)))
+            else:
+                check(lib().ffq_shard_create2(ctx.handle, idb, int(rank), int(world), b, int(tail_bytes), int(head_bytes),
+                                              1 if serial else 0, ctypes.byref(self._h)))
+                serial = None
+        if serial is not None and parent is None:
+            check(lib().ffq_shard_set_serial(self._h, 1 if serial else 0))
         import weakref
         ctx._children.append(weakref.ref(self))      # (a shard lives on its context: closed with it, before it)
 
@@ -726,6 +762,36 @@ class Shard:
 
     def transport(self):
         return lib().ffq_shard_transport(self._h).decode()
+
+    def info(self):
+        """Who is there and how the steps run (ffq_shard_get_info): dict with nranks_handoff / nranks_gather
+        (ncclCommCount), bus_ids (every rank's GPU as "dddd:bb:dd.f", None: unknown), serial, timeout_s, last_stage
+        (where the last watchdog trip found the step), poisoned."""
+        i = ShardInfo()
+        check(lib().ffq_shard_get_info(self._h, ctypes.byref(i)))
+
+        def bdf(v):
+            return None if v < 0 else "%04x:%02x:%02x.%d" % (v >> 16, (v >> 8) & 0xFF, (v >> 3) & 0x1F, v & 7)
+        return {"rank": i.rank, "world": i.world, "nranks_handoff": i.nranks_handoff, "nranks_gather": i.nranks_gather,
+                "serial": bool(i.serial), "mode": "serial" if i.serial else "pipelined", "timeout_s": float(i.timeout_s),
+                "last_stage": STAGE_NAMES[i.last_stage], "poisoned": bool(i.poisoned),
+                "bus_ids": [bdf(int(i.bus_id[r])) for r in range(i.n_bus)]}
+
+    def set_timeout(self, seconds):
+        """The step watchdog's deadline (0: none; default FFQ_SHARD_TIMEOUT_S or 30 s): every lane of the rank."""
+        check(lib().ffq_shard_set_timeout(self._h, float(seconds)))
+
+    def set_serial(self, on=True):
+        """Between steps (no lane pending), every rank alike: the serial step -- ONE communicator, ONE stream."""
+        check(lib().ffq_shard_set_serial(self._h, 1 if on else 0))
+
+    def abort(self):
+        """After E_TIMEOUT: ncclCommAbort on the communicators, the streams drained.  True: drained; only close() is left."""
+        return lib().ffq_shard_abort(self._h) == OK
+
+    def inject_stall(self, stage, seconds):
+        """diagnostics: the next step hangs at STAGE_* for up to `seconds` (released by abort / close)."""
+        check(lib().ffq_shard_inject_stall(self._h, int(stage), float(seconds)))
 
     def self_exchange(self, d_src, d_dst, n):
         check(lib().ffq_shard_self_exchange(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_dst), int(n)))

@@ -196,7 +196,8 @@ def _output(res, rc):
     out.record_base, out.total_records, out.rounds = int(res.record_base), int(res.total_records), int(res.rounds)
     out.tail, out.head = int(res.tail), int(res.head)
     out.comm = {"handoff_ms": float(res.handoff_ms), "handoff_bytes": int(res.handoff_bytes),
-                "allgather_ms": float(res.allgather_ms), "rescan_rounds": int(res.rounds), "regathers": int(res.regathers)}
+                "allgather_ms": float(res.allgather_ms), "rescan_rounds": int(res.rounds), "regathers": int(res.regathers),
+                "nranks": int(res.nranks), "mode": "serial" if res.serial else "pipelined"}
     return out
 
 
@@ -261,16 +262,45 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
-def native_unique_id(dist, device):
+def native_unique_id(dist, device, group=None):
     """The communicator id of the library's own RCCL transport, drawn by rank 0 and sent round with the process group
-    that is there (any backend)."""
+    that is there (any backend; group: a side group, e.g. a gloo one that still works when the GPUs' fabric does not).
+    One id serves ONE communicator set-up (ncclCommInitRank's bootstrap root stops listening once every rank has joined):
+    draw a new one for every Shard."""
     import torch
-    cpu = dist.get_backend() == "gloo"
+    cpu = dist.get_backend(group) == "gloo"
     t = torch.zeros(128, dtype=torch.uint8, device="cpu" if cpu else device)
-    if dist.get_rank() == 0:
+    if dist.get_rank(group) == 0:
         t.copy_(torch.frombuffer(bytearray(_hip.shard_unique_id()), dtype=torch.uint8))
-    dist.broadcast(t, 0)
+    dist.broadcast(t, dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     return bytes(t.cpu().numpy().tobytes())
+
+
+def check_bounds(bounds, world, size):
+    """A caller's cut points of a file: world + 1 offsets, not decreasing, inside [0, size].  (Any byte will do: a rank's
+    view is read from the file into an aligned device buffer whatever its file offset -- tests/test_fileshard.py cuts inside
+    headers and on '+' / '@' bytes.)  ValueError on the calling rank, before any collective is entered."""
+    b = [int(x) for x in bounds]
+    if len(b) != int(world) + 1:
+        raise ValueError("bounds: %d cut points for a world of %d (world + 1 are needed)" % (len(b), world))
+    if b[0] < 0 or b[-1] > int(size):
+        raise ValueError("bounds [%d, %d] reach outside the file (%d bytes)" % (b[0], b[-1], size))
+    for i in range(len(b) - 1):
+        if b[i] > b[i + 1]:
+            raise ValueError("bounds decrease: %d > %d (ranks %d, %d)" % (b[i], b[i + 1], i, i + 1))
+    return b
+
+
+def check_peers(info, expect_world=None):
+    """What a host asserts before it trusts a multi-GPU number (Shard.info()): the communicators count the ranks the job
+    was started with, and -- when the bus ids are known (RCCL gathers them) -- those ranks sit on DISTINCT GPUs."""
+    world = info["world"] if expect_world is None else int(expect_world)
+    if info["nranks_handoff"] != world or (not info["serial"] and info["nranks_gather"] not in (0, world)) or info["world"] != world:
+        raise RuntimeError("the shard's communicators count %d / %d ranks, the job has %d" % (info["nranks_handoff"], info["nranks_gather"], world))
+    known = [b for b in info["bus_ids"] if b is not None]
+    if len(known) == world and len(set(known)) != world:
+        raise RuntimeError("%d ranks share GPUs: bus ids %s" % (world, info["bus_ids"]))
+    return True
 
 
 def native_output(shard, ext, rc, res):
@@ -287,15 +317,25 @@ class NativeShardScanner:
     transport --, scan, cut and the gather of the hand-off words queued by ONE call, one read-back per step)."""
 
     def __init__(self, ctx, bounds, rank, world, tail_bytes=TAIL_BYTES, head_bytes=HEAD_BYTES, unique_id=None,
-                 local_world=None, parent=None, hosted=None):
+                 local_world=None, parent=None, hosted=None, serial=None):
+        """serial: True -- the serial step (ONE communicator, ONE stream: hand-off, scan, words, gather in order on the scan
+        stream), the fallback after a watchdog trip; None: what FFQ_SHARD_SERIAL says (default: the pipelined step)."""
         self.ctx, self.bounds, self.rank, self.world = ctx, list(bounds), rank, world
         self.tail_bytes, self.head_bytes = tail_bytes, head_bytes
         if parent is not None:
             self.sh = parent.sh.lane(ctx)
         else:
             self.sh = _hip.Shard(ctx, bounds, rank, world, tail_bytes, head_bytes, unique_id=unique_id, local_world=local_world,
-                                 hosted=hosted)
+                                 hosted=hosted, serial=serial)
         self._pending = None
+
+    def info(self):
+        return self.sh.info()
+
+    def abort(self):
+        """After hip.FFQTimeout: stop what the step left on the GPU (ncclCommAbort, streams drained); close() follows."""
+        self._pending = None
+        return self.sh.abort()
 
     def lane(self, ctx):
         return NativeShardScanner(ctx, self.bounds, self.rank, self.world, self.tail_bytes, self.head_bytes, parent=self)
@@ -340,10 +380,15 @@ class FileShard:
     (DistTransport over gloo: several processes that cannot talk RCCL, e.g. sharing one GPU), or None: a world of one needs nothing, a larger
     one takes torch.distributed's default process group (any backend) to hand the id round; the steps themselves
     are RCCL.  start / end: the part of the file that is the stream (offsets in every row are FILE offsets; the
-    default cut points are shard_bounds' -- 16-byte aligned, even shares --, bounds= names others)."""
+    default cut points are shard_bounds' -- 16-byte aligned, even shares --, bounds= names others: world + 1 file offsets,
+    not decreasing, inside the file -- ValueError otherwise, before anything collective).
+    serial: the serial step from the start (sharded.NativeShardScanner); group: the torch.distributed group the communicator
+    id travels over (default: the world's).  A step that does not come back raises hip.FFQTimeout on every rank (the
+    watchdog, include/ffq.h); where the ranks found each other through torch.distributed, scan() takes the serial step ONCE
+    on a new communicator before it gives up (self.recovered says so)."""
 
     def __init__(self, ctx, path, rank=0, world=1, comm=None, start=0, end=None, tail_bytes=TAIL_BYTES,
-                 head_bytes=HEAD_BYTES, device=None, bounds=None, qual_room=None):
+                 head_bytes=HEAD_BYTES, device=None, bounds=None, qual_room=None, serial=None, group=None):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         # scan(decode=True): bytes of the quality buffer per 16 KiB tile of the view -- hip.SEG_STRIDE (reads of a few hundred
         # bases in one pass) unless given; hip.INPLACE_STRIDE lets four-line reads of any length decode in one pass as well
@@ -355,30 +400,35 @@ class FileShard:
         end = size if end is None else min(int(end), size)
         start = min(int(start), end)
         self.bounds = [start + b for b in shard_bounds(end - start, world)]
-        if bounds is not None:               # (the caller's cut points: file offsets, world + 1 of them, not decreasing)
-            self.bounds = [int(b) for b in bounds]
-            assert len(self.bounds) == world + 1 and self.bounds[-1] <= size
+        if bounds is not None:
+            self.bounds = check_bounds(bounds, world, size)
+        if not 0 <= self.rank < self.world:
+            raise ValueError("FileShard: rank %d of %d" % (self.rank, self.world))
         self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         self._world_obj = None
+        self._dist = None                       # (set: the ranks found each other through torch.distributed -- a watchdog trip can be recovered from)
+        self._halo = (tail_bytes, head_bytes)
         if isinstance(comm, _hip.ShardWorld):
-            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, local_world=comm)
+            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, local_world=comm, serial=serial)
         elif isinstance(comm, (bytes, bytearray)):
-            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, unique_id=bytes(comm))
+            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, unique_id=bytes(comm), serial=serial)
         elif comm is not None and hasattr(comm, "allgather") and hasattr(comm, "exchange"):
             # a transport of the host step's kind (DistTransport over gloo, ...): the device step over it (file-backed
             # shards hand off nothing: 64 bytes of words per rank and step go through it)
-            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, hosted=comm)
+            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, hosted=comm, serial=serial)
         elif world == 1:
             self._world_obj = _hip.ShardWorld(1)
-            self.sh = _hip.Shard(ctx, self.bounds, 0, 1, tail_bytes, head_bytes, local_world=self._world_obj)
+            self.sh = _hip.Shard(ctx, self.bounds, 0, 1, tail_bytes, head_bytes, local_world=self._world_obj, serial=serial)
         else:
             import torch.distributed as dist
-            if not dist.is_initialized() or dist.get_world_size() != world:
+            if not dist.is_initialized() or dist.get_world_size(group) != world:
                 raise ValueError("FileShard: world %d needs comm= (a hip.ShardWorld, a communicator id) or an initialised "
                                  "torch.distributed group of that size" % world)
             import torch
             dev = device if device is not None else torch.device("cuda", ctx.device)
-            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, unique_id=native_unique_id(dist, dev))
+            self._dist = (dist, dev, group)
+            self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, unique_id=native_unique_id(dist, dev, group),
+                                 serial=serial)
         self.tail, self.head = self.sh.halo()
         self.n_view = self.tail + (self.hi - self.lo) + self.head
         self.d_ext = ctx.dev_alloc(self.n_view + 64)
@@ -426,9 +476,15 @@ class FileShard:
         while True:
             self._alloc(rows, decode, qneed)
             self.ctx.reserve(self.n_view + 64)
-            self.sh.step_submit(self.d_ext, self.d_table, self.table_cap, flags=flags, d_qual=self.d_qual if decode else None,
-                                qual_cap=self.qual_cap if decode else 0, d_qoff=self.d_qoff if decode else None)
-            rc, res = self.sh.step_wait()
+            try:
+                self.sh.step_submit(self.d_ext, self.d_table, self.table_cap, flags=flags, d_qual=self.d_qual if decode else None,
+                                    qual_cap=self.qual_cap if decode else 0, d_qoff=self.d_qoff if decode else None)
+                rc, res = self.sh.step_wait()
+            except _hip.FFQTimeout as e:
+                if self._dist is None or self.recovered:
+                    raise
+                self._recover_serial(e)
+                continue
             if rc == _hip.E_TABLE_FULL:
                 if int(res.scan.n_records) == 0 and int(res.scan.n_qual_bytes) > 0:      # (some rank's quality buffer: a view that grew)
                     qneed = max(2 * self.qual_cap, int(res.scan.n_qual_bytes) + 4096)
@@ -441,6 +497,20 @@ class FileShard:
         self.out = res
         self.decoded = bool(decode)
         return res
+
+    recovered = None          # the watchdog's message, once a step was taken again in serial mode
+
+    def _recover_serial(self, err):
+        """Every rank's step ran into the watchdog (a collective never returns on ONE rank only): stop what is left on the
+        GPU, a NEW communicator -- one, for the serial step -- over the process group, the range loaded again."""
+        dist, dev, group = self._dist
+        self.recovered = str(err)
+        self.sh.abort()
+        self.sh.close()
+        tail_bytes, head_bytes = self._halo
+        self.sh = _hip.Shard(self.ctx, self.bounds, self.rank, self.world, tail_bytes, head_bytes,
+                             unique_id=native_unique_id(dist, dev, group), serial=True)
+        self.load()
 
     # ---- this rank's rows (and decoded qualities) back on the host, a batch at a time -------------------------------
     def rows(self, i0=None, i1=None):

@@ -19,7 +19,7 @@ class SyntheticShard:
     record straddles every edge."""
 
     def __init__(self, ctx, kind, bytes_per_gpu, rank, world, dev, edge_shift=144, transport=None, total_records=None,
-                 native=None, solo_rccl=False):
+                 native=None, solo_rccl=False, serial=None, ctl_group=None):
         """total_records (S-single only): the whole stream has exactly this many records, dealt out as
         evenly as they go (BASELINE configs[4]: 333 460 193 records = 107 374 182 146 B over 8 ranges);
         bytes_per_gpu is ignored then.
@@ -28,7 +28,9 @@ class SyntheticShard:
         GPU -- RCCL refuses two ranks per device) -- the product path, and the default; False: the HOST step
         (ffq_shard_host_step) over host copies of the range with this transport, the GPU scanning through ffq_scan_host
         (tests).  solo_rccl: a world of one on the library's RCCL transport (communicators of one rank) instead of the
-        in-process one -- what the product's step costs with no peers."""
+        in-process one -- what the product's step costs with no peers.  serial: the serial step (ONE communicator, ONE
+        stream) from the start; ctl_group: the torch.distributed group communicator ids travel over (a gloo side group still
+        works when the GPUs' fabric does not)."""
         import torch
         from . import synth
         self.ctx, self.kind, self.rank, self.world, self.dev = ctx, kind, rank, world, dev
@@ -113,20 +115,22 @@ class SyntheticShard:
             native = True
         self.native = bool(native)
         self._own_world = None
+        self._ctl_group, self._solo_rccl = ctl_group, bool(solo_rccl)
+        self.recovered = None             # the watchdog's message, once the steps were taken again in serial mode
         if self.native:
             if isinstance(transport, LocalTransport):
-                self.scanner = NativeShardScanner(ctx, S, rank, world, local_world=transport.lw.native_world())
+                self.scanner = NativeShardScanner(ctx, S, rank, world, local_world=transport.lw.native_world(), serial=serial)
             elif isinstance(transport, SoloTransport) and solo_rccl:
-                self.scanner = NativeShardScanner(ctx, S, 0, 1, unique_id=_hip.shard_unique_id())
+                self.scanner = NativeShardScanner(ctx, S, 0, 1, unique_id=_hip.shard_unique_id(), serial=serial)
             elif isinstance(transport, SoloTransport):
                 self._own_world = _hip.ShardWorld(1)
-                self.scanner = NativeShardScanner(ctx, S, 0, 1, local_world=self._own_world)
+                self.scanner = NativeShardScanner(ctx, S, 0, 1, local_world=self._own_world, serial=serial)
             elif gloo:
                 # several processes that cannot talk RCCL (a dry run on ONE GPU): the device step all the same, its hand-offs
                 # staged through host memory around gloo, its words gathered by gloo (ffq_shard_create_hosted)
-                self.scanner = NativeShardScanner(ctx, S, rank, world, hosted=transport)
+                self.scanner = NativeShardScanner(ctx, S, rank, world, hosted=transport, serial=serial)
             else:
-                self.scanner = NativeShardScanner(ctx, S, rank, world, unique_id=native_unique_id(transport, dev))
+                self.scanner = NativeShardScanner(ctx, S, rank, world, unique_id=native_unique_id(transport, dev, ctl_group), serial=serial)
         else:
             self.scanner = HostShardScanner(transport, S, ctx=ctx)
         self._lanes = None
@@ -181,6 +185,30 @@ class SyntheticShard:
         self._exts = [self.ext] + [self.ext.clone() if self._overlap else self.ext for _ in range(n - 1)]
         self._queued = [None] * n
         return lanes
+
+    def recover_serial(self, err):
+        """After hip.FFQTimeout (the step watchdog; a collective that does not come back does so on EVERY rank): stop what
+        the abandoned steps left on the GPU (ncclCommAbort, streams drained), a NEW communicator -- ONE, for the serial
+        step -- from an id handed round over the control group, the lanes again.  Only for the RCCL transport: the others
+        have no communicator to replace."""
+        assert self.native and self.scanner.sh.transport() == "rccl", "nothing to rebuild on this transport"
+        self.recovered = str(err)
+        lanes = self._lanes or [self.scanner]
+        n_lanes = len(lanes) if self._lanes else 0
+        for ln in lanes:
+            ln.abort()
+        for ln in reversed(lanes):                 # (the lanes before the shard whose communicators they borrow)
+            ln.close()
+        for c in (getattr(self, "_lane_ctx", None) or [])[1:]:
+            c.close()
+        self._lanes = None
+        if self._solo_rccl:
+            uid = _hip.shard_unique_id()
+        else:
+            uid = native_unique_id(self.transport, self.dev, self._ctl_group)
+        self.scanner = NativeShardScanner(self.ctx, self.bounds, self.rank if not self._solo_rccl else 0, self.world, unique_id=uid, serial=True)
+        if n_lanes:
+            self.make_lanes(n_lanes)
 
     def submit(self, lane, table, flags=0, qual=None, qoff=None):
         ext = self._exts[lane]

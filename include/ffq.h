@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FFQ_ABI_VERSION 5
+#define FFQ_ABI_VERSION 6
 
 /* scanner status codes -- identical to the reference's module constants
  * (_fastqandfurious.c:7-15,254-262; fastqandfurious.py:19-27)             */
@@ -61,6 +61,7 @@ extern "C" {
 #define FFQ_E_NOMEM         (-4)
 #define FFQ_E_TABLE_FULL    (-5)   /* more records than table_cap: n_records holds the need */
 #define FFQ_E_INTERNAL      (-6)
+#define FFQ_E_TIMEOUT       (-7)   /* a shard step's watchdog: ffq_last_error names the stage and the ranks */
 
 /* flags for the scan calls */
 #define FFQ_F_DECODE_QUAL   1u     /* also emit Phred-decoded qualities (value added = qual_add) */
@@ -436,7 +437,25 @@ int ffq_selftest(ffq_ctx *ctx);
  *                         scan stream), on the first one's communicators: steps queued one ahead.
  *   ffq_shard_world_* / ffq_shard_create_local   k logical ranks as THREADS of one process on one GPU, hand-offs
  *                         by device copies (tests, dry runs): every rank's thread makes the same calls.
- * Every rank must make the same sequence of calls (they are collective).                              */
+ * Every rank must make the same sequence of calls (they are collective).
+ *
+ * A step cannot hang silently (round 6).  WATCHDOG: every wait of a step -- ffq_shard_step_wait, the in-process
+ * barrier -- polls with a deadline (FFQ_SHARD_TIMEOUT_S, default 30 s, 0 = none; ffq_shard_set_timeout); when it
+ * runs out the call returns FFQ_E_TIMEOUT and ffq_last_error names the STAGE the step is stuck in (hand-off / scan /
+ * gather), the transport, the mode and -- as far as this rank can see them -- the ranks whose words have and have not
+ * arrived; RCCL's own asynchronous errors (ncclCommGetAsyncError) end the wait at once.  After FFQ_E_TIMEOUT the shard is
+ * poisoned: ffq_shard_abort (ncclCommAbort on its communicators, its streams drained) and ffq_shard_destroy are what is
+ * left; the host may then build a new one.  SERIAL MODE: the pipelined step drives TWO communicators from THREE streams
+ * (hand-off of step i + 1 beside the scan of step i, the gather behind it); the serial step is ONE communicator on ONE
+ * stream -- hand-off, scan, words, gather in order on the scan stream (lanes share it) -- the same rows, nothing
+ * overlapped: the fallback a host takes once after a watchdog trip (FFQ_SHARD_SERIAL=1 at creation -- the second
+ * communicator is then never made --, or ffq_shard_set_serial between steps).  ffq_shard_result.serial / .nranks and
+ * ffq_shard_get_info say what ran.                                                                            */
+#define FFQ_SHARD_STAGE_NONE    0
+#define FFQ_SHARD_STAGE_HANDOFF 1
+#define FFQ_SHARD_STAGE_SCAN    2
+#define FFQ_SHARD_STAGE_GATHER  3
+#define FFQ_SHARD_MAX_INFO_RANKS 64
 typedef struct ffq_shard ffq_shard;
 typedef struct ffq_shard_world ffq_shard_world;
 typedef struct ffq_shard_result {
@@ -455,10 +474,30 @@ typedef struct ffq_shard_result {
     float   allgather_ms;      /* device time of the gather(s) of the eight words                           */
     uint8_t *d_ext;            /* the view the rows refer to (the caller's, or a grown one owned by the shard) */
     int64_t tail, head;
+    int32_t nranks;            /* ranks of the communicator the words were gathered on (ncclCommCount; == world) */
+    int32_t serial;            /* 1: the serial step ran (one communicator, one stream), 0: the pipelined one   */
 } ffq_shard_result;
+/* Who is there: filled at creation (RCCL: ncclCommCount of both communicators and ONE all-gather of every rank's PCI
+ * bus id, so that a host can assert "N ranks on N distinct GPUs" before it trusts a number).                     */
+typedef struct ffq_shard_info {
+    int32_t rank, world;
+    int32_t nranks_handoff;    /* ncclCommCount of the hand-off communicator (other transports: world)          */
+    int32_t nranks_gather;     /* ... of the gather communicator; 0: there is none (created serial)             */
+    int32_t serial;            /* the mode the next step runs in                                                */
+    int32_t last_stage;        /* FFQ_SHARD_STAGE_*: where the last watchdog trip found the step (0: no trip)   */
+    int32_t poisoned;          /* 1: a watchdog trip or an asynchronous RCCL error: only abort / destroy are left */
+    int32_t n_bus;             /* entries of bus_id that are filled: min(world, FFQ_SHARD_MAX_INFO_RANKS)       */
+    double  timeout_s;         /* the watchdog's deadline (0: none)                                             */
+    int64_t bus_id[FFQ_SHARD_MAX_INFO_RANKS];   /* PCI domain << 16 | bus << 8 | device << 3 | function of rank r's GPU; -1: unknown
+                                                   (in-process / hosted transports know their own only)        */
+} ffq_shard_info;
 int  ffq_shard_unique_id(uint8_t *id128);
 int  ffq_shard_create(ffq_ctx *ctx, const uint8_t *id128, int rank, int world, const int64_t *bounds,
                       int64_t tail_bytes, int64_t head_bytes, ffq_shard **out);
+/* ... with the mode said by the caller instead of the environment (mode: FFQ_SHARD_F_*) */
+#define FFQ_SHARD_F_SERIAL 1u
+int  ffq_shard_create2(ffq_ctx *ctx, const uint8_t *id128, int rank, int world, const int64_t *bounds,
+                       int64_t tail_bytes, int64_t head_bytes, uint32_t mode, ffq_shard **out);
 int  ffq_shard_create_lane(ffq_shard *parent, ffq_ctx *ctx, ffq_shard **out);
 int  ffq_shard_world_create(int world, ffq_shard_world **out);
 void ffq_shard_world_abort(ffq_shard_world *w);
@@ -471,7 +510,19 @@ int  ffq_shard_exchange_halo(ffq_shard *s, uint8_t *d_ext, int overlap);
 int  ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_handoff, uint32_t flags, int qual_add,
                            int64_t *d_table, int64_t table_cap, int8_t *d_qual, int64_t qual_cap, int64_t *d_qoff);
 int  ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out);
-const char *ffq_shard_transport(ffq_shard *s);    /* "rccl" / "in-process" */
+const char *ffq_shard_transport(ffq_shard *s);    /* "rccl" / "in-process" / "hosted" */
+int  ffq_shard_get_info(ffq_shard *s, ffq_shard_info *out);
+int  ffq_shard_set_timeout(ffq_shard *s, double seconds);      /* the watchdog's deadline (every lane of the rank) */
+int  ffq_shard_set_serial(ffq_shard *s, int on);               /* between steps, no lane pending; every rank alike */
+/* After FFQ_E_TIMEOUT (or at any time): ncclCommAbort on the shard's communicators -- kernels of a collective that
+ * waits for a peer leave --, an injected stall released, the shard's streams drained with a deadline of their own.
+ * FFQ_OK: drained; FFQ_E_TIMEOUT: something still runs (ffq_shard_destroy then leaks the shard's device memory
+ * rather than wait for ever).  Only ffq_shard_destroy may follow.                                               */
+int  ffq_shard_abort(ffq_shard *s);
+/* diagnostics: the NEXT step of this shard hangs at `stage` (FFQ_SHARD_STAGE_*) for up to `seconds` -- a one-lane
+ * kernel on that stage's stream that waits for a host flag (released by ffq_shard_abort / _destroy) -- so that the
+ * watchdog and the recovery can be exercised without a broken peer (tests/test_watchdog.py).                   */
+int  ffq_shard_inject_stall(ffq_shard *s, int stage, double seconds);
 /* A shard of a FILE: bounds[] are file offsets.  ffq_shard_load_fd reads this rank's bytes [lo - tail, hi + head) of fd
  * (pread: the descriptor's position is not moved) into d_ext -- helper threads -> pinned slots -> hipMemcpyAsync on two
  * copy streams -- and returns when they are there; a step submitted over that d_ext then hands off NOTHING between

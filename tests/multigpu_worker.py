@@ -2,7 +2,10 @@
 
 Every rank builds the same stream (the generators are counter-based), takes its byte range, and runs the library's own
 step (ffq_shard_*: halo hand-off by ncclSend / ncclRecv between DIFFERENT ranks, scan, one ncclAllGather of the eight
-words) -- plain, pipelined over two lanes with the hand-off on its own stream, with and without the decode -- and the
+words) -- plain, pipelined over two lanes with the hand-off on its own stream, with and without the decode, the same in
+SERIAL mode (one communicator, one stream), and once through the WATCHDOG: one rank's gather is stalled, every rank's step
+comes back with hip.FFQTimeout naming the stage, the communicators are aborted, a new one is built for the serial step and
+the step taken again -- and the
 file-backed form (every rank preads its range of one file; only the gather is RCCL).  Each rank leaves its rows in the
 scratch directory; rank 0 puts them together and compares with the oracle's scan of the whole stream, and with what k
 logical ranks in ONE process (the in-process transport the single-GPU tests use) give for the same ranges: same rows,
@@ -44,6 +47,10 @@ def main(scratch):
             lo, hi = bounds[rank], bounds[rank + 1]
             sc = sharded.NativeShardScanner(ctx, bounds, rank, world, unique_id=sharded.native_unique_id(dist, dev))
             assert sc.sh.transport() == "rccl"
+            info = sc.info()
+            sharded.check_peers(info, world)          # the communicators count `world` ranks, on distinct GPUs
+            assert info["nranks_handoff"] == world and info["nranks_gather"] == world and info["mode"] == "pipelined"
+            assert len(info["bus_ids"]) == world and all(b is not None for b in info["bus_ids"]), info
             lanes = [sc, sc.lane(lane_ctx)]
             tail, head = sc.halo()
             n_rows = stream.size // 40 + 64
@@ -81,10 +88,28 @@ def main(scratch):
                 lanes[i & 1].submit(exts[i & 1], tail, head, tabs[i & 1], overlap=True)
                 outs.append(("lane", (i - 1) & 1, lanes[(i - 1) & 1].finish()))
             outs.append(("lane", 0, lanes[0].finish()))
+            assert all(o.comm["mode"] == "pipelined" and o.comm["nranks"] == world for _n, _l, o in outs)
+            # the same in SERIAL mode: ONE communicator, ONE stream (hand-off, scan, words, gather in order) -- same rows, same rounds
+            sc.sh.set_serial(True)
+            for e in exts:
+                e[:tail].zero_()
+                e[tail + hi - lo:].zero_()
+            torch.cuda.synchronize()
+            outs.append(("serial", 0, sc.scan(exts[0], tail, head, tabs[0])))
+            for e in exts:
+                e[:tail].zero_()
+                e[tail + hi - lo:].zero_()
+            torch.cuda.synchronize()
+            lanes[0].submit(exts[0], tail, head, tabs[0], overlap=True)
+            lanes[1].submit(exts[1], tail, head, tabs[1], overlap=True)
+            outs.append(("serial-lane", 0, lanes[0].finish()))
+            outs.append(("serial-lane", 1, lanes[1].finish()))
+            assert all(o.comm["mode"] == "serial" and o.comm["nranks"] == world for _n, _l, o in outs[-3:])
+            sc.sh.set_serial(False)
             key = "%s@%d" % (kind, origin)
             rep = report[key] = {"steps": []}
             for name, li, o in outs:
-                rows = (tabs[li] if name == "lane" else tabs[0])[o.row_lo:o.row_hi].cpu().numpy()
+                rows = (tabs[li] if name.endswith("lane") else tabs[0])[o.row_lo:o.row_hi].cpu().numpy()
                 rep["steps"].append({"name": name, "base": o.record_base, "total": o.total_records, "rounds": o.rounds,
                                      "handoff_bytes": o.comm["handoff_bytes"], "n": int(rows.shape[0])})
                 np.save(os.path.join(scratch, "rows_%s_%s%d_%d.npy" % (key, name, len(rep["steps"]), rank)), rows)
@@ -96,6 +121,46 @@ def main(scratch):
             for ln in reversed(lanes):
                 ln.close()
             dist.barrier()
+    # ---- the watchdog and the recovery, with real peers: the LAST rank's gather stalls (a kernel that waits for a host flag
+    # in front of its all-gather), so no rank's all-gather completes; every rank's step must come back with FFQTimeout at
+    # stage 'gather' within the deadline, abort its communicators, join a NEW one -- ONE, serial mode -- and get the rows
+    stream = make_stream("wrapped")
+    t = torch.from_numpy(stream.copy()).to(dev)
+    bounds = bounds_for(stream.size, world, 0, 48)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    sc = sharded.NativeShardScanner(ctx, bounds, rank, world, unique_id=sharded.native_unique_id(dist, dev))
+    sc.sh.set_timeout(4.0)
+    tail, head = sc.halo()
+    ext = torch.zeros(tail + (hi - lo) + head + 64, dtype=torch.uint8, device=dev)
+    ext[tail:tail + hi - lo] = t[lo:hi]
+    tab = torch.empty((stream.size // 40 + 64, 6), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    if rank == world - 1:
+        sc.sh.inject_stall(hip.STAGE_GATHER, 60.0)
+    import time
+    t0 = time.perf_counter()
+    try:
+        sc.scan(ext, tail, head, tab)
+        raise AssertionError("rank %d: the stalled step came back" % rank)
+    except hip.FFQTimeout as e:
+        waited = time.perf_counter() - t0
+        assert "stage 'gather'" in str(e) and "transport rccl" in str(e), str(e)
+        assert 3.5 < waited < 30, waited
+        report["watchdog"] = {"message": str(e), "waited_s": waited, "stage": sc.info()["last_stage"]}
+    assert sc.abort(), "rank %d: the streams did not drain after the abort" % rank
+    sc.close()
+    ext[:tail].zero_()
+    ext[tail + hi - lo:].zero_()
+    torch.cuda.synchronize()
+    sc = sharded.NativeShardScanner(ctx, bounds, rank, world, unique_id=sharded.native_unique_id(dist, dev), serial=True)
+    info = sc.info()
+    sharded.check_peers(info, world)
+    assert info["mode"] == "serial" and info["nranks_gather"] == 0 and info["nranks_handoff"] == world
+    o = sc.scan(ext, tail, head, tab)
+    assert o.comm["mode"] == "serial" and o.comm["nranks"] == world
+    np.save(os.path.join(scratch, "rows_recovered_%d.npy" % rank), tab[o.row_lo:o.row_hi].cpu().numpy())
+    sc.close()
+    dist.barrier()
     # ---- one FILE read by all ranks: every rank preads its range, only the eight words travel ----------------------
     fpath = os.path.join(scratch, "shared.fq")
     fstream = make_stream("wrapped")
@@ -156,6 +221,9 @@ def check(scratch, world):
                   if os.path.exists(os.path.join(scratch, "qual_%s_%d.npy" % (key, r)))]
             assert (np.concatenate(qs) == wq).all(), "%s: decoded qualities over the ranks differ from the oracle's" % key
     fwant, _ = expected(oracle, make_stream("wrapped"))
+    got = np.concatenate([np.load(os.path.join(scratch, "rows_recovered_%d.npy" % r)) for r in range(world)])
+    assert got.shape == fwant.shape and (got == fwant).all(), "after the watchdog trip: the serial step's rows differ from the oracle's"
+    assert all(rep["watchdog"]["stage"] == "gather" for rep in reports)
     for k in (0, 2):
         got = np.concatenate([np.load(os.path.join(scratch, "file_rows_%d_%d.npy" % (k, r))) for r in range(world)])
         assert got.shape == fwant.shape and (got == fwant).all(), "file-backed ranges: rows over the ranks differ from the oracle's"

@@ -133,3 +133,57 @@ def test_entries_phred_native_equals_the_user_guide_entryfunc(oracle, pkg):
     with pytest.raises(ValueError):
         nat.entries_phred(b"x", memoryview(np.zeros((1, 6), np.int64)).cast("B"), 0, np.zeros(4, np.int8),
                           memoryview(np.array([0, 9], np.int64)).cast("B"), array)
+
+
+def test_entries_phred_arrays_are_arrays_and_calls_share_no_state(oracle, pkg):
+    """Round 6: the records' array('b') objects are built directly (no process-global staging array any more -- the
+    round-5 advisor's finding: a second thread's call could overwrite it mid-loop).  They must BE arrays -- mutable,
+    growable, accepted by arrayadd_b, picklable, freed normally --, a subclass of array must work too (it takes the slicing
+    path or its own probe), and calls from several threads at once must each get their own fill's qualities."""
+    import gc
+    import pickle
+    import threading
+    from array import array
+    from fastqandfurious_amd import entries, synth
+    nat = entries.native()
+    data = synth.single(0, 400, seed=42)
+    buf = data.tobytes()
+    table, *_ = oracle.scan(data)
+    qual, qoff = oracle.decode_quals(data, table)
+    rows = memoryview(np.ascontiguousarray(table)).cast("B")
+    qo = memoryview(np.ascontiguousarray(qoff)).cast("B")
+    got = nat.entries_phred(buf, rows, 0, qual, qo, array)
+    q = got[5][2]
+    ref = array("b", qual[int(qoff[5]):int(qoff[6])].tobytes())
+    assert type(q) is array and q.typecode == "b" and q.itemsize == 1 and q == ref and len(q) == 150
+    assert pickle.loads(pickle.dumps(q)) == ref and q.tobytes() == ref.tobytes() and bytes(memoryview(q)) == ref.tobytes()
+    q.append(-5); q.extend([1, 2, 3]); q[0] = 7
+    assert len(q) == 154 and q[-4] == -5 and q[0] == 7 and got[6][2][0] == int(qual[int(qoff[6])])   # (its neighbours are untouched)
+    oracle.arrayadd_b(q, 1)
+    assert q[0] == 8
+    del got, q
+    gc.collect()
+
+    class MyArray(array):
+        pass
+    sub = nat.entries_phred(buf, rows, 0, qual, qo, MyArray)
+    assert all(isinstance(e[2], array) and e[2] == array("b", qual[int(qoff[i]):int(qoff[i]) + 150].tobytes()) for i, e in enumerate(sub))
+    again = nat.entries_phred(buf, rows, 0, qual, qo, array)          # ... and back to the plain type
+    assert type(again[0][2]) is array and again[3][2] == sub[3][2]
+
+    # several threads, each with its OWN fill (qualities shifted by a per-thread constant): nobody sees another's bytes
+    bad = []
+
+    def work(k):
+        mine = (qual.astype(np.int16) + k).astype(np.int8)
+        for _ in range(60):
+            out = nat.entries_phred(buf, rows, 0, mine, qo, array)
+            for i in (0, 77, 399):
+                if out[i][2] != array("b", mine[int(qoff[i]):int(qoff[i]) + 150].tobytes()):
+                    bad.append((k, i))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad[:5]

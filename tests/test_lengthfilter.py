@@ -190,3 +190,45 @@ def test_stream_filter_c_abi_against_oracle(gpu_ctx, oracle, tmp_path):
         st.set_filter(None, 10)
     st.close()
     os.close(fd)
+
+
+class _OddOnly:
+    """(mixin) keeps records whose sequence length is ODD as well as under the threshold: a filter the device knows nothing of."""
+
+    def keeps(self, length):
+        return length % 2 == 1 and super().keeps(length)
+
+
+def _subclass_items(F, scanner, opener, **kw):
+    class Odd(_OddOnly, F.entryfunc_lengthfilter):
+        pass
+    return list(F.readfastq_iter(opener(), 20000, Odd(120, **kw), scanner))
+
+
+def test_a_subclassed_filter_is_called_not_pushed_down_python_scanner(pkg):
+    from fastqandfurious_amd import fastqandfurious as F, synth
+    data = synth.wrapped(0, 2000, seed=43)[0].tobytes()
+    got = _subclass_items(F, F.entrypos, lambda: io.BytesIO(data))
+    plain = list(F.readfastq_iter(io.BytesIO(data), 20000, F.entryfunc_lengthfilter(120), F.entrypos))
+    assert len(got) == len(plain) == 2000
+    # (keeps() sees pos3 - pos2: the sequence slice as the reference cuts it, embedded newlines included)
+    assert got == [p if (p is not None and len(p) % 2 == 1) else None for p in plain]
+    assert 0 < sum(g is not None for g in got) < sum(p is not None for p in plain)
+    assert not F._pushes_down(type("X", (_OddOnly, F.entryfunc_lengthfilter), {})(120)) and F._pushes_down(F.entryfunc_lengthfilter(120))
+    assert F._pushes_down(type("Y", (F.entryfunc_lengthfilter,), {"note": 1})(120))      # (a subclass that changes nothing that matters)
+
+
+@pytest.mark.gpu
+def test_a_subclassed_filter_yields_the_same_items_on_the_gpu_stream(gpu_ctx, tmp_path):
+    """Round-5 advisor: isinstance() let a subclass with its own keeps() be evaluated on the device from min_len / max_len
+    alone -- other items than on the CPU scanners.  Now only the library's own, unchanged filter is pushed down."""
+    from fastqandfurious_amd import fastqandfurious as F, _fastqandfurious as C, synth
+    data = synth.wrapped(0, 2000, seed=43)[0].tobytes()
+    p = tmp_path / "w.fq"
+    p.write_bytes(data)
+    want = _subclass_items(F, F.entrypos, lambda: io.BytesIO(data))
+    assert _subclass_items(F, C.entrypos, lambda: open(p, "rb")) == want
+    assert _subclass_items(F, C.entrypos, lambda: io.BytesIO(data)) == want
+    kept = [w for w in want if w is not None]
+    assert _subclass_items(F, C.entrypos, lambda: open(p, "rb"), yield_dropped=False) == kept
+    assert _subclass_items(F, F.entrypos, lambda: io.BytesIO(data), yield_dropped=False) == kept

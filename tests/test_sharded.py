@@ -125,7 +125,7 @@ def expected(oracle, stream, origin=0):
 
 # ---- k logical ranks as threads of one process ---------------------------------------------------
 def run_local(stream_t, bounds, make_backend, tail_bytes=None, head_bytes=None, flags=0, lanes=False,
-              table_rows=None, decode=False, native=False):
+              table_rows=None, decode=False, native=False, serial=None):
     """Every rank: ext = [zeros | own bytes | zeros] -> one step.  native: the device step (NativeShardScanner over
     hip.ShardWorld, `stream_t` on the GPU); else the host step (HostShardScanner over the thread transport, buffers in
     host memory, the engine's scan).  Returns the list of (ScanOutput, table, qual, qoff) per rank, or raises what the
@@ -147,7 +147,7 @@ def run_local(stream_t, bounds, make_backend, tail_bytes=None, head_bytes=None, 
             lo, hi = bounds[rank], bounds[rank + 1]
             qual = qoff = None
             if native:
-                sc = sharded.NativeShardScanner(eng.ctx, bounds, rank, world, local_world=lw.native_world(), **kw)
+                sc = sharded.NativeShardScanner(eng.ctx, bounds, rank, world, local_world=lw.native_world(), serial=serial, **kw)
                 tail, head = sc.halo()
                 ext = torch.zeros(tail + (hi - lo) + head + 64, dtype=torch.uint8, device=stream_t.device)
                 ext[tail:tail + hi - lo] = stream_t[lo - origin:hi - origin]
@@ -423,6 +423,53 @@ def test_sharded_stream_error_gloo(tmp_path, oracle):
         assert open(os.path.join(str(tmp_path), "err_%d.txt" % r)).read() == err
 
 
+def _failing_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        import fastqandfurious_amd  # noqa: F401
+        from fastqandfurious_amd import hip, sharded
+        stream = make_stream("wrapped")
+        S = sharded.shard_bounds(stream.size, world)
+        lo, hi = S[rank], S[rank + 1]
+
+        def scan(*a):
+            if rank == 1:
+                raise MemoryError("rank 1's engine gives up")
+            return oracle_scan(*a)
+        sc = sharded.HostShardScanner(sharded.DistTransport(dist), S, scan=scan)
+        tail, head = sc.halo()
+        ext = np.zeros(tail + (hi - lo) + head + 64, dtype=np.uint8)
+        ext[tail:tail + hi - lo] = stream[lo:hi]
+        try:
+            sc.scan(ext, tail, head, np.empty((100000, 6), dtype=np.int64))
+            msg = "came back"
+        except MemoryError as e:
+            msg = "MemoryError: %s" % e
+        except hip.FFQError as e:
+            msg = "FFQError %d: %s" % (e.code, e)
+        with open(os.path.join(tmpdir, "fail_%d.txt" % rank), "w") as fh:
+            fh.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rank_does_not_strand_its_peers_gloo(tmp_path):
+    """A rank whose OWN scan fails (not the stream's error: its engine's) used to return at once and leave the others in the
+    next all-gather for ever (round-5 advisor).  Now its words say "failed", every rank sees them in the gather that was
+    due anyway and comes back with an error: the failing rank with its own, the others naming it."""
+    mp.spawn(_failing_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    msgs = [open(os.path.join(str(tmp_path), "fail_%d.txt" % r)).read() for r in range(3)]
+    assert msgs[1].startswith("MemoryError"), msgs
+    for r in (0, 2):
+        assert msgs[r].startswith("FFQError -6") and "rank 1" in msgs[r], msgs
+
+
 def test_shard_bounds(pkg):
     from fastqandfurious_amd import sharded
     b = sharded.shard_bounds(1000003, 4)
@@ -509,6 +556,41 @@ def test_local_ranks_hip_engine(gpu_ctx, oracle, kind, world, kw, decode, native
         assert any(r[0].rounds > 0 and r[0].head > (1 << 20) for r in res), "no rank grew its look-ahead"
     if kind == "tricky":
         assert any(r[0].rounds > 0 for r in res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world,kw", [c for c in GPU_CASES if c[1] != 8 or c[0] in ("wrapped", "tricky")])
+@pytest.mark.parametrize("decode", (False, True))
+def test_serial_step_equals_the_pipelined_one(gpu_ctx, oracle, kind, world, kw, decode):
+    """The fallback mode of the device step (include/ffq.h: ONE communicator, ONE stream -- hand-off, scan, words, gather in
+    order on the scan stream): the same rows, the same repair rounds, the same grown views as the pipelined step on the same
+    ranges, and the oracle's rows; ffq_shard_result says which step ran."""
+    from fastqandfurious_amd import hip
+    stream = make_stream(kind)
+    want, err = expected(oracle, stream)
+    assert err is None
+    t = torch.from_numpy(stream.copy()).cuda()
+    bounds = bounds_for(stream.size, world, 5 * (1 << 32) + 123457, 48)
+    got = {}
+    for serial in (False, True):
+        make, made = _hip_backends(gpu_ctx)
+        res = run_local(t, bounds, make, lanes=True, decode=decode, flags=hip.F_DECODE_QUAL if decode else 0, native=True, serial=serial, **kw)
+        check_rows(res, bounds, want + bounds[0])
+        assert all(r[0].comm["mode"] == ("serial" if serial else "pipelined") and r[0].comm["nranks"] == world for r in res)
+        got[serial] = [(r[0].rounds, r[0].head, r[0].row_lo, r[0].row_hi) for r in res]
+        if decode:
+            wq, wqoff = oracle.decode_quals(stream, want)
+            base = 0
+            for r in range(world):
+                out, table, qual, qoff = res[r]
+                n_own = out.row_hi - out.row_lo
+                qo = qoff[out.row_lo:out.row_hi + 1].cpu().numpy()
+                q = qual[int(qo[0]):int(qo[-1])].cpu().numpy() if n_own else np.zeros(0, np.int8)
+                assert (q == wq[int(wqoff[base]):int(wqoff[base + n_own])]).all(), "rank %d: decoded qualities differ" % r
+                base += n_own
+        for c in made.values():
+            c.close()
+    assert got[True] == got[False], "the serial step took other rounds / views than the pipelined one"
 
 
 @pytest.mark.gpu

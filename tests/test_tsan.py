@@ -145,3 +145,20 @@ def test_shard_world_and_host_step_under_tsan(tsan, tmp_path):
     f = tmp_path / "wrapped.fq"
     for w in (2, 5):
         assert ("%d of %d ranks" % (w, w)) in tsan("abort", f, w).stdout
+
+
+def test_a_rank_that_never_arrives_trips_the_deadline_on_every_rank(tsan, tmp_path):
+    """The watchdog of the in-process world (csrc/ffq_shard_proto.h: ffq_shard_world::wait_for): rank 1 of k never enters
+    its step; the first rank whose wait runs out breaks the barrier for everybody, EVERY other rank's host step comes back
+    with FFQ_E_TIMEOUT within the deadline (not at the test's timeout), and the world names rank 1 as the absent one."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_sharded import make_stream
+    f = tmp_path / "wrapped.fq"
+    f.write_bytes(make_stream("wrapped").tobytes())
+    for w in (2, 3, 8):
+        t0 = time.perf_counter()
+        out = tsan("stall", f, w, 1.5).stdout
+        assert ("%d of %d ranks came back with FFQ_E_TIMEOUT; absent: 1" % (w - 1, w - 1)) in out, out
+        assert time.perf_counter() - t0 < 60

@@ -11,6 +11,9 @@
 //                                  gather through ffq_shard_world's breakable barrier (csrc/ffq_shard_proto.h), the settle
 //                                  rounds of the protocol; prints the rows' checksum
 //   abort FILE WORLD               the same with rank 1's scan failing: it breaks the barrier, every other rank comes back
+//   stall FILE WORLD SECONDS       the same with rank 1 never arriving: the barrier's DEADLINE (the watchdog of the in-process
+//                                  world) breaks it for everybody, every other rank comes back with FFQ_E_TIMEOUT within
+//                                  SECONDS and the world names rank 1 as the absent one
 //   race X                         a deliberate data race: the test checks that the detector reports it
 #include "../include/ffq.h"
 #include "../fastq-and-furious_amd/csrc/ffq_pool.h"
@@ -98,6 +101,13 @@ struct Rank {
     int rank, world;
     bool fail_scan;
     std::vector<const ffq_shard_piece *> *boards;      // what each rank parked for the others
+    double deadline = 0;                               // seconds a rank waits at the barrier (0: for ever)
+    // through / FFQ_E_TIMEOUT (somebody's wait ran out: the world says who was missing) / FFQ_E_INTERNAL (another rank failed)
+    int meet() const
+    {
+        const int r = W->wait_for(rank, deadline);
+        return r > 0 ? FFQ_OK : (r < 0 || W->timed_out) ? FFQ_E_TIMEOUT : FFQ_E_INTERNAL;
+    }
 };
 
 static int cb_scan(void *u, const uint8_t *buf, int64_t n, int sentinel, int64_t offset, int eof, int64_t add, int64_t *table, int64_t cap,
@@ -126,24 +136,24 @@ static int cb_exchange(void *u, const ffq_shard_piece *ps, int n)
 {
     Rank *r = static_cast<Rank *>(u);
     (*r->boards)[(size_t)r->rank] = ps;
-    if (!r->W->wait()) return FFQ_E_INTERNAL;
+    int rc = r->meet();
+    if (rc) return rc;
     for (int i = 0; i < n; i++)
         if (ps[i].dst == r->rank) memcpy(ps[i].ptr, (*r->boards)[(size_t)ps[i].src][i].ptr, (size_t)(ps[i].b - ps[i].a));   // (the same list on every rank)
-    if (!r->W->wait()) return FFQ_E_INTERNAL;          // the sources must stay as they are until read
-    return FFQ_OK;
+    return r->meet();          // the sources must stay as they are until read
 }
 
 static int cb_gather(void *u, const int64_t *mine, int64_t *all)
 {
     Rank *r = static_cast<Rank *>(u);
     memcpy(&r->W->slots[(size_t)r->rank * 8], mine, 64);
-    if (!r->W->wait()) return FFQ_E_INTERNAL;
+    int rc = r->meet();
+    if (rc) return rc;
     memcpy(all, r->W->slots.data(), (size_t)r->world * 64);
-    if (!r->W->wait()) return FFQ_E_INTERNAL;
-    return FFQ_OK;
+    return r->meet();
 }
 
-static int mode_shards(const char *path, int world, int64_t tail_bytes, int64_t head_bytes, bool with_abort)
+static int mode_shards(const char *path, int world, int64_t tail_bytes, int64_t head_bytes, bool with_abort, double stall_deadline = 0)
 {
     const std::vector<uint8_t> data = slurp(path);
     const int64_t total = (int64_t)data.size();
@@ -161,7 +171,8 @@ static int mode_shards(const char *path, int world, int64_t tail_bytes, int64_t 
     std::vector<std::thread> th;
     for (int r = 0; r < world; r++)
         th.emplace_back([&, r] {
-            Rank me{&W, r, world, with_abort && r == 1, &boards};
+            if (stall_deadline > 0 && r == 1) return;                  // (the rank that never arrives)
+            Rank me{&W, r, world, with_abort && r == 1, &boards, stall_deadline};
             ffq_shard_host_ops ops{&me, cb_scan, cb_exchange, cb_gather};
             const int64_t lo = B[(size_t)r], hi = B[(size_t)r + 1];
             const int64_t tail = std::min(tail_bytes, lo - B[0]), head = std::min(head_bytes, total - hi);
@@ -181,6 +192,12 @@ static int mode_shards(const char *path, int world, int64_t tail_bytes, int64_t 
             if (out.d_ext != ext.data()) ffq_shard_host_free(out.d_ext);
         });
     for (auto &t : th) t.join();
+    if (stall_deadline > 0) {
+        int timed = 0;
+        for (int r = 0; r < world; r++) timed += rcs[(size_t)r] == FFQ_E_TIMEOUT;
+        printf("stall: %d of %d ranks came back with FFQ_E_TIMEOUT; absent: %s\n", timed, world - 1, W.absent_list().c_str());
+        return (timed == world - 1 && W.absent_list() == "1") ? 0 : 1;
+    }
     if (with_abort) {
         int failed = 0;
         for (int r = 0; r < world; r++) failed += rcs[(size_t)r] != 0;
@@ -228,5 +245,6 @@ int main(int argc, char **argv)
         return 0;
     }
     if (mode == "abort") return mode_shards(argv[2], argc > 3 ? atoi(argv[3]) : 3, 1 << 20, 1 << 20, true);
+    if (mode == "stall") return mode_shards(argv[2], argc > 3 ? atoi(argv[3]) : 3, 1 << 20, 1 << 20, false, argc > 4 ? atof(argv[4]) : 1.0);
     return 2;
 }
