@@ -12,7 +12,9 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <unistd.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -89,6 +91,9 @@ struct ffq_ctx {
     ffq_ctx *owner = nullptr;            // the context whose stream this one uses (itself unless created shared)
     StreamTail tail;                     // (in the owner)
     bool owns_streams = true;            // false: streams borrowed from another context
+    double watchdog_s = 0;               // > 0: the waits INSIDE a scan (its marks, the stream in front of a scratch that grows) poll and give
+                                         //   up after this long with FFQ_E_TIMEOUT -- set by a shard step around its scan (ffq_shard.h): a scan
+                                         //   stream that waits for a hand-off, or carries a gather, whose peer never comes must not hold the host
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -325,6 +330,30 @@ extern "C" void ffq_ctx_destroy(ffq_ctx *c)
 // something other than a scan front goes onto the context's stream (every entry point that enqueues there says so)
 static inline void mark_other(ffq_ctx *c) { if (c && c->owner) c->owner->tail.is_scan = false; }
 
+// The waits of the scan path, with the context's watchdog (ffq_ctx::watchdog_s; 0: the plain blocking calls).  A scan is
+// through in milliseconds: the first two are spun, the rest slept in 100 us pieces.
+static int ctx_wait(ffq_ctx *c, hipEvent_t ev, hipStream_t st)
+{
+    if (c->watchdog_s <= 0) {
+        if (ev) HIPCHK(hipEventSynchronize(ev)); else HIPCHK(hipStreamSynchronize(st));
+        return FFQ_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1;; spins++) {
+        const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(st);
+        if (e == hipSuccess) return FFQ_OK;
+        if (e != hipErrorNotReady) return fail(FFQ_E_HIP, "%s failed: %s", ev ? "hipEventQuery" : "hipStreamQuery", hipGetErrorString(e));
+        if ((spins & 31) == 0) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > c->watchdog_s) return fail(FFQ_E_TIMEOUT, "scan: the stream made no progress within %.1f s", dt);
+            if (dt > 2e-3) usleep(100);
+        }
+        __builtin_ia32_pause();
+    }
+}
+#define CTX_WAIT_EVENT(c, ev) do { const int rc__ = ctx_wait((c), (ev), nullptr); if (rc__) return rc__; } while (0)
+#define CTX_SYNC(c) do { const int rc__ = ctx_wait((c), nullptr, (c)->stream); if (rc__) return rc__; } while (0)
+
 extern "C" void *ffq_ctx_stream(ffq_ctx *c)
 {
     if (!c) return nullptr;
@@ -357,7 +386,7 @@ constexpr int WPB_LITE = 2;                                    // k_chain_lite (
 static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
 {
     if (ntiles <= c->cap_tiles) return FFQ_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    CTX_SYNC(c);
     (void)hipFree(c->ent); (void)hipFree(c->cnt); (void)hipFree(c->ovf);
     c->ent = nullptr; c->cnt = nullptr; c->ovf = nullptr;
     free_chain(c);
@@ -399,7 +428,7 @@ static int reserve_tiles(ffq_ctx *c, int64_t ntiles)
 static int reserve_dstage(ffq_ctx *c, int64_t chunks)
 {
     if (chunks <= c->dstage_chunks) return FFQ_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    CTX_SYNC(c);
     (void)hipFree(c->cb.dstage);
     c->cb.dstage = nullptr; c->dstage_chunks = 0; c->cb.dchunks = 0;
     hipError_t e = hipMalloc((void **)&c->cb.dstage, (size_t)chunks * DCHUNK * sizeof(StageRec));
@@ -413,7 +442,7 @@ static int reserve_stage(ffq_ctx *c, int64_t ng, int nmax)
 {
     const int64_t need = ng * nmax;
     if (need <= c->stage_cap) return FFQ_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    CTX_SYNC(c);
     (void)hipFree(c->cb.stage);
     c->cb.stage = nullptr; c->stage_cap = 0;
     hipError_t e = hipMalloc((void **)&c->cb.stage, (size_t)need * sizeof(StageRec));
@@ -432,7 +461,7 @@ static int64_t qdir_blocks(int64_t n_bytes, int64_t qual_cap)
 static int reserve_qdir(ffq_ctx *c, int64_t blocks)
 {
     if (blocks <= c->qdir_cap) return FFQ_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    CTX_SYNC(c);
     (void)hipFree(c->qdir);
     c->qdir = nullptr; c->qdir_cap = 0;
     hipError_t e = hipMalloc((void **)&c->qdir, (size_t)blocks * sizeof(int64_t));
@@ -447,7 +476,7 @@ static int64_t p4s_need(int64_t n_bytes, int64_t table_cap) { return std::min<in
 static int reserve_p4s(ffq_ctx *c, int64_t entries)
 {
     if (entries <= c->p4s_cap) return FFQ_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    CTX_SYNC(c);
     (void)hipFree(c->p4s); (void)hipFree(c->qrel);
     c->p4s = nullptr; c->qrel = nullptr; c->p4s_cap = 0;
     hipError_t e = hipMalloc((void **)&c->p4s, (size_t)entries * sizeof(int64_t));
@@ -463,7 +492,7 @@ constexpr unsigned long long POOL_MIN = (unsigned long long)POOL_NB * TILE;
 static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 {
     if (entries <= c->pool_cap) return FFQ_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    CTX_SYNC(c);
     (void)hipFree(c->pool);
     c->pool = nullptr; c->pool_cap = 0;
     HIPCHK(hipMalloc((void **)&c->pool, (size_t)entries * sizeof(uint16_t)));
@@ -617,7 +646,7 @@ static_assert(SG_STRIDE == FFQ_SEG_STRIDE, "include/ffq.h and csrc/ffq_fused.h d
 static int enqueue_fused_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles, bool in_place)
 {
     if (ntiles > c->fz_tiles_cap) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        CTX_SYNC(c);
         (void)hipFree(c->fz_qphase);
         c->fz_qphase = nullptr; c->fz_tiles_cap = 0;
         if (hipMalloc((void **)&c->fz_qphase, (size_t)ntiles) != hipSuccess) return fail(FFQ_E_NOMEM, "hipMalloc(fused scratch) failed");
@@ -647,9 +676,15 @@ static Pub no_pub(ffq_ctx *c) { return Pub{c->ctl, nullptr, nullptr, nullptr, 0}
 // publisher needs none to say that it is through)
 static int poll_seq(ffq_ctx *c, unsigned long long want)
 {
+    const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spins = 1;; spins++) {
         if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) >= want) return FFQ_OK;
         if ((spins & 0x7FFF) == 0) {
+            if (c->watchdog_s > 0) {
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (dt > c->watchdog_s) return fail(FFQ_E_TIMEOUT, "scan: the result block was not published within %.1f s", dt);
+                if (dt > 2e-3) usleep(100);
+            }
             const hipError_t e = hipStreamQuery(c->stream);
             if (e == hipSuccess) {           // the stream has drained: the publisher has run, or never will
                 if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) >= want) return FFQ_OK;
@@ -1017,7 +1052,7 @@ static int run_ranked(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, int64_t
     if (launch_scan_i64v(c, sA, R.tbase, ntiles, (int64_t)0, c->col_res)) return 1;
     HIPCHK(hipMemcpyAsync(c->h_word, &c->col_res->n_qual_bytes, sizeof(int64_t), hipMemcpyDeviceToHost, sA));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(sA));
+    CTX_SYNC(c);
     const int64_t nc = c->h_word[0];
     if (nc >= 0x7FFFFFF0ll) return 1;
     // a context that remembers long records meets short ones again: back to the group kernels
@@ -1097,8 +1132,8 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             int rc = poll_seq(c, st.poll_seq);
             if (rc) return rc;
             // (the GPU is past this mark; the wait only lets the runtime note it before the mark is read)
-            if (!st.untimed) HIPCHK(hipEventSynchronize(c->ev[1]));
-        } else HIPCHK(hipEventSynchronize(c->ev[3]));
+            if (!st.untimed) CTX_WAIT_EVENT(c, c->ev[1]);
+        } else CTX_WAIT_EVENT(c, c->ev[3]);
         const LineIndex L = make_index(c, a, st.ntiles);
 
         if (c->h_ctl->err & ERR_POOL) {
@@ -1207,7 +1242,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             if (rc) return rc;
             HIPCHK(hipEventRecord(c->ev[2], sA));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipEventSynchronize(c->ev[2]));
+            CTX_WAIT_EVENT(c, c->ev[2]);
             HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[2]));
             res->ms_chain += ms; res->ms_total += ms;
             if (c->h_ctl->err & ERR_INTERNAL) return fail(FFQ_E_INTERNAL, "chain kernel invariant failed");
@@ -1291,7 +1326,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 if (rc) return rc;
                 HIPCHK(hipEventRecord(c->ev[2], sA));
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipEventSynchronize(c->ev[2]));
+                CTX_WAIT_EVENT(c, c->ev[2]);
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[2]));
                 res->ms_chain += ms; res->ms_total += ms;
                 st.repairs++;
@@ -1328,13 +1363,13 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             walk = rr > 0;
             if (rr == 0) {
                 HIPCHK(hipEventRecord(c->ev[2], sA));
-                HIPCHK(hipEventSynchronize(c->ev[2]));
+                CTX_WAIT_EVENT(c, c->ev[2]);
                 if (decode && !c->h_res->fallback) {
                     int rc = enqueue_offsets_and_decode(c, a, c->h_res->n_records);
                     if (rc) return rc;
                     HIPCHK(hipEventRecord(c->ev[2], sA));
                     HIPCHK(hipGetLastError());
-                    HIPCHK(hipEventSynchronize(c->ev[2]));
+                    CTX_WAIT_EVENT(c, c->ev[2]);
                 }
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[2]));
                 res->ms_chain += ms; res->ms_total += ms;
@@ -1353,7 +1388,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             if (decode) enqueue_decode(c, a, sA);
             HIPCHK(hipEventRecord(c->ev[2], sA));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipEventSynchronize(c->ev[2]));
+            CTX_WAIT_EVENT(c, c->ev[2]);
             HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[2]));
             res->ms_chain += ms;
             res->ms_total += ms;
@@ -1369,6 +1404,18 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         return fail(FFQ_E_TABLE_FULL, "quality buffer holds %lld bytes, %lld needed", (long long)a.qual_cap,
                     (long long)res->n_qual_bytes);
     return FFQ_OK;
+}
+
+// the scratch a scan of n_bytes needs (grow-only: a second call with the same sizes does nothing)
+static int scan_reserve(ffq_ctx *c, int64_t n_bytes, uint32_t flags, int64_t table_cap, int64_t qual_cap)
+{
+    const int64_t ntiles = tiles_for(n_bytes);
+    if (ntiles == 0 || ntiles > 0x7FFFFFF0) return FFQ_OK;          // (nothing to enqueue / refused by the submit)
+    int rc = reserve_tiles(c, ntiles);
+    if (!rc) rc = reserve_pool(c, POOL_MIN);
+    if (!rc && (flags & FFQ_F_DECODE_QUAL)) rc = reserve_qdir(c, qdir_blocks(n_bytes, qual_cap));
+    if (!rc && (flags & FFQ_F_DECODE_QUAL)) rc = reserve_p4s(c, p4s_need(n_bytes, table_cap));
+    return rc;
 }
 
 extern "C" int ffq_scan_submit(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes, int sentinel, int64_t offset,
@@ -1393,10 +1440,7 @@ extern "C" int ffq_scan_submit(ffq_ctx *c, const uint8_t *d_buf, int64_t n_bytes
     st.active = true;
     if (st.ntiles == 0) return FFQ_OK;                   // nothing to enqueue: ffq_scan_wait fills the result
     if (st.ntiles > 0x7FFFFFF0) { st.active = false; return fail(FFQ_E_ARG, "buffer too large"); }
-    int rc = reserve_tiles(c, st.ntiles);
-    if (!rc) rc = reserve_pool(c, POOL_MIN);
-    if (!rc && (flags & FFQ_F_DECODE_QUAL)) rc = reserve_qdir(c, qdir_blocks(n_bytes, qual_cap));
-    if (!rc && (flags & FFQ_F_DECODE_QUAL)) rc = reserve_p4s(c, p4s_need(n_bytes, table_cap));
+    int rc = scan_reserve(c, n_bytes, flags, table_cap, qual_cap);
     if (!rc) {
         st.ngroups = (int)groups_for(st.ntiles);
         rc = enqueue_front(c, st);
@@ -1421,7 +1465,7 @@ extern "C" int ffq_scan_wait(ffq_ctx *c, ffq_scan_result *res)
         for (int i = 0; i < 6; i++) res->last_pos[i] = -1;
         if ((st.a.flags & FFQ_F_DECODE_QUAL) != 0) {
             HIPCHK(hipMemsetAsync(st.a.d_qoff, 0, sizeof(int64_t), c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            CTX_SYNC(c);
         }
         return FFQ_OK;
     }
@@ -1444,7 +1488,7 @@ template <class T>
 static int grow_dev(ffq_ctx *c, T **p, int64_t *cap, int64_t need)
 {
     if (need <= *cap) return FFQ_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    CTX_SYNC(c);
     (void)hipFree(*p);
     *p = nullptr; *cap = 0;
     const int64_t want = std::max<int64_t>(need, 1 << 16);

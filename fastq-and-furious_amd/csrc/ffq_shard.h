@@ -703,6 +703,8 @@ static void shard_stall(ffq_shard *s, int stage, hipStream_t st)
     s->stall_stage = FFQ_SHARD_STAGE_NONE;
     *s->h_stall = 0;
     hipLaunchKernelGGL(k_shard_stall, dim3(1), dim3(64), 0, st, (const int *)s->hm_stall, (unsigned long long)(s->stall_s * 1e8));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess || sh_debug()) fprintf(stderr, "[ffq shard %d/%d] stall injected at stage '%s' for up to %.1f s: %s\n", s->rank, s->world, sh_stage_name(stage), s->stall_s, hipGetErrorString(e));
 }
 
 // step 1 alone (a caller that scans by other means): fills ext[:tail] and ext[tail + own : tail + own + head]
@@ -805,14 +807,11 @@ static std::string shard_words_seen(ffq_shard *s)
     return "words present from rank(s) [" + have + "], absent from [" + lack + "]";
 }
 
-// waits for one mark of the pending step with the watchdog's deadline
-static int shard_wait_mark(ffq_shard *s, hipEvent_t ev)
+// the watchdog has tripped (w: 1 the deadline, 2 an asynchronous RCCL error): where, who, FFQ_E_TIMEOUT / FFQ_E_HIP
+static int shard_tripped(ffq_shard *s, double waited, int w = 1, int at = -1)
 {
     ShTransport *tr = s->tr;
-    double waited = 0;
-    const int w = sh_wait_event(ev, tr->timeout_s, tr, &waited);
-    if (w <= 0) return w;
-    const int stage = shard_stage(s);
+    const int stage = at >= 0 ? at : shard_stage(s);
     s->last_stage = stage;
     tr->poisoned = true;
     s->pending = false;
@@ -822,6 +821,15 @@ static int shard_wait_mark(ffq_shard *s, hipEvent_t ev)
     std::string seen = (stage == FFQ_SHARD_STAGE_GATHER && s->world > 1 && !strcmp(tr->name(), "rccl")) ? "; " + shard_words_seen(s) : std::string();
     return fail(FFQ_E_TIMEOUT, "ffq_shard_step_wait: rank %d of %d: no progress within %.1f s at stage '%s' (transport %s, %s step; FFQ_SHARD_TIMEOUT_S)%s",
                 s->rank, s->world, waited, sh_stage_name(stage), tr->name(), tr->serial ? "serial" : "pipelined", seen.c_str());
+}
+
+// waits for one mark of the pending step with the watchdog's deadline
+static int shard_wait_mark(ffq_shard *s, hipEvent_t ev)
+{
+    double waited = 0;
+    const int w = sh_wait_event(ev, s->tr->timeout_s, s->tr, &waited);
+    if (w <= 0) return w;
+    return shard_tripped(s, waited, w);
 }
 
 extern "C" int ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_handoff, uint32_t flags, int qual_add,
@@ -841,11 +849,19 @@ extern "C" int ffq_shard_step_submit(ffq_shard *s, uint8_t *d_ext, int overlap_h
     s->handoff_bytes = 0; s->handoff_timed = false;
     s->local_fail = 0; s->last_stage = FFQ_SHARD_STAGE_NONE;
     s->from_file = s->fd >= 0 && d_ext == s->file_ext;
-    int rc = s->from_file ? FFQ_OK : shard_handoff(s, d_ext, tail, overlap_handoff != 0);
+    // The scan's scratch FIRST: a scratch that has to grow waits for the scan stream (and hipFree for the device), and that
+    // wait must not sit behind this step's hand-off -- a collective whose peer may never come.
+    int rc = scan_reserve(c, s->v.n_bytes, flags, table_cap, qual_cap);
+    if (rc) return rc;
+    rc = s->from_file ? FFQ_OK : shard_handoff(s, d_ext, tail, overlap_handoff != 0);
     if (rc) return rc;
     if (s->stall_stage == FFQ_SHARD_STAGE_SCAN) { mark_other(c); shard_stall(s, FFQ_SHARD_STAGE_SCAN, c->stream); }
+    c->watchdog_s = s->tr->timeout_s;        // (a front that must grow a scratch of its own waits for the stream: behind the hand-off by now)
     rc = ffq_scan_submit(c, d_ext, s->v.n_bytes, s->v.sentinel, 0, s->v.eof, s->v.add, s->flags, qual_add, d_table, table_cap,
                          d_qual, qual_cap, d_qoff);
+    c->watchdog_s = 0;
+    if (rc == FFQ_E_TIMEOUT)
+        return shard_tripped(s, s->tr->timeout_s, 1, (s->handoff_timed && hipEventQuery(s->ev_x[1]) == hipErrorNotReady) ? FFQ_SHARD_STAGE_HANDOFF : FFQ_SHARD_STAGE_SCAN);
     if (rc) return rc;
     if (s->v.n_bytes == 0) {
         // an empty view (nothing is enqueued for it, the device holds no result block of this scan): its words on the host --
@@ -865,8 +881,11 @@ static int shard_local(ffq_shard *s, ffq_scan_result *res, int64_t start)
 {
     const int64_t offset = start < 0 ? 0 : std::max(start, s->v.start) - s->v.add;
     s->start = start;
+    s->c->watchdog_s = s->tr->timeout_s;
     int rc = ffq_scan_device(s->c, s->ext, s->v.n_bytes, s->v.sentinel, offset, s->v.eof, s->v.add, s->flags, s->qual_add,
                              s->d_table, s->table_cap, s->d_qual, s->qual_cap, s->d_qoff, res);
+    s->c->watchdog_s = 0;
+    if (rc == FFQ_E_TIMEOUT) return shard_tripped(s, s->tr->timeout_s);
     if (rc && rc != FFQ_E_TABLE_FULL) {
         // (every rank gathers at the end of a repair round: mine says "failed", and the step ends with INTERNAL everywhere)
         s->local_fail = rc; s->local_msg = ffq_last_error();
@@ -893,7 +912,12 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
     int rc = shard_wait_mark(s, s->ev_w);
     if (rc) return rc;
     s->pending = false;
+    // (a scan that needs a later tier queues its kernels behind whatever the scan stream holds by now -- serial: this
+    // step's gather, the next step's hand-off -- and waits for them: with the watchdog too)
+    c->watchdog_s = s->tr->timeout_s;
     rc = ffq_scan_wait(c, &out->scan);
+    c->watchdog_s = 0;
+    if (rc == FFQ_E_TIMEOUT) return shard_tripped(s, s->tr->timeout_s);
     // A scan that failed HERE (not the stream's error: a kernel invariant, no memory for a later tier) must not leave the
     // peers waiting in the next collective: such a scan's words say "not ready" (its result block is marked), every rank
     // gathers once more, and this rank's words then say "failed" -- INTERNAL on every rank.
