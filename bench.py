@@ -45,6 +45,12 @@ WORKLOADS = {
     # ... and as rounds 1-2 measured it: packed CSR stream, two passes over the input
     "decode-10g-packed": dict(kind="single", bytes=10 * GIB, decode=True, diagnostic=True),
     "wrapped-10g": dict(kind="wrapped", bytes=10 * GIB, decode=False),
+    # ... with the decode (no BASELINE config: configs[2] decodes single-line reads, configs[3] wraps without decoding): one
+    # pass -- the index kernel writes EVERY byte decoded in place (FFQ_F_SINGLE_PASS with FFQ_INPLACE_STRIDE per tile,
+    # res.path 8) -- and, as a diagnostic, the two passes (packed stream)
+    "wrapped-10g-decode": dict(kind="wrapped", bytes=10 * GIB, decode=True, single_pass=True, in_place=True),
+    "wrapped-10g-decode-packed": dict(kind="wrapped", bytes=10 * GIB, decode=True, diagnostic=True),
+    "wrapped-64m-decode": dict(kind="wrapped", bytes=64 << 20, decode=True, single_pass=True, in_place=True),
     # the reference's own test template repeated (/root/reference/tests.py:8-35: 27-byte records, 6.75 bytes per line):
     # every index tile is DENSE (over its slot); 75 B of SURVEY 8(d) traffic per record, 48 of them the row
     "dense-1g": dict(kind="dense", bytes=1 * GIB, decode=False),
@@ -539,7 +545,8 @@ def run_workload(name, args, ctx, rank, world, dev, dist, ctl=None):
     qual = qoff = None
     if decode:
         # (room for the segmented layout of --single-pass too: 8704 bytes per 16 KiB tile)
-        qual = torch.empty(max(shard.ext.numel(), ((shard.ext.numel() + 16383) >> 14) * hip.SEG_STRIDE), dtype=torch.int8, device=dev)
+        qual = torch.empty(max(shard.ext.numel(), ((shard.ext.numel() + 16383) >> 14) * (hip.INPLACE_STRIDE if wl.get("in_place") else hip.SEG_STRIDE)),
+                           dtype=torch.int8, device=dev)
         qoff = torch.empty(table.shape[0] + 1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
@@ -713,7 +720,7 @@ def run_workload(name, args, ctx, rank, world, dev, dist, ctl=None):
         total_records, total_bytes = int(tot[0].item()), int(tot[1].item())
     else:
         total_records, total_bytes = out.n_own_records, n_own
-    assert out.res.path in (0, 3, 6), "a parallel chain path must be the one measured (got path %d)" % out.res.path
+    assert out.res.path in (0, 3, 6, 8), "a parallel chain path must be the one measured (got path %d)" % out.res.path
 
     # The same step once more OUTSIDE the timed region, one at a time and with an end event instead of
     # the polled completion word: the device span first kernel -> last kernel of ONE step (res.ms_total,
@@ -775,7 +782,13 @@ def run_workload(name, args, ctx, rank, world, dev, dist, ctl=None):
         # decoding, else the line-index kernel.  Algorithmic bytes per launch:
         #   k_scan_lines     every byte of the scanned buffer read once + 2 B of index per newline
         #   k_decode_stream  quality bytes read + written + 16 B of (offset, pos4) per record
-        if decode and out.res.path == 6:
+        if decode and out.res.path == 8:
+            # one pass on the general path (k_scan_lines<.., WIDE>): every byte read once AND written once (decoded in place),
+            # 2 B of index per newline -- the kernel's own bytes; what of them is quality shows in path_roofline
+            dom, t_dom = "k_scan_lines<WIDE>", float(np.mean(ms_index)) * 1e-3
+            algo = 2 * shard.ext_scanned_bytes + 2 * int(out.res.n_lines)
+            traffic = pmc_traffic(name, "k_scan_lines<")
+        elif decode and out.res.path == 6:
             # single pass (ffq_fused.h): the index kernel also writes the decoded qualities (segmented) -- every byte
             # of the buffer read once, 2 B of index per newline and the decoded bytes written
             dom, t_dom = "k_scan_seg", float(np.mean(ms_index)) * 1e-3
@@ -822,7 +835,9 @@ def run_workload(name, args, ctx, rank, world, dev, dist, ctl=None):
                                   "tests.py template x n (27-byte records, every tile dense)" if wl["kind"] == "dense" else "S-wrapped 50-300 bp",
                                   n_own, n_rec, "" if not decode else
                                   (", quality->int8 decode, segmented output (record i = qual[qoff[i] : qoff[i] + pos5 - pos4]), one pass"
-                                   if out.res.path == 6 else ", quality->int8 decode, packed CSR stream, two passes")),
+                                   if out.res.path == 6 else
+                                   ", quality->int8 decode IN PLACE (every byte of the buffer decoded at its own offset by the index pass, qoff[i] = pos4's offset), one pass"
+                                   if out.res.path == 8 else ", quality->int8 decode, packed CSR stream, two passes")),
                 "diagnostic": bool(wl.get("diagnostic")),      # True: kept for comparison, not what a caller of the product runs
                 "bytes_per_gpu": n_own,
                 "records_per_gpu": n_rec,

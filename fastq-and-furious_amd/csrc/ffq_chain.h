@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(1024) void k_resolve_b(ChainBufs B, int nblk, int e
 __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__restrict__ res, int64_t add,
                                                int64_t *__restrict__ table, int64_t table_cap,
                                                int64_t *__restrict__ qoff, int64_t *__restrict__ qdir,
-                                               int64_t qdir_cap, int64_t *__restrict__ p4s, int64_t p4_cap, int sshift)
+                                               int64_t qdir_cap, int64_t *__restrict__ p4s, int64_t p4_cap, int sshift, int in_place)
 {
     __shared__ __attribute__((aligned(16))) int64_t s_rows[64 * 6];
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -1275,7 +1275,10 @@ __global__ __launch_bounds__(64) void k_expand(ChainBufs B, const DevRes *__rest
             p0 = base + r.p0; p1 = base + r.p1; p3 = base + r.p3; p4 = base + r.p4;
         }
         const int64_t p5 = p4 + p3 - p1 - 1;
-        if (qoff) {
+        if (qoff && in_place) {
+            // (the index pass decoded every byte at its own offset: a record's bytes start where pos4 lies in the buffer)
+            if (ok && r0 + dd < table_cap) qoff[r0 + dd] = p4 - add - sshift;
+        } else if (qoff) {
             const uint32_t ql = ok ? (uint32_t)(p5 - p4) : 0u;
             // quality lengths are < 2^31; chunk sums of 64 fit 64 bits via two 32-bit scans
             const uint32_t lo = wave_incl_scan(ql & 0xFFFFu), hi = wave_incl_scan(ql >> 16);

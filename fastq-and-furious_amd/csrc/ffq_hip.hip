@@ -66,6 +66,8 @@ struct ScanState {
     bool in_place = false;    // the single pass of this front writes in place (k_scan_ident) rather than segments (k_scan_seg)
     bool seg_refused = false; // the segmented single pass met a shape it cannot take (a long line): the in-place one is next
     unsigned long long poll_seq = 0;   // FFQ_F_POLL_RESULT: the front ends in a publisher that writes this number; no end event
+    bool wide = false;        // the index kernel of this scan also wrote EVERY byte decoded in place (k_scan_lines<.., WIDE>): the general
+                              //   path's decode in one pass -- no tier of this scan runs a decode kernel, qoff[i] = pos4's offset in the buffer
     bool go_ranked = false;   // the front is the index kernel only: the list-ranking tier follows at the wait
     bool index_done = false;  // the line index of this buffer is built (a later tier re-uses it)
     int stage = 0;            // what the pending front consisted of: 1 fast four-line path, 2 general path
@@ -603,10 +605,25 @@ static LineIndex make_index(ffq_ctx *c, const ScanArgs &a, int64_t ntiles)
 // The line-index launch: one workgroup per whole tile; the ragged last tile (if any) rides along
 // as workgroup 0's second tile.  A buffer shorter than a tile is one workgroup.
 static void launch_scan_lines(ffq_ctx *c, hipStream_t st, const uint8_t *d_buf, int64_t n_bytes, int64_t ntiles,
-                              const LineIndex &L, uint32_t at_char, int ablate = 0, bool any_order = false)
+                              const LineIndex &L, uint32_t at_char, int ablate = 0, bool any_order = false,
+                              int8_t *wout = nullptr, int wadd = 0)
 {
     const int64_t nfull = n_bytes >> TILE_SHIFT;
     const int ragged = ntiles > nfull ? (int)nfull : -1;
+    int8_t *const no_out = nullptr;
+    if (wout) {
+        // the WIDE instantiation (ffq_kernels.h): the index AND every byte decoded in place, for the decode of records of any
+        // layout in one pass (FFQ_F_DECODE_QUAL | FFQ_F_SINGLE_PASS on the general path)
+        if (nfull > 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8, true>), dim3((unsigned)nfull), dim3(256), 0, st, d_buf,
+                               n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, ablate, L, c->d_L,
+                               at_char, ragged, wout, (uint32_t)wadd);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 8, true>), dim3(1), dim3(256), 0, st, d_buf,
+                               n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, ablate, L, c->d_L,
+                               at_char, 0, wout, (uint32_t)wadd);
+        return;
+    }
     if (nfull > 0 && any_order)
         // No barrier in front of this dispatch: it may start while the kernel queued before it (the previous
         // scan's last, one-workgroup kernel -- another context's, on the same stream) is still running.  The
@@ -614,15 +631,15 @@ static void launch_scan_lines(ffq_ctx *c, hipStream_t st, const uint8_t *d_buf, 
         // scan touches; the kernels behind it are ordinary launches and wait for everything in front of them.
         hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)nfull), dim3(256), 0, st, nullptr, nullptr,
                               hipExtAnyOrderLaunch, d_buf, n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0,
-                              ablate, L, c->d_L, at_char, ragged);
+                              ablate, L, c->d_L, at_char, ragged, no_out, 0u);
     else if (nfull > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<true, 8>), dim3((unsigned)nfull), dim3(256), 0, st, d_buf,
                            n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, ablate, L, c->d_L,
-                           at_char, ragged);
+                           at_char, ragged, no_out, 0u);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_lines<false, 8>), dim3(1), dim3(256), 0, st, d_buf,
                            n_bytes, c->ent, c->cnt, c->ovf, c->pool, c->pool_cap, c->ctl, 0, ablate, L, c->d_L,
-                           at_char, 0);
+                           at_char, 0, no_out, 0u);
 }
 
 // Phred decode of the finished table: the grid covers the largest possible quality stream;
@@ -700,6 +717,7 @@ static int poll_seq(ffq_ctx *c, unsigned long long want)
 static int enqueue_resolve(ffq_ctx *c, const ScanArgs &a, const ChainBufs &cb, bool timed, bool mins_set = false)
 {
     const bool decode = (a.flags & FFQ_F_DECODE_QUAL) != 0;
+    const bool wide = c->pend.wide;          // (the qualities are there already, in place: k_expand writes qoff[i] = pos4's buffer offset)
     int64_t *qoff = decode ? a.d_qoff : nullptr;
     hipStream_t sA = c->stream;
     const int ngroups = cb.ng;
@@ -708,12 +726,12 @@ static int enqueue_resolve(ffq_ctx *c, const ScanArgs &a, const ChainBufs &cb, b
     hipLaunchKernelGGL(k_resolve_a, dim3(nblk), dim3(RES_BLOCK), 0, sA, cb);
     hipLaunchKernelGGL(k_resolve_b, dim3(1), dim3(1024), 0, sA, cb, nblk, a.eof, a.offset, a.add, c->dres);
     hipLaunchKernelGGL(k_expand, dim3(ngroups), dim3(64), 0, sA, cb, (const DevRes *)c->dres, a.add, a.d_table,
-                       a.table_cap, qoff, c->qdir, c->qdir_cap, qoff ? c->p4s : (int64_t *)nullptr,
-                       qoff ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0, a.s);
+                       a.table_cap, qoff, wide ? (int64_t *)nullptr : c->qdir, c->qdir_cap, (qoff && !wide) ? c->p4s : (int64_t *)nullptr,
+                       (qoff && !wide) ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0, a.s, wide ? 1 : 0);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sA, c->dres, a.d_table, a.table_cap, a.add, a.offset, qoff,
-                       make_pub(c));
+                       make_pub(c), wide ? a.s : -1);
     c->ctl_clean = true;
-    if (decode) enqueue_decode(c, a, sA, timed);
+    if (decode && !wide) enqueue_decode(c, a, sA, timed);
     return FFQ_OK;
 }
 
@@ -916,9 +934,20 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
             if (tl.out_p[i] && o0 < b1 && b0 < o1) any_order = false;
         }
     }
+    // The decode of records of ANY layout in one pass (round 6): a scan that starts on the general path (wrapped records:
+    // the context remembers them; FFQ_F_FORCE_GENERAL; the ranking / one-wave tiers) with FFQ_F_SINGLE_PASS and
+    // FFQ_INPLACE_STRIDE bytes of quality buffer per tile has its index kernel write EVERY byte decoded at the offset it has
+    // in the buffer (k_scan_lines<.., WIDE>): no tier of the scan then runs a decode kernel -- qoff[i] = pos4's offset --
+    // and the input is read once.  (The four-line fast path has its own single passes, above; a scan that comes here from a
+    // refused fast path already has its index and takes the packed decode, as before.)
+    static const bool no_wide = getenv("FFQ_NO_WIDE") != nullptr;
+    if (!st.index_done)
+        st.wide = decode && (a.flags & FFQ_F_SINGLE_PASS) && !try_fast4 && ablate == 0 && !no_wide &&
+                  a.qual_cap >= ntiles * (int64_t)TILE && (reinterpret_cast<uintptr_t>(a.d_qual) & 15) == 0;
     if (!st.untimed) HIPCHK(hipEventRecord(c->ev[0], sA));
     if (!st.index_done)          // (a later tier of the same scan: the index is there already)
-        launch_scan_lines(c, sA, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', k1abl, any_order);
+        launch_scan_lines(c, sA, a.d_buf, a.n_bytes, ntiles, L, (uint32_t)'@', k1abl, any_order && !st.wide,
+                          st.wide ? a.d_qual : (int8_t *)nullptr, a.qual_add);
     if (!st.untimed) HIPCHK(hipEventRecord(c->ev[1], sA));
 
     if (try_fast4) {
@@ -1084,7 +1113,7 @@ static int run_ranked(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, int64_t
                            R.S[cur ^ 1], R.C[cur ^ 1], R.D, k);
     hipLaunchKernelGGL(k_rk_emit, dim3(gthr), dim3(256), 0, sA, L, R, a.eof, a.offset, a.add, a.d_table, a.table_cap, c->dres);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, sA, c->dres, (const int64_t *)a.d_table, a.table_cap, a.add, a.offset,
-                       (int64_t *)nullptr, make_pub(c));
+                       (int64_t *)nullptr, make_pub(c), -1);
     c->ctl_clean = true;
     HIPCHK(hipGetLastError());
     return FFQ_OK;
@@ -1109,6 +1138,16 @@ static int enqueue_offsets_and_decode(ffq_ctx *c, const ScanArgs &a, int64_t n_r
                        (const long long *)c->col_sum, (const DevRes *)c->dres, a.d_qoff, c->p4s, c->qdir, c->qdir_cap);
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, sA, c->dres, make_pub(c), 0);
     enqueue_decode(c, a, sA);
+    return FFQ_OK;
+}
+
+// ... and for a scan whose index pass decoded everything in place (ScanState::wide): only the offsets, qoff[i] = the
+// offset pos4 has in the buffer, from the finished table
+static int enqueue_offsets_in_place(ffq_ctx *c, const ScanArgs &a, int64_t n_rows)
+{
+    (void)n_rows;
+    hipLaunchKernelGGL(k_qoff_in_place, dim3(256), dim3(256), 0, c->stream, c->dres, (const int64_t *)a.d_table, a.table_cap, a.add, a.s,
+                       a.d_qoff, make_pub(c));
     return FFQ_OK;
 }
 
@@ -1365,7 +1404,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
                 HIPCHK(hipEventRecord(c->ev[2], sA));
                 CTX_WAIT_EVENT(c, c->ev[2]);
                 if (decode && !c->h_res->fallback) {
-                    int rc = enqueue_offsets_and_decode(c, a, c->h_res->n_records);
+                    int rc = st.wide ? enqueue_offsets_in_place(c, a, c->h_res->n_records) : enqueue_offsets_and_decode(c, a, c->h_res->n_records);
                     if (rc) return rc;
                     HIPCHK(hipEventRecord(c->ev[2], sA));
                     HIPCHK(hipGetLastError());
@@ -1380,12 +1419,14 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         if (walk) {
             path = 1;
             HIPCHK(hipEventRecord(c->ev[4], sA));
+            int64_t *const sq = st.wide ? (int64_t *)nullptr : qoff;       // (wide: the offsets from the finished table, below)
             hipLaunchKernelGGL(k_chain_serial, dim3(1), dim3(64), 0, sA, L, a.offset, a.eof, a.add, a.d_table,
-                               a.table_cap, qoff, c->qdir, c->qdir_cap, qoff ? c->p4s : (int64_t *)nullptr,
-                               qoff ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0, c->dres);
-            hipLaunchKernelGGL(k_finalize_serial, dim3(1), dim3(64), 0, sA, c->dres, a.table_cap, qoff, make_pub(c));
+                               a.table_cap, sq, c->qdir, c->qdir_cap, sq ? c->p4s : (int64_t *)nullptr,
+                               sq ? std::min<int64_t>(a.table_cap, c->p4s_cap) : (int64_t)0, c->dres);
+            hipLaunchKernelGGL(k_finalize_serial, dim3(1), dim3(64), 0, sA, c->dres, a.table_cap, sq, (decode && st.wide) ? no_pub(c) : make_pub(c));
             c->ctl_clean = true;
-            if (decode) enqueue_decode(c, a, sA);
+            if (decode && st.wide) hipLaunchKernelGGL(k_qoff_in_place, dim3(256), dim3(256), 0, sA, c->dres, (const int64_t *)a.d_table, a.table_cap, a.add, a.s, a.d_qoff, make_pub(c));
+            else if (decode) enqueue_decode(c, a, sA);
             HIPCHK(hipEventRecord(c->ev[2], sA));
             HIPCHK(hipGetLastError());
             CTX_WAIT_EVENT(c, c->ev[2]);
@@ -1394,7 +1435,7 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
             res->ms_total += ms;
         }
         if (tiers && c->lite_ran && (int64_t)c->h_res->n_declined * 4 > (int64_t)st.ngroups) c->lite_skip = 15;
-        fill_result(res, *c->h_res, path, st.retries + st.repairs);
+        fill_result(res, *c->h_res, path | ((decode && st.wide) ? FFQ_PATH_IN_PLACE : 0), st.retries + st.repairs);
         break;
     }
     if (res->n_records > a.table_cap)

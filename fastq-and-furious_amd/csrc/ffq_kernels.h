@@ -289,11 +289,19 @@ __device__ __forceinline__ void scan_tile_rest(ScanLds &sm, const int tile, cons
     scan_tile_store(sm, tile, wbase, wtot, total, dense, pbase, pool_ok, dense_any, nxt, ent, cnt, ovf, pool, ablate, at_char);
 }
 
-template <bool FULL>
+// WIDE (round 6): the same pass also writes EVERY byte decoded -- out[p] = d[p] + qadd (int8 arithmetic) at the offset the
+// byte has in the input -- so that the Phred decode of ANY record layout (wrapped records: which lines are quality lines is
+// known only behind the chain) needs no second read of the input: record i's bytes are out[pos4 : pos5] in the
+// coordinates of d (embedded newlines of a wrapped quality come out as '\n' + qadd, as the reference's slice + arrayadd_b
+// give them, /root/reference/src/_fastqandfurious.c:129, doc/user-guide.rst:126-141).  The price is the bytes nobody asked
+// for (headers, bases): input + as much written instead of input read twice + the qualities written.  The output must hold
+// ntiles * TILE bytes (the ragged last tile writes whole 16-byte pieces).
+template <bool FULL, bool WIDE = false>
 __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uint8_t *__restrict__ d, int64_t n,
                                           uint16_t *__restrict__ ent, uint32_t *__restrict__ cnt,
                                           unsigned long long *__restrict__ ovf, uint16_t *__restrict__ pool,
-                                          unsigned long long pool_cap, Ctl *ctl, int ablate, uint32_t at_char)
+                                          unsigned long long pool_cap, Ctl *ctl, int ablate, uint32_t at_char,
+                                          int8_t *__restrict__ wout = nullptr, uint32_t wadd = 0)
 {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int64_t base = (int64_t)tile << TILE_SHIFT;
@@ -326,6 +334,15 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
         m[i] = nl_mask16(v[i]);
         c[i] = __popc(m[i]);
     }
+    if (WIDE) {
+        const uint32_t vv = (wadd & 0xFFu) * 0x01010101u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 t; t.x = addb4(v[i].x, vv); t.y = addb4(v[i].y, vv); t.z = addb4(v[i].z, vv); t.w = addb4(v[i].w, vv);
+            __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(wout + base + o[i]));
+        }
+    }
     scan_tile_rest(sm, tile, m, c, o, nxt, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
 }
 
@@ -334,7 +351,7 @@ __device__ __forceinline__ void scan_tile(ScanLds &sm, const int tile, const uin
 // variant of the whole kernel with a ragged test in front of the loads ran 3-8 us per GiB slower
 // on every tile, and workgroup 0 is long done when the last round of the grid starts.
 // WHOLE = false: no whole tile at all (a buffer shorter than a tile), one workgroup.
-template <bool WHOLE, int MINW>
+template <bool WHOLE, int MINW, bool WIDE = false>
 __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restrict__ d, int64_t n,
                                                     uint16_t *__restrict__ ent,
                                                     uint32_t *__restrict__ cnt,
@@ -342,14 +359,14 @@ __global__ __launch_bounds__(256, MINW) void k_scan_lines(const uint8_t *__restr
                                                     uint16_t *__restrict__ pool,
                                                     unsigned long long pool_cap, Ctl *ctl, int tile0,
                                                     int ablate, LineIndex Lval, LineIndex *__restrict__ d_L,
-                                                    uint32_t at_char, int ragged_tile)
+                                                    uint32_t at_char, int ragged_tile, int8_t *__restrict__ wout, uint32_t wadd)
 {
     __shared__ ScanLds sm;
-    if (WHOLE) scan_tile<true>(sm, tile0 + (int)blockIdx.x, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
+    if (WHOLE) scan_tile<true, WIDE>(sm, tile0 + (int)blockIdx.x, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char, wout, wadd);
     if (blockIdx.x == 0) {
         if (ragged_tile >= 0) {
             if (WHOLE) __syncthreads();
-            scan_tile<false>(sm, ragged_tile, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char);
+            scan_tile<false, WIDE>(sm, ragged_tile, d, n, ent, cnt, ovf, pool, pool_cap, ctl, ablate, at_char, wout, wadd);
         }
         // the device copy of the index descriptor (out-of-line device functions take it by pointer)
         if (threadIdx.x == 0 && d_L) *d_L = Lval;
@@ -436,16 +453,42 @@ __global__ __launch_bounds__(64) void k_chain_serial(LineIndex L, int64_t offset
 
 // k_finalize: the iterator's `offset` at exit = pos5 - 1 of the last COMPLETE
 // record (fastqandfurious.py:254), read back from the table; qoff[n].
+// in_place_s >= 0 (the sentinel flag of a scan whose index pass decoded every byte in place): the qualities "end" where
+// the last record's do in the buffer -- n_qual_bytes and qoff[n] as k_qtotal4 leaves them for the in-place single pass.
 __global__ void k_finalize(DevRes *res, const int64_t *__restrict__ table, int64_t table_cap,
-                           int64_t add, int64_t offset, int64_t *__restrict__ qoff, Pub pb)
+                           int64_t add, int64_t offset, int64_t *__restrict__ qoff, Pub pb, int in_place_s)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (res->fallback) { publish(pb, res); return; }
     const int64_t ncomplete = res->n_records - (res->has_final ? 1 : 0);
     if (ncomplete > 0 && ncomplete <= table_cap) res->end_offset = table[(ncomplete - 1) * 6 + 5] - add - 1;
     else res->end_offset = offset;
+    if (qoff && in_place_s >= 0) {
+        const int64_t n = res->n_records;
+        res->n_qual_bytes = (n > 0 && n <= table_cap) ? table[(n - 1) * 6 + 5] - add - in_place_s : 0;
+    }
     if (qoff && res->n_records <= table_cap) qoff[res->n_records] = res->n_qual_bytes;
     publish(pb, res);
+}
+
+// qoff[i] = the offset pos4 of row i has in the buffer, qoff[n] = n_qual_bytes = where the last record's qualities end there:
+// the offsets of a scan whose index pass decoded every byte in place, for the tiers that do not write them on the way
+// (list ranking, the one-wave walker).  Publishes.
+__global__ __launch_bounds__(256) void k_qoff_in_place(DevRes *res, const int64_t *__restrict__ table, int64_t table_cap, int64_t add, int s,
+                                                       int64_t *__restrict__ qoff, Pub pb)
+{
+    const int64_t n = res->fallback ? 0 : min(res->n_records, table_cap);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        qoff[i] = table[i * 6 + 4] - add - s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!res->fallback) {
+            const int64_t nr = res->n_records;
+            const int64_t tot = (nr > 0 && nr <= table_cap) ? table[(nr - 1) * 6 + 5] - add - s : 0;
+            res->n_qual_bytes = tot;
+            if (nr <= table_cap) qoff[nr] = tot;
+        }
+        publish(pb, res);
+    }
 }
 
 __global__ void k_finalize_serial(DevRes *res, int64_t table_cap, int64_t *__restrict__ qoff, Pub pb)

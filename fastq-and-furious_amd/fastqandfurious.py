@@ -444,9 +444,12 @@ def readfastq_iter(fh: typing.BinaryIO, fbufsize: int,
         yield from _iter_batched(fh, fbufsize, entryfunc, scan_buffer)
         return
 
-    if _pushes_down(entryfunc) and not entryfunc.yield_dropped:
-        # (the kept records only: the reference's loop below with the guide's `if sequence is None: # do nothing` folded in)
-        keep_all = entryfunc_lengthfilter(min_len=entryfunc.min_len, max_len=entryfunc.max_len, column=entryfunc.column)
+    if isinstance(entryfunc, entryfunc_lengthfilter) and not entryfunc.yield_dropped:
+        # (the kept records only: the reference's loop below with the guide's `if sequence is None: # do nothing` folded in;
+        # the object itself -- a subclass with a __call__ / keeps() of its own included -- with yield_dropped switched on)
+        import copy
+        keep_all = copy.copy(entryfunc)
+        keep_all.yield_dropped = True
         yield from (e for e in readfastq_iter(fh, fbufsize, keep_all, entrypos) if e is not None)
         return
     posbuffer = array('q', [-1, ] * 6)

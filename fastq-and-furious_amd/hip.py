@@ -40,6 +40,7 @@ F_POLL_RESULT = 8
 F_SINGLE_PASS = 16
 SEG_STRIDE = 8704            # FFQ_F_SINGLE_PASS: bytes of the quality buffer every 16 KiB tile of the input owns (include/ffq.h)
 INPLACE_STRIDE = 16384       # ... and what admits the in-place layout as well (lines of any length)
+PATH_IN_PLACE = 8            # ScanResult.path bit (FFQ_PATH_IN_PLACE): the general path's index pass decoded every byte in place
 F_NO_TIMING = 32
 F_FORCE_GENERAL = 64        # tests: skip the four-line fast path
 

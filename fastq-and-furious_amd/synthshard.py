@@ -281,7 +281,7 @@ class SyntheticShard:
         import torch
         n = int(out.n_rows)
         lens = table[:n, 5] - table[:n, 4]
-        if out.res.path == 6:
+        if out.res.path in (6, 8):
             assert bool((qoff[1:n] >= qoff[:n - 1] + lens[:n - 1]).all()), "records' decoded bytes overlap or are out of order"
             assert n == 0 or int(qoff[n].item()) == int((qoff[n - 1] + lens[n - 1]).item())
         else:

@@ -88,11 +88,20 @@ extern "C" {
                                         qual_cap >= FFQ_INPLACE_STRIDE per tile: also IN PLACE, d_qoff[i] = the offset pos4 has
                                           in d_buf -- lines of any length (long reads); taken when the segmented pass refuses
                                           the buffer for its shape, and first from then on (until ffq_ctx_forget).
-                                      Less room -- or input the single pass cannot vouch for: wrapped records, a quality line
-                                      longer than its read, text in front of the first record -- and the two passes run: the
+                                      Records of ANY other layout -- WRAPPED ones, whose quality lines are known only behind
+                                      the record chain -- decode in one pass as well with FFQ_INPLACE_STRIDE bytes per tile
+                                      (round 6): a scan that starts on the general kernels (a context that has met such input
+                                      remembers it) has its index pass write EVERY byte of the buffer decoded at its own
+                                      offset, d_qoff[i] = the offset pos4 has in d_buf (res.path | FFQ_PATH_IN_PLACE); an
+                                      embedded newline of a wrapped quality comes out as '\n' + qual_add, as the reference's
+                                      slice + arrayadd_b give it (_fastqandfurious.c:129, doc/user-guide.rst:126-141).
+                                      Less room -- or four-line input the single pass cannot vouch for (a quality line longer
+                                      than its read, text in front of the first record), or the first scan of a context that
+                                      only finds out on the way that its input is not four-line -- and the two passes run: the
                                       output is packed (a special case of the same contract).                                */
 #define FFQ_SEG_STRIDE     8704
 #define FFQ_INPLACE_STRIDE 16384
+#define FFQ_PATH_IN_PLACE  8       /* ffq_scan_result.path bit: see there */
 #define FFQ_F_NO_TIMING    32u     /* with FFQ_F_POLL_RESULT: no timing marks around the line-index kernel either (ms_index is
                                       0 for this scan): the front then holds no stream marker at all.  Where the library itself
                                       can prove that the order does not matter it also dispatches the index kernel without a
@@ -119,7 +128,10 @@ typedef struct ffq_scan_result {
     int32_t path;           /* 3 = four-line fast path, 6 = the same with the Phred decode done by
                                the index pass itself (one pass over the input), 0 = general chain
                                kernels, 2 = the same with the dense LDS budget, 5 = list ranking
-                               over the "\n@" matches (long records), 1 = serial walker   */
+                               over the "\n@" matches (long records), 1 = serial walker;
+                               | FFQ_PATH_IN_PLACE (8, on 0 / 2 / 5 / 1): the index pass of that
+                               scan also decoded every byte in place -- records of any layout,
+                               one pass (FFQ_F_SINGLE_PASS)                                */
     int32_t retries;        /* internal re-runs (line-index pool growth)                  */
     int64_t n_lines;        /* newline count seen by the line-index kernel                */
     float   ms_index;       /* device time of the line-index kernel (hipEvent)            */

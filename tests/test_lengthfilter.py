@@ -214,6 +214,7 @@ def test_a_subclassed_filter_is_called_not_pushed_down_python_scanner(pkg):
     # (keeps() sees pos3 - pos2: the sequence slice as the reference cuts it, embedded newlines included)
     assert got == [p if (p is not None and len(p) % 2 == 1) else None for p in plain]
     assert 0 < sum(g is not None for g in got) < sum(p is not None for p in plain)
+    assert _subclass_items(F, F.entrypos, lambda: io.BytesIO(data), yield_dropped=False) == [g for g in got if g is not None]
     assert not F._pushes_down(type("X", (_OddOnly, F.entryfunc_lengthfilter), {})(120)) and F._pushes_down(F.entryfunc_lengthfilter(120))
     assert F._pushes_down(type("Y", (F.entryfunc_lengthfilter,), {"note": 1})(120))      # (a subclass that changes nothing that matters)
 
