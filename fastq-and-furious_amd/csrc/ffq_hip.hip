@@ -1877,6 +1877,12 @@ extern "C" int ffq_table_select_seqlen(ffq_ctx *c, const int64_t *d_table, int64
     return table_select(c, d_table, n_rows, min_len, max_len, d_out, nullptr, n_out);
 }
 
+extern "C" int ffq_table_select_seqlen_idx(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t min_len,
+                                           int64_t max_len, int64_t *d_out, int64_t *d_idx, int64_t *n_out)
+{
+    return table_select(c, d_table, n_rows, min_len, max_len, d_out, d_idx, n_out);
+}
+
 // (d_idx, optional: the ordinal of every kept row -- the stream front end's push-down, ffq_stream_set_filter)
 static int table_select(ffq_ctx *c, const int64_t *d_table, int64_t n_rows, int64_t min_len, int64_t max_len, int64_t *d_out,
                         int64_t *d_idx, int64_t *n_out)

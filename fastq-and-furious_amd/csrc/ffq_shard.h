@@ -448,6 +448,8 @@ struct ffq_shard {
     int stall_stage = FFQ_SHARD_STAGE_NONE;
     double stall_s = 0;
     int *h_stall = nullptr, *hm_stall = nullptr;     // the flag an injected stall waits for (host-mapped)
+    uint8_t *slab = nullptr;               // ffq_shard_scan_fd_slabs: the one device buffer a range that does not fit goes through
+    int64_t slab_cap = 0;
     bool leaked = false;                   // an abort could not drain the streams: destroy frees nothing on the device
     // a failure of THIS rank's own scan inside a step: the peers are told through the words before it is returned
     int local_fail = 0;
@@ -557,7 +559,7 @@ extern "C" void ffq_shard_destroy(ffq_shard *s)
     if (s->ev_w) (void)hipEventDestroy(s->ev_w);
     for (auto e : s->ev_x) if (e) (void)hipEventDestroy(e);
     for (auto e : s->ev_g) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(s->d_words); (void)hipFree(s->d_all); (void)hipFree(s->grown);
+    (void)hipFree(s->d_words); (void)hipFree(s->d_all); (void)hipFree(s->grown); (void)hipFree(s->slab);
     if (s->h_all) (void)hipHostFree(s->h_all);
     if (s->h_own) (void)hipHostFree(s->h_own);
     if (s->h_stall) (void)hipHostFree(s->h_stall);
@@ -1117,6 +1119,217 @@ extern "C" int ffq_shard_load_fd(ffq_shard *s, int fd, uint8_t *d_ext, int64_t *
     if (got != n) return fail(FFQ_E_ARG, "ffq_shard_load_fd: the file ends at byte %lld, the bounds say %lld", (long long)(s->lo - tail + got), (long long)s->total);
     s->fd = fd; s->file_ext = d_ext;
     if (n_bytes) *n_bytes = n;
+    return FFQ_OK;
+}
+
+// ---- a rank's range of a file that does NOT fit its GPU: the same step over SLABS ----------------------------------------
+// What the reference's loop does for any size of stream -- scan the buffer, keep buf[offset:] (the unfinished entry), read
+// more (/root/reference/src/fastqandfurious.py:251-279, the carry at :274-279) -- happens INSIDE the rank: its view
+// [lo - tail, hi + head) goes through ONE device buffer of slab_bytes, slab after slab; slab k + 1 begins at the byte the
+// search of slab k stopped at (the iterator's `offset`: the chain's exit of slab k is the entry of slab k + 1, exactly --
+// no guess between slabs), its rows go behind slab k's in the caller's table, and the bytes are dropped.  At the rank's two
+// EDGES nothing changes: the entry is a guess from the run-in, the eight words are what sh_words_from makes of the rows and
+// of the last slab's end, one gather, sh_decide; a rank whose guess its left neighbour's chain contradicts streams its range
+// again from that neighbour's exit (rare: "tricky" input); a look-ahead that must grow is simply read on (the file is right
+// there).  The scan is ~100 x faster than the load, so the slabs are loaded and scanned in turn, not overlapped.
+// No decode here: the qualities of a range that does not fit would not fit either.
+static int slab_pass(ffq_shard *s, int fd, int64_t slab_bytes, uint32_t flags, int64_t *d_table, int64_t table_cap,
+                     int64_t start, int64_t *head_io, ffq_scan_result *last, int64_t *n_rows_out, int64_t *n_slabs, int64_t *n_loaded)
+{
+    ffq_ctx *c = s->c;
+    const int64_t origin = s->origin, total = s->total, lo = s->lo, hi = s->hi;
+    int64_t tail, head0;
+    sh_halo_sizes(s->B, s->rank, s->tail_bytes, s->head_bytes, &tail, &head0);
+    int64_t head = std::max(*head_io, head0);
+    const int64_t vstart = lo - tail;
+    // P: the stream offset the next search starts at (the iterator's sentinel sits at origin - 1)
+    int64_t P = start < 0 ? vstart - (vstart == origin ? 1 : 0) : std::max(start, vstart);
+    int64_t nrows = 0;
+    memset(last, 0, sizeof *last);
+    last->end_state = FFQ_END_REFILL; last->last_status = FFQ_POS_HEAD_BEG;
+    for (int i = 0; i < 6; i++) last->last_pos[i] = -1;
+    for (;;) {
+        const int64_t E = hi + head;                                   // the view's end for now
+        // the buffer begins at the byte the search starts at; one that begins the stream has the sentinel in front
+        const int64_t bstart = std::max(origin, P);
+        const int sent = bstart == origin ? 1 : 0;
+        const int64_t want = std::min(slab_bytes, E - bstart);
+        if (want <= 0) break;
+        int64_t got = 0;
+        int rc = stage_fd2d(c, s->slab, fd, bstart, want, &got);
+        if (rc) return rc;
+        if (got != want) return fail(FFQ_E_ARG, "ffq_shard: the file ends at byte %lld, its bounds say %lld", (long long)(bstart + got), (long long)total);
+        *n_loaded += got; (*n_slabs)++;
+        const int64_t bend = bstart + got;
+        const int64_t offset = P - bstart + sent;
+        ffq_scan_result r;
+        rc = ffq_scan_device(c, s->slab, got, sent, offset, bend == total ? 1 : 0, bstart - sent, flags & ~(uint32_t)(FFQ_F_DECODE_QUAL | FFQ_F_SINGLE_PASS),
+                             0, d_table + nrows * 6, std::max<int64_t>(table_cap - nrows, 0), nullptr, 0, nullptr, &r);
+        if (rc == FFQ_E_TABLE_FULL) {
+            // the rows the whole view will need, from the rows per byte so far
+            nrows += r.n_records;
+            *n_rows_out = (int64_t)((double)nrows * ((double)(E - vstart) / (double)std::max<int64_t>(bend - vstart, 1)) * 1.05) + 1024;
+            *last = r;
+            return FFQ_E_TABLE_FULL;
+        }
+        if (rc) return rc;
+        nrows += r.n_records;
+        *last = r;
+        last->end_offset = (bstart + r.end_offset - sent);             // (as a STREAM offset: the byte the next search starts at)
+        if (r.end_state != FFQ_END_REFILL) break;                      // the stream's end, or its error
+        const int64_t Pn = bstart + r.end_offset - sent;
+        if (bend >= E) {
+            // the view is through.  Does the chain know its exit?  (the first record start at / behind hi: a row, or the entry
+            // the search stopped at)  If not, the record that straddles the edge is longer than the look-ahead: read on.
+            const bool inc = r.last_status != FFQ_POS_HEAD_BEG && r.last_pos[0] >= 0;
+            int64_t last_p0 = -1;
+            if (nrows > 0 && nrows <= table_cap) {
+                HIPCHK(hipMemcpyAsync(c->h_word, d_table + (nrows - 1) * 6, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                last_p0 = c->h_word[0];
+            }
+            if (hi >= total || last_p0 >= hi || (inc && r.last_pos[0] >= hi) || E >= total) break;
+            ShView v = sh_make_view(lo, hi, total, origin, tail, head);
+            head = sh_more_head(v, s->head_bytes);
+            P = Pn;
+            continue;
+        }
+        if (Pn <= P && got >= slab_bytes) {
+            // no record ended inside a whole slab: one record is longer than the slab -- a larger one
+            const int64_t cap = 2 * slab_bytes;
+            uint8_t *g = nullptr;
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (hipMalloc((void **)&g, (size_t)cap + 64) != hipSuccess) return fail(FFQ_E_NOMEM, "ffq_shard: a record longer than the slab (%lld bytes) and no memory for a larger one", (long long)slab_bytes);
+            (void)hipFree(s->slab);
+            s->slab = g; s->slab_cap = cap; slab_bytes = cap;
+        }
+        P = Pn;
+    }
+    *head_io = head;
+    *n_rows_out = nrows;
+    return FFQ_OK;
+}
+
+extern "C" int ffq_shard_scan_fd_slabs(ffq_shard *s, int fd, int64_t slab_bytes, uint32_t flags, int64_t *d_table, int64_t table_cap,
+                                       ffq_shard_result *out)
+{
+    if (!s || !out || fd < 0 || (table_cap > 0 && !d_table)) return fail(FFQ_E_ARG, "ffq_shard_scan_fd_slabs: bad argument");
+    if (s->pending) return fail(FFQ_E_ARG, "ffq_shard_scan_fd_slabs: a step is pending on this shard");
+    if (s->tr->poisoned) return fail(FFQ_E_ARG, "ffq_shard_scan_fd_slabs: this shard's last step did not come back (watchdog)");
+    if (flags & FFQ_F_DECODE_QUAL) return fail(FFQ_E_ARG, "ffq_shard_scan_fd_slabs: no decode over slabs (the qualities of a range that does not fit would not fit either)");
+    ffq_ctx *c = s->c;
+    HIPCHK(hipSetDevice(c->device));
+    memset(out, 0, sizeof *out);
+    slab_bytes = std::max<int64_t>((slab_bytes + 15) & ~(int64_t)15, 1 << 16);
+    if (s->slab_cap < slab_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(s->slab); s->slab = nullptr; s->slab_cap = 0;
+        if (hipMalloc((void **)&s->slab, (size_t)slab_bytes + 64) != hipSuccess) return fail(FFQ_E_NOMEM, "ffq_shard: no memory for a slab of %lld bytes", (long long)slab_bytes);
+        s->slab_cap = slab_bytes;
+    }
+    int rc = scan_reserve(c, s->slab_cap, flags, table_cap, 0);
+    if (rc) return rc;
+    const int W = s->world, rank = s->rank;
+    const std::vector<int64_t> &B = s->B;
+    int64_t tail, head;
+    sh_halo_sizes(B, rank, s->tail_bytes, s->head_bytes, &tail, &head);
+    out->nranks = s->tr->nranks(s->tr->serial ? 0 : 1);
+    out->serial = s->tr->serial ? 1 : 0;
+    s->handoff_bytes = 0; s->handoff_timed = false; s->local_fail = 0; s->last_stage = FFQ_SHARD_STAGE_NONE;
+    s->flags = flags; s->d_table = d_table; s->table_cap = table_cap; s->ext = nullptr; s->from_file = true;
+    int64_t n_slabs = 0, n_loaded = 0, nrows = 0, start = -1;
+    int64_t *h = s->h_own;
+    int64_t i0 = 0, i1 = 0;
+    // one streaming pass of my view from `start` (< 0: the view's beginning, a guess) and its eight words
+    auto pass = [&](int64_t st) -> int {
+        start = st;
+        i0 = i1 = 0; nrows = 0;
+        s->v = sh_view(s, tail, head);
+        if (s->v.n_bytes == 0) { sh_words_empty(s->v, s->head_bytes, h); h[8] = h[9] = h[10] = 0; return FFQ_OK; }
+        ffq_scan_result last;
+        int r = slab_pass(s, fd, s->slab_cap, flags, d_table, table_cap, st, &head, &last, &nrows, &n_slabs, &n_loaded);
+        out->scan = last;
+        if (r == FFQ_E_TABLE_FULL) {
+            const int64_t tf[SH_WORDS] = {SH_UNKNOWN, SH_UNKNOWN, 0, 0, head, SH_ERR_TABLE_FULL, nrows, 0};
+            memcpy(h, tf, sizeof tf); h[8] = h[9] = h[10] = 0;
+            return FFQ_OK;
+        }
+        if (r) { s->local_fail = r; s->local_msg = ffq_last_error(); sh_words_failed(s->v, h); h[8] = h[9] = h[10] = 0; return FFQ_OK; }
+        s->v = sh_view(s, tail, head);                                 // (the look-ahead the pass ended with)
+        int64_t cut[6];
+        if ((r = ffq_table_cut(c, d_table, nrows, sh_lo_bound(s->v), sh_hi_bound(s->v), cut))) return r;
+        ShScanFacts f;
+        f.n = nrows; f.i0 = cut[0]; f.i1 = cut[1]; f.p_i0 = cut[2]; f.p_i1 = cut[3]; f.q1 = cut[5];
+        f.end_state = last.end_state; f.last_status = last.last_status; f.last_pos0 = last.last_pos[0];
+        f.end_offset = last.end_offset - s->v.add;                     // (sh_words_from adds v.add back: stream offsets)
+        // (the pass reads its own look-ahead: a view that ends short of the stream ends in a refill, one that ends it in OK)
+        if (!s->v.eof && f.end_state == FFQ_END_OK) f.end_state = FFQ_END_REFILL;
+        const int64_t off0 = st < 0 ? 0 : std::max(st, s->v.start) - s->v.add;
+        sh_words_from(s->v, f, off0, s->head_bytes, h);
+        h[3] = 0;                                                      // (a look-ahead that had to grow was read on, above)
+        i0 = cut[0]; i1 = cut[1];
+        h[8] = i0; h[9] = i1; h[10] = nrows;
+        return FFQ_OK;
+    };
+    if ((rc = pass(-1))) return rc;
+    if ((rc = shard_gather_host_words(s))) return rc;
+    int rounds = 0;
+    float ms = 0;
+    for (;;) {
+        rc = shard_wait_mark(s, s->ev_g[1]);
+        if (!rc) rc = s->tr->gather_finish(s->h_all, s->ev_g[1]);
+        if (rc) { if (rc == FFQ_E_TIMEOUT) { s->tr->poisoned = true; if (!s->last_stage) s->last_stage = FFQ_SHARD_STAGE_GATHER; } return rc; }
+        if (hipEventElapsedTime(&ms, s->ev_g[0], s->ev_g[1]) == hipSuccess) out->allgather_ms += ms;
+        const int64_t *A = s->h_all;
+        const ShRound d = sh_decide(A, W, rank, B, s->v);
+        if (sh_debug()) {
+            std::string line;
+            char buf[256];
+            for (int r = 0; r < W; r++) {
+                snprintf(buf, sizeof buf, " [%d: exit %lld first %lld n %lld err %lld/%lld search %lld]", r, (long long)A[r * SH_WORDS], (long long)A[r * SH_WORDS + 1],
+                         (long long)A[r * SH_WORDS + 2], (long long)A[r * SH_WORDS + 5], (long long)A[r * SH_WORDS + 6], (long long)A[r * SH_WORDS + 7]);
+                line += buf;
+            }
+            fprintf(stderr, "[ffq shard %d/%d slabs] round %d kind %d slabs %lld rows %lld..%lld of %lld:%s\n", rank, W, rounds, (int)d.kind, (long long)n_slabs,
+                    (long long)h[8], (long long)h[9], (long long)h[10], line.c_str());
+        }
+        if (d.kind == ShRound::TABLE_FULL) {
+            out->scan.n_records = d.need;
+            return fail(FFQ_E_TABLE_FULL, "rank %d: offset table too small (%lld records in its view)", d.who, (long long)d.need);
+        }
+        if (d.kind == ShRound::INTERNAL || d.kind == ShRound::QUAL_FULL || d.kind == ShRound::NOT_READY) {
+            if (s->local_fail) return fail(s->local_fail, "%s", s->local_msg.c_str());
+            return fail(FFQ_E_INTERNAL, "sharded scan: rank %d %s", d.who, d.what);
+        }
+        if (s->local_fail) return fail(s->local_fail, "%s", s->local_msg.c_str());
+        if (d.kind == ShRound::STREAM_ERROR) { out->err_state = d.err_state; out->err_byte = d.err_byte; break; }
+        if (d.kind == ShRound::SETTLED) break;
+        if (++rounds > sh_max_rounds(W)) return fail(FFQ_E_INTERNAL, "sharded scan does not settle (%d rounds)", rounds);
+        if (d.i_force) {
+            if (d.passed_over) {
+                sh_words_passed_over(s->v, d.prev_exit, d.prev_search, h);
+                h[8] = h[9] = h[10] = 0;
+                i0 = i1 = 0; nrows = 0;
+                start = d.prev_search;
+            } else if ((rc = pass(d.prev_search))) return rc;           // my range again, from the left neighbour's exit
+        }
+        if ((rc = shard_gather_host_words(s))) return rc;               // (mine stand, or are new: the others' rounds need them)
+    }
+    out->n_rows = h[10]; out->row_lo = h[8]; out->row_hi = h[9];
+    out->exit_pos = h[0]; out->first_pos = h[1];
+    out->n_own_records = h[9] - h[8];
+    int64_t base = 0, tot = 0;
+    for (int r = 0; r < W; r++) {
+        const int64_t cnt = s->h_all[(size_t)r * SH_WORDS + 2];
+        if (r < rank) base += cnt;
+        tot += cnt;
+    }
+    out->record_base = base; out->total_records = tot;
+    out->rounds = rounds;
+    out->halo_source = 1;
+    out->handoff_bytes = 0;
+    out->n_slabs = n_slabs; out->bytes_read = n_loaded;
+    out->d_ext = nullptr; out->tail = tail; out->head = head;
     return FFQ_OK;
 }
 

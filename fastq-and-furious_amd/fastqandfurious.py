@@ -512,6 +512,56 @@ class RangeEntries:
         self._gen.close()
         self._sh.close()         # (a generator that never started has no `finally` to run)
 
+    def _filtered(self, view, mm):
+        """entryfunc_lengthfilter over this rank's records with the filter ON THE DEVICE (FileShard.select): one item per
+        record -- None for a dropped one, the filter's component for a kept one (/root/reference/doc/user-guide.rst:153-180) --
+        or, yield_dropped=False, the kept records' items alone.  Only the kept rows (and, from a resident range, their
+        gathered component) cross the link; a dropped record costs the host one pointer in a list."""
+        import numpy as np
+        sh, flt, nat = self._sh, self._entryfunc, _entries.native()
+        k, idx = sh.select(flt.min_len, flt.max_len)
+        step = self._batch
+        for i0 in range(0, self.n_records, step):                       # windows of ORIGINAL records
+            i1 = min(i0 + step, self.n_records)
+            ka, kb = int(np.searchsorted(idx, i0)), int(np.searchsorted(idx, i1))
+            n_items = i1 - i0
+            if kb == ka:
+                if flt.yield_dropped:
+                    yield from [None] * n_items
+                continue
+            rows = sh.kept_rows(ka, kb)
+            local = np.ascontiguousarray(idx[ka:kb] - i0)
+            if not flt.yield_dropped:
+                n_items, local = kb - ka, _np_arange(kb - ka)
+            a, b = int(rows[0, 0]), int(rows[-1, 5]) + 1
+            if flt.column == "entry":
+                if nat is not None and hasattr(nat, "sparse_entries"):
+                    yield from nat.sparse_entries(n_items, memoryview(local).cast('B'), view[a:b], memoryview(rows).cast('B'), a)
+                else:
+                    out, buf = [None] * n_items, mm[a:b]
+                    for j, (p0, p1, p2, p3, p4, p5) in zip(local.tolist(), (rows - a).tolist()):
+                        out[j] = (buf[p0 + 1:p1], buf[p2:p3], buf[p4:p5])
+                    yield from out
+                continue
+            got = sh.kept_column(ka, kb, flt.column, rows)
+            if got is None:
+                # the range is not resident (slabs; a view that grew): the kept rows' slices out of the file, in one numpy gather
+                ca, shf, cb = {"header": (0, 1, 1), "sequence": (2, 0, 3), "quality": (4, 0, 5)}[flt.column]
+                beg, lens = rows[:, ca] + shf - a, np.maximum(rows[:, cb] - rows[:, ca] - shf, 0)
+                off = np.zeros(kb - ka + 1, dtype=np.int64)
+                np.cumsum(lens, out=off[1:])
+                src = np.repeat(beg - off[:-1], lens) + np.arange(int(off[-1]), dtype=np.int64)
+                col = np.frombuffer(view[a:b], dtype=np.uint8)[src]
+            else:
+                col, off = got
+            if nat is not None and hasattr(nat, "sparse"):
+                yield from nat.sparse(n_items, memoryview(local).cast('B'), col, memoryview(off).cast('B'))
+            else:
+                out, cb_, offs = [None] * n_items, col.tobytes(), off.tolist()
+                for j, kk in zip(local.tolist(), range(kb - ka)):
+                    out[j] = cb_[offs[kk]:offs[kk + 1]]
+                yield from out
+
     def _entries(self):
         import mmap
         sh, entryfunc = self._sh, self._entryfunc
@@ -520,6 +570,10 @@ class RangeEntries:
             if self.n_records:
                 mm = mmap.mmap(sh.fd, 0, access=mmap.ACCESS_READ)       # (the page cache holds the range: it was just read)
                 view = memoryview(mm)
+            if self.n_records and _pushes_down(entryfunc):
+                yield from self._filtered(view, mm)
+                return
+            drop_none = isinstance(entryfunc, entryfunc_lengthfilter) and not entryfunc.yield_dropped      # (a filter that is not pushed down)
             for i0 in range(0, self.n_records, self._batch):
                 i1 = min(i0 + self._batch, self.n_records)
                 rows = sh.rows(i0, i1)
@@ -537,7 +591,9 @@ class RangeEntries:
                     rel = array('q')
                     rel.frombytes((rows - a).tobytes())
                     for i in range(0, len(rel), 6):
-                        yield entryfunc(buf, rel[i:i + 6], a)
+                        e = entryfunc(buf, rel[i:i + 6], a)
+                        if e is not None or not drop_none:
+                            yield e
         finally:
             if mm is not None:
                 try:
@@ -551,15 +607,17 @@ class RangeEntries:
 def readfastq_iter_range(path, rank: int, world: int, entryfunc: typing.Callable = entryfunc, comm=None, ctx=None,
                          start: int = 0, end: typing.Optional[int] = None, batch_rows: int = 1 << 15,
                          tail_bytes: typing.Optional[int] = None, head_bytes: typing.Optional[int] = None,
-                         bounds: typing.Optional[typing.Sequence[int]] = None) -> RangeEntries:
+                         bounds: typing.Optional[typing.Sequence[int]] = None,
+                         slab_bytes: typing.Optional[int] = None) -> RangeEntries:
     """readfastq_iter for ONE FILE read by `world` ranks (one process per GPU): rank `rank` gets the entries whose '@'
     lies in its byte range [S_rank, S_rank+1) of the file, the same objects in the same order the reference's
     iterator (:198-279) yields for them -- the ranks' iterators concatenated ARE readfastq_iter over the whole file.
 
     Collective: every rank calls it (and reaches its first entry only when all have: the ranges are proven against
     each other in one step, ffq_shard_step_*).  Each rank reads its own range of the file (plus 1 MiB either side)
-    into its GPU's memory -- nothing is handed from rank to rank but eight words each --, so the range must fit
-    there (a 100 GiB file over 8 GPUs: 12.5 GiB each).  Errors of the stream (the iterator's three ValueErrors,
+    into its GPU's memory -- nothing is handed from rank to rank but eight words each -- (a 100 GiB file over 8 GPUs:
+    12.5 GiB each); a range that does not fit there -- or slab_bytes= / FFQ_SHARD_SLAB_BYTES -- goes through one device
+    buffer slab after slab (sharded.FileShard), the entries are the same.  Errors of the stream (the iterator's three ValueErrors,
     :262, :269, :272) are raised on every rank alike, before any entry is yielded.
 
     comm: None (world 1; or torch.distributed's default group hands the communicator id round), 128 bytes of
@@ -573,10 +631,12 @@ def readfastq_iter_range(path, rank: int, world: int, entryfunc: typing.Callable
         kw["tail_bytes"] = tail_bytes
     if head_bytes is not None:
         kw["head_bytes"] = head_bytes
+    if slab_bytes:
+        kw["slab_bytes"] = slab_bytes
     sh = _sharded.FileShard(ctx, path, rank, world, comm=comm, start=start, end=end, bounds=bounds, **kw)
     try:
         sh.load()
-        sh.scan(decode=entryfunc is entryfunc_phred)
+        sh.scan(decode=entryfunc is entryfunc_phred and not sh.slab_bytes)      # (over slabs the decode is the host's, per record)
     except BaseException:
         sh.close()
         raise

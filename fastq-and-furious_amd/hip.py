@@ -61,7 +61,7 @@ SYMBOLS = (
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest", "ffq_shard_load_fd", "ffq_load_fd",
     "ffq_shard_host_step", "ffq_shard_host_free", "ffq_stream_set_filter", "ffq_stream_selected",
     "ffq_shard_create_hosted",
-    "ffq_shard_create2", "ffq_shard_get_info", "ffq_shard_set_timeout", "ffq_shard_set_serial", "ffq_shard_abort", "ffq_shard_inject_stall",
+    "ffq_shard_create2", "ffq_shard_scan_fd_slabs", "ffq_table_select_seqlen_idx", "ffq_shard_get_info", "ffq_shard_set_timeout", "ffq_shard_set_serial", "ffq_shard_abort", "ffq_shard_inject_stall",
 )
 
 
@@ -96,6 +96,7 @@ class ShardResult(ctypes.Structure):
         ("handoff_ms", ctypes.c_float), ("allgather_ms", ctypes.c_float),
         ("d_ext", ctypes.c_void_p), ("tail", ctypes.c_int64), ("head", ctypes.c_int64),
         ("nranks", ctypes.c_int32), ("serial", ctypes.c_int32),
+        ("n_slabs", ctypes.c_int64), ("bytes_read", ctypes.c_int64),
     ]
 
 
@@ -289,6 +290,7 @@ def lib():
         L.ffq_arrayadd_q.argtypes = [vp, vp, i64, i64]
         L.ffq_table_lower_bound.argtypes = [vp, vp, i64, i32, i64, P(i64)]
         L.ffq_table_select_seqlen.argtypes = [vp, vp, i64, i64, i64, vp, P(i64)]
+        L.ffq_table_select_seqlen_idx.argtypes = [vp, vp, i64, i64, i64, vp, vp, P(i64)]
         L.ffq_table_cut.argtypes = [vp, vp, i64, i64, i64, P(i64)]
         L.ffq_table_gather_column.argtypes = [vp, vp, i64, i32, i64, vp, i64, i32, i32, i32, i32, vp, i64, vp, P(i64)]
         L.ffq_stream_open.argtypes = [vp, i32, i64, P(vp)]
@@ -334,6 +336,7 @@ def lib():
         L.ffq_shard_abort.argtypes = [vp]
         L.ffq_shard_inject_stall.argtypes = [vp, i32, ctypes.c_double]
         L.ffq_shard_load_fd.argtypes = [vp, i32, vp, P(i64)]
+        L.ffq_shard_scan_fd_slabs.argtypes = [vp, i32, i64, u32, vp, i64, P(ShardResult)]
         L.ffq_load_fd.argtypes = [vp, i32, i64, i64, vp, P(i64)]
         L.ffq_shard_host_step.argtypes = [P(ShardHostOps), vp, i32, i32, P(i64), i64, i64, vp, vp, i64, P(ShardResult)]
         L.ffq_shard_create_hosted.argtypes = [vp, P(ShardHostOps), i32, i32, P(i64), i64, i64, P(vp)]
@@ -597,6 +600,13 @@ class Context:
                                             int(max_len), ctypes.c_void_p(d_out), ctypes.byref(k)))
         return k.value
 
+    def table_select_seqlen_idx(self, d_table, n_rows, min_len, max_len, d_out, d_idx):
+        """... and d_idx[i] = the ordinal in the table of kept row i (ffq_table_select_seqlen_idx)."""
+        k = ctypes.c_int64(0)
+        check(lib().ffq_table_select_seqlen_idx(self.handle, ctypes.c_void_p(d_table), int(n_rows), int(min_len), int(max_len),
+                                                ctypes.c_void_p(d_out), ctypes.c_void_p(d_idx), ctypes.byref(k)))
+        return k.value
+
     COLUMNS = {"header": (0, 1, 1), "sequence": (2, 0, 3), "quality": (4, 0, 5)}
 
     def table_gather_column(self, d_buf, n_bytes, d_table, n_rows, which, d_out, out_cap, d_off, sentinel=True,
@@ -806,6 +816,16 @@ class Shard:
         n = ctypes.c_int64()
         check(lib().ffq_shard_load_fd(self._h, int(fd), ctypes.c_void_p(d_ext), ctypes.byref(n)))
         return n.value
+
+    def scan_fd_slabs(self, fd, slab_bytes, d_table, table_cap, flags=0):
+        """This rank's range of the file behind fd through ONE device buffer of slab_bytes, slab after slab
+        (ffq_shard_scan_fd_slabs: a range that does not fit the GPU); collective like a step.  (rc, ShardResult)."""
+        res = ShardResult()
+        rc = lib().ffq_shard_scan_fd_slabs(self._h, int(fd), int(slab_bytes), int(flags), ctypes.c_void_p(d_table), int(table_cap), ctypes.byref(res))
+        if self._err:
+            raise self._err.pop(0)
+        check(rc, allow=(E_TABLE_FULL,))
+        return rc, res
 
     def step_submit(self, d_ext, d_table, table_cap, flags=0, qual_add=-33, d_qual=None, qual_cap=0, d_qoff=None, overlap=False):
         rc = lib().ffq_shard_step_submit(self._h, ctypes.c_void_p(d_ext), 1 if overlap else 0, int(flags), int(qual_add),

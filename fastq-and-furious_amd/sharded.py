@@ -385,10 +385,17 @@ class FileShard:
     serial: the serial step from the start (sharded.NativeShardScanner); group: the torch.distributed group the communicator
     id travels over (default: the world's).  A step that does not come back raises hip.FFQTimeout on every rank (the
     watchdog, include/ffq.h); where the ranks found each other through torch.distributed, scan() takes the serial step ONCE
-    on a new communicator before it gives up (self.recovered says so)."""
+    on a new communicator before it gives up (self.recovered says so).
+
+    slab_bytes: a range that does NOT fit the GPU (a 2 TB file over eight of them) goes through ONE device buffer of that many
+    bytes, slab after slab (ffq_shard_scan_fd_slabs: the reference's own buf[offset:] + read-more loop inside the rank,
+    /root/reference/src/fastqandfurious.py:274-279; the rank's edges are proven as ever) -- given, or FFQ_SHARD_SLAB_BYTES, or
+    taken (1 GiB) when the device has no room for the range; every rank decides for itself.  Rows, ordinals and the iterator
+    are the same; only the decode is not offered over slabs (scan(decode=True) raises: entryfunc_phred then decodes on the
+    host, record by record)."""
 
     def __init__(self, ctx, path, rank=0, world=1, comm=None, start=0, end=None, tail_bytes=TAIL_BYTES,
-                 head_bytes=HEAD_BYTES, device=None, bounds=None, qual_room=None, serial=None, group=None):
+                 head_bytes=HEAD_BYTES, device=None, bounds=None, qual_room=None, serial=None, group=None, slab_bytes=None):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         # scan(decode=True): bytes of the quality buffer per 16 KiB tile of the view -- hip.SEG_STRIDE (reads of a few hundred
         # bases in one pass) unless given; hip.INPLACE_STRIDE lets four-line reads of any length decode in one pass as well
@@ -431,7 +438,16 @@ class FileShard:
                                  serial=serial)
         self.tail, self.head = self.sh.halo()
         self.n_view = self.tail + (self.hi - self.lo) + self.head
-        self.d_ext = ctx.dev_alloc(self.n_view + 64)
+        env = os.environ.get("FFQ_SHARD_SLAB_BYTES")
+        self.slab_bytes = int(slab_bytes) if slab_bytes else (int(env) if env else 0)
+        self.d_ext = None
+        if not self.slab_bytes:
+            try:
+                self.d_ext = ctx.dev_alloc(self.n_view + 64)
+            except _hip.FFQError as e:
+                if e.code != _hip.E_NOMEM:
+                    raise
+                self.slab_bytes = 1 << 30             # (no room for the range: it goes through a slab)
         self.view_start = self.lo - self.tail                     # file offset of d_ext[0]
         self.d_table = self.d_qual = self.d_qoff = None
         self.table_cap = self.qual_cap = 0
@@ -439,7 +455,10 @@ class FileShard:
         self.out = None
 
     def load(self):
-        """This rank's bytes from the file into HBM; returns the bytes loaded."""
+        """This rank's bytes from the file into HBM; returns the bytes loaded (over slabs: 0 -- scan() reads them as it goes)."""
+        if self.slab_bytes:
+            self.loaded = True
+            return 0
         n = self.sh.load_fd(self.fd, self.d_ext)
         self.loaded = True
         return n
@@ -469,17 +488,22 @@ class FileShard:
         on ANY rank is grown on every rank and the step repeated.  Stream errors are raised on every rank alike."""
         if not self.loaded:
             self.load()
+        if decode and self.slab_bytes:
+            raise ValueError("FileShard: no decode over slabs (the qualities of a range that does not fit the GPU would not fit either)")
         if decode:
             flags |= _hip.F_DECODE_QUAL | _hip.F_SINGLE_PASS
         rows = int(rows_hint) if rows_hint else self.n_view // 160 + 1024
         qneed = 0
         while True:
             self._alloc(rows, decode, qneed)
-            self.ctx.reserve(self.n_view + 64)
+            self.ctx.reserve(min(self.n_view, self.slab_bytes or self.n_view) + 64)
             try:
-                self.sh.step_submit(self.d_ext, self.d_table, self.table_cap, flags=flags, d_qual=self.d_qual if decode else None,
-                                    qual_cap=self.qual_cap if decode else 0, d_qoff=self.d_qoff if decode else None)
-                rc, res = self.sh.step_wait()
+                if self.slab_bytes:
+                    rc, res = self.sh.scan_fd_slabs(self.fd, self.slab_bytes, self.d_table, self.table_cap, flags=flags)
+                else:
+                    self.sh.step_submit(self.d_ext, self.d_table, self.table_cap, flags=flags, d_qual=self.d_qual if decode else None,
+                                        qual_cap=self.qual_cap if decode else 0, d_qoff=self.d_qoff if decode else None)
+                    rc, res = self.sh.step_wait()
             except _hip.FFQTimeout as e:
                 if self._dist is None or self.recovered:
                     raise
@@ -541,12 +565,71 @@ class FileShard:
         qoff[n] = q1 - q0
         return qual, qoff
 
+    # ---- the length filter of the reference's user guide, on the device, over THIS RANK's rows --------------------------
+    def select(self, min_len=None, max_len=None):
+        """Rows of this rank whose sequence length pos3 - pos2 lies in [min_len, max_len] (None: open), selected on the
+        DEVICE (ffq_table_select_seqlen_idx): returns (k, index int64[k]) -- index[i] = the ordinal, among this rank's
+        records, of kept row i; the kept rows themselves stay on the device until kept_rows() asks for a batch.  What
+        /root/reference/doc/user-guide.rst:153-180 evaluates per record in an entryfunc, for the whole range at once: a
+        dropped record never reaches the host."""
+        res, c = self.out, self.ctx
+        n_own = int(res.row_hi - res.row_lo)
+        for name in ("d_sel", "d_idx"):
+            p = getattr(self, name, None)
+            if p:
+                c.dev_free(p)
+                setattr(self, name, None)
+        self.n_kept = 0
+        if n_own == 0:
+            return 0, np.zeros(0, dtype=np.int64)
+        self.d_sel, self.d_idx = c.dev_alloc(n_own * 48), c.dev_alloc(n_own * 8)
+        lo = 0 if min_len is None else int(min_len)
+        hi = (1 << 62) if max_len is None else int(max_len)
+        k = c.table_select_seqlen_idx(self.d_table + int(res.row_lo) * 48, n_own, lo, hi, self.d_sel, self.d_idx)
+        self.n_kept = k
+        idx = np.empty(k, dtype=np.int64)
+        if k:
+            c.d2h(idx, self.d_idx)
+        return k, idx
+
+    def kept_rows(self, k0, k1):
+        """Kept rows [k0, k1) of the last select() as int64[n][6], absolute file offsets."""
+        out = np.empty((max(k1 - k0, 0), 6), dtype=np.int64)
+        if out.size:
+            self.ctx.d2h(out, self.d_sel + k0 * 48)
+        return out
+
+    def kept_column(self, k0, k1, column, rows):
+        """(bytes uint8[], offsets int64[n + 1]) of component `column` ("header" as entryfunc cuts it, "sequence", "quality") of
+        kept rows [k0, k1) -- gathered on the DEVICE from the resident range (ffq_table_gather_column); None when the range is
+        not resident (slabs): the caller cuts the kept rows' slices out of the file."""
+        if not self.d_ext or k1 <= k0 or (int(self.out.d_ext or 0) and int(self.out.d_ext) != self.d_ext):
+            return None                          # (slabs; or a view that grew lives in the shard's own buffer: cut from the file instead)
+        c, n = self.ctx, k1 - k0
+        ca, sh, cb = c.COLUMNS[column]
+        need = int((rows[:, cb] - rows[:, ca] - sh).clip(min=0).sum())
+        d_col, d_off = c.dev_alloc(need + 64), c.dev_alloc((n + 1) * 8)
+        try:
+            sentinel = self.view_start == self.bounds[0]
+            rc, nb = c.table_gather_column(self.d_ext, self.n_view, self.d_sel + k0 * 48, n, column, d_col, need + 64, d_off,
+                                           sentinel=sentinel, add=self.view_start - (1 if sentinel else 0))
+            if rc != _hip.OK:
+                return None
+            col, off = np.empty(nb, dtype=np.uint8), np.empty(n + 1, dtype=np.int64)
+            if nb:
+                c.d2h(col, d_col)
+            c.d2h(off, d_off)
+            return col, off
+        finally:
+            c.dev_free(d_col)
+            c.dev_free(d_off)
+
     def close(self):
         if getattr(self, "sh", None) is not None:
             self.sh.close()
             self.sh = None
         c = self.ctx
-        for name in ("d_ext", "d_table", "d_qual", "d_qoff"):
+        for name in ("d_ext", "d_table", "d_qual", "d_qoff", "d_sel", "d_idx"):
             p = getattr(self, name, None)
             if p:
                 c.dev_free(p)

@@ -258,6 +258,11 @@ int ffq_table_cut(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t 
  * per-record object exists: filtering reads is deleting rows (:199-204).    */
 int ffq_table_select_seqlen(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t min_len,
                             int64_t max_len, int64_t *d_out, int64_t *n_out);
+/* ... with d_idx[i] = the ordinal in d_table of kept row i (n_rows entries of room; NULL: none): what a host
+ * that owes one item per ORIGINAL row -- the guide's loop sees None for a dropped record (:166-170) -- puts the
+ * kept ones back by.                                                                                       */
+int ffq_table_select_seqlen_idx(ffq_ctx *ctx, const int64_t *d_table, int64_t n_rows, int64_t min_len,
+                                int64_t max_len, int64_t *d_out, int64_t *d_idx, int64_t *n_out);
 
 /* One component of every row of a device offset table as a packed stream + CSR offsets: byte j of
  * row i's component is d_out[d_off[i] + j] = buf[pos[col_begin] + begin_shift + j] + value_add,
@@ -488,6 +493,8 @@ typedef struct ffq_shard_result {
     int64_t tail, head;
     int32_t nranks;            /* ranks of the communicator the words were gathered on (ncclCommCount; == world) */
     int32_t serial;            /* 1: the serial step ran (one communicator, one stream), 0: the pipelined one   */
+    int64_t n_slabs;           /* ffq_shard_scan_fd_slabs: slabs the range went through (re-reads included); else 0 */
+    int64_t bytes_read;        /* ... and the bytes it read from the file                                        */
 } ffq_shard_result;
 /* Who is there: filled at creation (RCCL: ncclCommCount of both communicators and ONE all-gather of every rank's PCI
  * bus id, so that a host can assert "N ranks on N distinct GPUs" before it trusts a number).                     */
@@ -545,6 +552,18 @@ int  ffq_shard_inject_stall(ffq_shard *s, int stage, double seconds);
  * reference's single reader per rank: read() (fastqandfurious.py:30-36), the first fill and its sentinel (:241-245,
  * rank 0's view starts the stream), the carry of an unfinished entry (:274-279, here the look-ahead).           */
 int  ffq_shard_load_fd(ffq_shard *s, int fd, uint8_t *d_ext, int64_t *n_bytes);
+/* ... and a range that does NOT fit the GPU (a 2 TB file over eight of them): the same step with this rank's view going
+ * through ONE device buffer of slab_bytes, slab after slab -- what the reference's loop does for any size of stream: scan
+ * the buffer, keep the unfinished entry, read more (fastqandfurious.py:251-279).  Slab k + 1 begins at the byte the search
+ * of slab k stopped at (the iterator's `offset`: exact, no guess between slabs), its rows go behind slab k's in d_table
+ * (rows [0, n_rows): all of the pass, [row_lo, row_hi) this rank's, absolute file offsets), the bytes are dropped.  At the
+ * rank's two edges nothing changes: the entry guessed from the run-in, eight words, one gather, the same decision; a rank
+ * whose guess its left neighbour's chain contradicts streams its range again from that neighbour's exit; a look-ahead that
+ * must grow is read on; one record longer than the slab doubles the slab.  Collective like a step (every rank calls it, or
+ * ffq_shard_step_* over a loaded range: the words are the same).  No FFQ_F_DECODE_QUAL.  FFQ_E_TABLE_FULL (every rank):
+ * scan.n_records = an estimate of the rows that rank's view needs.  d_ext of the result is NULL: nothing stays resident. */
+int  ffq_shard_scan_fd_slabs(ffq_shard *s, int fd, int64_t slab_bytes, uint32_t flags, int64_t *d_table, int64_t table_cap,
+                             ffq_shard_result *out);
 /* The same step over HOST memory with the transport supplied by the caller (and, for tests, the scan): the protocol
  * functions are the device step's (csrc/ffq_shard_proto.h), driven synchronously.  For hosts whose ranks cannot talk RCCL
  * -- a multi-process CPU test-suite over gloo (scan = the test's own engine), a functional dry run of several ranks on
