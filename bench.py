@@ -261,7 +261,7 @@ def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, b
     (page cache -> PCIe); like the other host-inclusive figures never `value`.  Collective."""
     import tempfile
     import torch
-    from fastqandfurious_amd import fastqandfurious as F, sharded
+    from fastqandfurious_amd import fastqandfurious as F, hip, sharded
     d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     tag = os.environ.get("MASTER_PORT", str(os.getpid())) if world > 1 else str(os.getpid())
     path = os.path.join(d, "ffq_bench_shards_%s.fq" % tag)
@@ -293,9 +293,14 @@ def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, b
         # process group -- an id is good for one ncclCommInitRank round); a dry run of several ranks on ONE GPU: the
         # device step over gloo
         comm = sharded.DistTransport(dist) if (world > 1 and dry_gloo(dist)) else None
+        # ONE FileShard, loaded three times into the buffer it keeps (round 6: a FileShard built and closed around every
+        # load measured the aftermath of the hipFree of the one before -- for ~130 ms after a buffer of this size is freed
+        # every load runs at 40 GB/s instead of 52, profiles/r06_probes/loader_vs_link.txt); the first load (staging slots,
+        # helper threads, new VRAM) is reported apart
         best = None
+        sh = sharded.FileShard(ctx, path, rank, world, comm=comm)
+        loads = []
         for _ in range(3):
-            sh = sharded.FileShard(ctx, path, rank, world, comm=comm)
             t0 = time.perf_counter()
             nb = sh.load()
             t1 = time.perf_counter()
@@ -303,14 +308,32 @@ def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, b
             t2 = time.perf_counter()
             recs, total = int(res.row_hi - res.row_lo), int(res.total_records)
             src, tr = int(res.halo_source), sh.sh.transport()
-            sh.close()
             el = [t1 - t0, t2 - t1]
             if world > 1:                                   # (the slowest rank's load and step)
                 tt = torch.tensor(el, dtype=torch.float64, device="cpu" if dry_gloo(dist) else dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = [float(x) for x in tt.tolist()]
+            loads.append(el[0])
             if best is None or sum(el) < sum(best):
                 best = el
+        sh.close()
+        # what the link gives this box right now: one raw pinned -> device copy of the same size on one stream
+        link = None
+        try:
+            import ctypes
+            L = hip.lib()
+            hp = ctypes.c_void_p()
+            hip.check(L.ffq_pinned_alloc(int(nb), ctypes.byref(hp)))
+            ctypes.memset(hp, 1, int(nb))
+            dd = ctx.dev_alloc(int(nb))
+            for _ in range(2):
+                t0 = time.perf_counter()
+                hip.check(L.ffq_copy_h2d(ctx.handle, ctypes.c_void_p(dd), hp, int(nb), 0))
+                link = nb / (time.perf_counter() - t0) / 1e9
+            ctx.dev_free(dd)
+            L.ffq_pinned_free(hp)
+        except Exception as e:      # noqa: BLE001
+            sys.stderr.write("link probe skipped: %s\n" % (e,))
         best_load, best_step = best
         # the per-rank iterator on top: Python tuples of THIS rank's records (readfastq_iter_range), bounded
         it = F.readfastq_iter_range(path, rank, world, F.entryfunc, comm=comm, ctx=ctx)
@@ -333,10 +356,13 @@ def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, b
     return {"value": round(whole / (best_load + best_step) / 1e9, 3), "unit": "GB/s",
             "m_reads_per_s": round(total / (best_load + best_step) / 1e6, 3),
             "load_gb_s_per_rank": round(nb / best_load / 1e9, 3), "load_ms": round(best_load * 1e3, 3), "step_ms": round(best_step * 1e3, 3),
+            "first_load_gb_s_per_rank": round(nb / loads[0] / 1e9, 3),
+            "link_gb_s": None if link is None else round(link, 2),
+            "load_over_link": None if link is None else round(nb / best_load / 1e9 / link, 3),
             "transport": tr, "halo_source": "file" if src else "ranks", "records_rank0": recs, "total_records": total,
             "iterator_m_reads_per_s_per_rank": round(n_it / el_it / 1e6, 3),
             "sample": "one %d-byte file in %s read by %d rank(s), an even share each (+ 1 MiB either side): ffq_shard_load_fd + one "
-                      "ffq_shard_step per rank, max over ranks, best of 3; iterator: readfastq_iter_range(entryfunc) tuples of "
+                      "ffq_shard_step per rank, max over ranks, best of 3 into the buffer the shard keeps (first_load: the first of them; link_gb_s: one raw pinned copy of the same bytes, this box, right behind); iterator: readfastq_iter_range(entryfunc) tuples of "
                       "rank 0's records, %.1f s" % (whole, d, world, el_it)}
 
 

@@ -68,12 +68,17 @@ def test_streams_through_small_slabs(gpu_ctx, oracle, shm_file, kind, world):
             check(res, want)
             if slab == 1 << 16 and kind in ("single", "wrapped"):
                 assert all(r["n_slabs"] >= r["n_view"] // (1 << 16) for r in res), [r["n_slabs"] for r in res]
-    # the resident step and the slabs agree on the repair rounds too (same words, same decision)
+    # the resident step and the slabs agree on the repair rounds (same words, same decision) -- except that a look-ahead
+    # that must grow costs the resident step a round and the slabs none (the pass reads on)
     from test_fileshard import shard_rows
     a, b = shard_rows(path, world), slab_rows(path, world, 1 << 20)
-    assert [r["rounds"] for r in a] == [r["rounds"] for r in b]
+    assert all(rb["rounds"] <= ra["rounds"] for ra, rb in zip(a, b))
+    if kind in ("single", "wrapped"):
+        assert [r["rounds"] for r in a] == [r["rounds"] for r in b] == [0] * world
+    if kind in ("long", "long-wrapped"):
+        assert any(ra["rounds"] > 0 for ra in a)
     if kind == "tricky":
-        assert any(r["rounds"] > 0 for r in b)
+        assert any(r["rounds"] > 0 for r in b)                        # a contradicted entry: the range streamed again
 
 
 @pytest.mark.parametrize("kind", ("truncated", "cut-header", "invalid"))

@@ -10,7 +10,28 @@ import numpy as np
 import fastqandfurious_amd  # noqa: F401
 from fastqandfurious_amd import hip
 
+import ctypes
 ctx = hip.Context(0)
+L = hip.lib()
+
+
+def link(n=1 << 30, reps=3):
+    """raw pinned -> device copy of n bytes on the context's stream (ffq_copy_h2d): what the link gives THIS box, now"""
+    hp = ctypes.c_void_p()
+    hip.check(L.ffq_pinned_alloc(n, ctypes.byref(hp)))
+    ctypes.memset(hp, 1, n)
+    d = ctx.dev_alloc(n)
+    out = []
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        hip.check(L.ffq_copy_h2d(ctx.handle, ctypes.c_void_p(d), hp, n, 0))
+        out.append(n / (time.perf_counter() - t0) / 1e9)
+    ctx.dev_free(d)
+    L.ffq_pinned_free(hp)
+    return "/".join("%.1f" % x for x in out[1:])
+
+
+print("raw link, pinned -> device, 1 GiB x3 (GB/s), before any kernel of this process:", link(), flush=True)
 path = "/dev/shm/ffq_load_probe.bin"
 blk = np.random.default_rng(1).integers(0, 255, 64 << 20, dtype=np.uint8).tobytes()
 for gib in (0.5, 2, 8):
@@ -34,4 +55,5 @@ for gib in (0.5, 2, 8):
         res.setdefault("touch_ms", []).append(tt); res.setdefault("touched", []).append(load(d)); ctx.dev_free(d)
     os.close(fd)
     print("%.1f GiB:" % gib, "  ".join("%s %s" % (k, "/".join(("%.1f GB/s" % (n / t / 1e9)) if k != "touch_ms" else ("%.1f ms" % (t * 1e3)) for t in v)) for k, v in res.items()), flush=True)
+print("raw link again, after the loads and the touch kernels:", link(), flush=True)
 os.unlink(path)
