@@ -578,8 +578,9 @@ class RangeEntries:
                 i1 = min(i0 + self._batch, self.n_records)
                 rows = sh.rows(i0, i1)
                 a, b = int(rows[0, 0]), int(rows[-1, 5]) + 1
-                if entryfunc is entryfunc_phred and sh.decoded and _entries.native() is not None and hasattr(_entries.native(), "entries_phred"):
-                    qual, qoff = sh.quals(i0, i1, rows)
+                if entryfunc is entryfunc_phred and (sh.decoded or sh.slab_bytes) and _entries.native() is not None and hasattr(_entries.native(), "entries_phred"):
+                    # the qualities from the step's own decode -- or, over slabs (nothing resident), decoded on the device batch by batch
+                    qual, qoff = sh.quals(i0, i1, rows) if sh.decoded else sh.quals_from_file(rows)
                     yield from _entries.native().entries_phred(view[a:b], memoryview(rows).cast('B'), a, qual, memoryview(qoff).cast('B'), array)
                 elif (entryfunc is _ENTRYFUNC or entryfunc is entryfunc_namedtuple) and _entries.native() is not None:
                     for chunk in _default_entries(view[a:b], rows, a, None if entryfunc is _ENTRYFUNC else Entry):
@@ -636,7 +637,7 @@ def readfastq_iter_range(path, rank: int, world: int, entryfunc: typing.Callable
     sh = _sharded.FileShard(ctx, path, rank, world, comm=comm, start=start, end=end, bounds=bounds, **kw)
     try:
         sh.load()
-        sh.scan(decode=entryfunc is entryfunc_phred and not sh.slab_bytes)      # (over slabs the decode is the host's, per record)
+        sh.scan(decode=entryfunc is entryfunc_phred and not sh.slab_bytes)      # (over slabs: decoded batch by batch, FileShard.quals_from_file)
     except BaseException:
         sh.close()
         raise

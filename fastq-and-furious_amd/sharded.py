@@ -391,8 +391,8 @@ class FileShard:
     bytes, slab after slab (ffq_shard_scan_fd_slabs: the reference's own buf[offset:] + read-more loop inside the rank,
     /root/reference/src/fastqandfurious.py:274-279; the rank's edges are proven as ever) -- given, or FFQ_SHARD_SLAB_BYTES, or
     taken (1 GiB) when the device has no room for the range; every rank decides for itself.  Rows, ordinals and the iterator
-    are the same; only the decode is not offered over slabs (scan(decode=True) raises: entryfunc_phred then decodes on the
-    host, record by record)."""
+    are the same; the decode is not part of a scan over slabs (scan(decode=True) raises): the range iterator decodes
+    entryfunc_phred's qualities batch by batch on the device instead (quals_from_file)."""
 
     def __init__(self, ctx, path, rank=0, world=1, comm=None, start=0, end=None, tail_bytes=TAIL_BYTES,
                  head_bytes=HEAD_BYTES, device=None, bounds=None, qual_room=None, serial=None, group=None, slab_bytes=None):
@@ -623,6 +623,32 @@ class FileShard:
         finally:
             c.dev_free(d_col)
             c.dev_free(d_off)
+
+    def quals_from_file(self, rows):
+        """(qual int8[], qoff int64[n + 1]) of the records of `rows` (absolute file offsets, in order) when the range is NOT
+        resident (slabs): the batch's bytes [pos0 of the first, pos5 of the last] are read into a scratch buffer on the device
+        again and the Phred decode is the column gather with value_add = -33 there (ffq_table_gather_column; doc/user-guide.rst
+        :206-214) -- the decode stays the GPU's, at the price of a second trip of those bytes over the link."""
+        c, n = self.ctx, int(rows.shape[0])
+        if n == 0:
+            return np.zeros(0, np.int8), np.zeros(1, np.int64)
+        a, b = int(rows[0, 0]), int(rows[-1, 5]) + 1
+        need = int((rows[:, 5] - rows[:, 4]).sum())
+        d_buf, d_rows = c.dev_alloc(b - a + 64), c.dev_alloc(n * 48)
+        d_col, d_off = c.dev_alloc(need + 64), c.dev_alloc((n + 1) * 8)
+        try:
+            assert c.load_fd(self.fd, a, b - a, d_buf) == b - a
+            c.h2d(d_rows, np.ascontiguousarray(rows))
+            rc, nb = c.table_gather_column(d_buf, b - a, d_rows, n, "quality", d_col, need + 64, d_off, sentinel=False, add=a, value_add=-33)
+            _hip.check(rc)
+            col, off = np.empty(nb, dtype=np.int8), np.empty(n + 1, dtype=np.int64)
+            if nb:
+                c.d2h(col, d_col)
+            c.d2h(off, d_off)
+            return col, off
+        finally:
+            for p in (d_buf, d_rows, d_col, d_off):
+                c.dev_free(p)
 
     def close(self):
         if getattr(self, "sh", None) is not None:

@@ -144,8 +144,9 @@ def test_one_gib_file_three_ranks_64m_slabs(gpu_ctx, shm_file):
 
 
 def test_range_iterator_through_slabs_matches_the_reference_tuples(gpu_ctx, golden, oracle, shm_file):
-    """readfastq_iter_range(..., slab_bytes=) == the reference's golden tuples; entryfunc_phred over slabs decodes on the host
-    (the reference's own per-record way) and still equals the oracle's decode."""
+    """readfastq_iter_range(..., slab_bytes=) == the reference's golden tuples; entryfunc_phred over slabs (nothing resident)
+    has its qualities decoded on the device batch by batch (FileShard.quals_from_file) and equals the oracle's decode and the
+    resident range's entries."""
     from array import array
     from fastqandfurious_amd import fastqandfurious as F, hip, synth
 
