@@ -253,7 +253,7 @@ def stream_inclusive(ctx, sample_u8, fbufsize=1 << 24):
                                "scanner) over the same file, %.1f s" % (n_it, el_it)}
 
 
-def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, budget_s=3.0):
+def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=1 << 30, budget_s=3.0):
     """File in, this rank's rows out through the file-backed byte-range shards (sharded.FileShard: ffq_shard_load_fd +
     one ffq_shard_step): every rank writes the first bytes of its range of the synthetic stream into ONE file in
     /dev/shm, then every rank loads ITS range of that file (pread -> pinned slots -> two copy streams) and the ranks
@@ -300,7 +300,7 @@ def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, b
         best = None
         sh = sharded.FileShard(ctx, path, rank, world, comm=comm)
         loads = []
-        for _ in range(3):
+        for _ in range(6):
             t0 = time.perf_counter()
             nb = sh.load()
             t1 = time.perf_counter()
@@ -362,7 +362,7 @@ def sharded_file(ctx, shard, rank, world, dev, dist, per_rank_bytes=512 << 20, b
             "transport": tr, "halo_source": "file" if src else "ranks", "records_rank0": recs, "total_records": total,
             "iterator_m_reads_per_s_per_rank": round(n_it / el_it / 1e6, 3),
             "sample": "one %d-byte file in %s read by %d rank(s), an even share each (+ 1 MiB either side): ffq_shard_load_fd + one "
-                      "ffq_shard_step per rank, max over ranks, best of 3 into the buffer the shard keeps (first_load: the first of them; link_gb_s: one raw pinned copy of the same bytes, this box, right behind); iterator: readfastq_iter_range(entryfunc) tuples of "
+                      "ffq_shard_step per rank, max over ranks, best of 6 into the buffer the shard keeps (first_load: the first of them; link_gb_s: one raw pinned copy of the same bytes, this box, right behind); iterator: readfastq_iter_range(entryfunc) tuples of "
                       "rank 0's records, %.1f s" % (whole, d, world, el_it)}
 
 
