@@ -272,18 +272,12 @@ __device__ __noinline__ int64_t cand_after_wave(const LineIndex *Lg, int t1, int
 // and the host re-runs the stage with the DOUBLING configuration).
 // (the body for ONE group g, by one wave; the kernel below calls it once per wave, or -- behind k_chain_lite -- for every
 // group of the list that kernel declined)
-// LA: look-ahead tiles behind the own ones (round 6).  One is what reads of up to a few kilobases need; with records of
-// 8-20 kbp (a wrapped record of 20 kbp is 40 KB: two and a half tiles) the calls of a group's LAST records reach past it and
-// went, one node at a time, through the whole-wave call over the global index (55 000 cycles each).  LA = 3 keeps them in
-// the window -- positions stay under 2^18, the entries must fit EMAX -- for contexts whose recent input had long records.
-template <int PER, int EMAX, int WPB, bool DOUBLING, int LA = 1>
+template <int PER, int EMAX, int WPB, bool DOUBLING>
 __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineIndex *__restrict__ Lg, int64_t offset, int eof,
                                                  const ChainBufs &B, const int g, int only_deferred, int ablate)
 {
     constexpr int NMAX = PER * 64;
     constexpr int ND = DOUBLING ? NMAX : 1;
-    constexpr int NTW = OWN_T + 1 + LA;        // (shadows the namespace's: run-in tile + own tiles + LA look-ahead tiles)
-    static_assert(NTW * TILE + 1 <= (int)WP_MASK, "window positions must fit WP_MASK");
     __shared__ uint32_t went_all[WPB][EMAX + 8];     // (+8: a lane's words past the last entry, see the window loop)
     __shared__ uint16_t nidx_all[WPB][NMAX];   // node -> window entry index of its "\n@"
     __shared__ uint16_t nx16_all[WPB][NMAX];   // node -> successor node / SN_*
@@ -309,7 +303,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
     const int own1 = min(own0 + OWN_T, L.ntiles);
     const bool has_runin = own0 > 0;
     const int wt0 = has_runin ? own0 - 1 : 0;
-    const int wt1 = min(own1 + LA, L.ntiles);
+    const int wt1 = min(own1 + 1, L.ntiles);
     const int nwt = wt1 - wt0;
     const int sent = (wt0 == 0 && L.s) ? 1 : 0;
     const int64_t wpos0 = (int64_t)wt0 << TILE_SHIFT;
@@ -1084,7 +1078,7 @@ __device__ __forceinline__ void chain_wave_group(const LineIndex &L, const LineI
     }
 }
 
-template <int PER, int EMAX, int WPB, bool DOUBLING, int LA = 1>
+template <int PER, int EMAX, int WPB, bool DOUBLING>
 __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const LineIndex *__restrict__ Lg,
                                                          int64_t offset, int eof, ChainBufs B, int g0, int g1,
                                                          int only_deferred, int ablate)
@@ -1092,7 +1086,7 @@ __global__ __launch_bounds__(WPB * 64) void k_chain_wave(LineIndex L, const Line
     const int wid = threadIdx.x >> 6;
     const int g = g0 + blockIdx.x * WPB + wid;
     if (g >= g1) return;                 // no workgroup barrier is used below
-    chain_wave_group<PER, EMAX, WPB, DOUBLING, LA>(L, Lg, offset, eof, B, g, only_deferred, ablate);
+    chain_wave_group<PER, EMAX, WPB, DOUBLING>(L, Lg, offset, eof, B, g, only_deferred, ablate);
 }
 
 // behind k_chain_lite (ffq_lite.h): the groups that kernel declined, from its list -- a grid of a few thousand waves takes

@@ -68,7 +68,6 @@ struct ScanState {
     unsigned long long poll_seq = 0;   // FFQ_F_POLL_RESULT: the front ends in a publisher that writes this number; no end event
     bool wide = false;        // the index kernel of this scan also wrote EVERY byte decoded in place (k_scan_lines<.., WIDE>): the general
                               //   path's decode in one pass -- no tier of this scan runs a decode kernel, qoff[i] = pos4's offset in the buffer
-    bool long_la = false;     // the general kernels of this scan run with three look-ahead tiles (records of many kilobases: ffq_ctx::long_rec)
     bool go_ranked = false;   // the front is the index kernel only: the list-ranking tier follows at the wait
     bool index_done = false;  // the line index of this buffer is built (a later tier re-uses it)
     int stage = 0;            // what the pending front consisted of: 1 fast four-line path, 2 general path
@@ -109,8 +108,6 @@ struct ffq_ctx {
     RankBufs rk = {};                    // its scratch (ffq_ranked.h), grow-only
     int64_t rk_cap_tiles = 0, rk_cap_c = 0;
     int dense_skip = 0;                  // scans left that start with the dense configuration of them
-    bool long_rec = false;               // the recent input's records are long (LONG_REC_BYTES and more on average): the general kernels take
-                                         //   three look-ahead tiles instead of one, so that the calls of a group's last records stay in the window
     bool lite_ran = false;               // the last general front used the lean kernel
     int lite_skip = 0;                   // scans left whose general path runs k_chain_wave over all groups (the lean kernel declined too many)
     bool dense4_remember = false;        // four-line input with dense tiles (reads of a dozen bases): the fast path starts with k_rows4<., true>
@@ -385,7 +382,6 @@ static int64_t tiles_for(int64_t n) { return (n + TILE - 1) >> TILE_SHIFT; }
 static int64_t groups_for(int64_t ntiles) { return (ntiles + OWN_T - 1) / OWN_T; }
 constexpr int PER_FAST = 6, EMAX_FAST = 2048, WPB_FAST = 2;   // k_chain_wave, usual line/record density
 constexpr int PER_DENSE = 15, EMAX_DENSE = NTW * SLOT + 8, WPB_DENSE = 1;   // short records / short lines
-constexpr int EMAX_LONG = 3072, LA_LONG = 3;                    // long records: three look-ahead tiles (ffq_chain.h, round 6), lines of 43 bytes and more
 constexpr int NMAX_FAST = PER_FAST * 64, NMAX_DENSE = PER_DENSE * 64;
 constexpr int WPB_LITE = 2;                                    // k_chain_lite (ffq_lite.h): groups per workgroup
 
@@ -508,7 +504,7 @@ static int reserve_pool(ffq_ctx *c, unsigned long long entries)
 
 extern "C" void ffq_ctx_forget(ffq_ctx *c)
 {
-    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->lite_skip = 0; c->dense4_remember = false; c->ranked_skip = 0; c->fused_skip = 0; c->fused_backoff = 15; c->fz_in_place = false; c->long_rec = false; }
+    if (c) { c->fast4_remember = false; c->fast4_skip = 0; c->dense_skip = 0; c->lite_skip = 0; c->dense4_remember = false; c->ranked_skip = 0; c->fused_skip = 0; c->fused_backoff = 15; c->fz_in_place = false; }
 }
 
 extern "C" int ffq_ctx_reserve(ffq_ctx *c, int64_t max_bytes)
@@ -761,11 +757,7 @@ static int enqueue_repair(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, boo
     ChainBufs cb = chain_bufs(c, ngroups, dense_cfg ? NMAX_DENSE : NMAX_FAST);
     hipStream_t sA = c->stream;
     hipLaunchKernelGGL(k_repair_mark, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, sA, cb);
-    if (!dense_cfg && c->pend.long_la)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_LONG, WPB_FAST, false, LA_LONG>),
-                           dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
-                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 2, 0);
-    else if (!dense_cfg)
+    if (!dense_cfg)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
                            dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 2, 0);
@@ -798,8 +790,7 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
     }
     HIPCHK(hipMemsetAsync(cb.flags, 0, (2 * (size_t)ngroups + 3) * 4, sA));      // flags, and: no group has a chunk of the walked groups' stage yet
     static const bool no_lite = getenv("FFQ_NO_LITE") != nullptr;
-    const bool long_la = !dense_cfg && c->pend.long_la;
-    bool lite = !dense_cfg && !long_la && ablate == 0 && (!cb.prof || (PROBES && getenv("FFQ_PROF_LITE"))) && !no_lite;
+    bool lite = !dense_cfg && ablate == 0 && (!cb.prof || (PROBES && getenv("FFQ_PROF_LITE"))) && !no_lite;
     // (a context whose recent input the lean kernel mostly declined -- tiles of more than LT_E lines that still fit the usual
     // window: lines of 43-48 bytes -- runs k_chain_wave directly for a while: the list kernel is the slower way to run many groups)
     if (lite && c->lite_skip > 0) { c->lite_skip--; lite = false; }
@@ -821,12 +812,6 @@ static int enqueue_general(ffq_ctx *c, const ScanArgs &a, const LineIndex &L, bo
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave_list<PER_FAST, EMAX_FAST, WPB_FAST, false>),
                            dim3(std::min((ngroups + WPB_FAST - 1) / WPB_FAST, 4096)), dim3(WPB_FAST * 64), 0, sA, L,
                            (const LineIndex *)c->d_L, a.offset, a.eof, cb);
-    else if (long_la)
-        // records of many kilobases: every group by the general kernel with three look-ahead tiles (the lean kernel's window is
-        // for reads of a few hundred bases)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_LONG, WPB_FAST, false, LA_LONG>),
-                           dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
-                           (const LineIndex *)c->d_L, a.offset, a.eof, cb, 0, ngroups, 0, ablate);
     else if (!dense_cfg)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain_wave<PER_FAST, EMAX_FAST, WPB_FAST, false>),
                            dim3((ngroups + WPB_FAST - 1) / WPB_FAST), dim3(WPB_FAST * 64), 0, sA, L,
@@ -882,8 +867,6 @@ static int enqueue_front(ffq_ctx *c, ScanState &st)
         else st.probe4 = !serial && !st.go_ranked && !st.index_done && ablate == 0;
     }
     if (c->dense_skip > 0 && !st.dense_cfg && !st.index_done) { c->dense_skip--; st.dense_cfg = true; }
-    static const bool no_long = getenv("FFQ_NO_LONG_LA") != nullptr;
-    if (c->long_rec && !st.dense_cfg && !no_long) st.long_la = true;
     const bool try_fast4 = !serial && !st.go_ranked && !st.dense_cfg && !st.fast4_failed && ablate == 0 &&
                            !(a.flags & FFQ_F_FORCE_GENERAL) && getenv("FFQ_NO_FAST4") == nullptr;
     const LineIndex L = make_index(c, a, ntiles);
@@ -1355,24 +1338,6 @@ static int scan_finish(ffq_ctx *c, ScanState &st, ffq_scan_result *res)
         // makes the first rejected group exact, so the first bad group moves forward; a round
         // that does not move it (a group that does not fit the kernel at all) ends the repairs.
         static const bool no_ranked = getenv("FFQ_NO_RANKED") != nullptr;
-        // Records of many kilobases (LONG_REC_BYTES and more on average, from the groups' own counts): the calls of a group's
-        // last records reach past ONE look-ahead tile, and what does not fit the window costs a whole-wave call per node or a
-        // repair pass per scan.  The first such scan of a context runs its general kernels again with three look-ahead tiles;
-        // the context remembers for as long as the records stay long.
-        static const int64_t LONG_REC_BYTES = getenv("FFQ_LONG_REC_BYTES") ? atoll(getenv("FFQ_LONG_REC_BYTES")) : 12000;
-        static const bool no_long2 = getenv("FFQ_NO_LONG_LA") != nullptr;
-        if (tiers && !no_long2) {
-            const int64_t nrec = c->h_res->approx_records;
-            const bool is_long = nrec > 0 && a.n_bytes / nrec >= LONG_REC_BYTES && st.ngroups >= 4;
-            if (is_long && !st.long_la && !st.dense_cfg && c->h_res->fallback) {
-                c->long_rec = true;
-                st.long_la = true;
-                st.fast4_failed = true;
-                st.retries++;
-                continue;
-            }
-            if (!c->h_res->fallback || st.long_la) c->long_rec = is_long;
-        }
         if (tiers && !(PROBES && getenv("FFQ_ABLATE") && atoi(getenv("FFQ_ABLATE")) != 0) && !getenv("FFQ_NO_REPAIR")) {
             int prev_bad = -1;
             const int first_bad = c->h_res->bad_group;
