@@ -168,7 +168,9 @@ def main(scratch):
         with open(fpath, "wb") as fh:
             fh.write(fstream.tobytes())
     dist.barrier()
-    for kw in ({}, dict(tail_bytes=200, head_bytes=64)):
+    # (the third form: the range through SLABS of 256 KiB -- ffq_shard_scan_fd_slabs, a range that would not fit the GPU --,
+    # its eight words over the same RCCL gather)
+    for kw in ({}, dict(tail_bytes=200, head_bytes=64), dict(slab_bytes=1 << 18, tail_bytes=300, head_bytes=100)):
         it = F.readfastq_iter_range(fpath, rank, world, F.entryfunc_abspos, ctx=ctx, comm=sharded.native_unique_id(dist, dev), **kw)
         assert it.comm["transport"] == "rccl" and it.comm["halo_source"] == "file"
         rows = np.array([list(p) for p in it], dtype=np.int64).reshape(-1, 6)
@@ -224,7 +226,7 @@ def check(scratch, world):
     got = np.concatenate([np.load(os.path.join(scratch, "rows_recovered_%d.npy" % r)) for r in range(world)])
     assert got.shape == fwant.shape and (got == fwant).all(), "after the watchdog trip: the serial step's rows differ from the oracle's"
     assert all(rep["watchdog"]["stage"] == "gather" for rep in reports)
-    for k in (0, 2):
+    for k in (0, 2, 3):
         got = np.concatenate([np.load(os.path.join(scratch, "file_rows_%d_%d.npy" % (k, r))) for r in range(world)])
         assert got.shape == fwant.shape and (got == fwant).all(), "file-backed ranges: rows over the ranks differ from the oracle's"
         assert [reports[r]["file%d" % k]["base"] for r in range(world)] == \
