@@ -557,7 +557,9 @@ def run_workload(name, args, ctx, rank, world, dev, dist, ctl=None):
     # (N = 1 --native-step: the device step on the library's RCCL transport at world 1 instead of the in-process one)
     shard = sharded.SyntheticShard(ctx, wl["kind"], wl["bytes"] // world if split else wl["bytes"], rank, world, dev,
                                    total_records=wl["bytes"] // 322 if split else None,
-                                   solo_rccl=bool(getattr(args, "native_step", False)), ctl_group=ctl)
+                                   solo_rccl=bool(getattr(args, "native_step", False)), ctl_group=ctl,
+                                   # (FFQ_BENCH_SOLO_NCCL: a torch.distributed world of ONE rank -- the N > 1 glue with no peers)
+                                   transport=dist if (dist is not None and world == 1) else None)
     # Who is there (N > 1, the library's own RCCL transport): the communicators must count --gpus ranks and those ranks
     # must sit on distinct GPUs -- asserted BEFORE anything is timed, printed in the line's `comm`
     peers = None
@@ -1098,7 +1100,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     ctl = None
-    if world > 1:
+    # FFQ_BENCH_SOLO_NCCL=1 under the launcher with ONE rank: everything the N > 1 line does on RCCL -- the nccl process group,
+    # the gloo side group the communicator ids travel over, the library's own RCCL transport with its peers check, the lanes,
+    # the reductions of the timings -- with no peer (tests/test_watchdog.py: the glue the first multi-GPU run will execute)
+    solo_nccl = os.environ.get("FFQ_BENCH_SOLO_NCCL") == "1" and world == 1 and "RANK" in os.environ
+    if solo_nccl:
+        args.lanes_step = True
+    if world > 1 or solo_nccl:
         import datetime
         import torch.distributed as dist
         if dry:

@@ -36,6 +36,11 @@ def main(scratch):
     dev = torch.device("cuda", local)
     dist.init_process_group(backend="nccl", device_id=dev)
     assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+    # (what bench.py does at N > 1: a gloo side group for the communicator ids -- it still works when the GPUs' fabric has just
+    # swallowed a collective, which is when a NEW id is needed)
+    import datetime
+    ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+    assert dist.get_backend(ctl) == "gloo"
     ctx = hip.Context(local)
     lane_ctx = hip.Context(share=ctx)
     report = {}
@@ -152,7 +157,7 @@ def main(scratch):
     ext[:tail].zero_()
     ext[tail + hi - lo:].zero_()
     torch.cuda.synchronize()
-    sc = sharded.NativeShardScanner(ctx, bounds, rank, world, unique_id=sharded.native_unique_id(dist, dev), serial=True)
+    sc = sharded.NativeShardScanner(ctx, bounds, rank, world, unique_id=sharded.native_unique_id(dist, dev, ctl), serial=True)      # (the new id over gloo)
     info = sc.info()
     sharded.check_peers(info, world)
     assert info["mode"] == "serial" and info["nranks_gather"] == 0 and info["nranks_handoff"] == world
