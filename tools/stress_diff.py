@@ -9,7 +9,7 @@ from oracle import ffq_oracle as oracle
 import test_gpu_parity as T
 def same_quals(res, want, qual, qoff, wq, wqoff):
     """packed stream, or -- res.path 6, FFQ_F_SINGLE_PASS -- segmented: record i = qual[qoff[i] : qoff[i] + pos5 - pos4]"""
-    if int(res.path) != 6:
+    if int(res.path) != 6 and not (int(res.path) & 8):        # (6: the fast path's single pass; | 8: the general path's, every byte in place)
         return qoff.shape == wqoff.shape and (qoff == wqoff).all() and qual.shape == wq.shape and (qual == wq).all()
     n = len(want)
     if qoff.shape[0] != n + 1:
@@ -23,6 +23,7 @@ def same_quals(res, want, qual, qoff, wq, wqoff):
     return bool((qual[idx] == wq).all())
 
 
+ROOM = int(os.environ.get("FFQ_STRESS_QUAL_ROOM", "0")) or None      # 16384: room for the in-place layouts (with FFQ_STRESS_FLAGS=16)
 EXTRA = int(os.environ.get("FFQ_STRESS_FLAGS", "0"))      # e.g. 16 = FFQ_F_SINGLE_PASS: the same inputs through the single-pass kernel
 ctx = hip.default_context(0)
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -48,7 +49,7 @@ for seed in range(SEED0, SEED0 + nseeds):
     for kw, extra in ((dict(), 0), (dict(eof=False), 0), (dict(offset=len(data) // 3), 0), (dict(), hip.F_FORCE_SERIAL),
                       (dict(eof=False, offset=7), hip.F_FORCE_SERIAL)):
         want, end, status, off = oracle.scan(data, **kw)
-        table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL | extra | EXTRA, **kw)
+        table, res, qual, qoff = ctx.scan_host(data, flags=hip.F_DECODE_QUAL | extra | EXTRA, qual_room=ROOM, **kw)
         wq, wqoff = oracle.decode_quals(data, want)
         ok = (table.shape == want.shape and (table == want).all() and int(res.end_state) == end and
               int(res.last_status) == status and int(res.end_offset) == off and same_quals(res, want, qual, qoff, wq, wqoff))

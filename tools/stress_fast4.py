@@ -13,7 +13,7 @@ from oracle import ffq_oracle as oracle
 import test_gpu_parity as T
 def same_quals(res, want, qual, qoff, wq, wqoff):
     """packed stream, or -- res.path 6, FFQ_F_SINGLE_PASS -- segmented: record i = qual[qoff[i] : qoff[i] + pos5 - pos4]"""
-    if int(res.path) != 6:
+    if int(res.path) != 6 and not (int(res.path) & 8):        # (| 8: the general path's one-pass decode, every byte in place)
         return qoff.shape == wqoff.shape and (qoff == wqoff).all() and qual.shape == wq.shape and (qual == wq).all()
     n = len(want)
     if qoff.shape[0] != n + 1:
