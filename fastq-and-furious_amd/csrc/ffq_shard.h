@@ -450,6 +450,10 @@ struct ffq_shard {
     int *h_stall = nullptr, *hm_stall = nullptr;     // the flag an injected stall waits for (host-mapped)
     uint8_t *slab = nullptr;               // ffq_shard_scan_fd_slabs: the one device buffer a range that does not fit goes through
     int64_t slab_cap = 0;
+    std::vector<uint8_t *> graveyard;      // grown views that were replaced: freed with the shard (hipFree waits for the device)
+    hipStream_t diag_st = nullptr;         // what a watchdog trip reads the gather's buffer with (made with the shard: nothing may be
+    hipEvent_t diag_ev = nullptr;          //   allocated or freed while a kernel is stuck -- those calls wait for the device)
+    int64_t *h_diag = nullptr;
     bool leaked = false;                   // an abort could not drain the streams: destroy frees nothing on the device
     // a failure of THIS rank's own scan inside a step: the peers are told through the words before it is returned
     int local_fail = 0;
@@ -482,6 +486,9 @@ static int shard_alloc(ffq_shard *s, ffq_shard *parent = nullptr)
     HIPCHK(hipHostMalloc((void **)&s->h_all, (size_t)s->world * SH_WORDS * 8, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&s->h_own, 16 * 8, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void **)&s->hm_own, s->h_own, 0));
+    HIPCHK(hipStreamCreateWithFlags(&s->diag_st, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&s->diag_ev, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void **)&s->h_diag, (size_t)s->world * SH_WORDS * 8, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&s->h_stall, 64, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void **)&s->hm_stall, s->h_stall, 0));
     *s->h_stall = 0;
@@ -560,9 +567,13 @@ extern "C" void ffq_shard_destroy(ffq_shard *s)
     for (auto e : s->ev_x) if (e) (void)hipEventDestroy(e);
     for (auto e : s->ev_g) if (e) (void)hipEventDestroy(e);
     (void)hipFree(s->d_words); (void)hipFree(s->d_all); (void)hipFree(s->grown); (void)hipFree(s->slab);
+    for (uint8_t *g : s->graveyard) (void)hipFree(g);
     if (s->h_all) (void)hipHostFree(s->h_all);
     if (s->h_own) (void)hipHostFree(s->h_own);
     if (s->h_stall) (void)hipHostFree(s->h_stall);
+    if (s->h_diag) (void)hipHostFree(s->h_diag);
+    if (s->diag_ev) (void)hipEventDestroy(s->diag_ev);
+    if (s->diag_st) (void)hipStreamDestroy(s->diag_st);
     delete s;
 }
 
@@ -786,23 +797,17 @@ static int shard_stage(ffq_shard *s)
 // front of the collective): read on a stream of its own, with a deadline of its own
 static std::string shard_words_seen(ffq_shard *s)
 {
+    // (everything it needs was made with the shard: a hipHostFree / hipFree / hipStreamDestroy HERE would wait for the device --
+    // for the very kernel that is stuck; found with real peers, tests/test_multigpu.py: the trip came back after the stall's
+    // 60 s instead of the deadline's 4)
     std::string have, lack;
-    std::vector<int64_t> seen((size_t)s->world * SH_WORDS, -1);
-    bool ok = false;
-    hipStream_t ds = nullptr;
-    hipEvent_t de = nullptr;
-    int64_t *h = nullptr;
-    if (hipStreamCreateWithFlags(&ds, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&de, hipEventDisableTiming) == hipSuccess &&
-        hipHostMalloc((void **)&h, seen.size() * 8, hipHostMallocDefault) == hipSuccess &&
-        hipMemcpyAsync(h, s->d_all, seen.size() * 8, hipMemcpyDeviceToHost, ds) == hipSuccess && hipEventRecord(de, ds) == hipSuccess &&
-        sh_wait_event(de, 1.0, nullptr) == 0) {
-        memcpy(seen.data(), h, seen.size() * 8);
-        ok = true;
-    }
-    if (ok) { (void)hipHostFree(h); (void)hipEventDestroy(de); (void)hipStreamDestroy(ds); }      // (else: left alone, a copy may be in flight)
-    if (!ok) return "which ranks' words have arrived could not be read";
+    const size_t nw = (size_t)s->world * SH_WORDS;
+    if (!s->diag_st || !s->diag_ev || !s->h_diag) return "which ranks' words have arrived could not be read";
+    if (hipMemcpyAsync(s->h_diag, s->d_all, nw * 8, hipMemcpyDeviceToHost, s->diag_st) != hipSuccess || hipEventRecord(s->diag_ev, s->diag_st) != hipSuccess ||
+        sh_wait_event(s->diag_ev, 1.0, nullptr) != 0)
+        return "which ranks' words have arrived could not be read";
     for (int r = 0; r < s->world; r++) {
-        std::string &dst = seen[(size_t)r * SH_WORDS + 4] >= 0 ? have : lack;
+        std::string &dst = s->h_diag[(size_t)r * SH_WORDS + 4] >= 0 ? have : lack;
         if (!dst.empty()) dst += ", ";
         dst += std::to_string(r);
     }
@@ -823,6 +828,17 @@ static int shard_tripped(ffq_shard *s, double waited, int w = 1, int at = -1)
     std::string seen = (stage == FFQ_SHARD_STAGE_GATHER && s->world > 1 && !strcmp(tr->name(), "rccl")) ? "; " + shard_words_seen(s) : std::string();
     return fail(FFQ_E_TIMEOUT, "ffq_shard_step_wait: rank %d of %d: no progress within %.1f s at stage '%s' (transport %s, %s step; FFQ_SHARD_TIMEOUT_S)%s",
                 s->rank, s->world, waited, sh_stage_name(stage), tr->name(), tr->serial ? "serial" : "pipelined", seen.c_str());
+}
+
+// the scan stream drained, with the watchdog's deadline
+static int shard_sync_scan_stream(ffq_shard *s)
+{
+    ffq_ctx *c = s->c;
+    const double keep = c->watchdog_s;
+    c->watchdog_s = s->tr->timeout_s;
+    const int rc = ctx_wait(c, nullptr, c->stream);
+    c->watchdog_s = keep;
+    return rc == FFQ_E_TIMEOUT ? shard_tripped(s, s->tr->timeout_s) : rc;
 }
 
 // waits for one mark of the pending step with the watchdog's deadline
@@ -992,14 +1008,15 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
                 if (hipMalloc((void **)&g, (size_t)cap) != hipSuccess) return fail(FFQ_E_NOMEM, "ffq_shard: no memory for a view of %lld bytes", (long long)cap);
                 mark_other(c);
                 hipError_t e = hipMemcpyAsync(g, s->ext, (size_t)s->v.n_bytes, hipMemcpyDeviceToDevice, c->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                // (waits with the watchdog's deadline; views that are replaced go to the graveyard, not to hipFree: a free waits
+                // for the DEVICE -- for the other lane's hand-off, for a collective whose peer may never come)
+                rc = e != hipSuccess ? fail(FFQ_E_HIP, "ffq_shard: %s", hipGetErrorString(e)) : shard_sync_scan_stream(s);
                 int64_t got = 0;
                 const int64_t more = nv.head - s->v.head;
-                rc = e != hipSuccess ? fail(FFQ_E_HIP, "ffq_shard: %s", hipGetErrorString(e))
-                                     : stage_fd2d(c, g + s->v.n_bytes, s->fd, s->hi + s->v.head, more, &got);
+                if (!rc) rc = stage_fd2d(c, g + s->v.n_bytes, s->fd, s->hi + s->v.head, more, &got);
                 if (!rc && got != more) rc = fail(FFQ_E_ARG, "ffq_shard: the file ends at byte %lld, its bounds say %lld", (long long)(s->hi + s->v.head + got), (long long)s->total);
-                if (rc) { (void)hipFree(g); return rc; }
-                if (s->grown) (void)hipFree(s->grown);           // (nothing in flight reads it: the stream was waited for above)
+                if (rc) { s->graveyard.push_back(g); return rc; }
+                if (s->grown) s->graveyard.push_back(s->grown);
                 s->grown = g; s->grown_cap = cap;
                 s->ext = g; s->v = nv;
             }
@@ -1029,7 +1046,7 @@ extern "C" int ffq_shard_step_wait(ffq_shard *s, ffq_shard_result *out)
             // (src_ext may BE the old grown view -- a rank growing a second time that a neighbour's look-ahead reaches into in
             // the same round: it is freed only once the exchange that reads it is through)
             rc = shard_serve(s, plan, src_ext, s->v.tail, dst_ext, dst_start, c->stream);
-            if (old_grown) { if (!rc) (void)hipStreamSynchronize(c->stream); (void)hipFree(old_grown); }
+            if (old_grown) s->graveyard.push_back(old_grown);      // (freed with the shard: the exchange that reads it may still be in flight)
             if (rc) return rc;
             if (i_grow) { s->ext = s->grown; s->v = nv; }
         }

@@ -15,6 +15,17 @@ import json
 import os
 import sys
 
+# FFQ_TEST_RANKS_ON_ONE_GPU=1: every rank on GPU 0.  RCCL refuses two ranks of one communicator on the same device of the same
+# HOST ("Duplicate GPU detected"); ranks that say they sit on different hosts (NCCL_HOSTID) pass, and talk over the socket
+# transport (loopback) instead of xGMI.  Nothing of that is fast and nothing of it is xGMI -- but it IS librccl with real
+# peers: communicators of N ranks, ncclSend / ncclRecv between different ranks, the all-gather, two communicators driven
+# from two streams at once, a collective whose peer never arrives and ncclCommAbort on it -- on a box with one GPU.
+ONE_GPU = os.environ.get("FFQ_TEST_RANKS_ON_ONE_GPU") == "1"
+if ONE_GPU:
+    os.environ["NCCL_HOSTID"] = "ffq-rank-as-host-%s" % os.environ.get("RANK", "0")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -30,8 +41,23 @@ from test_sharded import bounds_for, expected, make_stream
 KINDS = ("single", "wrapped", "tricky", "long-wrapped", "long", "small")
 
 
+def peers_ok(info, world):
+    """sharded.check_peers -- or, every rank on ONE GPU on purpose: the rank counts, and the bus ids all the same."""
+    if not ONE_GPU:
+        return sharded.check_peers(info, world)
+    assert info["nranks_handoff"] == world and len(set(info["bus_ids"])) == 1 and info["bus_ids"][0], info
+    if world > 1:
+        try:
+            sharded.check_peers(info, world)
+            raise AssertionError("check_peers let %d ranks on one GPU pass" % world)
+        except RuntimeError as e:
+            assert "share" in str(e)
+
+
 def main(scratch):
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if ONE_GPU:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist.init_process_group(backend="nccl", device_id=dev)
@@ -53,7 +79,7 @@ def main(scratch):
             sc = sharded.NativeShardScanner(ctx, bounds, rank, world, unique_id=sharded.native_unique_id(dist, dev))
             assert sc.sh.transport() == "rccl"
             info = sc.info()
-            sharded.check_peers(info, world)          # the communicators count `world` ranks, on distinct GPUs
+            peers_ok(info, world)                     # the communicators count `world` ranks, on distinct GPUs
             assert info["nranks_handoff"] == world and info["nranks_gather"] == world and info["mode"] == "pipelined"
             assert len(info["bus_ids"]) == world and all(b is not None for b in info["bus_ids"]), info
             lanes = [sc, sc.lane(lane_ctx)]
@@ -159,7 +185,7 @@ def main(scratch):
     torch.cuda.synchronize()
     sc = sharded.NativeShardScanner(ctx, bounds, rank, world, unique_id=sharded.native_unique_id(dist, dev, ctl), serial=True)      # (the new id over gloo)
     info = sc.info()
-    sharded.check_peers(info, world)
+    peers_ok(info, world)
     assert info["mode"] == "serial" and info["nranks_gather"] == 0 and info["nranks_handoff"] == world
     o = sc.scan(ext, tail, head, tab)
     assert o.comm["mode"] == "serial" and o.comm["nranks"] == world
@@ -195,7 +221,7 @@ def check(scratch, world):
     from oracle import ffq_oracle as oracle
     from test_sharded import _hip_backends, run_local
     reports = [json.load(open(os.path.join(scratch, "report_%d.json" % r))) for r in range(world)]
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", 0 if ONE_GPU else int(os.environ.get("LOCAL_RANK", "0")))
     for kind in KINDS:
         stream = make_stream(kind)
         want0, err = expected(oracle, stream)

@@ -26,8 +26,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(world, scratch, timeout):
+def _launch(world, scratch, timeout, one_gpu=False):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if one_gpu:
+        env["FFQ_TEST_RANKS_ON_ONE_GPU"] = "1"
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
@@ -63,3 +65,19 @@ def test_multigpu_worker_at_world_one(gpu_ctx, tmp_path):
     assert not isinstance(r, subprocess.TimeoutExpired), "worker timed out"
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     assert "multi-gpu shards ok: world 1" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", (2, 3))
+def test_native_shards_over_rccl_with_real_peers_on_one_gpu(gpu_ctx, tmp_path, world):
+    """RCCL WITH PEERS on a one-GPU box (round 6): `world` processes on GPU 0 that tell RCCL they sit on different hosts
+    (NCCL_HOSTID per rank; tests/multigpu_worker.py), so that its duplicate-GPU check lets them into one communicator -- over the
+    socket transport instead of xGMI, but the same librccl calls the product makes between GPUs: ncclCommInitRank of `world`
+    ranks twice (hand-off and gather communicators), ncclSend / ncclRecv between DIFFERENT ranks in one group, the all-gather,
+    both driven from their own streams at once (lanes), the serial one-communicator step, and the watchdog with a peer whose
+    gather really never arrives: FFQ_E_TIMEOUT on every rank, ncclCommAbort on a collective that is stuck, a new communicator,
+    the rows.  Everything the worker checks at world 1 and on a multi-GPU box, checked here against the oracle."""
+    r = _launch(world, tmp_path, 1500, one_gpu=True)
+    assert not isinstance(r, subprocess.TimeoutExpired), "worker timed out (world %d on one GPU)" % world
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-8000:]
+    assert "multi-gpu shards ok: world %d" % world in r.stdout
