@@ -566,7 +566,10 @@ def run_workload(name, args, ctx, rank, world, dev, dist, ctl=None):
     if hasattr(shard.scanner, "sh"):
         peers = shard.scanner.info()
         if peers and shard.scanner.sh.transport() == "rccl":
-            sharded.check_peers(peers, world)
+            if os.environ.get("FFQ_BENCH_RANKS_ON_ONE_GPU") == "1":      # (every rank on GPU 0 on purpose: the counts only)
+                assert peers["nranks_handoff"] == world and len(set(peers["bus_ids"])) == 1, peers
+            else:
+                sharded.check_peers(peers, world)
     n_own = shard.n_own_bytes
     ctx.reserve(shard.ext.numel())
     table = torch.empty((shard.max_records + 64, 6), dtype=torch.int64, device=dev)
@@ -1071,6 +1074,16 @@ def main():
     if args.native_step:
         args.lanes_step = True
 
+    # FFQ_BENCH_RANKS_ON_ONE_GPU=1: the N > 1 line over RCCL with every rank on GPU 0 -- ranks that tell RCCL they sit on
+    # different hosts (NCCL_HOSTID) pass its duplicate-GPU check and talk over the socket transport (loopback).  Functional
+    # only (the ranks share the GPU, nothing is xGMI): it is how a one-GPU box shows that `--gpus N` runs on librccl with
+    # real peers.  (Before torch -- and with it librccl -- is loaded.)
+    one_gpu = os.environ.get("FFQ_BENCH_RANKS_ON_ONE_GPU") == "1"
+    if one_gpu and "RANK" in os.environ:
+        os.environ["NCCL_HOSTID"] = "ffq-rank-as-host-%s" % os.environ["RANK"]
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
     import torch
     import fastqandfurious_amd  # noqa: F401
     from fastqandfurious_amd import hip
@@ -1094,7 +1107,7 @@ def main():
     # FFQ_BENCH_DRY_MULTI=1: every rank on GPU 0 over gloo -- a functional dry run of the N > 1
     # code path on a one-GPU box (its number means nothing; RCCL refuses two ranks per device)
     dry = os.environ.get("FFQ_BENCH_DRY_MULTI") == "1"
-    if dry:
+    if dry or one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -1188,7 +1201,7 @@ def main():
         torch.cuda.empty_cache()
         others = {}
         names = ("decode-10g", "decode-10g-packed", "wrapped-10g", "dense-1g", "single-100g") if world == 1 else ("single-100g",)
-        if os.environ.get("FFQ_BENCH_DRY_MULTI") == "1":
+        if os.environ.get("FFQ_BENCH_DRY_MULTI") == "1" or os.environ.get("FFQ_BENCH_RANKS_ON_ONE_GPU") == "1":
             names = ("single-4g-split",)             # (the dry run shares ONE GPU between the ranks)
         for other in names:
             ctx_o = hip.Context(local_rank)
