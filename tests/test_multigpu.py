@@ -68,7 +68,7 @@ def test_multigpu_worker_at_world_one(gpu_ctx, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", (2, 3))
+@pytest.mark.parametrize("world", (2, 3, 8))
 def test_native_shards_over_rccl_with_real_peers_on_one_gpu(gpu_ctx, tmp_path, world):
     """RCCL WITH PEERS on a one-GPU box (round 6): `world` processes on GPU 0 that tell RCCL they sit on different hosts
     (NCCL_HOSTID per rank; tests/multigpu_worker.py), so that its duplicate-GPU check lets them into one communicator -- over the
