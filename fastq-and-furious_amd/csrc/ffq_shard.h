@@ -27,7 +27,10 @@
 #include "ffq_shard_proto.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <atomic>
 #include <functional>
+#include <memory>
+#include <thread>
 
 namespace ffq {
 
@@ -229,13 +232,33 @@ struct ShRccl : ShTransport {
         }
         return nullptr;
     }
+    // ncclCommAbort raises the communicator's abort flag first -- the kernels of a collective that waits for a peer leave --
+    // and then tears the communicator down, which with a peer that is GONE (its process dead: the proxy thread sits in a socket
+    // call) does not come back for minutes (tests/test_multigpu.py: a peer that dies).  So the abort runs on a thread of its
+    // own and this call waits for it with a deadline; what is still tearing down after that is left to that thread.
+    int device = 0;
+    bool abort_stuck = false;
     void abort() override
     {
         if (aborted) return;
         aborted = true;
-        if (owner && A) {
-            if (cx) { A->CommAbort(cx); cx = nullptr; }
-            if (cg) { A->CommAbort(cg); cg = nullptr; }
+        if (!(owner && A)) return;
+        ncclComm_t a = cx, b = cg;
+        cx = cg = nullptr;
+        if (!a && !b) return;
+        auto done = std::make_shared<std::atomic<int>>(0);
+        RcclApi *api = A;
+        const int dev = device;
+        std::thread([api, a, b, done, dev] {
+            (void)hipSetDevice(dev);
+            if (a) api->CommAbort(a);
+            if (b) api->CommAbort(b);
+            done->store(1);
+        }).detach();
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!done->load()) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) { abort_stuck = true; return; }
+            usleep(1000);
         }
     }
     // a collective of the set-up, waited for with the watchdog's deadline: the FIRST thing that talks to the peers must
@@ -258,7 +281,7 @@ struct ShRccl : ShTransport {
     {
         A = rccl_api();
         if (!A) return fail(FFQ_E_NODEVICE, "ffq_shard: librccl could not be loaded (FFQ_RCCL_LIB names another copy)");
-        rank = rank_; world = world_; serial = serial_;
+        rank = rank_; world = world_; serial = serial_; this->device = device;
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
         RCCLCHK(A->CommInitRank(&cx, world, id, rank));
@@ -516,11 +539,28 @@ extern "C" int ffq_shard_abort(ffq_shard *s)
     if (!s) return fail(FFQ_E_ARG, "ffq_shard_abort: NULL shard");
     (void)hipSetDevice(s->c->device);
     if (s->h_stall) __atomic_store_n(s->h_stall, 1, __ATOMIC_RELEASE);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    if (sh_debug()) fprintf(stderr, "[ffq shard %d/%d] abort: communicators ...\n", s->rank, s->world);
     if (s->tr) { s->tr->poisoned = true; s->tr->abort(); }
+    if (sh_debug()) fprintf(stderr, "[ffq shard %d/%d] abort: communicators done after %.2f s; streams ...\n", s->rank, s->world, since());
     s->pending = false;
     s->c->pend.active = false;              // (the scan of the abandoned step: its result is never read)
+    if (ShRccl *r = dynamic_cast<ShRccl *>(s->tr)) {
+        if (r->abort_stuck) {
+            // ncclCommAbort itself has not come back (a peer whose PROCESS is gone: RCCL's teardown waits on its sockets for
+            // minutes) and holds the device's runtime meanwhile -- any HIP call of this thread, a stream query included, would
+            // wait behind it (seen with a real dead peer, tests/test_multigpu.py).  The caller has its error; nothing more of
+            // this shard is touched, and a host that wants to leave should leave with _exit.
+            s->leaked = true;
+            return fail(FFQ_E_TIMEOUT, "ffq_shard_abort: rank %d of %d: ncclCommAbort has not come back within 10 s (a peer's process is gone?); it goes on "
+                                       "on a thread of its own and holds the device meanwhile -- the shard is leaked, leave with _exit", s->rank, s->world);
+        }
+    }
     mark_other(s->c);
-    if (shard_drained(s, 10.0)) return FFQ_OK;
+    const bool drained = shard_drained(s, 10.0);
+    if (sh_debug()) fprintf(stderr, "[ffq shard %d/%d] abort: streams %s after %.2f s\n", s->rank, s->world, drained ? "drained" : "NOT drained", since());
+    if (drained) return FFQ_OK;
     s->leaked = true;
     return fail(FFQ_E_TIMEOUT, "ffq_shard_abort: rank %d of %d: the shard's streams did not drain within 10 s of the abort", s->rank, s->world);
 }

@@ -529,7 +529,10 @@ class FileShard:
         GPU, a NEW communicator -- one, for the serial step -- over the process group, the range loaded again."""
         dist, dev, group = self._dist
         self.recovered = str(err)
-        self.sh.abort()
+        if not self.sh.abort():
+            # (ncclCommAbort itself is still busy -- a peer's process is gone -- and holds the device: nothing to rebuild on)
+            raise RuntimeError("the step did not come back (%s) and the communicator's abort is still busy: %s"
+                               % (err, _hip.lib().ffq_last_error().decode("utf-8", "replace")))
         self.sh.close()
         tail_bytes, head_bytes = self._halo
         self.sh = _hip.Shard(self.ctx, self.bounds, self.rank, self.world, tail_bytes, head_bytes,

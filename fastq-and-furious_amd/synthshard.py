@@ -195,8 +195,12 @@ class SyntheticShard:
         self.recovered = str(err)
         lanes = self._lanes or [self.scanner]
         n_lanes = len(lanes) if self._lanes else 0
-        for ln in lanes:
-            ln.abort()
+        drained = [ln.abort() for ln in lanes]
+        if not all(drained):
+            # ncclCommAbort itself is still busy (a peer's process is gone): it holds the device, every further HIP call of this
+            # process would wait behind it -- nothing to rebuild on; the caller reports and leaves (bench.py: an "error" line, _exit)
+            raise RuntimeError("the step did not come back (%s) and the communicators' abort is still busy: %s"
+                               % (err, _hip.lib().ffq_last_error().decode("utf-8", "replace")))
         for ln in reversed(lanes):                 # (the lanes before the shard whose communicators they borrow)
             ln.close()
         for c in (getattr(self, "_lane_ctx", None) or [])[1:]:

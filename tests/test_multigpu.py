@@ -81,3 +81,28 @@ def test_native_shards_over_rccl_with_real_peers_on_one_gpu(gpu_ctx, tmp_path, w
     assert not isinstance(r, subprocess.TimeoutExpired), "worker timed out (world %d on one GPU)" % world
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-8000:]
     assert "multi-gpu shards ok: world %d" % world in r.stdout
+
+
+@pytest.mark.gpu
+def test_a_peer_that_dies_does_not_take_the_survivor_with_it(gpu_ctx, tmp_path):
+    """Two ranks over RCCL (both on GPU 0, ranks as hosts), one good step each, then rank 1's process exits without a word.  The
+    survivor's next step must come back with an error within the watchdog's deadline -- FFQ_E_TIMEOUT naming the stage, or RCCL's
+    own asynchronous error for the dead peer --, ffq_shard_abort must return, and the process must end by itself: what a real
+    node failure looks like to the ranks that are left (tests/rccl_peer_dies_worker.py; no torch.distributed.run around them --
+    its agent would kill the survivor)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    idfile = str(tmp_path / "rccl.id")
+    w = os.path.join(ROOT, "tests", "rccl_peer_dies_worker.py")
+    p1 = subprocess.Popen([sys.executable, w, "1", idfile], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    p0 = subprocess.Popen([sys.executable, w, "0", idfile], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out0, _ = p0.communicate(timeout=300)
+        out1, _ = p1.communicate(timeout=60)
+    except subprocess.TimeoutExpired:
+        p0.kill(); p1.kill()
+        raise AssertionError("the survivor did not come back: " + (p0.stdout.read() if p0.stdout else "")[-2000:])
+    assert "rank 1: first step ok" in out1, out1[-2000:]
+    assert p0.returncode == 0 and "survivor ok" in out0, out0[-4000:]
+    assert "rank 0: FFQTimeout" in out0 or "rank 0: FFQError" in out0, out0[-2000:]
