@@ -255,9 +255,12 @@ struct ShRccl : ShTransport {
             if (b) api->CommAbort(b);
             done->store(1);
         }).detach();
+        // (how long: seconds when the peers are there -- 8 ranks tearing down at once over sockets took more than 10 s now and
+        // then --, never while a peer's process is gone; FFQ_SHARD_ABORT_S, default 30)
+        static const double abort_s = getenv("FFQ_SHARD_ABORT_S") ? std::max(1.0, atof(getenv("FFQ_SHARD_ABORT_S"))) : 30.0;
         const auto t0 = std::chrono::steady_clock::now();
         while (!done->load()) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) { abort_stuck = true; return; }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > abort_s) { abort_stuck = true; return; }
             usleep(1000);
         }
     }
@@ -553,16 +556,16 @@ extern "C" int ffq_shard_abort(ffq_shard *s)
             // wait behind it (seen with a real dead peer, tests/test_multigpu.py).  The caller has its error; nothing more of
             // this shard is touched, and a host that wants to leave should leave with _exit.
             s->leaked = true;
-            return fail(FFQ_E_TIMEOUT, "ffq_shard_abort: rank %d of %d: ncclCommAbort has not come back within 10 s (a peer's process is gone?); it goes on "
+            return fail(FFQ_E_TIMEOUT, "ffq_shard_abort: rank %d of %d: ncclCommAbort has not come back in time (FFQ_SHARD_ABORT_S; a peer's process is gone?); it goes on "
                                        "on a thread of its own and holds the device meanwhile -- the shard is leaked, leave with _exit", s->rank, s->world);
         }
     }
     mark_other(s->c);
-    const bool drained = shard_drained(s, 10.0);
+    const bool drained = shard_drained(s, 30.0);
     if (sh_debug()) fprintf(stderr, "[ffq shard %d/%d] abort: streams %s after %.2f s\n", s->rank, s->world, drained ? "drained" : "NOT drained", since());
     if (drained) return FFQ_OK;
     s->leaked = true;
-    return fail(FFQ_E_TIMEOUT, "ffq_shard_abort: rank %d of %d: the shard's streams did not drain within 10 s of the abort", s->rank, s->world);
+    return fail(FFQ_E_TIMEOUT, "ffq_shard_abort: rank %d of %d: the shard's streams did not drain within 30 s of the abort", s->rank, s->world);
 }
 
 static int shard_common(ffq_ctx *c, int rank, int world, const int64_t *bounds, int64_t tail_bytes, int64_t head_bytes, ffq_shard **out)

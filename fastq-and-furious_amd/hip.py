@@ -357,6 +357,11 @@ def lib():
     return _lib
 
 
+def last_error():
+    """the calling thread's last error text (ffq_last_error)"""
+    return lib().ffq_last_error().decode("utf-8", "replace")
+
+
 def check(rc, allow=()):
     if rc != OK and rc not in allow:
         msg = lib().ffq_last_error().decode("utf-8", "replace")

@@ -276,6 +276,20 @@ def native_unique_id(dist, device, group=None):
     return bytes(t.cpu().numpy().tobytes())
 
 
+def abort_together(dist, group, shards):
+    """After hip.FFQTimeout: the ranks meet over the process group FIRST, then every one aborts its communicators.  A
+    collective that does not come back does so on every rank, but not at the same instant -- each rank's deadline runs from
+    its own stage -- and a rank whose ncclCommAbort starts after its peers have already torn THEIR ends down waits in RCCL's
+    teardown as it does for a peer whose process is gone (seen at world 8, tests/multigpu_worker.py: seven ranks through in
+    1.1 s, the one that tripped a second later still in ncclCommAbort after 30).  A peer that never reports (its process is
+    gone) fails the meeting instead -- RuntimeError, nothing aborted, leave with _exit.  -> whether every shard drained."""
+    try:
+        dist.barrier(group=group)
+    except Exception as e:          # (gloo: connection reset / timeout)
+        raise RuntimeError("the step did not come back and a peer did not report its own tripped step over the process group: %s" % (e,))
+    return all([sh.abort() for sh in shards])
+
+
 def check_bounds(bounds, world, size):
     """A caller's cut points of a file: world + 1 offsets, not decreasing, inside [0, size].  (Any byte will do: a rank's
     view is read from the file into an aligned device buffer whatever its file offset -- tests/test_fileshard.py cuts inside
@@ -529,7 +543,7 @@ class FileShard:
         GPU, a NEW communicator -- one, for the serial step -- over the process group, the range loaded again."""
         dist, dev, group = self._dist
         self.recovered = str(err)
-        if not self.sh.abort():
+        if not abort_together(dist, group, [self.sh]):
             # (ncclCommAbort itself is still busy -- a peer's process is gone -- and holds the device: nothing to rebuild on)
             raise RuntimeError("the step did not come back (%s) and the communicator's abort is still busy: %s"
                                % (err, _hip.lib().ffq_last_error().decode("utf-8", "replace")))

@@ -7,7 +7,7 @@ import numpy as np
 
 from . import hip as _hip
 from .sharded import (DistTransport, HostShardScanner, LocalTransport, NativeShardScanner, SoloTransport, halo_sizes,
-                      native_unique_id)
+                      abort_together, native_unique_id)
 
 DENSE_TEMPLATE = b"@foo#2\nAATTGCCG\n+\n3425@!#!\n"      # /root/reference/tests.py:8-35, single-line variant: 27 bytes
 
@@ -195,8 +195,11 @@ class SyntheticShard:
         self.recovered = str(err)
         lanes = self._lanes or [self.scanner]
         n_lanes = len(lanes) if self._lanes else 0
-        drained = [ln.abort() for ln in lanes]
-        if not all(drained):
+        if self._solo_rccl:
+            drained = all([ln.abort() for ln in lanes])
+        else:
+            drained = abort_together(self.transport, self._ctl_group, lanes)      # (the ranks meet first: sharded.abort_together)
+        if not drained:
             # ncclCommAbort itself is still busy (a peer's process is gone): it holds the device, every further HIP call of this
             # process would wait behind it -- nothing to rebuild on; the caller reports and leaves (bench.py: an "error" line, _exit)
             raise RuntimeError("the step did not come back (%s) and the communicators' abort is still busy: %s"

@@ -536,10 +536,13 @@ int  ffq_shard_set_serial(ffq_shard *s, int on);               /* between steps,
 /* After FFQ_E_TIMEOUT (or at any time): ncclCommAbort on the shard's communicators -- kernels of a collective that
  * waits for a peer leave --, an injected stall released, the shard's streams drained with a deadline of their own.
  * FFQ_OK: drained; FFQ_E_TIMEOUT: something still runs (ffq_shard_destroy then leaks the shard's device memory
- * rather than wait for ever) -- in particular ncclCommAbort ITSELF, which runs on a thread of its own with a 10 s
- * deadline here: with a peer whose process is gone RCCL's teardown waits on its sockets for minutes and holds the
- * device's runtime meanwhile (every other HIP call of the process waits behind it); the caller has its error in
- * time and should leave with _exit.  Only ffq_shard_destroy may follow.                                         */
+ * rather than wait for ever) -- in particular ncclCommAbort ITSELF, which runs on a thread of its own with a deadline
+ * (FFQ_SHARD_ABORT_S, default 30 s) here: with a peer whose process is gone RCCL's teardown waits on its sockets for
+ * minutes and holds the device's runtime meanwhile (every other HIP call of the process waits behind it); the caller
+ * has its error in time and should leave with _exit.  The same wait meets a rank that aborts AFTER its peers have
+ * torn their ends down: the ranks' deadlines do not run out at the same instant, so a host lets them MEET over its
+ * own control plane first and abort together (sharded.abort_together: a barrier on the process group, then this
+ * call; a peer that never reports fails the meeting and nothing is aborted).  Only ffq_shard_destroy may follow. */
 int  ffq_shard_abort(ffq_shard *s);
 /* diagnostics: the NEXT step of this shard hangs at `stage` (FFQ_SHARD_STAGE_*) for up to `seconds` -- a one-lane
  * kernel on that stage's stream that waits for a host flag (released by ffq_shard_abort / _destroy) -- so that the

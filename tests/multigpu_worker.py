@@ -178,7 +178,8 @@ def main(scratch):
         assert "stage 'gather'" in str(e) and "transport rccl" in str(e), str(e)
         assert 3.5 < waited < 30, waited
         report["watchdog"] = {"message": str(e), "waited_s": waited, "stage": sc.info()["last_stage"]}
-    assert sc.abort(), "rank %d: the streams did not drain after the abort" % rank
+    # (the ranks meet over gloo, THEN abort: a rank that aborts after its peers have torn their ends down waits in RCCL)
+    assert sharded.abort_together(dist, ctl, [sc]), "rank %d: the abort did not complete: %s" % (rank, hip.last_error())
     sc.close()
     ext[:tail].zero_()
     ext[tail + hi - lo:].zero_()
@@ -207,6 +208,20 @@ def main(scratch):
         rows = np.array([list(p) for p in it], dtype=np.int64).reshape(-1, 6)
         np.save(os.path.join(scratch, "file_rows_%d_%d.npy" % (len(kw), rank)), rows)
         report["file%d" % len(kw)] = {"base": it.record_base, "total": it.total_records, "n": it.n_records}
+    # ---- FileShard's own recovery: the ranks found each other through torch.distributed, the last rank's gather stalls, every
+    # rank's scan() trips, aborts, draws a new id over the side group and takes the serial step by itself
+    # (a world of one has no communicator to replace: its FileShard is the in-process one)
+    fs = sharded.FileShard(ctx, fpath, rank, world, group=ctl)
+    if world > 1:
+        fs.sh.set_timeout(4.0)
+        if rank == world - 1:
+            fs.sh.inject_stall(hip.STAGE_GATHER, 60.0)
+    res = fs.scan()
+    if world > 1:
+        assert fs.recovered and "stage 'gather'" in fs.recovered and fs.sh.info()["mode"] == "serial", fs.recovered
+    np.save(os.path.join(scratch, "file_rows_recovered_%d.npy" % rank), fs.rows())
+    fs.close()
+    dist.barrier()
     with open(os.path.join(scratch, "report_%d.json" % rank), "w") as fh:
         json.dump(report, fh)
     dist.barrier()
@@ -257,6 +272,8 @@ def check(scratch, world):
     got = np.concatenate([np.load(os.path.join(scratch, "rows_recovered_%d.npy" % r)) for r in range(world)])
     assert got.shape == fwant.shape and (got == fwant).all(), "after the watchdog trip: the serial step's rows differ from the oracle's"
     assert all(rep["watchdog"]["stage"] == "gather" for rep in reports)
+    got = np.concatenate([np.load(os.path.join(scratch, "file_rows_recovered_%d.npy" % r)) for r in range(world)])
+    assert got.shape == fwant.shape and (got == fwant).all(), "FileShard after its own recovery: rows over the ranks differ from the oracle's"
     for k in (0, 2, 3):
         got = np.concatenate([np.load(os.path.join(scratch, "file_rows_%d_%d.npy" % (k, r))) for r in range(world)])
         assert got.shape == fwant.shape and (got == fwant).all(), "file-backed ranges: rows over the ranks differ from the oracle's"

@@ -61,7 +61,7 @@ t0 = time.perf_counter()
 drained = sc.abort()
 took = time.perf_counter() - t0
 print("rank 0: abort -> %s in %.1f s (%s)" % (drained, took, "" if drained else hip.lib().ffq_last_error().decode()), flush=True)
-assert took < 25, took
+assert took < 50, took
 sc.close()                       # (a leaked shard: host objects only)
 if drained:
     ctx.close()
