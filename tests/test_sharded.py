@@ -470,6 +470,56 @@ def test_a_failing_rank_does_not_strand_its_peers_gloo(tmp_path):
         assert msgs[r].startswith("FFQError -6") and "rank 1" in msgs[r], msgs
 
 
+def _meeting_worker(rank, world, port, tmpdir, who_leaves):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime, time
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    import fastqandfurious_amd  # noqa: F401
+    from fastqandfurious_amd import sharded
+
+    class Tripped:          # (a shard whose step ran into the watchdog: abort() is what is left)
+        aborted_at = None
+
+        def abort(self):
+            self.aborted_at = time.time()
+            return True
+    sh = Tripped()
+    if rank == who_leaves:
+        os._exit(0)                         # gone before the meeting: no goodbye
+    if rank == world - 1:
+        time.sleep(1.5)                     # the rank whose deadline ran out later
+    t_in = time.time()
+    try:
+        ok = sharded.abort_together(dist, None, [sh])
+        msg = "ok %s %.3f %.3f" % (ok, t_in, sh.aborted_at)
+    except RuntimeError as e:
+        msg = "RuntimeError %s: %s" % (sh.aborted_at, e)
+    with open(os.path.join(tmpdir, "meet_%d.txt" % rank), "w") as fh:
+        fh.write(msg)
+    os._exit(0)                             # (a group whose peer is gone does not shut down cleanly)
+
+
+@pytest.mark.timeout(300)
+def test_ranks_meet_before_they_abort_gloo(tmp_path):
+    """sharded.abort_together: nobody aborts before the LAST rank's step has tripped (a rank that aborts after its peers tore
+    their ends down waits in RCCL's teardown: world 8), and a peer that never reports fails the meeting
+    with nothing aborted."""
+    d = str(tmp_path)
+    mp.spawn(_meeting_worker, args=(3, _free_port(), d, -1), nprocs=3, join=True)
+    rows = [open(os.path.join(d, "meet_%d.txt" % r)).read().split() for r in range(3)]
+    assert all(r[0] == "ok" and r[1] == "True" for r in rows), rows
+    late_in = float(rows[2][2])
+    assert all(float(r[3]) >= late_in for r in rows), rows          # every abort after the late rank arrived
+    for f in os.listdir(d):
+        os.remove(os.path.join(d, f))
+    mp.spawn(_meeting_worker, args=(3, _free_port(), d, 1), nprocs=3, join=True)
+    for r in (0, 2):
+        msg = open(os.path.join(d, "meet_%d.txt" % r)).read()
+        assert msg.startswith("RuntimeError None") and "did not report" in msg, msg
+
+
 def test_shard_bounds(pkg):
     from fastqandfurious_amd import sharded
     b = sharded.shard_bounds(1000003, 4)
