@@ -1317,7 +1317,9 @@ extern "C" int ffq_shard_scan_fd_slabs(ffq_shard *s, int fd, int64_t slab_bytes,
         if (r) { s->local_fail = r; s->local_msg = ffq_last_error(); sh_words_failed(s->v, h); h[8] = h[9] = h[10] = 0; return FFQ_OK; }
         s->v = sh_view(s, tail, head);                                 // (the look-ahead the pass ended with)
         int64_t cut[6];
-        if ((r = ffq_table_cut(c, d_table, nrows, sh_lo_bound(s->v), sh_hi_bound(s->v), cut))) return r;
+        if ((r = ffq_table_cut(c, d_table, nrows, sh_lo_bound(s->v), sh_hi_bound(s->v), cut))) {     // (the peers hear of it in the gather)
+            s->local_fail = r; s->local_msg = ffq_last_error(); sh_words_failed(s->v, h); h[8] = h[9] = h[10] = 0; return FFQ_OK;
+        }
         ShScanFacts f;
         f.n = nrows; f.i0 = cut[0]; f.i1 = cut[1]; f.p_i0 = cut[2]; f.p_i1 = cut[3]; f.q1 = cut[5];
         f.end_state = last.end_state; f.last_status = last.last_status; f.last_pos0 = last.last_pos[0];
