@@ -1109,6 +1109,15 @@ def main():
     dry = os.environ.get("FFQ_BENCH_DRY_MULTI") == "1"
     if dry or one_gpu:
         local_rank = 0
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        # (a line that says so, not a traceback the driver has to dig for)
+        if rank == 0:
+            print(json.dumps({"metric": "GB/s FASTQ parsed", "value": None, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+                              "config": {"workload": args.workload},
+                              "error": "rank %d has LOCAL_RANK %d but this process sees %d GPU(s): one process per GPU needs every rank's device visible"
+                                       % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0)}), flush=True)
+        raise SystemExit(1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
