@@ -1095,9 +1095,21 @@ def main():
         # no launcher: start one rank per GPU ourselves (the driver's own command line does the same)
         import socket
         import subprocess
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
+        import random
+        port = None
+        for _ in range(200):
+            # (below the kernel's ephemeral range: a bind-to-0 port can be taken by anybody's outgoing connection before the
+            # launcher listens on it)
+            cand = random.randrange(15000, 30000)
+            with socket.socket() as so:
+                try:
+                    so.bind(("127.0.0.1", cand))
+                except OSError:
+                    continue
+            port = cand
+            break
+        if port is None:
+            raise SystemExit("no free rendezvous port between 15000 and 30000")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))

@@ -11,7 +11,6 @@ Semantics matched: /root/reference/src/fastqandfurious.py:251-279 (the record ch
 ranges: every rank's rows must be exactly the rows of the one-range scan that fall into its range).
 """
 import os
-import socket
 import subprocess
 import sys
 import threading
@@ -79,10 +78,7 @@ def test_config5_eight_logical_ranges_full_size(gpu_ctx, native):
     torch.cuda.empty_cache()
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+from _ports import free_port as _free_port      # noqa: E402  (below the ephemeral range: tests/_ports.py)
 
 
 def _run_worker(mode, timeout):

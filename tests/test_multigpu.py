@@ -10,7 +10,6 @@ scan of the whole stream and with the run of the same ranges as k logical ranks 
 rounds), asserts transport == "rccl" and handoff_bytes > 0.  The invariance being tested is the reference's own:
 /root/reference/tests.py:219-226 (the entries do not depend on how the stream is cut into buffers)."""
 import os
-import socket
 import subprocess
 import sys
 
@@ -20,10 +19,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+from _ports import free_port as _free_port      # noqa: E402  (below the ephemeral range: tests/_ports.py)
 
 
 def _launch(world, scratch, timeout, one_gpu=False):

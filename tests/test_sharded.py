@@ -14,7 +14,6 @@ until a record fits (:274-279).
 
 Concatenated shard rows must equal the oracle's single-range table, bit for bit."""
 import os
-import socket
 import sys
 import threading
 
@@ -372,12 +371,7 @@ def _worker(rank, world, port, kind, tmpdir):
         dist.destroy_process_group()
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from _ports import free_port as _free_port      # noqa: E402  (below the ephemeral range: tests/_ports.py)
 
 
 @pytest.mark.parametrize("world,kind", ((2, "single"), (2, "wrapped"), (3, "wrapped"), (2, "long"), (3, "tricky")))
