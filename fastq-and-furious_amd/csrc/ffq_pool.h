@@ -3,6 +3,8 @@
 // entry points, ffq_scan_host) run on them in parallel.
 #pragma once
 #include <errno.h>
+#include <sched.h>
+#include <stdio.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -58,10 +60,44 @@ struct ReadPool {
         }
         return got;
     }
-    void start(int n)
+    // The CPUs next to a PCI device ("0000:8b:00.0": /sys/bus/pci/devices/<bdf>/local_cpulist), of those this process may
+    // run on.  The boxes here have two sockets with four GPUs each: helpers that run on the OTHER socket write the pinned
+    // slots (which the runtime puts on the GPU's node) across the socket link while the DMA engine reads them -- the file
+    // loader then runs at 37-41 GB/s instead of 51 (tools/load_threads.py, profiles/r06_probes/loader_numa.txt).
+    static bool local_cpus(const char *bdf, cpu_set_t *out)
     {
+        CPU_ZERO(out);
+        char path[160], buf[1024];
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+        fclose(f);
+        if (!ok) return false;
+        cpu_set_t mine;
+        CPU_ZERO(&mine);
+        if (sched_getaffinity(0, sizeof mine, &mine) != 0) return false;
+        int n = 0;
+        for (const char *p = buf; *p && *p != '\n';) {                     // "0-63,128-191"
+            char *e = nullptr;
+            long a = strtol(p, &e, 10), b = a;
+            if (e == p) break;
+            p = e;
+            if (*p == '-') { b = strtol(p + 1, &e, 10); if (e == p + 1) break; p = e; }
+            for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+                if (c >= 0 && CPU_ISSET((int)c, &mine)) { CPU_SET((int)c, out); n++; }
+            if (*p == ',') p++;
+        }
+        return n >= 2;
+    }
+    void start(int n, const cpu_set_t *cpus = nullptr)
+    {
+        cpu_set_t set;
+        const bool bind = cpus != nullptr;
+        if (bind) set = *cpus;
         for (int i = 0; i < n; i++)
-            th.emplace_back([this] {
+            th.emplace_back([this, bind, set] {
+                if (bind) (void)sched_setaffinity(0, sizeof set, &set);    // (this thread only; a refusal changes nothing)
                 for (;;) {
                     Job j;
                     {

@@ -122,8 +122,9 @@ static void stream_cache_drop(ffq_ctx *c)
     c->stream_cache = nullptr;
 }
 
-static int streambufs_alloc_slots(StreamBufs *b, int64_t room)
+static int streambufs_alloc_slots(ffq_ctx *c, StreamBufs *b, int64_t room)
 {
+    NearGpu near(c);                   // (the pinned slots on the GPU's node: ffq_hip.hip)
     for (auto &s : b->slot) {
         if (hipHostMalloc((void **)&s.h, (size_t)(room + b->fbufsize + 16), hipHostMallocDefault) != hipSuccess ||
             hipMalloc((void **)&s.d, (size_t)(room + b->fbufsize + 16)) != hipSuccess)
@@ -722,6 +723,7 @@ static void stream_free(ffq_stream *s)
 static int stream_alloc_tab(ffq_stream *s, int64_t rows)
 {
     StreamBufs *b = s->b;
+    NearGpu near(s->c);
     if (rows > b->tab_cap) {
         if (b->htab) (void)hipHostFree(b->htab);
         (void)hipFree(b->dtab);
@@ -811,7 +813,7 @@ static int stream_grow_room(ffq_stream *s, int64_t need)
     StreamSlot old[STREAM_SLOTS];
     for (int i = 0; i < STREAM_SLOTS; i++) { old[i] = b->slot[i]; b->slot[i].h = nullptr; b->slot[i].d = nullptr; }
     const int64_t old_room = b->room;
-    if (!rc) rc = streambufs_alloc_slots(b, room);
+    if (!rc) rc = streambufs_alloc_slots(s->c, b, room);
     if (!rc) {
         // chunks [released, produced) are alive: the one being carried from (cur, all of its fill)
         // and the ones read ahead (their chunk bytes)
@@ -884,7 +886,7 @@ static int stream_open_impl(ffq_ctx *c, int src, int fd, int64_t fbufsize, uint3
             for (auto &ev : sl.copied)
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e != hipSuccess) rc = fail(FFQ_E_HIP, "ffq_stream_open: %s", hipGetErrorString(e));
-        if (!rc) rc = streambufs_alloc_slots(b, 1 << 20);
+        if (!rc) rc = streambufs_alloc_slots(c, b, 1 << 20);
     }
     if (!rc && !(b->pool = ctx_pool(c))) rc = fail(FFQ_E_NOMEM, "out of host memory");
     s->b = b;
