@@ -399,7 +399,10 @@ int  ffq_stream_push(ffq_stream *s, int64_t n, int eof);
 /* Bytes [pos, pos + n_bytes) of the file behind fd into device memory (read(), fastqandfurious.py:30-36, for a range
  * that stays resident): pread in slices by the context's helper threads into pinned slots, each slot over the link in
  * two halves on two copy streams while the next is read.  Returns when the bytes are in d_dst; *n_loaded < n_bytes:
- * the file ended there.  The descriptor's position is not moved.                                                  */
+ * the file ended there.  The descriptor's position is not moved.  The helper threads (FFQ_POOL_THREADS, default 16) run
+ * on the CPUs next to the GPU (/sys/bus/pci/devices/<bdf>/local_cpulist within the process's own affinity) and the
+ * pinned slots are allocated from there: on a two-socket host the other socket costs a fifth of the rate
+ * (FFQ_POOL_AFFINITY=0: nothing is bound; FFQ_POOL_DEBUG=1 says what was done).                                   */
 int  ffq_load_fd(ffq_ctx *ctx, int fd, int64_t pos, int64_t n_bytes, void *d_dst, int64_t *n_loaded);
 
 /* ---- synthetic FASTQ generators (bench / test inputs) -----
