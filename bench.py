@@ -511,7 +511,7 @@ def pmc_traffic(workload, kernel="k_scan_lines<"):
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_fetch_write.json"))):
-        if workload.replace("-", "") not in os.path.basename(os.path.dirname(f)).replace("_", "").replace("-", ""):
+        if os.path.basename(os.path.dirname(f)).split("_", 2)[-1] != workload:      # (rNN_x_<workload>, exactly)
             continue
         try:
             d = json.load(open(f))
