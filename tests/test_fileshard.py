@@ -307,6 +307,49 @@ def test_load_fd_and_short_file(gpu_ctx, shm_file):
         sh.close()
 
 
+_AFFINITY_PROBE = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import fastqandfurious_amd
+from fastqandfurious_amd import hip
+before = sorted(os.sched_getaffinity(0))
+ctx = hip.Context(0)
+fd = os.open(sys.argv[1], os.O_RDONLY)
+n = os.fstat(fd).st_size
+d = ctx.dev_alloc(n + 64)
+assert ctx.load_fd(fd, 0, n, d) == n
+back = np.empty(n, dtype=np.uint8)
+ctx.d2h(back, d)
+assert (back == np.fromfile(sys.argv[1], dtype=np.uint8)).all()
+assert sorted(os.sched_getaffinity(0)) == before, "the calling thread's affinity was changed"
+print("probe ok")
+"""
+
+
+@pytest.mark.parametrize("affinity", ("1", "0"))
+def test_loader_helpers_next_to_the_gpu(shm_file, affinity):
+    """The loader's helper threads bind themselves to the CPUs next to the GPU (sysfs local_cpulist; two-socket hosts lose a
+    fifth of the rate on the other socket: profiles/r06_probes/loader_numa.txt) and the pinned slots are allocated from there;
+    FFQ_POOL_AFFINITY=0 switches it off.  Either way: the same bytes, the CALLER's affinity untouched, and FFQ_POOL_DEBUG
+    says what was done (a host without that sysfs entry: "not bound", nothing else changes)."""
+    import subprocess
+    import sys
+    from fastqandfurious_amd import synth
+    data = synth.single(0, 120000, seed=5)                     # 38 MB: two slots
+    path = shm_file(data)
+    env = dict(os.environ, FFQ_POOL_DEBUG="1", FFQ_POOL_AFFINITY=affinity)
+    r = subprocess.run([sys.executable, "-c", _AFFINITY_PROBE % os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "probe ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stderr.splitlines() if ln.startswith("[ffq pool]")]
+    assert len(lines) == 1, r.stderr[-2000:]
+    if affinity == "0":
+        assert "not bound" in lines[0], lines
+    else:
+        assert "next to the GPU" in lines[0] or "not bound" in lines[0], lines
+
+
 @pytest.mark.parametrize("kind,world", (("wrapped", 3), ("long", 2), ("tricky", 8), ("small", 5)))
 def test_device_step_over_a_hosted_transport(gpu_ctx, oracle, shm_file, kind, world):
     """ffq_shard_create_hosted: the device step (buffers in HBM, scan and words on the device) over the caller's own
