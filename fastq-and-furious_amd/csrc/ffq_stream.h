@@ -73,6 +73,7 @@ struct StreamBufs {
     StreamSlot slot[STREAM_SLOTS];
     hipStream_t cs[2] = {nullptr, nullptr};      // copy streams of the chunks: a chunk goes over in two halves, one
                                                  // per stream (two DMA engines: one did 41-45 GB/s of the link's ~55)
+    bool one_copy_stream = false;                // ... unless much goes BACK as well (stream_copy_chunk)
     int64_t *dtab = nullptr, *htab = nullptr;
     int64_t tab_cap = 0;
     int8_t *dqual = nullptr, *hqual = nullptr;
@@ -138,12 +139,17 @@ static int streambufs_alloc_slots(ffq_ctx *c, StreamBufs *b, int64_t room)
 // the H2D copy of a slot's chunk: two halves, two streams, two events
 static hipError_t stream_copy_chunk(StreamBufs *b, StreamSlot &sl, int64_t got)
 {
-    const int64_t half = ((got / 2) + 4095) & ~(int64_t)4095;
+    // (one stream for a stream that DECODES: two copy streams in and the copies back on a third share the copy engines --
+    // 42.9 GB/s in + 28.7 back against 54.7 + 36.6 with one stream in, tools/link_duplex.py; the stream front end with the
+    // decode 34-36 -> 43-45 GB/s, without it 54 -> 47-50, so a plain stream keeps its two)
+    const bool one = b->one_copy_stream;
+    const int64_t half = one ? got : ((got / 2) + 4095) & ~(int64_t)4095;
     hipError_t e = hipSuccess;
     for (int h = 0; h < 2 && e == hipSuccess; h++) {
         const int64_t a = h ? std::min(half, got) : 0, z = h ? got : std::min(half, got);
-        if (z > a) e = hipMemcpyAsync(sl.d + b->room + a, sl.h + b->room + a, (size_t)(z - a), hipMemcpyHostToDevice, b->cs[h]);
-        if (e == hipSuccess) e = hipEventRecord(sl.copied[h], b->cs[h]);
+        hipStream_t st = b->cs[one ? 0 : h];
+        if (z > a) e = hipMemcpyAsync(sl.d + b->room + a, sl.h + b->room + a, (size_t)(z - a), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(sl.copied[h], st);
     }
     return e;
 }
@@ -889,6 +895,10 @@ static int stream_open_impl(ffq_ctx *c, int src, int fd, int64_t fbufsize, uint3
         if (!rc) rc = streambufs_alloc_slots(c, b, 1 << 20);
     }
     if (!rc && !(b->pool = ctx_pool(c))) rc = fail(FFQ_E_NOMEM, "out of host memory");
+    {
+        const char *e1 = getenv("FFQ_STREAM_ONE_COPY_STREAM");                 // (measurements: 0 / 1 whatever the stream does)
+        b->one_copy_stream = e1 ? atoi(e1) != 0 : (flags & FFQ_F_DECODE_QUAL) != 0;
+    }
     s->b = b;
     if (!rc) rc = stream_alloc_tab(s, fbufsize / 64 + 1024);
     if (rc) { stream_free(s); return rc; }

@@ -32,3 +32,53 @@ for name, a, b, f in (("host -> device alone", True, False, 1.0), ("device -> ho
     best = min(run(a, b, f) for _ in range(5))
     moved = (n if a else 0) + (int(n * f) if b else 0)
     print("%-62s %6.2f ms  in %5.1f GB/s  total %5.1f GB/s" % (name, best * 1e3, (n / best / 1e9) if a else 0.0, moved / best / 1e9), flush=True)
+
+# ---- the same bytes as the stream front end moves them: 16 MiB chunks in, each in two halves on TWO streams (as the loader
+# does: one engine gives 41-45 GB/s), and per chunk 11 MB back on a third -- by the copy engine, or by a KERNEL that writes
+# the pinned memory itself
+piece = 16 << 20
+back = int(piece * 0.67)
+s3 = torch.cuda.Stream()
+
+
+def chunked(two_in_streams, back_mode):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n // piece):
+        a = k * piece
+        if two_in_streams:
+            with torch.cuda.stream(s1):
+                d_in[a:a + piece // 2].copy_(h_in[a:a + piece // 2], non_blocking=True)
+            with torch.cuda.stream(s2):
+                d_in[a + piece // 2:a + piece].copy_(h_in[a + piece // 2:a + piece], non_blocking=True)
+        else:
+            with torch.cuda.stream(s1):
+                d_in[a:a + piece].copy_(h_in[a:a + piece], non_blocking=True)
+        if back_mode:
+            with torch.cuda.stream(s3):
+                if back_mode == "engine":
+                    h_out[a:a + back].copy_(d_out[a:a + back], non_blocking=True)
+                else:
+                    h_out_dev[a:a + back].copy_(d_out[a:a + back])          # a device kernel writing host-mapped memory
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+# the pinned output buffer as a DEVICE tensor (its pages are mapped into the GPU's address space)
+h_out_dev = None
+try:
+    import ctypes
+    class _V:
+        pass
+    v = _V()
+    v.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (h_out.data_ptr(), False), "version": 2}
+    h_out_dev = torch.as_tensor(v, device="cuda")
+except Exception as e:      # noqa: BLE001
+    print("no device view of the pinned buffer:", e)
+for name, two, mode in (("chunks in on one stream, nothing back", False, None), ("chunks in on two streams, nothing back", True, None),
+                        ("one stream in, copy engine back", False, "engine"), ("two streams in, copy engine back", True, "engine"),
+                        ("one stream in, kernel back", False, "kernel"), ("two streams in, kernel back", True, "kernel")):
+    if mode == "kernel" and h_out_dev is None:
+        continue
+    best = min(chunked(two, mode) for _ in range(4))
+    print("%-45s %6.2f ms  in %5.1f GB/s%s" % (name, best * 1e3, n / best / 1e9, ("  back %5.1f GB/s" % (back * (n // piece) / best / 1e9)) if mode else ""), flush=True)
