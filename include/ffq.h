@@ -328,7 +328,10 @@ void ffq_stream_close(ffq_stream *s);
  * should leave it, as the reference's loop does.  A descriptor that cannot seek (a pipe) is read
  * behind poll(): closing the stream never waits for a writer that keeps the pipe open and idle, and a
  * chunk is handed over short -- which is not the end of the stream -- when nothing more has arrived
- * for 50 ms.                                                                                       */
+ * for 50 ms.  A chunk comes in over the link in two halves on two copy streams (two copy engines);
+ * a stream that decodes -- half as many bytes go back as come in -- uses one, the engines are
+ * shared between the directions (FFQ_STREAM_ONE_COPY_STREAM = 0 / 1 forces either; FFQ_STREAM_PROF=1
+ * prints where a stream's time went when it closes).                                               */
 int  ffq_stream_open2(ffq_ctx *ctx, int fd, int64_t fbufsize, uint32_t flags, int qual_add, int64_t start,
                       ffq_stream **out);
 int  ffq_stream_quals(ffq_stream *s, const int8_t **h_qual, const int64_t **h_qoff, int64_t *n_qual_bytes);
