@@ -253,6 +253,38 @@ def test_local_ranks_oracle_engine(oracle, pkg, kind, world, kw):
         assert any(r[0].rounds > 0 for r in res)
 
 
+@pytest.mark.parametrize("block", range(6))
+def test_local_ranks_oracle_engine_random_streams(oracle, pkg, block):
+    """The host step's protocol (csrc/ffq_shard_host.h through HostShardScanner) over seeded random streams, on the CPU: records
+    of random lengths, wrapped or not, a few bytes turned into newlines / '@' / '+' or cut out (tests/test_gpu_parity.mutate: the
+    hostile inputs the kernels are stressed with), cut into 2-7 ranges at random 16-byte aligned points with random halos of
+    16 ... 4096 bytes -- rows of every rank against the single-range scan, stream errors with the oracle's text on every rank.
+    (The device step over the same kind of input: tools/stress_fileshards.py, tools/stress_rccl.py on the GPU box.)"""
+    import test_gpu_parity as T
+    for seed in range(block * 6, block * 6 + 6):
+        rng = np.random.default_rng(77000 + seed)
+        lo, hi = ((100, 160), (20, 60), (250, 400), (1, 30), (800, 2500))[seed % 5]
+        nrec = int(rng.integers(100, 1500)) if hi < 800 else int(rng.integers(30, 200))
+        data = T.random_records(rng, nrec, lo, hi, wrap=int(rng.integers(60, 101)) if seed % 2 else 0, repeat_hdr=bool(seed & 4))
+        data = T.mutate(rng, data, (0, 1, 3, 8)[(seed // 5) % 4])
+        if seed % 3 == 0:
+            data = data[:len(data) - int(rng.integers(1, 200))]
+        stream = np.frombuffer(bytes(data), dtype=np.uint8)
+        want, err = expected(oracle, stream)
+        world = int(rng.integers(2, 8))
+        cuts = sorted(int(x) // 16 * 16 for x in rng.integers(0, stream.size + 1, world - 1))
+        bounds = [0] + cuts + [int(stream.size)]
+        kw = dict(tail_bytes=int(rng.integers(1, 257)) * 16, head_bytes=int(rng.integers(1, 257)) * 16)
+        t = torch.from_numpy(stream.copy())
+        if err is None:
+            res = run_local(t, bounds, lambda r: HostEngine(), lanes=bool(seed & 1), **kw)
+            check_rows(res, bounds, want)
+        else:
+            with pytest.raises(ValueError) as ei:
+                run_local(t, bounds, lambda r: HostEngine(), **kw)
+            assert str(ei.value).startswith(err), (seed, str(ei.value), err)
+
+
 @pytest.mark.parametrize("kind", ("truncated", "cut-header", "invalid"))
 @pytest.mark.parametrize("world", (2, 3, 8))
 def test_local_ranks_stream_errors(oracle, pkg, kind, world):
