@@ -405,7 +405,7 @@ def iterator_rates(ctx, sample_u8, n_gz, budget_s=3.0):
            "what": "readfastq_iter(fh, fbufsize, entryfunc, GPU scanner): Python tuples per second, one host core; "
                    "plain = %d-byte file in %s, gzip = its first %d bytes at level 1 (ONE member: inflated by gz_threads threads, "
                    "csrc/ffq_pgz.h), bgzf = the same bytes in BGZF members (inflated side by side); *_stream_gb_s = decompressed GB/s of the stream front end alone (tables, no "
-                   "tuples)" % (sample_u8.size, d, n_gz)}
+                   "tuples); bgzf_range_shard_gb_s = the BGZF file as one rank's range shard (sharded.BgzfFileShard: inflate + link + step)" % (sample_u8.size, d, n_gz)}
     def table_rate(path):
         # decompressed GB/s through the stream front end alone: offset tables out, no Python object per record
         best = None
@@ -425,6 +425,22 @@ def iterator_rates(ctx, sample_u8, n_gz, budget_s=3.0):
         out["gzip_stream_gb_s"] = table_rate(gz)
         out["bgzf_stream_gb_s"] = table_rate(bg)
         out["gz_threads"] = int(os.environ.get("FFQ_GZ_THREADS", "0")) or min(os.cpu_count() or 1, 32)
+        # the same BGZF file as a RANGE shard (sharded.BgzfFileShard at world 1: members sized, inflated side by side into host
+        # memory, over the link, one sharded step): decompressed GB/s of load + scan, best of 3
+        from fastqandfurious_amd import sharded
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            bsh = sharded.BgzfFileShard(ctx, bg, 0, 1)
+            try:
+                bsh.load()
+                nrec = int(bsh.scan().total_records)
+            finally:
+                bsh.close()
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        assert nrec > 0
+        out["bgzf_range_shard_gb_s"] = round(n_gz / best / 1e9, 3)
         out["gzip_engine"] = hip.gunzip_stats()
         for tag, opener in (("plain", lambda: open(plain, "rb")), ("gzip", lambda: gzip.open(gz, "rb")),
                             ("bgzf", lambda: gzip.open(bg, "rb"))):

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
 #include <cctype>
@@ -2284,5 +2285,6 @@ extern "C" int ffq_selftest(ffq_ctx *c)
 }
 
 #include "ffq_stream.h"
+#include "ffq_bgzf.h"
 #include "ffq_shard.h"
 #include "ffq_shard_host.h"

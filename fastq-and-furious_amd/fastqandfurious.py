@@ -567,7 +567,12 @@ class RangeEntries:
         sh, entryfunc = self._sh, self._entryfunc
         mm = None
         try:
-            if self.n_records:
+            if self.n_records and hasattr(sh, "host_bytes"):
+                # (a BGZF shard: the rank's inflated bytes are in host memory, sliced with stream offsets like a map of a plain file)
+                from .sharded import _Shifted
+                base, arr = sh.host_bytes()
+                mm, view = _Shifted(arr, base, as_bytes=True), _Shifted(arr, base)
+            elif self.n_records:
                 mm = mmap.mmap(sh.fd, 0, access=mmap.ACCESS_READ)       # (the page cache holds the range: it was just read)
                 view = memoryview(mm)
             if self.n_records and _pushes_down(entryfunc):
@@ -609,7 +614,8 @@ def readfastq_iter_range(path, rank: int, world: int, entryfunc: typing.Callable
                          start: int = 0, end: typing.Optional[int] = None, batch_rows: int = 1 << 15,
                          tail_bytes: typing.Optional[int] = None, head_bytes: typing.Optional[int] = None,
                          bounds: typing.Optional[typing.Sequence[int]] = None,
-                         slab_bytes: typing.Optional[int] = None) -> RangeEntries:
+                         slab_bytes: typing.Optional[int] = None, bgzf: typing.Optional[bool] = None,
+                         exchange: typing.Optional[typing.Callable] = None) -> RangeEntries:
     """readfastq_iter for ONE FILE read by `world` ranks (one process per GPU): rank `rank` gets the entries whose '@'
     lies in its byte range [S_rank, S_rank+1) of the file, the same objects in the same order the reference's
     iterator (:198-279) yields for them -- the ranks' iterators concatenated ARE readfastq_iter over the whole file.
@@ -623,10 +629,34 @@ def readfastq_iter_range(path, rank: int, world: int, entryfunc: typing.Callable
 
     comm: None (world 1; or torch.distributed's default group hands the communicator id round), 128 bytes of
     ffq_shard_unique_id, or a hip.ShardWorld (logical ranks as threads).  entryfunc_phred: the qualities are decoded
-    on the device with the scan.  Returns a RangeEntries (iterate it; .record_base is the global ordinal)."""
+    on the device with the scan.  Returns a RangeEntries (iterate it; .record_base is the global ordinal).
+
+    A BGZF file (bgzip's output; bgzf=None: recognised by its first member, True / False: said by the caller) is read by
+    ranges too -- the one compressed format that can be: every rank inflates the members that begin in its share of the
+    compressed file, the entries are those of the UNCOMPRESSED stream, what readfastq_iter(gzip.open(path), ...) yields
+    (sharded.BgzfFileShard; exchange: how the ranks tell each other their sizes when comm is not a transport object and
+    torch.distributed is not there).  start / end / bounds / slab_bytes do not apply to it."""
     from . import hip as _hip, sharded as _sharded
     if ctx is None:
         ctx = _hip.default_context()
+    if bgzf is None:
+        bgzf = _sharded.is_bgzf(path)
+    if bgzf:
+        if start or end is not None or bounds is not None or slab_bytes:
+            raise ValueError("readfastq_iter_range: start / end / bounds / slab_bytes do not apply to a BGZF file")
+        kwz = {}
+        if tail_bytes is not None:
+            kwz["tail_bytes"] = tail_bytes
+        if head_bytes is not None:
+            kwz["head_bytes"] = head_bytes
+        sh = _sharded.BgzfFileShard(ctx, path, rank, world, comm=comm, exchange=exchange, **kwz)
+        try:
+            sh.load()
+            sh.scan(decode=entryfunc is entryfunc_phred)
+        except BaseException:
+            sh.close()
+            raise
+        return RangeEntries(sh, entryfunc, batch_rows)
     kw = {}
     if tail_bytes is not None:
         kw["tail_bytes"] = tail_bytes

@@ -55,7 +55,7 @@ SYMBOLS = (
     "ffq_stream_open2", "ffq_stream_quals", "ffq_stream_tell", "ffq_stream_path",
     "ffq_shard_unique_id", "ffq_shard_create", "ffq_shard_create_lane", "ffq_shard_world_create", "ffq_shard_world_abort",
     "ffq_shard_world_destroy", "ffq_shard_create_local", "ffq_shard_destroy", "ffq_shard_halo", "ffq_shard_exchange_halo",
-    "ffq_shard_step_submit", "ffq_shard_step_wait", "ffq_shard_transport", "ffq_shard_self_exchange", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_gunzip_stats", "ffq_stream_open_push",
+    "ffq_shard_step_submit", "ffq_shard_step_wait", "ffq_shard_transport", "ffq_shard_self_exchange", "ffq_stream_open_gzip", "ffq_gunzip_fd", "ffq_gunzip_stats", "ffq_bgzf_range", "ffq_stream_open_push",
     "ffq_stream_push_buffer", "ffq_stream_push", "ffq_scan_fasta_device", "ffq_scan_fasta_host",
     "ffq_synth_single",
     "ffq_synth_wrapped_size", "ffq_synth_wrapped", "ffq_selftest", "ffq_shard_load_fd", "ffq_load_fd",
@@ -304,6 +304,7 @@ def lib():
         L.ffq_gunzip_fd.restype = i64
         L.ffq_gunzip_stats.argtypes = [P(i64)]
         L.ffq_gunzip_stats.restype = None
+        L.ffq_bgzf_range.argtypes = [i32, i64, i64, vp, i64, i32, P(i64), P(i64), P(i64), P(i64)]
         L.ffq_stream_open_push.argtypes = [vp, i64, u32, i32, P(vp)]
         L.ffq_stream_push_buffer.argtypes = [vp, P(vp), P(i64)]
         L.ffq_stream_push.argtypes = [vp, i64, i32]
@@ -1049,6 +1050,18 @@ def gunzip_fd(fd, cap, chunk=16 << 20, threads=0):
     if n < 0:
         check(int(n))
     return out[:n], int(npar.value)
+
+
+def bgzf_range(fd, c_lo, c_hi, out=None, threads=0):
+    """ffq_bgzf_range (host only): the BGZF members whose first byte lies in [c_lo, c_hi) of the file behind fd.
+    out=None: nothing is inflated -> (c_first, c_end, n_bytes, n_members), n_bytes = what the members' trailers promise;
+    out = a writable uint8 array of at least that many bytes: inflated into it, the same tuple.  FFQGzipError (an OSError)
+    for what is not BGZF or does not inflate to its trailer, FFQGzipTruncated (an EOFError) for a file cut short."""
+    cf, ce, no, nm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    check(lib().ffq_bgzf_range(int(fd), int(c_lo), int(c_hi), ctypes.c_void_p(out.ctypes.data) if out is not None else None,
+                               int(out.size) if out is not None else 0, int(threads), ctypes.byref(cf), ctypes.byref(ce),
+                               ctypes.byref(no), ctypes.byref(nm)))
+    return int(cf.value), int(ce.value), int(no.value), int(nm.value)
 
 
 def gunzip_stats():

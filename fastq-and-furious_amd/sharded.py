@@ -410,24 +410,35 @@ class FileShard:
 
     def __init__(self, ctx, path, rank=0, world=1, comm=None, start=0, end=None, tail_bytes=TAIL_BYTES,
                  head_bytes=HEAD_BYTES, device=None, bounds=None, qual_room=None, serial=None, group=None, slab_bytes=None):
-        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
-        # scan(decode=True): bytes of the quality buffer per 16 KiB tile of the view -- hip.SEG_STRIDE (reads of a few hundred
-        # bases in one pass) unless given; hip.INPLACE_STRIDE lets four-line reads of any length decode in one pass as well
-        self.qual_room = int(qual_room) if qual_room else _hip.SEG_STRIDE
-        self._own_fd = not isinstance(path, int)
-        self.fd = os.open(path, os.O_RDONLY) if self._own_fd else path
-        self.path = path
+        self._open(ctx, path, rank, world, qual_room)
         size = os.fstat(self.fd).st_size
         end = size if end is None else min(int(end), size)
         start = min(int(start), end)
         self.bounds = [start + b for b in shard_bounds(end - start, world)]
         if bounds is not None:
             self.bounds = check_bounds(bounds, world, size)
+        self._make_shard(comm, tail_bytes, head_bytes, device, serial, group)
+        env = os.environ.get("FFQ_SHARD_SLAB_BYTES")
+        self._alloc_view(int(slab_bytes) if slab_bytes else (int(env) if env else 0))
+
+    def _open(self, ctx, path, rank, world, qual_room):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         if not 0 <= self.rank < self.world:
             raise ValueError("FileShard: rank %d of %d" % (self.rank, self.world))
-        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        # scan(decode=True): bytes of the quality buffer per 16 KiB tile of the view -- hip.SEG_STRIDE (reads of a few hundred
+        # bases in one pass) unless given; hip.INPLACE_STRIDE lets four-line reads of any length decode in one pass as well
+        self.qual_room = int(qual_room) if qual_room else _hip.SEG_STRIDE
+        self._own_fd = not isinstance(path, int)
+        self.fd = os.open(path, os.O_RDONLY) if self._own_fd else path
+        self.path = path
         self._world_obj = None
         self._dist = None                       # (set: the ranks found each other through torch.distributed -- a watchdog trip can be recovered from)
+        self.sh = None
+
+    def _make_shard(self, comm, tail_bytes, head_bytes, device, serial, group):
+        """self.bounds are there: the shard object of the step over them, on whatever the ranks find each other through."""
+        ctx, rank, world = self.ctx, self.rank, self.world
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         self._halo = (tail_bytes, head_bytes)
         if isinstance(comm, _hip.ShardWorld):
             self.sh = _hip.Shard(ctx, self.bounds, rank, world, tail_bytes, head_bytes, local_world=comm, serial=serial)
@@ -452,8 +463,10 @@ class FileShard:
                                  serial=serial)
         self.tail, self.head = self.sh.halo()
         self.n_view = self.tail + (self.hi - self.lo) + self.head
-        env = os.environ.get("FFQ_SHARD_SLAB_BYTES")
-        self.slab_bytes = int(slab_bytes) if slab_bytes else (int(env) if env else 0)
+
+    def _alloc_view(self, slab_bytes):
+        ctx = self.ctx
+        self.slab_bytes = slab_bytes
         self.d_ext = None
         if not self.slab_bytes:
             try:
@@ -689,6 +702,136 @@ class FileShard:
             self.close()
         except Exception:
             pass
+
+
+def is_bgzf(path_or_fd):
+    """Does the file begin with a BGZF member (bgzip's output: a gzip member whose extra field says how long it is)?"""
+    fd = path_or_fd if isinstance(path_or_fd, int) else os.open(path_or_fd, os.O_RDONLY)
+    try:
+        h = os.pread(fd, 18, 0)
+    finally:
+        if not isinstance(path_or_fd, int):
+            os.close(fd)
+    return len(h) == 18 and h[:4] == b"\x1f\x8b\x08\x04" and h[12:14] == b"BC" and h[14:16] == b"\x02\x00"
+
+
+class _Shifted:
+    """bytes [base, base + len) of a stream held in memory, sliced with STREAM offsets (what a map of the file is for a
+    plain one): view[a:b] -> a memoryview, or, as_bytes, a bytes object."""
+
+    def __init__(self, arr, base, as_bytes=False):
+        self._mv, self._base, self._as_bytes = memoryview(arr), int(base), as_bytes
+
+    def __getitem__(self, sl):
+        v = self._mv[sl.start - self._base:sl.stop - self._base]
+        return v.tobytes() if self._as_bytes else v
+
+    def release(self):
+        pass
+
+    close = release
+
+
+class BgzfFileShard(FileShard):
+    """Rank `rank` of `world`'s share of a BGZF-compressed FASTQ file (bgzip: gzip members of at most 64 KiB that say how
+    long they are -- the one compressed format that can be read by ranges): the members whose first byte lies in the rank's
+    share of the COMPRESSED file are its own; their trailers say how many bytes they hold, one exchange of those numbers gives
+    every rank the cut points of the UNCOMPRESSED stream, the rank inflates its members side by side on the host
+    (ffq_bgzf_range), the bytes go to its GPU, and the ordinary sharded step runs over them -- the halos handed over between
+    the ranks (nothing but a rank's own members is ever inflated).  Rows, ordinals and entries are those of the uncompressed
+    stream, as the reference's loop over gzip.open(...) yields them (/root/reference/src/fastqandfurious.py:241-279,
+    :290-334 automagic_open); the ranks' rows concatenated are the scan of the whole inflated file.
+
+    comm: as FileShard.  exchange: how the ranks tell each other their sizes BEFORE the shard exists -- a callable
+    (list of ints) -> list over ranks of those lists; default: comm.allgather where comm is a transport object, else
+    torch.distributed (all_gather_object over `group`); a world of one needs none.  threads: inflating threads (0: the
+    library's default share of the host's cores).  No slabs: the inflated range must fit the GPU."""
+
+    def __init__(self, ctx, path, rank=0, world=1, comm=None, exchange=None, tail_bytes=TAIL_BYTES, head_bytes=HEAD_BYTES,
+                 device=None, qual_room=None, serial=None, group=None, threads=0):
+        self._open(ctx, path, rank, world, qual_room)
+        try:
+            self.threads = int(threads)
+            size = os.fstat(self.fd).st_size
+            self.c_lo, self.c_hi = size * self.rank // self.world, size * (self.rank + 1) // self.world
+            c_first, c_end, n_bytes, n_members = _hip.bgzf_range(self.fd, self.c_lo, self.c_hi)      # (nothing inflated yet)
+            mine = [c_first, c_end, n_bytes, n_members]
+            if self.world == 1:
+                every = [mine]
+            elif exchange is not None:
+                every = exchange(mine)
+            elif comm is not None and hasattr(comm, "allgather") and hasattr(comm, "exchange"):
+                every = comm.allgather(mine)
+            else:
+                import torch.distributed as dist
+                if not dist.is_initialized() or dist.get_world_size(group) != self.world:
+                    raise ValueError("BgzfFileShard: world %d needs exchange= or an initialised torch.distributed group of that size"
+                                     % self.world)
+                every = [None] * self.world
+                dist.all_gather_object(every, mine, group=group)
+            every = [[int(x) for x in e] for e in every]
+            for r in range(1, self.world):
+                if every[r - 1][1] != every[r][0]:
+                    raise _hip.FFQGzipError(_hip.E_ARG, "BGZF: rank %d's members end at byte %d of %r, rank %d found its first one at %d"
+                                            % (r - 1, every[r - 1][1], path, r, every[r][0]))
+            if every[-1][1] != size:
+                raise _hip.FFQGzipError(_hip.E_ARG, "BGZF: the members of %r end at byte %d of %d" % (path, every[-1][1], size))
+            self.members = [e[3] for e in every]
+            self.bounds = [0]
+            for e in every:
+                self.bounds.append(self.bounds[-1] + e[2])
+            self._make_shard(comm, tail_bytes, head_bytes, device, serial, group)
+            self._alloc_view(0)
+            if self.slab_bytes:
+                raise _hip.FFQError(_hip.E_NOMEM, "BgzfFileShard: the inflated range (%d bytes) does not fit the GPU" % (self.hi - self.lo))
+            self.h_own = None
+            self._h_view = None
+        except BaseException:
+            self.close()
+            raise
+
+    def load(self):
+        """This rank's members inflated (host threads) and its bytes in HBM; returns the bytes loaded.  The halos either side
+        come with the step, from the neighbours."""
+        own = self.hi - self.lo
+        self.h_own = np.empty(max(own, 1), dtype=np.uint8)[:own]
+        if own:
+            got = _hip.bgzf_range(self.fd, self.c_lo, self.c_hi, out=self.h_own, threads=self.threads)
+            assert got[2] == own, (got, own)
+            self.ctx.h2d(self.d_ext + self.tail, self.h_own)
+        self._h_view = None
+        self.loaded = True
+        return own
+
+    def scan(self, decode=False, flags=0, rows_hint=None):
+        res = super().scan(decode=decode, flags=flags, rows_hint=rows_hint)
+        self._h_view = None
+        return res
+
+    def host_bytes(self):
+        """(base, uint8[]) -- the bytes of this rank's records in host memory: array[x - base] is byte x of the uncompressed
+        stream, from the rank's first byte to the end of its last record (which may lie in the next rank's range: those bytes
+        came over with the look-ahead and are fetched from the device)."""
+        if self._h_view is None:
+            res = self.out
+            n_own = int(res.row_hi - res.row_lo)
+            end = self.hi
+            if n_own:
+                end = max(end, int(self.rows(n_own - 1, n_own)[0, 5]) + 1)
+            extra = end - self.hi
+            if extra > 0:
+                d_ext = int(res.d_ext or 0) or self.d_ext
+                tail = int(res.tail) if int(res.d_ext or 0) else self.tail
+                more = np.empty(extra, dtype=np.uint8)
+                self.ctx.d2h(more, d_ext + tail + (self.hi - self.lo))
+                arr = np.concatenate([self.h_own, more])
+            else:
+                arr = self.h_own
+            self._h_view = (self.lo, arr)
+        return self._h_view
+
+    def quals_from_file(self, rows):
+        raise ValueError("BgzfFileShard: no slabs")
 
 
 def __getattr__(name):

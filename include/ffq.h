@@ -389,6 +389,18 @@ int64_t ffq_gunzip_fd(int fd, uint8_t *h_dst, int64_t cap, int64_t chunk, int th
  * ffq_gunzip_stats: process-wide counters of that engine since the library was loaded --
  * out[0] batches, [1] chunks taken, [2] chunks not taken, [3] times it gave up, [4] members finished.    */
 void ffq_gunzip_stats(int64_t out[5]);
+/* A byte RANGE of a BGZF file (bgzip's format: gzip members of at most 64 KiB of data that say how long they are) on its
+ * own, host only: the members whose FIRST byte lies in [c_lo, c_hi) of the compressed file -- the first one found by
+ * its signature and proven by the chain of headers behind it, nothing inflated to find it -- inflated side by side
+ * (threads; 0 = as ffq_gunzip_fd) into h_dst.  h_dst = NULL, cap = 0: nothing is inflated, *n_out = the bytes the
+ * members' trailers promise (the pass that sizes the buffer and, summed over the ranks that share a file, gives the cut
+ * points of the uncompressed stream).  *c_first / *c_end: file offsets of the first member taken and behind the last
+ * (rank r's c_end is rank r + 1's c_first when their shares meet).  FFQ_E_ARG with "gzip: " in the text: not BGZF, cut
+ * short, or a member that does not inflate to its trailer's length and CRC-32; FFQ_E_TABLE_FULL: more than cap bytes.
+ * What it stands for: the reference's loop over gzip.open(...) (fastqandfurious.py:241-279), per rank of a file that
+ * several GPUs read together (sharded.BgzfFileShard).                                                              */
+int  ffq_bgzf_range(int fd, int64_t c_lo, int64_t c_hi, uint8_t *h_dst, int64_t cap, int threads,
+                    int64_t *c_first, int64_t *c_end, int64_t *n_out, int64_t *n_members);
 /* The same without a reader thread, for sources only the host can read (any object with a read() /
  * readinto(): BytesIO, bz2, lzma, sockets ...): the host asks where the next chunk goes
  * (ffq_stream_push_buffer: pinned memory, *cap = fbufsize bytes of room), writes up to *cap bytes

@@ -222,6 +222,33 @@ def main(scratch):
     np.save(os.path.join(scratch, "file_rows_recovered_%d.npy" % rank), fs.rows())
     fs.close()
     dist.barrier()
+    # ---- the same stream as a BGZF file read by ranges (sharded.BgzfFileShard): every rank inflates the members that begin in its
+    # share of the COMPRESSED file, the sizes go round over the side group, the step hands the halos over RCCL
+    zpath = os.path.join(scratch, "shared.fq.gz")
+    if rank == 0:
+        from fastqandfurious_amd import bgzf
+        with open(zpath + ".tmp", "wb") as fh:
+            fh.write(bgzf.compress(fstream.tobytes(), block_bytes=30000, level=1))
+        os.rename(zpath + ".tmp", zpath)
+    dist.barrier()
+    for kw in ({}, dict(tail_bytes=200, head_bytes=64)):
+        bz = sharded.BgzfFileShard(ctx, zpath, rank, world, group=ctl, **kw)
+        try:
+            bz.load()
+            res = bz.scan(decode=True)
+            assert bz.sh.transport() == ("rccl" if world > 1 else "in-process") and int(res.halo_source) == 0
+            rows = bz.rows()
+            np.save(os.path.join(scratch, "bgzf_rows_%d_%d.npy" % (len(kw), rank)), rows)
+            if rows.shape[0]:
+                q, qo = bz.quals(0, rows.shape[0], rows)
+                ln = rows[:, 5] - rows[:, 4]
+                ix = np.repeat(qo[:len(rows)], ln) + (np.arange(int(ln.sum())) - np.repeat(np.cumsum(ln) - ln, ln))
+                np.save(os.path.join(scratch, "bgzf_qual_%d_%d.npy" % (len(kw), rank)), q[ix])
+            report["bgzf%d" % len(kw)] = {"base": int(res.record_base), "total": int(res.total_records), "n": int(rows.shape[0]),
+                                          "bounds": [int(b) for b in bz.bounds]}
+        finally:
+            bz.close()
+        dist.barrier()
     with open(os.path.join(scratch, "report_%d.json" % rank), "w") as fh:
         json.dump(report, fh)
     dist.barrier()
@@ -274,6 +301,15 @@ def check(scratch, world):
     assert all(rep["watchdog"]["stage"] == "gather" for rep in reports)
     got = np.concatenate([np.load(os.path.join(scratch, "file_rows_recovered_%d.npy" % r)) for r in range(world)])
     assert got.shape == fwant.shape and (got == fwant).all(), "FileShard after its own recovery: rows over the ranks differ from the oracle's"
+    fq, _ = oracle.decode_quals(make_stream("wrapped"), fwant)
+    for k in (0, 2):
+        got = np.concatenate([np.load(os.path.join(scratch, "bgzf_rows_%d_%d.npy" % (k, r))) for r in range(world)])
+        assert got.shape == fwant.shape and (got == fwant).all(), "BGZF ranges: rows over the ranks differ from the oracle's scan of the inflated stream"
+        qs = [np.load(os.path.join(scratch, "bgzf_qual_%d_%d.npy" % (k, r))) for r in range(world)
+              if os.path.exists(os.path.join(scratch, "bgzf_qual_%d_%d.npy" % (k, r)))]
+        assert (np.concatenate(qs) == fq).all(), "BGZF ranges: decoded qualities differ from the oracle's"
+        assert reports[0]["bgzf%d" % k]["bounds"][0] == 0 and reports[0]["bgzf%d" % k]["bounds"][-1] == make_stream("wrapped").size
+        assert [reports[r]["bgzf%d" % k]["base"] for r in range(world)] == [sum(reports[q]["bgzf%d" % k]["n"] for q in range(r)) for r in range(world)]
     for k in (0, 2, 3):
         got = np.concatenate([np.load(os.path.join(scratch, "file_rows_%d_%d.npy" % (k, r))) for r in range(world)])
         assert got.shape == fwant.shape and (got == fwant).all(), "file-backed ranges: rows over the ranks differ from the oracle's"
