@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>

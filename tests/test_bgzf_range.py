@@ -50,8 +50,17 @@ def ranges(fd, world, threads=3):
     return parts, meta
 
 
+@pytest.fixture(params=("mapped", "read"))
+def how(request, monkeypatch):
+    """ffq_bgzf_range walks and inflates the members where the page cache holds them (mmap); a descriptor that cannot be mapped is
+    read in windows (FFQ_BGZF_NO_MMAP=1 forces that path)."""
+    if request.param == "read":
+        monkeypatch.setenv("FFQ_BGZF_NO_MMAP", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("block_bytes", (100, 7000, 65280))
-def test_ranges_of_members_add_up_to_the_file(pkg, tmp_bgzf, block_bytes):
+def test_ranges_of_members_add_up_to_the_file(pkg, tmp_bgzf, block_bytes, how):
     """Whatever the number of ranks and the size of the members: the ranks' members follow each other without a gap (rank r's
     end is rank r + 1's first), their bytes concatenated are what gzip makes of the whole file, and the sizing pass (nothing
     inflated) promises exactly what the inflating pass delivers."""
@@ -72,7 +81,7 @@ def test_ranges_of_members_add_up_to_the_file(pkg, tmp_bgzf, block_bytes):
         os.close(fd)
 
 
-def test_members_with_other_extra_subfields_and_no_eof_marker(pkg, tmp_path):
+def test_members_with_other_extra_subfields_and_no_eof_marker(pkg, tmp_path, how):
     """The "BC" subfield need not be the only one in a member's extra field, nor the first; the empty member at the end is a
     convention, not a must; a range that begins in the last member's tail holds nothing."""
     from fastqandfurious_amd import bgzf, hip
@@ -92,7 +101,7 @@ def test_members_with_other_extra_subfields_and_no_eof_marker(pkg, tmp_path):
         os.close(fd)
 
 
-def test_what_is_not_bgzf_is_said_so(pkg, tmp_path, tmp_bgzf):
+def test_what_is_not_bgzf_is_said_so(pkg, tmp_path, tmp_bgzf, how):
     """A plain gzip file, a BGZF file cut short, one whose member lies about its length or does not match its CRC-32: errors
     of the kinds Python's gzip raises (OSError / EOFError), never bytes."""
     from fastqandfurious_amd import hip, sharded
