@@ -70,6 +70,79 @@ static int64_t first_member(int fd, int64_t from, int64_t size)
 
 }  // namespace bgzf_range
 
+namespace bgzf_range {
+
+// the members of a range as they are met, and their inflation side by side
+struct Walk {
+    uint8_t *h_dst;
+    int64_t cap;
+    int64_t out = 0, members = 0;
+    std::vector<GzJob> jobs;
+    GzPool *pool = nullptr;
+    z_stream own;
+    bool own_init = false;
+    int nthreads;
+
+    Walk(uint8_t *dst, int64_t cap_, int threads) : h_dst(dst), cap(cap_), nthreads(threads > 0 ? std::min(threads, 256) : gz_threads_default())
+    {
+        memset(&own, 0, sizeof own);
+    }
+    ~Walk()
+    {
+        delete pool;
+        if (own_init) (void)inflateEnd(&own);
+    }
+    // the member of `avail` readable bytes at mem = byte `at` of the file (size bytes long): its length through *total, or an error
+    int take(const uint8_t *mem, int64_t avail, int64_t at, int64_t size, int64_t *total_out)
+    {
+        int xl = 0;
+        const int64_t total = bgzf_member_len(mem, avail, &xl);
+        *total_out = total;
+        if (total == 0) return fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: what follows byte %lld is not a BGZF member", (long long)at);
+        if (total < 0 || total > avail) {
+            if (at + std::max<int64_t>(total, 18) > size)
+                return fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: compressed file ended before the end-of-stream marker was reached (the BGZF member at byte %lld is cut short)", (long long)at);
+            return 1;                       // (all there in the file, not in what the caller holds of it)
+        }
+        const uint8_t *e = mem + total;
+        const uint32_t crc = (uint32_t)e[-8] | ((uint32_t)e[-7] << 8) | ((uint32_t)e[-6] << 16) | ((uint32_t)e[-5] << 24);
+        const uint32_t isz = (uint32_t)e[-4] | ((uint32_t)e[-3] << 8) | ((uint32_t)e[-2] << 16) | ((uint32_t)e[-1] << 24);
+        if (isz > 65536) return fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: the member at byte %lld says it holds %u bytes (a BGZF member holds at most 65536)", (long long)at, isz);
+        if (h_dst) {
+            if (out + (int64_t)isz > cap) return fail(FFQ_E_TABLE_FULL, "ffq_bgzf_range: the range inflates to more than %lld bytes", (long long)cap);
+            try { jobs.push_back(GzJob{mem + 12 + xl, (uint32_t)(total - xl - 20), h_dst + out, isz, crc}); }
+            catch (const std::bad_alloc &) { return fail(FFQ_E_NOMEM, "out of host memory"); }
+        }
+        out += isz;
+        members++;
+        return FFQ_OK;
+    }
+    // the jobs gathered so far (their compressed bytes still where take() saw them), by the pool's threads and this one
+    int inflate(int64_t from, int64_t to)
+    {
+        if (!h_dst || jobs.empty()) { jobs.clear(); return FFQ_OK; }
+        if (!own_init) {
+            if (inflateInit2(&own, -15) != Z_OK) return fail(FFQ_E_NOMEM, "ffq_bgzf_range: zlib could not be initialised");
+            own_init = true;
+        }
+        if (!pool && nthreads > 1 && jobs.size() > 1) {
+            pool = new (std::nothrow) GzPool();
+            if (pool && !pool->start(nthreads - 1)) { delete pool; pool = nullptr; }
+        }
+        bool ok = true;
+        for (size_t j0 = 0; j0 < jobs.size() && ok; j0 += (size_t)1 << 20) {              // (in batches the pool's counter can hold)
+            const int nj = (int)std::min<size_t>((size_t)1 << 20, jobs.size() - j0);
+            if (pool) ok = pool->run(jobs.data() + j0, nj, &own);
+            else for (int j = 0; j < nj && ok; j++) ok = GzPool::inflate_fast(jobs[j0 + (size_t)j]) || GzPool::inflate_one(&own, jobs[j0 + (size_t)j]);
+        }
+        jobs.clear();
+        if (!ok) return fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: a member between bytes %lld and %lld does not inflate to what its trailer says (length or CRC-32)", (long long)from, (long long)to);
+        return FFQ_OK;
+    }
+};
+
+}  // namespace bgzf_range
+
 extern "C" int ffq_bgzf_range(int fd, int64_t c_lo, int64_t c_hi, uint8_t *h_dst, int64_t cap, int threads,
                               int64_t *c_first, int64_t *c_end, int64_t *n_out, int64_t *n_members)
 {
@@ -82,15 +155,9 @@ extern "C" int ffq_bgzf_range(int fd, int64_t c_lo, int64_t c_hi, uint8_t *h_dst
     int64_t p = first_member(fd, std::min(c_lo, size), size);
     if (p < 0) return fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: no BGZF member at or behind byte %lld (not a BGZF file, or one that is cut short)", (long long)c_lo);
     if (c_first) *c_first = p;
-    int64_t out = 0, members = 0;
-    std::vector<uint8_t> win;
-    std::vector<GzJob> jobs;
-    GzPool *pool = nullptr;
-    z_stream own;
-    memset(&own, 0, sizeof own);
-    bool own_init = false;
+    Walk w(h_dst, cap, threads);
     int rc = FFQ_OK;
-    const int nthreads = threads > 0 ? std::min(threads, 256) : gz_threads_default();
+    bool mapped = false;
     // ---- a file that can be mapped: the members are walked and inflated where the page cache holds them -- no copy of the
     // compressed bytes, no read in front of every batch (the windows of the loop below cost 30 ms of a 65 ms inflate per 256 MB
     // of FASTQ, one thread reading while the others wait), ONE batch of jobs over the whole range ---------------------------
@@ -99,117 +166,39 @@ extern "C" int ffq_bgzf_range(int fd, int64_t c_lo, int64_t c_hi, uint8_t *h_dst
         const int64_t map_lo = p & ~(page - 1), map_hi = std::min(size, c_hi + 65536 + 64);
         void *mp = mmap(nullptr, (size_t)(map_hi - map_lo), PROT_READ, MAP_PRIVATE, fd, (off_t)map_lo);
         if (mp != MAP_FAILED) {
+            mapped = true;
             const uint8_t *m = static_cast<const uint8_t *>(mp) - map_lo;          // m[x] = byte x of the file
-            int64_t q = p;
-            while (q < c_hi && !rc) {
-                int xl = 0;
-                const int64_t avail = map_hi - q;
-                const int64_t total = bgzf_member_len(m + q, avail, &xl);
-                if (total < 0 || (total > 0 && total > avail)) {
-                    if (q + std::max<int64_t>(total, 18) > size)
-                        rc = fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: compressed file ended before the end-of-stream marker was reached (the BGZF member at byte %lld is cut short)", (long long)q);
-                    else rc = fail(FFQ_E_INTERNAL, "ffq_bgzf_range: a member at byte %lld reaches past the mapped range", (long long)q);
-                    break;
-                }
-                if (total == 0) { rc = fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: what follows byte %lld is not a BGZF member", (long long)q); break; }
-                const uint8_t *e = m + q + total;
-                const uint32_t crc = (uint32_t)e[-8] | ((uint32_t)e[-7] << 8) | ((uint32_t)e[-6] << 16) | ((uint32_t)e[-5] << 24);
-                const uint32_t isz = (uint32_t)e[-4] | ((uint32_t)e[-3] << 8) | ((uint32_t)e[-2] << 16) | ((uint32_t)e[-1] << 24);
-                if (isz > 65536) { rc = fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: the member at byte %lld says it holds %u bytes (a BGZF member holds at most 65536)", (long long)q, isz); break; }
-                if (h_dst) {
-                    if (out + (int64_t)isz > cap) { rc = fail(FFQ_E_TABLE_FULL, "ffq_bgzf_range: the range inflates to more than %lld bytes", (long long)cap); break; }
-                    try { jobs.push_back(GzJob{m + q + 12 + xl, (uint32_t)(total - xl - 20), h_dst + out, isz, crc}); }
-                    catch (const std::bad_alloc &) { rc = fail(FFQ_E_NOMEM, "out of host memory"); break; }
-                }
-                out += isz;
-                members++;
-                q += total;
+            const int64_t p0 = p;
+            while (p < c_hi && !rc) {
+                int64_t total = 0;
+                rc = w.take(m + p, map_hi - p, p, size, &total);
+                if (rc == 1) rc = fail(FFQ_E_INTERNAL, "ffq_bgzf_range: the member at byte %lld reaches past the mapped range", (long long)p);
+                if (!rc) p += total;
             }
-            if (!rc && h_dst && !jobs.empty()) {
-                bool ok = inflateInit2(&own, -15) == Z_OK;
-                if (!ok) rc = fail(FFQ_E_NOMEM, "ffq_bgzf_range: zlib could not be initialised");
-                else {
-                    own_init = true;
-                    if (nthreads > 1 && jobs.size() > 1) {
-                        pool = new (std::nothrow) GzPool();
-                        if (pool && !pool->start(nthreads - 1)) { delete pool; pool = nullptr; }
-                    }
-                    // (in batches the pool's int counter can hold)
-                    for (size_t j0 = 0; j0 < jobs.size() && ok; j0 += (size_t)1 << 20) {
-                        const int nj = (int)std::min<size_t>((size_t)1 << 20, jobs.size() - j0);
-                        if (pool) ok = pool->run(jobs.data() + j0, nj, &own);
-                        else for (int j = 0; j < nj && ok; j++) ok = GzPool::inflate_fast(jobs[j0 + (size_t)j]) || GzPool::inflate_one(&own, jobs[j0 + (size_t)j]);
-                    }
-                    if (!ok) rc = fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: a member between bytes %lld and %lld does not inflate to what its trailer says (length or CRC-32)", (long long)p, (long long)q);
-                }
-            }
+            if (!rc) rc = w.inflate(p0, p);
             (void)munmap(mp, (size_t)(map_hi - map_lo));
-            delete pool;
-            if (own_init) (void)inflateEnd(&own);
-            if (rc) return rc;
-            if (c_end) *c_end = q;
-            if (n_out) *n_out = out;
-            if (n_members) *n_members = members;
-            return FFQ_OK;
         }
     }
     // ---- what cannot be mapped: windows of compressed bytes read in front of each batch -------------------------------------
-    while (p < c_hi && !rc) {
-        // one window of compressed bytes from member start p: its whole members, those that start in front of c_hi
+    std::vector<uint8_t> win;
+    while (!mapped && p < c_hi && !rc) {
+        // one window from member start p: its whole members, those that start in front of c_hi
         const int64_t n = std::min<int64_t>(WINDOW + 65536, size - p);
         try { win.resize((size_t)n + 16); } catch (const std::bad_alloc &) { rc = fail(FFQ_E_NOMEM, "out of host memory"); break; }
         if (pread_full(fd, win.data(), n, p) != n) { rc = fail(FFQ_E_ARG, "ffq_bgzf_range: read failed at byte %lld: %s", (long long)p, strerror(errno)); break; }
-        jobs.clear();
-        int64_t q = 0, w_out = 0;
-        while (p + q < c_hi && q < n) {
-            int xl = 0;
-            const int64_t total = bgzf_member_len(win.data() + q, n - q, &xl);
-            if (total > 0 && total > n - q && p + q + total <= size && q > 0) break;         // (the next window begins with it)
-            if (total < 0 || total > n - q) {               // (its header, or its body, runs past the end of the file)
-                rc = fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: compressed file ended before the end-of-stream marker was reached (the BGZF member at byte %lld is cut short)", (long long)(p + q));
-                break;
-            }
-            if (total == 0) { rc = fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: what follows byte %lld is not a BGZF member", (long long)(p + q)); break; }
-            const uint8_t *e = win.data() + q + total;
-            const uint32_t crc = (uint32_t)e[-8] | ((uint32_t)e[-7] << 8) | ((uint32_t)e[-6] << 16) | ((uint32_t)e[-5] << 24);
-            const uint32_t isz = (uint32_t)e[-4] | ((uint32_t)e[-3] << 8) | ((uint32_t)e[-2] << 16) | ((uint32_t)e[-1] << 24);
-            if (isz > 65536) { rc = fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: the member at byte %lld says it holds %u bytes (a BGZF member holds at most 65536)", (long long)(p + q), isz); break; }
-            if (h_dst) {
-                if (out + w_out + (int64_t)isz > cap) { rc = fail(FFQ_E_TABLE_FULL, "ffq_bgzf_range: the range inflates to more than %lld bytes", (long long)cap); break; }
-                jobs.push_back(GzJob{win.data() + q + 12 + xl, (uint32_t)(total - xl - 20), h_dst + out + w_out, isz, crc});
-            }
-            w_out += isz;
-            members++;
-            q += total;
-            if (q >= WINDOW) break;
+        int64_t q = 0;
+        while (p + q < c_hi && q < WINDOW && !rc) {
+            int64_t total = 0;
+            rc = w.take(win.data() + q, n - q, p + q, size, &total);
+            if (rc == 1) { rc = q > 0 ? FFQ_OK : fail(FFQ_E_INTERNAL, "ffq_bgzf_range: no progress at byte %lld", (long long)p); break; }      // (the next window begins with it)
+            if (!rc) q += total;
         }
-        if (rc) break;
-        if (h_dst && !jobs.empty()) {
-            if (!own_init) {
-                if (inflateInit2(&own, -15) != Z_OK) { rc = fail(FFQ_E_NOMEM, "ffq_bgzf_range: zlib could not be initialised"); break; }
-                own_init = true;
-            }
-            if (!pool && nthreads > 1 && jobs.size() > 1) {
-                pool = new (std::nothrow) GzPool();
-                if (pool && !pool->start(nthreads - 1)) { delete pool; pool = nullptr; }
-            }
-            bool ok;
-            if (pool) ok = pool->run(jobs.data(), (int)jobs.size(), &own);
-            else {
-                ok = true;
-                for (const GzJob &j : jobs) ok = ok && (GzPool::inflate_fast(j) || GzPool::inflate_one(&own, j));
-            }
-            if (!ok) { rc = fail(FFQ_E_ARG, "ffq_bgzf_range: gzip: a member between bytes %lld and %lld does not inflate to what its trailer says (length or CRC-32)", (long long)p, (long long)(p + q)); break; }
-        }
-        out += w_out;
-        if (q == 0) { rc = fail(FFQ_E_INTERNAL, "ffq_bgzf_range: no progress at byte %lld", (long long)p); break; }
+        if (!rc) rc = w.inflate(p, p + q);
         p += q;
     }
-    delete pool;
-    if (own_init) (void)inflateEnd(&own);
     if (rc) return rc;
     if (c_end) *c_end = p;
-    if (n_out) *n_out = out;
-    if (n_members) *n_members = members;
+    if (n_out) *n_out = w.out;
+    if (n_members) *n_members = w.members;
     return FFQ_OK;
 }
