@@ -641,6 +641,10 @@ def readfastq_iter_range(path, rank: int, world: int, entryfunc: typing.Callable
         ctx = _hip.default_context()
     if bgzf is None:
         bgzf = _sharded.is_bgzf(path)
+        if not bgzf and _sharded.is_gzip(path):
+            raise ValueError("readfastq_iter_range: %r is a gzip file but not BGZF -- ordinary gzip members cannot be entered in the "
+                             "middle, so the file cannot be read by ranges; readfastq_iter(automagic_open(path), ...) streams it "
+                             "(or recompress it with bgzip)" % (path,))
     if bgzf:
         if start or end is not None or bounds is not None or slab_bytes:
             raise ValueError("readfastq_iter_range: start / end / bounds / slab_bytes do not apply to a BGZF file")

@@ -715,6 +715,17 @@ def is_bgzf(path_or_fd):
     return len(h) == 18 and h[:4] == b"\x1f\x8b\x08\x04" and h[12:14] == b"BC" and h[14:16] == b"\x02\x00"
 
 
+def is_gzip(path_or_fd):
+    """Does the file begin with a gzip member (of any kind)?"""
+    fd = path_or_fd if isinstance(path_or_fd, int) else os.open(path_or_fd, os.O_RDONLY)
+    try:
+        h = os.pread(fd, 3, 0)
+    finally:
+        if not isinstance(path_or_fd, int):
+            os.close(fd)
+    return h == b"\x1f\x8b\x08"
+
+
 class _Shifted:
     """bytes [base, base + len) of a stream held in memory, sliced with STREAM offsets (what a map of the file is for a
     plain one): view[a:b] -> a memoryview, or, as_bytes, a bytes object."""

@@ -325,3 +325,8 @@ def test_range_iterator_over_bgzf_matches_reference_tuples(gpu_ctx, golden, tmp_
             assert [e for _, o in res for e in o] == ref_f
     with pytest.raises(ValueError, match="do not apply to a BGZF file"):
         F.readfastq_iter_range(path, 0, 1, start=5)
+    plain_gz = str(tmp_bgzf(b"", name="dir.marker")) + ".plain.gz"
+    with gzip.open(plain_gz, "wb") as fh:
+        fh.write(golden_file("test.fq"))
+    with pytest.raises(ValueError, match="is a gzip file but not BGZF"):
+        F.readfastq_iter_range(plain_gz, 0, 1)
