@@ -235,7 +235,15 @@ def main(scratch):
         bz = sharded.BgzfFileShard(ctx, zpath, rank, world, group=ctl, **kw)
         try:
             bz.load()
+            if kw and world > 1:
+                # (and the shard's own recovery over inflated ranges: the last rank's gather stalls, every rank trips, the ranks meet,
+                # abort, join one new communicator, inflate and load again, take the serial step)
+                bz.sh.set_timeout(4.0)
+                if rank == world - 1:
+                    bz.sh.inject_stall(hip.STAGE_GATHER, 60.0)
             res = bz.scan(decode=True)
+            if kw and world > 1:
+                assert bz.recovered and "stage 'gather'" in bz.recovered and bz.sh.info()["mode"] == "serial", bz.recovered
             assert bz.sh.transport() == ("rccl" if world > 1 else "in-process") and int(res.halo_source) == 0
             rows = bz.rows()
             np.save(os.path.join(scratch, "bgzf_rows_%d_%d.npy" % (len(kw), rank)), rows)
